@@ -1,0 +1,249 @@
+"""Generate golden vectors from the REFERENCE's own model code  (build container only).
+
+Runs ``/root/reference/src/components/graphs/models.py`` (GcnSAGE / MeanSAGE) under
+a stub ``dgl`` module and stores inputs + outputs as ``tests/golden/*.npz``.
+Nothing from the reference is copied: the fixtures are data (inputs, the
+reference's ``state_dict`` values, activations, loss, gradients, one Adam step).
+
+The stub encodes DGL's documented gSpMM semantics for the two call sites the
+model uses (models.py:53-54 and :146-149): message ``h[u] * w_e`` (scalar edge
+weight broadcast over features), reducer ``sum`` / ``mean`` over the incoming
+edges of each destination, zeros for in-degree-0 nodes.  It deliberately uses a
+different algorithm (gather + index_add_) from the oracle's CSR SpMM.
+
+Usage:  python oracle/make_golden.py            (needs /root/reference; never runs
+on the GPU box -- the committed .npz files travel instead).
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF_MODELS = "/root/reference/src/components/graphs/models.py"
+OUT_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+# ------------------------------ stub dgl ----------------------------------- #
+def _install_stub_dgl():
+    dgl = types.ModuleType("dgl")
+    nn_ = types.ModuleType("dgl.nn")
+    pt = types.ModuleType("dgl.nn.pytorch")
+    conv = types.ModuleType("dgl.nn.pytorch.conv")
+    conv.SAGEConv = object
+    fn = types.ModuleType("dgl.function")
+    fn.u_mul_e = lambda u, e, m: ("u_mul_e", u, e, m)
+    fn.copy_u = lambda u, m: ("copy_u", u, m)
+    fn.sum = lambda msg, out: ("sum", msg, out)
+    fn.mean = lambda msg, out: ("mean", msg, out)
+    dgl.nn, nn_.pytorch, pt.conv, dgl.function = nn_, pt, conv, fn
+    for name, mod in [("dgl", dgl), ("dgl.nn", nn_), ("dgl.nn.pytorch", pt),
+                      ("dgl.nn.pytorch.conv", conv), ("dgl.function", fn)]:
+        sys.modules[name] = mod
+
+
+class StubGraph:
+    def __init__(self, src, dst, n):
+        self.src = torch.as_tensor(src, dtype=torch.long)
+        self.dst = torch.as_tensor(dst, dtype=torch.long)
+        self.n = n
+        self.ndata, self.edata = {}, {}
+
+    def local_var(self):
+        g = StubGraph(self.src, self.dst, self.n)
+        g.ndata, g.edata = dict(self.ndata), dict(self.edata)
+        return g
+
+    class _Scope:
+        def __init__(self, g):
+            self.g = g
+
+        def __enter__(self):
+            self.nd, self.ed = dict(self.g.ndata), dict(self.g.edata)
+
+        def __exit__(self, *a):
+            self.g.ndata, self.g.edata = self.nd, self.ed
+
+    def local_scope(self):
+        return StubGraph._Scope(self)
+
+    def in_degrees(self):
+        return torch.bincount(self.dst, minlength=self.n)
+
+    def update_all(self, message_func=None, reduce_func=None):
+        mf, rf = message_func, reduce_func
+        x = self.ndata[mf[1]][self.src]
+        if mf[0] == "u_mul_e":
+            x = x * self.edata[mf[2]].unsqueeze(-1)
+        out = torch.zeros(self.n, x.shape[1], dtype=x.dtype).index_add_(0, self.dst, x)
+        if rf[0] == "mean":
+            out = out / self.in_degrees().clamp(min=1).to(x.dtype)[:, None]
+        self.ndata[rf[2]] = out
+
+
+def _load_reference_models():
+    _install_stub_dgl()
+    spec = importlib.util.spec_from_file_location("ref_models", REF_MODELS)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ------------------------------ graphs -------------------------------------- #
+def knn_like_graph(rng, n, k, bidirect=True):
+    """Page-like graph: nodes on a jittered reading-order grid, k nearest by
+    centre distance, neighbour -> node, optional to_simple + to_bidirected."""
+    cols = max(2, int(np.sqrt(n)))
+    pos = np.stack([(np.arange(n) % cols) * 60.0, (np.arange(n) // cols) * 25.0], 1)
+    pos += rng.uniform(-8, 8, size=pos.shape)
+    d = np.linalg.norm(pos[:, None] - pos[None], axis=-1)
+    np.fill_diagonal(d, np.inf)
+    kk = min(k, n - 1)
+    nbr = np.argsort(d, axis=1)[:, :kk]
+    src = nbr.reshape(-1)
+    dst = np.repeat(np.arange(n), kk)
+    if bidirect:
+        pairs = set(zip(src.tolist(), dst.tolist()))
+        pairs |= {(b, a) for a, b in pairs}
+        pairs = sorted(pairs, key=lambda p: (p[1], p[0]))
+        src = np.array([p[0] for p in pairs], dtype=np.int64)
+        dst = np.array([p[1] for p in pairs], dtype=np.int64)
+    dist = np.floor(d[dst, src])
+    m = dist.max() if len(dist) and dist.max() > 0 else 1.0
+    w = (1.0 - dist / m).astype(np.float32)                      # loader.py:341-344
+    return src.astype(np.int64), dst.astype(np.int64), w
+
+
+def random_graph(rng, n, e):
+    return rng.integers(0, n, e), rng.integers(0, n, e), rng.uniform(0, 1, e).astype(np.float32)
+
+
+# ------------------------------ cases --------------------------------------- #
+def run_gcnsage_case(ref, name, src, dst, w, n, f0, hid, n_cls, n_layers, seed, x_scale=1.0,
+                     class_weights=None, bbox_like=False):
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    model = ref.GcnSAGE(f0, hid, n_cls, n_layers, F.relu, 0)
+    if bbox_like:   # raw-pixel magnitudes like nlp/bbox.py geometry features
+        x = np.concatenate([rng.uniform(0, 2000, (n, 6)), rng.uniform(0, 5e5, (n, 3)),
+                            rng.uniform(0, 1, (n, f0 - 9))], 1).astype(np.float32)
+    else:
+        x = (rng.standard_normal((n, f0)) * x_scale).astype(np.float32)
+    y = rng.integers(0, n_cls, n).astype(np.int64)
+    g = StubGraph(src, dst, n)
+    g.ndata["feat"] = torch.from_numpy(x)
+    g.edata["feat"] = torch.from_numpy(np.asarray(w, dtype=np.float32))
+    state0 = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+
+    hidden = []
+    hooks = [l.register_forward_hook(lambda m, i, o: hidden.append(o.detach().numpy().copy()))
+             for l in model.layers]
+    cw = None if class_weights is None else torch.tensor(class_weights, dtype=torch.float32)
+    loss_fn = torch.nn.CrossEntropyLoss(weight=cw)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)   # model_train.py:168
+    logits = model(g)
+    for h in hooks:
+        h.remove()
+    loss = loss_fn(logits, torch.from_numpy(y))
+    opt.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.detach().clone().numpy() for k, p in model.named_parameters()}
+    opt.step()
+    state1 = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        logits1 = model(g).numpy()
+
+    out = dict(src=src, dst=dst, w=np.asarray(w, dtype=np.float32), x=x, y=y,
+               meta=np.array([n, f0, hid, n_cls, n_layers, seed], dtype=np.int64),
+               logits=logits.detach().numpy(), loss=np.float32(loss.item()), logits_after_step=logits1)
+    if class_weights is not None:
+        out["class_weights"] = np.asarray(class_weights, dtype=np.float32)
+    for i, h in enumerate(hidden):
+        out[f"hidden.{i}"] = h
+    for k, v in state0.items():
+        out["state0." + k] = v
+    for k, v in grads.items():
+        out["grad." + k] = v
+    for k, v in state1.items():
+        out["state1." + k] = v
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: N={n} E={len(src)} F0={f0} H={hid} L={n_layers} loss={loss.item():.6f} "
+          f"-> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+def run_meansage_case(ref, name, src, dst, w, n, f0, hid, n_cls, n_layers, seed):
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    model = ref.MeanSAGE(f0, hid, n_cls, n_layers)
+    x = rng.standard_normal((n, f0)).astype(np.float32)
+    g = StubGraph(src, dst, n)
+    out_t = model(g, torch.from_numpy(x), torch.from_numpy(np.asarray(w, dtype=np.float32)))
+    out = dict(src=src, dst=dst, w=np.asarray(w, dtype=np.float32), x=x,
+               meta=np.array([n, f0, hid, n_cls, n_layers, seed], dtype=np.int64),
+               out=out_t.detach().numpy())
+    for k, v in model.state_dict().items():
+        out["state0." + k] = v.detach().numpy()
+    np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), **out)
+    print(f"{name}: MeanSAGE N={n} E={len(src)}")
+
+
+def main():
+    os.makedirs(OUT_DIR, exist_ok=True)
+    ref = _load_reference_models()
+    rng = np.random.default_rng(42)
+
+    # (1) hand-checkable: 6 nodes, 10 edges incl. a duplicate edge, a self loop,
+    #     and node 5 with in-degree 0
+    src = np.array([0, 1, 2, 3, 4, 0, 0, 2, 2, 5])
+    dst = np.array([1, 2, 3, 4, 0, 2, 2, 2, 0, 3])
+    w = np.array([1.0, 0.5, 0.25, 0.75, 0.0, 0.5, 0.5, 1.0, 0.3, 0.9], dtype=np.float32)
+    run_gcnsage_case(ref, "tiny_6n_10e", src, dst, w, 6, 3, 4, 9, 2, seed=1)
+
+    # (2) BASELINE cfg1: one 200-word page, k-NN, F0=13, 2 layers, H=256
+    s, d, ww = knn_like_graph(rng, 200, 5)
+    run_gcnsage_case(ref, "page200_f13_l2", s, d, ww, 200, 13, 256, 9, 2, seed=2, bbox_like=True)
+
+    # (3) 3 layers, class weights as in model_train.py:115-117 ('default' method)
+    s, d, ww = knn_like_graph(rng, 200, 5)
+    run_gcnsage_case(ref, "page200_f13_l3_cw", s, d, ww, 200, 13, 128, 9, 3, seed=3,
+                     class_weights=[1, 1, 1, 1, 1, 1, 2, 1, 1])
+
+    # (4) wide features F0=831 (BBOX+REPR+SCIBERT), smaller hidden to keep the file small
+    s, d, ww = knn_like_graph(rng, 300, 5)
+    run_gcnsage_case(ref, "page300_f831_l3", s, d, ww, 300, 831, 48, 9, 3, seed=4)
+
+    # (5) directed k-NN only (bidirectional=False) -> some zero in-degree nodes possible,
+    #     random multigraph with duplicates + self loops
+    s, d, ww = random_graph(rng, 300, 1500)
+    run_gcnsage_case(ref, "random300_multi", s, d, ww, 300, 63, 96, 9, 3, seed=5)
+
+    # (6) unit edge weights (--edge_features=False contract: missing weights == 1.0)
+    s, d, _ = knn_like_graph(rng, 150, 5, bidirect=False)
+    run_gcnsage_case(ref, "page150_unitw", s, d, np.ones(len(s), np.float32), 150, 50, 32, 9, 3, seed=6)
+
+    # (7) single node, no edges
+    run_gcnsage_case(ref, "single_node", np.zeros(0, np.int64), np.zeros(0, np.int64),
+                     np.zeros(0, np.float32), 1, 13, 16, 9, 2, seed=7)
+
+    # (8) batch of heterogeneous pages (block-diagonal union, as dgl.batch)
+    srcs, dsts, ws, off = [], [], [], 0
+    for n in (17, 230, 64, 5, 121):
+        s, d, ww = knn_like_graph(rng, n, 5)
+        srcs.append(s + off), dsts.append(d + off), ws.append(ww)
+        off += n
+    run_gcnsage_case(ref, "batch5_hetero", np.concatenate(srcs), np.concatenate(dsts),
+                     np.concatenate(ws), off, 13, 128, 9, 3, seed=8, bbox_like=True)
+
+    # (9) MeanSAGE (fn.mean reducer), n_layers=2 -> 3 WeightedMeanSAGELayers
+    s, d, ww = knn_like_graph(rng, 120, 5)
+    run_meansage_case(ref, "meansage_120", s, d, ww, 120, 20, 32, 9, 2, seed=9)
+
+
+if __name__ == "__main__":
+    main()
