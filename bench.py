@@ -1,0 +1,228 @@
+"""nodes/sec of the GcnSAGE train step (fwd + loss + bwd + Adam) on synthetic PubLayNet-style page
+graphs -- the metric of BASELINE.json -- on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] / SURVEY 8(d) cfg2): batches of 100 page graphs, 3-layer
+GraphSAGE-GCN, F0 = 831 (BBOX+REPR+SCIBERT), hidden 256, 9 classes, fp32, Adam(lr 0.01, wd 5e-4),
+unweighted cross-entropy.  Every rank owns DISTINCT pages (weak scaling); the only collective is
+one RCCL all-reduce of the flat gradient per step.  The batched graphs (CSR, features, labels) are
+resident in HBM before the timed region; a "step" = forward + loss + backward + optimiser on one
+resident batch.  One JSON line is printed by rank 0.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel (fp32 MFMA forward GEMM), live HIP-event timing over the timed region
+  gather        the aggregation kernel on BASELINE cfg4 (1 M nodes, deg 12, F = 512): HBM GB/s
+  cpu_baseline  the CPU oracle (oracle/gcnsage_cpu.py: torch-CPU + OpenMP CSR SpMM) on the same
+                first batch, on this box's host cores ("port"; baseline only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # fp32 matrix peak (dense)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--in-feats", type=int, default=831)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--pages", type=int, default=100, help="page graphs per batch per GPU")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather-probe", action="store_true")
+    ap.add_argument("--gather-nodes", type=int, default=1_000_000)
+    return ap.parse_args()
+
+
+def build_batches(S, gte, args, rank, dev):
+    batches = []
+    for b in range(args.batches):
+        first = (rank * args.batches + b) * args.pages
+        pages = S.make_pages(args.pages, in_feats=args.in_feats, first_id=first)
+        src, dst, w, feat, label, off = S.concat_pages(pages)
+        g = gte.PageGraph(src, dst, int(off[-1]), device=dev)
+        g.ndata["feat"] = torch.from_numpy(feat).to(dev)
+        g.edata["feat"] = torch.from_numpy(w).to(dev)
+        g.batch_num_nodes_ = [p.num_nodes for p in pages]
+        batches.append((g, torch.from_numpy(label).to(dev), (src, dst, w, feat, label, off)))
+    return batches
+
+
+def cpu_baseline(args, host_batch, state):
+    from oracle import gcnsage_cpu as oc
+    src, dst, w, feat, label, off = host_batch
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    tr = oc.OracleTrainer(state, lr=0.01, weight_decay=5e-4)
+    og = oc.OracleGraph(src, dst, int(off[-1]), w)
+    x, y = torch.from_numpy(feat), torch.from_numpy(label)
+    for _ in range(2):
+        tr.step(og, x, y)
+    times = []
+    t_all = time.time()
+    while len(times) < 5 or (time.time() - t_all < 10 and len(times) < 20):
+        t0 = time.time()
+        tr.step(og, x, y)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": int(off[-1]) / med, "unit": "nodes/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} train steps (median) of the CPU oracle on batch 0 ({int(off[-1])} nodes, "
+                      f"{len(src)} edges, F0={args.in_feats}); aggregation = "
+                      f"{'OpenMP CSR SpMM' if oc.omp_available() else 'torch.sparse_csr'}, "
+                      f"dense ops = torch CPU ({torch.get_num_threads()} threads)",
+            "ms_per_step": med * 1e3}
+
+
+def gather_probe(args, gte, S, dev):
+    """Aggregation kernel alone on BASELINE cfg4 (HBM-bandwidth stress)."""
+    from gnn_tableextraction_amd import ops
+    n, k, f = args.gather_nodes, 12, 512
+    src, dst, w = S.make_knn_stress_graph(n, k)
+    indptr, indices, perm, wout = ops.coo_to_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n,
+                                                 torch.from_numpy(w).to(dev))
+    x = torch.randn(n, f, device=dev)
+    out = torch.empty_like(x)
+    for _ in range(3):
+        ops.spmm_csr(indptr, indices, wout, x, n, mean=True, out=out)
+    torch.cuda.synchronize()
+    reps = 10
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s, e in evs:
+        s.record()
+        ops.spmm_csr(indptr, indices, wout, x, n, mean=True, out=out)
+        e.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
+    alg_bytes = 2.0 * n * f * 4 + 8.0 * n * k + 4.0 * (n + 1)      # 2*F*s + 8*d + 4 per node
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {"workload": f"cfg4: 1 graph, {n} nodes, in-degree {k}, F={f} fp32, k-NN of 2-D points in Morton order",
+            "kernel": "spmm_csr_kernel<F32,64,2>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms_per_pass": ms, "algorithmic_bytes": alg_bytes,
+            "nodes_per_s_per_pass": n / (ms * 1e-3), "traffic": None}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import ops
+    from gnn_tableextraction_amd.data import synthetic as S
+    from gnn_tableextraction_amd.models.engine import TrainStep
+
+    batches = build_batches(S, gte, args, rank, dev)
+    torch.manual_seed(42)
+    model = gte.GcnSAGE(args.in_feats, args.hidden, 9, args.layers, torch.nn.functional.relu, 0)
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    trainer = TrainStep(model, lr=0.01, weight_decay=5e-4, distributed=distributed)
+
+    # global node count of step i (every rank can compute it: page sizes are seeded metadata)
+    local_nodes = [b[0].num_nodes() for b in batches]
+    if distributed:
+        t = torch.tensor(local_nodes, dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        global_nodes = t.cpu().tolist()
+    else:
+        global_nodes = local_nodes
+
+    def run(i):
+        g, y, _ = batches[i % len(batches)]
+        return trainer.step(g, y, n_global=global_nodes[i % len(batches)])
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        run(i)
+    barrier()
+    ops.enable_kernel_timers(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out3 = run(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kt = ops.kernel_timer_report()
+    ops.enable_kernel_timers(False)
+
+    nodes_local = sum(local_nodes[i % len(batches)] for i in range(args.steps))
+    stat = torch.tensor([elapsed, float(nodes_local)], dtype=torch.float64, device=dev)
+    if distributed:
+        tmax = stat.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stat, op=dist.ReduceOp.SUM)
+        elapsed, nodes_total = float(tmax[0]), float(stat[1])
+    else:
+        nodes_total = float(nodes_local)
+    final_loss = float(out3[0])
+
+    if rank == 0:
+        n_launch, ms, flops = kt.get("gemm_nt", (0, 0.0, 0.0))
+        tf = (flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel<NT> (layer transforms, forward)",
+                    "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                    "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1), "traffic": None}
+        per_kernel = {}
+        for tag, (n, tms, work) in kt.items():
+            unit = "GB/s" if tag == "spmm_csr" else "TFLOP/s"
+            rate = work / (tms * 1e-3) / (1e9 if tag == "spmm_csr" else 1e12) if tms > 0 else 0.0
+            per_kernel[tag] = {"launches": n, "total_ms": tms, "avg_ms": tms / max(n, 1), "rate": rate, "unit": unit}
+        line = {
+            "metric": "nodes/sec (fwd+bwd node classification) on PubLayNet page graphs",
+            "value": nodes_total / elapsed, "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2: {args.pages} synthetic PubLayNet-style page graphs per GPU per step "
+                                   f"(~{int(np.mean(local_nodes))} nodes, k-NN k=5 bidirected), GcnSAGE "
+                                   f"{args.layers} layers F0={args.in_feats} hidden={args.hidden} classes=9, "
+                                   f"CE + Adam(lr 0.01, wd 5e-4); batches resident in HBM",
+                       "pages_per_gpu_per_step": args.pages, "global_pages_per_step": args.pages * world,
+                       "nodes_per_step_per_gpu": int(np.mean(local_nodes)), "parallelism": f"dp{world}"},
+            "final_loss": final_loss, "roofline": roofline, "kernels": per_kernel,
+        }
+        if world == 1 and not args.no_gather_probe:
+            line["gather"] = gather_probe(args, gte, S, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args, batches[0][2], state0)
+            line["cpu_baseline"] = cb
+            line["gpu_over_cpu"] = line["value"] / cb["value"]
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""ctypes binding of libgte_hip.so (the C ABI declared in include/gte.h).
+
+The product path has NO fallback: if the shared library is missing, or a compute
+entry point is called without a HIP device, this raises -- loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgte_hip.so")
+
+# name -> (restype, argtypes); mirrors include/gte.h declaration by declaration
+SIGNATURES = {
+    "gte_version": (c_int, []),
+    "gte_last_error": (c_char_p, []),
+    "gte_device_info": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "gte_spmm_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                             c_int64, c_int64, c_int, c_int, c_void_p]),
+    "gte_spmm_csr_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                        c_int64, c_int64, c_int, c_int, c_void_p]),
+    "gte_coo_to_csr_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "gte_coo_to_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gte_inv_degree": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "gte_sage_linear_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                    c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                    c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "gte_ln_relu_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p,
+                                c_int64, c_int64, c_void_p]),
+    "gte_ln_relu_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "gte_ln_relu_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                c_void_p, c_int64, c_void_p]),
+    "gte_gemm_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "gte_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                             c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "gte_weighted_ce_workspace_bytes": (c_int64, [c_int64]),
+    "gte_weighted_ce": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int, c_float,
+                                c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gte_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                              c_float, c_float, c_int64, c_float, c_void_p]),
+}
+
+GTE_F32, GTE_BF16 = 0, 1
+REDUCE_SUM, REDUCE_MEAN = 0, 1
+
+_lib = None
+
+
+class GteError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgte_hip.so once; raise if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GteError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C gnn-tableextraction_amd/csrc`. There is no CPU fallback for the HIP path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().gte_last_error()
+        raise GteError(f"{what or 'gte call'} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t, what: str) -> None:
+    if not t.is_cuda:
+        raise GteError(f"{what}: tensor is on {t.device}; the HIP path needs device tensors "
+                       f"(there is no CPU fallback -- the CPU oracle lives under oracle/ for tests only)")

@@ -1,0 +1,183 @@
+// Loss and optimiser of the train step (gfx950).
+//
+// gte_weighted_ce : nn.CrossEntropyLoss(weight)(logits, labels.long()) forward + backward and the
+//                   accuracy count -- reference src/models/model_train.py:171,327-328.
+// gte_adam_step   : torch.optim.Adam(lr, weight_decay).step() on one flat fp32 buffer --
+//                   reference src/models/model_train.py:168,332.  L2-coupled decay (not AdamW).
+//
+// Both are HBM-bound and tiny next to the transforms (N x 9 logits; <= 4 M parameters).  The CE
+// is deterministic: per-block partial sums in a fixed order, one reducing block, no atomics.
+#include "gte_common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int kCeBlock = 256;
+
+template <typename L>
+__device__ __forceinline__ int label_of(const L* labels, int64_t i) { return (int)labels[i]; }
+
+// pass 1: per-node nll / weight / correct, block-reduced into partial[block][3]
+template <typename L>
+__global__ void __launch_bounds__(kCeBlock)
+ce_partial_kernel(const float* __restrict__ logits, int64_t ld, const L* __restrict__ labels,
+                  const float* __restrict__ cw, int64_t n, int c, float* __restrict__ partial) {
+    const int64_t i = (int64_t)blockIdx.x * kCeBlock + threadIdx.x;
+    float loss = 0.f, wsum = 0.f, correct = 0.f;
+    if (i < n) {
+        const float* row = logits + i * ld;
+        float m = row[0];
+        int arg = 0;
+        for (int j = 1; j < c; ++j) {
+            const float v = row[j];
+            if (v > m) { m = v; arg = j; }           // first maximum, as torch.argmax
+        }
+        float s = 0.f;
+        for (int j = 0; j < c; ++j) s += expf(row[j] - m);
+        const int y = label_of(labels, i);
+        if (y >= 0 && y < c) {
+            const float w = cw ? cw[y] : 1.0f;
+            loss = w * (logf(s) + m - row[y]);
+            wsum = w;
+            correct = (arg == y) ? 1.f : 0.f;
+        }
+    }
+    // wave reduce (64 lanes) then across the 4 waves through LDS, fixed order
+    __shared__ float red[3][kCeBlock / gte::kWave];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        loss += __shfl_down(loss, off, 64);
+        wsum += __shfl_down(wsum, off, 64);
+        correct += __shfl_down(correct, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = loss; red[1][wave] = wsum; red[2][wave] = correct; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f, d = 0.f;
+        for (int w = 0; w < kCeBlock / gte::kWave; ++w) { a += red[0][w]; b += red[1][w]; d += red[2][w]; }
+        partial[(int64_t)blockIdx.x * 3 + 0] = a;
+        partial[(int64_t)blockIdx.x * 3 + 1] = b;
+        partial[(int64_t)blockIdx.x * 3 + 2] = d;
+    }
+}
+
+// pass 2: one block folds the partials in a fixed order -> out3 = {loss, sum w, #correct}
+__global__ void __launch_bounds__(kCeBlock)
+ce_final_kernel(const float* __restrict__ partial, int64_t nblocks, float* __restrict__ out3) {
+    __shared__ double red[3][kCeBlock];
+    double a = 0., b = 0., d = 0.;
+    for (int64_t i = threadIdx.x; i < nblocks; i += kCeBlock) {
+        a += partial[i * 3 + 0];
+        b += partial[i * 3 + 1];
+        d += partial[i * 3 + 2];
+    }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = d;
+    __syncthreads();
+    for (int s = kCeBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+            red[2][threadIdx.x] += red[2][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out3[0] = (float)(red[1][0] > 0. ? red[0][0] / red[1][0] : 0.);
+        out3[1] = (float)red[1][0];
+        out3[2] = (float)red[2][0];
+    }
+}
+
+// pass 3: dlogits = grad_scale * w_y / sum_w * (softmax - onehot)
+template <typename L>
+__global__ void __launch_bounds__(kCeBlock)
+ce_grad_kernel(const float* __restrict__ logits, int64_t ld, const L* __restrict__ labels,
+               const float* __restrict__ cw, int64_t n, int c, float grad_scale,
+               const float* __restrict__ out3, float* __restrict__ dl, int64_t lddl) {
+    const int64_t i = (int64_t)blockIdx.x * kCeBlock + threadIdx.x;
+    if (i >= n) return;
+    const float* row = logits + i * ld;
+    float* drow = dl + i * lddl;
+    const int y = label_of(labels, i);
+    const float wsum = out3[1];
+    const bool ok = (y >= 0 && y < c && wsum > 0.f);
+    const float w = ok ? (cw ? cw[y] : 1.0f) * grad_scale / wsum : 0.f;
+    float m = row[0];
+    for (int j = 1; j < c; ++j) m = fmaxf(m, row[j]);
+    float s = 0.f;
+    for (int j = 0; j < c; ++j) s += expf(row[j] - m);
+    const float inv = 1.0f / s;
+    for (int j = 0; j < c; ++j) {
+        const float p = expf(row[j] - m) * inv;
+        drow[j] = w * (p - (j == y ? 1.f : 0.f));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+            int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+            float grad_scale) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float pi = p[i];
+        const float gi = fmaf(wd, pi, grad_scale * g[i]);       // L2-coupled decay: grad + wd * param
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);       // exp_avg.lerp_(grad, 1-b1)
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t gte_weighted_ce_workspace_bytes(int64_t n_nodes) {
+    return gte::round_up(gte::ceil_div(n_nodes > 0 ? n_nodes : 1, kCeBlock) * 3 * (int64_t)sizeof(float), 256);
+}
+
+extern "C" int gte_weighted_ce(const float* logits, int64_t ld, const void* labels, int labels_f32,
+                               const float* class_weight, int64_t n_nodes, int n_classes, float grad_scale,
+                               float* dlogits, int64_t lddl, float* out3, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    if (n_nodes <= 0 || n_classes <= 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "weighted_ce: empty input");
+    if (!logits || !labels || !out3 || !workspace) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "weighted_ce: null pointer");
+    if (ld < n_classes || (dlogits && lddl < n_classes)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "weighted_ce: ld < n_classes");
+    if (workspace_bytes < gte_weighted_ce_workspace_bytes(n_nodes))
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "weighted_ce: workspace too small");
+    hipStream_t s = gte::as_stream(stream);
+    const int64_t nb = gte::ceil_div(n_nodes, kCeBlock);
+    float* partial = reinterpret_cast<float*>(workspace);
+    if (labels_f32)
+        hipLaunchKernelGGL(ce_partial_kernel<float>, dim3((unsigned)nb), dim3(kCeBlock), 0, s, logits, ld,
+                           (const float*)labels, class_weight, n_nodes, n_classes, partial);
+    else
+        hipLaunchKernelGGL(ce_partial_kernel<int64_t>, dim3((unsigned)nb), dim3(kCeBlock), 0, s, logits, ld,
+                           (const int64_t*)labels, class_weight, n_nodes, n_classes, partial);
+    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(kCeBlock), 0, s, partial, nb, out3);
+    if (dlogits) {
+        if (labels_f32)
+            hipLaunchKernelGGL(ce_grad_kernel<float>, dim3((unsigned)nb), dim3(kCeBlock), 0, s, logits, ld,
+                               (const float*)labels, class_weight, n_nodes, n_classes, grad_scale, out3, dlogits, lddl);
+        else
+            hipLaunchKernelGGL(ce_grad_kernel<int64_t>, dim3((unsigned)nb), dim3(kCeBlock), 0, s, logits, ld,
+                               (const int64_t*)labels, class_weight, n_nodes, n_classes, grad_scale, out3, dlogits, lddl);
+    }
+    return gte::check_launch("weighted_ce");
+}
+
+extern "C" int gte_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                             float grad_scale, void* stream) {
+    if (n < 0 || step < 1) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step: n < 0 or step < 1");
+    if (n == 0) return GTE_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step: null pointer");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int64_t blocks = gte::ceil_div(n, 256) < 2048 ? gte::ceil_div(n, 256) : 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, gte::as_stream(stream), param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return gte::check_launch("adam_step");
+}

@@ -1,0 +1,597 @@
+// Per-node transform of GcnSAGELayer on gfx950: fp32 MFMA GEMMs + LayerNorm/ReLU.
+//
+// replaces (reference src/components/graphs/models.py):
+//   :69-72  torch.cat((h, ah*norm), 1)      -> never materialised: the A operand is read from two
+//                                              buffers (K segments [0,k1) and [k1,k1+k2))
+//   :63     nn.Linear(2F, out)              -> v_mfma_f32_32x32x2_f32 GEMM, bias in the epilogue
+//   :64-66  nn.LayerNorm(out) + activation  -> row-wise kernel (one wave per node row)
+// and their autograd: dX = dZ W (NN), dW = dZ^T X (TN, split over the node dimension with a
+// deterministic slab reduction), LayerNorm/ReLU backward with column sums for dgamma/dbeta/dbias.
+//
+// Roofline: MFMA (fp32 matrix peak 157.3 TFLOP/s; v_mfma_f32_32x32x2_f32 is bit-exact fp32 FMA
+// chains, no TF32-like shortcut exists on gfx950).  LayerNorm passes are HBM-bound.
+//
+// GEMM structure (one workgroup = 4 waves, wave64):
+//   block tile BM x BN (128x128, 128x32 or 32x128), BK = 32; every wave owns a (BM/WM)x(BN/WN) patch
+//   of 32x32 MFMA tiles held in accumulator registers.
+//   global -> registers (dwordx4, prefetch of tile t+1 issued before the MFMAs of tile t)
+//          -> LDS (ds_write_b128) -> fragments.
+//   K-contiguous operands ([rows][K] in memory) keep [rows][BK+4] LDS images: the +4 pad makes the
+//   16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots; one b128 read feeds 4 MFMAs
+//   (k = k0+4h+t, h = lane>>5: any k order is valid as long as A and B agree).
+//   Row-contiguous operands ([K][rows]) keep [BK][rows+4] images read with conflict-free ds_read_b32.
+//   blockIdx is remapped so that the tiles sharing an A row-panel run on one XCD (its L2 keeps it).
+#include "gte_common.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+
+constexpr int BK = 32;
+constexpr int KPAD = BK + 4;      // row stride (floats) of a K-contiguous LDS image
+
+struct GemmParams {
+    // A(m,k): segment 0 = A1 for k in [0,K1), segment 1 = A2 for k in [K1, K1+K2)
+    const float* A1; int64_t lda1; int K1;
+    const float* A2; int64_t lda2; int K2;
+    const float* B; int64_t ldb;       // B(k,n); k runs over K1+K2 (segment 1 starts at row/col K1)
+    float* C; int64_t ldc;
+    const float* bias;                 // nullable, per column n
+    int M, N;
+    int relu;                          // epilogue max(0, .) (only without split-K)
+    int accumulate;                    // C += (only without split-K)
+    int splits;                        // >1: write partial slabs to `slab` instead of C
+    float* slab;                       // [splits][M][N] (ld = N)
+    int tiles_per_split;               // K tiles (of BK) per split
+};
+
+// ---- staging: one BMxBK (or BKxBM) operand tile, global -> regs -> LDS ---------------------------
+// K-contiguous source ([rows][K], ld): thread t loads float4 chunks (row = c / 8, kq = c % 8).
+template <int ROWS>
+struct StageK {
+    static constexpr int CHUNKS = ROWS * (BK / 4);
+    static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
+    float4 r[PER_THREAD];
+    __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int row0, int nrows, int k0,
+                                         int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (CHUNKS % 256 == 0 || c < CHUNKS) {
+                const int row = row0 + c / (BK / 4);
+                const int k = k0 + (c % (BK / 4)) * 4;
+                if (row < nrows && k < kend) {
+                    const float* p = src + (int64_t)row * ld + k;
+                    if (k + 3 < kend) {
+                        const f4u t = *reinterpret_cast<const f4u*>(p);
+                        v = make_float4(t.x, t.y, t.z, t.w);
+                    } else {
+                        v.x = p[0];
+                        if (k + 1 < kend) v.y = p[1];
+                        if (k + 2 < kend) v.z = p[2];
+                    }
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * 256;
+            if (CHUNKS % 256 == 0 || c < CHUNKS)
+                *reinterpret_cast<float4*>(lds + (c / (BK / 4)) * KPAD + (c % (BK / 4)) * 4) = r[i];
+        }
+    }
+};
+
+// Row-contiguous source ([K][rows], ld): chunk c -> (k = c / (ROWS/4), rq = c % (ROWS/4)).
+template <int ROWS>
+struct StageR {
+    static constexpr int RPAD = ROWS + 4;
+    static constexpr int CHUNKS = BK * (ROWS / 4);
+    static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
+    float4 r[PER_THREAD];
+    __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int row0, int nrows, int k0,
+                                         int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (CHUNKS % 256 == 0 || c < CHUNKS) {
+                const int k = k0 + c / (ROWS / 4);
+                const int row = row0 + (c % (ROWS / 4)) * 4;
+                if (k < kend && row < nrows) {
+                    const float* p = src + (int64_t)k * ld + row;
+                    if (row + 3 < nrows) {
+                        const f4u t = *reinterpret_cast<const f4u*>(p);
+                        v = make_float4(t.x, t.y, t.z, t.w);
+                    } else {
+                        v.x = p[0];
+                        if (row + 1 < nrows) v.y = p[1];
+                        if (row + 2 < nrows) v.z = p[2];
+                    }
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * 256;
+            if (CHUNKS % 256 == 0 || c < CHUNKS)
+                *reinterpret_cast<float4*>(lds + (c / (ROWS / 4)) * RPAD + (c % (ROWS / 4)) * 4) = r[i];
+        }
+    }
+};
+
+template <int ROWS>
+constexpr int lds_floats(bool kcontig) { return kcontig ? ROWS * KPAD : BK * (ROWS + 4); }
+
+// fragment of one 32-row block for k-group kg (8 k values): f[t] is the operand of MFMA t (k = 8kg+4h+t)
+template <bool KCONTIG, int ROWS>
+__device__ __forceinline__ void read_frag(const float* __restrict__ lds, int blk_row0, int kg, int lane, float (&f)[4]) {
+    const int i = lane & 31, h = lane >> 5;
+    if constexpr (KCONTIG) {
+        const float4 v = *reinterpret_cast<const float4*>(lds + (blk_row0 + i) * KPAD + kg * 8 + h * 4);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+        const float* p = lds + (kg * 8 + h * 4) * (ROWS + 4) + blk_row0 + i;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f[t] = p[t * (ROWS + 4)];
+    }
+}
+
+// AK: A stored [M][K] (K-contiguous) else [K][M].  BKC: B stored [N][K] (K-contiguous) else [K][N].
+template <bool AK, bool BKC, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256)
+gemm_f32_mfma_kernel(const GemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;          // 32x32 tiles per wave
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    constexpr int A_FLOATS = lds_floats<BM>(AK), B_FLOATS = lds_floats<BN>(BKC);
+    __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + B_FLOATS];
+    float* sA = lds;
+    float* sB = lds + A_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // tile mapping: consecutive logical blocks walk N first (they share the A row panel)
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const unsigned ntile = (unsigned)(tiles_m * tiles_n);
+    const unsigned lb = gte_xcd_remap(blockIdx.x, ntile);
+    const int tm = lb / tiles_n, tn = lb % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
+
+    const int tiles_seg0 = (p.K1 + BK - 1) / BK, tiles_seg1 = (p.K2 + BK - 1) / BK;
+    const int total_tiles = tiles_seg0 + tiles_seg1;
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    typename std::conditional<AK, StageK<BM>, StageR<BM>>::type stA;
+    typename std::conditional<BKC, StageK<BN>, StageR<BN>>::type stB;
+
+    auto issue = [&](int t) {
+        const bool s1 = t >= tiles_seg0;
+        const int kl = (s1 ? t - tiles_seg0 : t) * BK;            // k inside the segment
+        const int kseg = s1 ? p.K2 : p.K1;
+        const float* a = s1 ? p.A2 : p.A1;
+        const int64_t lda = s1 ? p.lda2 : p.lda1;
+        stA.load(a, lda, m0, p.M, kl, kseg, tid);
+        // B(k, n): global k = segment base + kl; masked to the same kseg so padded k never multiplies
+        const int kb = s1 ? p.K1 : 0;
+        if constexpr (BKC) stB.load(p.B + kb, p.ldb, n0, p.N, kl, kseg, tid);
+        else stB.load(p.B + (int64_t)kb * p.ldb, p.ldb, n0, p.N, kl, kseg, tid);
+    };
+
+    if (t_begin < t_end) issue(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();                       // previous tile's fragment reads are done
+        stA.store(sA, tid);
+        stB.store(sB, tid);
+        __syncthreads();
+        if (t + 1 < t_end) issue(t + 1);       // prefetch under the MFMAs
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            float fa[TM][4], fb[TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) read_frag<AK, BM>(sA, (wm * TM + a) * 32, kg, lane, fa[a]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) read_frag<BKC, BN>(sB, (wn * TN + b) * 32, kg, lane, fb[b]);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][tt], fb[b][tt], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int col_l = lane & 31, hrow = (lane >> 5) * 4;
+    float* outp = p.splits > 1 ? p.slab + (int64_t)split * p.M * p.N : p.C;
+    const int64_t ldo = p.splits > 1 ? p.N : p.ldc;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + (wn * TN + b) * 32 + col_l;
+        if (col >= p.N) continue;
+        const float bv = (p.bias && p.splits <= 1) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int rbase = m0 + (wm * TM + a) * 32 + hrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < p.M) {
+                    float v = acc[a][b][r] + bv;
+                    float* dst = outp + (int64_t)row * ldo + col;
+                    if (p.splits <= 1) {
+                        if (p.accumulate) v += *dst;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                    }
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// C[m][n] (+)= bias[n] + sum_s slab[s][m][n]   -- fixed order, deterministic
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t mn, int N, float* __restrict__ C, int64_t ldc,
+                     const float* __restrict__ bias, int accumulate, int relu) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += stride) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * mn + i];
+        const int64_t m = i / N;
+        const int n = (int)(i - m * N);
+        if (bias) s += bias[n];
+        float* dst = C + m * ldc + n;
+        if (accumulate) s += *dst;
+        if (relu) s = fmaxf(s, 0.f);
+        *dst = s;
+    }
+}
+
+struct Plan { int bm, bn, tiles, splits, tiles_per_split; };
+
+Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2) {
+    Plan pl;
+    if (N <= 32) { pl.bm = 128; pl.bn = 32; }
+    else if (M <= 32) { pl.bm = 32; pl.bn = 128; }
+    else { pl.bm = 128; pl.bn = 128; }
+    pl.tiles = (int)(gte::ceil_div(M, pl.bm) * gte::ceil_div(N, pl.bn));
+    const int ktiles = (int)(gte::ceil_div(K1, BK) + gte::ceil_div(K2, BK));
+    const int cus = gte::device_props().cus;
+    int splits = 1;
+    // the reduction dimension is the node count for dW = dZ^T X: few output tiles, very long K
+    if (pl.tiles < cus && ktiles >= 16) {
+        splits = (int)gte::ceil_div(2 * cus, pl.tiles);
+        const int max_splits = ktiles / 8 > 0 ? ktiles / 8 : 1;      // >= 8 K tiles (256 k) per split
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    pl.tiles_per_split = (int)gte::ceil_div(ktiles, splits);
+    pl.splits = (int)gte::ceil_div(ktiles, pl.tiles_per_split);
+    return pl;
+}
+
+template <bool AK, bool BKC>
+int launch_shape(const GemmParams& p, const Plan& pl, hipStream_t s) {
+    dim3 grid((unsigned)pl.tiles, (unsigned)pl.splits), block(256);
+    if (pl.bm == 128 && pl.bn == 128)
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 128, 128, 2, 2>), grid, block, 0, s, p);
+    else if (pl.bn == 32)
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 128, 32, 4, 1>), grid, block, 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 32, 128, 1, 4>), grid, block, 0, s, p);
+    return gte::check_launch("gemm_f32");
+}
+
+int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+    if (p.M == 0 || p.N == 0) return GTE_OK;
+    const Plan pl = make_plan(p.M, p.N, p.K1, p.K2);
+    p.splits = pl.splits;
+    p.tiles_per_split = pl.tiles_per_split;
+    p.slab = nullptr;
+    const int relu = p.relu, accumulate = p.accumulate;
+    if (pl.splits > 1) {
+        const int64_t need = (int64_t)pl.splits * p.M * p.N * (int64_t)sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "gemm_f32: split-K needs %lld workspace bytes, got %lld",
+                             (long long)need, (long long)workspace_bytes);
+        p.slab = reinterpret_cast<float*>(workspace);
+    }
+    int rc;
+    if (ak && bkc) rc = launch_shape<true, true>(p, pl, s);
+    else if (ak && !bkc) rc = launch_shape<true, false>(p, pl, s);
+    else if (!ak && bkc) rc = launch_shape<false, true>(p, pl, s);
+    else rc = launch_shape<false, false>(p, pl, s);
+    if (rc != GTE_OK) return rc;
+    if (pl.splits > 1) {
+        const int64_t mn = (int64_t)p.M * p.N;
+        const int64_t blocks = gte::ceil_div(mn, 256) < 4096 ? gte::ceil_div(mn, 256) : 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slab, pl.splits, mn, p.N, p.C,
+                           p.ldc, p.bias, accumulate, relu);
+        return gte::check_launch("gemm_f32 split-K reduce");
+    }
+    return GTE_OK;
+}
+
+int64_t gemm_workspace(int64_t M, int64_t N, int64_t K1, int64_t K2) {
+    if (M <= 0 || N <= 0) return 256;
+    const Plan pl = make_plan(M, N, K1, K2);
+    return pl.splits > 1 ? gte::round_up((int64_t)pl.splits * M * N * 4, 256) : 256;
+}
+
+// ------------------------------- LayerNorm + ReLU, forward ----------------------------------------
+// y = relu?( gamma * (z - mean) * rstd + beta ); one wave per row, two-pass mean/variance (biased
+// variance, eps inside the sqrt: torch.nn.LayerNorm).  In place (y == z) is allowed.
+constexpr int LN_CACHE = 16;      // elements per lane kept in registers -> rows up to 1024 wide
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float ln_affine(float xhat, float g, float b) { return fmaf(xhat, g, b); }
+
+__global__ void __launch_bounds__(256)
+ln_relu_fwd_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, float eps, int relu, float* __restrict__ y, int64_t ldy,
+                   float* __restrict__ stats, int M, int n) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* zr = z + (int64_t)row * ldz;
+    float* yr = y + (int64_t)row * ldy;
+    float c[LN_CACHE];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_CACHE; ++t) {
+        const int j = lane + 64 * t;
+        c[t] = j < n ? zr[j] : 0.f;
+        s += c[t];
+    }
+    for (int j = lane + 64 * LN_CACHE; j < n; j += 64) s += zr[j];
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_CACHE; ++t) {
+        const int j = lane + 64 * t;
+        const float d = j < n ? c[t] - mean : 0.f;
+        q = fmaf(d, d, q);
+    }
+    for (int j = lane + 64 * LN_CACHE; j < n; j += 64) { const float d = zr[j] - mean; q = fmaf(d, d, q); }
+    const float rstd = rsqrtf(wave_sum(q) / (float)n + eps);
+    if (stats && lane == 0) { stats[row] = mean; stats[M + row] = rstd; }
+#pragma unroll
+    for (int t = 0; t < LN_CACHE; ++t) {
+        const int j = lane + 64 * t;
+        if (j < n) {
+            float v = ln_affine((c[t] - mean) * rstd, gamma[j], beta[j]);
+            if (relu) v = fmaxf(v, 0.f);
+            yr[j] = v;
+        }
+    }
+    for (int j = lane + 64 * LN_CACHE; j < n; j += 64) {
+        float v = ln_affine((zr[j] - mean) * rstd, gamma[j], beta[j]);
+        if (relu) v = fmaxf(v, 0.f);
+        yr[j] = v;
+    }
+}
+
+// ------------------------------- LayerNorm + ReLU, backward ---------------------------------------
+// Per row: g = relu ? (pre > 0 ? dy : 0) : dy ; dxhat = g*gamma ;
+//          dz = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat))
+// Column sums (dgamma = sum g*xhat, dbeta = sum g, dbias = sum dz) are accumulated per block in
+// registers over the block's rows, written as partials [block][3][n] and folded by a second kernel
+// in block order (deterministic, no atomics).
+constexpr int LNB_ROWS = 32;      // rows per block (8 per wave)
+
+__global__ void __launch_bounds__(256)
+ln_relu_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ z, int64_t ldz,
+                   const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                   int relu, float* __restrict__ dz, int64_t lddz, float* __restrict__ partial, int M, int n) {
+    __shared__ float red[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row_begin = blockIdx.x * LNB_ROWS;
+    const bool has_ln = gamma != nullptr;
+    // column chunk loop: 64 columns at a time so the per-column partials stay in three registers
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool jok = j < n;
+        const float gj = (has_ln && jok) ? gamma[j] : 1.f;
+        const float bj = (has_ln && jok) ? beta[j] : 0.f;
+        float s_dg = 0.f, s_db = 0.f, s_dbias = 0.f;
+        for (int rr = wave; rr < LNB_ROWS; rr += 4) {
+            const int row = row_begin + rr;
+            if (row >= M) break;
+            const float* dyr = dy + (int64_t)row * lddy;
+            const float* zr = z + (int64_t)row * ldz;
+            float* dzr = dz + (int64_t)row * lddz;
+            if (has_ln) {
+                const float mean = stats[row], rstd = stats[M + row];
+                // row means of dxhat and dxhat*xhat need the whole row: recomputed per 64-column chunk from
+                // L1/L2-resident rows (a row is <= 4 KB); cheap next to the GEMMs
+                float a = 0.f, b = 0.f;
+                for (int jj = lane; jj < n; jj += 64) {
+                    const float xh = (zr[jj] - mean) * rstd;
+                    float g = dyr[jj];
+                    if (relu && ln_affine(xh, gamma[jj], beta[jj]) <= 0.f) g = 0.f;
+                    const float dxh = g * gamma[jj];
+                    a += dxh;
+                    b = fmaf(dxh, xh, b);
+                }
+                const float c1 = wave_sum(a) / (float)n, c2 = wave_sum(b) / (float)n;
+                if (jok) {
+                    const float xh = (zr[j] - mean) * rstd;
+                    float g = dyr[j];
+                    if (relu && ln_affine(xh, gj, bj) <= 0.f) g = 0.f;
+                    const float dxh = g * gj;
+                    const float d = rstd * (dxh - c1 - xh * c2);
+                    s_dg = fmaf(g, xh, s_dg);
+                    s_db += g;
+                    s_dbias += d;
+                    dzr[j] = d;          // safe when dz aliases dy: the row-mean pass above is complete
+                }
+            } else if (jok) {
+                float g = dyr[j];
+                if (relu && zr[j] <= 0.f) g = 0.f;
+                s_dbias += g;
+                dzr[j] = g;
+            }
+        }
+        red[0][wave][lane] = s_dg; red[1][wave][lane] = s_db; red[2][wave][lane] = s_dbias;
+        __syncthreads();
+        if (wave == 0 && jok) {
+            float* pp = partial + (int64_t)blockIdx.x * 3 * n;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                pp[q * n + j] = red[q][0][lane] + red[q][1][lane] + red[q][2][lane] + red[q][3][lane];
+        }
+        __syncthreads();
+    }
+}
+
+// NOTE on aliasing: with LayerNorm and n > 64 the row means for chunk j0 > 0 re-read dy after dz has
+// overwritten chunk 0 -- so dz must NOT alias dy when n > 64 and gamma != NULL (checked on the host).
+
+__global__ void __launch_bounds__(256)
+colsum_fold_kernel(const float* __restrict__ partial, int nblocks, int n, float* __restrict__ dgamma,
+                   float* __restrict__ dbeta, float* __restrict__ dbias) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int k = 0; k < nblocks; ++k) {
+        const float* pp = partial + (int64_t)k * 3 * n;
+        a += pp[j]; b += pp[n + j]; c += pp[2 * n + j];
+    }
+    if (dgamma) dgamma[j] += a;
+    if (dbeta) dbeta[j] += b;
+    if (dbias) dbias[j] += c;
+}
+
+}  // namespace
+
+// ------------------------------------------ C ABI -------------------------------------------------
+extern "C" int64_t gte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) { return gemm_workspace(M, N, K, 0); }
+
+extern "C" int gte_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                            const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_f32: bad sizes");
+    if (M == 0 || N == 0) return GTE_OK;
+    if (!A || !B || !C) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_f32: null pointer");
+    if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_f32: leading dimension too small");
+    GemmParams p = {};
+    p.A1 = A; p.lda1 = lda; p.K1 = (int)K; p.A2 = nullptr; p.lda2 = 0; p.K2 = 0;
+    p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = nullptr; p.M = (int)M; p.N = (int)N;
+    p.relu = 0; p.accumulate = accumulate ? 1 : 0;
+    return run_gemm(!trans_a, trans_b != 0, p, workspace, workspace_bytes, gte::as_stream(stream));
+}
+
+extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2,
+                                   int64_t k2, const float* W, int64_t ldw, const float* bias, const float* gamma,
+                                   const float* beta, float eps, int relu, float* z_save, int64_t ldz, float* stats,
+                                   float* y, int64_t ldy, int64_t M, int64_t n_out, void* stream) {
+    if (M < 0 || n_out <= 0 || k1 <= 0 || k2 < 0 || M > INT32_MAX || n_out > INT32_MAX || k1 + k2 > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: bad sizes");
+    if (M == 0) return GTE_OK;
+    if (!a1 || !W || !y || (k2 > 0 && !a2)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: null pointer");
+    if (lda1 < k1 || (k2 > 0 && lda2 < k2) || ldw < k1 + k2 || ldy < n_out || (z_save && ldz < n_out))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: leading dimension too small");
+    if (gamma && !beta) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: gamma without beta");
+    hipStream_t s = gte::as_stream(stream);
+    const bool ln = gamma != nullptr;
+    // z goes to z_save when the backward needs it, else straight into y (LayerNorm then runs in place)
+    float* zbuf = (ln && z_save) ? z_save : y;
+    const int64_t ldzz = (ln && z_save) ? ldz : ldy;
+    GemmParams p = {};
+    p.A1 = a1; p.lda1 = lda1; p.K1 = (int)k1; p.A2 = a2; p.lda2 = lda2; p.K2 = (int)k2;
+    p.B = W; p.ldb = ldw; p.C = zbuf; p.ldc = ldzz; p.bias = bias; p.M = (int)M; p.N = (int)n_out;
+    p.relu = (!ln && relu) ? 1 : 0; p.accumulate = 0;
+    // forward K = k1+k2 is short and M is the node count: never split (workspace-free)
+    const Plan pl = make_plan(M, n_out, k1, k2);
+    if (pl.splits > 1) {
+        // tiny M with long K (not a page-graph shape): run unsplit rather than demand a workspace
+        Plan one = pl; one.splits = 1; one.tiles_per_split = (int)(gte::ceil_div(k1, BK) + gte::ceil_div(k2, BK));
+        p.splits = 1; p.tiles_per_split = one.tiles_per_split;
+        int rc = launch_shape<true, true>(p, one, s);
+        if (rc != GTE_OK) return rc;
+    } else {
+        int rc = run_gemm(true, true, p, nullptr, 0, s);
+        if (rc != GTE_OK) return rc;
+    }
+    if (!ln && z_save && z_save != y) {
+        // no LayerNorm but the caller wants z (= pre-activation): only meaningful with relu; keep the contract simple
+        return gte::fail(GTE_ERR_UNSUPPORTED, "sage_linear_fwd: z_save without LayerNorm is not supported");
+    }
+    if (ln) {
+        hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3((unsigned)gte::ceil_div(M, 4)), dim3(256), 0, s, zbuf, ldzz, gamma,
+                           beta, eps, relu, y, ldy, stats, (int)M, (int)n_out);
+        return gte::check_launch("ln_relu_fwd");
+    }
+    return GTE_OK;
+}
+
+extern "C" int gte_ln_relu_fwd(const float* z, int64_t ldz, const float* gamma, const float* beta, float eps, int relu,
+                               float* y, int64_t ldy, float* stats, int64_t M, int64_t n_out, void* stream) {
+    if (M < 0 || n_out <= 0 || M > INT32_MAX || n_out > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_fwd: bad sizes");
+    if (M == 0) return GTE_OK;
+    if (!z || !y || !gamma || !beta) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_fwd: null pointer");
+    if (ldz < n_out || ldy < n_out) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_fwd: ld < n_out");
+    hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3((unsigned)gte::ceil_div(M, 4)), dim3(256), 0, gte::as_stream(stream), z,
+                       ldz, gamma, beta, eps, relu, y, ldy, stats, (int)M, (int)n_out);
+    return gte::check_launch("ln_relu_fwd");
+}
+
+extern "C" int64_t gte_ln_relu_bwd_workspace_bytes(int64_t M, int64_t n_out) {
+    const int64_t nb = gte::ceil_div(M > 0 ? M : 1, LNB_ROWS);
+    return gte::round_up(nb * 3 * (n_out > 0 ? n_out : 1) * 4, 256);
+}
+
+extern "C" int gte_ln_relu_bwd(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* stats,
+                               const float* gamma, const float* beta, int relu, float* dz, int64_t lddz,
+                               float* dgamma, float* dbeta, float* dbias, int64_t M, int64_t n_out, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    if (M < 0 || n_out <= 0 || M > INT32_MAX || n_out > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: bad sizes");
+    if (M == 0) return GTE_OK;
+    if (!dy || !dz || !workspace) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: null pointer");
+    if ((gamma || relu) && !z) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: z is required");
+    if (gamma && (!beta || !stats)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: LayerNorm needs beta and stats");
+    if (gamma && n_out > 64 && dz == dy)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: dz must not alias dy when n_out > 64 with LayerNorm");
+    if (workspace_bytes < gte_ln_relu_bwd_workspace_bytes(M, n_out))
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "ln_relu_bwd: workspace too small");
+    hipStream_t s = gte::as_stream(stream);
+    const int nb = (int)gte::ceil_div(M, LNB_ROWS);
+    const float* zz = z ? z : dy;
+    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, dy, lddy, zz, z ? ldz : lddy, stats, gamma,
+                       beta, relu, dz, lddz, reinterpret_cast<float*>(workspace), (int)M, (int)n_out);
+    if (dgamma || dbeta || dbias)
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)gte::ceil_div(n_out, 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(workspace), nb, (int)n_out, dgamma, dbeta, dbias);
+    return gte::check_launch("ln_relu_bwd");
+}

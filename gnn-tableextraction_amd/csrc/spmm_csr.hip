@@ -1,0 +1,250 @@
+// Neighbour aggregation for page graphs: CSR gather-SpMM on gfx950 (wave64).
+//
+//   out[v, :] = scale_v * sum_{e in row v} w[e] * x[indices[e], :]
+//
+// replaces the reference's DGL call  g.update_all(fn.u_mul_e('h','feat','m'), fn.sum('m','h'))
+// (src/components/graphs/models.py:53-54), the fn.mean reducer (:146-149) and get_norm (:74-78).
+// Run on the out-edge CSR it is that call's backward (DGL GSpMM.backward).
+//
+// Roofline: HBM.  Algorithmic bytes per destination row = 2*F*s + 8*deg + 4.
+//
+// Mapping (CDNA4):
+//   * a group of G lanes (G = 4..64, power of two, chosen from F) owns one destination row;
+//     a wave64 therefore processes 64/G rows at once -- small F (13, 9) does not idle lanes.
+//   * every lane owns up to CPL 16-byte chunks of the feature row (global_load_dwordx4 through
+//     4-byte-aligned vector types: gfx950 takes unaligned wide loads, so F = 831 rows use the
+//     same instructions as 16-byte-aligned ones) plus, for the
+//     F mod 4 tail, one scalar element on the first lanes of the group.
+//   * the row's edge list (indices, weights) is read ONCE, coalesced, one edge per lane, and
+//     broadcast inside the group with ds_bpermute (__shfl); four source rows are in flight
+//     per lane-group per iteration to cover HBM/L2 latency.
+//   * fixed summation order (CSR order) => bit-reproducible run to run; fp32 accumulate.
+//   * blocks take contiguous row ranges and blockIdx is remapped so each XCD's L2 serves one
+//     contiguous 1/8 of the (reading-order) node range: neighbouring rows share sources.
+#include "gte_common.h"
+
+namespace {
+
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(2))) u4u { unsigned x, y, z, w; };
+
+// ---- element traits: f32 (4 per 16-byte chunk) and bf16 (8 per chunk, f32 accumulate) ----
+struct F32 {
+    using elem = float;
+    static constexpr int EPC = 4;
+    static __device__ __forceinline__ void load(const elem* p, float (&v)[4]) {
+        const f4u t = *reinterpret_cast<const f4u*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(elem* p, const float (&v)[4]) {
+        f4u t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        *reinterpret_cast<f4u*>(p) = t;
+    }
+    static __device__ __forceinline__ float to_f32(elem e) { return e; }
+    static __device__ __forceinline__ elem from_f32(float f) { return f; }
+};
+
+struct BF16 {
+    using elem = unsigned short;
+    static constexpr int EPC = 8;
+    static __device__ __forceinline__ float to_f32(elem e) { return __uint_as_float(((unsigned)e) << 16); }
+    static __device__ __forceinline__ elem from_f32(float f) {
+        // round-to-nearest-even via the hardware convert (keeps NaN a NaN on gfx950)
+        __bf16 b = (__bf16)f;
+        return *reinterpret_cast<unsigned short*>(&b);
+    }
+    static __device__ __forceinline__ void load(const elem* p, float (&v)[8]) {
+        unsigned w[4];
+        const u4u t = *reinterpret_cast<const u4u*>(p);
+        w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(elem* p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (unsigned)from_f32(v[2 * i]) | ((unsigned)from_f32(v[2 * i + 1]) << 16);
+        u4u t; t.x = w[0]; t.y = w[1]; t.z = w[2]; t.w = w[3];
+        *reinterpret_cast<u4u*>(p) = t;
+    }
+};
+
+constexpr int kEdgeUnroll = 4;   // source rows in flight per lane group
+
+template <typename T, int G, int CPL, bool ACCUM>
+__global__ void __launch_bounds__(256)
+spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                const float* __restrict__ ew, const typename T::elem* __restrict__ x, int64_t ldx,
+                typename T::elem* __restrict__ out, int64_t ldo, int n_rows, int n_feat, int reduce,
+                int rows_per_block) {
+    using elem = typename T::elem;
+    constexpr int EPC = T::EPC;
+    constexpr int RPW = gte::kWave / G;                 // rows per wave per pass
+    const int lane = threadIdx.x & (gte::kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane / G, li = lane % G;
+    const int nchunk = n_feat / EPC;                    // full 16-byte chunks per row
+    const int rem = n_feat - nchunk * EPC;              // scalar tail elements (< EPC <= G... EPC 8 needs G >= 8)
+    const unsigned lb = gte_xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = (int)lb * rows_per_block;
+    const int row_end = min(row0 + rows_per_block, n_rows);
+
+    for (int rbase = row0 + wave * RPW; rbase < row_end; rbase += 4 * RPW) {
+        const int r = rbase + sub;
+        const bool row_ok = r < row_end;
+        int lo = 0, hi = 0;
+        if (row_ok) { lo = indptr[r]; hi = indptr[r + 1]; }
+        const float scale = (reduce == GTE_REDUCE_MEAN) ? (hi > lo ? 1.0f / (float)(hi - lo) : 0.0f) : 1.0f;
+
+        for (int cb = 0; cb < nchunk || (cb == 0 && rem); cb += G * CPL) {
+            float acc[CPL][EPC];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                for (int q = 0; q < EPC; ++q) acc[j][q] = 0.f;
+            float tail = 0.f;
+            const bool do_tail = (cb == 0) && (li < rem);
+            const int64_t tail_off = (int64_t)nchunk * EPC + li;
+
+            for (int eb = lo; eb < hi; eb += G) {
+                const int my_e = eb + li;
+                int my_u = 0;
+                float my_w = 0.f;
+                if (my_e < hi) {
+                    my_u = indices[my_e];
+                    my_w = ew ? ew[my_e] : 1.0f;
+                }
+                const int cnt = min(G, hi - eb);
+                for (int t = 0; t < cnt; t += kEdgeUnroll) {
+                    int u[kEdgeUnroll];
+                    float w[kEdgeUnroll];
+#pragma unroll
+                    for (int k = 0; k < kEdgeUnroll; ++k) {
+                        // past the end of the row: re-use the last valid source (cache hit) with w = 0
+                        const int tt = min(t + k, cnt - 1);
+                        u[k] = __shfl(my_u, tt, G);
+                        w[k] = (t + k < cnt) ? __shfl(my_w, tt, G) : 0.f;
+                    }
+                    float v[kEdgeUnroll][CPL][EPC];
+                    float tv[kEdgeUnroll];
+#pragma unroll
+                    for (int k = 0; k < kEdgeUnroll; ++k) {
+                        const elem* xr = x + (int64_t)u[k] * ldx;
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) {
+                            const int c = cb + li + j * G;
+                            if (c < nchunk) T::load(xr + (int64_t)c * EPC, v[k][j]);
+                        }
+                        tv[k] = do_tail ? T::to_f32(xr[tail_off]) : 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < kEdgeUnroll; ++k) {
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) {
+                            const int c = cb + li + j * G;
+                            if (c < nchunk) {
+#pragma unroll
+                                for (int q = 0; q < EPC; ++q) acc[j][q] = fmaf(w[k], v[k][j][q], acc[j][q]);
+                            }
+                        }
+                        tail = fmaf(w[k], tv[k], tail);
+                    }
+                }
+            }
+
+            if (row_ok) {
+                elem* orow = out + (int64_t)r * ldo;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const int c = cb + li + j * G;
+                    if (c < nchunk) {
+                        float o[EPC];
+                        if constexpr (ACCUM) {
+                            T::load(orow + (int64_t)c * EPC, o);
+#pragma unroll
+                            for (int q = 0; q < EPC; ++q) o[q] += acc[j][q] * scale;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < EPC; ++q) o[q] = acc[j][q] * scale;
+                        }
+                        T::store(orow + (int64_t)c * EPC, o);
+                    }
+                }
+                if (do_tail) {
+                    float o = tail * scale;
+                    if constexpr (ACCUM) o += T::to_f32(orow[tail_off]);
+                    orow[tail_off] = T::from_f32(o);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int G, int CPL, bool ACCUM>
+int launch_g(const int32_t* indptr, const int32_t* indices, const float* ew, const void* x, int64_t ldx,
+             void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, hipStream_t s) {
+    using elem = typename T::elem;
+    constexpr int RPW = gte::kWave / G;
+    const int rows_per_block = 4 * RPW * 4;            // 4 waves x RPW rows x 4 passes, contiguous
+    const int64_t nblocks = gte::ceil_div(n_rows, rows_per_block);
+    dim3 grid((unsigned)nblocks), block(256);
+    hipLaunchKernelGGL((spmm_csr_kernel<T, G, CPL, ACCUM>), grid, block, 0, s, indptr, indices, ew,
+                       (const elem*)x, ldx, (elem*)out, ldo, (int)n_rows, (int)n_feat, reduce, rows_per_block);
+    return gte::check_launch("spmm_csr");
+}
+
+template <typename T, bool ACCUM>
+int dispatch(const int32_t* indptr, const int32_t* indices, const float* ew, const void* x, int64_t ldx,
+             void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, hipStream_t s) {
+    const int64_t nchunk = n_feat / T::EPC;
+#define GTE_L(G, CPL) return launch_g<T, G, CPL, ACCUM>(indptr, indices, ew, x, ldx, out, ldo, n_rows, n_feat, reduce, s)
+    if (nchunk <= 8 && T::EPC <= 8) {
+        if (nchunk <= 4 && T::EPC == 4) GTE_L(4, 1);
+        GTE_L(8, 1);
+    }
+    if (nchunk <= 16) GTE_L(16, 1);
+    if (nchunk <= 32) GTE_L(32, 1);
+    if (nchunk <= 64) GTE_L(64, 1);
+    if (nchunk <= 128) GTE_L(64, 2);
+    GTE_L(64, 4);                                     // wider rows loop over 256-chunk feature blocks
+#undef GTE_L
+}
+
+int spmm_entry(bool accumulate, const int32_t* indptr, const int32_t* indices, const float* eweight,
+               const void* x, int64_t ldx, void* out, int64_t ldo, int64_t n_rows, int64_t n_feat,
+               int dtype, int reduce, void* stream) {
+    if (n_rows < 0 || n_feat < 0 || n_rows > INT32_MAX || n_feat > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr: bad sizes n_rows=%lld n_feat=%lld", (long long)n_rows,
+                         (long long)n_feat);
+    if (n_rows == 0 || n_feat == 0) return GTE_OK;
+    if (!indptr || !x || !out) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr: null pointer");
+    if (ldx < n_feat || ldo < n_feat) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr: ld < n_feat");
+    if (reduce != GTE_REDUCE_SUM && reduce != GTE_REDUCE_MEAN)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr: reduce must be 0 (sum) or 1 (mean)");
+    hipStream_t s = gte::as_stream(stream);
+    if (dtype == GTE_F32) {
+        return accumulate ? dispatch<F32, true>(indptr, indices, eweight, x, ldx, out, ldo, n_rows, n_feat, reduce, s)
+                          : dispatch<F32, false>(indptr, indices, eweight, x, ldx, out, ldo, n_rows, n_feat, reduce, s);
+    } else if (dtype == GTE_BF16) {
+        return accumulate ? dispatch<BF16, true>(indptr, indices, eweight, x, ldx, out, ldo, n_rows, n_feat, reduce, s)
+                          : dispatch<BF16, false>(indptr, indices, eweight, x, ldx, out, ldo, n_rows, n_feat, reduce, s);
+    }
+    return gte::fail(GTE_ERR_UNSUPPORTED, "spmm_csr: dtype %d", dtype);
+}
+
+}  // namespace
+
+extern "C" int gte_spmm_csr(const int32_t* indptr, const int32_t* indices, const float* eweight, const void* x,
+                            int64_t ldx, void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int dtype,
+                            int reduce, void* stream) {
+    return spmm_entry(false, indptr, indices, eweight, x, ldx, out, ldo, n_rows, n_feat, dtype, reduce, stream);
+}
+
+extern "C" int gte_spmm_csr_accumulate(const int32_t* indptr, const int32_t* indices, const float* eweight,
+                                       const void* x, int64_t ldx, void* out, int64_t ldo, int64_t n_rows,
+                                       int64_t n_feat, int dtype, int reduce, void* stream) {
+    return spmm_entry(true, indptr, indices, eweight, x, ldx, out, ldo, n_rows, n_feat, dtype, reduce, stream);
+}

@@ -1,0 +1,276 @@
+"""Page-graph container: the DGL-graph duck type the reference's model and train loop use.
+
+The reference builds one ``dgl.graph((u, v), num_nodes, idtype=torch.int32)`` per PDF page
+(src/components/graphs/builder.py:425), batches pages with ``dgl.batch``
+(src/models/model_train.py:246,297) and the model touches only
+``g.local_var() / g.in_degrees() / g.ndata / g.edata / g.update_all(msg, reduce) / g.to(dev)``
+(src/components/graphs/models.py:46-78, :105-106, :144-150).  ``PageGraph`` implements that
+surface over device-resident CSR arrays so ``model(g)`` runs unchanged without DGL.
+
+Layout in HBM (all int32, the reference's idtype):
+  in-edge CSR   ``indptr[N+1], indices[E]`` (= sources, rows = destinations), ``perm[E]`` = COO
+                edge ids in row order (stable by destination => fixed summation order)
+  out-edge CSR  the same keyed by source (rows = sources, indices = destinations): the backward
+                of the aggregation is an SpMM over it
+Edge data (``edata['feat']``, one fp32 scalar per edge: loader.py:332-344) stays in COO order as
+the user set it; the CSR-ordered copies are cached per tensor version.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+class _FrameDict(dict):
+    """ndata / edata: plain dict with DGL's pop semantics."""
+
+
+class CSR:
+    __slots__ = ("indptr", "indices", "perm")
+
+    def __init__(self, indptr, indices, perm):
+        self.indptr, self.indices, self.perm = indptr, indices, perm
+
+
+def _build_csr(key: torch.Tensor, other: torch.Tensor, n: int) -> CSR:
+    """Stable counting sort of the COO by ``key`` -> CSR(indptr, indices=other[perm], perm)."""
+    from . import ops
+    if key.is_cuda:
+        return CSR(*ops.coo_to_csr(key, other, n))
+    # host-side graph preparation (CPU tensors): index bookkeeping only, no feature arithmetic
+    e = key.numel()
+    if e == 0:
+        z = torch.zeros(n + 1, dtype=torch.int32, device=key.device)
+        return CSR(z, key.new_zeros(0, dtype=torch.int32), key.new_zeros(0, dtype=torch.int32))
+    perm = torch.sort(key.long(), stable=True).indices
+    counts = torch.bincount(key.long(), minlength=n)
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=key.device)
+    indptr[1:] = torch.cumsum(counts, 0)
+    return CSR(indptr.to(torch.int32), other[perm].to(torch.int32).contiguous(), perm.to(torch.int32))
+
+
+class PageGraph:
+    """Directed multigraph over ``num_nodes`` nodes with edges ``src[e] -> dst[e]``."""
+
+    def __init__(self, src, dst, num_nodes: int, device=None):
+        src = torch.as_tensor(src)
+        dst = torch.as_tensor(dst)
+        if src.shape != dst.shape or src.dim() != 1:
+            raise ValueError("src and dst must be 1-D tensors of equal length")
+        if device is not None:
+            src, dst = src.to(device), dst.to(device)
+        self._src = src.to(torch.int32).contiguous()
+        self._dst = dst.to(torch.int32).contiguous()
+        self._n = int(num_nodes)
+        self.ndata: Dict[str, torch.Tensor] = _FrameDict()
+        self.edata: Dict[str, torch.Tensor] = _FrameDict()
+        self._in_csr: Optional[CSR] = None
+        self._out_csr: Optional[CSR] = None
+        self._inv_deg: Optional[torch.Tensor] = None
+        self._wcache: Dict[tuple, torch.Tensor] = {}
+        self.batch_num_nodes_: List[int] = [self._n]
+        self.batch_num_edges_: List[int] = [int(self._src.numel())]
+
+    # ---- DGL surface used by the reference -------------------------------------------------
+    @property
+    def device(self):
+        return self._src.device
+
+    def num_nodes(self) -> int:
+        return self._n
+
+    number_of_nodes = num_nodes
+
+    def num_edges(self) -> int:
+        return int(self._src.numel())
+
+    number_of_edges = num_edges
+
+    def edges(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self._src, self._dst
+
+    def batch_num_nodes(self) -> torch.Tensor:
+        return torch.tensor(self.batch_num_nodes_, dtype=torch.int64)
+
+    def batch_num_edges(self) -> torch.Tensor:
+        return torch.tensor(self.batch_num_edges_, dtype=torch.int64)
+
+    def in_degrees(self) -> torch.Tensor:
+        ip = self.in_csr().indptr
+        return (ip[1:] - ip[:-1]).to(torch.int64)
+
+    def out_degrees(self) -> torch.Tensor:
+        ip = self.out_csr().indptr
+        return (ip[1:] - ip[:-1]).to(torch.int64)
+
+    def local_var(self) -> "PageGraph":
+        """Shallow copy: new ndata/edata dicts over the same tensors and the same cached CSRs
+        (models.py:47)."""
+        g = PageGraph.__new__(PageGraph)
+        g.__dict__.update(self.__dict__)
+        g.ndata = _FrameDict(self.ndata)
+        g.edata = _FrameDict(self.edata)
+        return g
+
+    class _Scope:
+        def __init__(self, g):
+            self.g = g
+
+        def __enter__(self):
+            self.nd, self.ed = _FrameDict(self.g.ndata), _FrameDict(self.g.edata)
+            return self.g
+
+        def __exit__(self, *exc):
+            self.g.ndata, self.g.edata = self.nd, self.ed
+            return False
+
+    def local_scope(self):
+        return PageGraph._Scope(self)
+
+    def to(self, device) -> "PageGraph":
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        g = PageGraph.__new__(PageGraph)
+        g.__dict__.update(self.__dict__)
+        g._src, g._dst = self._src.to(device), self._dst.to(device)
+        g.ndata = _FrameDict({k: v.to(device) for k, v in self.ndata.items()})
+        g.edata = _FrameDict({k: v.to(device) for k, v in self.edata.items()})
+        mv = lambda c: None if c is None else CSR(c.indptr.to(device), c.indices.to(device), c.perm.to(device))
+        g._in_csr, g._out_csr = mv(self._in_csr), mv(self._out_csr)
+        g._inv_deg = None if self._inv_deg is None else self._inv_deg.to(device)
+        g._wcache = {}
+        return g
+
+    def update_all(self, message_func, reduce_func) -> None:
+        """``update_all(fn.u_mul_e(u, e, m), fn.sum|mean(m, out))`` / ``fn.copy_u`` through the HIP
+        aggregation kernel (differentiable w.r.t. the node feature)."""
+        from . import ops
+        kind = message_func[0]
+        if kind not in ("u_mul_e", "copy_u") or reduce_func[0] not in ("sum", "mean"):
+            raise NotImplementedError(f"update_all({message_func}, {reduce_func}) is not part of the hot path")
+        h = self.ndata[message_func[1]]
+        w = self.edata[message_func[2]] if kind == "u_mul_e" else None
+        self.ndata[reduce_func[2]] = ops.aggregate(self, h, w, mean=(reduce_func[0] == "mean"))
+
+    # ---- CSR views ---------------------------------------------------------------------------
+    def in_csr(self) -> CSR:
+        if self._in_csr is None:
+            self._in_csr = _build_csr(self._dst, self._src, self._n)
+        return self._in_csr
+
+    def out_csr(self) -> CSR:
+        if self._out_csr is None:
+            self._out_csr = _build_csr(self._src, self._dst, self._n)
+        return self._out_csr
+
+    def inv_in_degree(self) -> torch.Tensor:
+        """norm of models.py:74-78 as a vector: 1/in_degree, 0 where the degree is 0 (fp32 [N])."""
+        if self._inv_deg is None:
+            deg = self.in_degrees().to(torch.float32)
+            inv = torch.where(deg > 0, 1.0 / deg.clamp(min=1), torch.zeros_like(deg))
+            self._inv_deg = inv.contiguous()
+        return self._inv_deg
+
+    def _cached(self, tag: str, w: torch.Tensor, make):
+        key = (tag, w.data_ptr(), w._version, tuple(w.shape))
+        hit = self._wcache.get(key)
+        if hit is None:
+            if len(self._wcache) > 16:
+                self._wcache.clear()
+            hit = self._wcache[key] = make()
+        return hit
+
+    def in_weights(self, w: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """Edge weights in in-edge-CSR order."""
+        if w is None:
+            return None
+        if w.numel() != self.num_edges():
+            raise ValueError(f"edge weight has {w.numel()} entries, graph has {self.num_edges()} edges")
+        w = w.reshape(-1)
+        return self._cached("in", w, lambda: w.detach().to(torch.float32)[self.in_csr().perm.long()].contiguous())
+
+    def out_weights(self, w: Optional[torch.Tensor], mean: bool) -> Optional[torch.Tensor]:
+        """Edge weights in out-edge-CSR order; with ``mean`` each is pre-multiplied by
+        1/in_degree(dst) so the backward of (sum * norm) is one plain SpMM."""
+        csr = self.out_csr()
+        if w is None and not mean:
+            return None
+
+        def make():
+            base = (torch.ones(self.num_edges(), dtype=torch.float32, device=self.device) if w is None
+                    else w.detach().reshape(-1).to(torch.float32))[csr.perm.long()]
+            if mean:
+                base = base * self.inv_in_degree()[csr.indices.long()]
+            return base.contiguous()
+
+        if w is None:
+            key = ("out_unit_mean",)
+            hit = self._wcache.get(key)
+            if hit is None:
+                hit = self._wcache[key] = make()
+            return hit
+        return self._cached("out_mean" if mean else "out", w.reshape(-1), make)
+
+
+# ---- constructors mirroring dgl.graph / dgl.batch ------------------------------------------------
+def graph(data, num_nodes: Optional[int] = None, idtype=torch.int32, device=None) -> PageGraph:
+    """``dgl.graph((u, v), num_nodes=..., idtype=torch.int32)`` (builder.py:425)."""
+    u, v = data
+    u, v = torch.as_tensor(u), torch.as_tensor(v)
+    if num_nodes is None:
+        num_nodes = int(max(u.max().item(), v.max().item())) + 1 if u.numel() else 0
+    return PageGraph(u, v, num_nodes, device=device)
+
+
+def from_edge_index(edge_index: torch.Tensor, num_nodes: int, edge_weight: Optional[torch.Tensor] = None) -> PageGraph:
+    """Tensor-level form named by BASELINE.json: ``edge_index[2, E]`` rows = (src; dst)."""
+    g = PageGraph(edge_index[0], edge_index[1], num_nodes)
+    if edge_weight is not None:
+        g.edata["feat"] = edge_weight
+    return g
+
+
+def batch(graphs: Sequence[PageGraph]) -> PageGraph:
+    """Block-diagonal union of page graphs (``dgl.batch``: model_train.py:246,297).  Node and edge
+    data present in every graph are concatenated.  Cached CSRs of the parts are concatenated with
+    offsets instead of re-sorting (rows of a block-diagonal union are the parts' rows)."""
+    graphs = list(graphs)
+    if not graphs:
+        raise ValueError("batch() needs at least one graph")
+    dev = graphs[0].device
+    n_off, e_off = [0], [0]
+    for g in graphs:
+        n_off.append(n_off[-1] + g.num_nodes())
+        e_off.append(e_off[-1] + g.num_edges())
+    src = torch.cat([g._src + n_off[i] for i, g in enumerate(graphs)])
+    dst = torch.cat([g._dst + n_off[i] for i, g in enumerate(graphs)])
+    out = PageGraph(src, dst, n_off[-1], device=dev)
+    out.batch_num_nodes_ = [n for g in graphs for n in g.batch_num_nodes_]
+    out.batch_num_edges_ = [n for g in graphs for n in g.batch_num_edges_]
+    for frame, name in ((lambda g: g.ndata, "ndata"), (lambda g: g.edata, "edata")):
+        keys = set(frame(graphs[0]).keys())
+        for g in graphs[1:]:
+            keys &= set(frame(g).keys())
+        for k in keys:
+            getattr(out, name)[k] = torch.cat([frame(g)[k] for g in graphs], dim=0)
+
+    def cat_csr(get):
+        parts = [get(g) for g in graphs]
+        if any(p is None for p in parts):
+            return None
+        indptr = torch.cat([parts[0].indptr[:1]] + [p.indptr[1:] + e_off[i] for i, p in enumerate(parts)])
+        indices = torch.cat([p.indices + n_off[i] for i, p in enumerate(parts)])
+        perm = torch.cat([p.perm + e_off[i] for i, p in enumerate(parts)])
+        return CSR(indptr.to(torch.int32), indices.to(torch.int32), perm.to(torch.int32))
+
+    out._in_csr = cat_csr(lambda g: g._in_csr)
+    out._out_csr = cat_csr(lambda g: g._out_csr)
+    return out
+
+
+def unbatch_sizes(g: PageGraph) -> List[int]:
+    return list(g.batch_num_nodes_)

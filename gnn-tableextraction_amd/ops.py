@@ -1,0 +1,336 @@
+"""Thin Python wrappers + torch.autograd.Functions over the C ABI (include/gte.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every arithmetic step of the
+hot path runs in libgte_hip.so.  Nothing in this file has a CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr, require_device
+
+_ws_cache = {}
+
+# ---- optional per-kernel timing (bench.py): HIP events on the launch stream around tagged calls ----
+_timers = None          # None = off; dict tag -> {"events": [(start, end)], "work": float}
+
+
+def enable_kernel_timers(on: bool = True) -> None:
+    global _timers
+    _timers = {} if on else None
+
+
+def kernel_timer_report():
+    """tag -> (launches, total_ms, total_work) ; synchronises."""
+    out = {}
+    if _timers:
+        torch.cuda.synchronize()
+        for tag, rec in _timers.items():
+            ms = sum(s.elapsed_time(e) for s, e in rec["events"])
+            out[tag] = (len(rec["events"]), ms, rec["work"])
+    return out
+
+
+class _timed:
+    __slots__ = ("tag", "work", "ev")
+
+    def __init__(self, tag, work):
+        self.tag, self.work = tag, work
+
+    def __enter__(self):
+        if _timers is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()          # torch's current stream == the stream the kernel is launched on
+        return self
+
+    def __exit__(self, *exc):
+        if _timers is not None:
+            self.ev[1].record()
+            rec = _timers.setdefault(self.tag, {"events": [], "work": 0.0})
+            rec["events"].append(self.ev)
+            rec["work"] += self.work
+        return False
+
+
+def _workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
+    """Grow-only per-(device, stream, tag) scratch buffer (caller-provided workspace of the ABI)."""
+    key = (device.index, current_stream(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _row_major(t: torch.Tensor) -> torch.Tensor:
+    """2-D tensor whose rows are contiguous (arbitrary row stride is fine for the ABI)."""
+    if t.dim() != 2:
+        raise ValueError("expected a 2-D tensor")
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+# --------------------------------------------------------------------------------------------------
+# graph preparation
+# --------------------------------------------------------------------------------------------------
+def coo_to_csr(key: torch.Tensor, other: torch.Tensor, n: int, eweight: Optional[torch.Tensor] = None,
+               row_scale: Optional[torch.Tensor] = None):
+    """Stable sort of the COO by ``key`` on the device -> (indptr, indices, perm[, wout])."""
+    require_device(key, "coo_to_csr")
+    lib = _lib.load()
+    e = key.numel()
+    dev = key.device
+    key = key.to(torch.int32).contiguous()
+    other = other.to(torch.int32).contiguous()
+    indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    indices = torch.empty(e, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    wout = torch.empty(e, dtype=torch.float32, device=dev) if (eweight is not None or row_scale is not None) else None
+    nbytes = lib.gte_coo_to_csr_workspace_bytes(n, e)
+    ws = _workspace(nbytes, dev, "csr")
+    check(lib.gte_coo_to_csr(ptr(key), ptr(other), ptr(eweight), ptr(row_scale), n, e, ptr(indptr), ptr(indices),
+                             ptr(perm), ptr(wout), ptr(ws), ws.numel(), current_stream()), "gte_coo_to_csr")
+    return (indptr, indices, perm) if wout is None else (indptr, indices, perm, wout)
+
+
+def inv_degree(indptr: torch.Tensor) -> torch.Tensor:
+    require_device(indptr, "inv_degree")
+    n = indptr.numel() - 1
+    out = torch.empty(n, dtype=torch.float32, device=indptr.device)
+    check(_lib.load().gte_inv_degree(ptr(indptr), ptr(out), n, current_stream()), "gte_inv_degree")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# raw kernels
+# --------------------------------------------------------------------------------------------------
+def spmm_csr(indptr, indices, weight, x: torch.Tensor, n_rows: int, mean: bool = False,
+             out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """out[v] = scale_v * sum_e w[e] * x[indices[e]] over row v of the CSR (fp32 or bf16 features)."""
+    require_device(x, "spmm_csr")
+    lib = _lib.load()
+    x = _row_major(x)
+    if x.dtype == torch.float32:
+        dt = _lib.GTE_F32
+    elif x.dtype == torch.bfloat16:
+        dt = _lib.GTE_BF16
+    else:
+        raise TypeError(f"spmm_csr: unsupported dtype {x.dtype}")
+    f = x.shape[1]
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an output tensor")
+        out = torch.empty((n_rows, f), dtype=x.dtype, device=x.device)
+    fn = lib.gte_spmm_csr_accumulate if accumulate else lib.gte_spmm_csr
+    nnz_bytes = 8.0 * indices.numel() if weight is not None else 4.0 * indices.numel()
+    with _timed("spmm_csr", 2.0 * n_rows * f * x.element_size() + nnz_bytes + 4.0 * (n_rows + 1)):
+        check(fn(ptr(indptr), ptr(indices), ptr(weight), ptr(x), _ld(x), ptr(out), _ld(out), n_rows, f, dt,
+                 _lib.REDUCE_MEAN if mean else _lib.REDUCE_SUM, current_stream()), "gte_spmm_csr")
+    return out
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
+         out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """C = op(A) op(B) in fp32 on the MFMA path.  ``a``/``b`` are the STORED matrices."""
+    require_device(a, "gemm")
+    lib = _lib.load()
+    a, b = _row_major(a), _row_major(b)
+    m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    kb, n = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if k != kb:
+        raise ValueError(f"gemm: inner dimensions differ ({k} vs {kb})")
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    nbytes = lib.gte_gemm_workspace_bytes(m, n, k)
+    ws = _workspace(nbytes, a.device, "gemm")
+    with _timed("gemm_tn" if trans_a else "gemm_nn", 2.0 * m * n * k):
+        check(lib.gte_gemm_f32(int(trans_a), int(trans_b), m, n, k, ptr(a), _ld(a), ptr(b), _ld(b), ptr(out),
+                               _ld(out), int(accumulate), ptr(ws), ws.numel(), current_stream()), "gte_gemm_f32")
+    return out
+
+
+def sage_linear_fwd(a1, a2, weight, bias, gamma, beta, eps: float, relu: bool, save_for_backward: bool):
+    """y = relu?(LN?([a1|a2] W^T + b)); returns (y, z_save, stats)."""
+    lib = _lib.load()
+    a1 = _row_major(a1)
+    m, k1 = a1.shape
+    k2 = 0
+    if a2 is not None:
+        a2 = _row_major(a2)
+        k2 = a2.shape[1]
+    weight = _row_major(weight)
+    n_out = weight.shape[0]
+    dev = a1.device
+    y = torch.empty((m, n_out), dtype=torch.float32, device=dev)
+    ln = gamma is not None
+    z = torch.empty((m, n_out), dtype=torch.float32, device=dev) if (ln and save_for_backward) else None
+    stats = torch.empty(2 * m, dtype=torch.float32, device=dev) if (ln and save_for_backward) else None
+    # two ABI calls (linear, then LayerNorm/ReLU) so each kernel can be timed on its own
+    lin_out = z if z is not None else y
+    with _timed("gemm_nt", 2.0 * m * (k1 + k2) * n_out):
+        check(lib.gte_sage_linear_fwd(ptr(a1), _ld(a1), k1, ptr(a2), 0 if a2 is None else _ld(a2), k2,
+                                      ptr(weight), _ld(weight), ptr(bias), None, None, float(eps),
+                                      int(relu and not ln), None, 0, None, ptr(lin_out), _ld(lin_out), m, n_out,
+                                      current_stream()), "gte_sage_linear_fwd")
+    if ln:
+        check(lib.gte_ln_relu_fwd(ptr(lin_out), _ld(lin_out), ptr(gamma), ptr(beta), float(eps), int(relu),
+                                  ptr(y), _ld(y), ptr(stats), m, n_out, current_stream()), "gte_ln_relu_fwd")
+    return y, z, stats
+
+
+def ln_relu_bwd(dy, z, stats, gamma, beta, relu: bool, dgamma, dbeta, dbias) -> torch.Tensor:
+    lib = _lib.load()
+    dy = _row_major(dy)
+    m, n = dy.shape
+    dz = torch.empty((m, n), dtype=torch.float32, device=dy.device)
+    nbytes = lib.gte_ln_relu_bwd_workspace_bytes(m, n)
+    ws = _workspace(nbytes, dy.device, "lnbwd")
+    check(lib.gte_ln_relu_bwd(ptr(dy), _ld(dy), ptr(z), 0 if z is None else _ld(z), ptr(stats), ptr(gamma), ptr(beta),
+                              int(relu), ptr(dz), _ld(dz), ptr(dgamma), ptr(dbeta), ptr(dbias), m, n, ptr(ws),
+                              ws.numel(), current_stream()), "gte_ln_relu_bwd")
+    return dz
+
+
+def weighted_ce(logits: torch.Tensor, labels: torch.Tensor, class_weight: Optional[torch.Tensor] = None,
+                want_grad: bool = True, grad_scale: float = 1.0):
+    """Returns (out3 = [loss, sum_w, n_correct] on the device, dlogits or None)."""
+    require_device(logits, "weighted_ce")
+    lib = _lib.load()
+    logits = _row_major(logits)
+    n, c = logits.shape
+    if labels.dtype == torch.float32:
+        lf = 1
+    elif labels.dtype == torch.int64:
+        lf = 0
+    else:
+        labels, lf = labels.to(torch.int64), 0
+    labels = labels.contiguous()
+    out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+    dl = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_grad else None
+    ws = _workspace(lib.gte_weighted_ce_workspace_bytes(n), logits.device, "ce")
+    check(lib.gte_weighted_ce(ptr(logits), _ld(logits), ptr(labels), lf, ptr(class_weight), n, c, float(grad_scale),
+                              ptr(dl), 0 if dl is None else _ld(dl), ptr(out3), ptr(ws), ws.numel(), current_stream()),
+          "gte_weighted_ce")
+    return out3, dl
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999,
+              eps: float = 1e-8, weight_decay: float = 0.0, grad_scale: float = 1.0) -> None:
+    require_device(param, "adam_step")
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise ValueError("adam_step: flat contiguous fp32 buffers required")
+    check(_lib.load().gte_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr),
+                                    float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                    float(grad_scale), current_stream()), "gte_adam_step")
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd: aggregation  (models.py:53-54 + DGL GSpMM.backward)
+# --------------------------------------------------------------------------------------------------
+class _Aggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, graph, w, mean):
+        csr = graph.in_csr()
+        ctx.graph, ctx.w, ctx.mean = graph, w, mean
+        return spmm_csr(csr.indptr, csr.indices, graph.in_weights(w), h, graph.num_nodes(), mean=mean)
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.graph
+        rcsr = g.out_csr()
+        # d h[u] = sum_{e: u->v} w_e * norm_v * dout[v]   (norm folded into the out-edge weights)
+        dh = spmm_csr(rcsr.indptr, rcsr.indices, g.out_weights(ctx.w, ctx.mean), dout.contiguous(), g.num_nodes())
+        return dh, None, None, None
+
+
+def aggregate(graph, h: torch.Tensor, w: Optional[torch.Tensor] = None, mean: bool = False) -> torch.Tensor:
+    """``update_all(u_mul_e | copy_u, sum | mean)`` on a PageGraph, differentiable in ``h``."""
+    require_device(h, "aggregate")
+    return _Aggregate.apply(h, graph, w, mean)
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd: one whole GcnSAGELayer  (models.py:46-72)
+# --------------------------------------------------------------------------------------------------
+class _SageLayer(torch.autograd.Function):
+    """y = act(LN([h | (A_w h) * norm] W^T + b)) with every piece in HIP:
+    aggregation -> split-weight MFMA GEMM (no concat) -> LayerNorm/ReLU; hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, gamma, beta, graph, w, relu, eps, use_pp):
+        h = _row_major(h)
+        need_grad = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (h, weight, bias, gamma, beta))
+        ahn = None
+        if not use_pp:
+            csr = graph.in_csr()
+            ahn = spmm_csr(csr.indptr, csr.indices, graph.in_weights(w), h, graph.num_nodes(), mean=True)
+        y, z, stats = sage_linear_fwd(h, ahn, weight, bias, gamma, beta, eps, relu, need_grad)
+        ctx.graph, ctx.w, ctx.relu, ctx.use_pp = graph, w, relu, use_pp
+        ctx.has_bias, ctx.has_ln = bias is not None, gamma is not None
+        ctx.save_for_backward(h, ahn, weight, gamma, beta, z, stats, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, ahn, weight, gamma, beta, z, stats, y = ctx.saved_tensors
+        need_h, need_w, need_b, need_g, need_be = ctx.needs_input_grad[:5]
+        n_out, f = weight.shape[0], h.shape[1]
+        dev = h.device
+        dgamma = torch.zeros(n_out, dtype=torch.float32, device=dev) if ctx.has_ln else None
+        dbeta = torch.zeros(n_out, dtype=torch.float32, device=dev) if ctx.has_ln else None
+        dbias = torch.zeros(n_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        # (1) LayerNorm/ReLU backward (+ bias/gamma/beta column sums); relu without LN masks on y
+        dz = ln_relu_bwd(dy, z if ctx.has_ln else y, stats, gamma, beta, ctx.relu, dgamma, dbeta, dbias)
+        # (2) dW = dZ^T [h | ahn]  (reduction over the nodes, split-K inside)
+        dweight = None
+        if need_w:
+            dweight = torch.empty_like(weight)
+            gemm(dz, h, trans_a=True, out=dweight[:, :f])
+            if ahn is not None:
+                gemm(dz, ahn, trans_a=True, out=dweight[:, f:])
+        # (3) dh = dZ W_self + A_w^T (norm * (dZ W_neigh))
+        dh = None
+        if need_h:
+            dh = gemm(dz, weight[:, :f])
+            if ahn is not None:
+                dahn = gemm(dz, weight[:, f:])
+                g = ctx.graph
+                rcsr = g.out_csr()
+                spmm_csr(rcsr.indptr, rcsr.indices, g.out_weights(ctx.w, True), dahn, g.num_nodes(), out=dh,
+                         accumulate=True)
+        return dh, dweight, dbias, dgamma, dbeta, None, None, None, None, None
+
+
+def sage_layer(graph, h, weight, bias=None, gamma=None, beta=None, edge_weight=None, relu: bool = False,
+               eps: float = 1e-5, use_pp: bool = False) -> torch.Tensor:
+    require_device(h, "sage_layer")
+    return _SageLayer.apply(h, weight, bias, gamma, beta, graph, edge_weight, relu, eps, use_pp)
+
+
+class _WeightedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, class_weight):
+        out3, dl = weighted_ce(logits, labels, class_weight, want_grad=logits.requires_grad)
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(out3)
+        return out3[0], out3
+
+    @staticmethod
+    def backward(ctx, dloss, _d3):
+        (dl,) = ctx.saved_tensors
+        return dl * dloss, None, None
+
+
+def cross_entropy(logits, labels, class_weight=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(loss, out3) -- ``nn.CrossEntropyLoss(weight)(logits, labels.long())`` (model_train.py:171,327)."""
+    return _WeightedCE.apply(logits, labels, class_weight)

@@ -1,0 +1,162 @@
+/* gte.h -- C ABI of libgte_hip.so: the MI355X (gfx950) hot path of GNN-TableExtraction.
+ *
+ * The reference (AILab-UniFI/GNN-TableExtraction) has no FFI: its boundary for this path
+ * is a Python nn.Module API (src/components/graphs/models.py:15-116) that reaches the
+ * arithmetic through DGL (update_all / gSpMM) and PyTorch (Linear, LayerNorm, ReLU,
+ * CrossEntropyLoss, Adam).  Each entry point below replaces one of those call sites; the
+ * reference file:line it replaces is cited on the declaration.  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no C++/torch types, no exceptions.
+ *   - every pointer is a BORROWED DEVICE pointer (hipMalloc'ed by the caller, e.g. a torch
+ *     tensor's data_ptr()); the caller keeps it alive until the stream has drained.
+ *   - outputs and workspaces are pre-allocated by the caller; nothing is allocated inside
+ *     (graph-capture safe).  Workspace sizes come from the *_workspace_bytes() queries.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every launch
+ *     goes to that stream; no call synchronises.
+ *   - return 0 on success, a negative gte_status otherwise; gte_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - re-entrant and thread-safe (autograd calls backward from another thread).
+ *   - "ld*" arguments are leading dimensions in ELEMENTS (row stride); rows need only be
+ *     4-byte aligned (F = 831 is a first-class shape), 16-byte alignment is faster.
+ */
+#ifndef GTE_H_
+#define GTE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTE_VERSION 100 /* major*10000 + minor*100 + patch */
+
+enum gte_status {
+    GTE_OK = 0,
+    GTE_ERR_INVALID_ARGUMENT = -1,
+    GTE_ERR_LAUNCH = -2,
+    GTE_ERR_WORKSPACE_TOO_SMALL = -3,
+    GTE_ERR_UNSUPPORTED = -4,
+};
+
+enum gte_reduce { GTE_REDUCE_SUM = 0, GTE_REDUCE_MEAN = 1 }; /* MEAN: sum * 1/in_degree, 0 if none */
+enum gte_dtype { GTE_F32 = 0, GTE_BF16 = 1 };
+
+int gte_version(void);
+const char* gte_last_error(void);
+/* Device facts the host side sizes launches with: compute units, wave size, LDS bytes/CU. */
+int gte_device_info(int* compute_units, int* wave_size, int* lds_bytes, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------------
+ * A6 / A9  neighbour aggregation (CSR gather SpMM)
+ * replaces  models.py:53-54  g.update_all(fn.u_mul_e('h','feat','m'), fn.sum('m','h'))
+ *           models.py:146-149 (fn.mean reducer)  and  models.py:74-78 get_norm (REDUCE_MEAN
+ *           folds norm = 1/in_degree, inf->0, into the epilogue; in_degree = indptr[v+1]-indptr[v])
+ *   out[v, 0:F] = scale_v * sum_{e in [indptr[v], indptr[v+1])} w[e] * x[indices[e], 0:F]
+ * The same entry point run on the out-edge CSR is the backward of A6 (A7, DGL GSpMM.backward).
+ * indptr: int32[n_rows+1]; indices: int32[nnz] (row ids of x); eweight: f32[nnz] or NULL (=1.0).
+ * dtype GTE_BF16: x/out are bf16 (uint16 storage), accumulation in f32.
+ * ---------------------------------------------------------------------------------------- */
+int gte_spmm_csr(const int32_t* indptr, const int32_t* indices, const float* eweight,
+                 const void* x, int64_t ldx, void* out, int64_t ldo,
+                 int64_t n_rows, int64_t n_feat, int dtype, int reduce, void* stream);
+
+/* Same contraction, but ACCUMULATING into out (out += ...): lets the backward add the
+ * transpose-aggregated gradient onto the self-path gradient without a temporary. */
+int gte_spmm_csr_accumulate(const int32_t* indptr, const int32_t* indices, const float* eweight,
+                            const void* x, int64_t ldx, void* out, int64_t ldo,
+                            int64_t n_rows, int64_t n_feat, int dtype, int reduce, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph preparation (what DGL does lazily per batched graph before gSpMM / its backward)
+ * replaces  dgl.graph((u,v)) COO->CSC build (builder.py:425) and the reverse-CSR build DGL
+ *           performs for GSpMM.backward; SURVEY 8(f) N1.
+ * gte_coo_to_csr: stable counting sort of E edges by `key` (destination for the in-edge CSR,
+ *   source for the out-edge CSR).  Writes indptr[n+1], indices[E] = other[perm], perm[E]
+ *   (edge ids in row order; within a row ascending edge id => fixed summation order), and, if
+ *   eweight != NULL, wout[E] = eweight[perm] * (scale_by_indeg ? 1/in_degree(dst) : 1).
+ * workspace: gte_coo_to_csr_workspace_bytes(n, E).
+ * ---------------------------------------------------------------------------------------- */
+int64_t gte_coo_to_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int gte_coo_to_csr(const int32_t* key, const int32_t* other, const float* eweight,
+                   const float* row_scale /* f32[n] or NULL: multiplies wout by row_scale[other] */,
+                   int64_t n_nodes, int64_t n_edges,
+                   int32_t* indptr, int32_t* indices, int32_t* perm, float* wout,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+/* inv_deg[v] = 1/(indptr[v+1]-indptr[v]) or 0  (models.py:74-78 as a standalone vector) */
+int gte_inv_degree(const int32_t* indptr, float* inv_deg, int64_t n_nodes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A8  per-node transform: split-weight linear + bias + LayerNorm + ReLU, fp32 MFMA
+ * replaces  models.py:69-72 (torch.cat((h, ah*norm),1)), :63 nn.Linear(2F,out), :64 nn.LayerNorm,
+ *           :65-66 activation.
+ *   z = a1[M,k1] * W[:, 0:k1]^T + a2[M,k2] * W[:, k1:k1+k2]^T + bias        (W: [n_out, k1+k2])
+ *   y = relu?( LN?(z) ) ; LN over n_out with eps, affine (gamma, beta)
+ * a2 may be NULL (k2 = 0; use_pp=True path, models.py:49).  gamma == NULL => no LayerNorm.
+ * z_save (nullable): pre-LayerNorm z for the backward; stats (nullable): f32[2*M] = mean, rstd.
+ * ---------------------------------------------------------------------------------------- */
+int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1,
+                        const float* a2, int64_t lda2, int64_t k2,
+                        const float* W, int64_t ldw, const float* bias,
+                        const float* gamma, const float* beta, float eps, int relu,
+                        float* z_save, int64_t ldz, float* stats,
+                        float* y, int64_t ldy, int64_t M, int64_t n_out, void* stream);
+
+/* LayerNorm + ReLU alone (row-wise over n_out):  y = relu?(gamma * (z - mean) * rstd + beta).
+ * replaces models.py:64-66 when the caller ran the linear part separately.  In place (y == z) is
+ * allowed.  stats (nullable): f32[2*M] = mean, rstd. */
+int gte_ln_relu_fwd(const float* z, int64_t ldz, const float* gamma, const float* beta, float eps, int relu,
+                    float* y, int64_t ldy, float* stats, int64_t M, int64_t n_out, void* stream);
+
+/* Backward of LayerNorm+ReLU (+ bias grad):  given dy, the saved z and stats, writes
+ *   dz[M,n_out], and accumulates column sums into dgamma, dbeta, dbias (f32[n_out], nullable).
+ * With gamma == NULL it is the backward of (relu?)(z) only.  dz may alias dy only when gamma == NULL
+ * or n_out <= 64 (the row means re-read dy).
+ * workspace: gte_ln_relu_bwd_workspace_bytes(M, n_out). */
+int64_t gte_ln_relu_bwd_workspace_bytes(int64_t M, int64_t n_out);
+int gte_ln_relu_bwd(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* stats,
+                    const float* gamma, const float* beta, int relu,
+                    float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dbias,
+                    int64_t M, int64_t n_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* General fp32 MFMA GEMM used by the backward:  C[M,N] (+)= op(A)[M,K] * op(B)[K,N]
+ *   trans_a = 0: A is [M,K] row-major (lda);  1: A is stored [K,M] (lda) and used transposed
+ *   trans_b = 0: B is [K,N] row-major (ldb);  1: B is stored [N,K] (ldb) and used transposed
+ * accumulate != 0 adds into C.  K may be huge (dW = dZ^T X reduces over the nodes): the kernel
+ * splits K across workgroups and reduces the partial slabs deterministically in `workspace`
+ * (gte_gemm_workspace_bytes).  replaces autograd of nn.Linear (models.py:63). */
+int64_t gte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gte_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                 const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc, int accumulate,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A10  loss and optimiser
+ * gte_weighted_ce: replaces nn.CrossEntropyLoss(weight)(logits, labels.long()) forward+backward
+ *   (model_train.py:171,327) and the accuracy count (:328).
+ *   loss = sum_i w[y_i] * nll_i / sum_i w[y_i]   (w == NULL => plain mean)
+ *   dlogits (nullable) = grad_scale * d loss / d logits.
+ *   out3: f32[3] = {loss, sum of weights, #correct (argmax == label)}.
+ *   labels: int64[n]  (labels_f32 != 0: float32 holding integers, loader.py:350-354).
+ * workspace: gte_weighted_ce_workspace_bytes(n).
+ * ---------------------------------------------------------------------------------------- */
+int64_t gte_weighted_ce_workspace_bytes(int64_t n_nodes);
+int gte_weighted_ce(const float* logits, int64_t ld, const void* labels, int labels_f32,
+                    const float* class_weight, int64_t n_nodes, int n_classes, float grad_scale,
+                    float* dlogits, int64_t lddl, float* out3,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* gte_adam_step: replaces torch.optim.Adam(lr, weight_decay).step() (model_train.py:168,332) on one
+ * flat fp32 buffer: g' = grad_scale*g + weight_decay*p (L2-coupled, NOT AdamW);
+ * m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+ * `step` is t (1-based).  lr is read from the host value. */
+int gte_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                  float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTE_H_ */

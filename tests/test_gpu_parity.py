@@ -1,0 +1,383 @@
+"""GPU parity: every HIP entry point (through the C ABI) against the CPU oracle and the golden
+vectors generated from the reference's models.py.  Run with ``-m gpu`` on an MI355X.
+
+Tolerances: forward logits 1e-5 abs/rel in fp32 (BASELINE.json north_star); index/integer outputs
+bit-exact; bf16 aggregation 2e-2 (storage rounding), fp32 accumulate.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gnn_tableextraction_amd as gte
+from gnn_tableextraction_amd import graph as G, ops
+from gnn_tableextraction_amd.data import synthetic as S
+from oracle import gcnsage_cpu as oc
+from tests.conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+GCN_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                   if not os.path.basename(p).startswith("meansage"))
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(a)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def test_device_is_gfx950():
+    import ctypes
+    lib = gte._lib.load()
+    cu, wave, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    name = ctypes.create_string_buffer(64)
+    assert lib.gte_device_info(ctypes.byref(cu), ctypes.byref(wave), ctypes.byref(lds), name, 64) == 0
+    assert wave.value == 64 and b"gfx950" in name.value and cu.value >= 200
+
+
+# ---------------------------------------------------------------- graph preparation (bit-exact)
+@pytest.mark.parametrize("n,e", [(1, 0), (7, 1), (50, 400), (5000, 60000), (100000, 1200000)])
+def test_coo_to_csr_bit_exact(n, e):
+    rng = np.random.default_rng(n + e)
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    w = rng.random(e).astype(np.float32)
+    ip, ix, wo, perm = oc.coo_to_in_csr(src, dst, n, w)
+    if e == 0:
+        g = G.PageGraph(src, dst, n, device=DEV)
+        assert g.in_csr().indptr.cpu().tolist() == [0, 0]
+        return
+    indptr, indices, p, wout = ops.coo_to_csr(dev(dst, torch.int32), dev(src, torch.int32), n, dev(w))
+    np.testing.assert_array_equal(indptr.cpu().numpy(), ip)
+    np.testing.assert_array_equal(indices.cpu().numpy(), ix)
+    np.testing.assert_array_equal(p.cpu().numpy(), perm)
+    np.testing.assert_array_equal(wout.cpu().numpy(), wo)
+    inv = ops.inv_degree(indptr).cpu().numpy()
+    np.testing.assert_array_equal(inv, oc.in_degree_norm(ip)[:, 0])
+
+
+# ---------------------------------------------------------------- aggregation
+@pytest.mark.parametrize("f", [1, 3, 9, 13, 16, 63, 64, 100, 256, 512, 831, 1100])
+@pytest.mark.parametrize("mean", [False, True])
+def test_spmm_f32_matches_oracle(f, mean):
+    rng = np.random.default_rng(f)
+    n, e = 700, 5000
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    dst[dst == 5] = 6                                    # node 5: in-degree 0
+    w = rng.random(e).astype(np.float32)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    g = oc.OracleGraph(src, dst, n, w)
+    want = oc.spmm_csr_numpy(g.indptr, g.indices, g.weight, x, mean=False)
+    if mean:
+        want = want * g.norm
+    got = ops.spmm_csr(dev(g.indptr), dev(g.indices), dev(g.weight), dev(x), n, mean=mean).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+    assert np.all(got[5] == 0)
+    # unit weights (NULL pointer) == copy_u
+    want1 = oc.spmm_csr_numpy(g.indptr, g.indices, None, x)
+    got1 = ops.spmm_csr(dev(g.indptr), dev(g.indices), None, dev(x), n).cpu().numpy()
+    np.testing.assert_allclose(got1, want1, rtol=2e-6, atol=2e-6)
+
+
+def test_spmm_strided_rows_and_accumulate():
+    rng = np.random.default_rng(1)
+    n, e, f = 300, 2000, 37
+    g = oc.OracleGraph(rng.integers(0, n, e), rng.integers(0, n, e), n, rng.random(e).astype(np.float32))
+    big = dev(rng.standard_normal((n, 64)).astype(np.float32))
+    x = big[:, 3:3 + f]                                   # ld = 64, base not 16-byte aligned
+    want = oc.spmm_csr_numpy(g.indptr, g.indices, g.weight, x.cpu().numpy())
+    out = torch.full((n, 50), 7.0, device=DEV)
+    ops.spmm_csr(dev(g.indptr), dev(g.indices), dev(g.weight), x, n, out=out[:, 5:5 + f], accumulate=True)
+    np.testing.assert_allclose(out[:, 5:5 + f].cpu().numpy(), want + 7.0, rtol=2e-6, atol=2e-6)
+    assert torch.all(out[:, :5] == 7.0) and torch.all(out[:, 5 + f:] == 7.0)   # nothing outside the view
+
+
+def test_spmm_is_bit_reproducible_and_degree_heavy_rows():
+    rng = np.random.default_rng(2)
+    n, f = 400, 256
+    dst = np.concatenate([np.zeros(3000, np.int64), rng.integers(0, n, 2000)])     # row 0: 3000 in-edges
+    src = rng.integers(0, n, len(dst))
+    w = rng.random(len(dst)).astype(np.float32)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    g = oc.OracleGraph(src, dst, n, w)
+    a = ops.spmm_csr(dev(g.indptr), dev(g.indices), dev(g.weight), dev(x), n)
+    b = ops.spmm_csr(dev(g.indptr), dev(g.indices), dev(g.weight), dev(x), n)
+    assert torch.equal(a, b)
+    want = oc.spmm_csr_numpy(g.indptr, g.indices, g.weight, x.astype(np.float64))
+    np.testing.assert_allclose(a.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("f", [8, 13, 64, 256, 520])
+def test_spmm_bf16(f):
+    rng = np.random.default_rng(f)
+    n, e = 500, 4000
+    g = oc.OracleGraph(rng.integers(0, n, e), rng.integers(0, n, e), n, rng.random(e).astype(np.float32))
+    xb = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(torch.bfloat16)
+    want = oc.spmm_csr_numpy(g.indptr, g.indices, g.weight, xb.float().numpy(), mean=False) * g.norm
+    got = ops.spmm_csr(dev(g.indptr), dev(g.indices), dev(g.weight), xb.to(DEV), n, mean=True)
+    assert got.dtype == torch.bfloat16
+    np.testing.assert_allclose(got.float().cpu().numpy(), want, rtol=2e-2, atol=2e-2)
+
+
+def test_aggregate_autograd_matches_oracle_backward():
+    rng = np.random.default_rng(3)
+    n, e, f = 200, 1500, 48
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    w = rng.random(e).astype(np.float32)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    up = rng.standard_normal((n, f)).astype(np.float32)
+    og = oc.OracleGraph(src, dst, n, w)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    (oc._SpMM.apply(xt, og) * torch.from_numpy(og.norm) * torch.from_numpy(up)).sum().backward()
+    g = G.PageGraph(src, dst, n, device=DEV)
+    xd = dev(x).requires_grad_(True)
+    (ops.aggregate(g, xd, dev(w), mean=True) * dev(up)).sum().backward()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xt.grad.numpy(), rtol=1e-5, atol=1e-5)
+    # DGL surface: update_all
+    g.ndata["h"], g.edata["feat"] = dev(x), dev(w)
+    g.update_all(gte.function.u_mul_e("h", "feat", "m"), gte.function.sum("m", "h"))
+    want = oc.spmm_csr_numpy(og.indptr, og.indices, og.weight, x)
+    np.testing.assert_allclose(g.ndata["h"].cpu().numpy(), want, rtol=2e-6, atol=2e-6)
+
+
+# ---------------------------------------------------------------- MFMA GEMMs
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (33, 9, 70), (130, 256, 1662), (257, 100, 31), (9, 512, 5000),
+                                   (256, 831, 20000), (300, 218, 436)])
+def test_gemm_f32_all_layouts(ta, tb, m, n, k):
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
+    b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
+    want = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    got = ops.gemm(dev(a), dev(b), trans_a=ta, trans_b=tb).cpu().numpy()
+    tol = 2e-6 * np.sqrt(k) * 4 + 1e-6
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=tol * np.abs(want).max() / 4 + 1e-5)
+    c0 = rng.standard_normal((m, n)).astype(np.float32)
+    acc = ops.gemm(dev(a), dev(b), trans_a=ta, trans_b=tb, out=dev(c0).clone(), accumulate=True).cpu().numpy()
+    np.testing.assert_allclose(acc, want + c0, rtol=1e-5, atol=tol * np.abs(want).max() / 4 + 1e-5)
+
+
+def test_gemm_exact_small_integers_and_strided_views():
+    # integer-valued operands: fp32 MFMA must be exact -> catches any fragment/layout mix-up
+    rng = np.random.default_rng(5)
+    m, n, k = 70, 45, 99
+    a = rng.integers(-4, 5, (m, 128)).astype(np.float32)
+    b = rng.integers(-4, 5, (k, 64)).astype(np.float32)          # asymmetric on purpose
+    A = dev(a)[:, 7:7 + k]
+    B = dev(b)[:, 3:3 + n]
+    got = ops.gemm(A, B).cpu().numpy()
+    np.testing.assert_array_equal(got, a[:, 7:7 + k] @ b[:, 3:3 + n])
+    out = torch.zeros(m, 80, device=DEV)
+    ops.gemm(A, B, out=out[:, 10:10 + n])
+    np.testing.assert_array_equal(out[:, 10:10 + n].cpu().numpy(), got)
+    assert torch.all(out[:, :10] == 0) and torch.all(out[:, 10 + n:] == 0)
+
+
+@pytest.mark.parametrize("m,k1,k2,n_out,ln,relu", [
+    (500, 13, 13, 256, True, True), (500, 831, 831, 256, True, True), (333, 256, 256, 9, False, False),
+    (100, 64, 0, 32, True, False), (77, 20, 20, 218, True, True), (64, 50, 50, 1000, True, True),
+    (40, 16, 16, 24, False, True), (3000, 96, 96, 96, True, True)])
+def test_sage_linear_fwd_vs_torch(m, k1, k2, n_out, ln, relu):
+    rng = np.random.default_rng(m + n_out)
+    a1 = rng.standard_normal((m, k1)).astype(np.float32)
+    a2 = rng.standard_normal((m, k2)).astype(np.float32) if k2 else None
+    w = (rng.standard_normal((n_out, k1 + k2)) / np.sqrt(k1 + k2)).astype(np.float32)
+    b = rng.standard_normal(n_out).astype(np.float32)
+    gam = (1 + 0.1 * rng.standard_normal(n_out)).astype(np.float32) if ln else None
+    bet = (0.1 * rng.standard_normal(n_out)).astype(np.float32) if ln else None
+    cat = torch.from_numpy(a1 if a2 is None else np.concatenate([a1, a2], 1)).double()
+    z = torch.nn.functional.linear(cat, torch.from_numpy(w).double(), torch.from_numpy(b).double())
+    want = z
+    if ln:
+        want = torch.nn.functional.layer_norm(z, (n_out,), torch.from_numpy(gam).double(), torch.from_numpy(bet).double(), 1e-5)
+    if relu:
+        want = torch.relu(want)
+    y, zs, st = ops.sage_linear_fwd(dev(a1), None if a2 is None else dev(a2), dev(w), dev(b),
+                                    None if gam is None else dev(gam), None if bet is None else dev(bet),
+                                    1e-5, relu, save_for_backward=True)
+    np.testing.assert_allclose(y.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    if ln:
+        np.testing.assert_allclose(zs.cpu().numpy(), z.numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(st[:m].cpu().numpy(), z.mean(1).numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,n,ln,relu", [(300, 256, True, True), (100, 9, False, False), (513, 218, True, True),
+                                         (64, 40, False, True), (50, 1000, True, False), (31, 64, True, True)])
+def test_ln_relu_bwd_vs_torch_autograd(m, n, ln, relu):
+    rng = np.random.default_rng(m + n)
+    z = torch.from_numpy(rng.standard_normal((m, n))).double().requires_grad_(True)
+    gam = torch.from_numpy(1 + 0.1 * rng.standard_normal(n)).double().requires_grad_(True)
+    bet = torch.from_numpy(0.1 * rng.standard_normal(n)).double().requires_grad_(True)
+    dy = rng.standard_normal((m, n)).astype(np.float32)
+    y = torch.nn.functional.layer_norm(z, (n,), gam, bet, 1e-5) if ln else z
+    if relu:
+        y = torch.relu(y)
+    y.backward(torch.from_numpy(dy).double())
+    zd = dev(z.detach().float())
+    stats = None
+    if ln:
+        mu = z.detach().mean(1)
+        rstd = 1.0 / torch.sqrt(z.detach().var(1, unbiased=False) + 1e-5)
+        stats = dev(torch.cat([mu, rstd]).float())
+    dg = torch.zeros(n, device=DEV) if ln else None
+    db = torch.zeros(n, device=DEV) if ln else None
+    dbias = torch.zeros(n, device=DEV)
+    dz = ops.ln_relu_bwd(dev(dy), zd, stats, dev(gam.detach().float()) if ln else None,
+                         dev(bet.detach().float()) if ln else None, relu, dg, db, dbias)
+    np.testing.assert_allclose(dz.cpu().numpy(), z.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dbias.cpu().numpy(), z.grad.sum(0).numpy(), rtol=1e-4, atol=1e-4)
+    if ln:
+        np.testing.assert_allclose(dg.cpu().numpy(), gam.grad.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(db.cpu().numpy(), bet.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------- loss + optimiser
+@pytest.mark.parametrize("n,c,weighted,float_labels", [(1, 9, False, False), (1000, 9, True, False),
+                                                       (7777, 9, False, True), (300, 13, True, True)])
+def test_weighted_ce_vs_torch(n, c, weighted, float_labels):
+    rng = np.random.default_rng(n)
+    logits = (3 * rng.standard_normal((n, c))).astype(np.float32)
+    y = rng.integers(0, c, n)
+    cw = (0.5 + rng.random(c)).astype(np.float32) if weighted else None
+    lt = torch.from_numpy(logits).requires_grad_(True)
+    loss = torch.nn.CrossEntropyLoss(weight=None if cw is None else torch.from_numpy(cw))(lt, torch.from_numpy(y))
+    loss.backward()
+    labels = dev(y.astype(np.float32)) if float_labels else dev(y)
+    out3, dl = ops.weighted_ce(dev(logits), labels, None if cw is None else dev(cw))
+    o = out3.cpu().numpy()
+    assert abs(o[0] - loss.item()) < 1e-5 * max(1, abs(loss.item()))
+    assert int(o[2]) == int((logits.argmax(1) == y).sum())
+    np.testing.assert_allclose(dl.cpu().numpy(), lt.grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_adam_step_vs_torch_adam():
+    rng = np.random.default_rng(0)
+    n = 100003
+    p0 = rng.standard_normal(n).astype(np.float32)
+    pt = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=0.01, weight_decay=5e-4)
+    p, m, v = dev(p0.copy()), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 6):
+        g = rng.standard_normal(n).astype(np.float32)
+        pt.grad = torch.from_numpy(g.copy())
+        opt.step()
+        ops.adam_step(p, dev(g), m, v, step, lr=0.01, weight_decay=5e-4)
+    np.testing.assert_allclose(p.cpu().numpy(), pt.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------- whole model vs the reference's golden vectors
+def load_model(z):
+    n, f0, hid, ncls, nl, seed = (int(v) for v in z["meta"])
+    m = gte.GcnSAGE(f0, hid, ncls, nl, torch.nn.functional.relu, 0)
+    m.load_state_dict({k[len("state0."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("state0.")})
+    g = G.PageGraph(z["src"], z["dst"], n, device=DEV)
+    g.ndata["feat"] = dev(z["x"])
+    g.edata["feat"] = dev(z["w"])
+    return m.to(DEV), g
+
+
+@pytest.mark.parametrize("name", GCN_CASES)
+def test_gcnsage_forward_matches_reference_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    model, g = load_model(z)
+    hidden = []
+    hooks = [l.register_forward_hook(lambda m, i, o: hidden.append(o.detach().cpu().numpy())) for l in model.layers]
+    with torch.no_grad():
+        logits = model(g).cpu().numpy()
+    for h in hooks:
+        h.remove()
+    np.testing.assert_allclose(logits, z["logits"], rtol=1e-5, atol=1e-5)       # north_star tolerance
+    for i, h in enumerate(hidden):
+        np.testing.assert_allclose(h, z[f"hidden.{i}"], rtol=1e-5, atol=2e-5)
+    # tensor-level call signature: (node_feats, edge_index[, edge_weight]) -> logits
+    ei = torch.stack([dev(z["src"]), dev(z["dst"])])
+    with torch.no_grad():
+        l2 = model(dev(z["x"]), ei, dev(z["w"])).cpu().numpy()
+    np.testing.assert_array_equal(l2, logits)
+
+
+@pytest.mark.parametrize("name", GCN_CASES)
+def test_gcnsage_train_step_matches_reference_golden(name):
+    """loss.backward() through the HIP autograd nodes + torch.optim.Adam, exactly as model_train.py:320-332
+    drives the model; gradients and the post-step logits against the reference's."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    model, g = load_model(z)
+    cw = dev(z["class_weights"]) if "class_weights" in z.files else None
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    logits = model(g)
+    loss = torch.nn.CrossEntropyLoss(weight=cw)(logits, dev(z["y"]))
+    opt.zero_grad()
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    for k, p in model.named_parameters():
+        ref = z["grad." + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(ref).max())
+    opt.step()
+    with torch.no_grad():
+        after = model(g).cpu().numpy()
+    assert np.abs(after - z["logits_after_step"]).max() < 5e-3
+    # same step with the HIP loss: identical gradients
+    model2, g2 = load_model(z)
+    loss2, out3 = ops.cross_entropy(model2(g2), dev(z["y"]), cw)
+    loss2.backward()
+    assert abs(loss2.item() - float(z["loss"])) < 1e-5
+    for (k, p), (_, q) in zip(model.named_parameters(), model2.named_parameters()):
+        np.testing.assert_allclose(q.grad.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_meansage_matches_reference_golden():
+    z = np.load(os.path.join(GOLDEN_DIR, "meansage_120.npz"))
+    n, f0, hid, ncls, nl, _ = (int(v) for v in z["meta"])
+    m = gte.MeanSAGE(f0, hid, ncls, nl)
+    m.load_state_dict({k[len("state0."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("state0.")})
+    g = G.PageGraph(z["src"], z["dst"], n, device=DEV)
+    with torch.no_grad():
+        out = m.to(DEV)(g, dev(z["x"]), dev(z["w"])).cpu().numpy()
+    np.testing.assert_allclose(out, z["out"], rtol=1e-5, atol=1e-5)
+
+
+def test_batched_pages_vs_oracle_and_per_page_equivalence():
+    """100-page batch (BASELINE cfg2 shape, F0=13): forward vs the CPU oracle; and batching must not
+    change a page's logits (block-diagonal: no edge crosses pages)."""
+    pages = S.make_pages(100, in_feats=13)
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    torch.manual_seed(0)
+    model = gte.GcnSAGE(13, 256, 9, 3, torch.nn.functional.relu, 0)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    want = oc.gcnsage_forward(state, oc.OracleGraph(src, dst, int(off[-1]), w), torch.from_numpy(feat)).numpy()
+    model = model.to(DEV)
+    gs = []
+    for p in pages:
+        g = G.PageGraph(p.src, p.dst, p.num_nodes, device=DEV)
+        g.ndata["feat"], g.edata["feat"] = dev(p.feat), dev(p.weight)
+        gs.append(g)
+    with torch.no_grad():
+        got = model(G.batch(gs)).cpu().numpy()
+        one = model(gs[7]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(one, got[off[7]:off[8]])          # bitwise: same row-local summation order
+
+
+def test_large_graph_linearity_and_permutation_properties():
+    """Size-independent properties at a size the CPU oracle would not finish quickly (200k nodes, F=512):
+    linearity A(ax+by) = aA(x)+bA(y); all-ones input -> row sums of weights; mean of unit weights == 1."""
+    rng = np.random.default_rng(11)
+    n, deg, f = 200_000, 12, 512
+    src = rng.integers(0, n, n * deg)
+    dst = np.repeat(np.arange(n), deg)
+    w = rng.random(n * deg).astype(np.float32)
+    indptr, indices, perm, wout = ops.coo_to_csr(dev(dst, torch.int32), dev(src, torch.int32), n, dev(w))
+    x, y = torch.randn(n, f, device=DEV), torch.randn(n, f, device=DEV)
+    ax = ops.spmm_csr(indptr, indices, wout, x, n)
+    ay = ops.spmm_csr(indptr, indices, wout, y, n)
+    axy = ops.spmm_csr(indptr, indices, wout, 2.0 * x - 3.0 * y, n)
+    assert torch.allclose(axy, 2.0 * ax - 3.0 * ay, rtol=1e-4, atol=1e-4)
+    ones = ops.spmm_csr(indptr, indices, wout, torch.ones(n, 8, device=DEV), n)
+    rowsum = torch.from_numpy(np.add.reduceat(w, np.arange(0, n * deg, deg))).to(DEV)
+    assert torch.allclose(ones[:, 0], rowsum, rtol=1e-5, atol=1e-5)
+    m1 = ops.spmm_csr(indptr, indices, None, torch.ones(n, 16, device=DEV), n, mean=True)
+    assert torch.all(m1 == 1.0)
