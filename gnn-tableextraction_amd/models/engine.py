@@ -54,7 +54,7 @@ class TrainStep:
         self.model.train()
         self.flat_grad.zero_()
         logits = self.model(g)
-        loss, out3 = ops.cross_entropy(logits, labels, self.class_weights)
+        loss, out3 = self._loss(logits, labels)
         n_local = labels.shape[0]
         if self.distributed and n_global:
             loss = loss * (float(n_local) / float(n_global))
@@ -63,9 +63,16 @@ class TrainStep:
             import torch.distributed as dist
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         self.t += 1
+        self._optimizer_step()
+        return out3
+
+    # the two arithmetic pieces of the step; HIP here (tests of the DP logic override them on CPU)
+    def _loss(self, logits, labels):
+        return ops.cross_entropy(logits, labels, self.class_weights)
+
+    def _optimizer_step(self) -> None:
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.t, self.lr,
                       self.betas[0], self.betas[1], self.eps, self.weight_decay)
-        return out3
 
     # checkpoint-compatible with torch.optim.Adam's state_dict layout is handled by model_train.py
     def lr_scale(self, factor: float) -> None:

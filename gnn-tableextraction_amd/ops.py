@@ -268,8 +268,8 @@ class _SageLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, weight, bias, gamma, beta, graph, w, relu, eps, use_pp):
         h = _row_major(h)
-        need_grad = torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (h, weight, bias, gamma, beta))
+        # grad mode is off inside Function.forward: ask the ctx which inputs need a gradient
+        need_grad = any(ctx.needs_input_grad[:5])
         ahn = None
         if not use_pp:
             csr = graph.in_csr()
