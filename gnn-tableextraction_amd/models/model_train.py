@@ -1,0 +1,272 @@
+"""Training entry point on the MI355X HIP path: ``train(data, config, name_time=None)``.
+
+Same call, config keys, run name, checkpoint / weights / results-JSON layout as the reference's
+``src/models/model_train.py:44-457`` (with ``src/utils/training.py:14-49``), restated around the HIP
+engine: one flat parameter buffer, fused Adam, HIP cross-entropy, and -- when launched with
+torchrun on several GPUs -- pages sharded per step with one RCCL gradient all-reduce.
+What is NOT here, by design (SURVEY 8 scope): feature generation (``_generate_features`` at :242,
+:293) -- graphs arrive pre-built with ``ndata['feat']``; TensorBoard is optional.
+The reference falls back to the CPU when CUDA is missing (:128-130); this path refuses instead.
+"""
+from __future__ import annotations
+
+import json
+import os
+from math import inf
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import distributed as D
+from .. import graph as G
+from .. import ops
+from ..components.features.utils import calculate_hidden, get_in_feats_
+from ..components.graphs.models import GcnSAGE
+from ..utils.config import AttrDict, logs_from_config
+from ..utils.training import EarlyStopping
+from .engine import TrainStep
+
+TABLE_TCELL, TABLE_COLH = 10, 8          # Categories_names values used for the printed F1s (const.py:4-18)
+
+
+class _ScalarLog:
+    """SummaryWriter when tensorboard is installed, else a JSONL file with the same add_scalar calls."""
+
+    def __init__(self, path):
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            self.w, self.f = SummaryWriter(path), None
+        except Exception:
+            os.makedirs(path, exist_ok=True)
+            self.w, self.f = None, open(os.path.join(path, "scalars.jsonl"), "a")
+
+    def add_scalar(self, tag, value, step):
+        if self.w is not None:
+            self.w.add_scalar(tag, value, step)
+        else:
+            self.f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+            self.f.flush()
+
+
+def _class_weights(config, all_labels, n_classes):
+    if not config.TRAINING.class_weights:
+        return None
+    method = config.TRAINING.class_weights_method
+    if method == 'auto':                                   # model_train.py:106-112
+        from sklearn.utils import class_weight
+        wl = all_labels[all_labels != 4]
+        cw = class_weight.compute_class_weight(class_weight='balanced', classes=np.unique(wl), y=wl)
+        return np.insert(cw, 4, 0.1)
+    if method == 'default':                                # :113-116
+        return np.insert(np.asarray([1.] * 8), 6, 2.)
+    raise ValueError('please specify the "class_weights_method" attribute')
+
+
+def _hidden_width(config, in_feats, n_classes):
+    mode = config.TRAINING.mode_params
+    if mode not in ['fixed', 'scaled', 'half']:
+        raise ValueError(f'Mode {mode} not in list: check config file. Exit.')
+    if mode == 'fixed':
+        return config.MODES.fixed.h_layer_dim
+    if mode == 'scaled':
+        assert config.MODES.scaled.params_no is not None and config.TRAINING.n_layers is not None
+        return calculate_hidden(in_feats, n_classes, config.MODES.scaled.params_no, config.TRAINING.n_layers)
+    return in_feats / 2
+
+
+def adam_state_dict(step: TrainStep, model) -> dict:
+    """torch.optim.Adam.state_dict() layout from the flat buffers (checkpoint compatibility, :411-419)."""
+    state, off = {}, 0
+    for i, p in enumerate(q for q in model.parameters() if q.requires_grad):
+        n = p.numel()
+        state[i] = {'step': torch.tensor(float(step.t)),
+                    'exp_avg': step.exp_avg[off:off + n].view_as(p).detach().cpu().clone(),
+                    'exp_avg_sq': step.exp_avg_sq[off:off + n].view_as(p).detach().cpu().clone()}
+        off += n
+    return {'state': state, 'param_groups': [{'lr': step.lr, 'betas': step.betas, 'eps': step.eps,
+                                              'weight_decay': step.weight_decay, 'amsgrad': False,
+                                              'params': list(range(len(state)))}]}
+
+
+def load_adam_state_dict(step: TrainStep, model, sd: dict) -> None:
+    off = 0
+    for i, p in enumerate(q for q in model.parameters() if q.requires_grad):
+        n = p.numel()
+        st = sd['state'].get(i)
+        if st is not None:
+            step.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
+            step.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+            step.t = int(st['step'])
+        off += n
+    step.lr = sd['param_groups'][0]['lr']
+
+
+def evaluate(model, graph, labels, class_weights=None):
+    """no_grad forward on one (batched) graph: (loss, accuracy, predictions) -- :349-353."""
+    model.eval()
+    with torch.no_grad():
+        logits = model(graph)
+        out3, _ = ops.weighted_ce(logits, labels, class_weights, want_grad=False)
+        pred = logits.argmax(dim=1)
+    o = out3.cpu().tolist()
+    return o[0], o[2] / max(labels.shape[0], 1), pred
+
+
+def train(data, config, name_time=None):
+    rank, local_rank, world = D.env_world()
+    distributed = world > 1
+    n_classes = data.num_classes
+    batch_size = config.TRAINING.batch_size
+    say = print if rank == 0 else (lambda *a, **k: None)
+    say(f"MODE: using {' '.join(config.PREPROCESS.features)} features")
+    say("DATA: classes stats:\n -> n [{}]\n -> # {}\n -> % {}".format(n_classes, data.stats['numbers'],
+                                                                  data.stats['percentages']))
+    in_feats = get_in_feats_(config)
+    feat_w = data.graphs[0].ndata['feat'].shape[1]
+    if feat_w != in_feats:
+        raise ValueError(f"pre-built graphs carry {feat_w} features, config asks for {in_feats}")
+    h_layer_dim = _hidden_width(config, in_feats, n_classes)
+    config.TRAINING.h_layer_dim = h_layer_dim
+    say(f" -> f [{in_feats}]")
+
+    all_labels = torch.cat([g.ndata['label'] for g in data.graphs]).numpy()
+    cw = _class_weights(config, all_labels, n_classes)
+    if not (config.TRAINING.gpu >= 0 and torch.cuda.is_available()):
+        raise RuntimeError("this train loop runs on the MI355X HIP path only (no CPU fallback); "
+                           "set TRAINING.gpu >= 0 on a GPU box")
+    device = torch.device('cuda', local_rank if distributed else config.TRAINING.gpu)
+    torch.cuda.set_device(device)
+    if distributed:
+        D.init_process_group("nccl", device)
+    class_weights = None if cw is None else torch.tensor(cw, dtype=torch.float32, device=device)
+
+    logs = logs_from_config(config)
+    out_root = config.GENERAL.get('output_dir', 'output')
+    weights_dir = os.path.join(out_root, 'weights')
+    ckpt_dir = os.path.join(out_root, 'checkpoints')
+    res_dir = os.path.join(out_root, 'results')
+    writer = _ScalarLog(os.path.join(out_root, 'runs', logs)) if rank == 0 else None
+    metrics = AttrDict({'train': {'loss': inf, 'acc': 0.0}, 'val': {'loss': inf, 'acc': 0.0},
+                        'f1_vect': [0.0 for _ in range(n_classes)]})
+
+    torch.manual_seed(config.PREPROCESS.get('seed', 42))
+    model = GcnSAGE(in_feats, int(h_layer_dim), n_classes, config.TRAINING.n_layers, F.relu,
+                    config.TRAINING.dropout).to(device)
+    say(model)
+    step = TrainStep(model, lr=config.TRAINING.lr, weight_decay=config.TRAINING.weight_decay,
+                     class_weights=class_weights, distributed=distributed)
+    stopper = EarlyStopping(weights=weights_dir, name=logs, patience=config.TRAINING.es_patience)
+    # ReduceLROnPlateau('min', factor=0.5) drives a stand-in optimiser whose lr is mirrored into the engine
+    _lr_holder = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=config.TRAINING.lr)
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(_lr_holder, 'min', factor=0.5)
+
+    start_epoch = 0
+    ckpt_path = os.path.join(ckpt_dir, logs)
+    if config.GENERAL.from_checkpoint and os.path.isfile(ckpt_path):
+        ck = torch.load(ckpt_path, map_location='cpu', weights_only=False)
+        start_epoch = ck['epoch']
+        model.load_state_dict(ck['state_dict'])             # parameters are views of the flat buffer: copies in place
+        load_adam_state_dict(step, model, ck['optimizer'])
+        metrics = AttrDict(ck['metrics'])
+        _lr_holder.param_groups[0]['lr'] = step.lr
+        say(f"=> loaded checkpoint '{ckpt_path}' (epoch {start_epoch})")
+
+    train_graphs, val_graphs, _ = data.split(len(data))
+    train_graphs = [g.to(device) for g in train_graphs]      # device-resident pages: features, COO, labels
+    for g in train_graphs:
+        g.in_csr(), g.out_csr()                              # per-page CSRs once; batches concatenate them
+    sizes = [g.num_nodes() for g in train_graphs]
+    val_shard = val_graphs[rank::world] if distributed else val_graphs
+    val_graph = G.batch([g.to(device) for g in val_shard]) if val_shard else None
+    val_labels = None if val_graph is None else val_graph.ndata['label']
+    label_ids = [v for v in range(n_classes)]
+
+    say("\n### START TRAINING ###\n")
+    train_loss = train_acc = float('nan')
+    for epoch in range(start_epoch, config.TRAINING.n_epochs):
+        plan = D.plan_epoch(sizes, batch_size, world, seed=config.PREPROCESS.get('seed', 42), epoch=epoch)
+        counts = D.step_node_counts(plan, sizes)
+        out3 = None
+        for s, ranks in enumerate(plan):
+            bg = G.batch([train_graphs[i] for i in ranks[rank]])
+            out3 = step.step(bg, bg.ndata['label'], n_global=int(counts[s].sum()))
+        if out3 is not None:
+            o = out3.cpu().tolist()
+            train_loss, train_acc = o[0], o[2] / max(int(counts[-1][rank]), 1)
+
+        # ---- validation on the (sharded) batched val graph -------------------------------------------
+        if val_graph is not None:
+            vl, va, pred = evaluate(model, val_graph, val_labels, class_weights)
+            n_val = val_labels.shape[0]
+            y_true, y_pred = val_labels.long().cpu().numpy(), pred.cpu().numpy()
+        else:
+            vl, va, n_val, y_true, y_pred = 0.0, 0.0, 0, np.zeros(0, np.int64), np.zeros(0, np.int64)
+        conf = np.zeros((n_classes, n_classes), dtype=np.float64)
+        np.add.at(conf, (y_true, y_pred), 1.0)
+        red = torch.tensor([vl * n_val, va * n_val, float(n_val)] + conf.reshape(-1).tolist(), dtype=torch.float64,
+                           device=device)
+        if distributed:
+            import torch.distributed as dist
+            dist.all_reduce(red)                              # one small vector: loss sum, correct, n, confusion
+        red = red.cpu().numpy()
+        n_tot = max(red[2], 1.0)
+        val_loss, val_acc = float(red[0] / n_tot), float(red[1] / n_tot)
+        conf = red[3:].reshape(n_classes, n_classes)
+        tp = np.diag(conf)
+        denom = conf.sum(0) + conf.sum(1)
+        f1_vect = np.where(denom > 0, 2 * tp / np.maximum(denom, 1), 0.0)   # per-class F1, zero_division=0
+
+        scheduler.step(val_loss)
+        step.lr = _lr_holder.param_groups[0]['lr']
+        early_stop, counter = (stopper.step(val_loss, model) if rank == 0 else (False, 0))
+        if distributed:
+            flag = torch.tensor([1.0 if early_stop else 0.0], device=device)
+            dist.broadcast(flag, src=0)
+            early_stop = bool(flag.item())
+        conv = data.label_tranformer.origin_to_conv
+        say(" -> Epoch {} | Train: Loss {:.4f} Acc {:.4f} | Validation: Loss {:.4f} | Accuracy {:.4f} | Cell F1 {:.4f}"
+            " | Table Header F1 {:.4f}".format(epoch + 1, train_loss, train_acc, val_loss, val_acc,
+                                               f1_vect[conv[TABLE_TCELL]], f1_vect[conv[TABLE_COLH]]))
+        if writer is not None:
+            for tag, v in (('Loss/train', train_loss), ('Accuracy/train', train_acc), ('Loss/val', val_loss),
+                           ('Accuracy/val', val_acc), ('f1/t-cell', f1_vect[conv[TABLE_TCELL]]),
+                           ('f1/h-cell', f1_vect[conv[TABLE_COLH]]), ('Accuracy/counter', counter)):
+                writer.add_scalar(tag, v, epoch + 1)
+        if early_stop:
+            break
+        if val_loss < metrics.val.loss:
+            metrics['train']['loss'], metrics['train']['acc'] = train_loss, train_acc
+            metrics['val']['loss'], metrics['val']['acc'] = val_loss, val_acc
+            metrics['f1_vect'] = f1_vect.tolist()
+        if rank == 0:
+            os.makedirs(ckpt_dir, exist_ok=True)
+            torch.save({'epoch': epoch + 1,
+                        'state_dict': {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                        'optimizer': adam_state_dict(step, model), 'metrics': dict(metrics)}, ckpt_path)
+
+    say("\n### TRAINING ENDED ###\n")
+    if rank == 0:
+        os.makedirs(res_dir, exist_ok=True)
+        path = os.path.join(res_dir, f'{logs}.json')
+        results = {}
+        if os.path.isfile(path):
+            with open(path) as f:
+                results = json.load(f)
+        conv = data.label_tranformer.origin_to_conv
+        results[logs] = {"train_loss": metrics.train.loss, "train_acc": metrics.train.acc,
+                         "val_loss": metrics.val.loss, "val_acc": metrics.val.acc,
+                         "cell_f1": metrics.f1_vect[conv[TABLE_TCELL]], "header_f1": metrics.f1_vect[conv[TABLE_COLH]]}
+        with open(path, 'w') as f:
+            json.dump(results, f, indent=4)
+    return metrics
+
+
+if __name__ == '__main__':
+    from ..components.graphs.loader import PrebuiltPages
+    from ..parsers.graphs import parse_args_ModelTrain
+    cfg = parse_args_ModelTrain()
+    src = os.environ.get("GTE_PAGES")
+    dataset = PrebuiltPages.load(src) if src else PrebuiltPages.synthetic(cfg.TRAINING.num_graphs or 400,
+                                                                          in_feats=get_in_feats_(cfg))
+    train(dataset, cfg)
