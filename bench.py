@@ -63,15 +63,29 @@ def build_batches(S, gte, args, rank, dev):
     return batches
 
 
-def cpu_baseline(args, host_batch, state):
-    from oracle import gcnsage_cpu as oc
-    src, dst, w, feat, label, off = host_batch
+def usable_cores() -> int:
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU box
+    shows 256 hardware threads but its cgroup grants a quota (cpu.max); oversubscribing it stalls."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def cpu_baseline(args, host_batch, state):
+    from oracle import gcnsage_cpu as oc
+    src, dst, w, feat, label, off = host_batch
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    oc.set_omp_threads(cores)
     tr = oc.OracleTrainer(state, lr=0.01, weight_decay=5e-4)
     og = oc.OracleGraph(src, dst, int(off[-1]), w)
     x, y = torch.from_numpy(feat), torch.from_numpy(label)

@@ -49,34 +49,40 @@ struct GemmParams {
 };
 
 // ---- staging: one BMxBK (or BKxBM) operand tile, global -> regs -> LDS ---------------------------
+// Guarded 16-byte loads WITHOUT branches: the address of every chunk is clamped into its contiguous
+// run (row of A / k-row of B), so the load itself is unconditional and all loads of a stage issue
+// back to back (a first version with `if (in range) load` compiled to one exec-masked branch per
+// chunk with s_waitcnt vmcnt(0) inside it: eight serialised memory round trips per K stage).
+// A chunk that straddles the end of its run is loaded from run_len-4 and shifted; the shift/zero
+// selects are applied when the registers are written to LDS (after the wait), from `meta`:
+//   meta = s in 0..3 : element j of the chunk is loaded[j + s] (zero if j + s > 3);  meta >= 4 : zeros.
+// Requires every run to hold >= 4 floats (the host routes smaller shapes to gemm_small_kernel).
+__device__ __forceinline__ float4 shift_chunk(const float4 t, int s) {
+    float4 v;
+    v.x = s == 0 ? t.x : s == 1 ? t.y : s == 2 ? t.z : s == 3 ? t.w : 0.f;
+    v.y = s == 0 ? t.y : s == 1 ? t.z : s == 2 ? t.w : 0.f;
+    v.z = s == 0 ? t.z : s == 1 ? t.w : 0.f;
+    v.w = s == 0 ? t.w : 0.f;
+    return v;
+}
+
 // K-contiguous source ([rows][K], ld): thread t loads float4 chunks (row = c / 8, kq = c % 8).
 template <int ROWS>
 struct StageK {
     static constexpr int CHUNKS = ROWS * (BK / 4);
     static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
-    float4 r[PER_THREAD];
+    f4u r[PER_THREAD];
+    int meta[PER_THREAD];
     __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int row0, int nrows, int k0,
                                          int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
-            const int c = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (CHUNKS % 256 == 0 || c < CHUNKS) {
-                const int row = row0 + c / (BK / 4);
-                const int k = k0 + (c % (BK / 4)) * 4;
-                if (row < nrows && k < kend) {
-                    const float* p = src + (int64_t)row * ld + k;
-                    if (k + 3 < kend) {
-                        const f4u t = *reinterpret_cast<const f4u*>(p);
-                        v = make_float4(t.x, t.y, t.z, t.w);
-                    } else {
-                        v.x = p[0];
-                        if (k + 1 < kend) v.y = p[1];
-                        if (k + 2 < kend) v.z = p[2];
-                    }
-                }
-            }
-            r[i] = v;
+            const int c = min(tid + i * 256, CHUNKS - 1);
+            const int row = row0 + c / (BK / 4);
+            const int k = k0 + (c % (BK / 4)) * 4;
+            const int kk = min(k, kend - 4);
+            meta[i] = (row < nrows && k < kend) ? k - kk : 4;
+            r[i] = *reinterpret_cast<const f4u*>(src + (int64_t)min(row, nrows - 1) * ld + kk);
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
@@ -84,7 +90,8 @@ struct StageK {
         for (int i = 0; i < PER_THREAD; ++i) {
             const int c = tid + i * 256;
             if (CHUNKS % 256 == 0 || c < CHUNKS)
-                *reinterpret_cast<float4*>(lds + (c / (BK / 4)) * KPAD + (c % (BK / 4)) * 4) = r[i];
+                *reinterpret_cast<float4*>(lds + (c / (BK / 4)) * KPAD + (c % (BK / 4)) * 4) =
+                    shift_chunk(make_float4(r[i].x, r[i].y, r[i].z, r[i].w), meta[i]);
         }
     }
 };
@@ -95,29 +102,18 @@ struct StageR {
     static constexpr int RPAD = ROWS + 4;
     static constexpr int CHUNKS = BK * (ROWS / 4);
     static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
-    float4 r[PER_THREAD];
+    f4u r[PER_THREAD];
+    int meta[PER_THREAD];
     __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int row0, int nrows, int k0,
                                          int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
-            const int c = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (CHUNKS % 256 == 0 || c < CHUNKS) {
-                const int k = k0 + c / (ROWS / 4);
-                const int row = row0 + (c % (ROWS / 4)) * 4;
-                if (k < kend && row < nrows) {
-                    const float* p = src + (int64_t)k * ld + row;
-                    if (row + 3 < nrows) {
-                        const f4u t = *reinterpret_cast<const f4u*>(p);
-                        v = make_float4(t.x, t.y, t.z, t.w);
-                    } else {
-                        v.x = p[0];
-                        if (row + 1 < nrows) v.y = p[1];
-                        if (row + 2 < nrows) v.z = p[2];
-                    }
-                }
-            }
-            r[i] = v;
+            const int c = min(tid + i * 256, CHUNKS - 1);
+            const int k = k0 + c / (ROWS / 4);
+            const int row = row0 + (c % (ROWS / 4)) * 4;
+            const int rr = min(row, nrows - 4);
+            meta[i] = (k < kend && row < nrows) ? row - rr : 4;
+            r[i] = *reinterpret_cast<const f4u*>(src + (int64_t)min(k, kend - 1) * ld + rr);
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
@@ -125,7 +121,8 @@ struct StageR {
         for (int i = 0; i < PER_THREAD; ++i) {
             const int c = tid + i * 256;
             if (CHUNKS % 256 == 0 || c < CHUNKS)
-                *reinterpret_cast<float4*>(lds + (c / (ROWS / 4)) * RPAD + (c % (ROWS / 4)) * 4) = r[i];
+                *reinterpret_cast<float4*>(lds + (c / (ROWS / 4)) * RPAD + (c % (ROWS / 4)) * 4) =
+                    shift_chunk(make_float4(r[i].x, r[i].y, r[i].z, r[i].w), meta[i]);
         }
     }
 };
@@ -205,20 +202,28 @@ gemm_f32_mfma_kernel(const GemmParams p) {
         stB.store(sB, tid);
         __syncthreads();
         if (t + 1 < t_end) issue(t + 1);       // prefetch under the MFMAs
+        // fragments of k-group kg+1 are read from LDS while the MFMAs of k-group kg run
+        float fa[2][TM][4], fb[2][TN][4];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) read_frag<AK, BM>(sA, (wm * TM + a) * 32, 0, lane, fa[0][a]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) read_frag<BKC, BN>(sB, (wn * TN + b) * 32, 0, lane, fb[0][b]);
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
-            float fa[TM][4], fb[TN][4];
+            const int cur = kg & 1, nxt = cur ^ 1;
+            if (kg + 1 < BK / 8) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) read_frag<AK, BM>(sA, (wm * TM + a) * 32, kg, lane, fa[a]);
+                for (int a = 0; a < TM; ++a) read_frag<AK, BM>(sA, (wm * TM + a) * 32, kg + 1, lane, fa[nxt][a]);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) read_frag<BKC, BN>(sB, (wn * TN + b) * 32, kg, lane, fb[b]);
+                for (int b = 0; b < TN; ++b) read_frag<BKC, BN>(sB, (wn * TN + b) * 32, kg + 1, lane, fb[nxt][b]);
+            }
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][tt], fb[b][tt], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][a][tt], fb[cur][b][tt], acc[a][b], 0, 0, 0);
         }
     }
 
@@ -269,16 +274,58 @@ splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t mn, int
     }
 }
 
+// Shapes with a contiguous run shorter than 4 floats (F = 3 toy graphs, a single-node page): one thread
+// per output element, plain fp32 FMA chain in k order.  Never on the measured path.
+template <bool AK, bool BKC>
+__global__ void __launch_bounds__(256)
+gemm_small_kernel(const GemmParams p) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)p.M * p.N) return;
+    const int m = (int)(idx / p.N), n = (int)(idx % p.N);
+    float acc = 0.f;
+    for (int seg = 0; seg < 2; ++seg) {
+        const float* A = seg ? p.A2 : p.A1;
+        const int64_t lda = seg ? p.lda2 : p.lda1;
+        const int K = seg ? p.K2 : p.K1, kb = seg ? p.K1 : 0;
+        for (int k = 0; k < K; ++k) {
+            const float a = AK ? A[(int64_t)m * lda + k] : A[(int64_t)k * lda + m];
+            const float b = BKC ? p.B[(int64_t)n * p.ldb + kb + k] : p.B[(int64_t)(kb + k) * p.ldb + n];
+            acc = fmaf(a, b, acc);
+        }
+    }
+    if (p.bias) acc += p.bias[n];
+    float* dst = p.C + (int64_t)m * p.ldc + n;
+    if (p.accumulate) acc += *dst;
+    if (p.relu) acc = fmaxf(acc, 0.f);
+    *dst = acc;
+}
+
+// every contiguous run the MFMA kernel's 16-byte staging loads touch must hold >= 4 floats
+bool needs_small_path(bool ak, bool bkc, const GemmParams& p) {
+    const int kmin = p.K2 > 0 ? (p.K1 < p.K2 ? p.K1 : p.K2) : p.K1;
+    const int a_run = ak ? kmin : p.M;
+    const int b_run = bkc ? kmin : p.N;
+    return a_run < 4 || b_run < 4;
+}
+
 struct Plan { int bm, bn, tiles, splits, tiles_per_split; };
 
 Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2) {
     Plan pl;
+    const int cus = gte::device_props().cus;
     if (N <= 32) { pl.bm = 128; pl.bn = 32; }
     else if (M <= 32) { pl.bm = 32; pl.bn = 128; }
-    else { pl.bm = 128; pl.bn = 128; }
+    else {
+        // tile quantisation: a page batch gives ~1.5 waves of 128x128 tiles over the 256 CUs (the last
+        // half-empty wave costs a full tile time); 64x128 tiles cut the tail.  Compare rounds x tile area.
+        const int64_t t128 = gte::ceil_div(M, 128) * gte::ceil_div(N, 128);
+        const int64_t t64 = gte::ceil_div(M, 64) * gte::ceil_div(N, 128);
+        const int64_t c128 = gte::ceil_div(t128, cus) * 2, c64 = gte::ceil_div(t64, cus);
+        pl.bn = 128;
+        pl.bm = (t128 >= cus && c64 * 10 < c128 * 9) ? 64 : 128;
+    }
     pl.tiles = (int)(gte::ceil_div(M, pl.bm) * gte::ceil_div(N, pl.bn));
     const int ktiles = (int)(gte::ceil_div(K1, BK) + gte::ceil_div(K2, BK));
-    const int cus = gte::device_props().cus;
     int splits = 1;
     // the reduction dimension is the node count for dW = dZ^T X: few output tiles, very long K
     if (pl.tiles < cus && ktiles >= 16) {
@@ -297,6 +344,8 @@ int launch_shape(const GemmParams& p, const Plan& pl, hipStream_t s) {
     dim3 grid((unsigned)pl.tiles, (unsigned)pl.splits), block(256);
     if (pl.bm == 128 && pl.bn == 128)
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 128, 128, 2, 2>), grid, block, 0, s, p);
+    else if (pl.bm == 64 && pl.bn == 128)
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 64, 128, 2, 2>), grid, block, 0, s, p);
     else if (pl.bn == 32)
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 128, 32, 4, 1>), grid, block, 0, s, p);
     else
@@ -304,8 +353,19 @@ int launch_shape(const GemmParams& p, const Plan& pl, hipStream_t s) {
     return gte::check_launch("gemm_f32");
 }
 
+int run_small(bool ak, bool bkc, GemmParams p, hipStream_t s) {
+    p.splits = 1;
+    dim3 grid((unsigned)gte::ceil_div((int64_t)p.M * p.N, 256)), block(256);
+    if (ak && bkc) hipLaunchKernelGGL((gemm_small_kernel<true, true>), grid, block, 0, s, p);
+    else if (ak) hipLaunchKernelGGL((gemm_small_kernel<true, false>), grid, block, 0, s, p);
+    else if (bkc) hipLaunchKernelGGL((gemm_small_kernel<false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_small_kernel<false, false>), grid, block, 0, s, p);
+    return gte::check_launch("gemm_small");
+}
+
 int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace_bytes, hipStream_t s) {
     if (p.M == 0 || p.N == 0) return GTE_OK;
+    if (needs_small_path(ak, bkc, p)) return run_small(ak, bkc, p, s);
     const Plan pl = make_plan(p.M, p.N, p.K1, p.K2);
     p.splits = pl.splits;
     p.tiles_per_split = pl.tiles_per_split;
@@ -401,36 +461,113 @@ ln_relu_fwd_kernel(const float* __restrict__ z, int64_t ldz, const float* __rest
 // ------------------------------- LayerNorm + ReLU, backward ---------------------------------------
 // Per row: g = relu ? (pre > 0 ? dy : 0) : dy ; dxhat = g*gamma ;
 //          dz = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat))
-// Column sums (dgamma = sum g*xhat, dbeta = sum g, dbias = sum dz) are accumulated per block in
-// registers over the block's rows, written as partials [block][3][n] and folded by a second kernel
-// in block order (deterministic, no atomics).
-constexpr int LNB_ROWS = 32;      // rows per block (8 per wave)
+// Column sums (dgamma = sum g*xhat, dbeta = sum g, dbias = sum dz) never touch atomics: every wave
+// keeps its partial sums for its columns (lane + 64 t) in registers over the rows it owns, the four
+// waves of a block are folded through LDS, the block writes partial[block][3][n], and a second kernel
+// folds the (<= LNB_MAX_BLOCKS) block partials in a fixed order.  HBM-bound: reads dy and z once,
+// writes dz once.
+constexpr int LNB_MAX_BLOCKS = 512;
 
+template <int NCH>                 // row width n <= 64 * NCH, whole row in registers
 __global__ void __launch_bounds__(256)
 ln_relu_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ z, int64_t ldz,
                    const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                    int relu, float* __restrict__ dz, int64_t lddz, float* __restrict__ partial, int M, int n) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [4 waves][3][NCH*64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool has_ln = gamma != nullptr;
+    float gam[NCH], bet[NCH], s_dg[NCH], s_db[NCH], s_dbias[NCH];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        const int j = lane + 64 * t;
+        gam[t] = (has_ln && j < n) ? gamma[j] : 1.f;
+        bet[t] = (has_ln && j < n) ? beta[j] : 0.f;
+        s_dg[t] = s_db[t] = s_dbias[t] = 0.f;
+    }
+    const float inv_n = 1.0f / (float)n;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float* dyr = dy + (int64_t)row * lddy;
+        const float* zr = z + (int64_t)row * ldz;
+        float* dzr = dz + (int64_t)row * lddz;
+        float g[NCH], xh[NCH];
+        if (has_ln) {
+            const float mean = stats[row], rstd = stats[M + row];
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const int j = lane + 64 * t;
+                const bool ok = j < n;
+                xh[t] = ok ? (zr[j] - mean) * rstd : 0.f;
+                float gv = ok ? dyr[j] : 0.f;
+                if (relu && ln_affine(xh[t], gam[t], bet[t]) <= 0.f) gv = 0.f;
+                g[t] = gv;
+                const float dxh = gv * gam[t];
+                a += dxh;
+                b = fmaf(dxh, xh[t], b);
+            }
+            const float c1 = wave_sum(a) * inv_n, c2 = wave_sum(b) * inv_n;
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const int j = lane + 64 * t;
+                if (j < n) {
+                    const float d = rstd * (g[t] * gam[t] - c1 - xh[t] * c2);
+                    s_dg[t] = fmaf(g[t], xh[t], s_dg[t]);
+                    s_db[t] += g[t];
+                    s_dbias[t] += d;
+                    dzr[j] = d;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const int j = lane + 64 * t;
+                if (j < n) {
+                    float gv = dyr[j];
+                    if (relu && zr[j] <= 0.f) gv = 0.f;
+                    s_dbias[t] += gv;
+                    dzr[j] = gv;
+                }
+            }
+        }
+    }
+    constexpr int W = NCH * 64;
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        red[(wave * 3 + 0) * W + lane + 64 * t] = s_dg[t];
+        red[(wave * 3 + 1) * W + lane + 64 * t] = s_db[t];
+        red[(wave * 3 + 2) * W + lane + 64 * t] = s_dbias[t];
+    }
+    __syncthreads();
+    float* pp = partial + (int64_t)blockIdx.x * 3 * n;
+    for (int i = threadIdx.x; i < 3 * W; i += 256) {
+        const int q = i / W, j = i - q * W;
+        if (j < n) pp[q * n + j] = red[(0 * 3 + q) * W + j] + red[(1 * 3 + q) * W + j] + red[(2 * 3 + q) * W + j] +
+                                   red[(3 * 3 + q) * W + j];
+    }
+}
+
+// Rows wider than 1024: same maths, the row is re-read from L1/L2 instead of cached in registers, and
+// the column partials are produced 64 columns at a time.  dz must not alias dy here.
+__global__ void __launch_bounds__(256)
+ln_relu_bwd_wide_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ z, int64_t ldz,
+                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                        const float* __restrict__ beta, int relu, float* __restrict__ dz, int64_t lddz,
+                        float* __restrict__ partial, int M, int n) {
     __shared__ float red[3][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row_begin = blockIdx.x * LNB_ROWS;
     const bool has_ln = gamma != nullptr;
-    // column chunk loop: 64 columns at a time so the per-column partials stay in three registers
     for (int j0 = 0; j0 < n; j0 += 64) {
         const int j = j0 + lane;
         const bool jok = j < n;
         const float gj = (has_ln && jok) ? gamma[j] : 1.f;
         const float bj = (has_ln && jok) ? beta[j] : 0.f;
         float s_dg = 0.f, s_db = 0.f, s_dbias = 0.f;
-        for (int rr = wave; rr < LNB_ROWS; rr += 4) {
-            const int row = row_begin + rr;
-            if (row >= M) break;
+        for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
             const float* dyr = dy + (int64_t)row * lddy;
             const float* zr = z + (int64_t)row * ldz;
             float* dzr = dz + (int64_t)row * lddz;
             if (has_ln) {
                 const float mean = stats[row], rstd = stats[M + row];
-                // row means of dxhat and dxhat*xhat need the whole row: recomputed per 64-column chunk from
-                // L1/L2-resident rows (a row is <= 4 KB); cheap next to the GEMMs
                 float a = 0.f, b = 0.f;
                 for (int jj = lane; jj < n; jj += 64) {
                     const float xh = (zr[jj] - mean) * rstd;
@@ -445,12 +582,11 @@ ln_relu_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __re
                     const float xh = (zr[j] - mean) * rstd;
                     float g = dyr[j];
                     if (relu && ln_affine(xh, gj, bj) <= 0.f) g = 0.f;
-                    const float dxh = g * gj;
-                    const float d = rstd * (dxh - c1 - xh * c2);
+                    const float d = rstd * (g * gj - c1 - xh * c2);
                     s_dg = fmaf(g, xh, s_dg);
                     s_db += g;
                     s_dbias += d;
-                    dzr[j] = d;          // safe when dz aliases dy: the row-mean pass above is complete
+                    dzr[j] = d;
                 }
             } else if (jok) {
                 float g = dyr[j];
@@ -471,22 +607,34 @@ ln_relu_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __re
     }
 }
 
-// NOTE on aliasing: with LayerNorm and n > 64 the row means for chunk j0 > 0 re-read dy after dz has
-// overwritten chunk 0 -- so dz must NOT alias dy when n > 64 and gamma != NULL (checked on the host).
-
-__global__ void __launch_bounds__(256)
+// fold the block partials: block = 64 columns x 16 slices of the block list; fixed order; WRITES results
+__global__ void __launch_bounds__(1024)
 colsum_fold_kernel(const float* __restrict__ partial, int nblocks, int n, float* __restrict__ dgamma,
                    float* __restrict__ dbeta, float* __restrict__ dbias) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
     float a = 0.f, b = 0.f, c = 0.f;
-    for (int k = 0; k < nblocks; ++k) {
-        const float* pp = partial + (int64_t)k * 3 * n;
-        a += pp[j]; b += pp[n + j]; c += pp[2 * n + j];
+    if (j < n) {
+        for (int k = slice; k < nblocks; k += 16) {
+            const float* pp = partial + (int64_t)k * 3 * n;
+            a += pp[j]; b += pp[n + j]; c += pp[2 * n + j];
+        }
     }
-    if (dgamma) dgamma[j] += a;
-    if (dbeta) dbeta[j] += b;
-    if (dbias) dbias[j] += c;
+    red[0][slice][lane] = a; red[1][slice][lane] = b; red[2][slice][lane] = c;
+    __syncthreads();
+    if (slice < 3 && j < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[slice][k][lane];
+        float* dst = slice == 0 ? dgamma : slice == 1 ? dbeta : dbias;
+        if (dst) dst[j] = s;
+    }
+}
+
+int ln_bwd_blocks(int64_t M) {
+    const int64_t b = gte::ceil_div(M, 4);
+    return (int)(b < LNB_MAX_BLOCKS ? b : LNB_MAX_BLOCKS);
 }
 
 }  // namespace
@@ -532,7 +680,10 @@ extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, co
     p.relu = (!ln && relu) ? 1 : 0; p.accumulate = 0;
     // forward K = k1+k2 is short and M is the node count: never split (workspace-free)
     const Plan pl = make_plan(M, n_out, k1, k2);
-    if (pl.splits > 1) {
+    if (needs_small_path(true, true, p)) {
+        int rc = run_small(true, true, p, s);
+        if (rc != GTE_OK) return rc;
+    } else if (pl.splits > 1) {
         // tiny M with long K (not a page-graph shape): run unsplit rather than demand a workspace
         Plan one = pl; one.splits = 1; one.tiles_per_split = (int)(gte::ceil_div(k1, BK) + gte::ceil_div(k2, BK));
         p.splits = 1; p.tiles_per_split = one.tiles_per_split;
@@ -567,8 +718,7 @@ extern "C" int gte_ln_relu_fwd(const float* z, int64_t ldz, const float* gamma, 
 }
 
 extern "C" int64_t gte_ln_relu_bwd_workspace_bytes(int64_t M, int64_t n_out) {
-    const int64_t nb = gte::ceil_div(M > 0 ? M : 1, LNB_ROWS);
-    return gte::round_up(nb * 3 * (n_out > 0 ? n_out : 1) * 4, 256);
+    return gte::round_up((int64_t)ln_bwd_blocks(M > 0 ? M : 1) * 3 * (n_out > 0 ? n_out : 1) * 4, 256);
 }
 
 extern "C" int gte_ln_relu_bwd(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* stats,
@@ -581,17 +731,30 @@ extern "C" int gte_ln_relu_bwd(const float* dy, int64_t lddy, const float* z, in
     if (!dy || !dz || !workspace) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: null pointer");
     if ((gamma || relu) && !z) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: z is required");
     if (gamma && (!beta || !stats)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: LayerNorm needs beta and stats");
-    if (gamma && n_out > 64 && dz == dy)
-        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: dz must not alias dy when n_out > 64 with LayerNorm");
+    if (gamma && n_out > 1024 && dz == dy)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: dz must not alias dy when n_out > 1024 with LayerNorm");
     if (workspace_bytes < gte_ln_relu_bwd_workspace_bytes(M, n_out))
         return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "ln_relu_bwd: workspace too small");
     hipStream_t s = gte::as_stream(stream);
-    const int nb = (int)gte::ceil_div(M, LNB_ROWS);
+    const int nb = ln_bwd_blocks(M);
     const float* zz = z ? z : dy;
-    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, dy, lddy, zz, z ? ldz : lddy, stats, gamma,
-                       beta, relu, dz, lddz, reinterpret_cast<float*>(workspace), (int)M, (int)n_out);
+    const int64_t ldzz = z ? ldz : lddy;
+    float* part = reinterpret_cast<float*>(workspace);
+    dim3 grid((unsigned)nb), block(256);
+#define GTE_LNB(NCH)                                                                                              \
+    hipLaunchKernelGGL((ln_relu_bwd_kernel<NCH>), grid, block, (size_t)(4 * 3 * NCH * 64) * sizeof(float), s, dy, lddy, \
+                       zz, ldzz, stats, gamma, beta, relu, dz, lddz, part, (int)M, (int)n_out)
+    if (n_out <= 64) GTE_LNB(1);
+    else if (n_out <= 128) GTE_LNB(2);
+    else if (n_out <= 256) GTE_LNB(4);
+    else if (n_out <= 512) GTE_LNB(8);
+    else if (n_out <= 1024) GTE_LNB(16);
+    else
+        hipLaunchKernelGGL(ln_relu_bwd_wide_kernel, grid, block, 0, s, dy, lddy, zz, ldzz, stats, gamma, beta, relu, dz,
+                           lddz, part, (int)M, (int)n_out);
+#undef GTE_LNB
     if (dgamma || dbeta || dbias)
-        hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)gte::ceil_div(n_out, 256)), dim3(256), 0, s,
-                           reinterpret_cast<const float*>(workspace), nb, (int)n_out, dgamma, dbeta, dbias);
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)gte::ceil_div(n_out, 64)), dim3(1024), 0, s, part, nb,
+                           (int)n_out, dgamma, dbeta, dbias);
     return gte::check_launch("ln_relu_bwd");
 }

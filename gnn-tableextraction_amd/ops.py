@@ -286,9 +286,9 @@ class _SageLayer(torch.autograd.Function):
         need_h, need_w, need_b, need_g, need_be = ctx.needs_input_grad[:5]
         n_out, f = weight.shape[0], h.shape[1]
         dev = h.device
-        dgamma = torch.zeros(n_out, dtype=torch.float32, device=dev) if ctx.has_ln else None
-        dbeta = torch.zeros(n_out, dtype=torch.float32, device=dev) if ctx.has_ln else None
-        dbias = torch.zeros(n_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        dgamma = torch.empty(n_out, dtype=torch.float32, device=dev) if ctx.has_ln else None
+        dbeta = torch.empty(n_out, dtype=torch.float32, device=dev) if ctx.has_ln else None
+        dbias = torch.empty(n_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
         # (1) LayerNorm/ReLU backward (+ bias/gamma/beta column sums); relu without LN masks on y
         dz = ln_relu_bwd(dy, z if ctx.has_ln else y, stats, gamma, beta, ctx.relu, dgamma, dbeta, dbias)
         # (2) dW = dZ^T [h | ahn]  (reduction over the nodes, split-K inside)

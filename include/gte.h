@@ -110,9 +110,9 @@ int gte_ln_relu_fwd(const float* z, int64_t ldz, const float* gamma, const float
                     float* y, int64_t ldy, float* stats, int64_t M, int64_t n_out, void* stream);
 
 /* Backward of LayerNorm+ReLU (+ bias grad):  given dy, the saved z and stats, writes
- *   dz[M,n_out], and accumulates column sums into dgamma, dbeta, dbias (f32[n_out], nullable).
- * With gamma == NULL it is the backward of (relu?)(z) only.  dz may alias dy only when gamma == NULL
- * or n_out <= 64 (the row means re-read dy).
+ *   dz[M,n_out], and WRITES the column sums dgamma, dbeta, dbias (f32[n_out], nullable; no zero-init needed).
+ * With gamma == NULL it is the backward of (relu?)(z) only.  dz may alias dy unless gamma != NULL and
+ * n_out > 1024 (wide rows are re-read).
  * workspace: gte_ln_relu_bwd_workspace_bytes(M, n_out). */
 int64_t gte_ln_relu_bwd_workspace_bytes(int64_t M, int64_t n_out);
 int gte_ln_relu_bwd(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* stats,

@@ -94,6 +94,7 @@ def _load_omp():
                 ctypes.c_int64, ctypes.c_int]
             lib.oracle_spmm_csr_f32.restype = None
             lib.oracle_num_threads.restype = ctypes.c_int
+            lib.oracle_set_threads.argtypes = [ctypes.c_int]
             _omp_lib = lib
         else:
             _omp_lib = False
@@ -102,6 +103,12 @@ def _load_omp():
 
 def omp_available() -> bool:
     return bool(_load_omp())
+
+
+def set_omp_threads(n: int) -> None:
+    lib = _load_omp()
+    if lib:
+        lib.oracle_set_threads(int(n))
 
 
 def omp_threads() -> int:

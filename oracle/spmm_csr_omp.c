@@ -28,6 +28,14 @@ int oracle_num_threads(void) {
 #endif
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* mode 0: weighted sum; mode 1: weighted sum / in_degree (0 if none). */
 void oracle_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, const float* w,
                          const float* x, float* out, int64_t n, int64_t f,
