@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--pages", type=int, default=100, help="page graphs per batch per GPU")
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches cycled through")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true")
     ap.add_argument("--gather-nodes", type=int, default=1_000_000)
@@ -152,14 +153,14 @@ def main():
     import gnn_tableextraction_amd as gte
     from gnn_tableextraction_amd import ops
     from gnn_tableextraction_amd.data import synthetic as S
-    from gnn_tableextraction_amd.models.engine import TrainStep
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
 
     batches = build_batches(S, gte, args, rank, dev)
     torch.manual_seed(42)
     model = gte.GcnSAGE(args.in_feats, args.hidden, 9, args.layers, torch.nn.functional.relu, 0)
     state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
-    trainer = TrainStep(model, lr=0.01, weight_decay=5e-4, distributed=distributed)
+    trainer = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4, distributed=distributed)
 
     # global node count of step i (every rank can compute it: page sizes are seeded metadata)
     local_nodes = [b[0].num_nodes() for b in batches]
@@ -170,9 +171,17 @@ def main():
     else:
         global_nodes = local_nodes
 
-    def run(i):
-        g, y, _ = batches[i % len(batches)]
-        return trainer.step(g, y, n_global=global_nodes[i % len(batches)])
+    # one HIP graph per resident batch (forward + loss + backward); all-reduce and Adam follow eagerly
+    replays = None
+    if not args.no_graph:
+        replays = [trainer.capture(g, y, n_global=global_nodes[i]) for i, (g, y, _) in enumerate(batches)]
+
+    def run(i, eager=False):
+        j = i % len(batches)
+        if replays is not None and not eager:
+            return replays[j]()
+        g, y, _ = batches[j]
+        return trainer.step(g, y, n_global=global_nodes[j])
 
     def barrier():
         if distributed:
@@ -182,12 +191,17 @@ def main():
     for i in range(args.warmup):
         run(i)
     barrier()
-    ops.enable_kernel_timers(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out3 = run(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    final_loss = float(out3[0])
+    # per-kernel HIP-event timing: the SAME steps launched eagerly (events cannot sit between the nodes of
+    # a graph replay), on the launch stream, right after the timed region
+    ops.enable_kernel_timers(True)
+    for i in range(len(batches) * 2):
+        run(i, eager=True)
     kt = ops.kernel_timer_report()
     ops.enable_kernel_timers(False)
 
@@ -200,7 +214,6 @@ def main():
         elapsed, nodes_total = float(tmax[0]), float(stat[1])
     else:
         nodes_total = float(nodes_local)
-    final_loss = float(out3[0])
 
     if rank == 0:
         n_launch, ms, flops = kt.get("gemm_nt", (0, 0.0, 0.0))
@@ -221,7 +234,8 @@ def main():
             "config": {"workload": f"cfg2: {args.pages} synthetic PubLayNet-style page graphs per GPU per step "
                                    f"(~{int(np.mean(local_nodes))} nodes, k-NN k=5 bidirected), GcnSAGE "
                                    f"{args.layers} layers F0={args.in_feats} hidden={args.hidden} classes=9, "
-                                   f"CE + Adam(lr 0.01, wd 5e-4); batches resident in HBM",
+                                   f"CE + Adam(lr 0.01, wd 5e-4); batches resident in HBM; "
+                                   f"{'HIP-graph replay per batch' if replays is not None else 'eager launches'}",
                        "pages_per_gpu_per_step": args.pages, "global_pages_per_step": args.pages * world,
                        "nodes_per_step_per_gpu": int(np.mean(local_nodes)), "parallelism": f"dp{world}"},
             "final_loss": final_loss, "roofline": roofline, "kernels": per_kernel,

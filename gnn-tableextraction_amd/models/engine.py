@@ -77,3 +77,190 @@ class TrainStep:
     # checkpoint-compatible with torch.optim.Adam's state_dict layout is handled by model_train.py
     def lr_scale(self, factor: float) -> None:
         self.lr *= factor
+
+
+# ======================================================================================================
+# Hand-scheduled step for GcnSAGE: no autograd, no per-step allocation, HIP-graph capturable
+# ======================================================================================================
+from .. import _lib                                                     # noqa: E402
+from ..components.graphs.models import GcnSAGE, _is_relu               # noqa: E402
+import torch.nn as nn                                                  # noqa: E402
+
+
+class FusedGcnSageStep(TrainStep):
+    """The same optimisation step as :class:`TrainStep` for a :class:`GcnSAGE` model, scheduled by hand:
+
+    * forward and backward are explicit sequences of C-ABI calls (aggregation, split-weight GEMM,
+      LayerNorm/ReLU, CE, LayerNorm backward, dW / dX GEMMs, transpose aggregation) -- no autograd
+      graph, no Python allocation per step (buffers are cached per node count);
+    * parameter gradients are written by the kernels DIRECTLY into their slices of ``flat_grad`` (every
+      producer overwrites, so the buffer is never zeroed and never accumulated into);
+    * nothing in a step synchronises or allocates, so a step on a resident batch can be captured
+      into a HIP graph (:meth:`capture`) and replayed with one launch -- the page-batch regime is a few
+      dozen 10-300 us kernels, where per-launch host time would otherwise bound the step.
+    Requires the configuration every shipped reference run uses: ReLU (or no) activation, dropout 0,
+    use_pp False; anything else goes through the autograd path (:class:`TrainStep`).
+    """
+
+    def __init__(self, model: GcnSAGE, **kw):
+        if not isinstance(model, GcnSAGE):
+            raise TypeError("FusedGcnSageStep needs a GcnSAGE model")
+        for layer in model.layers:
+            if layer.use_pp or (layer.dropout and layer.dropout.p > 0) or not (layer.activation is None or _is_relu(layer.activation)):
+                raise ValueError("FusedGcnSageStep supports ReLU/None activations, dropout 0, use_pp False")
+        if model.dropout.p > 0:
+            raise ValueError("FusedGcnSageStep supports dropout 0 only")
+        super().__init__(model, **kw)
+        self.lib = _lib.load()
+        # slices of the flat gradient, in model.parameters() order
+        self._gslice = {}
+        off = 0
+        for p in (q for q in model.parameters() if q.requires_grad):
+            self._gslice[id(p)] = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self._bufs = {}
+        self._graphs = {}
+
+    # -- buffers -------------------------------------------------------------------------------------
+    def _buffers(self, n: int, f0: int):
+        key = (n, f0)
+        b = self._bufs.get(key)
+        if b is None:
+            dev = self.flat_param.device
+            new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            layers = self.model.layers
+            dims = [f0] + [l.out_feats for l in layers]
+            b = {"ahn": [new(n, dims[i]) for i in range(len(layers))],
+                 "z": [new(n, dims[i + 1]) if isinstance(l.lynorm, nn.LayerNorm) else None for i, l in enumerate(layers)],
+                 "stats": [new(2 * n) if isinstance(l.lynorm, nn.LayerNorm) else None for l in layers],
+                 "y": [new(n, dims[i + 1]) for i in range(len(layers))],
+                 "dy": [new(n, dims[i + 1]) for i in range(len(layers))],      # grad w.r.t. layer output (dz in place)
+                 "dahn": new(n, max(dims[1:-1]) if len(dims) > 2 else 1),
+                 "out3": new(3)}
+            lib = self.lib
+            ws = max([lib.gte_weighted_ce_workspace_bytes(n)] +
+                     [lib.gte_ln_relu_bwd_workspace_bytes(n, d) for d in dims[1:]] +
+                     [lib.gte_gemm_workspace_bytes(dims[i + 1], dims[i], n) for i in range(len(layers))])
+            b["ws"] = torch.empty(int(ws), dtype=torch.uint8, device=dev)
+            self._bufs[key] = b
+        return b
+
+    # -- the schedule ----------------------------------------------------------------------------------
+    def forward_backward(self, g, labels: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:
+        lib, P, check = self.lib, _lib.ptr, _lib.check
+        st = _lib.current_stream()
+        timed = ops._timed
+        x = ops._row_major(g.ndata['feat'])
+        _lib.require_device(x, "FusedGcnSageStep")
+        n, f0 = x.shape
+        b = self._buffers(n, f0)
+        layers = list(self.model.layers)
+        ew = g.edata.get("feat")
+        csr, rcsr = g.in_csr(), g.out_csr()
+        w_in, w_out = g.in_weights(ew), g.out_weights(ew, True)
+        ws, wsn = P(b["ws"]), b["ws"].numel()
+        ld = ops._ld
+
+        # ---------------- forward ----------------
+        h = x
+        for i, L in enumerate(layers):
+            fin, fout = h.shape[1], L.out_feats
+            W, bias = L.linear.weight, L.linear.bias
+            ln = isinstance(L.lynorm, nn.LayerNorm)
+            relu = L.activation is not None
+            ahn, y = b["ahn"][i], b["y"][i]
+            with timed("spmm_csr", 2.0 * n * fin * 4 + 8.0 * csr.indices.numel() + 4.0 * (n + 1)):
+                check(lib.gte_spmm_csr(P(csr.indptr), P(csr.indices), P(w_in), P(h), ld(h), P(ahn), fin, n, fin,
+                                       _lib.GTE_F32, _lib.REDUCE_MEAN, st), "gte_spmm_csr")
+            lin_out = b["z"][i] if ln else y
+            with timed("gemm_nt", 4.0 * n * fin * fout):
+                check(lib.gte_sage_linear_fwd(P(h), ld(h), fin, P(ahn), fin, fin, P(W), 2 * fin, P(bias), None, None,
+                                              1e-5, int(relu and not ln), None, 0, None, P(lin_out), fout, n, fout, st),
+                      "gte_sage_linear_fwd")
+            if ln:
+                check(lib.gte_ln_relu_fwd(P(lin_out), fout, P(L.lynorm.weight), P(L.lynorm.bias), float(L.lynorm.eps),
+                                          int(relu), P(y), fout, P(b["stats"][i]), n, fout, st), "gte_ln_relu_fwd")
+            h = y
+        logits = h
+
+        # ---------------- loss ----------------
+        lab = labels if labels.dtype in (torch.float32, torch.int64) else labels.to(torch.int64)
+        dl = b["dy"][-1]
+        check(lib.gte_weighted_ce(P(logits), logits.shape[1], P(lab), int(lab.dtype == torch.float32),
+                                  P(self.class_weights), n, logits.shape[1], float(grad_scale), P(dl), dl.shape[1],
+                                  P(b["out3"]), ws, wsn, st), "gte_weighted_ce")
+
+        # ---------------- backward ----------------
+        for i in range(len(layers) - 1, -1, -1):
+            L = layers[i]
+            hin = x if i == 0 else b["y"][i - 1]
+            fin, fout = hin.shape[1], L.out_feats
+            W = L.linear.weight
+            ln = isinstance(L.lynorm, nn.LayerNorm)
+            relu = L.activation is not None
+            dy = b["dy"][i]
+            gW = self._gslice[id(W)]
+            gb = self._gslice[id(L.linear.bias)] if L.linear.bias is not None else None
+            gg = self._gslice[id(L.lynorm.weight)] if ln else None
+            gbe = self._gslice[id(L.lynorm.bias)] if ln else None
+            zsrc = b["z"][i] if ln else b["y"][i]
+            # dz in place of dy; column sums straight into the flat gradient
+            check(lib.gte_ln_relu_bwd(P(dy), fout, P(zsrc), fout, P(b["stats"][i]) if ln else None,
+                                      P(L.lynorm.weight) if ln else None, P(L.lynorm.bias) if ln else None, int(relu),
+                                      P(dy), fout, P(gg), P(gbe), P(gb), n, fout, ws, wsn, st), "gte_ln_relu_bwd")
+            dz, ahn = dy, b["ahn"][i]
+            with timed("gemm_tn", 4.0 * n * fin * fout):
+                check(lib.gte_gemm_f32(1, 0, fout, fin, n, P(dz), fout, P(hin), ld(hin), P(gW), 2 * fin, 0, ws, wsn, st),
+                      "gte_gemm_f32 dW_self")
+                check(lib.gte_gemm_f32(1, 0, fout, fin, n, P(dz), fout, P(ahn), fin, P(gW) + 4 * fin, 2 * fin, 0, ws, wsn,
+                                       st), "gte_gemm_f32 dW_neigh")
+            if i > 0:
+                dh, dahn = b["dy"][i - 1], b["dahn"]
+                with timed("gemm_nn", 4.0 * n * fin * fout):
+                    check(lib.gte_gemm_f32(0, 0, n, fin, fout, P(dz), fout, P(W), 2 * fin, P(dh), fin, 0, ws, wsn, st),
+                          "gte_gemm_f32 dh_self")
+                    check(lib.gte_gemm_f32(0, 0, n, fin, fout, P(dz), fout, P(W) + 4 * fin, 2 * fin, P(dahn), fin, 0, ws,
+                                           wsn, st), "gte_gemm_f32 dh_neigh")
+                with timed("spmm_csr", 2.0 * n * fin * 4 + 8.0 * rcsr.indices.numel() + 4.0 * (n + 1)):
+                    check(lib.gte_spmm_csr_accumulate(P(rcsr.indptr), P(rcsr.indices), P(w_out), P(dahn), fin, P(dh), fin,
+                                                      n, fin, _lib.GTE_F32, _lib.REDUCE_SUM, st), "gte_spmm_csr bwd")
+        return b["out3"]
+
+    def step(self, g, labels: torch.Tensor, n_global: Optional[int] = None) -> torch.Tensor:
+        scale = float(labels.shape[0]) / float(n_global) if (self.distributed and n_global) else 1.0
+        out3 = self.forward_backward(g, labels, scale)
+        if self.distributed:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        self.t += 1
+        self._optimizer_step()
+        return out3
+
+    # -- HIP graph capture of a step on a RESIDENT batch ------------------------------------------------
+    def capture(self, g, labels: torch.Tensor, n_global: Optional[int] = None):
+        """Returns ``replay() -> out3``: forward+backward of this batch as one HIP-graph launch, followed
+        by the (eager) all-reduce and Adam launch.  The batch's tensors must stay alive and unchanged in
+        place (resident pages).  Adam stays outside the graph because its bias correction depends on the
+        step count, a host scalar."""
+        scale = float(labels.shape[0]) / float(n_global) if (self.distributed and n_global) else 1.0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up on the side stream: buffers, CSR caches, props
+            for _ in range(2):
+                self.forward_backward(g, labels, scale)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out3 = self.forward_backward(g, labels, scale)
+
+        def replay():
+            graph.replay()
+            if self.distributed:
+                import torch.distributed as dist
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.t += 1
+            self._optimizer_step()
+            return out3
+        self._graphs[id(g)] = graph
+        return replay
