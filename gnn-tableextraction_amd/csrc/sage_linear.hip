@@ -23,9 +23,23 @@
 //   blockIdx is remapped so that the tiles sharing an A row-panel run on one XCD (its L2 keeps it).
 #include "gte_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace {
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [0, N).  The staging registers are
+// arrays indexed by chunk number; a runtime index (even one that unrolls to a constant later) lets
+// hipcc demote them to scratch/LDS ("promote alloca"), so every chunk index is a template constant.
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
@@ -49,15 +63,20 @@ struct GemmParams {
 };
 
 // ---- staging: one BMxBK (or BKxBM) operand tile, global -> regs -> LDS ---------------------------
-// Guarded 16-byte loads WITHOUT branches: the address of every chunk is clamped into its contiguous
-// run (row of A / k-row of B), so the load itself is unconditional and all loads of a stage issue
-// back to back (a first version with `if (in range) load` compiled to one exec-masked branch per
-// chunk with s_waitcnt vmcnt(0) inside it: eight serialised memory round trips per K stage).
-// A chunk that straddles the end of its run is loaded from run_len-4 and shifted; the shift/zero
-// selects are applied when the registers are written to LDS (after the wait), from `meta`:
+// Everything that does not depend on the K position is computed ONCE per K segment (init): the
+// per-chunk row pointers (clamped into the matrix, so every load is in bounds and unconditional) and,
+// for row-contiguous operands, the shift of a chunk that straddles the last row.  Inside the K loop an
+// interior stage is just `pointer + k offset -> global_load_dwordx4 -> ds_write_b128`; only the last
+// K tile of a segment (K % 32 != 0) and the edge M/N tiles take the guarded path, selected by a
+// block-uniform flag.  (Measured on the first version, which recomputed addresses and guards per
+// chunk per stage: ~300 VALU instructions per stage per wave beside 32 MFMAs kept the MFMA pipe at
+// 62 % busy; and a version with `if (in range) load` serialised the loads -- one exec-masked branch
+// with s_waitcnt vmcnt(0) per chunk.)
+// Rows past the end of the matrix are NOT zeroed: they only feed accumulator rows/columns that the
+// epilogue never stores.  K positions past the end ARE zeroed (they feed every output).
 //   meta = s in 0..3 : element j of the chunk is loaded[j + s] (zero if j + s > 3);  meta >= 4 : zeros.
-// Requires every run to hold >= 4 floats (the host routes smaller shapes to gemm_small_kernel).
-__device__ __forceinline__ float4 shift_chunk(const float4 t, int s) {
+// Requires every contiguous run to hold >= 4 floats (the host routes smaller shapes to gemm_small_kernel).
+__device__ __forceinline__ float4 shift_chunk(const f4u t, int s) {
     float4 v;
     v.x = s == 0 ? t.x : s == 1 ? t.y : s == 2 ? t.z : s == 3 ? t.w : 0.f;
     v.y = s == 0 ? t.y : s == 1 ? t.z : s == 2 ? t.w : 0.f;
@@ -66,63 +85,92 @@ __device__ __forceinline__ float4 shift_chunk(const float4 t, int s) {
     return v;
 }
 
-// K-contiguous source ([rows][K], ld): thread t loads float4 chunks (row = c / 8, kq = c % 8).
+// K-contiguous source ([rows][K], ld): chunk c -> (row = c / 8, kq = c % 8), 4 consecutive k.
 template <int ROWS>
 struct StageK {
     static constexpr int CHUNKS = ROWS * (BK / 4);
     static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
+    const float* base[PER_THREAD];      // &src[row][kq*4], row clamped
     f4u r[PER_THREAD];
     int meta[PER_THREAD];
-    __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int row0, int nrows, int k0,
-                                         int kend, int tid) {
+    __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int row0, int nrows, int tid) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int c = min(tid + i * 256, CHUNKS - 1);
-            const int row = row0 + c / (BK / 4);
-            const int k = k0 + (c % (BK / 4)) * 4;
-            const int kk = min(k, kend - 4);
-            meta[i] = (row < nrows && k < kend) ? k - kk : 4;
-            r[i] = *reinterpret_cast<const f4u*>(src + (int64_t)min(row, nrows - 1) * ld + kk);
+            base[i] = src + (int64_t)min(row0 + c / (BK / 4), nrows - 1) * ld + (c % (BK / 4)) * 4;
         }
     }
-    __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int c = tid + i * 256;
-            if (CHUNKS % 256 == 0 || c < CHUNKS)
-                *reinterpret_cast<float4*>(lds + (c / (BK / 4)) * KPAD + (c % (BK / 4)) * 4) =
-                    shift_chunk(make_float4(r[i].x, r[i].y, r[i].z, r[i].w), meta[i]);
+    __device__ __forceinline__ bool row_edge() const { return false; }
+    // one chunk of the tile starting at k = kl of a segment of length kseg; k_edge = (kl + BK > kseg), uniform
+    template <int i>
+    __device__ __forceinline__ void load_chunk(int kl, int kseg, bool k_edge, int tid) {
+        if (!k_edge) {
+            r[i] = *reinterpret_cast<const f4u*>(base[i] + kl);
+        } else {
+            const int c = min(tid + i * 256, CHUNKS - 1);
+            const int k = kl + (c % (BK / 4)) * 4;
+            const int kk = min(k, kseg - 4);
+            meta[i] = k < kseg ? k - kk : 4;
+            r[i] = *reinterpret_cast<const f4u*>(base[i] + kl + (kk - k));
+        }
+    }
+    template <int i>
+    __device__ __forceinline__ void store_chunk(float* __restrict__ lds, bool edge, int tid) const {
+        const int c = tid + i * 256;
+        if (CHUNKS % 256 == 0 || c < CHUNKS) {
+            float4 v = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
+            if (edge) v = shift_chunk(r[i], meta[i]);
+            *reinterpret_cast<float4*>(lds + (c / (BK / 4)) * KPAD + (c % (BK / 4)) * 4) = v;
         }
     }
 };
 
-// Row-contiguous source ([K][rows], ld): chunk c -> (k = c / (ROWS/4), rq = c % (ROWS/4)).
+// Row-contiguous source ([K][rows], ld): chunk c -> (k = c / (ROWS/4), rq = c % (ROWS/4)), 4 consecutive rows.
 template <int ROWS>
 struct StageR {
     static constexpr int RPAD = ROWS + 4;
     static constexpr int CHUNKS = BK * (ROWS / 4);
     static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
+    const float* base[PER_THREAD];      // &src[kr][rr], rr = row clamped to nrows-4
+    int64_t ldk;
+    int shift[PER_THREAD];              // row - rr  (0 except in the chunk that straddles the last row)
+    bool any_shift;
     f4u r[PER_THREAD];
     int meta[PER_THREAD];
-    __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int row0, int nrows, int k0,
-                                         int kend, int tid) {
+    __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int row0, int nrows, int tid) {
+        ldk = ld;
+        any_shift = row0 + ROWS > nrows;                 // block-uniform: this tile holds the last rows
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int c = min(tid + i * 256, CHUNKS - 1);
-            const int k = k0 + c / (ROWS / 4);
             const int row = row0 + (c % (ROWS / 4)) * 4;
-            const int rr = min(row, nrows - 4);
-            meta[i] = (k < kend && row < nrows) ? row - rr : 4;
-            r[i] = *reinterpret_cast<const f4u*>(src + (int64_t)min(k, kend - 1) * ld + rr);
+            const int rr = max(min(row, nrows - 4), 0);
+            shift[i] = row < nrows ? row - rr : 4;
+            base[i] = src + (int64_t)(c / (ROWS / 4)) * ld + rr;
         }
     }
-    __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int c = tid + i * 256;
-            if (CHUNKS % 256 == 0 || c < CHUNKS)
-                *reinterpret_cast<float4*>(lds + (c / (ROWS / 4)) * RPAD + (c % (ROWS / 4)) * 4) =
-                    shift_chunk(make_float4(r[i].x, r[i].y, r[i].z, r[i].w), meta[i]);
+    __device__ __forceinline__ bool row_edge() const { return any_shift; }
+    template <int i>
+    __device__ __forceinline__ void load_chunk(int kl, int kseg, bool k_edge, int tid) {
+        if (!k_edge) {
+            r[i] = *reinterpret_cast<const f4u*>(base[i] + (int64_t)kl * ldk);
+            meta[i] = shift[i];
+        } else {
+            const int c = min(tid + i * 256, CHUNKS - 1);
+            const int kr = c / (ROWS / 4);
+            const int k = kl + kr;
+            const int kc = min(k, kseg - 1);
+            meta[i] = k < kseg ? shift[i] : 4;
+            r[i] = *reinterpret_cast<const f4u*>(base[i] + (int64_t)(kc - kr) * ldk);
+        }
+    }
+    template <int i>
+    __device__ __forceinline__ void store_chunk(float* __restrict__ lds, bool edge, int tid) const {
+        const int c = tid + i * 256;
+        if (CHUNKS % 256 == 0 || c < CHUNKS) {
+            float4 v = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
+            if (edge) v = shift_chunk(r[i], meta[i]);
+            *reinterpret_cast<float4*>(lds + (c / (ROWS / 4)) * RPAD + (c % (ROWS / 4)) * 4) = v;
         }
     }
 };
@@ -151,9 +199,11 @@ gemm_f32_mfma_kernel(const GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;          // 32x32 tiles per wave
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
     constexpr int A_FLOATS = lds_floats<BM>(AK), B_FLOATS = lds_floats<BN>(BKC);
+    // ONE LDS buffer (27-37 KB): 3-4 workgroups stay resident per CU, which hides the two barriers per
+    // K stage better than a double-buffered image at 2 workgroups per CU did (measured: see DESIGN.md)
     __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + B_FLOATS];
-    float* sA = lds;
-    float* sB = lds + A_FLOATS;
+    auto sAbuf = [&](int) -> float* { return lds; };
+    auto sBbuf = [&](int) -> float* { return lds + A_FLOATS; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -182,48 +232,80 @@ gemm_f32_mfma_kernel(const GemmParams p) {
     typename std::conditional<AK, StageK<BM>, StageR<BM>>::type stA;
     typename std::conditional<BKC, StageK<BN>, StageR<BN>>::type stB;
 
-    auto issue = [&](int t) {
-        const bool s1 = t >= tiles_seg0;
-        const int kl = (s1 ? t - tiles_seg0 : t) * BK;            // k inside the segment
-        const int kseg = s1 ? p.K2 : p.K1;
-        const float* a = s1 ? p.A2 : p.A1;
-        const int64_t lda = s1 ? p.lda2 : p.lda1;
-        stA.load(a, lda, m0, p.M, kl, kseg, tid);
-        // B(k, n): global k = segment base + kl; masked to the same kseg so padded k never multiplies
-        const int kb = s1 ? p.K1 : 0;
-        if constexpr (BKC) stB.load(p.B + kb, p.ldb, n0, p.N, kl, kseg, tid);
-        else stB.load(p.B + (int64_t)kb * p.ldb, p.ldb, n0, p.N, kl, kseg, tid);
+    // K segments: 0 = A1 / B rows-or-cols [0,K1), 1 = A2 / B [K1,K1+K2).  The hoisted pointers are
+    // (re)initialised when the prefetch crosses into segment 1 (at most once per block).
+    constexpr int NM = 4 * TM * TN;                       // MFMAs per k-group
+    constexpr int NCA = decltype(stA)::PER_THREAD, NCB = decltype(stB)::PER_THREAD;
+    int cur_seg = -1;
+    // tile being prefetched: position inside its segment, and whether it is that segment's K-tail tile
+    int pf_kl = 0, pf_kseg = 0;
+    bool pf_edge = false;       // K-tail flag of the tile whose loads are issued next
+    bool st_edge = false;       // ... of the tile sitting in the staging registers (next to be stored)
+    auto prefetch_setup = [&](int t) {                    // uniform scalar work + rare pointer re-init
+        const int seg = t >= tiles_seg0 ? 1 : 0;
+        if (seg != cur_seg) {
+            cur_seg = seg;
+            const int kb = seg ? p.K1 : 0;
+            stA.init(seg ? p.A2 : p.A1, seg ? p.lda2 : p.lda1, m0, p.M, tid);
+            if constexpr (BKC) stB.init(p.B + kb, p.ldb, n0, p.N, tid);
+            else stB.init(p.B + (int64_t)kb * p.ldb, p.ldb, n0, p.N, tid);
+        }
+        pf_kl = (seg ? t - tiles_seg0 : t) * BK;
+        pf_kseg = seg ? p.K2 : p.K1;
+        pf_edge = pf_kl + BK > pf_kseg;
+    };
+    auto load_chunk = [&](auto J) {                       // chunk J of the tile set up by prefetch_setup
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < NCA) stA.template load_chunk<j>(pf_kl, pf_kseg, pf_edge, tid);
+        else stB.template load_chunk<j - NCA>(pf_kl, pf_kseg, pf_edge, tid);
+    };
+    auto store_chunk = [&](auto J, int buf) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < NCA) stA.template store_chunk<j>(sAbuf(buf), st_edge || stA.row_edge(), tid);
+        else stB.template store_chunk<j - NCA>(sBbuf(buf), st_edge || stB.row_edge(), tid);
+    };
+    float fa[2][TM][4], fb[2][TN][4];
+    auto read_frags = [&](int buf, int kg, int slot) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) read_frag<AK, BM>(sAbuf(buf), (wm * TM + a) * 32, kg, lane, fa[slot][a]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) read_frag<BKC, BN>(sBbuf(buf), (wn * TN + b) * 32, kg, lane, fb[slot][b]);
+    };
+    auto mfma_one = [&](int slot, int j) {                // j -> (tt, a, b), b fastest: consecutive MFMAs hit different accumulators
+        const int b = j % TN, a = (j / TN) % TM, tt = j / (TN * TM);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][a][tt], fb[slot][b][tt], acc[a][b], 0, 0, 0);
+    };
+    auto mfma_group = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < NM; ++j) mfma_one(slot, j);
     };
 
-    if (t_begin < t_end) issue(t_begin);
+    // Per K stage: barrier | staging registers (tile t) -> LDS | barrier | issue the global loads of tile
+    // t+1 (they land under this stage's MFMAs) | 4 k-groups of MFMAs, the fragments of k-group g+1 being
+    // read while the MFMAs of k-group g run (sched_barrier pins "reads before the MFMAs they hide under").
+    // Tried and measured slower or equal on the page-batch shapes (profiles/r01/gemm_variants.md): LDS double
+    // buffering with one barrier per stage (2 workgroups/CU instead of 3-4), per-MFMA interleaving of the
+    // staging instructions, a start-time stagger of co-resident workgroups.
+    if (t_begin < t_end) {
+        prefetch_setup(t_begin);
+        static_for<NCA + NCB>([&](auto J) { load_chunk(J); });
+    }
     for (int t = t_begin; t < t_end; ++t) {
+        st_edge = pf_edge;
         __syncthreads();                       // previous tile's fragment reads are done
-        stA.store(sA, tid);
-        stB.store(sB, tid);
+        static_for<NCA + NCB>([&](auto J) { store_chunk(J, 0); });
         __syncthreads();
-        if (t + 1 < t_end) issue(t + 1);       // prefetch under the MFMAs
-        // fragments of k-group kg+1 are read from LDS while the MFMAs of k-group kg run
-        float fa[2][TM][4], fb[2][TN][4];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) read_frag<AK, BM>(sA, (wm * TM + a) * 32, 0, lane, fa[0][a]);
-#pragma unroll
-        for (int b = 0; b < TN; ++b) read_frag<BKC, BN>(sB, (wn * TN + b) * 32, 0, lane, fb[0][b]);
+        if (t + 1 < t_end) {                   // prefetch under the MFMAs
+            prefetch_setup(t + 1);
+            static_for<NCA + NCB>([&](auto J) { load_chunk(J); });
+        }
+        read_frags(0, 0, 0);
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
-            const int cur = kg & 1, nxt = cur ^ 1;
-            if (kg + 1 < BK / 8) {
-#pragma unroll
-                for (int a = 0; a < TM; ++a) read_frag<AK, BM>(sA, (wm * TM + a) * 32, kg + 1, lane, fa[nxt][a]);
-#pragma unroll
-                for (int b = 0; b < TN; ++b) read_frag<BKC, BN>(sB, (wn * TN + b) * 32, kg + 1, lane, fb[nxt][b]);
-            }
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][a][tt], fb[cur][b][tt], acc[a][b], 0, 0, 0);
+            if (kg + 1 < BK / 8) read_frags(0, kg + 1, (kg + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(kg & 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
