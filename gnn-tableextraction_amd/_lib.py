@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgte_hip.so")
+# GTE_LIB_PATH: profiling builds of the same ABI (e.g. ablation variants); default = the in-tree library
+LIB_PATH = os.environ.get("GTE_LIB_PATH") or os.path.join(_HERE, "libgte_hip.so")
 
 # name -> (restype, argtypes); mirrors include/gte.h declaration by declaration
 SIGNATURES = {
