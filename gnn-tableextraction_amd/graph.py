@@ -71,6 +71,11 @@ class PageGraph:
         self._out_csr: Optional[CSR] = None
         self._inv_deg: Optional[torch.Tensor] = None
         self._wcache: Dict[tuple, torch.Tensor] = {}
+        self._in_tiles = None
+        self._out_tiles = None
+        # LDS-staged aggregation needs per-tile distinct-source lists (one sort/unique per graph): worth it
+        # for graphs that are aggregated many times (resident batches, the validation graph, inference)
+        self.use_tiles = True
         self.batch_num_nodes_: List[int] = [self._n]
         self.batch_num_edges_: List[int] = [int(self._src.numel())]
 
@@ -143,6 +148,7 @@ class PageGraph:
         g._in_csr, g._out_csr = mv(self._in_csr), mv(self._out_csr)
         g._inv_deg = None if self._inv_deg is None else self._inv_deg.to(device)
         g._wcache = {}
+        g._in_tiles = g._out_tiles = None
         return g
 
     def update_all(self, message_func, reduce_func) -> None:
@@ -166,6 +172,27 @@ class PageGraph:
         if self._out_csr is None:
             self._out_csr = _build_csr(self._src, self._dst, self._n)
         return self._out_csr
+
+    TILES_MIN_NODES = 100_000      # tile plans only pay for graphs whose features overflow the caches (ops.use_tiled)
+
+    def _tiles(self, which: str):
+        if not self.use_tiles or not self._src.is_cuda or self._n < self.TILES_MIN_NODES:
+            return None
+        attr = "_in_tiles" if which == "in" else "_out_tiles"
+        plan = getattr(self, attr)
+        if plan is None:
+            from . import ops
+            csr = self.in_csr() if which == "in" else self.out_csr()
+            plan = ops.build_tile_plan(csr.indptr, csr.indices, self._n)
+            setattr(self, attr, plan)
+        return plan
+
+    def in_tiles(self):
+        """Tile plan of the in-edge CSR (forward aggregation) or None when tiling is off / not worthwhile."""
+        return self._tiles("in")
+
+    def out_tiles(self):
+        return self._tiles("out")
 
     def inv_in_degree(self) -> torch.Tensor:
         """norm of models.py:74-78 as a vector: 1/in_degree, 0 where the degree is 0 (fp32 [N])."""

@@ -158,6 +158,21 @@ class FusedGcnSageStep(TrainStep):
         ew = g.edata.get("feat")
         csr, rcsr = g.in_csr(), g.out_csr()
         w_in, w_out = g.in_weights(ew), g.out_weights(ew, True)
+        big = ops.use_tiled(n, max(f0, max(l.out_feats for l in self.model.layers)))
+        t_in, t_out = (g.in_tiles(), g.out_tiles()) if big else (None, None)
+
+        def aggregate(csr_, w_, tiles_, src, ldsrc, dst, lddst, f, reduce, accumulate):
+            nbytes = 2.0 * n * f * 4 + 8.0 * csr_.indices.numel() + 4.0 * (n + 1)
+            if tiles_ is not None and ops.use_tiled(n, f):
+                with timed("spmm_tiled", nbytes):
+                    check(lib.gte_spmm_csr_tiled(P(csr_.indptr), P(csr_.indices), P(tiles_.local_index), P(w_),
+                                                 P(tiles_.tile_ptr), P(tiles_.tile_src), P(src), ldsrc, P(dst), lddst,
+                                                 n, f, reduce, int(accumulate), st), "gte_spmm_csr_tiled")
+            else:
+                fn = lib.gte_spmm_csr_accumulate if accumulate else lib.gte_spmm_csr
+                with timed("spmm_csr", nbytes):
+                    check(fn(P(csr_.indptr), P(csr_.indices), P(w_), P(src), ldsrc, P(dst), lddst, n, f, _lib.GTE_F32,
+                             reduce, st), "gte_spmm_csr")
         ws, wsn = P(b["ws"]), b["ws"].numel()
         ld = ops._ld
 
@@ -169,9 +184,7 @@ class FusedGcnSageStep(TrainStep):
             ln = isinstance(L.lynorm, nn.LayerNorm)
             relu = L.activation is not None
             ahn, y = b["ahn"][i], b["y"][i]
-            with timed("spmm_csr", 2.0 * n * fin * 4 + 8.0 * csr.indices.numel() + 4.0 * (n + 1)):
-                check(lib.gte_spmm_csr(P(csr.indptr), P(csr.indices), P(w_in), P(h), ld(h), P(ahn), fin, n, fin,
-                                       _lib.GTE_F32, _lib.REDUCE_MEAN, st), "gte_spmm_csr")
+            aggregate(csr, w_in, t_in, h, ld(h), ahn, fin, fin, _lib.REDUCE_MEAN, False)
             lin_out = b["z"][i] if ln else y
             with timed("gemm_nt", 4.0 * n * fin * fout):
                 check(lib.gte_sage_linear_fwd(P(h), ld(h), fin, P(ahn), fin, fin, P(W), 2 * fin, P(bias), None, None,
@@ -221,9 +234,7 @@ class FusedGcnSageStep(TrainStep):
                           "gte_gemm_f32 dh_self")
                     check(lib.gte_gemm_f32(0, 0, n, fin, fout, P(dz), fout, P(W) + 4 * fin, 2 * fin, P(dahn), fin, 0, ws,
                                            wsn, st), "gte_gemm_f32 dh_neigh")
-                with timed("spmm_csr", 2.0 * n * fin * 4 + 8.0 * rcsr.indices.numel() + 4.0 * (n + 1)):
-                    check(lib.gte_spmm_csr_accumulate(P(rcsr.indptr), P(rcsr.indices), P(w_out), P(dahn), fin, P(dh), fin,
-                                                      n, fin, _lib.GTE_F32, _lib.REDUCE_SUM, st), "gte_spmm_csr bwd")
+                aggregate(rcsr, w_out, t_out, dahn, fin, dh, fin, fin, _lib.REDUCE_SUM, True)
         return b["out3"]
 
     def step(self, g, labels: torch.Tensor, n_global: Optional[int] = None) -> torch.Tensor:

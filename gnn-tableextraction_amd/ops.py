@@ -112,12 +112,72 @@ def inv_degree(indptr: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------
 # raw kernels
 # --------------------------------------------------------------------------------------------------
+class TilePlan:
+    """Per-tile distinct-source lists of a CSR (graph structure; see gte_spmm_csr_tiled)."""
+    __slots__ = ("tile_ptr", "tile_src", "local_index", "tile_rows", "max_unique")
+
+    def __init__(self, tile_ptr, tile_src, local_index, tile_rows, max_unique):
+        self.tile_ptr, self.tile_src, self.local_index = tile_ptr, tile_src, local_index
+        self.tile_rows, self.max_unique = tile_rows, max_unique
+
+
+def build_tile_plan(indptr: torch.Tensor, indices: torch.Tensor, n_rows: int) -> TilePlan:
+    """Distinct sources per tile of ``gte_spmm_tile_rows()`` destination rows.  Index bookkeeping on the
+    device (sort/unique through torch); done once per graph, reused by every layer / pass / epoch."""
+    R = _lib.load().gte_spmm_tile_rows()
+    dev = indptr.device
+    nnz = indices.numel()
+    ntiles = (n_rows + R - 1) // R
+    if nnz == 0:
+        z = torch.zeros(ntiles + 1, dtype=torch.int32, device=dev)
+        return TilePlan(z, torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int16, device=dev), R, 0)
+    deg = (indptr[1:] - indptr[:-1]).long()
+    row_of_edge = torch.repeat_interleave(torch.arange(n_rows, device=dev), deg)
+    tile_of_edge = row_of_edge // R
+    span = int(indices.max().item()) + 1
+    key = tile_of_edge * span + indices.long()
+    uniq, inv = torch.unique(key, return_inverse=True)                       # sorted by (tile, source)
+    tile_of_u = uniq // span
+    tile_ptr = torch.searchsorted(tile_of_u, torch.arange(ntiles + 1, device=dev)).to(torch.int32)
+    local = inv - tile_ptr.long()[tile_of_edge]
+    max_unique = int((tile_ptr[1:] - tile_ptr[:-1]).max().item())
+    return TilePlan(tile_ptr.contiguous(), (uniq % span).to(torch.int32).contiguous(),
+                    local.clamp(max=32767).to(torch.int16).contiguous(), R, max_unique)
+
+
+TILED_MIN_FEATS = 32      # narrower rows (9, 13 features) leave most of a 16-lane row group idle: plain kernel
+# The LDS-staged kernel wins once the gathered matrix no longer lives in L2 / Infinity Cache (measured on
+# MI355X: 1 M x 512 fp32 = 2 GB: 1.06 ms vs 1.81 ms; 1 M x 64 = 256 MB: 176 vs 220 us; a 100-page batch,
+# 80 MB: 57 us vs 46 us for the plain
+# kernel, whose re-fetches are then L2 hits).  Below this size the plain row-per-wave kernel runs.
+TILED_MIN_BYTES = 192 << 20
+
+
+def use_tiled(n_rows: int, n_feat: int) -> bool:
+    return n_feat >= TILED_MIN_FEATS and n_rows * n_feat * 4 >= TILED_MIN_BYTES
+
+
 def spmm_csr(indptr, indices, weight, x: torch.Tensor, n_rows: int, mean: bool = False,
-             out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """out[v] = scale_v * sum_e w[e] * x[indices[e]] over row v of the CSR (fp32 or bf16 features)."""
+             out: Optional[torch.Tensor] = None, accumulate: bool = False,
+             tiles: Optional[TilePlan] = None, force_tiled: bool = False) -> torch.Tensor:
+    """out[v] = scale_v * sum_e w[e] * x[indices[e]] over row v of the CSR (fp32 or bf16 features).
+    With a ``TilePlan`` (and fp32 rows of >= 32 features) the LDS-staged kernel runs instead."""
     require_device(x, "spmm_csr")
     lib = _lib.load()
     x = _row_major(x)
+    if tiles is not None and x.dtype == torch.float32 and (force_tiled or use_tiled(n_rows, x.shape[1])):
+        f = x.shape[1]
+        if out is None:
+            if accumulate:
+                raise ValueError("accumulate needs an output tensor")
+            out = torch.empty((n_rows, f), dtype=x.dtype, device=x.device)
+        nnz_bytes = 8.0 * indices.numel() if weight is not None else 4.0 * indices.numel()
+        with _timed("spmm_tiled", 2.0 * n_rows * f * 4 + nnz_bytes + 4.0 * (n_rows + 1)):
+            check(lib.gte_spmm_csr_tiled(ptr(indptr), ptr(indices), ptr(tiles.local_index), ptr(weight),
+                                         ptr(tiles.tile_ptr), ptr(tiles.tile_src), ptr(x), _ld(x), ptr(out), _ld(out),
+                                         n_rows, f, _lib.REDUCE_MEAN if mean else _lib.REDUCE_SUM, int(accumulate),
+                                         current_stream()), "gte_spmm_csr_tiled")
+        return out
     if x.dtype == torch.float32:
         dt = _lib.GTE_F32
     elif x.dtype == torch.bfloat16:
@@ -241,14 +301,16 @@ class _Aggregate(torch.autograd.Function):
     def forward(ctx, h, graph, w, mean):
         csr = graph.in_csr()
         ctx.graph, ctx.w, ctx.mean = graph, w, mean
-        return spmm_csr(csr.indptr, csr.indices, graph.in_weights(w), h, graph.num_nodes(), mean=mean)
+        return spmm_csr(csr.indptr, csr.indices, graph.in_weights(w), h, graph.num_nodes(), mean=mean,
+                        tiles=graph.in_tiles())
 
     @staticmethod
     def backward(ctx, dout):
         g = ctx.graph
         rcsr = g.out_csr()
         # d h[u] = sum_{e: u->v} w_e * norm_v * dout[v]   (norm folded into the out-edge weights)
-        dh = spmm_csr(rcsr.indptr, rcsr.indices, g.out_weights(ctx.w, ctx.mean), dout.contiguous(), g.num_nodes())
+        dh = spmm_csr(rcsr.indptr, rcsr.indices, g.out_weights(ctx.w, ctx.mean), dout.contiguous(), g.num_nodes(),
+                      tiles=g.out_tiles())
         return dh, None, None, None
 
 
@@ -273,7 +335,8 @@ class _SageLayer(torch.autograd.Function):
         ahn = None
         if not use_pp:
             csr = graph.in_csr()
-            ahn = spmm_csr(csr.indptr, csr.indices, graph.in_weights(w), h, graph.num_nodes(), mean=True)
+            ahn = spmm_csr(csr.indptr, csr.indices, graph.in_weights(w), h, graph.num_nodes(), mean=True,
+                           tiles=graph.in_tiles())
         y, z, stats = sage_linear_fwd(h, ahn, weight, bias, gamma, beta, eps, relu, need_grad)
         ctx.graph, ctx.w, ctx.relu, ctx.use_pp = graph, w, relu, use_pp
         ctx.has_bias, ctx.has_ln = bias is not None, gamma is not None
@@ -307,7 +370,7 @@ class _SageLayer(torch.autograd.Function):
                 g = ctx.graph
                 rcsr = g.out_csr()
                 spmm_csr(rcsr.indptr, rcsr.indices, g.out_weights(ctx.w, True), dahn, g.num_nodes(), out=dh,
-                         accumulate=True)
+                         accumulate=True, tiles=g.out_tiles())
         return dh, dweight, dbias, dgamma, dbeta, None, None, None, None, None
 
 

@@ -68,6 +68,22 @@ int gte_spmm_csr_accumulate(const int32_t* indptr, const int32_t* indices, const
                             const void* x, int64_t ldx, void* out, int64_t ldo,
                             int64_t n_rows, int64_t n_feat, int dtype, int reduce, void* stream);
 
+/* LDS-staged variant of the same contraction for graphs with locality (page graphs: consecutive
+ * destination rows share most sources).  A workgroup owns a tile of gte_spmm_tile_rows() consecutive
+ * destination rows, stages the tile's DISTINCT source rows in LDS once per 32-float feature chunk and
+ * reduces from LDS in CSR order (bit-identical to gte_spmm_csr).  Tile metadata is graph structure,
+ * built once per graph by the caller:
+ *   tile_ptr    int32[n_tiles+1]  offsets into tile_src        (n_tiles = ceil(n_rows / tile_rows))
+ *   tile_src    int32[...]        distinct source rows of each tile
+ *   local_index uint16[nnz]       position of indices[e] inside its tile's tile_src segment
+ * Tiles with more than 128 distinct sources or 512 edges are gathered directly (no size limit on the
+ * graph).  fp32 only.  accumulate != 0: out += ... */
+int gte_spmm_tile_rows(void);
+int gte_spmm_csr_tiled(const int32_t* indptr, const int32_t* indices, const uint16_t* local_index,
+                       const float* eweight, const int32_t* tile_ptr, const int32_t* tile_src,
+                       const float* x, int64_t ldx, float* out, int64_t ldo,
+                       int64_t n_rows, int64_t n_feat, int reduce, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Graph preparation (what DGL does lazily per batched graph before gSpMM / its backward)
  * replaces  dgl.graph((u,v)) COO->CSC build (builder.py:425) and the reverse-CSR build DGL

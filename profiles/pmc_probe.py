@@ -26,7 +26,8 @@ elif what == "spmm":
     src, dst, w = S.make_knn_stress_graph(n, k)
     indptr, indices, perm, wout = ops.coo_to_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, torch.from_numpy(w).to(dev))
     x = torch.randn(n, f, device=dev); out = torch.empty_like(x)
-    fn = lambda: ops.spmm_csr(indptr, indices, wout, x, n, mean=True, out=out)
+    plan = ops.build_tile_plan(indptr, indices, n) if os.environ.get("GTE_TILED", "1") == "1" else None
+    fn = lambda: ops.spmm_csr(indptr, indices, wout, x, n, mean=True, out=out, tiles=plan, force_tiled=True)
 for _ in range(reps):
     fn()
 torch.cuda.synchronize()

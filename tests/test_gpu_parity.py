@@ -430,3 +430,79 @@ def test_fused_step_graph_replay_is_bitwise_the_eager_step():
         assert torch.equal(la, lb)
     assert torch.equal(a.flat_param, b.flat_param)
     assert float(la[0]) < 2.2                                  # the loss goes down from ln(9)
+
+
+# ---------------------------------------------------------------- LDS-staged (tiled) aggregation
+@pytest.mark.parametrize("f", [32, 63, 64, 100, 256, 512, 831])
+@pytest.mark.parametrize("mean", [False, True])
+def test_spmm_tiled_is_bitwise_the_plain_kernel(f, mean):
+    """Same CSR order => the LDS-staged kernel must reproduce the row-per-wave kernel bit for bit,
+    on a page-like graph (locality), with hub rows (direct-gather tiles) and an empty row."""
+    pages = S.make_pages(40, in_feats=13)
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    n = int(off[-1])
+    rng = np.random.default_rng(f)
+    hub_src = rng.integers(0, n, 3000)                         # row 100: 3000 extra in-edges (> EMAX)
+    far_src = rng.integers(0, n, 40 * 30)                      # rows 2000..2029: 40 random far sources each (> UMAX)
+    src = np.concatenate([src, hub_src, far_src])
+    dst = np.concatenate([dst, np.full(3000, 100), np.repeat(np.arange(2000, 2030), 40)])
+    w = np.concatenate([w, rng.random(len(src) - len(w)).astype(np.float32)])
+    g = oc.OracleGraph(src, dst, n, w)
+    ip, ix, wt = dev(g.indptr), dev(g.indices), dev(g.weight)
+    x = dev(rng.standard_normal((n, f)).astype(np.float32))
+    plan = ops.build_tile_plan(ip, ix, n)
+    assert plan.max_unique > 128                                # both the staged and the direct path are exercised
+    a = ops.spmm_csr(ip, ix, wt, x, n, mean=mean)
+    b = ops.spmm_csr(ip, ix, wt, x, n, mean=mean, tiles=plan, force_tiled=True)
+    assert torch.equal(a, b)
+    c = ops.spmm_csr(ip, ix, None, x, n, mean=mean, tiles=plan, force_tiled=True)
+    assert torch.equal(c, ops.spmm_csr(ip, ix, None, x, n, mean=mean))
+    base = torch.randn(n, f, device=DEV)
+    o1, o2 = base.clone(), base.clone()
+    ops.spmm_csr(ip, ix, wt, x, n, mean=mean, out=o1, accumulate=True)
+    ops.spmm_csr(ip, ix, wt, x, n, mean=mean, out=o2, accumulate=True, tiles=plan, force_tiled=True)
+    assert torch.equal(o1, o2)
+
+
+def test_tile_plan_contract_and_oracle_parity():
+    pages = S.make_pages(30, in_feats=13)
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    n = int(off[-1])
+    g = oc.OracleGraph(src, dst, n, w)
+    ip, ix = dev(g.indptr), dev(g.indices)
+    plan = ops.build_tile_plan(ip, ix, n)
+    R = plan.tile_rows
+    tp, ts, li = plan.tile_ptr.cpu().numpy(), plan.tile_src.cpu().numpy(), plan.local_index.cpu().numpy()
+    assert len(tp) == (n + R - 1) // R + 1 and tp[0] == 0 and tp[-1] == len(ts)
+    for t in range(0, len(tp) - 1, 7):
+        e0, e1 = g.indptr[t * R], g.indptr[min((t + 1) * R, n)]
+        seg = ts[tp[t]:tp[t + 1]]
+        np.testing.assert_array_equal(seg, np.unique(g.indices[e0:e1]))            # distinct, sorted
+        np.testing.assert_array_equal(seg[li[e0:e1]], g.indices[e0:e1])            # local index round trip
+    x = np.random.default_rng(0).standard_normal((n, 96)).astype(np.float32)
+    want = oc.spmm_csr_numpy(g.indptr, g.indices, g.weight, x) * g.norm
+    got = ops.spmm_csr(ip, ix, dev(g.weight), dev(x), n, mean=True, tiles=plan, force_tiled=True).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+
+
+def test_model_with_and_without_tiles_is_bitwise_identical():
+    pages = S.make_pages(40, in_feats=63)
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    torch.manual_seed(3)
+    model = gte.GcnSAGE(63, 128, 9, 3, torch.nn.functional.relu, 0).to(DEV)
+    outs = []
+    monkey = (G.PageGraph.TILES_MIN_NODES, ops.TILED_MIN_BYTES)
+    G.PageGraph.TILES_MIN_NODES, ops.TILED_MIN_BYTES = 1, 1            # force the tiled path at test size
+    for use in (True, False):
+        g = G.PageGraph(src, dst, int(off[-1]), device=DEV)
+        g.use_tiles = use
+        g.ndata["feat"], g.edata["feat"] = dev(feat), dev(w)
+        logits = model(g)
+        logits.square().mean().backward()
+        outs.append((logits.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+        model.zero_grad()
+        assert (g.in_tiles() is not None) == use
+    G.PageGraph.TILES_MIN_NODES, ops.TILED_MIN_BYTES = monkey
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
