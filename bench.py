@@ -33,6 +33,16 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # fp32 matrix peak (dense)
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN/pmc_traffic.json: how they
+    were collected is in that file).  PMC counters cannot be read from inside this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if not files:
+        return {}, None
+    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,7 +149,9 @@ def gather_probe(args, gte, S, dev):
             "kernel": "spmm_tiled_kernel (LDS-staged distinct sources)", "plain_kernel_ms": ms_plain,
             "plain_kernel_GBs": alg_bytes / (ms_plain * 1e-3) / 1e9, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms_per_pass": ms, "algorithmic_bytes": alg_bytes,
-            "nodes_per_s_per_pass": n / (ms * 1e-3), "traffic": None}
+            "nodes_per_s_per_pass": n / (ms * 1e-3),
+            "traffic": pmc_traffic()[0].get("gather_cfg4_tiled_bytes_per_launch") if n == 1_000_000 else None,
+            "traffic_source": pmc_traffic()[1]}
 
 
 def main():
@@ -227,7 +239,10 @@ def main():
         tf = (flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel<NT> (layer transforms, forward)",
                     "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-                    "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1), "traffic": None}
+                    "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
+                    "algorithmic_flops_per_launch": flops / max(n_launch, 1),
+                    "traffic": pmc_traffic()[0].get("gemm_nt_bytes_per_launch") if args.in_feats == 831 else None,
+                    "traffic_source": pmc_traffic()[1]}
         per_kernel = {}
         for tag, (n, tms, work) in kt.items():
             unit = "GB/s" if tag == "spmm_csr" else "TFLOP/s"
