@@ -338,14 +338,33 @@ gemm_f32_mfma_kernel(const GemmParams p) {
     }
 }
 
-// C[m][n] (+)= bias[n] + sum_s slab[s][m][n]   -- fixed order, deterministic
-__global__ void __launch_bounds__(256)
+// C[m][n] (+)= bias[n] + sum_s slab[s][m][n]   -- fixed order, deterministic.
+// A block folds 32 consecutive output elements; its 8 split-lanes each sum every 8th slab (independent
+// loads in flight, 128-B coalesced over the elements), then the 8 partials are added in lane order through
+// LDS.  (First version: one thread per element looping over all slabs -- with a 9 x 256 output and hundreds
+// of slabs that was 9 workgroups chasing one load at a time: 18 us per launch, 9 launches per step.)
+constexpr int RED_E = 32, RED_S = 8;
+__global__ void __launch_bounds__(RED_E * RED_S)
 splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t mn, int N, float* __restrict__ C, int64_t ldc,
                      const float* __restrict__ bias, int accumulate, int relu) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += stride) {
+    __shared__ float part[RED_S][RED_E];
+    const int e = threadIdx.x % RED_E, sl = threadIdx.x / RED_E;
+    const int64_t i = (int64_t)blockIdx.x * RED_E + e;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < mn) {
+        int k = sl;
+        for (; k + RED_S < splits; k += 2 * RED_S) {
+            s0 += slab[(int64_t)k * mn + i];
+            s1 += slab[(int64_t)(k + RED_S) * mn + i];
+        }
+        if (k < splits) s0 += slab[(int64_t)k * mn + i];
+    }
+    part[sl][e] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && i < mn) {
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * mn + i];
+#pragma unroll
+        for (int q = 0; q < RED_S; ++q) s += part[q][e];
         const int64_t m = i / N;
         const int n = (int)(i - m * N);
         if (bias) s += bias[n];
@@ -353,6 +372,80 @@ splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t mn, int
         if (accumulate) s += *dst;
         if (relu) s = fmaxf(s, 0.f);
         *dst = s;
+    }
+}
+
+// ------------------------------- skinny GEMMs (class-count-sized dimension) -----------------------
+// The last layer has n_classes = 9 outputs.  Its dW = dZ^T X is a [9 x F] result reduced over all nodes and
+// its dX = dZ W has an inner dimension of 9: both are HBM-bound (read or write one [N, F] matrix) with
+// ~18 flop/byte, and a 32-wide MFMA tile would spend 72 % of its rows on padding.  Plain fp32 FMA chains.
+constexpr int SK_MAX = 16;         // skinny dimension bound
+constexpr int SK_ROWS = 32;        // k rows (nodes) per block of the TN kernel: ~N/32 blocks fill the chip
+
+// C[m][n] = sum_k A[k][m] * B[k][n],  m < M <= 16;  A stored [K][M] (lda), B stored [K][N] (ldb).
+// One thread per column n (coalesced B rows, all SK_ROWS loads of a thread in flight at once); the block's
+// A rows are staged in LDS and read back as broadcasts.  Partial sums of the block's k-chunk go to
+// slab[blockIdx.y][m][n]; splitk_reduce_kernel folds them in a fixed order (deterministic, no atomics).
+__global__ void __launch_bounds__(256)
+gemm_tn_skinny_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                      float* __restrict__ slab, int M, int N, int K) {
+    __shared__ float sA[SK_ROWS][SK_MAX];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int k0 = blockIdx.y * SK_ROWS, nk = min(SK_ROWS, K - k0);
+    for (int i = threadIdx.x; i < SK_ROWS * SK_MAX; i += 256) {
+        const int r = i / SK_MAX, c = i % SK_MAX;
+        sA[r][c] = (r < nk && c < M) ? A[(int64_t)(k0 + r) * lda + c] : 0.f;
+    }
+    float b[SK_ROWS];
+    const int nn = min(n, N - 1);
+#pragma unroll
+    for (int r = 0; r < SK_ROWS; ++r) b[r] = B[(int64_t)(k0 + min(r, nk - 1)) * ldb + nn];
+    __syncthreads();
+    float acc[SK_MAX];
+#pragma unroll
+    for (int i = 0; i < SK_MAX; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < SK_ROWS; ++r) {
+#pragma unroll
+        for (int i = 0; i < SK_MAX; ++i) acc[i] = fmaf(sA[r][i], b[r], acc[i]);   // rows >= nk hold zeros in sA
+    }
+    if (n < N) {
+        float* out = slab + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+        for (int i = 0; i < SK_MAX; ++i)
+            if (i < M) out[(int64_t)i * N + n] = acc[i];
+    }
+}
+
+// C[m][n] (+)= sum_k A[m][k] * B[k][n],  K <= 16;  A stored [M][K] (lda), B stored [K][N] (ldb).
+// One thread per 4 consecutive columns (16-byte loads of B and stores of C, 4-byte aligned is enough on
+// gfx950); the K x N operand B is small (<= 16 rows) and stays in L1/L2; A's row is a wave-wide broadcast.
+__global__ void __launch_bounds__(256)
+gemm_nn_skinny_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                      float* __restrict__ C, int64_t ldc, int M, int N, int K, int accumulate) {
+    const int nq = (N + 3) / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * nq) return;
+    const int m = (int)(idx / nq), n = (int)(idx % nq) * 4;
+    const float* a = A + (int64_t)m * lda;
+    float* c = C + (int64_t)m * ldc + n;
+    if (n + 3 < N) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < K; ++k) {
+            const float av = a[k];
+            const f4u b = *reinterpret_cast<const f4u*>(B + (int64_t)k * ldb + n);
+            acc.x = fmaf(av, b.x, acc.x); acc.y = fmaf(av, b.y, acc.y);
+            acc.z = fmaf(av, b.z, acc.z); acc.w = fmaf(av, b.w, acc.w);
+        }
+        if (accumulate) { const f4u o = *reinterpret_cast<const f4u*>(c); acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        f4u o; o.x = acc.x; o.y = acc.y; o.z = acc.z; o.w = acc.w;
+        *reinterpret_cast<f4u*>(c) = o;
+    } else {
+        for (int j = 0; n + j < N; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < K; ++k) acc = fmaf(a[k], B[(int64_t)k * ldb + n + j], acc);
+            c[j] = accumulate ? c[j] + acc : acc;
+        }
     }
 }
 
@@ -405,6 +498,9 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2) {
         const int64_t c128 = gte::ceil_div(t128, cus) * 2, c64 = gte::ceil_div(t64, cus);
         pl.bn = 128;
         pl.bm = (t128 >= cus && c64 * 10 < c128 * 9) ? 64 : 128;
+        // split-K with very few output tiles (dW of a 256 x 256 layer: 4 tiles over 24 k nodes): smaller tiles ->
+        // half the K splits -> half the slab bytes (measured 58 -> 44 us; at 14 tiles, 256 x 831, it loses: 147 -> 161)
+        if (t128 <= 8 && M >= 64) pl.bm = 64;
     }
     pl.tiles = (int)(gte::ceil_div(M, pl.bm) * gte::ceil_div(N, pl.bn));
     const int ktiles = (int)(gte::ceil_div(K1, BK) + gte::ceil_div(K2, BK));
@@ -468,9 +564,8 @@ int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace
     if (rc != GTE_OK) return rc;
     if (pl.splits > 1) {
         const int64_t mn = (int64_t)p.M * p.N;
-        const int64_t blocks = gte::ceil_div(mn, 256) < 4096 ? gte::ceil_div(mn, 256) : 4096;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slab, pl.splits, mn, p.N, p.C,
-                           p.ldc, p.bias, accumulate, relu);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gte::ceil_div(mn, RED_E)), dim3(RED_E * RED_S), 0, s, p.slab,
+                           pl.splits, mn, p.N, p.C, p.ldc, p.bias, accumulate, relu);
         return gte::check_launch("gemm_f32 split-K reduce");
     }
     return GTE_OK;
@@ -722,7 +817,11 @@ int ln_bwd_blocks(int64_t M) {
 }  // namespace
 
 // ------------------------------------------ C ABI -------------------------------------------------
-extern "C" int64_t gte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) { return gemm_workspace(M, N, K, 0); }
+extern "C" int64_t gte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    const int64_t mfma = gemm_workspace(M, N, K, 0);
+    const int64_t skinny = (M > 0 && M <= SK_MAX) ? gte::round_up(gte::ceil_div(K > 0 ? K : 1, SK_ROWS) * M * N * 4, 256) : 0;
+    return mfma > skinny ? mfma : skinny;
+}
 
 extern "C" int gte_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                             const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate, void* workspace,
@@ -733,11 +832,32 @@ extern "C" int gte_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int6
     if (!A || !B || !C) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_f32: null pointer");
     if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_f32: leading dimension too small");
+    hipStream_t s = gte::as_stream(stream);
+    if (trans_a && !trans_b && M <= SK_MAX && K >= 4 * SK_ROWS) {          // dW of a class-count-sized layer
+        const int splits = (int)gte::ceil_div(K, SK_ROWS);
+        const int64_t need = (int64_t)splits * M * N * 4;
+        if (!workspace || workspace_bytes < need)
+            return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "gemm_f32 (skinny TN): workspace %lld < %lld",
+                             (long long)workspace_bytes, (long long)need);
+        float* slab = reinterpret_cast<float*>(workspace);
+        hipLaunchKernelGGL(gemm_tn_skinny_kernel, dim3((unsigned)gte::ceil_div(N, 256), (unsigned)splits), dim3(256), 0, s,
+                           A, lda, B, ldb, slab, (int)M, (int)N, (int)K);
+        const int64_t mn = M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gte::ceil_div(mn, RED_E)), dim3(RED_E * RED_S), 0, s, slab,
+                           splits, mn, (int)N, C, ldc, (const float*)nullptr, accumulate ? 1 : 0, 0);
+        return gte::check_launch("gemm_f32 skinny TN");
+    }
+    if (!trans_a && !trans_b && K <= SK_MAX) {                              // dX through a class-count-sized layer
+        const int64_t work = M * gte::ceil_div(N, 4);
+        hipLaunchKernelGGL(gemm_nn_skinny_kernel, dim3((unsigned)gte::ceil_div(work, 256)), dim3(256), 0, s, A, lda, B, ldb, C,
+                           ldc, (int)M, (int)N, (int)K, accumulate ? 1 : 0);
+        return gte::check_launch("gemm_f32 skinny NN");
+    }
     GemmParams p = {};
     p.A1 = A; p.lda1 = lda; p.K1 = (int)K; p.A2 = nullptr; p.lda2 = 0; p.K2 = 0;
     p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = nullptr; p.M = (int)M; p.N = (int)N;
     p.relu = 0; p.accumulate = accumulate ? 1 : 0;
-    return run_gemm(!trans_a, trans_b != 0, p, workspace, workspace_bytes, gte::as_stream(stream));
+    return run_gemm(!trans_a, trans_b != 0, p, workspace, workspace_bytes, s);
 }
 
 extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2,

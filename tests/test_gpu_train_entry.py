@@ -1,0 +1,75 @@
+"""End-to-end on an MI355X: the reference-compatible entry points train(data, config) and test(data, config)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gnn_tableextraction_amd.components.graphs.loader import PrebuiltPages
+from gnn_tableextraction_amd.models import model_predict, model_train
+from gnn_tableextraction_amd.parsers.graphs import parse_args_ModelTrain
+from gnn_tableextraction_amd.utils.config import logs_from_config
+
+pytestmark = pytest.mark.gpu
+
+
+def make_cfg(tmp_path, **flags):
+    argv = ["--mode=knn", "--features", "BBOX", "--n_layers=3", "--mode_params=fixed", "--h_layer_dim=64",
+            "--batch_size=8", "--n_epochs=4", "--lr=0.01", "--output_dir", str(tmp_path)]
+    for k, v in flags.items():
+        argv += [f"--{k}", str(v)]
+    return parse_args_ModelTrain(argv=argv)
+
+
+def learnable_pages(n_pages):
+    """Synthetic pages whose label is a function of the geometry features, so training has signal."""
+    data = PrebuiltPages.synthetic(n_pages, in_feats=13)
+    for p, g in zip(data.page_arrays, data.graphs):
+        y = (p.feat[:, 1] // 260).astype(np.int64).clip(0, 8)          # y0 band of the word -> class
+        p.label[:] = y
+        g.ndata['label'] = torch.from_numpy(y.astype(np.float32))
+    return data
+
+
+def test_train_writes_reference_layout_and_learns(tmp_path):
+    data = learnable_pages(48)
+    cfg = make_cfg(tmp_path)
+    metrics = model_train.train(data, cfg)
+    logs = logs_from_config(cfg)
+    assert os.path.isfile(tmp_path / "weights" / f"{logs}.pt")
+    assert os.path.isfile(tmp_path / "checkpoints" / logs)
+    res = json.load(open(tmp_path / "results" / f"{logs}.json"))[logs]
+    assert set(res) == {"train_loss", "train_acc", "val_loss", "val_acc", "cell_f1", "header_f1"}
+    assert metrics.val.loss < np.log(9.0)                              # better than uniform
+    ck = torch.load(tmp_path / "checkpoints" / logs, weights_only=False)
+    assert ck["epoch"] == 4 and set(ck) == {"epoch", "state_dict", "optimizer", "metrics"}
+    assert sorted(ck["state_dict"]) == ["layers.0.linear.bias", "layers.0.linear.weight", "layers.0.lynorm.bias",
+                                        "layers.0.lynorm.weight", "layers.1.linear.bias", "layers.1.linear.weight",
+                                        "layers.1.lynorm.bias", "layers.1.lynorm.weight", "layers.2.linear.bias",
+                                        "layers.2.linear.weight"]
+    # torch.optim.Adam can load the optimizer state (checkpoint compatibility with the reference's format)
+    from gnn_tableextraction_amd import GcnSAGE
+    m = GcnSAGE(13, 64, 9, 3, torch.nn.functional.relu, 0)
+    m.load_state_dict(ck["state_dict"])
+    torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=5e-4).load_state_dict(ck["optimizer"])
+
+    # resume: two more epochs from the checkpoint
+    cfg2 = make_cfg(tmp_path, n_epochs=6, from_checkpoint="true")
+    m2 = model_train.train(data, cfg2)
+    assert torch.load(tmp_path / "checkpoints" / logs, weights_only=False)["epoch"] == 6
+    assert m2.val.loss <= metrics.val.loss + 0.05
+
+    # inference entry point with the saved best weights
+    out = model_predict.test(data, cfg2)
+    assert len(out["all_pred"]) == len(data) and out["accuracy"] > 0.3
+    assert os.path.isfile(tmp_path / "predictions" / f"{logs}.pkl")
+    one_by_one = make_cfg(tmp_path, n_epochs=6, batch_size=1)
+    one_by_one.TRAINING.batch_size = 8                                  # same run name (bt_8) -> same weights file
+    cfg2.TRAINING.batch_size = 8
+    a = model_predict.test(data, cfg2, save_predictions=False)
+    cfg2.TRAINING.batch_size = 1                                        # one forward per page, as the reference does
+    w = os.path.join(str(tmp_path), "weights", f"{logs}.pt")
+    b = model_predict.test(data, cfg2, weights_path=w, save_predictions=False)
+    for pa, pb in zip(a["all_pred"], b["all_pred"]):
+        np.testing.assert_array_equal(pa, pb)                           # batching pages does not change predictions
