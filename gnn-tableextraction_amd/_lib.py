@@ -28,10 +28,19 @@ SIGNATURES = {
     "gte_coo_to_csr_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "gte_coo_to_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gte_batch_csr": (c_int, [c_void_p, c_int64] + [c_void_p] * 10 + [c_int64, c_int64, c_void_p]),
+    "gte_batch_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                               c_int64, c_void_p]),
+    "gte_edge_weights_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "gte_edge_weights_bbox": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                                      c_int64, c_void_p]),
     "gte_inv_degree": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_sage_linear_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                     c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "gte_sage_linear_dw_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
+    "gte_sage_linear_dw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                   c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gte_ln_relu_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p,
                                 c_int64, c_int64, c_void_p]),
     "gte_ln_relu_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),

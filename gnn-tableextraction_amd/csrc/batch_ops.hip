@@ -1,0 +1,168 @@
+// Device-side batching of resident page graphs and the edge-weight computation.
+//
+// replaces, per training step,
+//   dgl.batch(train_batch).to(device)                       src/models/model_train.py:297  (block-diagonal union)
+//   the host->device copy of every tensor the batch carries  src/models/model_train.py:297-298
+// and, at data-preparation time,
+//   edata['feat'] = 1 - distance(bbox_u, bbox_v) / max_e distance   src/components/graphs/loader.py:332-344
+//   with distance() of src/components/graphs/utils.py:56-88 (integer pixel distances, int(sqrt(.)) on diagonals).
+//
+// Dataset layout in HBM (all pages of the dataset concatenated once; "resident pages"):
+//   node_off[P+1], edge_off[P+1]        int32   page p owns nodes [node_off[p], node_off[p+1]) and CSR entries
+//                                               [edge_off[p], edge_off[p+1])
+//   indptr_loc[Ntot + P]                int32   per page its own indptr (n_p + 1 entries, starting at 0), packed:
+//                                               page p's indptr starts at node_off[p] + p
+//   indices_loc[Etot]                   int32   column ids LOCAL to the page
+//   weight[Etot]                        f32     per-entry weight in CSR order (may be NULL)
+// A batch is a list of page ids; the kernels write the batched CSR (global ids, block diagonal) by pure
+// index arithmetic -- no sort: rows of a block-diagonal union are the pages' rows.  HBM-bound integer work,
+// one thread per output element, binary search over the (<= a few hundred) batch offsets.
+#include "gte_common.h"
+
+namespace {
+
+// largest i in [0, nb) with off[i] <= x   (off is ascending, off[0] = 0)
+__device__ __forceinline__ int seg_of(const int32_t* __restrict__ off, int nb, int x) {
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256)
+batch_indptr_kernel(const int32_t* __restrict__ pages, int nb, const int32_t* __restrict__ node_off,
+                    const int32_t* __restrict__ b_node_off, const int32_t* __restrict__ b_edge_off,
+                    const int32_t* __restrict__ indptr_loc, int32_t* __restrict__ indptr_out, int n_out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r > n_out) return;
+    if (r == n_out) { indptr_out[r] = b_edge_off[nb]; return; }
+    const int i = seg_of(b_node_off, nb, r);
+    const int p = pages[i];
+    indptr_out[r] = indptr_loc[node_off[p] + p + (r - b_node_off[i])] + b_edge_off[i];
+}
+
+__global__ void __launch_bounds__(256)
+batch_edges_kernel(const int32_t* __restrict__ pages, int nb, const int32_t* __restrict__ edge_off,
+                   const int32_t* __restrict__ b_node_off, const int32_t* __restrict__ b_edge_off,
+                   const int32_t* __restrict__ indices_loc, const float* __restrict__ weight,
+                   int32_t* __restrict__ indices_out, float* __restrict__ weight_out, int e_out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= e_out) return;
+    const int i = seg_of(b_edge_off, nb, e);
+    const int p = pages[i];
+    const int64_t s = (int64_t)edge_off[p] + (e - b_edge_off[i]);
+    indices_out[e] = indices_loc[s] + b_node_off[i];
+    if (weight_out) weight_out[e] = weight ? weight[s] : 1.0f;
+}
+
+// rows of a [Ntot, F] matrix (features) or a vector (labels): out[b_node_off[i] + r] = in[node_off[pages[i]] + r]
+// one 16-lane group per row chunk; dword granularity (any F, any alignment)
+__global__ void __launch_bounds__(256)
+batch_rows_kernel(const int32_t* __restrict__ pages, int nb, const int32_t* __restrict__ node_off,
+                  const int32_t* __restrict__ b_node_off, const float* __restrict__ in, int64_t ld_in,
+                  float* __restrict__ out, int64_t ld_out, int n_out, int f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= n_out) return;
+    const int i = seg_of(b_node_off, nb, r);
+    const float* src = in + (int64_t)(node_off[pages[i]] + (r - b_node_off[i])) * ld_in;
+    float* dst = out + (int64_t)r * ld_out;
+    for (int j = lane; j < f; j += 64) dst[j] = src[j];
+}
+
+// ---- edge weights from word boxes -----------------------------------------------------------------
+__device__ __forceinline__ int box_distance(const int4 a, const int4 b) {
+    // graphs/utils.py:56-88: 0 if the boxes intersect (touching counts), the axis gap if they face each other,
+    // else int(sqrt(dx^2 + dy^2)) between the nearest corners.  Boxes are (x0, y0, x1, y1) integers.
+    const int dx = max(max(b.x - a.z, a.x - b.z), 0);
+    const int dy = max(max(b.y - a.w, a.y - b.w), 0);
+    if (dx > 0 && dy > 0) return (int)sqrt((double)dx * dx + (double)dy * dy);
+    return max(dx, dy);
+}
+
+__global__ void __launch_bounds__(256)
+edge_dist_kernel(const int32_t* __restrict__ bbox, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                 const int32_t* __restrict__ graph_of_node, int32_t* __restrict__ dist, int32_t* __restrict__ gmax,
+                 int64_t n_edges) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edges) return;
+    const int u = src[e], v = dst[e];
+    const int4 a = *reinterpret_cast<const int4*>(bbox + (int64_t)u * 4);
+    const int4 b = *reinterpret_cast<const int4*>(bbox + (int64_t)v * 4);
+    const int d = box_distance(a, b);
+    dist[e] = d;
+    atomicMax(&gmax[graph_of_node[v]], d);        // integer max: order-independent, deterministic
+}
+
+__global__ void __launch_bounds__(256)
+edge_weight_kernel(const int32_t* __restrict__ dist, const int32_t* __restrict__ dst,
+                   const int32_t* __restrict__ graph_of_node, const int32_t* __restrict__ gmax,
+                   float* __restrict__ w, int64_t n_edges) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edges) return;
+    const int m = gmax[graph_of_node[dst[e]]];
+    // the reference divides by max(distances) even when it is 0 (loader.py:341-342: ZeroDivisionError); a page
+    // whose edges all have distance 0 gets weight 1 here -- documented deviation
+    w[e] = m > 0 ? (float)(1.0 - (double)dist[e] / (double)m) : 1.0f;
+}
+
+}  // namespace
+
+extern "C" int gte_batch_csr(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* edge_off,
+                             const int32_t* b_node_off, const int32_t* b_edge_off, const int32_t* indptr_loc,
+                             const int32_t* indices_loc, const float* weight, int32_t* indptr_out,
+                             int32_t* indices_out, float* weight_out, int64_t n_out, int64_t e_out, void* stream) {
+    if (n_batch <= 0 || n_out < 0 || e_out < 0 || n_out >= INT32_MAX || e_out >= INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_csr: bad sizes");
+    if (!pages || !node_off || !edge_off || !b_node_off || !b_edge_off || !indptr_loc || !indptr_out)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_csr: null pointer");
+    if (e_out > 0 && (!indices_loc || !indices_out)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_csr: null indices");
+    hipStream_t s = gte::as_stream(stream);
+    hipLaunchKernelGGL(batch_indptr_kernel, dim3((unsigned)gte::ceil_div(n_out + 1, 256)), dim3(256), 0, s, pages,
+                       (int)n_batch, node_off, b_node_off, b_edge_off, indptr_loc, indptr_out, (int)n_out);
+    if (e_out > 0)
+        hipLaunchKernelGGL(batch_edges_kernel, dim3((unsigned)gte::ceil_div(e_out, 256)), dim3(256), 0, s, pages,
+                           (int)n_batch, edge_off, b_node_off, b_edge_off, indices_loc, weight, indices_out, weight_out,
+                           (int)e_out);
+    return gte::check_launch("batch_csr");
+}
+
+extern "C" int gte_batch_rows(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,
+                              const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t n_out,
+                              int64_t n_cols, void* stream) {
+    if (n_batch <= 0 || n_out < 0 || n_cols <= 0 || n_out >= INT32_MAX || n_cols > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_rows: bad sizes");
+    if (n_out == 0) return GTE_OK;
+    if (!pages || !node_off || !b_node_off || !in || !out) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_rows: null pointer");
+    if (ld_in < n_cols || ld_out < n_cols) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_rows: ld < n_cols");
+    hipLaunchKernelGGL(batch_rows_kernel, dim3((unsigned)gte::ceil_div(n_out, 4)), dim3(256), 0, gte::as_stream(stream), pages,
+                       (int)n_batch, node_off, b_node_off, in, ld_in, out, ld_out, (int)n_out, (int)n_cols);
+    return gte::check_launch("batch_rows");
+}
+
+extern "C" int64_t gte_edge_weights_workspace_bytes(int64_t n_edges, int64_t n_graphs) {
+    return gte::round_up((n_edges > 0 ? n_edges : 1) * 4, 256) + gte::round_up((n_graphs > 0 ? n_graphs : 1) * 4, 256);
+}
+
+extern "C" int gte_edge_weights_bbox(const int32_t* bbox, const int32_t* src, const int32_t* dst,
+                                     const int32_t* graph_of_node, int64_t n_edges, int64_t n_graphs, float* weight,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n_edges < 0 || n_graphs <= 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "edge_weights_bbox: bad sizes");
+    if (n_edges == 0) return GTE_OK;
+    if (!bbox || !src || !dst || !graph_of_node || !weight || !workspace)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "edge_weights_bbox: null pointer");
+    if (((uintptr_t)bbox & 15) != 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "edge_weights_bbox: bbox must be 16-byte aligned");
+    if (workspace_bytes < gte_edge_weights_workspace_bytes(n_edges, n_graphs))
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "edge_weights_bbox: workspace too small");
+    hipStream_t s = gte::as_stream(stream);
+    int32_t* dist = reinterpret_cast<int32_t*>(workspace);
+    int32_t* gmax = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + gte::round_up(n_edges * 4, 256));
+    if (hipMemsetAsync(gmax, 0, (size_t)n_graphs * 4, s) != hipSuccess)
+        return gte::fail(GTE_ERR_LAUNCH, "edge_weights_bbox: memset failed");
+    const unsigned blocks = (unsigned)gte::ceil_div(n_edges, 256);
+    hipLaunchKernelGGL(edge_dist_kernel, dim3(blocks), dim3(256), 0, s, bbox, src, dst, graph_of_node, dist, gmax, n_edges);
+    hipLaunchKernelGGL(edge_weight_kernel, dim3(blocks), dim3(256), 0, s, dist, dst, graph_of_node, gmax, weight, n_edges);
+    return gte::check_launch("edge_weights_bbox");
+}

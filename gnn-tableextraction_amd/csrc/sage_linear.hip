@@ -52,6 +52,8 @@ struct GemmParams {
     const float* A1; int64_t lda1; int K1;
     const float* A2; int64_t lda2; int K2;
     const float* B; int64_t ldb;       // B(k,n); k runs over K1+K2 (segment 1 starts at row/col K1)
+    const float* Bn2; int64_t ldbn2;   // optional second B for output columns [Nseg, 2*Nseg): C = A [B | Bn2]
+    int Nseg;                          // columns per N segment when Bn2 != nullptr (then N == 2*Nseg)
     float* C; int64_t ldc;
     const float* bias;                 // nullable, per column n
     int M, N;
@@ -209,11 +211,17 @@ gemm_f32_mfma_kernel(const GemmParams p) {
     const int wm = wave / WN, wn = wave % WN;
 
     // tile mapping: consecutive logical blocks walk N first (they share the A row panel)
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    // N may be split into two column segments fed by two B matrices (dW = dZ^T [h | ahn] in ONE launch)
+    const int seg_cols = p.Bn2 ? p.Nseg : p.N;
+    const int seg_tiles = (seg_cols + BN - 1) / BN;
+    const int tiles_n = p.Bn2 ? 2 * seg_tiles : seg_tiles, tiles_m = (p.M + BM - 1) / BM;
     const unsigned ntile = (unsigned)(tiles_m * tiles_n);
     const unsigned lb = gte_xcd_remap(blockIdx.x, ntile);
     const int tm = lb / tiles_n, tn = lb % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int nseg = tn / seg_tiles;                       // 0, or 1 for the second B
+    const int m0 = tm * BM, n0 = (tn % seg_tiles) * BN;    // n0: column inside the segment
+    const float* Bmat = nseg ? p.Bn2 : p.B;
+    const int64_t ldbm = nseg ? p.ldbn2 : p.ldb;
     const int split = blockIdx.y;
 
     const int tiles_seg0 = (p.K1 + BK - 1) / BK, tiles_seg1 = (p.K2 + BK - 1) / BK;
@@ -247,8 +255,8 @@ gemm_f32_mfma_kernel(const GemmParams p) {
             cur_seg = seg;
             const int kb = seg ? p.K1 : 0;
             stA.init(seg ? p.A2 : p.A1, seg ? p.lda2 : p.lda1, m0, p.M, tid);
-            if constexpr (BKC) stB.init(p.B + kb, p.ldb, n0, p.N, tid);
-            else stB.init(p.B + (int64_t)kb * p.ldb, p.ldb, n0, p.N, tid);
+            if constexpr (BKC) stB.init(Bmat + kb, ldbm, n0, seg_cols, tid);
+            else stB.init(Bmat + (int64_t)kb * ldbm, ldbm, n0, seg_cols, tid);
         }
         pf_kl = (seg ? t - tiles_seg0 : t) * BK;
         pf_kseg = seg ? p.K2 : p.K1;
@@ -315,8 +323,9 @@ gemm_f32_mfma_kernel(const GemmParams p) {
     const int64_t ldo = p.splits > 1 ? p.N : p.ldc;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-        const int col = n0 + (wn * TN + b) * 32 + col_l;
-        if (col >= p.N) continue;
+        const int col_in_seg = n0 + (wn * TN + b) * 32 + col_l;
+        if (col_in_seg >= seg_cols) continue;
+        const int col = nseg * seg_cols + col_in_seg;
         const float bv = (p.bias && p.splits <= 1) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -464,7 +473,10 @@ gemm_small_kernel(const GemmParams p) {
         const int K = seg ? p.K2 : p.K1, kb = seg ? p.K1 : 0;
         for (int k = 0; k < K; ++k) {
             const float a = AK ? A[(int64_t)m * lda + k] : A[(int64_t)k * lda + m];
-            const float b = BKC ? p.B[(int64_t)n * p.ldb + kb + k] : p.B[(int64_t)(kb + k) * p.ldb + n];
+            const float* Bm = (p.Bn2 && n >= p.Nseg) ? p.Bn2 : p.B;
+            const int64_t ldbm = (p.Bn2 && n >= p.Nseg) ? p.ldbn2 : p.ldb;
+            const int nn = (p.Bn2 && n >= p.Nseg) ? n - p.Nseg : n;
+            const float b = BKC ? Bm[(int64_t)nn * ldbm + kb + k] : Bm[(int64_t)(kb + k) * ldbm + nn];
             acc = fmaf(a, b, acc);
         }
     }
@@ -479,13 +491,13 @@ gemm_small_kernel(const GemmParams p) {
 bool needs_small_path(bool ak, bool bkc, const GemmParams& p) {
     const int kmin = p.K2 > 0 ? (p.K1 < p.K2 ? p.K1 : p.K2) : p.K1;
     const int a_run = ak ? kmin : p.M;
-    const int b_run = bkc ? kmin : p.N;
+    const int b_run = bkc ? kmin : (p.Bn2 ? p.Nseg : p.N);
     return a_run < 4 || b_run < 4;
 }
 
 struct Plan { int bm, bn, tiles, splits, tiles_per_split; };
 
-Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2) {
+Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
     Plan pl;
     const int cus = gte::device_props().cus;
     if (N <= 32) { pl.bm = 128; pl.bn = 32; }
@@ -502,7 +514,7 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2) {
         // half the K splits -> half the slab bytes (measured 58 -> 44 us; at 14 tiles, 256 x 831, it loses: 147 -> 161)
         if (t128 <= 8 && M >= 64) pl.bm = 64;
     }
-    pl.tiles = (int)(gte::ceil_div(M, pl.bm) * gte::ceil_div(N, pl.bn));
+    pl.tiles = (int)(gte::ceil_div(M, pl.bm) * (Nseg > 0 ? 2 * gte::ceil_div(Nseg, pl.bn) : gte::ceil_div(N, pl.bn)));
     const int ktiles = (int)(gte::ceil_div(K1, BK) + gte::ceil_div(K2, BK));
     int splits = 1;
     // the reduction dimension is the node count for dW = dZ^T X: few output tiles, very long K
@@ -544,7 +556,7 @@ int run_small(bool ak, bool bkc, GemmParams p, hipStream_t s) {
 int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace_bytes, hipStream_t s) {
     if (p.M == 0 || p.N == 0) return GTE_OK;
     if (needs_small_path(ak, bkc, p)) return run_small(ak, bkc, p, s);
-    const Plan pl = make_plan(p.M, p.N, p.K1, p.K2);
+    const Plan pl = make_plan(p.M, p.N, p.K1, p.K2, p.Bn2 ? p.Nseg : 0);
     p.splits = pl.splits;
     p.tiles_per_split = pl.tiles_per_split;
     p.slab = nullptr;
@@ -571,9 +583,9 @@ int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace
     return GTE_OK;
 }
 
-int64_t gemm_workspace(int64_t M, int64_t N, int64_t K1, int64_t K2) {
+int64_t gemm_workspace(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
     if (M <= 0 || N <= 0) return 256;
-    const Plan pl = make_plan(M, N, K1, K2);
+    const Plan pl = make_plan(M, N, K1, K2, Nseg);
     return pl.splits > 1 ? gte::round_up((int64_t)pl.splits * M * N * 4, 256) : 256;
 }
 
@@ -858,6 +870,40 @@ extern "C" int gte_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int6
     p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = nullptr; p.M = (int)M; p.N = (int)N;
     p.relu = 0; p.accumulate = accumulate ? 1 : 0;
     return run_gemm(!trans_a, trans_b != 0, p, workspace, workspace_bytes, s);
+}
+
+extern "C" int64_t gte_sage_linear_dw_workspace_bytes(int64_t n_out, int64_t k1, int64_t k2, int64_t n_nodes) {
+    if (k2 > 0 && k2 == k1 && n_out > SK_MAX) return gemm_workspace(n_out, 2 * k1, n_nodes, 0, k1);
+    const int64_t a = gte_gemm_workspace_bytes(n_out, k1, n_nodes), b = k2 > 0 ? gte_gemm_workspace_bytes(n_out, k2, n_nodes) : 0;
+    return a > b ? a : b;
+}
+
+extern "C" int gte_sage_linear_dw(const float* dz, int64_t lddz, const float* x1, int64_t ldx1, int64_t k1,
+                                  const float* x2, int64_t ldx2, int64_t k2, float* dW, int64_t lddw, int64_t n_out,
+                                  int64_t n_nodes, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n_out <= 0 || k1 <= 0 || k2 < 0 || n_nodes < 0 || n_out > INT32_MAX || k1 + k2 > INT32_MAX || n_nodes > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_dw: bad sizes");
+    if (!dz || !x1 || !dW || (k2 > 0 && !x2)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_dw: null pointer");
+    if (lddz < n_out || ldx1 < k1 || (k2 > 0 && ldx2 < k2) || lddw < k1 + k2)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_dw: leading dimension too small");
+    if (n_nodes == 0) {
+        for (int64_t r = 0; r < n_out; ++r)
+            if (hipMemsetAsync(dW + r * lddw, 0, (size_t)(k1 + k2) * 4, gte::as_stream(stream)) != hipSuccess)
+                return gte::fail(GTE_ERR_LAUNCH, "sage_linear_dw: memset failed");
+        return GTE_OK;
+    }
+    const bool skinny = n_out <= SK_MAX;
+    if (k2 > 0 && k2 == k1 && !skinny) {
+        // one launch: C[n_out, 2F] = dZ^T [x1 | x2]; A = dZ stored [nodes][n_out], B segments stored [nodes][F]
+        GemmParams p = {};
+        p.A1 = dz; p.lda1 = lddz; p.K1 = (int)n_nodes; p.A2 = nullptr; p.lda2 = 0; p.K2 = 0;
+        p.B = x1; p.ldb = ldx1; p.Bn2 = x2; p.ldbn2 = ldx2; p.Nseg = (int)k1;
+        p.C = dW; p.ldc = lddw; p.bias = nullptr; p.M = (int)n_out; p.N = (int)(2 * k1); p.relu = 0; p.accumulate = 0;
+        return run_gemm(false, false, p, workspace, workspace_bytes, gte::as_stream(stream));
+    }
+    int rc = gte_gemm_f32(1, 0, n_out, k1, n_nodes, dz, lddz, x1, ldx1, dW, lddw, 0, workspace, workspace_bytes, stream);
+    if (rc != GTE_OK || k2 == 0) return rc;
+    return gte_gemm_f32(1, 0, n_out, k2, n_nodes, dz, lddz, x2, ldx2, dW + k1, lddw, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2,

@@ -301,3 +301,149 @@ def batch(graphs: Sequence[PageGraph]) -> PageGraph:
 
 def unbatch_sizes(g: PageGraph) -> List[int]:
     return list(g.batch_num_nodes_)
+
+
+# ================================================================================================
+# Resident pages: the whole dataset concatenated once in HBM; a batch is four kernel launches
+# ================================================================================================
+class ResidentBatch(PageGraph):
+    """A batched graph produced by :meth:`ResidentPages.batch`: the CSRs and the CSR-ordered edge weights are
+    gathered on the device from the resident dataset instead of being rebuilt (no COO, no sort)."""
+
+    def __init__(self, n, n_edges, in_csr, out_csr, w_in, w_out_mean, device):
+        z = torch.zeros(0, dtype=torch.int32, device=device)
+        super().__init__(z, z, n)
+        self._in_csr, self._out_csr = in_csr, out_csr
+        self._w_in, self._w_out_mean = w_in, w_out_mean
+        self._n_edges = int(n_edges)
+        self.batch_num_edges_ = [self._n_edges]
+
+    def num_edges(self) -> int:
+        return self._n_edges
+
+    number_of_edges = num_edges
+
+    def edges(self):
+        raise NotImplementedError("ResidentBatch keeps CSRs only; COO edge lists are not materialised")
+
+    def in_weights(self, w):
+        return None if w is None else self._w_in
+
+    def out_weights(self, w, mean: bool):
+        if mean:
+            return self._w_out_mean
+        raise NotImplementedError("ResidentBatch stores the mean-normalised out-edge weights only")
+
+
+class ResidentPages:
+    """All pages of a dataset, concatenated once on the device.
+
+    Replaces the reference's per-step ``dgl.batch(train_batch).to(device)`` (model_train.py:297): features,
+    labels, both CSRs and the CSR-ordered edge weights live in HBM for the whole run; ``batch(page_ids)``
+    writes the block-diagonal union of the chosen pages with ``gte_batch_csr`` / ``gte_batch_rows``.
+    288 GB of HBM hold ~80 M nodes of 831 fp32 features.
+    """
+
+    def __init__(self, graphs: Sequence[PageGraph], device, feat_key: str = "feat", label_key: str = "label",
+                 weight_key: str = "feat"):
+        from . import ops
+        self.device = torch.device(device)
+        sizes = [g.num_nodes() for g in graphs]
+        self.node_off_host = torch.zeros(len(graphs) + 1, dtype=torch.int64)
+        self.node_off_host[1:] = torch.cumsum(torch.tensor(sizes), 0)
+        whole = batch([g.to("cpu") if g.device.type != "cpu" else g for g in graphs]).to(self.device)
+        n = whole.num_nodes()
+        self.n_pages, self.n_nodes = len(graphs), n
+        self.feat = whole.ndata[feat_key].to(torch.float32).contiguous()
+        lab = whole.ndata.get(label_key)
+        self.label = None if lab is None else lab.to(torch.float32).reshape(-1, 1).contiguous()
+        w = whole.edata.get(weight_key)
+        self.weighted = w is not None
+        self.node_off = self.node_off_host.to(torch.int32).to(self.device)
+        page_of_node = torch.repeat_interleave(torch.arange(len(graphs), device=self.device),
+                                               torch.tensor(sizes, device=self.device))
+        self._sets = {}
+        for name, csr, wt in (("in", whole.in_csr(), whole.in_weights(w)),
+                              ("out", whole.out_csr(), whole.out_weights(w, True))):
+            edge_off = csr.indptr.long()[self.node_off.long()]                              # [P+1] CSR entries per page
+            row_of_entry = torch.repeat_interleave(torch.arange(n, device=self.device),
+                                                   (csr.indptr[1:] - csr.indptr[:-1]).long())
+            page_of_entry = page_of_node[row_of_entry]
+            indices_loc = (csr.indices.long() - self.node_off.long()[page_of_entry]).to(torch.int32).contiguous()
+            # packed local indptr: page p's n_p + 1 entries at node_off[p] + p
+            pos_page = torch.repeat_interleave(torch.arange(len(graphs), device=self.device),
+                                               torch.tensor([s + 1 for s in sizes], device=self.device))
+            pos_row = torch.arange(n + len(graphs), device=self.device) - pos_page          # global row (or page end)
+            indptr_loc = (csr.indptr.long()[pos_row] - edge_off[pos_page]).to(torch.int32).contiguous()
+            self._sets[name] = dict(edge_off=edge_off.to(torch.int32).contiguous(), edge_off_host=edge_off.cpu(),
+                                    indices_loc=indices_loc, indptr_loc=indptr_loc,
+                                    weight=None if wt is None else wt.contiguous())
+
+    def __len__(self):
+        return self.n_pages
+
+    def page_sizes(self):
+        return (self.node_off_host[1:] - self.node_off_host[:-1]).tolist()
+
+    def batch(self, page_ids) -> ResidentBatch:
+        lib, P, st = _lib.load(), _lib.ptr, _lib.current_stream()
+        ids = torch.as_tensor(page_ids, dtype=torch.int64)
+        nb = ids.numel()
+        n_sizes = self.node_off_host[ids + 1] - self.node_off_host[ids]
+        offs = [torch.zeros(nb + 1, dtype=torch.int64)]
+        offs[0][1:] = torch.cumsum(n_sizes, 0)
+        for name in ("in", "out"):
+            eo = self._sets[name]["edge_off_host"]
+            o = torch.zeros(nb + 1, dtype=torch.int64)
+            o[1:] = torch.cumsum(eo[ids + 1] - eo[ids], 0)
+            offs.append(o)
+        n_out, e_in, e_out = int(offs[0][-1]), int(offs[1][-1]), int(offs[2][-1])
+        meta = torch.cat([ids] + offs).to(torch.int32).to(self.device, non_blocking=True)     # one small H2D copy
+        pages = meta[:nb]
+        b_node, b_ein, b_eout = (meta[nb + i * (nb + 1): nb + (i + 1) * (nb + 1)] for i in range(3))
+        dev = self.device
+        csrs, weights = [], []
+        for name, b_eoff, e_cnt in (("in", b_ein, e_in), ("out", b_eout, e_out)):
+            s = self._sets[name]
+            indptr = torch.empty(n_out + 1, dtype=torch.int32, device=dev)
+            indices = torch.empty(e_cnt, dtype=torch.int32, device=dev)
+            wout = torch.empty(e_cnt, dtype=torch.float32, device=dev) if s["weight"] is not None else None
+            _lib.check(lib.gte_batch_csr(P(pages), nb, P(self.node_off), P(s["edge_off"]), P(b_node), P(b_eoff),
+                                         P(s["indptr_loc"]), P(s["indices_loc"]), P(s["weight"]), P(indptr), P(indices),
+                                         P(wout), n_out, e_cnt, st), "gte_batch_csr")
+            csrs.append(CSR(indptr, indices, None))
+            weights.append(wout)
+        g = ResidentBatch(n_out, e_in, csrs[0], csrs[1], weights[0], weights[1], dev)
+        g.batch_num_nodes_ = n_sizes.tolist()
+        f = self.feat.shape[1]
+        feat = torch.empty((n_out, f), dtype=torch.float32, device=dev)
+        _lib.check(lib.gte_batch_rows(P(pages), nb, P(self.node_off), P(b_node), P(self.feat), self.feat.stride(0),
+                                      P(feat), f, n_out, f, st), "gte_batch_rows feat")
+        g.ndata["feat"] = feat
+        if self.label is not None:
+            lab = torch.empty((n_out, 1), dtype=torch.float32, device=dev)
+            _lib.check(lib.gte_batch_rows(P(pages), nb, P(self.node_off), P(b_node), P(self.label), 1, P(lab), 1, n_out, 1,
+                                          st), "gte_batch_rows label")
+            g.ndata["label"] = lab.reshape(-1)
+        if self.weighted:
+            g.edata["feat"] = weights[0]                # CSR order; ResidentBatch.in/out_weights ignore the argument
+        g._keepalive = meta
+        return g
+
+
+def edge_weights_from_boxes(bbox: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, graph_of_node: torch.Tensor,
+                            n_graphs: int) -> torch.Tensor:
+    """``edata['feat']`` of loader.py:332-344 on the device: 1 - d/max d per page, d = the reference box distance."""
+    from . import ops
+    _lib.require_device(bbox, "edge_weights_from_boxes")
+    lib = _lib.load()
+    bbox = bbox.to(torch.int32).contiguous()
+    src, dst = src.to(torch.int32).contiguous(), dst.to(torch.int32).contiguous()
+    gon = graph_of_node.to(torch.int32).contiguous()
+    e = src.numel()
+    w = torch.empty(e, dtype=torch.float32, device=bbox.device)
+    ws = ops._workspace(lib.gte_edge_weights_workspace_bytes(e, n_graphs), bbox.device, "ew")
+    _lib.check(lib.gte_edge_weights_bbox(_lib.ptr(bbox), _lib.ptr(src), _lib.ptr(dst), _lib.ptr(gon), e, n_graphs,
+                                         _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+               "gte_edge_weights_bbox")
+    return w

@@ -140,7 +140,8 @@ class FusedGcnSageStep(TrainStep):
             lib = self.lib
             ws = max([lib.gte_weighted_ce_workspace_bytes(n)] +
                      [lib.gte_ln_relu_bwd_workspace_bytes(n, d) for d in dims[1:]] +
-                     [lib.gte_gemm_workspace_bytes(dims[i + 1], dims[i], n) for i in range(len(layers))])
+                     [lib.gte_gemm_workspace_bytes(dims[i + 1], dims[i], n) for i in range(len(layers))] +
+                     [lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], n) for i in range(len(layers))])
             b["ws"] = torch.empty(int(ws), dtype=torch.uint8, device=dev)
             self._bufs[key] = b
         return b
@@ -223,10 +224,8 @@ class FusedGcnSageStep(TrainStep):
                                       P(dy), fout, P(gg), P(gbe), P(gb), n, fout, ws, wsn, st), "gte_ln_relu_bwd")
             dz, ahn = dy, b["ahn"][i]
             with timed("gemm_tn", 4.0 * n * fin * fout):
-                check(lib.gte_gemm_f32(1, 0, fout, fin, n, P(dz), fout, P(hin), ld(hin), P(gW), 2 * fin, 0, ws, wsn, st),
-                      "gte_gemm_f32 dW_self")
-                check(lib.gte_gemm_f32(1, 0, fout, fin, n, P(dz), fout, P(ahn), fin, P(gW) + 4 * fin, 2 * fin, 0, ws, wsn,
-                                       st), "gte_gemm_f32 dW_neigh")
+                check(lib.gte_sage_linear_dw(P(dz), fout, P(hin), ld(hin), fin, P(ahn), fin, fin, P(gW), 2 * fin, fout, n,
+                                             ws, wsn, st), "gte_sage_linear_dw")
             if i > 0:
                 dh, dahn = b["dy"][i - 1], b["dahn"]
                 with timed("gemm_nn", 4.0 * n * fin * fout):

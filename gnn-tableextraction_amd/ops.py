@@ -217,6 +217,24 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     return out
 
 
+def sage_linear_dw(dz: torch.Tensor, x1: torch.Tensor, x2: Optional[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
+    """out[n_out, k1+k2] = dz^T [x1 | x2] in one launch (weight gradient of the split-weight linear)."""
+    lib = _lib.load()
+    dz, x1 = _row_major(dz), _row_major(x1)
+    m, n_out = dz.shape
+    k1 = x1.shape[1]
+    k2 = 0
+    if x2 is not None:
+        x2 = _row_major(x2)
+        k2 = x2.shape[1]
+    ws = _workspace(lib.gte_sage_linear_dw_workspace_bytes(n_out, k1, k2, m), dz.device, "gemm")
+    with _timed("gemm_tn", 2.0 * m * n_out * (k1 + k2)):
+        check(lib.gte_sage_linear_dw(ptr(dz), _ld(dz), ptr(x1), _ld(x1), k1, ptr(x2), 0 if x2 is None else _ld(x2), k2,
+                                     ptr(out), _ld(out), n_out, m, ptr(ws), ws.numel(), current_stream()),
+              "gte_sage_linear_dw")
+    return out
+
+
 def sage_linear_fwd(a1, a2, weight, bias, gamma, beta, eps: float, relu: bool, save_for_backward: bool):
     """y = relu?(LN?([a1|a2] W^T + b)); returns (y, z_save, stats)."""
     lib = _lib.load()
@@ -358,9 +376,7 @@ class _SageLayer(torch.autograd.Function):
         dweight = None
         if need_w:
             dweight = torch.empty_like(weight)
-            gemm(dz, h, trans_a=True, out=dweight[:, :f])
-            if ahn is not None:
-                gemm(dz, ahn, trans_a=True, out=dweight[:, f:])
+            sage_linear_dw(dz, h, ahn, dweight)
         # (3) dh = dZ W_self + A_w^T (norm * (dZ W_neigh))
         dh = None
         if need_h:

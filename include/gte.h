@@ -100,6 +100,28 @@ int gte_coo_to_csr(const int32_t* key, const int32_t* other, const float* eweigh
                    int64_t n_nodes, int64_t n_edges,
                    int32_t* indptr, int32_t* indices, int32_t* perm, float* wout,
                    void* workspace, int64_t workspace_bytes, void* stream);
+/* Device-side batching of RESIDENT pages (replaces dgl.batch(...).to(device), model_train.py:297, per step).
+ * Dataset arrays (built once): node_off[P+1], edge_off[P+1]; indptr_loc packed per page (page p's n_p+1 entries
+ * start at node_off[p] + p and count from 0); indices_loc = column ids local to the page; weight in CSR order.
+ * Batch = pages[n_batch] with b_node_off[n_batch+1], b_edge_off[n_batch+1] (exclusive prefix sums of the chosen
+ * pages' node / CSR-entry counts, computed by the caller from host metadata).  Writes the block-diagonal CSR:
+ * indptr_out[n_out+1], indices_out[e_out] (global ids), weight_out[e_out] (nullable).  Pure index work, no sort. */
+int gte_batch_csr(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* edge_off,
+                  const int32_t* b_node_off, const int32_t* b_edge_off, const int32_t* indptr_loc,
+                  const int32_t* indices_loc, const float* weight, int32_t* indptr_out, int32_t* indices_out,
+                  float* weight_out, int64_t n_out, int64_t e_out, void* stream);
+/* out[b_node_off[i] + r, 0:n_cols] = in[node_off[pages[i]] + r, 0:n_cols]  (features, labels stored as f32) */
+int gte_batch_rows(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,
+                   const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t n_out, int64_t n_cols,
+                   void* stream);
+/* Edge weights of loader.py:332-344: w_e = 1 - d_e / max_{e in the page} d_e with d = the reference's integer box
+ * distance (graphs/utils.py:56-88).  bbox int32[N,4] (x0,y0,x1,y1; 16-byte aligned), graph_of_node int32[N].
+ * A page whose distances are all 0 gets weight 1 (the reference divides by zero there).  Bit-exact vs the
+ * double-precision host formula. */
+int64_t gte_edge_weights_workspace_bytes(int64_t n_edges, int64_t n_graphs);
+int gte_edge_weights_bbox(const int32_t* bbox, const int32_t* src, const int32_t* dst, const int32_t* graph_of_node,
+                          int64_t n_edges, int64_t n_graphs, float* weight, void* workspace, int64_t workspace_bytes,
+                          void* stream);
 /* inv_deg[v] = 1/(indptr[v+1]-indptr[v]) or 0  (models.py:74-78 as a standalone vector) */
 int gte_inv_degree(const int32_t* indptr, float* inv_deg, int64_t n_nodes, void* stream);
 
@@ -118,6 +140,15 @@ int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1,
                         const float* gamma, const float* beta, float eps, int relu,
                         float* z_save, int64_t ldz, float* stats,
                         float* y, int64_t ldy, int64_t M, int64_t n_out, void* stream);
+
+/* Weight gradient of the split-weight linear, both halves in ONE launch:
+ *   dW[n_out, k1+k2] = dZ[M, n_out]^T * [x1[M,k1] | x2[M,k2]]        (autograd of models.py:63 w.r.t. the weight)
+ * The reduction runs over the M nodes (split over workgroups, deterministic slab reduction).  x2 may be
+ * NULL (k2 = 0).  workspace: gte_sage_linear_dw_workspace_bytes(n_out, k1, k2, M). */
+int64_t gte_sage_linear_dw_workspace_bytes(int64_t n_out, int64_t k1, int64_t k2, int64_t n_nodes);
+int gte_sage_linear_dw(const float* dz, int64_t lddz, const float* x1, int64_t ldx1, int64_t k1,
+                       const float* x2, int64_t ldx2, int64_t k2, float* dW, int64_t lddw,
+                       int64_t n_out, int64_t n_nodes, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* LayerNorm + ReLU alone (row-wise over n_out):  y = relu?(gamma * (z - mean) * rstd + beta).
  * replaces models.py:64-66 when the caller ran the linear part separately.  In place (y == z) is

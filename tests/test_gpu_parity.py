@@ -506,3 +506,61 @@ def test_model_with_and_without_tiles_is_bitwise_identical():
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------- resident pages: device-side batching, edge weights
+def _page_graphs(pages, device="cpu"):
+    gs = []
+    for p in pages:
+        g = G.PageGraph(p.src, p.dst, p.num_nodes, device=device)
+        g.ndata["feat"], g.ndata["label"] = torch.from_numpy(p.feat).to(device), torch.from_numpy(p.label.astype(np.float32)).to(device)
+        g.edata["feat"] = torch.from_numpy(p.weight).to(device)
+        gs.append(g)
+    return gs
+
+
+def test_resident_batch_is_bitwise_the_host_batch():
+    pages = S.make_pages(25, in_feats=63)
+    res = G.ResidentPages(_page_graphs(pages), DEV)
+    assert len(res) == 25 and res.page_sizes() == [p.num_nodes for p in pages]
+    ids = [7, 3, 19, 3, 0, 24]                                   # unordered, one page twice
+    rb = res.batch(ids)
+    hb = G.batch(_page_graphs([pages[i] for i in ids], DEV))
+    w = hb.edata["feat"]
+    for a, b in ((rb.in_csr(), hb.in_csr()), (rb.out_csr(), hb.out_csr())):
+        assert torch.equal(a.indptr, b.indptr) and torch.equal(a.indices, b.indices)
+    assert torch.equal(rb.in_weights(rb.edata["feat"]), hb.in_weights(w))
+    assert torch.equal(rb.out_weights(rb.edata["feat"], True), hb.out_weights(w, True))
+    assert torch.equal(rb.ndata["feat"], hb.ndata["feat"]) and torch.equal(rb.ndata["label"], hb.ndata["label"])
+    assert rb.num_nodes() == hb.num_nodes() and rb.num_edges() == hb.num_edges()
+    assert rb.batch_num_nodes().tolist() == [pages[i].num_nodes for i in ids]
+    torch.manual_seed(0)
+    model = gte.GcnSAGE(63, 64, 9, 3, torch.nn.functional.relu, 0).to(DEV)
+    la = model(rb)
+    lb = model(hb)
+    assert torch.equal(la, lb)
+    la.square().mean().backward()
+    ga = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    lb.square().mean().backward()
+    for x, y in zip(ga, model.parameters()):
+        assert torch.equal(x, y.grad)
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    f1 = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+    o1 = f1.forward_backward(rb, rb.ndata["label"]).clone()
+    g1 = f1.flat_grad.clone()
+    o2 = f1.forward_backward(hb, hb.ndata["label"]).clone()
+    assert torch.equal(o1, o2) and torch.equal(g1, f1.flat_grad)
+
+
+def test_edge_weights_kernel_matches_the_reference_formula_bitwise():
+    pages = S.make_pages(12, in_feats=13)
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    bbox = np.concatenate([p.bbox for p in pages]).astype(np.int32)
+    gon = np.repeat(np.arange(len(pages)), [p.num_nodes for p in pages]).astype(np.int32)
+    got = G.edge_weights_from_boxes(dev(bbox), dev(src), dev(dst), dev(gon), len(pages)).cpu().numpy()
+    np.testing.assert_array_equal(got, w)                         # the generator applies the host formula in float64
+    # a page whose edges all have distance 0 (overlapping boxes): weight 1, no division by zero
+    b = np.array([[0, 0, 10, 10], [5, 5, 15, 15]], dtype=np.int32)
+    one = G.edge_weights_from_boxes(dev(b), dev(np.array([0, 1])), dev(np.array([1, 0])), dev(np.zeros(2, np.int32)), 1)
+    assert one.cpu().tolist() == [1.0, 1.0]
