@@ -143,6 +143,28 @@ def gather_probe(args, gte, S, dev):
 
     ms_plain = timed(None)
     ms = timed(plan)
+    # (iii) of SURVEY 8(d) cfg4: one full GcnSAGELayer(512 -> 512) forward + backward on the same graph
+    layer_ms = None
+    if n == 1_000_000:
+        torch.manual_seed(0)
+        layer = gte.GcnSAGELayer(f, f, torch.nn.functional.relu, 0).to(dev)
+        g = gte.PageGraph(src, dst, n, device=dev)
+        g.edata["feat"] = torch.from_numpy(w).to(dev)
+        h = x.clone().requires_grad_(True)
+        up = torch.randn(n, f, device=dev)
+        def fb():
+            y = layer(g, h)
+            y.backward(up)
+            layer.zero_grad(set_to_none=True); h.grad = None
+        for _ in range(2):
+            fb()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fb()
+        torch.cuda.synchronize()
+        layer_ms = (time.perf_counter() - t0) / 5 * 1e3
+        del layer, g, h, up
     alg_bytes = 2.0 * n * f * 4 + 8.0 * n * k + 4.0 * (n + 1)      # 2*F*s + 8*d + 4 per node
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return {"workload": f"cfg4: 1 graph, {n} nodes, in-degree {k}, F={f} fp32, k-NN of 2-D points in Morton order",
@@ -150,6 +172,8 @@ def gather_probe(args, gte, S, dev):
             "plain_kernel_GBs": alg_bytes / (ms_plain * 1e-3) / 1e9, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms_per_pass": ms, "algorithmic_bytes": alg_bytes,
             "nodes_per_s_per_pass": n / (ms * 1e-3),
+            "full_layer_512_fwd_bwd_ms": layer_ms,
+            "full_layer_nodes_per_s": (n / (layer_ms * 1e-3)) if layer_ms else None,
             "traffic": pmc_traffic()[0].get("gather_cfg4_tiled_bytes_per_launch") if n == 1_000_000 else None,
             "traffic_source": pmc_traffic()[1]}
 
