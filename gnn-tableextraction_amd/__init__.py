@@ -6,5 +6,6 @@ Import name: ``gnn_tableextraction_amd`` (the directory is ``gnn-tableextraction
 from . import _lib, function, graph, ops                                   # noqa: F401
 from .graph import PageGraph, batch, from_edge_index                       # noqa: F401
 from .components.graphs.models import GcnSAGE, GcnSAGELayer, MeanSAGE, WeightedMeanSAGELayer  # noqa: F401
+from .components.graphs.gat import GAT, GATLayer                          # noqa: F401
 
 __version__ = "0.1.0"

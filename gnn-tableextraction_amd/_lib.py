@@ -50,6 +50,14 @@ SIGNATURES = {
     "gte_gemm_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "gte_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                              c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "gte_gat_scores": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                               c_int, c_int, c_void_p]),
+    "gte_gat_aggregate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "gte_gat_bwd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "gte_gat_aggregate_bwd": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_void_p, c_int64] + [c_void_p] * 7 +
+                              [c_int64] + [c_void_p] * 4 + [c_int64] + [c_void_p] * 3 + [c_int64, c_int, c_int,
+                                                                                        c_void_p, c_int64, c_void_p]),
     "gte_weighted_ce_workspace_bytes": (c_int64, [c_int64]),
     "gte_weighted_ce": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int, c_float,
                                 c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -194,6 +194,18 @@ class PageGraph:
     def out_tiles(self):
         return self._tiles("out")
 
+    def out_to_in_pos(self) -> torch.Tensor:
+        """pos[i] = position in the in-edge CSR of the edge stored at position i of the out-edge CSR (int32 [E])."""
+        hit = self._wcache.get(("o2i",))
+        if hit is None:
+            pin, pout = self.in_csr().perm, self.out_csr().perm
+            if pin is None or pout is None:
+                raise NotImplementedError("edge permutation is not kept for this graph")
+            inv = torch.empty_like(pin)
+            inv[pin.long()] = torch.arange(pin.numel(), dtype=pin.dtype, device=pin.device)
+            hit = self._wcache[("o2i",)] = inv[pout.long()].contiguous()
+        return hit
+
     def inv_in_degree(self) -> torch.Tensor:
         """norm of models.py:74-78 as a vector: 1/in_degree, 0 where the degree is 0 (fp32 [N])."""
         if self._inv_deg is None:

@@ -203,6 +203,30 @@ int gte_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                   float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * A13  multi-head graph attention (BASELINE.json configs[2]).  The reference has NO GAT: the
+ * layer is the standard formulation (DGL GATConv semantics), oracle = oracle/gat_cpu.py, parity unpinned.
+ *   z [N, H*D] (= X W, computed with gte_gemm_f32);  heads <= 8, heads*dim <= 1024
+ * gte_gat_scores: el[v,h] = <a_l[h], z[v,h]>, er likewise; optionally writes a bf16 copy of z for the gathers.
+ * gte_gat_aggregate_fwd: e = LeakyReLU_0.2(el[u] + er[v]) over in-edges, online softmax, out[v] = sum alpha z[u] (+bias);
+ *   saves the softmax max / sum per (node, head) for the backward.  dtype = storage of the gathered z (f32 / bf16).
+ * gte_gat_aggregate_bwd: given dout, writes dz (incl. the el/er paths), d a_l, d a_r, d bias; ds [E,H], der, del [N,H]
+ *   are caller-provided scratch outputs; pos_in[i] = position in the in-edge CSR of the i-th out-edge-CSR entry.
+ * ---------------------------------------------------------------------------------------- */
+int gte_gat_scores(const float* z, int64_t ldz, const float* a_l, const float* a_r, float* el, float* er,
+                   void* z_bf16 /* nullable */, int64_t ldzb, int64_t n_nodes, int heads, int dim, void* stream);
+int gte_gat_aggregate_fwd(const int32_t* indptr, const int32_t* indices, const void* z, int64_t ldz, int dtype,
+                          const float* el, const float* er, const float* bias /* nullable */, float* out, int64_t ldo,
+                          float* smax, float* ssum, int64_t n_nodes, int heads, int dim, void* stream);
+int64_t gte_gat_bwd_workspace_bytes(int64_t n_nodes, int heads, int dim);
+int gte_gat_aggregate_bwd(const int32_t* indptr, const int32_t* indices, const int32_t* rindptr, const int32_t* rindices,
+                          const int32_t* pos_in, const void* z, int64_t ldz, int dtype, const float* z_f32, int64_t ldzf,
+                          const float* el, const float* er, const float* smax, const float* ssum,
+                          const float* a_l, const float* a_r, const float* dout, int64_t lddo,
+                          float* ds, float* der, float* del, float* dz, int64_t lddz,
+                          float* da_l, float* da_r, float* dbias, int64_t n_nodes, int heads, int dim,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

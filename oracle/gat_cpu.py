@@ -1,0 +1,47 @@
+"""CPU oracle for the GAT layer of BASELINE cfg3  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+The reference repository contains NO GAT (no attention, no bf16; ``SAGEConv`` is imported
+but unused at src/components/graphs/models.py:1).  BASELINE.json configs[2] nevertheless names a "4-head GAT
+bf16", so the layer is defined here by the standard formulation (Velickovic et al. 2018, as implemented by
+DGL's GATConv):
+    z = X W                         [N, H, D]
+    e_uv,h = LeakyReLU_0.2( <a_l[h], z[u,h]> + <a_r[h], z[v,h]> )      for every edge u -> v
+    alpha_uv,h = softmax over the in-edges of v
+    out[v,h] = sum_u alpha_uv,h z[u,h]  + bias
+    hidden layers concatenate the heads, the output layer averages them.
+PARITY UNPINNED: there is no reference code, golden vector or published number for this row; this plain
+PyTorch-CPU restatement (per-edge tensors + index_add, fp32 or fp64) is the only oracle.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def gat_layer(x, w, a_l, a_r, bias, src, dst, n, heads, mean_heads=False, slope=0.2):
+    """x [N,F]; w [H*D, F]; a_l, a_r [H, D]; bias [H*D] (or [D] when mean_heads); src/dst int64 [E]."""
+    z = (x @ w.t()).view(n, heads, -1)                                   # [N,H,D]
+    el = (z * a_l.unsqueeze(0)).sum(-1)                                   # [N,H]
+    er = (z * a_r.unsqueeze(0)).sum(-1)
+    e = torch.nn.functional.leaky_relu(el[src] + er[dst], slope)          # [E,H]
+    m = torch.full((n, heads), -float("inf"), dtype=x.dtype).scatter_reduce(0, dst[:, None].expand(-1, heads), e,
+                                                                            reduce="amax", include_self=True)
+    p = torch.exp(e - m[dst])
+    denom = torch.zeros(n, heads, dtype=x.dtype).index_add_(0, dst, p)
+    alpha = p / denom[dst]
+    out = torch.zeros(n, heads, z.shape[-1], dtype=x.dtype).index_add_(0, dst, alpha.unsqueeze(-1) * z[src])
+    if mean_heads:
+        out = out.mean(1)
+        return out + bias if bias is not None else out
+    out = out.reshape(n, -1)
+    return out + bias if bias is not None else out
+
+
+def gat_forward(params, src, dst, n, x, heads, activation=torch.nn.functional.elu):
+    """params: list of dicts(w, a_l, a_r, bias) ; hidden layers concat + activation, last layer mean of heads."""
+    h = x
+    for i, p in enumerate(params):
+        last = i == len(params) - 1
+        h = gat_layer(h, p["w"], p["a_l"], p["a_r"], p["bias"], src, dst, n, heads, mean_heads=last)
+        if not last:
+            h = activation(h)
+    return h
