@@ -362,7 +362,8 @@ splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t mn, int
     float s0 = 0.f, s1 = 0.f;
     if (i < mn) {
         int k = sl;
-        for (; k + RED_S < splits; k += 2 * RED_S) {
+#pragma unroll 4
+        for (; k + RED_S < splits; k += 2 * RED_S) {             // 8 independent loads in flight
             s0 += slab[(int64_t)k * mn + i];
             s1 += slab[(int64_t)(k + RED_S) * mn + i];
         }
@@ -519,7 +520,9 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
     int splits = 1;
     // the reduction dimension is the node count for dW = dZ^T X: few output tiles, very long K
     if (pl.tiles < cus && ktiles >= 16) {
-        splits = (int)gte::ceil_div(2 * cus, pl.tiles);
+        // fill the resident slots (2 workgroups per CU) EXACTLY or stay below: 28 tiles x 19 splits = 532 workgroups
+        // on 512 slots ran a 20-workgroup straggler round that cost a third of the kernel (305 us -> see DESIGN)
+        splits = (2 * cus) / pl.tiles;
         const int max_splits = ktiles / 8 > 0 ? ktiles / 8 : 1;      // >= 8 K tiles (256 k) per split
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
@@ -805,7 +808,8 @@ colsum_fold_kernel(const float* __restrict__ partial, int nblocks, int n, float*
     const int j = blockIdx.x * 64 + lane;
     float a = 0.f, b = 0.f, c = 0.f;
     if (j < n) {
-        for (int k = slice; k < nblocks; k += 16) {
+#pragma unroll 4
+        for (int k = slice; k < nblocks; k += 16) {               // 4 x 3 independent loads in flight
             const float* pp = partial + (int64_t)k * 3 * n;
             a += pp[j]; b += pp[n + j]; c += pp[2 * n + j];
         }

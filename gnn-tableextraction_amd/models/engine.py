@@ -13,6 +13,7 @@ over ONE flat fp32 parameter buffer and ONE flat gradient buffer:
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -120,6 +121,8 @@ class FusedGcnSageStep(TrainStep):
             off += p.numel()
         self._bufs = {}
         self._graphs = {}
+        self._side = torch.cuda.Stream(device=self.flat_param.device)
+        self.overlap_dw = os.environ.get("GTE_OVERLAP_DW", "1") == "1"
 
     # -- buffers -------------------------------------------------------------------------------------
     def _buffers(self, n: int, f0: int):
@@ -143,6 +146,9 @@ class FusedGcnSageStep(TrainStep):
                      [lib.gte_gemm_workspace_bytes(dims[i + 1], dims[i], n) for i in range(len(layers))] +
                      [lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], n) for i in range(len(layers))])
             b["ws"] = torch.empty(int(ws), dtype=torch.uint8, device=dev)
+            # one private workspace per layer for the dW GEMMs: they run on the side stream, several at once
+            b["ws_dw"] = [torch.empty(int(lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], n)),
+                                      dtype=torch.uint8, device=dev) for i in range(len(layers))]
             self._bufs[key] = b
         return b
 
@@ -205,6 +211,7 @@ class FusedGcnSageStep(TrainStep):
                                   P(b["out3"]), ws, wsn, st), "gte_weighted_ce")
 
         # ---------------- backward ----------------
+        side_used = False
         for i in range(len(layers) - 1, -1, -1):
             L = layers[i]
             hin = x if i == 0 else b["y"][i - 1]
@@ -223,9 +230,22 @@ class FusedGcnSageStep(TrainStep):
                                       P(L.lynorm.weight) if ln else None, P(L.lynorm.bias) if ln else None, int(relu),
                                       P(dy), fout, P(gg), P(gbe), P(gb), n, fout, ws, wsn, st), "gte_ln_relu_bwd")
             dz, ahn = dy, b["ahn"][i]
-            with timed("gemm_tn", 4.0 * n * fin * fout):
-                check(lib.gte_sage_linear_dw(P(dz), fout, P(hin), ld(hin), fin, P(ahn), fin, fin, P(gW), 2 * fin, fout, n,
-                                             ws, wsn, st), "gte_sage_linear_dw")
+            # dW is MFMA-bound and nothing downstream needs it before Adam; the rest of the backward chain (dX, the
+            # transpose aggregation, the next LayerNorm backward) is mostly HBM-bound: run dW on the side stream so
+            # the two kinds of work share the chip.  dz (= dy_i, final for this step) and ahn/h are read-only here.
+            wdw = b["ws_dw"][i]
+            if self.overlap_dw and ops._timers is None:
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ev)
+                    check(lib.gte_sage_linear_dw(P(dz), fout, P(hin), ld(hin), fin, P(ahn), fin, fin, P(gW), 2 * fin, fout,
+                                                 n, P(wdw), wdw.numel(), self._side.cuda_stream), "gte_sage_linear_dw")
+                side_used = True
+            else:
+                with timed("gemm_tn", 4.0 * n * fin * fout):
+                    check(lib.gte_sage_linear_dw(P(dz), fout, P(hin), ld(hin), fin, P(ahn), fin, fin, P(gW), 2 * fin, fout,
+                                                 n, P(wdw), wdw.numel(), st), "gte_sage_linear_dw")
             if i > 0:
                 dh, dahn = b["dy"][i - 1], b["dahn"]
                 with timed("gemm_nn", 4.0 * n * fin * fout):
@@ -234,6 +254,8 @@ class FusedGcnSageStep(TrainStep):
                     check(lib.gte_gemm_f32(0, 0, n, fin, fout, P(dz), fout, P(W) + 4 * fin, 2 * fin, P(dahn), fin, 0, ws,
                                            wsn, st), "gte_gemm_f32 dh_neigh")
                 aggregate(rcsr, w_out, t_out, dahn, fin, dh, fin, fin, _lib.REDUCE_SUM, True)
+        if side_used:
+            torch.cuda.current_stream().wait_stream(self._side)          # join: Adam / all-reduce need every dW
         return b["out3"]
 
     def step(self, g, labels: torch.Tensor, n_global: Optional[int] = None) -> torch.Tensor:
