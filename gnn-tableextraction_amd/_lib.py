@@ -34,6 +34,7 @@ SIGNATURES = {
     "gte_edge_weights_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "gte_edge_weights_bbox": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                       c_int64, c_void_p]),
+    "gte_bbox_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "gte_inv_degree": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_sage_linear_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_int,

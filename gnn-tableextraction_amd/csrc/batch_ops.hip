@@ -166,3 +166,56 @@ extern "C" int gte_edge_weights_bbox(const int32_t* bbox, const int32_t* src, co
     hipLaunchKernelGGL(edge_weight_kernel, dim3(blocks), dim3(256), 0, s, dist, dst, graph_of_node, gmax, weight, n_edges);
     return gte::check_launch("edge_weights_bbox");
 }
+
+// ---- BBOX node features on the device ---------------------------------------------
+// replaces src/components/nlp/bbox.py:49-124 (Bbox.__call__), called per batch through _generate_features at
+// src/models/model_train.py:293: per word 9 geometry values
+//   [w, h, cx, cy, w*h, x0, y0, x1, y1],  cx = x1 - int(w/2), cy = y1 - int(h/2)        (bbox.py:49-54)
+// and the 4-bin content histogram [letters, digits, others, empty] of the word's characters (bbox.py:56-107):
+// fractions in float64, the largest bin absorbs 1 - sum so the bins add up to exactly 1, empty text -> [0,0,0,1].
+// The character classes are counted on the host (str.isalpha / str.isdigit are Unicode tables); everything
+// arithmetic is here.  Output = float32 of the float64 values, as `.float()` does at model_train.py:296.
+namespace {
+__global__ void __launch_bounds__(256)
+bbox_features_kernel(const int32_t* __restrict__ bbox, const int32_t* __restrict__ counts, float* __restrict__ out,
+                     int64_t ldo, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x0 = bbox[i * 4 + 0], y0 = bbox[i * 4 + 1], x1 = bbox[i * 4 + 2], y1 = bbox[i * 4 + 3];
+    const int w = x1 - x0, h = y1 - y0;
+    // Python int(w/2): true division then truncation toward zero
+    const int cx = x1 - (int)((double)w / 2.0), cy = y1 - (int)((double)h / 2.0);
+    float* o = out + i * ldo;
+    o[0] = (float)w; o[1] = (float)h; o[2] = (float)cx; o[3] = (float)cy;
+    o[4] = (float)((double)w * (double)h);
+    o[5] = (float)x0; o[6] = (float)y0; o[7] = (float)x1; o[8] = (float)y1;
+    const int na = counts[i * 3 + 0], nd = counts[i * 3 + 1], no = counts[i * 3 + 2];
+    const int ns = na + nd + no;
+    double hst[4] = {0.0, 0.0, 0.0, 0.0};
+    if (ns != 0) {
+        hst[0] = (double)na / (double)ns;
+        hst[1] = (double)nd / (double)ns;
+        hst[2] = (double)no / (double)ns;
+        const double sum = ((hst[0] + hst[1]) + hst[2]) + hst[3];       // Python sum(): left to right from 0
+        if (sum != 1.0) {
+            const double diff = 1.0 - sum;
+            int im = 0;                                                   // list.index(max(...)): first maximum
+            for (int j = 1; j < 4; ++j) if (hst[j] > hst[im]) im = j;
+            hst[im] = hst[im] + diff;
+        }
+    }
+    if (hst[0] == 0.0 && hst[1] == 0.0 && hst[2] == 0.0) hst[3] = 1.0;
+    for (int j = 0; j < 4; ++j) o[9 + j] = (float)hst[j];
+}
+}  // namespace
+
+extern "C" int gte_bbox_features(const int32_t* bbox, const int32_t* char_counts, float* out, int64_t ldo,
+                                 int64_t n_nodes, void* stream) {
+    if (n_nodes < 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "bbox_features: n < 0");
+    if (n_nodes == 0) return GTE_OK;
+    if (!bbox || !char_counts || !out) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "bbox_features: null pointer");
+    if (ldo < 13) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "bbox_features: ldo < 13");
+    hipLaunchKernelGGL(bbox_features_kernel, dim3((unsigned)gte::ceil_div(n_nodes, 256)), dim3(256), 0,
+                       gte::as_stream(stream), bbox, char_counts, out, ldo, n_nodes);
+    return gte::check_launch("bbox_features");
+}

@@ -122,6 +122,12 @@ int64_t gte_edge_weights_workspace_bytes(int64_t n_edges, int64_t n_graphs);
 int gte_edge_weights_bbox(const int32_t* bbox, const int32_t* src, const int32_t* dst, const int32_t* graph_of_node,
                           int64_t n_edges, int64_t n_graphs, float* weight, void* workspace, int64_t workspace_bytes,
                           void* stream);
+/* BBOX node features (replaces nlp/bbox.py:49-124 called at model_train.py:293): per word
+ * out[i, 0:13] = [w, h, cx, cy, w*h, x0, y0, x1, y1, hist_letters, hist_digits, hist_others, hist_empty].
+ * bbox int32[N,4]; char_counts int32[N,3] = (#letters, #digits, #other characters) of the word, counted on the host;
+ * float64 arithmetic as the reference, stored as float32.  Bit-exact vs the host formula. */
+int gte_bbox_features(const int32_t* bbox, const int32_t* char_counts, float* out, int64_t ldo, int64_t n_nodes,
+                      void* stream);
 /* inv_deg[v] = 1/(indptr[v+1]-indptr[v]) or 0  (models.py:74-78 as a standalone vector) */
 int gte_inv_degree(const int32_t* indptr, float* inv_deg, int64_t n_nodes, void* stream);
 
