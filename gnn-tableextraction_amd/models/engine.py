@@ -120,37 +120,56 @@ class FusedGcnSageStep(TrainStep):
             self._gslice[id(p)] = self.flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
         self._bufs = {}
+        self._graph_bufs = {}
+        self._private_key = None
         self._graphs = {}
         self._side = torch.cuda.Stream(device=self.flat_param.device)
         self.overlap_dw = os.environ.get("GTE_OVERLAP_DW", "1") == "1"
 
     # -- buffers -------------------------------------------------------------------------------------
-    def _buffers(self, n: int, f0: int):
-        key = (n, f0)
-        b = self._bufs.get(key)
-        if b is None:
-            dev = self.flat_param.device
-            new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-            layers = self.model.layers
-            dims = [f0] + [l.out_feats for l in layers]
-            b = {"ahn": [new(n, dims[i]) for i in range(len(layers))],
-                 "z": [new(n, dims[i + 1]) if isinstance(l.lynorm, nn.LayerNorm) else None for i, l in enumerate(layers)],
-                 "stats": [new(2 * n) if isinstance(l.lynorm, nn.LayerNorm) else None for l in layers],
-                 "y": [new(n, dims[i + 1]) for i in range(len(layers))],
-                 "dy": [new(n, dims[i + 1]) for i in range(len(layers))],      # grad w.r.t. layer output (dz in place)
-                 "dahn": new(n, max(dims[1:-1]) if len(dims) > 2 else 1),
-                 "out3": new(3)}
-            lib = self.lib
-            ws = max([lib.gte_weighted_ce_workspace_bytes(n)] +
-                     [lib.gte_ln_relu_bwd_workspace_bytes(n, d) for d in dims[1:]] +
-                     [lib.gte_gemm_workspace_bytes(dims[i + 1], dims[i], n) for i in range(len(layers))] +
-                     [lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], n) for i in range(len(layers))])
-            b["ws"] = torch.empty(int(ws), dtype=torch.uint8, device=dev)
-            # one private workspace per layer for the dW GEMMs: they run on the side stream, several at once
-            b["ws_dw"] = [torch.empty(int(lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], n)),
-                                      dtype=torch.uint8, device=dev) for i in range(len(layers))]
-            self._bufs[key] = b
+    def _alloc(self, cap: int, f0: int):
+        dev = self.flat_param.device
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        layers = self.model.layers
+        dims = [f0] + [l.out_feats for l in layers]
+        b = {"cap": cap,
+             "ahn": [new(cap, dims[i]) for i in range(len(layers))],
+             "z": [new(cap, dims[i + 1]) if isinstance(l.lynorm, nn.LayerNorm) else None for i, l in enumerate(layers)],
+             "stats": [new(2 * cap) if isinstance(l.lynorm, nn.LayerNorm) else None for l in layers],
+             "y": [new(cap, dims[i + 1]) for i in range(len(layers))],
+             "dy": [new(cap, dims[i + 1]) for i in range(len(layers))],      # grad w.r.t. layer output (dz in place)
+             "dahn": new(cap, max(dims[1:-1]) if len(dims) > 2 else 1),
+             "out3": new(3)}
+        lib = self.lib
+        # every workspace requirement grows with the node count, so the capacity's requirement covers any n <= cap
+        ws = max([lib.gte_weighted_ce_workspace_bytes(cap)] +
+                 [lib.gte_ln_relu_bwd_workspace_bytes(cap, d) for d in dims[1:]] +
+                 [lib.gte_gemm_workspace_bytes(dims[i + 1], dims[i], cap) for i in range(len(layers))])
+        b["ws"] = torch.empty(int(ws), dtype=torch.uint8, device=dev)
+        # one private workspace per layer for the dW GEMMs: they run on the side stream, several at once
+        b["ws_dw"] = [torch.empty(int(lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], cap)),
+                                  dtype=torch.uint8, device=dev) for i in range(len(layers))]
         return b
+
+    def _buffers(self, n: int, f0: int, private=None):
+        """Row views [0:n] of buffers allocated for a CAPACITY, not for n: in the real loop every batch has a
+        different node count, and per-count buffers would grow without bound (~300 MB per new count at F0=831).
+        The shared set grows geometrically to the largest batch seen.  A captured HIP graph bakes pointers in,
+        so each captured batch owns a private exact-size set (``private`` = its key) that is never reallocated."""
+        if private is not None:
+            full = self._graph_bufs.get(private)
+            if full is None:
+                full = self._graph_bufs[private] = self._alloc(n, f0)
+        else:
+            full = self._bufs.get(f0)
+            if full is None or full["cap"] < n:
+                cap = -(-int(n * 1.125) // 4096) * 4096
+                full = self._bufs[f0] = self._alloc(cap, f0)
+        v = lambda t: None if t is None else t[:n]
+        return {"ahn": [v(t) for t in full["ahn"]], "z": [v(t) for t in full["z"]],
+                "stats": [None if t is None else t[:2 * n] for t in full["stats"]], "y": [v(t) for t in full["y"]],
+                "dy": [v(t) for t in full["dy"]], "dahn": v(full["dahn"]), "out3": full["out3"], "ws": full["ws"],
+                "ws_dw": full["ws_dw"]}
 
     # -- the schedule ----------------------------------------------------------------------------------
     def forward_backward(self, g, labels: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:
@@ -160,7 +179,7 @@ class FusedGcnSageStep(TrainStep):
         x = ops._row_major(g.ndata['feat'])
         _lib.require_device(x, "FusedGcnSageStep")
         n, f0 = x.shape
-        b = self._buffers(n, f0)
+        b = self._buffers(n, f0, self._private_key)
         layers = list(self.model.layers)
         ew = g.edata.get("feat")
         csr, rcsr = g.in_csr(), g.out_csr()
@@ -275,6 +294,14 @@ class FusedGcnSageStep(TrainStep):
         place (resident pages).  Adam stays outside the graph because its bias correction depends on the
         step count, a host scalar."""
         scale = float(labels.shape[0]) / float(n_global) if (self.distributed and n_global) else 1.0
+        key = id(g)
+        self._private_key = key                       # this batch's buffers are private to its graph (never reallocated)
+        try:
+            return self._capture(g, labels, scale, key)
+        finally:
+            self._private_key = None
+
+    def _capture(self, g, labels, scale, key):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up on the side stream: buffers, CSR caches, props
@@ -294,5 +321,5 @@ class FusedGcnSageStep(TrainStep):
             self.t += 1
             self._optimizer_step()
             return out3
-        self._graphs[id(g)] = graph
+        self._graphs[key] = graph
         return replay

@@ -564,3 +564,28 @@ def test_edge_weights_kernel_matches_the_reference_formula_bitwise():
     b = np.array([[0, 0, 10, 10], [5, 5, 15, 15]], dtype=np.int32)
     one = G.edge_weights_from_boxes(dev(b), dev(np.array([0, 1])), dev(np.array([1, 0])), dev(np.zeros(2, np.int32)), 1)
     assert one.cpu().tolist() == [1.0, 1.0]
+
+
+def test_fused_step_buffers_do_not_grow_with_distinct_batch_sizes():
+    """In the real loop every batch has a different node count: buffers are capacity-based row views, not per-count."""
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    pages = S.make_pages(60, in_feats=13)
+    res = G.ResidentPages(_page_graphs(pages), DEV)
+    torch.manual_seed(0)
+    model = gte.GcnSAGE(13, 64, 9, 3, torch.nn.functional.relu, 0).to(DEV)
+    eng = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+    rng = np.random.default_rng(0)
+    big = res.batch(list(range(40)))
+    eng.step(big, big.ndata["label"])
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    sizes = set()
+    for _ in range(25):
+        ids = rng.choice(60, size=int(rng.integers(5, 35)), replace=False)
+        bg = res.batch(ids)
+        sizes.add(bg.num_nodes())
+        out3 = eng.step(bg, bg.ndata["label"])
+    torch.cuda.synchronize()
+    assert len(sizes) > 15 and len(eng._bufs) == 1
+    assert torch.cuda.memory_allocated() - base < 8 << 20        # only the (freed) per-batch graphs' worth of slack
+    assert np.isfinite(float(out3[0]))
