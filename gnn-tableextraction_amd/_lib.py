@@ -42,6 +42,13 @@ SIGNATURES = {
     "gte_sage_linear_dw_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
     "gte_sage_linear_dw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                    c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_sage_narrow_supported": (c_int, [c_int64, c_int64]),
+    "gte_sage_narrow_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                    c_void_p, c_int64, c_int64, c_void_p]),
+    "gte_sage_narrow_bwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "gte_sage_narrow_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                    c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                    c_void_p]),
     "gte_ln_relu_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p,
                                 c_int64, c_int64, c_void_p]),
     "gte_ln_relu_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),

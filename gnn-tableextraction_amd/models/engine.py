@@ -139,12 +139,14 @@ class FusedGcnSageStep(TrainStep):
              "y": [new(cap, dims[i + 1]) for i in range(len(layers))],
              "dy": [new(cap, dims[i + 1]) for i in range(len(layers))],      # grad w.r.t. layer output (dz in place)
              "dahn": new(cap, max(dims[1:-1]) if len(dims) > 2 else 1),
+             "tn": new(cap, dims[-1]), "q": new(cap, dims[-1]),       # narrow (class-count-wide) output layer
              "out3": new(3)}
         lib = self.lib
         # every workspace requirement grows with the node count, so the capacity's requirement covers any n <= cap
         ws = max([lib.gte_weighted_ce_workspace_bytes(cap)] +
                  [lib.gte_ln_relu_bwd_workspace_bytes(cap, d) for d in dims[1:]] +
-                 [lib.gte_gemm_workspace_bytes(dims[i + 1], dims[i], cap) for i in range(len(layers))])
+                 [lib.gte_gemm_workspace_bytes(dims[i + 1], dims[i], cap) for i in range(len(layers))] +
+                 [lib.gte_sage_narrow_bwd_workspace_bytes(cap, min(dims[-2], 256), min(dims[-1], 16))])
         b["ws"] = torch.empty(int(ws), dtype=torch.uint8, device=dev)
         # one private workspace per layer for the dW GEMMs: they run on the side stream, several at once
         b["ws_dw"] = [torch.empty(int(lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], cap)),
@@ -168,8 +170,13 @@ class FusedGcnSageStep(TrainStep):
         v = lambda t: None if t is None else t[:n]
         return {"ahn": [v(t) for t in full["ahn"]], "z": [v(t) for t in full["z"]],
                 "stats": [None if t is None else t[:2 * n] for t in full["stats"]], "y": [v(t) for t in full["y"]],
-                "dy": [v(t) for t in full["dy"]], "dahn": v(full["dahn"]), "out3": full["out3"], "ws": full["ws"],
+                "dy": [v(t) for t in full["dy"]], "dahn": v(full["dahn"]), "tn": v(full["tn"]), "q": v(full["q"]),
+                "out3": full["out3"], "ws": full["ws"],
                 "ws_dw": full["ws_dw"]}
+
+    def _narrow(self, layer, fin: int) -> bool:
+        return (not isinstance(layer.lynorm, nn.LayerNorm) and layer.activation is None and layer.linear.bias is not None
+                and bool(self.lib.gte_sage_narrow_supported(fin, layer.out_feats)))
 
     # -- the schedule ----------------------------------------------------------------------------------
     def forward_backward(self, g, labels: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:
@@ -210,6 +217,14 @@ class FusedGcnSageStep(TrainStep):
             ln = isinstance(L.lynorm, nn.LayerNorm)
             relu = L.activation is not None
             ahn, y = b["ahn"][i], b["y"][i]
+            if self._narrow(L, fin):
+                # class-count-wide layer: logits = h W_s^T + b + mean-aggregate(h W_n^T)  (aggregation on C columns)
+                with timed("narrow_fwd", 2.0 * n * fin * 4):
+                    check(lib.gte_sage_narrow_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(y), fout, P(b["tn"]),
+                                                  fout, n, st), "gte_sage_narrow_fwd")
+                aggregate(csr, w_in, None, b["tn"], fout, y, fout, fout, _lib.REDUCE_MEAN, True)
+                h = y
+                continue
             aggregate(csr, w_in, t_in, h, ld(h), ahn, fin, fin, _lib.REDUCE_MEAN, False)
             lin_out = b["z"][i] if ln else y
             with timed("gemm_nt", 4.0 * n * fin * fout):
@@ -243,6 +258,14 @@ class FusedGcnSageStep(TrainStep):
             gb = self._gslice[id(L.linear.bias)] if L.linear.bias is not None else None
             gg = self._gslice[id(L.lynorm.weight)] if ln else None
             gbe = self._gslice[id(L.lynorm.bias)] if ln else None
+            if self._narrow(L, fin):
+                # q = A_w^T (norm * dlogits) on C columns; dW = [dl^T h | q^T h], dh = dl W_s + q W_n, dbias = colsum(dl)
+                aggregate(rcsr, w_out, None, dy, fout, b["q"], fout, fout, _lib.REDUCE_SUM, False)
+                dh = b["dy"][i - 1] if i > 0 else None
+                with timed("narrow_bwd", 3.0 * n * fin * 4):
+                    check(lib.gte_sage_narrow_bwd(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,
+                                                  P(dh), fin, P(gW), 2 * fin, P(gb), n, ws, wsn, st), "gte_sage_narrow_bwd")
+                continue
             zsrc = b["z"][i] if ln else b["y"][i]
             # dz in place of dy; column sums straight into the flat gradient
             check(lib.gte_ln_relu_bwd(P(dy), fout, P(zsrc), fout, P(b["stats"][i]) if ln else None,

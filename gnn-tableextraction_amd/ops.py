@@ -390,9 +390,52 @@ class _SageLayer(torch.autograd.Function):
         return dh, dweight, dbias, dgamma, dbeta, None, None, None, None, None
 
 
+class _NarrowSageLayer(torch.autograd.Function):
+    """The class-count-wide output layer in transform-then-aggregate form (csrc/narrow_layer.hip):
+    logits = h W_s^T + b + mean-aggregate(h W_n^T) -- equal by linearity to [h | norm*A_w h] W^T + b."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, graph, w):
+        lib = _lib.load()
+        h = _row_major(h)
+        n, f = h.shape
+        c = weight.shape[0]
+        y = torch.empty((n, c), dtype=torch.float32, device=h.device)
+        tn = torch.empty((n, c), dtype=torch.float32, device=h.device)
+        check(lib.gte_sage_narrow_fwd(ptr(h), _ld(h), f, ptr(weight), _ld(weight), ptr(bias), c, ptr(y), c, ptr(tn), c, n,
+                                      current_stream()), "gte_sage_narrow_fwd")
+        csr = graph.in_csr()
+        spmm_csr(csr.indptr, csr.indices, graph.in_weights(w), tn, n, mean=True, out=y, accumulate=True)
+        ctx.graph, ctx.w = graph, w
+        ctx.save_for_backward(h, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        h, weight = ctx.saved_tensors
+        g = ctx.graph
+        n, f = h.shape
+        c = weight.shape[0]
+        dy = _row_major(dy.contiguous())
+        rcsr = g.out_csr()
+        q = spmm_csr(rcsr.indptr, rcsr.indices, g.out_weights(ctx.w, True), dy, n)
+        dh = torch.empty((n, f), dtype=torch.float32, device=h.device) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight)
+        db = torch.empty(c, dtype=torch.float32, device=h.device)
+        ws = _workspace(lib.gte_sage_narrow_bwd_workspace_bytes(n, f, c), h.device, "narrow")
+        check(lib.gte_sage_narrow_bwd(ptr(dy), _ld(dy), ptr(q), _ld(q), ptr(h), _ld(h), f, ptr(weight), _ld(weight), c,
+                                      ptr(dh), f, ptr(dw), _ld(dw), ptr(db), n, ptr(ws), ws.numel(), current_stream()),
+              "gte_sage_narrow_bwd")
+        return dh, dw, db, None, None
+
+
 def sage_layer(graph, h, weight, bias=None, gamma=None, beta=None, edge_weight=None, relu: bool = False,
                eps: float = 1e-5, use_pp: bool = False) -> torch.Tensor:
     require_device(h, "sage_layer")
+    if (gamma is None and not relu and not use_pp and bias is not None and h.dim() == 2
+            and _lib.load().gte_sage_narrow_supported(h.shape[1], weight.shape[0])):
+        return _NarrowSageLayer.apply(h, weight, bias, graph, edge_weight)
     return _SageLayer.apply(h, weight, bias, gamma, beta, graph, edge_weight, relu, eps, use_pp)
 
 

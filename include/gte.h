@@ -156,6 +156,23 @@ int gte_sage_linear_dw(const float* dz, int64_t lddz, const float* x1, int64_t l
                        const float* x2, int64_t ldx2, int64_t k2, float* dW, int64_t lddw,
                        int64_t n_out, int64_t n_nodes, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The class-count-wide output layer (hidden -> n_classes, no LayerNorm / activation: models.py:101-103) in
+ * transform-then-aggregate form (n_out <= 16, n_feat <= 256; gte_sage_narrow_supported says so):
+ *   fwd: t_self = h W[:, 0:F]^T + bias, t_neigh = h W[:, F:2F]^T;  the caller finishes with
+ *        logits = t_self + mean-aggregate(t_neigh)  (gte_spmm_csr_accumulate, REDUCE_MEAN) -- by linearity equal to
+ *        [h | norm * A_w h] W^T + b of models.py:53-72, with the aggregation on n_out columns instead of n_feat.
+ *   bwd: given dl = dlogits and q = A_w^T(norm * dl) (gte_spmm_csr over the out-edge CSR), writes
+ *        dh = dl W_s + q W_n (nullable), dW = [dl^T h | q^T h], dbias = colsum(dl).  Reads h once. */
+int gte_sage_narrow_supported(int64_t n_feat, int64_t n_out);
+int gte_sage_narrow_fwd(const float* h, int64_t ldh, int64_t n_feat, const float* W, int64_t ldw, const float* bias,
+                        int64_t n_out, float* t_self, int64_t ld_self, float* t_neigh, int64_t ld_neigh,
+                        int64_t n_nodes, void* stream);
+int64_t gte_sage_narrow_bwd_workspace_bytes(int64_t n_nodes, int64_t n_feat, int64_t n_out);
+int gte_sage_narrow_bwd(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
+                        int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dh, int64_t lddh,
+                        float* dW, int64_t lddw, float* dbias, int64_t n_nodes,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
 /* LayerNorm + ReLU alone (row-wise over n_out):  y = relu?(gamma * (z - mean) * rstd + beta).
  * replaces models.py:64-66 when the caller ran the linear part separately.  In place (y == z) is
  * allowed.  stats (nullable): f32[2*M] = mean, rstd. */
