@@ -12,10 +12,10 @@
 // chains, no TF32-like shortcut exists on gfx950).  LayerNorm passes are HBM-bound.
 //
 // GEMM structure (one workgroup = 4 waves, wave64):
-//   block tile BM x BN (128x128, 128x32 or 32x128), BK = 32; every wave owns a (BM/WM)x(BN/WN) patch
+//   block tile BM x BN (128x128, 64x128, 128x32 or 32x128), BK = 32; every wave owns a (BM/WM)x(BN/WN) patch
 //   of 32x32 MFMA tiles held in accumulator registers.
-//   global -> registers (dwordx4, prefetch of tile t+1 issued before the MFMAs of tile t)
-//          -> LDS (ds_write_b128) -> fragments.
+//   global -> registers (buffer_load_dwordx4 through a descriptor that range-checks the tile window; tile t+2
+//          is in flight while tile t is multiplied) -> LDS double buffer (ds_write_b128) -> fragments.
 //   K-contiguous operands ([rows][K] in memory) keep [rows][BK+4] LDS images: the +4 pad makes the
 //   16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots; one b128 read feeds 4 MFMAs
 //   (k = k0+4h+t, h = lane>>5: any k order is valid as long as A and B agree).
@@ -64,148 +64,162 @@ struct GemmParams {
     int tiles_per_split;               // K tiles (of BK) per split
 };
 
-// ---- staging: one BMxBK (or BKxBM) operand tile, global -> regs -> LDS ---------------------------
-// Everything that does not depend on the K position is computed ONCE per K segment (init): the
-// per-chunk row pointers (clamped into the matrix, so every load is in bounds and unconditional) and,
-// for row-contiguous operands, the shift of a chunk that straddles the last row.  Inside the K loop an
-// interior stage is just `pointer + k offset -> global_load_dwordx4 -> ds_write_b128`; only the last
-// K tile of a segment (K % 32 != 0) and the edge M/N tiles take the guarded path, selected by a
-// block-uniform flag.  (Measured on the first version, which recomputed addresses and guards per
-// chunk per stage: ~300 VALU instructions per stage per wave beside 32 MFMAs kept the MFMA pipe at
-// 62 % busy; and a version with `if (in range) load` serialised the loads -- one exec-masked branch
-// with s_waitcnt vmcnt(0) per chunk.)
-// Rows past the end of the matrix are NOT zeroed: they only feed accumulator rows/columns that the
-// epilogue never stores.  K positions past the end ARE zeroed (they feed every output).
-//   meta = s in 0..3 : element j of the chunk is loaded[j + s] (zero if j + s > 3);  meta >= 4 : zeros.
-// Requires every contiguous run to hold >= 4 floats (the host routes smaller shapes to gemm_small_kernel).
-__device__ __forceinline__ float4 shift_chunk(const f4u t, int s) {
-    float4 v;
-    v.x = s == 0 ? t.x : s == 1 ? t.y : s == 2 ? t.z : s == 3 ? t.w : 0.f;
-    v.y = s == 0 ? t.y : s == 1 ? t.z : s == 2 ? t.w : 0.f;
-    v.z = s == 0 ? t.z : s == 1 ? t.w : 0.f;
-    v.w = s == 0 ? t.w : 0.f;
-    return v;
-}
+// ---- operand tiles: global -> registers -> LDS ----------------------------------------------------
+// Every tile is read through a buffer descriptor (SRD) that covers exactly the valid part of the operand
+// window: rows past the matrix edge and K positions past the end of the reduction range fail the hardware
+// range check and read as 0.  The K loop therefore has no branches, no address clamps and no per-chunk
+// guards; the only per-stage vector work is one `or` per chunk (K-contiguous operands: chunks that START
+// past the row end are pushed out of the window) and three selects per chunk (a chunk that STRADDLES the
+// row end keeps its valid prefix).  The SRD base / size move with the K position on the scalar unit.
+//   (History, profiles/r01/gemm_variants.md: `if (in range) load` serialised the loads behind one
+//   s_waitcnt each; clamped addresses + selects cost ~300 VALU per stage; a lean interior path plus a guarded
+//   edge path put uniform branches between the MFMAs and kept the schedule from being pinned.)
+// Rows past the matrix edge of a row-contiguous operand may read the neighbouring k-row instead of 0: they
+// only feed accumulator rows / columns the epilogue never stores.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned SRD_FLAGS = 0x00020000u;      // gfx9 raw buffer, 32-bit data format
 
-// K-contiguous source ([rows][K], ld): chunk c -> (row = c / 8, kq = c % 8), 4 consecutive k.
-template <int ROWS>
-struct StageK {
-    static constexpr int CHUNKS = ROWS * (BK / 4);
-    static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
-    const float* base[PER_THREAD];      // &src[row][kq*4], row clamped
-    f4u r[PER_THREAD];
-    int meta[PER_THREAD];
-    __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int row0, int nrows, int tid) {
+constexpr int64_t GEMM_MAX_LD = (int64_t)1 << 22;   // (tile rows - 1) * ld * 4 bytes must fit the 31-bit window offset
+
+// One operand of the block tile: ROWS rows (M or N direction) x BK.  KC: stored [rows][K] (K-contiguous),
+// else [K][rows].  Per thread NCH 16-byte chunks:
+//   KC : chunk i = (row r0 + 32 i, k = 4 kq),  kq = tid % 8, r0 = tid / 8        LDS image [ROWS][KPAD]
+//   !KC: chunk i = (k = kr0 + i KSTEP, rows 4 rq ..), rq = tid % (ROWS/4)         LDS image [BK][ROWS + 4]
+template <bool KC, int ROWS>
+struct Operand {
+    static constexpr int NCH = ROWS * (BK / 4) / 256;
+    static constexpr int CPR = ROWS / 4, KSTEP = 256 / CPR;
+    static constexpr int LDS_FLOATS = KC ? ROWS * KPAD : BK * (ROWS + 4);
+    static_assert(NCH >= 1 && ROWS % 32 == 0, "tile rows");
+    int voff[2][NCH];        // byte offset of chunk i inside the window, per K segment (the segments may differ in ld)
+    int wofs;                // LDS float offset of chunk 0
+    int kpos;                // KC: 4 kq (k offset of this lane's chunks inside a stage)
+    f32x4 r[NCH];
+    int vc;                  // KC: valid k count of the staged chunks (<= 0 none, >= 4 all)
+
+    __device__ __forceinline__ void init(int64_t ld0, int64_t ld1, int tid) {
+        if constexpr (KC) {
+            const int kq = tid & 7, r0 = tid >> 3;
+            kpos = kq * 4;
+            wofs = r0 * KPAD + kq * 4;
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int c = min(tid + i * 256, CHUNKS - 1);
-            base[i] = src + (int64_t)min(row0 + c / (BK / 4), nrows - 1) * ld + (c % (BK / 4)) * 4;
-        }
-    }
-    __device__ __forceinline__ bool row_edge() const { return false; }
-    // one chunk of the tile starting at k = kl of a segment of length kseg; k_edge = (kl + BK > kseg), uniform
-    template <int i>
-    __device__ __forceinline__ void load_chunk(int kl, int kseg, bool k_edge, int tid) {
-        if (!k_edge) {
-            r[i] = *reinterpret_cast<const f4u*>(base[i] + kl);
+            for (int i = 0; i < NCH; ++i) {
+                voff[0][i] = (int)(((r0 + 32 * i) * ld0 + kq * 4) * 4);
+                voff[1][i] = (int)(((r0 + 32 * i) * ld1 + kq * 4) * 4);
+            }
         } else {
-            const int c = min(tid + i * 256, CHUNKS - 1);
-            const int k = kl + (c % (BK / 4)) * 4;
-            const int kk = min(k, kseg - 4);
-            meta[i] = k < kseg ? k - kk : 4;
-            r[i] = *reinterpret_cast<const f4u*>(base[i] + kl + (kk - k));
+            const int rq = tid % CPR, kr0 = tid / CPR;
+            kpos = 0;
+            wofs = kr0 * (ROWS + 4) + rq * 4;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                voff[0][i] = (int)(((kr0 + i * KSTEP) * ld0 + rq * 4) * 4);
+                voff[1][i] = (int)(((kr0 + i * KSTEP) * ld1 + rq * 4) * 4);
+            }
+        }
+        vc = 4;
+    }
+    static constexpr int lds_chunk_stride() { return KC ? 32 * KPAD : KSTEP * (ROWS + 4); }
+
+    // window of the stage at K position kl of a segment of length kseg: `origin` = &src[row0][0] (KC) or
+    // &src[0][row0] (!KC) of that segment, rows_valid rows of the tile exist.  32-bit scalar arithmetic only (the
+    // host bounds ld): a `left > 0 ? 64-bit expression : 0` here compiled to scalar BRANCHES inside the K loop.
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t window(const float* origin, int ld, int kl, int kseg,
+                                                              int rows_valid) const {
+        const int left = kseg - kl;
+        const int pos = left > 0 ? 1 : 0;
+        if constexpr (KC) {
+            const int bytes = ((rows_valid - 1) * ld + left) * 4 * pos;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(origin + kl), 0, bytes, SRD_FLAGS);
+        } else {
+            const int krows = left < BK ? left : BK;
+            const int bytes = ((krows - 1) * ld + rows_valid) * 4 * pos;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(origin + (int64_t)kl * ld), 0, bytes, SRD_FLAGS);
         }
     }
     template <int i>
-    __device__ __forceinline__ void store_chunk(float* __restrict__ lds, bool edge, int tid) const {
-        const int c = tid + i * 256;
-        if (CHUNKS % 256 == 0 || c < CHUNKS) {
-            float4 v = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
-            if (edge) v = shift_chunk(r[i], meta[i]);
-            *reinterpret_cast<float4*>(lds + (c / (BK / 4)) * KPAD + (c % (BK / 4)) * 4) = v;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t srd, int seg, int oob) {
+        const int vo = seg ? voff[1][i] : voff[0][i];
+        r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, KC ? (vo | oob) : vo, 0, 0));
+    }
+    template <int i>
+    __device__ __forceinline__ void store(float* __restrict__ lds) const {
+        f32x4 v = r[i];
+        if constexpr (KC) {
+            v.y = vc > 1 ? v.y : 0.f;
+            v.z = vc > 2 ? v.z : 0.f;
+            v.w = vc > 3 ? v.w : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(lds + wofs + i * lds_chunk_stride()) = v;
+    }
+    // fragment of the 32-row block starting at blk_row0 for k-group kg (8 k values): element t feeds MFMA t
+    // (k = 8 kg + 4 h + t, h = lane >> 5: any k order is valid as long as A and B agree)
+    static __device__ __forceinline__ f32x4 frag(const float* __restrict__ lds, int blk_row0, int kg, int lane) {
+        const int i = lane & 31, h = lane >> 5;
+        if constexpr (KC) {
+            return *reinterpret_cast<const f32x4*>(lds + (blk_row0 + i) * KPAD + kg * 8 + h * 4);
+        } else {
+            const float* p = lds + (kg * 8 + h * 4) * (ROWS + 4) + blk_row0 + i;
+            f32x4 f;
+            f.x = p[0]; f.y = p[ROWS + 4]; f.z = p[2 * (ROWS + 4)]; f.w = p[3 * (ROWS + 4)];
+            return f;
         }
     }
+    static constexpr int frag_reads() { return KC ? 1 : 4; }
 };
 
-// Row-contiguous source ([K][rows], ld): chunk c -> (k = c / (ROWS/4), rq = c % (ROWS/4)), 4 consecutive rows.
-template <int ROWS>
-struct StageR {
-    static constexpr int RPAD = ROWS + 4;
-    static constexpr int CHUNKS = BK * (ROWS / 4);
-    static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
-    const float* base[PER_THREAD];      // &src[kr][rr], rr = row clamped to nrows-4
-    int64_t ldk;
-    int shift[PER_THREAD];              // row - rr  (0 except in the chunk that straddles the last row)
-    bool any_shift;
-    f4u r[PER_THREAD];
-    int meta[PER_THREAD];
-    __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int row0, int nrows, int tid) {
-        ldk = ld;
-        any_shift = row0 + ROWS > nrows;                 // block-uniform: this tile holds the last rows
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int c = min(tid + i * 256, CHUNKS - 1);
-            const int row = row0 + (c % (ROWS / 4)) * 4;
-            const int rr = max(min(row, nrows - 4), 0);
-            shift[i] = row < nrows ? row - rr : 4;
-            base[i] = src + (int64_t)(c / (ROWS / 4)) * ld + rr;
-        }
-    }
-    __device__ __forceinline__ bool row_edge() const { return any_shift; }
-    template <int i>
-    __device__ __forceinline__ void load_chunk(int kl, int kseg, bool k_edge, int tid) {
-        if (!k_edge) {
-            r[i] = *reinterpret_cast<const f4u*>(base[i] + (int64_t)kl * ldk);
-            meta[i] = shift[i];
-        } else {
-            const int c = min(tid + i * 256, CHUNKS - 1);
-            const int kr = c / (ROWS / 4);
-            const int k = kl + kr;
-            const int kc = min(k, kseg - 1);
-            meta[i] = k < kseg ? shift[i] : 4;
-            r[i] = *reinterpret_cast<const f4u*>(base[i] + (int64_t)(kc - kr) * ldk);
-        }
-    }
-    template <int i>
-    __device__ __forceinline__ void store_chunk(float* __restrict__ lds, bool edge, int tid) const {
-        const int c = tid + i * 256;
-        if (CHUNKS % 256 == 0 || c < CHUNKS) {
-            float4 v = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
-            if (edge) v = shift_chunk(r[i], meta[i]);
-            *reinterpret_cast<float4*>(lds + (c / (ROWS / 4)) * RPAD + (c % (ROWS / 4)) * 4) = v;
-        }
-    }
-};
+template <bool AK, bool BKC, int BM, int BN>
+constexpr int gemm_lds_bytes() { return 2 * (Operand<AK, BM>::LDS_FLOATS + Operand<BKC, BN>::LDS_FLOATS) * (int)sizeof(float); }
 
-template <int ROWS>
-constexpr int lds_floats(bool kcontig) { return kcontig ? ROWS * KPAD : BK * (ROWS + 4); }
+#define GTE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_VALU = 0x002, SG_SALU = 0x004, SG_MFMA = 0x008, SG_VMEM_R = 0x020, SG_DS_R = 0x100, SG_DS_W = 0x200;
 
-// fragment of one 32-row block for k-group kg (8 k values): f[t] is the operand of MFMA t (k = 8kg+4h+t)
-template <bool KCONTIG, int ROWS>
-__device__ __forceinline__ void read_frag(const float* __restrict__ lds, int blk_row0, int kg, int lane, float (&f)[4]) {
-    const int i = lane & 31, h = lane >> 5;
-    if constexpr (KCONTIG) {
-        const float4 v = *reinterpret_cast<const float4*>(lds + (blk_row0 + i) * KPAD + kg * 8 + h * 4);
-        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-    } else {
-        const float* p = lds + (kg * 8 + h * 4) * (ROWS + 4) + blk_row0 + i;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) f[t] = p[t * (ROWS + 4)];
-    }
+// Scheduling pattern of one k-group: NMF MFMAs with NR LDS reads, then NP (ds_write, buffer_load) pairs, spread
+// one memory instruction behind every MFMA (two when there are more memory instructions than MFMAs).
+template <int NMF, int NR, int NP, bool SCALAR = false>
+__device__ __forceinline__ void pin_schedule() {
+    constexpr int OPS = NR + 2 * NP;
+    constexpr int Q = (OPS + NMF - 1) / NMF;                  // memory instructions per MFMA slot
+    // address / window arithmetic (scalar) and the tail selects (vector) ride along in the same slots: left to
+    // itself the scheduler clumps ~50 of them between two MFMAs, and a single wave cannot issue the next MFMA
+    // until it is through them (the matrix pipe idles once the gap exceeds the 64 cycles of one MFMA)
+    constexpr int NV = NP > 0 ? (40 + NMF - 1) / NMF : (SCALAR ? (8 + NMF - 1) / NMF : 0);
+    constexpr int NS = SCALAR ? (64 + NMF - 1) / NMF : (NP > 0 ? (8 + NMF - 1) / NMF : 0);
+    static_for<NMF>([&](auto Mi) {
+        constexpr int m = decltype(Mi)::value;
+        GTE_SGB(SG_MFMA, 1);
+        if constexpr (NS > 0) GTE_SGB(SG_SALU, NS);
+        if constexpr (NV > 0) GTE_SGB(SG_VALU, NV);
+        static_for<Q>([&](auto Qi) {
+            constexpr int o = m * Q + decltype(Qi)::value;
+            if constexpr (o < NR) GTE_SGB(SG_DS_R, 1);
+            else if constexpr (o < OPS && ((o - NR) & 1) == 0) GTE_SGB(SG_DS_W, 1);
+            else if constexpr (o < OPS) GTE_SGB(SG_VMEM_R, 1);
+        });
+    });
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // AK: A stored [M][K] (K-contiguous) else [K][M].  BKC: B stored [N][K] (K-contiguous) else [K][N].
+//
+// Software pipeline, one barrier per K stage (LDS double buffer).  While tile t is multiplied out of LDS[t & 1]:
+//   k-group 0/1: tile t+1 goes registers -> LDS[(t+1) & 1]; each ds_write is followed by the buffer_load that
+//                refills the same registers with tile t+2 (a full stage in flight before it is needed);
+//   k-group 2  : only fragment reads; then s_waitcnt lgkmcnt(0) + s_barrier;
+//   k-group 3  : its MFMAs hide the first fragment reads of tile t+1.
+// Every memory instruction sits behind an MFMA (pin_schedule), so ONE wave per SIMD keeps the matrix pipe fed;
+// the loop body is a single basic block.  Measured (profiles/micro/gemm_pipe.hip, M = 24 495): NT K = 1662,
+// N = 256: 120 TF (the two-barrier, single-buffer predecessor: 92 TF; vendor hipBLASLt: 98-121 TF);
+// N = 1000, K = 2000: 133 TF (predecessor 110, vendor 142).
 template <bool AK, bool BKC, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(256)
 gemm_f32_mfma_kernel(const GemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;          // 32x32 tiles per wave
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
-    constexpr int A_FLOATS = lds_floats<BM>(AK), B_FLOATS = lds_floats<BN>(BKC);
-    // ONE LDS buffer (27-37 KB): 3-4 workgroups stay resident per CU, which hides the two barriers per
-    // K stage better than a double-buffered image at 2 workgroups per CU did (measured: see DESIGN.md)
-    __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + B_FLOATS];
-    auto sAbuf = [&](int) -> float* { return lds; };
-    auto sBbuf = [&](int) -> float* { return lds + A_FLOATS; };
+    using OpA = Operand<AK, BM>;
+    using OpB = Operand<BKC, BN>;
+    constexpr int A_FLOATS = OpA::LDS_FLOATS, BUF = A_FLOATS + OpB::LDS_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -229,6 +243,79 @@ gemm_f32_mfma_kernel(const GemmParams p) {
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
 
+    // operand windows (block-uniform): origin of the tile's rows in each K segment
+    const int rowsA = min(BM, p.M - m0), rowsB = min(BN, seg_cols - n0);
+    const float* a_org0 = AK ? p.A1 + (int64_t)m0 * p.lda1 : p.A1 + m0;
+    const float* a_org1 = p.A2 ? (AK ? p.A2 + (int64_t)m0 * p.lda2 : p.A2 + m0) : a_org0;
+    const float* b_org0 = BKC ? Bmat + (int64_t)n0 * ldbm : Bmat + n0;
+    const float* b_org1 = BKC ? b_org0 + p.K1 : b_org0 + (int64_t)p.K1 * ldbm;
+
+    const int ld_a0 = (int)p.lda1, ld_a1 = (int)(p.A2 ? p.lda2 : p.lda1), ld_b = (int)ldbm;   // < GEMM_MAX_LD (host)
+
+    OpA opa;
+    OpB opb;
+    opa.init(p.lda1, p.A2 ? p.lda2 : p.lda1, tid);
+    opb.init(ldbm, ldbm, tid);
+
+    constexpr int NCA = OpA::NCH, NCB = OpB::NCH, NC = NCA + NCB, H = (NC + 1) / 2;
+    // Cursor over the K tiles this block loads: (segment, k position, tiles left).  `describe()` turns the cursor
+    // into the two operand windows + the per-lane tail masks of that tile and advances it; it is pure scalar
+    // work plus four vector instructions and runs in k-group 2, one stage before the loads that use it.
+    struct TileDesc {
+        __amdgpu_buffer_rsrc_t sa, sb;
+        int seg, oob_a, oob_b, vca, vcb;
+    };
+    int c_seg = t_begin >= tiles_seg0 ? 1 : 0;
+    int c_kl = (t_begin - (c_seg ? tiles_seg0 : 0)) * BK;
+    int c_left = t_end - t_begin;
+    // segment lengths pinned in scalar registers (read straight from the kernel argument the compiler turned the
+    // selects below into branches around lazy s_load_dword's -- inside the K loop)
+    int kseg0 = p.K1, kseg1 = p.K2;
+    asm volatile("" : "+s"(kseg0), "+s"(kseg1));
+    auto describe = [&]() {
+        TileDesc d;
+        int kseg = c_seg == 0 ? kseg0 : kseg1;
+        kseg = (c_seg < 2 && c_left > 0) ? kseg : 0;
+        const int left = kseg - c_kl;
+        d.seg = c_seg == 1 ? 1 : 0;
+        d.sa = opa.window(d.seg ? a_org1 : a_org0, d.seg ? ld_a1 : ld_a0, c_kl, kseg, rowsA);
+        d.sb = opb.window(d.seg ? b_org1 : b_org0, ld_b, c_kl, kseg, rowsB);
+        // K-contiguous chunks that start at or past the row end are pushed out of the window (plain arithmetic:
+        // a `cond ? x : y` on the offset became a divergent branch around the load)
+        d.vca = left - opa.kpos;
+        d.vcb = left - opb.kpos;
+        d.oob_a = ((d.vca - 1) >> 31) & (int)0x80000000;
+        d.oob_b = ((d.vcb - 1) >> 31) & (int)0x80000000;
+        c_kl += BK;
+        --c_left;
+        const bool done = c_kl >= kseg;
+        c_seg = done ? (c_seg < 2 ? c_seg + 1 : 2) : c_seg;
+        c_kl = done ? 0 : c_kl;
+        return d;
+    };
+    TileDesc D;
+    auto issue_loads = [&](auto FROM, auto TO) {           // chunks [FROM, TO) of the described tile (A first, then B)
+        static_for<NC>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j >= decltype(FROM)::value && j < decltype(TO)::value) {
+                if constexpr (j < NCA) opa.template load<j>(D.sa, D.seg, D.oob_a);
+                else opb.template load<j - NCA>(D.sb, D.seg, D.oob_b);
+            }
+        });
+    };
+    auto staged = [&]() { opa.vc = D.vca; opb.vc = D.vcb; };   // the described tile now sits in the staging registers
+    auto store_chunks = [&](int buf, auto FROM, auto TO) {
+        float* la = lds + buf * BUF;
+        float* lbp = la + A_FLOATS;
+        static_for<NC>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j >= decltype(FROM)::value && j < decltype(TO)::value) {
+                if constexpr (j < NCA) opa.template store<j>(la);
+                else opb.template store<j - NCA>(lbp);
+            }
+        });
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -237,83 +324,63 @@ gemm_f32_mfma_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    typename std::conditional<AK, StageK<BM>, StageR<BM>>::type stA;
-    typename std::conditional<BKC, StageK<BN>, StageR<BN>>::type stB;
-
-    // K segments: 0 = A1 / B rows-or-cols [0,K1), 1 = A2 / B [K1,K1+K2).  The hoisted pointers are
-    // (re)initialised when the prefetch crosses into segment 1 (at most once per block).
-    constexpr int NM = 4 * TM * TN;                       // MFMAs per k-group
-    constexpr int NCA = decltype(stA)::PER_THREAD, NCB = decltype(stB)::PER_THREAD;
-    int cur_seg = -1;
-    // tile being prefetched: position inside its segment, and whether it is that segment's K-tail tile
-    int pf_kl = 0, pf_kseg = 0;
-    bool pf_edge = false;       // K-tail flag of the tile whose loads are issued next
-    bool st_edge = false;       // ... of the tile sitting in the staging registers (next to be stored)
-    auto prefetch_setup = [&](int t) {                    // uniform scalar work + rare pointer re-init
-        const int seg = t >= tiles_seg0 ? 1 : 0;
-        if (seg != cur_seg) {
-            cur_seg = seg;
-            const int kb = seg ? p.K1 : 0;
-            stA.init(seg ? p.A2 : p.A1, seg ? p.lda2 : p.lda1, m0, p.M, tid);
-            if constexpr (BKC) stB.init(Bmat + kb, ldbm, n0, seg_cols, tid);
-            else stB.init(Bmat + (int64_t)kb * ldbm, ldbm, n0, seg_cols, tid);
-        }
-        pf_kl = (seg ? t - tiles_seg0 : t) * BK;
-        pf_kseg = seg ? p.K2 : p.K1;
-        pf_edge = pf_kl + BK > pf_kseg;
-    };
-    auto load_chunk = [&](auto J) {                       // chunk J of the tile set up by prefetch_setup
-        constexpr int j = decltype(J)::value;
-        if constexpr (j < NCA) stA.template load_chunk<j>(pf_kl, pf_kseg, pf_edge, tid);
-        else stB.template load_chunk<j - NCA>(pf_kl, pf_kseg, pf_edge, tid);
-    };
-    auto store_chunk = [&](auto J, int buf) {
-        constexpr int j = decltype(J)::value;
-        if constexpr (j < NCA) stA.template store_chunk<j>(sAbuf(buf), st_edge || stA.row_edge(), tid);
-        else stB.template store_chunk<j - NCA>(sBbuf(buf), st_edge || stB.row_edge(), tid);
-    };
-    float fa[2][TM][4], fb[2][TN][4];
+    f32x4 fa[2][TM], fb[2][TN];
     auto read_frags = [&](int buf, int kg, int slot) {
+        const float* la = lds + buf * BUF;
+        const float* lbp = la + A_FLOATS;
 #pragma unroll
-        for (int a = 0; a < TM; ++a) read_frag<AK, BM>(sAbuf(buf), (wm * TM + a) * 32, kg, lane, fa[slot][a]);
+        for (int a = 0; a < TM; ++a) fa[slot][a] = OpA::frag(la, (wm * TM + a) * 32, kg, lane);
 #pragma unroll
-        for (int b = 0; b < TN; ++b) read_frag<BKC, BN>(sBbuf(buf), (wn * TN + b) * 32, kg, lane, fb[slot][b]);
+        for (int b = 0; b < TN; ++b) fb[slot][b] = OpB::frag(lbp, (wn * TN + b) * 32, kg, lane);
     };
-    auto mfma_one = [&](int slot, int j) {                // j -> (tt, a, b), b fastest: consecutive MFMAs hit different accumulators
-        const int b = j % TN, a = (j / TN) % TM, tt = j / (TN * TM);
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][a][tt], fb[slot][b][tt], acc[a][b], 0, 0, 0);
-    };
-    auto mfma_group = [&](int slot) {
+    auto mfma_group = [&](int slot) {                      // b fastest: consecutive MFMAs hit different accumulators
 #pragma unroll
-        for (int j = 0; j < NM; ++j) mfma_one(slot, j);
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][a][tt], fb[slot][b][tt], acc[a][b], 0, 0, 0);
     };
+    constexpr int NMF = 4 * TM * TN;                       // MFMAs per k-group
+    constexpr int NR = TM * OpA::frag_reads() + TN * OpB::frag_reads();
+    using I0 = std::integral_constant<int, 0>;
+    using IH = std::integral_constant<int, H>;
+    using IN = std::integral_constant<int, NC>;
 
-    // Per K stage: barrier | staging registers (tile t) -> LDS | barrier | issue the global loads of tile
-    // t+1 (they land under this stage's MFMAs) | 4 k-groups of MFMAs, the fragments of k-group g+1 being
-    // read while the MFMAs of k-group g run (sched_barrier pins "reads before the MFMAs they hide under").
-    // Tried and measured slower or equal on the page-batch shapes (profiles/r01/gemm_variants.md): LDS double
-    // buffering with one barrier per stage (2 workgroups/CU instead of 3-4), per-MFMA interleaving of the
-    // staging instructions, a start-time stagger of co-resident workgroups.
     if (t_begin < t_end) {
-        prefetch_setup(t_begin);
-        static_for<NCA + NCB>([&](auto J) { load_chunk(J); });
-    }
-    for (int t = t_begin; t < t_end; ++t) {
-        st_edge = pf_edge;
-        __syncthreads();                       // previous tile's fragment reads are done
-        static_for<NCA + NCB>([&](auto J) { store_chunk(J, 0); });
-        __syncthreads();
-        if (t + 1 < t_end) {                   // prefetch under the MFMAs
-            prefetch_setup(t + 1);
-            static_for<NCA + NCB>([&](auto J) { load_chunk(J); });
-        }
+        // prologue: tile t_begin -> LDS[0], tile t_begin + 1 -> registers
+        D = describe();
+        issue_loads(I0{}, IN{});
+        staged();
+        store_chunks(0, I0{}, IN{});
+        D = describe();
+        issue_loads(I0{}, IN{});
+        staged();
+        D = describe();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         read_frags(0, 0, 0);
-#pragma unroll
-        for (int kg = 0; kg < BK / 8; ++kg) {
-            if (kg + 1 < BK / 8) read_frags(0, kg + 1, (kg + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_group(kg & 1);
-            __builtin_amdgcn_sched_barrier(0);
+        int cur = 0;
+        for (int t = t_begin; t < t_end; ++t, cur ^= 1) {
+            read_frags(cur, 1, 1);
+            store_chunks(cur ^ 1, I0{}, IH{});
+            issue_loads(I0{}, IH{});
+            mfma_group(0);
+            pin_schedule<NMF, NR, H>();
+            read_frags(cur, 2, 0);
+            store_chunks(cur ^ 1, IH{}, IN{});
+            issue_loads(IH{}, IN{});
+            mfma_group(1);
+            pin_schedule<NMF, NR, NC - H>();
+            staged();
+            read_frags(cur, 3, 1);
+            D = describe();
+            mfma_group(0);
+            pin_schedule<NMF, NR, 0, true>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            read_frags(cur ^ 1, 0, 0);
+            mfma_group(1);
+            pin_schedule<NMF, NR, 0>();
         }
     }
 
@@ -532,17 +599,25 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
     return pl;
 }
 
+template <bool AK, bool BKC, int BM, int BN, int WM, int WN>
+void launch_tile(const GemmParams& p, dim3 grid, hipStream_t s) {
+    constexpr int shm = gemm_lds_bytes<AK, BKC, BM, BN>();
+    static bool configured = false;                       // > 64 KB of dynamic LDS needs the opt-in, once per kernel
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<AK, BKC, BM, BN, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, BM, BN, WM, WN>), grid, dim3(256), shm, s, p);
+}
+
 template <bool AK, bool BKC>
 int launch_shape(const GemmParams& p, const Plan& pl, hipStream_t s) {
-    dim3 grid((unsigned)pl.tiles, (unsigned)pl.splits), block(256);
-    if (pl.bm == 128 && pl.bn == 128)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 128, 128, 2, 2>), grid, block, 0, s, p);
-    else if (pl.bm == 64 && pl.bn == 128)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 64, 128, 2, 2>), grid, block, 0, s, p);
-    else if (pl.bn == 32)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 128, 32, 4, 1>), grid, block, 0, s, p);
-    else
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, 32, 128, 1, 4>), grid, block, 0, s, p);
+    dim3 grid((unsigned)pl.tiles, (unsigned)pl.splits);
+    if (pl.bm == 128 && pl.bn == 128) launch_tile<AK, BKC, 128, 128, 2, 2>(p, grid, s);
+    else if (pl.bm == 64 && pl.bn == 128) launch_tile<AK, BKC, 64, 128, 2, 2>(p, grid, s);
+    else if (pl.bn == 32) launch_tile<AK, BKC, 128, 32, 4, 1>(p, grid, s);
+    else launch_tile<AK, BKC, 32, 128, 1, 4>(p, grid, s);
     return gte::check_launch("gemm_f32");
 }
 
@@ -559,6 +634,8 @@ int run_small(bool ak, bool bkc, GemmParams p, hipStream_t s) {
 int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace_bytes, hipStream_t s) {
     if (p.M == 0 || p.N == 0) return GTE_OK;
     if (needs_small_path(ak, bkc, p)) return run_small(ak, bkc, p, s);
+    if (p.lda1 >= GEMM_MAX_LD || p.lda2 >= GEMM_MAX_LD || p.ldb >= GEMM_MAX_LD || p.ldbn2 >= GEMM_MAX_LD)
+        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_f32: leading dimensions must be < 2^22 elements");
     const Plan pl = make_plan(p.M, p.N, p.K1, p.K2, p.Bn2 ? p.Nseg : 0);
     p.splits = pl.splits;
     p.tiles_per_split = pl.tiles_per_split;
