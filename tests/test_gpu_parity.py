@@ -205,6 +205,51 @@ def test_sage_linear_fwd_vs_torch(m, k1, k2, n_out, ln, relu):
         np.testing.assert_allclose(st[:m].cpu().numpy(), z.mean(1).numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,f,c", [(1000, 256, 9), (777, 64, 4), (333, 200, 16), (50, 13, 9), (2049, 128, 12), (31, 8, 1),
+                                   (24495, 256, 9)])
+def test_narrow_layer_fwd_bwd_vs_float64(n, f, c):
+    """The class-count-wide output layer (gte_sage_narrow_fwd / _bwd: matrix-pipe kernels when F % 8 == 0, plain
+    FMA kernels otherwise) against float64: t_self = h W_s^T + b, t_neigh = h W_n^T; dh = dl W_s + q W_n,
+    dW = [dl^T h | q^T h], dbias = colsum(dl).  Strided h / dh / dW exercise the leading dimensions."""
+    lib = gte._lib.load()
+    P, cs = gte._lib.ptr, gte._lib.current_stream
+    assert lib.gte_sage_narrow_supported(f, c)
+    rng = np.random.default_rng(n + f + c)
+    hbuf = dev(rng.standard_normal((n, f + 3)).astype(np.float32))
+    h = hbuf[:, :f]
+    W = dev((rng.standard_normal((c, 2 * f)) / np.sqrt(2 * f)).astype(np.float32))
+    b = dev(rng.standard_normal(c).astype(np.float32))
+    ts, tn = torch.full((n, c), 7.0, device=DEV), torch.full((n, c), 7.0, device=DEV)
+    gte._lib.check(lib.gte_sage_narrow_fwd(P(h), h.stride(0), f, P(W), W.stride(0), P(b), c, P(ts), c, P(tn), c, n, cs()), "fwd")
+    hd, Wd = h.double().cpu(), W.double().cpu()
+    np.testing.assert_allclose(ts.cpu().numpy(), (hd @ Wd[:, :f].T + b.double().cpu()).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tn.cpu().numpy(), (hd @ Wd[:, f:].T).numpy(), rtol=1e-5, atol=1e-5)
+
+    dl = dev(rng.standard_normal((n, c)).astype(np.float32) / n)
+    q = dev(rng.standard_normal((n, c)).astype(np.float32) / n)
+    dhbuf = torch.full((n, f + 5), 3.0, device=DEV)
+    dh = dhbuf[:, :f]
+    dWbuf = torch.full((c, 2 * f + 2), 3.0, device=DEV)
+    dW = dWbuf[:, :2 * f]
+    db = torch.full((c,), 3.0, device=DEV)
+    ws = torch.empty(lib.gte_sage_narrow_bwd_workspace_bytes(n, f, c), dtype=torch.uint8, device=DEV)
+    gte._lib.check(lib.gte_sage_narrow_bwd(P(dl), c, P(q), c, P(h), h.stride(0), f, P(W), W.stride(0), c, P(dh), dh.stride(0),
+                                           P(dW), dW.stride(0), P(db), n, P(ws), ws.numel(), cs()), "bwd")
+    dld, qd = dl.double().cpu(), q.double().cpu()
+    want_dh = dld @ Wd[:, :f] + qd @ Wd[:, f:]
+    want_dW = torch.cat([dld.T @ hd, qd.T @ hd], 1)
+    tol = lambda ref: dict(rtol=1e-5, atol=2e-6 * float(ref.abs().max()) + 1e-9)
+    np.testing.assert_allclose(dh.cpu().numpy(), want_dh.numpy(), **tol(want_dh))
+    np.testing.assert_allclose(dW.cpu().numpy(), want_dW.numpy(), **tol(want_dW))
+    np.testing.assert_allclose(db.cpu().numpy(), dld.sum(0).numpy(), **tol(dld.sum(0)))
+    assert float(dhbuf[:, f:].min()) == 3.0 and float(dWbuf[:, 2 * f:].min()) == 3.0          # padding untouched
+    # dh == nullptr (first layer): dW / dbias only
+    dW2, db2 = torch.empty(c, 2 * f, device=DEV), torch.empty(c, device=DEV)
+    gte._lib.check(lib.gte_sage_narrow_bwd(P(dl), c, P(q), c, P(h), h.stride(0), f, P(W), W.stride(0), c, None, f,
+                                           P(dW2), 2 * f, P(db2), n, P(ws), ws.numel(), cs()), "bwd")
+    assert torch.equal(dW2, dW.contiguous()) and torch.equal(db2, db)
+
+
 @pytest.mark.parametrize("m,n,ln,relu", [(300, 256, True, True), (100, 9, False, False), (513, 218, True, True),
                                          (64, 40, False, True), (50, 1000, True, False), (31, 64, True, True)])
 def test_ln_relu_bwd_vs_torch_autograd(m, n, ln, relu):
