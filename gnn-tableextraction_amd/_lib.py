@@ -42,6 +42,13 @@ SIGNATURES = {
     "gte_sage_linear_dw_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
     "gte_sage_linear_dw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                    c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_sage_transform_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                       c_int64, c_void_p]),
+    "gte_sage_qform_dw_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "gte_sage_qform_dw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                  c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_sage_qform_dx": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                  c_int64, c_int64, c_void_p]),
     "gte_sage_narrow_supported": (c_int, [c_int64, c_int64]),
     "gte_sage_narrow_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                     c_void_p, c_int64, c_int64, c_void_p]),

@@ -52,8 +52,11 @@ struct GemmParams {
     const float* A1; int64_t lda1; int K1;
     const float* A2; int64_t lda2; int K2;
     const float* B; int64_t ldb;       // B(k,n); k runs over K1+K2 (segment 1 starts at row/col K1)
+    const float* B2;                   // optional origin of B's K segment 1 (default: K1 rows / columns after B's origin)
     const float* Bn2; int64_t ldbn2;   // optional second B for output columns [Nseg, 2*Nseg): C = A [B | Bn2]
     int Nseg;                          // columns per N segment when Bn2 != nullptr (then N == 2*Nseg)
+    const float* An2; int64_t ldan2;   // optional A of N segment 1 (with Bn2): C = [A B | An2 Bn2]
+    int bias_cols;                     // > 0: the bias covers columns [0, bias_cols) only
     float* C; int64_t ldc;
     const float* bias;                 // nullable, per column n
     int M, N;
@@ -245,16 +248,19 @@ gemm_f32_mfma_kernel(const GemmParams p) {
 
     // operand windows (block-uniform): origin of the tile's rows in each K segment
     const int rowsA = min(BM, p.M - m0), rowsB = min(BN, seg_cols - n0);
-    const float* a_org0 = AK ? p.A1 + (int64_t)m0 * p.lda1 : p.A1 + m0;
+    const float* Amat = (nseg && p.An2) ? p.An2 : p.A1;
+    const int64_t ldam = (nseg && p.An2) ? p.ldan2 : p.lda1;
+    const float* a_org0 = AK ? Amat + (int64_t)m0 * ldam : Amat + m0;
     const float* a_org1 = p.A2 ? (AK ? p.A2 + (int64_t)m0 * p.lda2 : p.A2 + m0) : a_org0;
     const float* b_org0 = BKC ? Bmat + (int64_t)n0 * ldbm : Bmat + n0;
-    const float* b_org1 = BKC ? b_org0 + p.K1 : b_org0 + (int64_t)p.K1 * ldbm;
+    const float* b_org1 = p.B2 ? (BKC ? p.B2 + (int64_t)n0 * ldbm : p.B2 + n0)
+                               : (BKC ? b_org0 + p.K1 : b_org0 + (int64_t)p.K1 * ldbm);
 
-    const int ld_a0 = (int)p.lda1, ld_a1 = (int)(p.A2 ? p.lda2 : p.lda1), ld_b = (int)ldbm;   // < GEMM_MAX_LD (host)
+    const int ld_a0 = (int)ldam, ld_a1 = (int)(p.A2 ? p.lda2 : ldam), ld_b = (int)ldbm;   // < GEMM_MAX_LD (host)
 
     OpA opa;
     OpB opb;
-    opa.init(p.lda1, p.A2 ? p.lda2 : p.lda1, tid);
+    opa.init(ldam, p.A2 ? p.lda2 : ldam, tid);
     opb.init(ldbm, ldbm, tid);
 
     constexpr int NCA = OpA::NCH, NCB = OpB::NCH, NC = NCA + NCB, H = (NC + 1) / 2;
@@ -393,7 +399,7 @@ gemm_f32_mfma_kernel(const GemmParams p) {
         const int col_in_seg = n0 + (wn * TN + b) * 32 + col_l;
         if (col_in_seg >= seg_cols) continue;
         const int col = nseg * seg_cols + col_in_seg;
-        const float bv = (p.bias && p.splits <= 1) ? p.bias[col] : 0.f;
+        const float bv = (p.bias && p.splits <= 1 && (p.bias_cols <= 0 || col < p.bias_cols)) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int rbase = m0 + (wm * TM + a) * 32 + hrow;
@@ -422,7 +428,7 @@ gemm_f32_mfma_kernel(const GemmParams p) {
 constexpr int RED_E = 32, RED_S = 8;
 __global__ void __launch_bounds__(RED_E * RED_S)
 splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t mn, int N, float* __restrict__ C, int64_t ldc,
-                     const float* __restrict__ bias, int accumulate, int relu) {
+                     const float* __restrict__ bias, int accumulate, int relu, int bias_cols = 0) {
     __shared__ float part[RED_S][RED_E];
     const int e = threadIdx.x % RED_E, sl = threadIdx.x / RED_E;
     const int64_t i = (int64_t)blockIdx.x * RED_E + e;
@@ -444,7 +450,7 @@ splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t mn, int
         for (int q = 0; q < RED_S; ++q) s += part[q][e];
         const int64_t m = i / N;
         const int n = (int)(i - m * N);
-        if (bias) s += bias[n];
+        if (bias && (bias_cols <= 0 || n < bias_cols)) s += bias[n];
         float* dst = C + m * ldc + n;
         if (accumulate) s += *dst;
         if (relu) s = fmaxf(s, 0.f);
@@ -535,20 +541,21 @@ gemm_small_kernel(const GemmParams p) {
     if (idx >= (int64_t)p.M * p.N) return;
     const int m = (int)(idx / p.N), n = (int)(idx % p.N);
     float acc = 0.f;
+    const bool n2 = p.Bn2 && n >= p.Nseg;
     for (int seg = 0; seg < 2; ++seg) {
-        const float* A = seg ? p.A2 : p.A1;
-        const int64_t lda = seg ? p.lda2 : p.lda1;
-        const int K = seg ? p.K2 : p.K1, kb = seg ? p.K1 : 0;
+        const float* A = seg ? p.A2 : ((n2 && p.An2) ? p.An2 : p.A1);
+        const int64_t lda = seg ? p.lda2 : ((n2 && p.An2) ? p.ldan2 : p.lda1);
+        const int K = seg ? p.K2 : p.K1, kb = (seg && !p.B2) ? p.K1 : 0;
         for (int k = 0; k < K; ++k) {
             const float a = AK ? A[(int64_t)m * lda + k] : A[(int64_t)k * lda + m];
-            const float* Bm = (p.Bn2 && n >= p.Nseg) ? p.Bn2 : p.B;
-            const int64_t ldbm = (p.Bn2 && n >= p.Nseg) ? p.ldbn2 : p.ldb;
-            const int nn = (p.Bn2 && n >= p.Nseg) ? n - p.Nseg : n;
+            const float* Bm = (seg && p.B2) ? p.B2 : (n2 ? p.Bn2 : p.B);
+            const int64_t ldbm = n2 ? p.ldbn2 : p.ldb;
+            const int nn = n2 ? n - p.Nseg : n;
             const float b = BKC ? Bm[(int64_t)nn * ldbm + kb + k] : Bm[(int64_t)(kb + k) * ldbm + nn];
             acc = fmaf(a, b, acc);
         }
     }
-    if (p.bias) acc += p.bias[n];
+    if (p.bias && (p.bias_cols <= 0 || n < p.bias_cols)) acc += p.bias[n];
     float* dst = p.C + (int64_t)m * p.ldc + n;
     if (p.accumulate) acc += *dst;
     if (p.relu) acc = fmaxf(acc, 0.f);
@@ -634,7 +641,7 @@ int run_small(bool ak, bool bkc, GemmParams p, hipStream_t s) {
 int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace_bytes, hipStream_t s) {
     if (p.M == 0 || p.N == 0) return GTE_OK;
     if (needs_small_path(ak, bkc, p)) return run_small(ak, bkc, p, s);
-    if (p.lda1 >= GEMM_MAX_LD || p.lda2 >= GEMM_MAX_LD || p.ldb >= GEMM_MAX_LD || p.ldbn2 >= GEMM_MAX_LD)
+    if (p.lda1 >= GEMM_MAX_LD || p.lda2 >= GEMM_MAX_LD || p.ldb >= GEMM_MAX_LD || p.ldbn2 >= GEMM_MAX_LD || p.ldan2 >= GEMM_MAX_LD)
         return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_f32: leading dimensions must be < 2^22 elements");
     const Plan pl = make_plan(p.M, p.N, p.K1, p.K2, p.Bn2 ? p.Nseg : 0);
     p.splits = pl.splits;
@@ -657,7 +664,7 @@ int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace
     if (pl.splits > 1) {
         const int64_t mn = (int64_t)p.M * p.N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gte::ceil_div(mn, RED_E)), dim3(RED_E * RED_S), 0, s, p.slab,
-                           pl.splits, mn, p.N, p.C, p.ldc, p.bias, accumulate, relu);
+                           pl.splits, mn, p.N, p.C, p.ldc, p.bias, accumulate, relu, p.bias_cols);
         return gte::check_launch("gemm_f32 split-K reduce");
     }
     return GTE_OK;
@@ -985,6 +992,87 @@ extern "C" int gte_sage_linear_dw(const float* dz, int64_t lddz, const float* x1
     int rc = gte_gemm_f32(1, 0, n_out, k1, n_nodes, dz, lddz, x1, ldx1, dW, lddw, 0, workspace, workspace_bytes, stream);
     if (rc != GTE_OK || k2 == 0) return rc;
     return gte_gemm_f32(1, 0, n_out, k2, n_nodes, dz, lddz, x2, ldx2, dW + k1, lddw, 0, workspace, workspace_bytes, stream);
+}
+
+// ---- transform-then-aggregate ("q-form") entry points ---------------------------------------------------------
+// The reference layer computes z = [h | norm * A_w h] W^T + b (models.py:53-72).  With W = [W_s | W_n] and the
+// aggregation linear, z = h W_s^T + b + norm * A_w (h W_n^T): when the layer narrows (831 -> 256) aggregating AFTER
+// the transform moves 256 columns instead of 831.  In the backward, with q = A_w^T (norm * dz):
+//     dW = [dz^T h | q^T h],   dh = dz W_s + q W_n
+// so the aggregated input never has to be kept for the backward and dh is ONE GEMM with K = 2 * n_out.
+extern "C" int gte_sage_transform_fwd(const float* x, int64_t ldx, int64_t n_feat, const float* W, int64_t ldw,
+                                      const float* bias, int64_t n_out, float* t, int64_t ldt, int64_t n_nodes,
+                                      void* stream) {
+    if (n_nodes < 0 || n_out <= 0 || n_feat <= 0 || n_nodes > INT32_MAX || 2 * n_out > INT32_MAX || n_feat > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_transform_fwd: bad sizes");
+    if (n_nodes == 0) return GTE_OK;
+    if (!x || !W || !t) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_transform_fwd: null pointer");
+    if (ldx < n_feat || ldw < 2 * n_feat || ldt < 2 * n_out)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_transform_fwd: leading dimension too small");
+    // t[:, 0:n_out] = x W_s^T + b,  t[:, n_out:2 n_out] = x W_n^T : one launch, two N segments of B = W (stored [n_out][2F])
+    GemmParams p = {};
+    p.A1 = x; p.lda1 = ldx; p.K1 = (int)n_feat;
+    p.B = W; p.ldb = ldw; p.Bn2 = W + n_feat; p.ldbn2 = ldw; p.Nseg = (int)n_out;
+    p.C = t; p.ldc = ldt; p.bias = bias; p.bias_cols = (int)n_out; p.M = (int)n_nodes; p.N = (int)(2 * n_out);
+    hipStream_t s = gte::as_stream(stream);
+    if (needs_small_path(true, true, p)) return run_small(true, true, p, s);
+    if (p.lda1 >= GEMM_MAX_LD || p.ldb >= GEMM_MAX_LD)
+        return gte::fail(GTE_ERR_UNSUPPORTED, "sage_transform_fwd: leading dimensions must be < 2^22 elements");
+    Plan pl = make_plan(n_nodes, 2 * n_out, n_feat, 0, n_out);
+    pl.splits = 1;                                          // K = n_feat is short and M is the node count: never split
+    pl.tiles_per_split = (int)gte::ceil_div(n_feat, BK);
+    p.splits = 1; p.tiles_per_split = pl.tiles_per_split; p.slab = nullptr;
+    return launch_shape<true, true>(p, pl, s);
+}
+
+extern "C" int64_t gte_sage_qform_dw_workspace_bytes(int64_t n_out, int64_t n_feat, int64_t n_nodes) {
+    return gemm_workspace(n_out, 2 * n_feat, n_nodes, 0, n_feat);
+}
+
+// dW[n_out, 2F] = [dz^T x | q^T x]   (dz, q: [nodes][n_out]; x: [nodes][F])
+extern "C" int gte_sage_qform_dw(const float* dz, int64_t lddz, const float* q, int64_t ldq, const float* x, int64_t ldx,
+                                 int64_t n_feat, float* dW, int64_t lddw, int64_t n_out, int64_t n_nodes, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+    if (n_out <= 0 || n_feat <= 0 || n_nodes < 0 || n_out > INT32_MAX || 2 * n_feat > INT32_MAX || n_nodes > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_qform_dw: bad sizes");
+    if (!dz || !q || !x || !dW) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_qform_dw: null pointer");
+    if (lddz < n_out || ldq < n_out || ldx < n_feat || lddw < 2 * n_feat)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_qform_dw: leading dimension too small");
+    if (n_nodes == 0) {
+        for (int64_t r = 0; r < n_out; ++r)
+            if (hipMemsetAsync(dW + r * lddw, 0, (size_t)(2 * n_feat) * 4, gte::as_stream(stream)) != hipSuccess)
+                return gte::fail(GTE_ERR_LAUNCH, "sage_qform_dw: memset failed");
+        return GTE_OK;
+    }
+    GemmParams p = {};
+    p.A1 = dz; p.lda1 = lddz; p.K1 = (int)n_nodes; p.An2 = q; p.ldan2 = ldq;
+    p.B = x; p.ldb = ldx; p.Bn2 = x; p.ldbn2 = ldx; p.Nseg = (int)n_feat;
+    p.C = dW; p.ldc = lddw; p.M = (int)n_out; p.N = (int)(2 * n_feat);
+    return run_gemm(false, false, p, workspace, workspace_bytes, gte::as_stream(stream));
+}
+
+// dx[nodes, F] = dz W_s + q W_n   (W stored [n_out][2F]: W_s = W[:, 0:F], W_n = W[:, F:2F])
+extern "C" int gte_sage_qform_dx(const float* dz, int64_t lddz, const float* q, int64_t ldq, const float* W, int64_t ldw,
+                                 int64_t n_feat, int64_t n_out, float* dx, int64_t lddx, int64_t n_nodes, void* stream) {
+    if (n_out <= 0 || n_feat <= 0 || n_nodes < 0 || 2 * n_out > INT32_MAX || n_feat > INT32_MAX || n_nodes > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_qform_dx: bad sizes");
+    if (n_nodes == 0) return GTE_OK;
+    if (!dz || !q || !W || !dx) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_qform_dx: null pointer");
+    if (lddz < n_out || ldq < n_out || ldw < 2 * n_feat || lddx < n_feat)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_qform_dx: leading dimension too small");
+    GemmParams p = {};
+    p.A1 = dz; p.lda1 = lddz; p.K1 = (int)n_out; p.A2 = q; p.lda2 = ldq; p.K2 = (int)n_out;
+    p.B = W; p.ldb = ldw; p.B2 = W + n_feat;               // B(k, n) = W[k][n] for the dz rows, W[k][F + n] for the q rows
+    p.C = dx; p.ldc = lddx; p.M = (int)n_nodes; p.N = (int)n_feat;
+    hipStream_t s = gte::as_stream(stream);
+    if (needs_small_path(true, false, p)) return run_small(true, false, p, s);
+    if (p.lda1 >= GEMM_MAX_LD || p.lda2 >= GEMM_MAX_LD || p.ldb >= GEMM_MAX_LD)
+        return gte::fail(GTE_ERR_UNSUPPORTED, "sage_qform_dx: leading dimensions must be < 2^22 elements");
+    Plan pl = make_plan(n_nodes, n_feat, n_out, n_out);
+    pl.splits = 1;
+    pl.tiles_per_split = (int)(2 * gte::ceil_div(n_out, BK));
+    p.splits = 1; p.tiles_per_split = pl.tiles_per_split; p.slab = nullptr;
+    return launch_shape<true, false>(p, pl, s);
 }
 
 extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2,

@@ -125,6 +125,9 @@ class FusedGcnSageStep(TrainStep):
         self._graphs = {}
         self._side = torch.cuda.Stream(device=self.flat_param.device)
         self.overlap_dw = os.environ.get("GTE_OVERLAP_DW", "1") == "1"
+        # transform-then-aggregate where a layer narrows + q-form backward (see _transform_first / _qform); "0" keeps
+        # the reference's aggregate-then-transform order everywhere (same math, different summation order)
+        self.transform_first = os.environ.get("GTE_TRANSFORM_FIRST", "1") == "1"
 
     # -- buffers -------------------------------------------------------------------------------------
     def _alloc(self, cap: int, f0: int):
@@ -132,13 +135,20 @@ class FusedGcnSageStep(TrainStep):
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         layers = self.model.layers
         dims = [f0] + [l.out_feats for l in layers]
+        tf = [self._transform_first(l, dims[i]) for i, l in enumerate(layers)]
+        qf = [self._qform(i, l, dims[i]) for i, l in enumerate(layers)]
         b = {"cap": cap,
-             "ahn": [new(cap, dims[i]) for i in range(len(layers))],
-             "z": [new(cap, dims[i + 1]) if isinstance(l.lynorm, nn.LayerNorm) else None for i, l in enumerate(layers)],
+             # aggregated input [cap, fin] of an aggregate-first layer; a q-form layer reuses it for q in the backward
+             "ahn": [None if tf[i] else new(cap, dims[i]) for i in range(len(layers))],
+             # transform-first layer: t = [x W_s^T + b | x W_n^T]; z is accumulated into the left half, q reuses the right
+             "t": [new(cap, 2 * dims[i + 1]) if tf[i] else None for i in range(len(layers))],
+             "z": [new(cap, dims[i + 1]) if (isinstance(l.lynorm, nn.LayerNorm) and not tf[i]) else None
+                   for i, l in enumerate(layers)],
              "stats": [new(2 * cap) if isinstance(l.lynorm, nn.LayerNorm) else None for l in layers],
              "y": [new(cap, dims[i + 1]) for i in range(len(layers))],
              "dy": [new(cap, dims[i + 1]) for i in range(len(layers))],      # grad w.r.t. layer output (dz in place)
-             "dahn": new(cap, max(dims[1:-1]) if len(dims) > 2 else 1),
+             "dahn": new(cap, max([dims[i] for i in range(1, len(layers)) if not qf[i] and not self._narrow(layers[i], dims[i])]
+                                  + [1])),
              "tn": new(cap, dims[-1]), "q": new(cap, dims[-1]),       # narrow (class-count-wide) output layer
              "out3": new(3)}
         lib = self.lib
@@ -149,7 +159,8 @@ class FusedGcnSageStep(TrainStep):
                  [lib.gte_sage_narrow_bwd_workspace_bytes(cap, min(dims[-2], 256), min(dims[-1], 16))])
         b["ws"] = torch.empty(int(ws), dtype=torch.uint8, device=dev)
         # one private workspace per layer for the dW GEMMs: they run on the side stream, several at once
-        b["ws_dw"] = [torch.empty(int(lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], cap)),
+        b["ws_dw"] = [torch.empty(int(max(lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], cap),
+                                          lib.gte_sage_qform_dw_workspace_bytes(dims[i + 1], dims[i], cap))),
                                   dtype=torch.uint8, device=dev) for i in range(len(layers))]
         return b
 
@@ -168,7 +179,7 @@ class FusedGcnSageStep(TrainStep):
                 cap = -(-int(n * 1.125) // 4096) * 4096
                 full = self._bufs[f0] = self._alloc(cap, f0)
         v = lambda t: None if t is None else t[:n]
-        return {"ahn": [v(t) for t in full["ahn"]], "z": [v(t) for t in full["z"]],
+        return {"ahn": [v(t) for t in full["ahn"]], "t": [v(t) for t in full["t"]], "z": [v(t) for t in full["z"]],
                 "stats": [None if t is None else t[:2 * n] for t in full["stats"]], "y": [v(t) for t in full["y"]],
                 "dy": [v(t) for t in full["dy"]], "dahn": v(full["dahn"]), "tn": v(full["tn"]), "q": v(full["q"]),
                 "out3": full["out3"], "ws": full["ws"],
@@ -177,6 +188,19 @@ class FusedGcnSageStep(TrainStep):
     def _narrow(self, layer, fin: int) -> bool:
         return (not isinstance(layer.lynorm, nn.LayerNorm) and layer.activation is None and layer.linear.bias is not None
                 and bool(self.lib.gte_sage_narrow_supported(fin, layer.out_feats)))
+
+    def _transform_first(self, layer, fin: int) -> bool:
+        """Forward as  z = h W_s^T + b + mean-aggregate(h W_n^T)  when the layer narrows (831 -> 256): the aggregation
+        moves out_feats columns instead of fin (gte_sage_transform_fwd)."""
+        return (self.transform_first and isinstance(layer.lynorm, nn.LayerNorm) and layer.linear.bias is not None
+                and not self._narrow(layer, fin) and fin > layer.out_feats)
+
+    def _qform(self, i: int, layer, fin: int) -> bool:
+        """Backward through q = A_w^T(norm * dz): dW = [dz^T h | q^T h], dh = dz W_s + q W_n.  Always for a transform-first
+        layer (nothing else was saved); for an inner layer when q is not wider than the classic dahn."""
+        if self._narrow(layer, fin):
+            return False
+        return self._transform_first(layer, fin) or (self.transform_first and i > 0 and layer.out_feats <= fin)
 
     # -- the schedule ----------------------------------------------------------------------------------
     def forward_backward(self, g, labels: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:
@@ -194,17 +218,19 @@ class FusedGcnSageStep(TrainStep):
         big = ops.use_tiled(n, max(f0, max(l.out_feats for l in self.model.layers)))
         t_in, t_out = (g.in_tiles(), g.out_tiles()) if big else (None, None)
 
+        PP = lambda a: a if isinstance(a, int) else P(a)           # tensor or raw device address (a column offset into one)
+
         def aggregate(csr_, w_, tiles_, src, ldsrc, dst, lddst, f, reduce, accumulate):
             nbytes = 2.0 * n * f * 4 + 8.0 * csr_.indices.numel() + 4.0 * (n + 1)
             if tiles_ is not None and ops.use_tiled(n, f):
                 with timed("spmm_tiled", nbytes):
                     check(lib.gte_spmm_csr_tiled(P(csr_.indptr), P(csr_.indices), P(tiles_.local_index), P(w_),
-                                                 P(tiles_.tile_ptr), P(tiles_.tile_src), P(src), ldsrc, P(dst), lddst,
+                                                 P(tiles_.tile_ptr), P(tiles_.tile_src), PP(src), ldsrc, PP(dst), lddst,
                                                  n, f, reduce, int(accumulate), st), "gte_spmm_csr_tiled")
             else:
                 fn = lib.gte_spmm_csr_accumulate if accumulate else lib.gte_spmm_csr
                 with timed("spmm_csr", nbytes):
-                    check(fn(P(csr_.indptr), P(csr_.indices), P(w_), P(src), ldsrc, P(dst), lddst, n, f, _lib.GTE_F32,
+                    check(fn(P(csr_.indptr), P(csr_.indices), P(w_), PP(src), ldsrc, PP(dst), lddst, n, f, _lib.GTE_F32,
                              reduce, st), "gte_spmm_csr")
         ws, wsn = P(b["ws"]), b["ws"].numel()
         ld = ops._ld
@@ -223,6 +249,16 @@ class FusedGcnSageStep(TrainStep):
                     check(lib.gte_sage_narrow_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(y), fout, P(b["tn"]),
                                                   fout, n, st), "gte_sage_narrow_fwd")
                 aggregate(csr, w_in, None, b["tn"], fout, y, fout, fout, _lib.REDUCE_MEAN, True)
+                h = y
+                continue
+            if self._transform_first(L, fin):
+                t = b["t"][i]
+                with timed("gemm_nt", 4.0 * n * fin * fout):
+                    check(lib.gte_sage_transform_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(t), 2 * fout, n, st),
+                          "gte_sage_transform_fwd")
+                aggregate(csr, w_in, t_in, P(t) + 4 * fout, 2 * fout, t, 2 * fout, fout, _lib.REDUCE_MEAN, True)
+                check(lib.gte_ln_relu_fwd(P(t), 2 * fout, P(L.lynorm.weight), P(L.lynorm.bias), float(L.lynorm.eps),
+                                          int(relu), P(y), fout, P(b["stats"][i]), n, fout, st), "gte_ln_relu_fwd")
                 h = y
                 continue
             aggregate(csr, w_in, t_in, h, ld(h), ahn, fin, fin, _lib.REDUCE_MEAN, False)
@@ -266,29 +302,44 @@ class FusedGcnSageStep(TrainStep):
                     check(lib.gte_sage_narrow_bwd(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,
                                                   P(dh), fin, P(gW), 2 * fin, P(gb), n, ws, wsn, st), "gte_sage_narrow_bwd")
                 continue
-            zsrc = b["z"][i] if ln else b["y"][i]
+            tfirst, qform = self._transform_first(L, fin), self._qform(i, L, fin)
+            zsrc = b["t"][i] if tfirst else (b["z"][i] if ln else b["y"][i])
             # dz in place of dy; column sums straight into the flat gradient
-            check(lib.gte_ln_relu_bwd(P(dy), fout, P(zsrc), fout, P(b["stats"][i]) if ln else None,
+            check(lib.gte_ln_relu_bwd(P(dy), fout, P(zsrc), 2 * fout if tfirst else fout, P(b["stats"][i]) if ln else None,
                                       P(L.lynorm.weight) if ln else None, P(L.lynorm.bias) if ln else None, int(relu),
                                       P(dy), fout, P(gg), P(gbe), P(gb), n, fout, ws, wsn, st), "gte_ln_relu_bwd")
             dz, ahn = dy, b["ahn"][i]
+            if qform:
+                # q = A_w^T (norm * dz) into the dead right half of t (transform-first) or the dead ahn buffer
+                qp, ldq = (P(b["t"][i]) + 4 * fout, 2 * fout) if tfirst else (P(ahn), fin)
+                aggregate(rcsr, w_out, t_out, dz, fout, qp, ldq, fout, _lib.REDUCE_SUM, False)
             # dW is MFMA-bound and nothing downstream needs it before Adam; the rest of the backward chain (dX, the
             # transpose aggregation, the next LayerNorm backward) is mostly HBM-bound: run dW on the side stream so
             # the two kinds of work share the chip.  dz (= dy_i, final for this step) and ahn/h are read-only here.
             wdw = b["ws_dw"][i]
+
+            def dw_launch(stream):
+                if qform:
+                    check(lib.gte_sage_qform_dw(P(dz), fout, qp, ldq, P(hin), ld(hin), fin, P(gW), 2 * fin, fout, n, P(wdw),
+                                                wdw.numel(), stream), "gte_sage_qform_dw")
+                else:
+                    check(lib.gte_sage_linear_dw(P(dz), fout, P(hin), ld(hin), fin, P(ahn), fin, fin, P(gW), 2 * fin, fout,
+                                                 n, P(wdw), wdw.numel(), stream), "gte_sage_linear_dw")
             if self.overlap_dw and ops._timers is None:
                 ev = torch.cuda.Event()
                 ev.record()
                 with torch.cuda.stream(self._side):
                     self._side.wait_event(ev)
-                    check(lib.gte_sage_linear_dw(P(dz), fout, P(hin), ld(hin), fin, P(ahn), fin, fin, P(gW), 2 * fin, fout,
-                                                 n, P(wdw), wdw.numel(), self._side.cuda_stream), "gte_sage_linear_dw")
+                    dw_launch(self._side.cuda_stream)
                 side_used = True
             else:
                 with timed("gemm_tn", 4.0 * n * fin * fout):
-                    check(lib.gte_sage_linear_dw(P(dz), fout, P(hin), ld(hin), fin, P(ahn), fin, fin, P(gW), 2 * fin, fout,
-                                                 n, P(wdw), wdw.numel(), st), "gte_sage_linear_dw")
-            if i > 0:
+                    dw_launch(st)
+            if i > 0 and qform:
+                with timed("gemm_nn", 4.0 * n * fin * fout):
+                    check(lib.gte_sage_qform_dx(P(dz), fout, qp, ldq, P(W), 2 * fin, fin, fout, P(b["dy"][i - 1]), fin, n, st),
+                          "gte_sage_qform_dx")
+            elif i > 0:
                 dh, dahn = b["dy"][i - 1], b["dahn"]
                 with timed("gemm_nn", 4.0 * n * fin * fout):
                     check(lib.gte_gemm_f32(0, 0, n, fin, fout, P(dz), fout, P(W), 2 * fin, P(dh), fin, 0, ws, wsn, st),

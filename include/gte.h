@@ -156,6 +156,23 @@ int gte_sage_linear_dw(const float* dz, int64_t lddz, const float* x1, int64_t l
                        const float* x2, int64_t ldx2, int64_t k2, float* dW, int64_t lddw,
                        int64_t n_out, int64_t n_nodes, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- transform-then-aggregate ("q-form") of a GcnSAGELayer --------------------------------------------------
+ * replaces (reference src/components/graphs/models.py:53-72, `torch.cat((h, ah * norm), 1)` -> nn.Linear) where the
+ * layer narrows: by linearity  z = h W_s^T + b + norm * A_w (h W_n^T), so the aggregation moves n_out columns
+ * instead of n_feat.  Backward with q = A_w^T (norm * dz):  dW = [dz^T h | q^T h],  dh = dz W_s + q W_n.
+ *   gte_sage_transform_fwd : t[:, 0:n_out] = x W_s^T + bias,  t[:, n_out:2 n_out] = x W_n^T      (one GEMM launch)
+ *   gte_sage_qform_dw      : dW[n_out, 2 n_feat] = [dz^T x | q^T x]                               (split over nodes)
+ *   gte_sage_qform_dx      : dx[nodes, n_feat]   = dz W_s + q W_n                                 (one GEMM, K = 2 n_out)
+ * W is the layer weight [n_out][2 n_feat] (ldw >= 2 n_feat).  All matrices fp32 row-major with leading dimensions. */
+int gte_sage_transform_fwd(const float* x, int64_t ldx, int64_t n_feat, const float* W, int64_t ldw, const float* bias,
+                           int64_t n_out, float* t, int64_t ldt, int64_t n_nodes, void* stream);
+int64_t gte_sage_qform_dw_workspace_bytes(int64_t n_out, int64_t n_feat, int64_t n_nodes);
+int gte_sage_qform_dw(const float* dz, int64_t lddz, const float* q, int64_t ldq, const float* x, int64_t ldx,
+                      int64_t n_feat, float* dW, int64_t lddw, int64_t n_out, int64_t n_nodes, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+int gte_sage_qform_dx(const float* dz, int64_t lddz, const float* q, int64_t ldq, const float* W, int64_t ldw,
+                      int64_t n_feat, int64_t n_out, float* dx, int64_t lddx, int64_t n_nodes, void* stream);
+
 /* The class-count-wide output layer (hidden -> n_classes, no LayerNorm / activation: models.py:101-103) in
  * transform-then-aggregate form (n_out <= 16, n_feat <= 256; gte_sage_narrow_supported says so):
  *   fwd: t_self = h W[:, 0:F]^T + bias, t_neigh = h W[:, F:2F]^T;  the caller finishes with
