@@ -31,6 +31,12 @@ struct DeviceProps {
 };
 const DeviceProps& device_props();
 
+// Deferred folds (gte_fold_defer_begin / _flush): while a deferral is open on this thread, a producer that would launch
+// its own partial-sum fold kernel queues the fold instead; the flush runs every queued fold in ONE launch.
+//   dst[r * ld + c] = sum_{k < count} src[k * stride + r * rowlen + c]   (fixed order: deterministic)
+// Returns false when no deferral is open (the producer launches its own fold as usual).
+bool defer_fold(const float* src, int64_t stride, int count, int rows, int rowlen, float* dst, int64_t ld);
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 

@@ -38,7 +38,102 @@ const DeviceProps& device_props() {
     return props;
 }
 
+// ---- deferred folds ------------------------------------------------------------------------------------------
+// A training step ends five kernels with "sum the per-block partials": LayerNorm column sums (x2), the narrow layer's
+// dW, two split-K dW GEMMs.  Each fold is a few hundred KB to a few MB and latency-bound (6-11 us as its own launch,
+// plus the launch gap); queued and run together they overlap each other: one launch before the optimizer.
+constexpr int kMaxFolds = 24;
+struct FoldDesc {
+    const float* src; long long stride; float* dst; long long ld;
+    int count, rows, rowlen, first_block, slices;
+};
+struct FoldBatch { FoldDesc d[kMaxFolds]; int n; };
+
+struct FoldQueue { FoldBatch batch; bool open = false; hipStream_t stream = nullptr; int blocks = 0; };
+static FoldQueue& fold_queue() {
+    static thread_local FoldQueue q;
+    return q;
+}
+
 }  // namespace gte
+
+// block = 256 threads = `slices` x (256 / slices) elements.  slice s sums partials s, s + slices, ... (independent loads
+// in flight), the slice sums are added in slice order through LDS.  A split-K slab set (tens of partials, ~0.5 M
+// elements) runs with one slice -- a thread streams its element through all partials; a block-partial set (hundreds
+// of partials, a few thousand elements) with 16.
+__global__ void __launch_bounds__(256)
+gte_fold_batch_kernel(const gte::FoldBatch fb) {
+    __shared__ float part[256];
+    int di = 0;
+#pragma unroll 1
+    for (int i = 1; i < fb.n; ++i) if ((int)blockIdx.x >= fb.d[i].first_block) di = i;
+    const gte::FoldDesc d = fb.d[di];
+    const int epb = 256 / d.slices;
+    const int el = threadIdx.x % epb, sl = threadIdx.x / epb;
+    const long long total = (long long)d.rows * d.rowlen;
+    const long long e = (long long)((int)blockIdx.x - d.first_block) * epb + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < total) {
+        const float* p = d.src + e;
+        const long long st = d.stride * d.slices;
+        int k = sl;
+        for (; k + 3 * d.slices < d.count; k += 4 * d.slices) {
+            const float* pk = p + k * d.stride;
+            s0 += pk[0]; s1 += pk[st]; s2 += pk[2 * st]; s3 += pk[3 * st];
+        }
+        for (; k < d.count; k += d.slices) s0 += p[k * d.stride];
+    }
+    part[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && e < total) {
+        float v = 0.f;
+        for (int t = 0; t < d.slices; ++t) v += part[t * epb + el];
+        const long long r = e / d.rowlen;
+        d.dst[r * d.ld + (e - r * d.rowlen)] = v;
+    }
+}
+
+namespace gte {
+
+static int flush_folds(FoldQueue& q) {
+    if (q.batch.n == 0) return GTE_OK;
+    hipLaunchKernelGGL(gte_fold_batch_kernel, dim3((unsigned)q.blocks), dim3(256), 0, q.stream, q.batch);
+    q.batch.n = 0;
+    q.blocks = 0;
+    return check_launch("fold_batch");
+}
+
+bool defer_fold(const float* src, int64_t stride, int count, int rows, int rowlen, float* dst, int64_t ld) {
+    FoldQueue& q = fold_queue();
+    if (!q.open) return false;
+    if (!dst || rows <= 0 || rowlen <= 0) return true;
+    if (q.batch.n == kMaxFolds) (void)flush_folds(q);
+    FoldDesc& d = q.batch.d[q.batch.n++];
+    d.src = src; d.stride = stride; d.dst = dst; d.ld = ld;
+    d.count = count; d.rows = rows; d.rowlen = rowlen; d.first_block = q.blocks;
+    d.slices = count >= 128 ? 16 : (count >= 32 ? 4 : 1);
+    q.blocks += (int)ceil_div((int64_t)rows * rowlen, 256 / d.slices);
+    return true;
+}
+
+}  // namespace gte
+
+extern "C" int gte_fold_defer_begin(void* stream) {
+    gte::FoldQueue& q = gte::fold_queue();
+    if (q.open) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_begin: a deferral is already open on this thread");
+    q.open = true;
+    q.stream = gte::as_stream(stream);
+    q.batch.n = 0;
+    q.blocks = 0;
+    return GTE_OK;
+}
+
+extern "C" int gte_fold_defer_flush(void) {
+    gte::FoldQueue& q = gte::fold_queue();
+    if (!q.open) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush: no deferral is open on this thread");
+    q.open = false;
+    return gte::flush_folds(q);
+}
 
 extern "C" int gte_version(void) { return GTE_VERSION; }
 

@@ -453,8 +453,14 @@ extern "C" int gte_sage_narrow_bwd(const float* dl, int64_t lddl, const float* q
                        (int)n_nodes, F, C)
         if (n_out <= 4) GTE_NBM(4); else if (n_out <= 8) GTE_NBM(8); else if (n_out <= 12) GTE_NBM(12); else GTE_NBM(16);
 #undef GTE_NBM
-        hipLaunchKernelGGL(narrow_fold16_kernel, dim3((unsigned)gte::ceil_div(2 * C * F + C, 64)), dim3(1024), 0, s, part, nbm, F,
-                           C, dW, lddw, dbias);
+        const int64_t pstride = 2 * (int64_t)C * F + C;
+        if (gte::defer_fold(part, pstride, nbm, C, F, dW, lddw)) {                    // [dl^T h]
+            gte::defer_fold(part + (int64_t)C * F, pstride, nbm, C, F, dW + F, lddw);   // [q^T h]
+            gte::defer_fold(part + 2 * (int64_t)C * F, pstride, nbm, 1, C, dbias, C);
+        } else {
+            hipLaunchKernelGGL(narrow_fold16_kernel, dim3((unsigned)gte::ceil_div(2 * C * F + C, 64)), dim3(1024), 0, s, part, nbm,
+                               F, C, dW, lddw, dbias);
+        }
         return gte::check_launch("sage_narrow_bwd");
     }
     const int nb = narrow_blocks(n_nodes);

@@ -663,6 +663,7 @@ int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace
     if (rc != GTE_OK) return rc;
     if (pl.splits > 1) {
         const int64_t mn = (int64_t)p.M * p.N;
+        if (!p.bias && !accumulate && !relu && gte::defer_fold(p.slab, mn, pl.splits, p.M, p.N, p.C, p.ldc)) return GTE_OK;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gte::ceil_div(mn, RED_E)), dim3(RED_E * RED_S), 0, s, p.slab,
                            pl.splits, mn, p.N, p.C, p.ldc, p.bias, accumulate, relu, p.bias_cols);
         return gte::check_launch("gemm_f32 split-K reduce");
@@ -1170,8 +1171,15 @@ extern "C" int gte_ln_relu_bwd(const float* dy, int64_t lddy, const float* z, in
         hipLaunchKernelGGL(ln_relu_bwd_wide_kernel, grid, block, 0, s, dy, lddy, zz, ldzz, stats, gamma, beta, relu, dz,
                            lddz, part, (int)M, (int)n_out);
 #undef GTE_LNB
-    if (dgamma || dbeta || dbias)
-        hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)gte::ceil_div(n_out, 64)), dim3(1024), 0, s, part, nb,
-                           (int)n_out, dgamma, dbeta, dbias);
+    if (dgamma || dbeta || dbias) {
+        // deferred (gte_fold_defer_begin): the three column sums join the step's fold batch
+        if (gte::defer_fold(part, 3 * n_out, nb, 1, (int)n_out, dgamma, n_out)) {
+            gte::defer_fold(part + n_out, 3 * n_out, nb, 1, (int)n_out, dbeta, n_out);
+            gte::defer_fold(part + 2 * n_out, 3 * n_out, nb, 1, (int)n_out, dbias, n_out);
+        } else {
+            hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)gte::ceil_div(n_out, 64)), dim3(1024), 0, s, part, nb,
+                               (int)n_out, dgamma, dbeta, dbias);
+        }
+    }
     return gte::check_launch("ln_relu_bwd");
 }

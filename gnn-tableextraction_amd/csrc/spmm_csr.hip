@@ -188,7 +188,12 @@ int launch_g(const int32_t* indptr, const int32_t* indices, const float* ew, con
              void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, hipStream_t s) {
     using elem = typename T::elem;
     constexpr int RPW = gte::kWave / G;
-    const int rows_per_block = 4 * RPW * 4;            // 4 waves x RPW rows x 4 passes, contiguous
+    // 4 waves x RPW rows x `passes` passes, contiguous.  Narrow rows (G = 4: 16 rows per wave per pass) at 4 passes
+    // gave a 24 k-node batch 96 blocks -- a third of the CUs, each wave walking 4 dependent index -> row latency
+    // chains (13 us for 2 MB): fewer passes until the grid covers the chip twice.
+    int passes = 4;
+    while (passes > 1 && gte::ceil_div(n_rows, (int64_t)4 * RPW * passes) < 2 * gte::device_props().cus) passes /= 2;
+    const int rows_per_block = 4 * RPW * passes;
     const int64_t nblocks = gte::ceil_div(n_rows, rows_per_block);
     dim3 grid((unsigned)nblocks), block(256);
     hipLaunchKernelGGL((spmm_csr_kernel<T, G, CPL, ACCUM>), grid, block, 0, s, indptr, indices, ew,

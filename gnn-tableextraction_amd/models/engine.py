@@ -124,7 +124,9 @@ class FusedGcnSageStep(TrainStep):
         self._private_key = None
         self._graphs = {}
         self._side = torch.cuda.Stream(device=self.flat_param.device)
-        self.overlap_dw = os.environ.get("GTE_OVERLAP_DW", "1") == "1"
+        # dW GEMMs on a side stream (GTE_OVERLAP_DW=1).  Off by default since the pipelined GEMM: with the matrix pipe at
+        # 110-120 TF the HBM-bound kernels it would overlap with slow it down more than they hide (0.887 vs 0.862 ms/step)
+        self.overlap_dw = os.environ.get("GTE_OVERLAP_DW", "0") == "1"
         # transform-then-aggregate where a layer narrows + q-form backward (see _transform_first / _qform); "0" keeps
         # the reference's aggregate-then-transform order everywhere (same math, different summation order)
         self.transform_first = os.environ.get("GTE_TRANSFORM_FIRST", "1") == "1"
@@ -158,6 +160,12 @@ class FusedGcnSageStep(TrainStep):
                  [lib.gte_gemm_workspace_bytes(dims[i + 1], dims[i], cap) for i in range(len(layers))] +
                  [lib.gte_sage_narrow_bwd_workspace_bytes(cap, min(dims[-2], 256), min(dims[-1], 16))])
         b["ws"] = torch.empty(int(ws), dtype=torch.uint8, device=dev)
+        # the backward defers its partial-sum folds to one launch (gte_fold_defer_*): every producer keeps its partials
+        # in a workspace of its own until the flush
+        b["ws_ln"] = [torch.empty(int(lib.gte_ln_relu_bwd_workspace_bytes(cap, dims[i + 1])), dtype=torch.uint8, device=dev)
+                      for i in range(len(layers))]
+        b["ws_nar"] = torch.empty(int(lib.gte_sage_narrow_bwd_workspace_bytes(cap, min(dims[-2], 256), min(dims[-1], 16))),
+                                  dtype=torch.uint8, device=dev)
         # one private workspace per layer for the dW GEMMs: they run on the side stream, several at once
         b["ws_dw"] = [torch.empty(int(max(lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], cap),
                                           lib.gte_sage_qform_dw_workspace_bytes(dims[i + 1], dims[i], cap))),
@@ -182,7 +190,7 @@ class FusedGcnSageStep(TrainStep):
         return {"ahn": [v(t) for t in full["ahn"]], "t": [v(t) for t in full["t"]], "z": [v(t) for t in full["z"]],
                 "stats": [None if t is None else t[:2 * n] for t in full["stats"]], "y": [v(t) for t in full["y"]],
                 "dy": [v(t) for t in full["dy"]], "dahn": v(full["dahn"]), "tn": v(full["tn"]), "q": v(full["q"]),
-                "out3": full["out3"], "ws": full["ws"],
+                "out3": full["out3"], "ws": full["ws"], "ws_ln": full["ws_ln"], "ws_nar": full["ws_nar"],
                 "ws_dw": full["ws_dw"]}
 
     def _narrow(self, layer, fin: int) -> bool:
@@ -282,6 +290,20 @@ class FusedGcnSageStep(TrainStep):
 
         # ---------------- backward ----------------
         side_used = False
+        check(lib.gte_fold_defer_begin(st), "gte_fold_defer_begin")
+        try:
+            side_used = self._backward(g, b, layers, x, n, aggregate, rcsr, w_out, t_out, st)
+        finally:
+            if side_used:
+                torch.cuda.current_stream().wait_stream(self._side)      # join: the folds / Adam / all-reduce need every dW
+            check(lib.gte_fold_defer_flush(), "gte_fold_defer_flush")
+        return b["out3"]
+
+    def _backward(self, g, b, layers, x, n, aggregate, rcsr, w_out, t_out, st) -> bool:
+        lib, P, check = self.lib, _lib.ptr, _lib.check
+        timed, ld = ops._timed, ops._ld
+        ws, wsn = P(b["ws"]), b["ws"].numel()
+        side_used = False
         for i in range(len(layers) - 1, -1, -1):
             L = layers[i]
             hin = x if i == 0 else b["y"][i - 1]
@@ -300,14 +322,16 @@ class FusedGcnSageStep(TrainStep):
                 dh = b["dy"][i - 1] if i > 0 else None
                 with timed("narrow_bwd", 3.0 * n * fin * 4):
                     check(lib.gte_sage_narrow_bwd(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,
-                                                  P(dh), fin, P(gW), 2 * fin, P(gb), n, ws, wsn, st), "gte_sage_narrow_bwd")
+                                                  P(dh), fin, P(gW), 2 * fin, P(gb), n, P(b["ws_nar"]), b["ws_nar"].numel(), st),
+                          "gte_sage_narrow_bwd")
                 continue
             tfirst, qform = self._transform_first(L, fin), self._qform(i, L, fin)
             zsrc = b["t"][i] if tfirst else (b["z"][i] if ln else b["y"][i])
             # dz in place of dy; column sums straight into the flat gradient
             check(lib.gte_ln_relu_bwd(P(dy), fout, P(zsrc), 2 * fout if tfirst else fout, P(b["stats"][i]) if ln else None,
                                       P(L.lynorm.weight) if ln else None, P(L.lynorm.bias) if ln else None, int(relu),
-                                      P(dy), fout, P(gg), P(gbe), P(gb), n, fout, ws, wsn, st), "gte_ln_relu_bwd")
+                                      P(dy), fout, P(gg), P(gbe), P(gb), n, fout, P(b["ws_ln"][i]), b["ws_ln"][i].numel(), st),
+                  "gte_ln_relu_bwd")
             dz, ahn = dy, b["ahn"][i]
             if qform:
                 # q = A_w^T (norm * dz) into the dead right half of t (transform-first) or the dead ahn buffer
@@ -347,9 +371,7 @@ class FusedGcnSageStep(TrainStep):
                     check(lib.gte_gemm_f32(0, 0, n, fin, fout, P(dz), fout, P(W) + 4 * fin, 2 * fin, P(dahn), fin, 0, ws,
                                            wsn, st), "gte_gemm_f32 dh_neigh")
                 aggregate(rcsr, w_out, t_out, dahn, fin, dh, fin, fin, _lib.REDUCE_SUM, True)
-        if side_used:
-            torch.cuda.current_stream().wait_stream(self._side)          # join: Adam / all-reduce need every dW
-        return b["out3"]
+        return side_used
 
     def step(self, g, labels: torch.Tensor, n_global: Optional[int] = None) -> torch.Tensor:
         scale = float(labels.shape[0]) / float(n_global) if (self.distributed and n_global) else 1.0

@@ -156,6 +156,16 @@ int gte_sage_linear_dw(const float* dz, int64_t lddz, const float* x1, int64_t l
                        const float* x2, int64_t ldx2, int64_t k2, float* dW, int64_t lddw,
                        int64_t n_out, int64_t n_nodes, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- deferred folds -------------------------------------------------------------------------------------------
+ * Several entry points end with a small "sum the per-block partials" kernel (gte_ln_relu_bwd: column sums;
+ * gte_sage_narrow_bwd: dW / dbias; split-K GEMMs behind gte_sage_linear_dw / gte_sage_qform_dw / gte_gemm_f32).  Between
+ * gte_fold_defer_begin(stream) and gte_fold_defer_flush() (same host thread) those folds are queued instead of launched
+ * and the flush runs all of them in ONE launch on `stream`.  While a deferral is open every such call needs its OWN
+ * workspace (it holds the partials until the flush) and its results are not final before the flush.  Fixed summation
+ * order: deterministic.  No counterpart in the reference (torch autograd launches one reduction per parameter). */
+int gte_fold_defer_begin(void* stream);
+int gte_fold_defer_flush(void);
+
 /* ---- transform-then-aggregate ("q-form") of a GcnSAGELayer --------------------------------------------------
  * replaces (reference src/components/graphs/models.py:53-72, `torch.cat((h, ah * norm), 1)` -> nn.Linear) where the
  * layer narrows: by linearity  z = h W_s^T + b + norm * A_w (h W_n^T), so the aggregation moves n_out columns
