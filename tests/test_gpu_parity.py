@@ -286,7 +286,8 @@ def test_narrow_layer_fwd_bwd_vs_float64(n, f, c):
 
 
 @pytest.mark.parametrize("m,n,ln,relu", [(300, 256, True, True), (100, 9, False, False), (513, 218, True, True),
-                                         (64, 40, False, True), (50, 1000, True, False), (31, 64, True, True)])
+                                         (64, 40, False, True), (50, 1000, True, False), (31, 64, True, True),
+                                         (4099, 512, True, True), (777, 128, True, False), (2500, 256, False, True)])
 def test_ln_relu_bwd_vs_torch_autograd(m, n, ln, relu):
     rng = np.random.default_rng(m + n)
     z = torch.from_numpy(rng.standard_normal((m, n))).double().requires_grad_(True)
