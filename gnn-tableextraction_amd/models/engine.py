@@ -261,9 +261,10 @@ class FusedGcnSageStep(TrainStep):
                 continue
             if self._transform_first(L, fin):
                 t = b["t"][i]
-                with timed("gemm_nt", 4.0 * n * fin * fout):
-                    check(lib.gte_sage_transform_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(t), 2 * fout, n, st),
-                          "gte_sage_transform_fwd")
+                with timed("gemm_nt", 4.0 * n * fin * fout) as tm:
+                    for _ in tm.repeat():
+                        check(lib.gte_sage_transform_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(t), 2 * fout, n,
+                                                         st), "gte_sage_transform_fwd")
                 aggregate(csr, w_in, t_in, P(t) + 4 * fout, 2 * fout, t, 2 * fout, fout, _lib.REDUCE_MEAN, True)
                 check(lib.gte_ln_relu_fwd(P(t), 2 * fout, P(L.lynorm.weight), P(L.lynorm.bias), float(L.lynorm.eps),
                                           int(relu), P(y), fout, P(b["stats"][i]), n, fout, st), "gte_ln_relu_fwd")
@@ -271,10 +272,11 @@ class FusedGcnSageStep(TrainStep):
                 continue
             aggregate(csr, w_in, t_in, h, ld(h), ahn, fin, fin, _lib.REDUCE_MEAN, False)
             lin_out = b["z"][i] if ln else y
-            with timed("gemm_nt", 4.0 * n * fin * fout):
-                check(lib.gte_sage_linear_fwd(P(h), ld(h), fin, P(ahn), fin, fin, P(W), 2 * fin, P(bias), None, None,
-                                              1e-5, int(relu and not ln), None, 0, None, P(lin_out), fout, n, fout, st),
-                      "gte_sage_linear_fwd")
+            with timed("gemm_nt", 4.0 * n * fin * fout) as tm:
+                for _ in tm.repeat():
+                    check(lib.gte_sage_linear_fwd(P(h), ld(h), fin, P(ahn), fin, fin, P(W), 2 * fin, P(bias), None, None,
+                                                  1e-5, int(relu and not ln), None, 0, None, P(lin_out), fout, n, fout, st),
+                          "gte_sage_linear_fwd")
             if ln:
                 check(lib.gte_ln_relu_fwd(P(lin_out), fout, P(L.lynorm.weight), P(L.lynorm.bias), float(L.lynorm.eps),
                                           int(relu), P(y), fout, P(b["stats"][i]), n, fout, st), "gte_ln_relu_fwd")
@@ -357,12 +359,14 @@ class FusedGcnSageStep(TrainStep):
                     dw_launch(self._side.cuda_stream)
                 side_used = True
             else:
-                with timed("gemm_tn", 4.0 * n * fin * fout):
-                    dw_launch(st)
+                with timed("gemm_tn", 4.0 * n * fin * fout) as tm:
+                    for _ in tm.repeat():
+                        dw_launch(st)
             if i > 0 and qform:
-                with timed("gemm_nn", 4.0 * n * fin * fout):
-                    check(lib.gte_sage_qform_dx(P(dz), fout, qp, ldq, P(W), 2 * fin, fin, fout, P(b["dy"][i - 1]), fin, n, st),
-                          "gte_sage_qform_dx")
+                with timed("gemm_nn", 4.0 * n * fin * fout) as tm:
+                    for _ in tm.repeat():
+                        check(lib.gte_sage_qform_dx(P(dz), fout, qp, ldq, P(W), 2 * fin, fin, fout, P(b["dy"][i - 1]), fin, n,
+                                                    st), "gte_sage_qform_dx")
             elif i > 0:
                 dh, dahn = b["dy"][i - 1], b["dahn"]
                 with timed("gemm_nn", 4.0 * n * fin * fout):

@@ -23,22 +23,30 @@ def enable_kernel_timers(on: bool = True) -> None:
     _timers = {} if on else None
 
 
+TIMER_REPS = 5          # launches per timed region when the timers are on (see _timed)
+
+
 def kernel_timer_report():
     """tag -> (launches, total_ms, total_work) ; synchronises."""
     out = {}
     if _timers:
         torch.cuda.synchronize()
         for tag, rec in _timers.items():
-            ms = sum(s.elapsed_time(e) for s, e in rec["events"])
-            out[tag] = (len(rec["events"]), ms, rec["work"])
+            ms = sum(s.elapsed_time(e) for s, e, _ in rec["events"])
+            out[tag] = (sum(r for _, _, r in rec["events"]), ms, rec["work"])
     return out
 
 
 class _timed:
-    __slots__ = ("tag", "work", "ev")
+    """HIP-event pair around a kernel launch on the launch stream (off unless enable_kernel_timers).  A region whose
+    body is written ``for _ in range(t.reps): launch()`` repeats its (idempotent) launch TIMER_REPS times inside one
+    event pair when the timers are on: the ~5-10 us an event pair adds to a single 60 us kernel is amortised and the
+    average is per launch."""
+    __slots__ = ("tag", "work", "ev", "reps")
 
     def __init__(self, tag, work):
         self.tag, self.work = tag, work
+        self.reps = 1
 
     def __enter__(self):
         if _timers is not None:
@@ -46,12 +54,17 @@ class _timed:
             self.ev[0].record()          # torch's current stream == the stream the kernel is launched on
         return self
 
+    def repeat(self):
+        """range() for an idempotent launch: TIMER_REPS launches when timing, one otherwise"""
+        self.reps = TIMER_REPS if _timers is not None else 1
+        return range(self.reps)
+
     def __exit__(self, *exc):
         if _timers is not None:
             self.ev[1].record()
             rec = _timers.setdefault(self.tag, {"events": [], "work": 0.0})
-            rec["events"].append(self.ev)
-            rec["work"] += self.work
+            rec["events"].append((self.ev[0], self.ev[1], self.reps))
+            rec["work"] += self.work * self.reps
         return False
 
 
