@@ -37,6 +37,10 @@ const DeviceProps& device_props();
 // Returns false when no deferral is open (the producer launches its own fold as usual).
 bool defer_fold(const float* src, int64_t stride, int count, int rows, int rowlen, float* dst, int64_t ld);
 
+// Caller-provided scratch for the GEMM tail split (gte_gemm_set_tail_workspace), thread-local; {nullptr, 0} when unset.
+struct TailWorkspace { float* ptr; int64_t bytes; };
+TailWorkspace tail_workspace();
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 

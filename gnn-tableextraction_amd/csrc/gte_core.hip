@@ -118,6 +118,26 @@ bool defer_fold(const float* src, int64_t stride, int count, int rows, int rowle
 
 }  // namespace gte
 
+namespace gte {
+static TailWorkspace& tail_ws_slot() {
+    static thread_local TailWorkspace w = {nullptr, 0};
+    return w;
+}
+TailWorkspace tail_workspace() { return tail_ws_slot(); }
+}  // namespace gte
+
+extern "C" int64_t gte_gemm_tail_workspace_bytes(void) {
+    // at most one partial tile (128 x 128 fp32) per compute unit
+    return (int64_t)gte::device_props().cus * 128 * 128 * 4;
+}
+
+extern "C" int gte_gemm_set_tail_workspace(void* workspace, int64_t workspace_bytes) {
+    if (workspace_bytes < 0 || (workspace_bytes > 0 && !workspace))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_set_tail_workspace: bad arguments");
+    gte::tail_ws_slot() = {reinterpret_cast<float*>(workspace), workspace ? workspace_bytes : 0};
+    return GTE_OK;
+}
+
 extern "C" int gte_fold_defer_begin(void* stream) {
     gte::FoldQueue& q = gte::fold_queue();
     if (q.open) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_begin: a deferral is already open on this thread");

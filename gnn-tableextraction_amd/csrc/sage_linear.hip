@@ -57,6 +57,10 @@ struct GemmParams {
     int Nseg;                          // columns per N segment when Bn2 != nullptr (then N == 2*Nseg)
     const float* An2; int64_t ldan2;   // optional A of N segment 1 (with Bn2): C = [A B | An2 Bn2]
     int bias_cols;                     // > 0: the bias covers columns [0, bias_cols) only
+    // tail split (whole-K launches only): logical tiles [sk_full, ntile) are cut into sk_pieces K ranges of sk_tps K
+    // tiles; piece p of tail tile j writes its tile-local partial to sk_slab[(j * sk_pieces + p)][BM][BN]
+    int sk_full, sk_pieces, sk_tps;
+    float* sk_slab;
     float* C; int64_t ldc;
     const float* bias;                 // nullable, per column n
     int M, N;
@@ -233,7 +237,12 @@ gemm_f32_mfma_kernel(const GemmParams p) {
     const int seg_tiles = (seg_cols + BN - 1) / BN;
     const int tiles_n = p.Bn2 ? 2 * seg_tiles : seg_tiles, tiles_m = (p.M + BM - 1) / BM;
     const unsigned ntile = (unsigned)(tiles_m * tiles_n);
-    const unsigned lb = gte_xcd_remap(blockIdx.x, ntile);
+    // work unit -> (logical tile, K range).  Without a tail split every unit is a whole tile.
+    const bool tail = p.sk_pieces > 1 && (int)blockIdx.x >= p.sk_full;
+    const int tail_j = tail ? ((int)blockIdx.x - p.sk_full) / p.sk_pieces : 0;
+    const int tail_p = tail ? ((int)blockIdx.x - p.sk_full) % p.sk_pieces : 0;
+    const unsigned nremap = p.sk_pieces > 1 ? (unsigned)p.sk_full : ntile;
+    const unsigned lb = tail ? (unsigned)(p.sk_full + tail_j) : gte_xcd_remap(blockIdx.x, nremap);
     const int tm = lb / tiles_n, tn = lb % tiles_n;
     const int nseg = tn / seg_tiles;                       // 0, or 1 for the second B
     const int m0 = tm * BM, n0 = (tn % seg_tiles) * BN;    // n0: column inside the segment
@@ -243,8 +252,8 @@ gemm_f32_mfma_kernel(const GemmParams p) {
 
     const int tiles_seg0 = (p.K1 + BK - 1) / BK, tiles_seg1 = (p.K2 + BK - 1) / BK;
     const int total_tiles = tiles_seg0 + tiles_seg1;
-    const int t_begin = split * p.tiles_per_split;
-    const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
+    const int t_begin = tail ? tail_p * p.sk_tps : split * p.tiles_per_split;
+    const int t_end = min(total_tiles, t_begin + (tail ? p.sk_tps : p.tiles_per_split));
 
     // operand windows (block-uniform): origin of the tile's rows in each K segment
     const int rowsA = min(BM, p.M - m0), rowsB = min(BN, seg_cols - n0);
@@ -392,6 +401,17 @@ gemm_f32_mfma_kernel(const GemmParams p) {
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const int col_l = lane & 31, hrow = (lane >> 5) * 4;
+    if (tail) {                                            // tile-local partial, finished by gemm_tail_fixup_kernel
+        float* sp = p.sk_slab + (int64_t)(tail_j * p.sk_pieces + tail_p) * (BM * BN);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sp[((wm * TM + a) * 32 + hrow + (r & 3) + 8 * (r >> 2)) * BN + (wn * TN + b) * 32 + col_l] = acc[a][b][r];
+        return;
+    }
     float* outp = p.splits > 1 ? p.slab + (int64_t)split * p.M * p.N : p.C;
     const int64_t ldo = p.splits > 1 ? p.N : p.ldc;
 #pragma unroll
@@ -417,6 +437,41 @@ gemm_f32_mfma_kernel(const GemmParams p) {
                 }
             }
         }
+    }
+}
+
+// Finishes the tail tiles of a split launch: C tile = bias + sum over the pieces (piece order: deterministic), with the
+// same bias / accumulate / relu rules as the GEMM epilogue.  grid = (tail tiles, BM * BN / 1024), 4 elements per thread.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+gemm_tail_fixup_kernel(const GemmParams p) {
+    const int seg_cols = p.Bn2 ? p.Nseg : p.N;
+    const int seg_tiles = (seg_cols + BN - 1) / BN;
+    const int tiles_n = p.Bn2 ? 2 * seg_tiles : seg_tiles;
+    const int lb = p.sk_full + (int)blockIdx.x;
+    const int tm = lb / tiles_n, tn = lb % tiles_n, nseg = tn / seg_tiles;
+    const int m0 = tm * BM, n0 = (tn % seg_tiles) * BN;
+    const float* sp = p.sk_slab + (int64_t)blockIdx.x * p.sk_pieces * (BM * BN);
+    const int e = ((int)blockIdx.y * 256 + (int)threadIdx.x) * 4;
+    const int r = e / BN, c = e % BN;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pc = 0; pc < p.sk_pieces; ++pc) {
+        const float4 t = *reinterpret_cast<const float4*>(sp + (int64_t)pc * (BM * BN) + e);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const int row = m0 + r;
+    if (row >= p.M) return;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col_in_seg = n0 + c + q;
+        if (col_in_seg >= seg_cols) continue;
+        const int col = nseg * seg_cols + col_in_seg;
+        float o = vv[q] + ((p.bias && (p.bias_cols <= 0 || col < p.bias_cols)) ? p.bias[col] : 0.f);
+        float* dst = p.C + (int64_t)row * p.ldc + col;
+        if (p.accumulate) o += *dst;
+        if (p.relu) o = fmaxf(o, 0.f);
+        *dst = o;
     }
 }
 
@@ -578,13 +633,27 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
     if (N <= 32) { pl.bm = 128; pl.bn = 32; }
     else if (M <= 32) { pl.bm = 32; pl.bn = 128; }
     else {
-        // tile quantisation: a page batch gives ~1.5 waves of 128x128 tiles over the 256 CUs (the last
-        // half-empty wave costs a full tile time); 64x128 tiles cut the tail.  Compare rounds x tile area.
-        const int64_t t128 = gte::ceil_div(M, 128) * gte::ceil_div(N, 128);
-        const int64_t t64 = gte::ceil_div(M, 64) * gte::ceil_div(N, 128);
-        const int64_t c128 = gte::ceil_div(t128, cus) * 2, c64 = gte::ceil_div(t64, cus);
+        // Tile quantisation: T tiles run ceil(T / CUs) rounds of one tile per CU (two co-resident workgroups share a
+        // CU's matrix pipe, so rounds count CUs, not slots) -- unless the tail split is available (plan_tail), which
+        // turns a short last round of r tiles into 1/S of a round.  Cost in units of one 128x128 tile time; a 64x128
+        // tile costs 0.57 (half the flops at ~117 instead of ~133 TF: smaller wave tiles, prologue/epilogue twice).
+        const int ktiles_all = (int)(gte::ceil_div(K1, BK) + gte::ceil_div(K2, BK));
+        const bool tail_ok = gte::tail_workspace().ptr != nullptr;
+        auto rounds = [&](int64_t T) -> double {
+            if (T <= cus) return 1.0;
+            const int64_t full = T / cus, r = T % cus;
+            if (r == 0) return (double)full;
+            if (tail_ok && 2 * r <= cus) {
+                int64_t S = cus / r;
+                if (S > ktiles_all / 4) S = ktiles_all / 4;
+                if (S >= 2) return (double)full + 1.0 / (double)S + 0.08;     // + fix-up launch
+            }
+            return (double)(full + 1);
+        };
+        const int64_t ncol = Nseg > 0 ? 2 * gte::ceil_div(Nseg, 128) : gte::ceil_div(N, 128);
+        const int64_t t128 = gte::ceil_div(M, 128) * ncol, t64 = gte::ceil_div(M, 64) * ncol;
         pl.bn = 128;
-        pl.bm = (t128 >= cus && c64 * 10 < c128 * 9) ? 64 : 128;
+        pl.bm = (t128 >= cus && rounds(t64) * 0.57 < rounds(t128) * 0.97) ? 64 : 128;
         // split-K with very few output tiles (dW of a 256 x 256 layer: 4 tiles over 24 k nodes): smaller tiles ->
         // half the K splits -> half the slab bytes (measured 58 -> 44 us; at 14 tiles, 256 x 831, it loses: 147 -> 161)
         if (t128 <= 8 && M >= 64) pl.bm = 64;
@@ -606,8 +675,34 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
     return pl;
 }
 
+// Tail split of a whole-K launch.  A launch of T tiles on the chip runs ceil(T / CUs) rounds of "one tile per CU at
+// full rate" (two co-resident workgroups share a CU's matrix pipe, so the count is per CU, not per slot).  When the last
+// round holds r <= CUs/2 tiles, (CUs - r) CUs idle for a whole tile time: 800 tiles = 3.125 rounds cost 4.  The r tail
+// tiles are instead cut into S = CUs / r K ranges (>= 4 K tiles each): r * S <= CUs short units that fill the round
+// evenly, tile-local partials in the caller's tail workspace, one small fix-up launch.  (A full stream-K decomposition
+// would route nearly every tile of these 3-round launches through partials: ~3x the C traffic.)
+template <int BM, int BN>
+bool plan_tail(GemmParams& p, int tiles, dim3& grid) {
+    p.sk_full = tiles; p.sk_pieces = 1; p.sk_tps = 0; p.sk_slab = nullptr;
+    const gte::TailWorkspace tw = gte::tail_workspace();
+    const int cus = gte::device_props().cus;
+    if (!tw.ptr || p.splits > 1 || tiles < cus) return false;
+    const int r = tiles % cus;
+    if (r == 0 || 2 * r > cus) return false;
+    const int ktiles = (int)(gte::ceil_div(p.K1, BK) + gte::ceil_div(p.K2, BK));
+    int S = cus / r;
+    if (S > ktiles / 4) S = ktiles / 4;
+    if (S < 2) return false;
+    const int tps = (int)gte::ceil_div(ktiles, S);
+    S = (int)gte::ceil_div(ktiles, tps);
+    if (S < 2 || (int64_t)r * S * BM * BN * 4 > tw.bytes) return false;
+    p.sk_full = tiles - r; p.sk_pieces = S; p.sk_tps = tps; p.sk_slab = tw.ptr;
+    grid = dim3((unsigned)(p.sk_full + r * S), 1);
+    return true;
+}
+
 template <bool AK, bool BKC, int BM, int BN, int WM, int WN>
-void launch_tile(const GemmParams& p, dim3 grid, hipStream_t s) {
+void launch_tile(GemmParams p, dim3 grid, hipStream_t s) {
     constexpr int shm = gemm_lds_bytes<AK, BKC, BM, BN>();
     static bool configured = false;                       // > 64 KB of dynamic LDS needs the opt-in, once per kernel
     if (!configured) {
@@ -615,7 +710,11 @@ void launch_tile(const GemmParams& p, dim3 grid, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, shm);
         configured = true;
     }
+    const int tiles = (int)grid.x;
+    const bool tail = plan_tail<BM, BN>(p, tiles, grid);
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, BM, BN, WM, WN>), grid, dim3(256), shm, s, p);
+    if (tail)
+        hipLaunchKernelGGL((gemm_tail_fixup_kernel<BM, BN>), dim3((unsigned)(tiles - p.sk_full), BM * BN / 1024), dim3(256), 0, s, p);
 }
 
 template <bool AK, bool BKC>

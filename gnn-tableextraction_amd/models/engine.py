@@ -130,6 +130,8 @@ class FusedGcnSageStep(TrainStep):
         # transform-then-aggregate where a layer narrows + q-form backward (see _transform_first / _qform); "0" keeps
         # the reference's aggregate-then-transform order everywhere (same math, different summation order)
         self.transform_first = os.environ.get("GTE_TRANSFORM_FIRST", "1") == "1"
+        self.tail_split = os.environ.get("GTE_TAIL_SPLIT", "1") == "1"
+        self._tail_ws = None
 
     # -- buffers -------------------------------------------------------------------------------------
     def _alloc(self, cap: int, f0: int):
@@ -243,6 +245,21 @@ class FusedGcnSageStep(TrainStep):
         ws, wsn = P(b["ws"]), b["ws"].numel()
         ld = ops._ld
 
+        # scratch for the GEMM tail split (see gte_gemm_set_tail_workspace): registered for this launch sequence only
+        if self._tail_ws is None:
+            self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=x.device)
+        check(lib.gte_gemm_set_tail_workspace(P(self._tail_ws) if self.tail_split else None,
+                                              self._tail_ws.numel() if self.tail_split else 0), "gte_gemm_set_tail_workspace")
+        try:
+            return self._forward_backward(g, labels, grad_scale, x, n, f0, b, layers, csr, rcsr, w_in, w_out, t_in, t_out,
+                                          aggregate, st)
+        finally:
+            lib.gte_gemm_set_tail_workspace(None, 0)
+
+    def _forward_backward(self, g, labels, grad_scale, x, n, f0, b, layers, csr, rcsr, w_in, w_out, t_in, t_out, aggregate, st):
+        lib, P, check = self.lib, _lib.ptr, _lib.check
+        timed, ld = ops._timed, ops._ld
+        ws, wsn = P(b["ws"]), b["ws"].numel()
         # ---------------- forward ----------------
         h = x
         for i, L in enumerate(layers):

@@ -156,6 +156,17 @@ int gte_sage_linear_dw(const float* dz, int64_t lddz, const float* x1, int64_t l
                        const float* x2, int64_t ldx2, int64_t k2, float* dW, int64_t lddw,
                        int64_t n_out, int64_t n_nodes, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- GEMM tail split ----------------------------------------------------------------------------------------------
+ * A whole-K GEMM launch (gte_sage_linear_fwd, gte_sage_transform_fwd, gte_sage_qform_dx, gte_gemm_f32 without split-K)
+ * whose last round of tiles would leave more than half of the compute units idle cuts those tiles' reduction range into
+ * pieces that fill the idle units, and finishes them with a small fix-up launch.  It needs scratch for the partial
+ * tiles: gte_gemm_set_tail_workspace registers a caller-owned device buffer (>= gte_gemm_tail_workspace_bytes()) for the
+ * calling host thread; NULL / 0 unregisters (launches then never split).  Launches that may split must not run
+ * concurrently on two streams with one workspace.  Results are deterministic either way (fixed summation order), but a
+ * split tile sums its K range in pieces: last-bit differences against the unsplit launch. */
+int64_t gte_gemm_tail_workspace_bytes(void);
+int gte_gemm_set_tail_workspace(void* workspace, int64_t workspace_bytes);
+
 /* ---- deferred folds -------------------------------------------------------------------------------------------
  * Several entry points end with a small "sum the per-block partials" kernel (gte_ln_relu_bwd: column sums;
  * gte_sage_narrow_bwd: dW / dbias; split-K GEMMs behind gte_sage_linear_dw / gte_sage_qform_dw / gte_gemm_f32).  Between

@@ -205,6 +205,30 @@ def test_sage_linear_fwd_vs_torch(m, k1, k2, n_out, ln, relu):
         np.testing.assert_allclose(st[:m].cpu().numpy(), z.mean(1).numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("ta,tb,m,n,k", [(False, True, 128 * 264, 128, 1024), (False, False, 64 * 520 - 5, 128, 831),
+                                          (False, True, 128 * 259 - 77, 256, 300)])
+def test_gemm_tail_split_matches_unsplit_and_float64(ta, tb, m, n, k):
+    """GEMM tail split (gte_gemm_set_tail_workspace): launches whose last round holds few tiles cut those tiles' K range
+    into pieces + a fix-up launch.  Same result as the unsplit launch up to summation order, and against float64."""
+    lib = gte._lib.load()
+    rng = np.random.default_rng(m + n + k)
+    a = dev(rng.standard_normal((m, k)).astype(np.float32))
+    b = dev((rng.standard_normal((n, k) if tb else (k, n)) / np.sqrt(k)).astype(np.float32))
+    plain = ops.gemm(a, b, trans_b=tb)
+    ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=DEV)
+    gte._lib.check(lib.gte_gemm_set_tail_workspace(gte._lib.ptr(ws), ws.numel()), "set")
+    try:
+        split = ops.gemm(a, b, trans_b=tb)
+        again = ops.gemm(a, b, trans_b=tb)
+    finally:
+        lib.gte_gemm_set_tail_workspace(None, 0)
+    assert torch.equal(split, again)                                   # deterministic
+    assert not torch.equal(split, plain) or m * n < 1                  # the split path really ran (different summation order)
+    want = a.double().cpu() @ (b.double().cpu().T if tb else b.double().cpu())
+    np.testing.assert_allclose(split.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(plain.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("n,f,o", [(1000, 831, 256), (513, 256, 256), (300, 13, 40), (77, 50, 33), (5, 3, 2), (24495, 831, 256)])
 def test_qform_entry_points_vs_float64(n, f, o):
     """gte_sage_transform_fwd / gte_sage_qform_dw / gte_sage_qform_dx (transform-then-aggregate form of a layer)
