@@ -241,14 +241,18 @@ gemm_f32_mfma_kernel(const GemmParams p) {
     const bool tail = p.sk_pieces > 1 && (int)blockIdx.x >= p.sk_full;
     const int tail_j = tail ? ((int)blockIdx.x - p.sk_full) / p.sk_pieces : 0;
     const int tail_p = tail ? ((int)blockIdx.x - p.sk_full) % p.sk_pieces : 0;
-    const unsigned nremap = p.sk_pieces > 1 ? (unsigned)p.sk_full : ntile;
-    const unsigned lb = tail ? (unsigned)(p.sk_full + tail_j) : gte_xcd_remap(blockIdx.x, nremap);
+    const unsigned nremap = p.sk_pieces > 1 ? (unsigned)p.sk_full : ntile * (unsigned)(p.splits > 1 ? p.splits : 1);
+    // split-K launches (dW: K = the node dimension): units are ordered split-major before the XCD remap, so one XCD
+    // works through whole K slabs -- every tile of a split re-reads the same rows of dz / h, and with the splits dealt
+    // round-robin over the XCDs each slab was fetched by all eight L2s (PMC: 544 MB per dW launch, 145 MB algorithmic)
+    const unsigned lu = tail ? (unsigned)(p.sk_full + tail_j) : gte_xcd_remap(blockIdx.x, nremap);
+    const unsigned lb = lu % ntile;
+    const int split = (int)(lu / ntile);
     const int tm = lb / tiles_n, tn = lb % tiles_n;
     const int nseg = tn / seg_tiles;                       // 0, or 1 for the second B
     const int m0 = tm * BM, n0 = (tn % seg_tiles) * BN;    // n0: column inside the segment
     const float* Bmat = nseg ? p.Bn2 : p.B;
     const int64_t ldbm = nseg ? p.ldbn2 : p.ldb;
-    const int split = blockIdx.y;
 
     const int tiles_seg0 = (p.K1 + BK - 1) / BK, tiles_seg1 = (p.K2 + BK - 1) / BK;
     const int total_tiles = tiles_seg0 + tiles_seg1;
@@ -719,7 +723,7 @@ void launch_tile(GemmParams p, dim3 grid, hipStream_t s) {
 
 template <bool AK, bool BKC>
 int launch_shape(const GemmParams& p, const Plan& pl, hipStream_t s) {
-    dim3 grid((unsigned)pl.tiles, (unsigned)pl.splits);
+    dim3 grid((unsigned)(pl.tiles * pl.splits), 1);
     if (pl.bm == 128 && pl.bn == 128) launch_tile<AK, BKC, 128, 128, 2, 2>(p, grid, s);
     else if (pl.bm == 64 && pl.bn == 128) launch_tile<AK, BKC, 64, 128, 2, 2>(p, grid, s);
     else if (pl.bn == 32) launch_tile<AK, BKC, 128, 32, 4, 1>(p, grid, s);
