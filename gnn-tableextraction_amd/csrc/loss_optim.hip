@@ -132,6 +132,36 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
     }
 }
 
+// The same update with the hyper-parameters and the step count read from DEVICE memory, so the launch can sit inside
+// a HIP graph (the host-scalar version bakes lr and the bias corrections into the launch).
+//   hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale};  t = *step_counter + 1
+__global__ void __launch_bounds__(256)
+adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                int64_t n, const float* __restrict__ hyper, const int64_t* __restrict__ step_counter) {
+    __shared__ float bc[2];
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], grad_scale = hyper[5];
+    if (threadIdx.x == 0) {
+        const double t = (double)(*step_counter + 1);
+        bc[0] = (float)(1.0 - pow((double)b1, t));                   // same double arithmetic as gte_adam_step's host side
+        bc[1] = (float)sqrt(1.0 - pow((double)b2, t));
+    }
+    __syncthreads();
+    const float bc1 = bc[0], bc2_sqrt = bc[1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float pi = p[i];
+        const float gi = fmaf(wd, pi, grad_scale * g[i]);
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+__global__ void counter_inc_kernel(int64_t* c) { *c += 1; }
+
 }  // namespace
 
 extern "C" int64_t gte_weighted_ce_workspace_bytes(int64_t n_nodes) {
@@ -180,4 +210,19 @@ extern "C" int gte_adam_step(float* param, const float* grad, float* exp_avg, fl
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, gte::as_stream(stream), param, grad, exp_avg,
                        exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
     return gte::check_launch("adam_step");
+}
+
+extern "C" int gte_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 const float* hyper, int64_t* step_counter, void* stream) {
+    if (n < 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: n < 0");
+    if (!hyper || !step_counter) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: null pointer");
+    hipStream_t s = gte::as_stream(stream);
+    if (n > 0) {
+        if (!param || !grad || !exp_avg || !exp_avg_sq) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: null pointer");
+        const int64_t blocks = gte::ceil_div(n, 256) < 2048 ? gte::ceil_div(n, 256) : 2048;
+        hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, hyper,
+                           step_counter);
+    }
+    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, s, step_counter);
+    return gte::check_launch("adam_step_dev");
 }

@@ -313,27 +313,30 @@ gemm_f32_mfma_kernel(const GemmParams p) {
         return d;
     };
     TileDesc D;
-    auto issue_loads = [&](auto FROM, auto TO) {           // chunks [FROM, TO) of the described tile (A first, then B)
+    // chunks [FROM, TO) of tile `d` (A chunks first, then B) into the staging registers of (oa, ob)
+    auto issue_loads_into = [&](OpA& oa, OpB& ob, const TileDesc& d, auto FROM, auto TO) {
         static_for<NC>([&](auto J) {
             constexpr int j = decltype(J)::value;
             if constexpr (j >= decltype(FROM)::value && j < decltype(TO)::value) {
-                if constexpr (j < NCA) opa.template load<j>(D.sa, D.seg, D.oob_a);
-                else opb.template load<j - NCA>(D.sb, D.seg, D.oob_b);
+                if constexpr (j < NCA) oa.template load<j>(d.sa, d.seg, d.oob_a);
+                else ob.template load<j - NCA>(d.sb, d.seg, d.oob_b);
             }
         });
     };
+    auto issue_loads = [&](auto FROM, auto TO) { issue_loads_into(opa, opb, D, FROM, TO); };
     auto staged = [&]() { opa.vc = D.vca; opb.vc = D.vcb; };   // the described tile now sits in the staging registers
-    auto store_chunks = [&](int buf, auto FROM, auto TO) {
+    auto store_chunks_from = [&](const OpA& oa, const OpB& ob, int buf, auto FROM, auto TO) {
         float* la = lds + buf * BUF;
         float* lbp = la + A_FLOATS;
         static_for<NC>([&](auto J) {
             constexpr int j = decltype(J)::value;
             if constexpr (j >= decltype(FROM)::value && j < decltype(TO)::value) {
-                if constexpr (j < NCA) opa.template store<j>(la);
-                else opb.template store<j - NCA>(lbp);
+                if constexpr (j < NCA) oa.template store<j>(la);
+                else ob.template store<j - NCA>(lbp);
             }
         });
     };
+    auto store_chunks = [&](int buf, auto FROM, auto TO) { store_chunks_from(opa, opb, buf, FROM, TO); };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -368,15 +371,21 @@ gemm_f32_mfma_kernel(const GemmParams p) {
     using IN = std::integral_constant<int, NC>;
 
     if (t_begin < t_end) {
-        // prologue: tile t_begin -> LDS[0], tile t_begin + 1 -> registers
-        D = describe();
-        issue_loads(I0{}, IN{});
-        staged();
-        store_chunks(0, I0{}, IN{});
-        D = describe();
-        issue_loads(I0{}, IN{});
-        staged();
-        D = describe();
+        // prologue: tile t_begin -> LDS[0], tile t_begin + 1 -> staging registers.  BOTH tiles are requested before
+        // the first wait (tile t_begin goes through a second, prologue-only register set): one memory round trip
+        // before the first MFMA instead of two
+        {
+            OpA pa = opa;
+            OpB pb = opb;
+            const TileDesc D0 = describe();
+            issue_loads_into(pa, pb, D0, I0{}, IN{});
+            D = describe();
+            issue_loads(I0{}, IN{});
+            pa.vc = D0.vca; pb.vc = D0.vcb;
+            store_chunks_from(pa, pb, 0, I0{}, IN{});
+            staged();
+            D = describe();
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         read_frags(0, 0, 0);
         int cur = 0;

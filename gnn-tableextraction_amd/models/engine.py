@@ -404,12 +404,44 @@ class FusedGcnSageStep(TrainStep):
         self._optimizer_step()
         return out3
 
+    # -- optimiser: hyper-parameters and step count live on the device, so the launch is graph-capturable ----------
+    def _adam_state(self):
+        dev = self.flat_param.device
+        want = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay), 1.0)
+        if getattr(self, "_hyper", None) is None:
+            self._hyper = torch.tensor(want, dtype=torch.float32, device=dev)
+            self._hyper_host = want
+            self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            self._step_dev_host = 0                   # what the device counter holds (completed optimiser steps)
+        return want
+
+    def _sync_adam_state(self) -> None:
+        """Eager-only: push changed hyper-parameters (lr_scale) / a changed step count (checkpoint restore) to the device."""
+        want = self._adam_state()
+        if want != self._hyper_host:
+            self._hyper.copy_(torch.tensor(want, dtype=torch.float32))
+            self._hyper_host = want
+        if self._step_dev_host != self.t - 1:
+            self._step_dev.fill_(self.t - 1)
+            self._step_dev_host = self.t - 1
+
+    def _adam_dev_launch(self) -> None:
+        P = _lib.ptr
+        _lib.check(self.lib.gte_adam_step_dev(P(self.flat_param), P(self.flat_grad), P(self.exp_avg), P(self.exp_avg_sq),
+                                              self.flat_param.numel(), P(self._hyper), P(self._step_dev),
+                                              _lib.current_stream()), "gte_adam_step_dev")
+        self._step_dev_host += 1
+
+    def _optimizer_step(self) -> None:              # called with self.t already advanced
+        self._sync_adam_state()
+        self._adam_dev_launch()
+
     # -- HIP graph capture of a step on a RESIDENT batch ------------------------------------------------
     def capture(self, g, labels: torch.Tensor, n_global: Optional[int] = None):
         """Returns ``replay() -> out3``: forward+backward of this batch as one HIP-graph launch, followed
-        by the (eager) all-reduce and Adam launch.  The batch's tensors must stay alive and unchanged in
-        place (resident pages).  Adam stays outside the graph because its bias correction depends on the
-        step count, a host scalar."""
+        by Adam -- inside the same graph on one GPU (gte_adam_step_dev reads lr and the step count from device
+        memory), eagerly after the all-reduce when distributed.  The batch's tensors must stay alive and unchanged
+        in place (resident pages)."""
         scale = float(labels.shape[0]) / float(n_global) if (self.distributed and n_global) else 1.0
         key = id(g)
         self._private_key = key                       # this batch's buffers are private to its graph (never reallocated)
@@ -426,15 +458,26 @@ class FusedGcnSageStep(TrainStep):
                 self.forward_backward(g, labels, scale)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._adam_state()
+        in_graph_adam = not self.distributed          # the all-reduce sits between backward and Adam, eagerly
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out3 = self.forward_backward(g, labels, scale)
+            if in_graph_adam:
+                self._adam_dev_launch()               # reads lr / step count from device memory at replay time
+        if in_graph_adam:
+            self._step_dev_host -= 1                  # capturing did not run it
 
         def replay():
+            if in_graph_adam:
+                self.t += 1
+                self._sync_adam_state()               # no-op unless lr / t were changed from outside
+                graph.replay()
+                self._step_dev_host += 1
+                return out3
             graph.replay()
-            if self.distributed:
-                import torch.distributed as dist
-                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.t += 1
             self._optimizer_step()
             return out3

@@ -263,6 +263,11 @@ int gte_weighted_ce(const float* logits, int64_t ld, const void* labels, int lab
 int gte_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                   float grad_scale, void* stream);
+/* The same update with everything that changes from step to step read from DEVICE memory, so the launch can be captured
+ * in a HIP graph: hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale} (6 floats), t = *step_counter + 1; the call
+ * also enqueues `*step_counter += 1` after the update.  Bias corrections in double like the host-scalar version. */
+int gte_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const float* hyper, int64_t* step_counter, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A13  multi-head graph attention (BASELINE.json configs[2]).  The reference has NO GAT: the
