@@ -23,6 +23,8 @@
 //     contiguous 1/8 of the (reading-order) node range: neighbouring rows share sources.
 #include "gte_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
@@ -188,11 +190,12 @@ int launch_g(const int32_t* indptr, const int32_t* indices, const float* ew, con
              void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, hipStream_t s) {
     using elem = typename T::elem;
     constexpr int RPW = gte::kWave / G;
-    // 4 waves x RPW rows x `passes` passes, contiguous.  Narrow rows (G = 4: 16 rows per wave per pass) at 4 passes
-    // gave a 24 k-node batch 96 blocks -- a third of the CUs, each wave walking 4 dependent index -> row latency
-    // chains (13 us for 2 MB): fewer passes until the grid covers the chip twice.
+    // 4 waves x RPW rows x `passes` passes, contiguous.  A wave walks its passes one after the other, each a chain of
+    // dependent index -> row latencies, so passes only pay when the grid already oversubscribes the chip: 16 blocks
+    // per CU before a second pass (measured at 21.5 k rows: F = 256 16.8 -> 14.3 us, F = 831 45 -> 39 us; narrow rows
+    // at 4 passes had left two thirds of the CUs empty: 13 -> 6 us).
     int passes = 4;
-    while (passes > 1 && gte::ceil_div(n_rows, (int64_t)4 * RPW * passes) < 2 * gte::device_props().cus) passes /= 2;
+    while (passes > 1 && gte::ceil_div(n_rows, (int64_t)4 * RPW * passes) < (int64_t)16 * gte::device_props().cus) passes /= 2;
     const int rows_per_block = 4 * RPW * passes;
     const int64_t nblocks = gte::ceil_div(n_rows, rows_per_block);
     dim3 grid((unsigned)nblocks), block(256);
