@@ -42,6 +42,9 @@ SIGNATURES = {
     "gte_sage_linear_dw_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
     "gte_sage_linear_dw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                    c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_spmm_csr_accumulate_ln_supported": (c_int, [c_int64]),
+    "gte_spmm_csr_accumulate_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                           c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "gte_gemm_tail_workspace_bytes": (c_int64, []),
     "gte_gemm_set_tail_workspace": (c_int, [c_void_p, c_int64]),
     "gte_fold_defer_begin": (c_int, [c_void_p]),

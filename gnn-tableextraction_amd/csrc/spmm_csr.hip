@@ -76,12 +76,27 @@ struct BF16 {
 
 constexpr int kEdgeUnroll = 4;   // source rows in flight per lane group
 
-template <typename T, int G, int CPL, bool ACCUM>
+// Optional LayerNorm(+ReLU) epilogue (LNE kernels: f32, accumulate, the whole row inside one lane group): the row a
+// group has just finished (z = out + aggregate) is normalised in registers and written to y as well -- the separate
+// LayerNorm kernel would read z back from HBM (models.py:64-66 after :53-54 in transform-then-aggregate order).
+struct LnEpilogue {
+    const float* gamma; const float* beta; float eps; int relu;
+    float* y; int64_t ldy; float* stats;                 // stats[row] = mean, stats[n_rows + row] = rstd
+};
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
+    return v;
+}
+
+template <typename T, int G, int CPL, bool ACCUM, bool LNE = false>
 __global__ void __launch_bounds__(256)
 spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                 const float* __restrict__ ew, const typename T::elem* __restrict__ x, int64_t ldx,
                 typename T::elem* __restrict__ out, int64_t ldo, int n_rows, int n_feat, int reduce,
-                int rows_per_block) {
+                int rows_per_block, const LnEpilogue ln = LnEpilogue{}) {
     using elem = typename T::elem;
     constexpr int EPC = T::EPC;
     constexpr int RPW = gte::kWave / G;                 // rows per wave per pass
@@ -173,7 +188,36 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                             for (int q = 0; q < EPC; ++q) o[q] = acc[j][q] * scale;
                         }
                         T::store(orow + (int64_t)c * EPC, o);
+                        if constexpr (LNE) {
+#pragma unroll
+                            for (int q = 0; q < EPC; ++q) acc[j][q] = o[q];          // keep z for the epilogue
+                        }
+                    } else if constexpr (LNE) {
+#pragma unroll
+                        for (int q = 0; q < EPC; ++q) acc[j][q] = 0.f;
                     }
+                }
+                if constexpr (LNE) {                         // CPL == 1, rem == 0, nchunk <= G: acc[0] is this lane's z chunk
+                    const bool have = li < nchunk;
+                    float sm = 0.f;
+#pragma unroll
+                    for (int q = 0; q < EPC; ++q) sm += acc[0][q];
+                    const float mean = group_sum<G>(sm) / (float)n_feat;
+                    float sq = 0.f;
+#pragma unroll
+                    for (int q = 0; q < EPC; ++q) { const float d = have ? acc[0][q] - mean : 0.f; sq = fmaf(d, d, sq); }
+                    const float rstd = rsqrtf(group_sum<G>(sq) / (float)n_feat + ln.eps);
+                    if (have) {
+                        float yv[EPC];
+#pragma unroll
+                        for (int q = 0; q < EPC; ++q) {
+                            const int col = li * EPC + q;
+                            float v = fmaf((acc[0][q] - mean) * rstd, ln.gamma[col], ln.beta[col]);
+                            yv[q] = ln.relu ? fmaxf(v, 0.f) : v;
+                        }
+                        F32::store(ln.y + (int64_t)r * ln.ldy + (int64_t)li * EPC, yv);
+                    }
+                    if (li == 0 && ln.stats) { ln.stats[r] = mean; ln.stats[n_rows + r] = rstd; }
                 }
                 if (do_tail) {
                     float o = tail * scale;
@@ -221,6 +265,18 @@ int dispatch(const int32_t* indptr, const int32_t* indices, const float* ew, con
 #undef GTE_L
 }
 
+template <int G>
+int launch_ln(const int32_t* indptr, const int32_t* indices, const float* ew, const float* x, int64_t ldx, float* out,
+              int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, const LnEpilogue& ln, hipStream_t s) {
+    constexpr int RPW = gte::kWave / G;
+    int passes = 4;
+    while (passes > 1 && gte::ceil_div(n_rows, (int64_t)4 * RPW * passes) < (int64_t)16 * gte::device_props().cus) passes /= 2;
+    const int rows_per_block = 4 * RPW * passes;
+    hipLaunchKernelGGL((spmm_csr_kernel<F32, G, 1, true, true>), dim3((unsigned)gte::ceil_div(n_rows, rows_per_block)), dim3(256), 0,
+                       s, indptr, indices, ew, x, ldx, out, ldo, (int)n_rows, (int)n_feat, reduce, rows_per_block, ln);
+    return gte::check_launch("spmm_csr_accumulate_ln");
+}
+
 int spmm_entry(bool accumulate, const int32_t* indptr, const int32_t* indices, const float* eweight,
                const void* x, int64_t ldx, void* out, int64_t ldo, int64_t n_rows, int64_t n_feat,
                int dtype, int reduce, void* stream) {
@@ -255,4 +311,32 @@ extern "C" int gte_spmm_csr_accumulate(const int32_t* indptr, const int32_t* ind
                                        const void* x, int64_t ldx, void* out, int64_t ldo, int64_t n_rows,
                                        int64_t n_feat, int dtype, int reduce, void* stream) {
     return spmm_entry(true, indptr, indices, eweight, x, ldx, out, ldo, n_rows, n_feat, dtype, reduce, stream);
+}
+
+extern "C" int gte_spmm_csr_accumulate_ln_supported(int64_t n_feat) {
+    return (n_feat >= 4 && n_feat % 4 == 0 && n_feat <= 256) ? 1 : 0;
+}
+
+extern "C" int gte_spmm_csr_accumulate_ln(const int32_t* indptr, const int32_t* indices, const float* eweight,
+                                          const float* x, int64_t ldx, float* z, int64_t ldz, int64_t n_rows,
+                                          int64_t n_feat, int reduce, const float* gamma, const float* beta, float eps,
+                                          int relu, float* y, int64_t ldy, float* stats, void* stream) {
+    if (n_rows < 0 || n_rows > INT32_MAX) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: bad n_rows");
+    if (!gte_spmm_csr_accumulate_ln_supported(n_feat))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "spmm_csr_accumulate_ln: needs n_feat %% 4 == 0 and n_feat <= 256");
+    if (n_rows == 0) return GTE_OK;
+    if (!indptr || !x || !z || !gamma || !beta || !y) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: null pointer");
+    if (ldx < n_feat || ldz < n_feat || ldy < n_feat) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: ld < n_feat");
+    if (reduce != GTE_REDUCE_SUM && reduce != GTE_REDUCE_MEAN)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: reduce must be 0 (sum) or 1 (mean)");
+    const LnEpilogue ln = {gamma, beta, eps, relu, y, ldy, stats};
+    hipStream_t s = gte::as_stream(stream);
+    const int64_t nchunk = n_feat / 4;
+#define GTE_LN(G) return launch_ln<G>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, n_feat, reduce, ln, s)
+    if (nchunk <= 4) GTE_LN(4);
+    if (nchunk <= 8) GTE_LN(8);
+    if (nchunk <= 16) GTE_LN(16);
+    if (nchunk <= 32) GTE_LN(32);
+    GTE_LN(64);
+#undef GTE_LN
 }

@@ -282,9 +282,17 @@ class FusedGcnSageStep(TrainStep):
                     for _ in tm.repeat():
                         check(lib.gte_sage_transform_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(t), 2 * fout, n,
                                                          st), "gte_sage_transform_fwd")
-                aggregate(csr, w_in, t_in, P(t) + 4 * fout, 2 * fout, t, 2 * fout, fout, _lib.REDUCE_MEAN, True)
-                check(lib.gte_ln_relu_fwd(P(t), 2 * fout, P(L.lynorm.weight), P(L.lynorm.bias), float(L.lynorm.eps),
-                                          int(relu), P(y), fout, P(b["stats"][i]), n, fout, st), "gte_ln_relu_fwd")
+                if lib.gte_spmm_csr_accumulate_ln_supported(fout) and not (t_in is not None and ops.use_tiled(n, fout)):
+                    # z = t_self + mean-aggregate(t_neigh) and y = relu(LayerNorm(z)) in one pass over the rows
+                    with timed("spmm_csr", 3.0 * n * fout * 4 + 8.0 * csr.indices.numel() + 4.0 * (n + 1)):
+                        check(lib.gte_spmm_csr_accumulate_ln(P(csr.indptr), P(csr.indices), P(w_in), P(t) + 4 * fout, 2 * fout,
+                                                             P(t), 2 * fout, n, fout, _lib.REDUCE_MEAN, P(L.lynorm.weight),
+                                                             P(L.lynorm.bias), float(L.lynorm.eps), int(relu), P(y), fout,
+                                                             P(b["stats"][i]), st), "gte_spmm_csr_accumulate_ln")
+                else:
+                    aggregate(csr, w_in, t_in, P(t) + 4 * fout, 2 * fout, t, 2 * fout, fout, _lib.REDUCE_MEAN, True)
+                    check(lib.gte_ln_relu_fwd(P(t), 2 * fout, P(L.lynorm.weight), P(L.lynorm.bias), float(L.lynorm.eps),
+                                              int(relu), P(y), fout, P(b["stats"][i]), n, fout, st), "gte_ln_relu_fwd")
                 h = y
                 continue
             aggregate(csr, w_in, t_in, h, ld(h), ahn, fin, fin, _lib.REDUCE_MEAN, False)

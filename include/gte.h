@@ -156,6 +156,17 @@ int gte_sage_linear_dw(const float* dz, int64_t lddz, const float* x1, int64_t l
                        const float* x2, int64_t ldx2, int64_t k2, float* dW, int64_t lddw,
                        int64_t n_out, int64_t n_nodes, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* gte_spmm_csr_accumulate with a LayerNorm(+ReLU) epilogue, for a layer in transform-then-aggregate order
+ * (models.py:53-54 then :64-66): z[v,:] += scale_v * sum_e w[e] x[src,:] (z written back: the LayerNorm backward
+ * needs it), then y[v,:] = relu?(gamma * (z - mean) / sqrt(var + eps) + beta) and stats[v] = mean,
+ * stats[n_rows + v] = rstd (nullable) -- same statistics as gte_ln_relu_fwd.  f32 only, n_feat % 4 == 0, n_feat <= 256
+ * (a row must fit one lane group; gte_spmm_csr_accumulate_ln_supported says so). */
+int gte_spmm_csr_accumulate_ln_supported(int64_t n_feat);
+int gte_spmm_csr_accumulate_ln(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x,
+                               int64_t ldx, float* z, int64_t ldz, int64_t n_rows, int64_t n_feat, int reduce,
+                               const float* gamma, const float* beta, float eps, int relu, float* y, int64_t ldy,
+                               float* stats, void* stream);
+
 /* ---- GEMM tail split ----------------------------------------------------------------------------------------------
  * A whole-K GEMM launch (gte_sage_linear_fwd, gte_sage_transform_fwd, gte_sage_qform_dx, gte_gemm_f32 without split-K)
  * whose last round of tiles would leave more than half of the compute units idle cuts those tiles' reduction range into

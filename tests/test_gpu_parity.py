@@ -83,6 +83,32 @@ def test_spmm_f32_matches_oracle(f, mean):
     np.testing.assert_allclose(got1, want1, rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("f,relu", [(256, True), (128, False), (64, True), (20, True), (8, False)])
+def test_spmm_accumulate_ln_epilogue_matches_the_two_kernels(f, relu):
+    """gte_spmm_csr_accumulate_ln == gte_spmm_csr_accumulate followed by gte_ln_relu_fwd (z bitwise: same aggregation;
+    y / stats to 1e-6: the row sums are taken in a different order)."""
+    lib = gte._lib.load()
+    P, cs, check = gte._lib.ptr, gte._lib.current_stream, gte._lib.check
+    assert lib.gte_spmm_csr_accumulate_ln_supported(f) and not lib.gte_spmm_csr_accumulate_ln_supported(258)
+    rng = np.random.default_rng(f)
+    n, e = 1003, 7000
+    g = oc.OracleGraph(rng.integers(0, n, e), rng.integers(0, n, e), n, rng.random(e).astype(np.float32))
+    ip, ix, w = dev(g.indptr), dev(g.indices), dev(g.weight)
+    t0 = dev(rng.standard_normal((n, 2 * f + 1)).astype(np.float32))          # [t_self | t_neigh | pad], ld = 2f + 1
+    gam, bet = dev(1 + 0.1 * rng.standard_normal(f).astype(np.float32)), dev(0.1 * rng.standard_normal(f).astype(np.float32))
+    ta, tb = t0.clone(), t0.clone()
+    ya, yb = torch.empty(n, f, device=DEV), torch.empty(n, f, device=DEV)
+    sa, sb = torch.empty(2 * n, device=DEV), torch.empty(2 * n, device=DEV)
+    ld = ta.stride(0)
+    check(lib.gte_spmm_csr_accumulate(P(ip), P(ix), P(w), P(ta) + 4 * f, ld, P(ta), ld, n, f, gte._lib.GTE_F32, 1, cs()), "acc")
+    check(lib.gte_ln_relu_fwd(P(ta), ld, P(gam), P(bet), 1e-5, int(relu), P(ya), f, P(sa), n, f, cs()), "ln")
+    check(lib.gte_spmm_csr_accumulate_ln(P(ip), P(ix), P(w), P(tb) + 4 * f, ld, P(tb), ld, n, f, 1, P(gam), P(bet), 1e-5,
+                                         int(relu), P(yb), f, P(sb), cs()), "acc_ln")
+    assert torch.equal(ta, tb)
+    np.testing.assert_allclose(yb.cpu().numpy(), ya.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(sb.cpu().numpy(), sa.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_spmm_strided_rows_and_accumulate():
     rng = np.random.default_rng(1)
     n, e, f = 300, 2000, 37
