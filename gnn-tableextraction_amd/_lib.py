@@ -85,7 +85,7 @@ SIGNATURES = {
                                 c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                               c_float, c_float, c_int64, c_float, c_void_p]),
-    "gte_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "gte_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 GTE_F32, GTE_BF16 = 0, 1

@@ -63,10 +63,8 @@ ce_partial_kernel(const float* __restrict__ logits, int64_t ld, const L* __restr
     }
 }
 
-// pass 2: one block folds the partials in a fixed order -> out3 = {loss, sum w, #correct}
-__global__ void __launch_bounds__(kCeBlock)
-ce_final_kernel(const float* __restrict__ partial, int64_t nblocks, float* __restrict__ out3) {
-    __shared__ double red[3][kCeBlock];
+// fold of the block partials in a fixed order (every thread of the block takes part; result in red[.][0])
+__device__ __forceinline__ void ce_fold(const float* __restrict__ partial, int64_t nblocks, double (&red)[3][kCeBlock]) {
     double a = 0., b = 0., d = 0.;
     for (int64_t i = threadIdx.x; i < nblocks; i += kCeBlock) {
         a += partial[i * 3 + 0];
@@ -83,25 +81,40 @@ ce_final_kernel(const float* __restrict__ partial, int64_t nblocks, float* __res
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        out3[0] = (float)(red[1][0] > 0. ? red[0][0] / red[1][0] : 0.);
-        out3[1] = (float)red[1][0];
-        out3[2] = (float)red[2][0];
-    }
 }
 
-// pass 3: dlogits = grad_scale * w_y / sum_w * (softmax - onehot)
+__device__ __forceinline__ void ce_write_out3(const double (&red)[3][kCeBlock], float* __restrict__ out3) {
+    out3[0] = (float)(red[1][0] > 0. ? red[0][0] / red[1][0] : 0.);
+    out3[1] = (float)red[1][0];
+    out3[2] = (float)red[2][0];
+}
+
+// pass 2 (no gradient wanted): one block folds the partials -> out3 = {loss, sum w, #correct}
+__global__ void __launch_bounds__(kCeBlock)
+ce_final_kernel(const float* __restrict__ partial, int64_t nblocks, float* __restrict__ out3) {
+    __shared__ double red[3][kCeBlock];
+    ce_fold(partial, nblocks, red);
+    if (threadIdx.x == 0) ce_write_out3(red, out3);
+}
+
+// pass 2+3: dlogits = grad_scale * w_y / sum_w * (softmax - onehot).  Every block repeats the (tiny) fold of the
+// partials itself -- same order, same value everywhere -- instead of waiting for a one-block kernel in between;
+// block 0 also writes out3.
 template <typename L>
 __global__ void __launch_bounds__(kCeBlock)
 ce_grad_kernel(const float* __restrict__ logits, int64_t ld, const L* __restrict__ labels,
                const float* __restrict__ cw, int64_t n, int c, float grad_scale,
-               const float* __restrict__ out3, float* __restrict__ dl, int64_t lddl) {
+               const float* __restrict__ partial, int64_t nblocks, float* __restrict__ out3,
+               float* __restrict__ dl, int64_t lddl) {
+    __shared__ double red[3][kCeBlock];
+    ce_fold(partial, nblocks, red);
+    const float wsum = (float)red[1][0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ce_write_out3(red, out3);
     const int64_t i = (int64_t)blockIdx.x * kCeBlock + threadIdx.x;
     if (i >= n) return;
     const float* row = logits + i * ld;
     float* drow = dl + i * lddl;
     const int y = label_of(labels, i);
-    const float wsum = out3[1];
     const bool ok = (y >= 0 && y < c && wsum > 0.f);
     const float w = ok ? (cw ? cw[y] : 1.0f) * grad_scale / wsum : 0.f;
     float m = row[0];
@@ -132,21 +145,16 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
     }
 }
 
-// The same update with the hyper-parameters and the step count read from DEVICE memory, so the launch can sit inside
-// a HIP graph (the host-scalar version bakes lr and the bias corrections into the launch).
-//   hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale};  t = *step_counter + 1
+// The same update with the hyper-parameters, the bias corrections and the step count read from DEVICE memory, so the
+// launch can sit inside a HIP graph (the host-scalar version bakes lr and the bias corrections into the launch).
+//   state = {lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, sqrt(bc2)} for step t = *step_counter + 1.
+// The block that finishes LAST (ticket counter) advances the state to step t + 1: every block has read the state before it
+// takes its ticket, so the update cannot race with a reader.  bc in double like gte_adam_step's host side.
 __global__ void __launch_bounds__(256)
 adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                int64_t n, const float* __restrict__ hyper, const int64_t* __restrict__ step_counter) {
-    __shared__ float bc[2];
-    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], grad_scale = hyper[5];
-    if (threadIdx.x == 0) {
-        const double t = (double)(*step_counter + 1);
-        bc[0] = (float)(1.0 - pow((double)b1, t));                   // same double arithmetic as gte_adam_step's host side
-        bc[1] = (float)sqrt(1.0 - pow((double)b2, t));
-    }
-    __syncthreads();
-    const float bc1 = bc[0], bc2_sqrt = bc[1];
+                int64_t n, float* __restrict__ state, int64_t* __restrict__ step_counter, unsigned* __restrict__ ticket) {
+    const float lr = state[0], b1 = state[1], b2 = state[2], eps = state[3], wd = state[4], grad_scale = state[5];
+    const float bc1 = state[6], bc2_sqrt = state[7];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float pi = p[i];
@@ -158,9 +166,19 @@ adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __res
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = pi - (lr / bc1) * (mi / denom);
     }
+    __syncthreads();                                         // the whole block is done with `state`
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(ticket, 1u);
+        if (t == gridDim.x - 1) {
+            *ticket = 0;
+            const int64_t done = *step_counter + 1;
+            *step_counter = done;
+            const double tn = (double)(done + 1);
+            state[6] = (float)(1.0 - pow((double)b1, tn));
+            state[7] = (float)sqrt(1.0 - pow((double)b2, tn));
+        }
+    }
 }
-
-__global__ void counter_inc_kernel(int64_t* c) { *c += 1; }
 
 }  // namespace
 
@@ -186,14 +204,17 @@ extern "C" int gte_weighted_ce(const float* logits, int64_t ld, const void* labe
     else
         hipLaunchKernelGGL(ce_partial_kernel<int64_t>, dim3((unsigned)nb), dim3(kCeBlock), 0, s, logits, ld,
                            (const int64_t*)labels, class_weight, n_nodes, n_classes, partial);
-    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(kCeBlock), 0, s, partial, nb, out3);
     if (dlogits) {
         if (labels_f32)
             hipLaunchKernelGGL(ce_grad_kernel<float>, dim3((unsigned)nb), dim3(kCeBlock), 0, s, logits, ld,
-                               (const float*)labels, class_weight, n_nodes, n_classes, grad_scale, out3, dlogits, lddl);
+                               (const float*)labels, class_weight, n_nodes, n_classes, grad_scale, partial, nb, out3, dlogits,
+                               lddl);
         else
             hipLaunchKernelGGL(ce_grad_kernel<int64_t>, dim3((unsigned)nb), dim3(kCeBlock), 0, s, logits, ld,
-                               (const int64_t*)labels, class_weight, n_nodes, n_classes, grad_scale, out3, dlogits, lddl);
+                               (const int64_t*)labels, class_weight, n_nodes, n_classes, grad_scale, partial, nb, out3, dlogits,
+                               lddl);
+    } else {
+        hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(kCeBlock), 0, s, partial, nb, out3);
     }
     return gte::check_launch("weighted_ce");
 }
@@ -212,17 +233,16 @@ extern "C" int gte_adam_step(float* param, const float* grad, float* exp_avg, fl
     return gte::check_launch("adam_step");
 }
 
-extern "C" int gte_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                 const float* hyper, int64_t* step_counter, void* stream) {
-    if (n < 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: n < 0");
-    if (!hyper || !step_counter) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: null pointer");
-    hipStream_t s = gte::as_stream(stream);
-    if (n > 0) {
-        if (!param || !grad || !exp_avg || !exp_avg_sq) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: null pointer");
-        const int64_t blocks = gte::ceil_div(n, 256) < 2048 ? gte::ceil_div(n, 256) : 2048;
-        hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, hyper,
-                           step_counter);
-    }
-    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, s, step_counter);
+extern "C" int gte_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                 int64_t* step_counter, unsigned* ticket, void* stream) {
+    if (n <= 0) return n == 0 ? gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: n == 0 (nothing would advance the step)")
+                              : gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: n < 0");
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state || !step_counter || !ticket)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: null pointer");
+    // one ticket atomic per block on a single address: 2048 blocks spent 25 us queueing on it; 256 blocks (a grid-stride
+    // loop over ~2300 elements per block at 590 k parameters) keep the 16 MB update at ~5 us
+    const int64_t blocks = gte::ceil_div(n, 1024) < 256 ? gte::ceil_div(n, 1024) : 256;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, gte::as_stream(stream), param, grad, exp_avg,
+                       exp_avg_sq, n, state, step_counter, ticket);
     return gte::check_launch("adam_step_dev");
 }

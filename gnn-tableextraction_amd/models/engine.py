@@ -16,6 +16,7 @@ from __future__ import annotations
 import os
 from typing import Optional
 
+import numpy as np
 import torch
 
 from .. import ops
@@ -413,30 +414,40 @@ class FusedGcnSageStep(TrainStep):
         return out3
 
     # -- optimiser: hyper-parameters and step count live on the device, so the launch is graph-capturable ----------
-    def _adam_state(self):
-        dev = self.flat_param.device
-        want = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay), 1.0)
+    def _adam_host_state(self, t_next: int):
+        """{lr, b1, b2, eps, wd, grad_scale, bc1, sqrt(bc2)} for step t_next, bias corrections in double (gte_adam_step)"""
+        b1, b2 = float(self.betas[0]), float(self.betas[1])
+        return (float(self.lr), b1, b2, float(self.eps), float(self.weight_decay), 1.0,
+                float(np.float32(1.0 - b1 ** t_next)), float(np.float32(np.sqrt(1.0 - b2 ** t_next))))
+
+    def _adam_state(self) -> None:
         if getattr(self, "_hyper", None) is None:
-            self._hyper = torch.tensor(want, dtype=torch.float32, device=dev)
-            self._hyper_host = want
+            dev = self.flat_param.device
+            self._hyper_host = self._adam_host_state(1)
+            self._hyper = torch.tensor(self._hyper_host, dtype=torch.float32, device=dev)
             self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
             self._step_dev_host = 0                   # what the device counter holds (completed optimiser steps)
-        return want
 
     def _sync_adam_state(self) -> None:
-        """Eager-only: push changed hyper-parameters (lr_scale) / a changed step count (checkpoint restore) to the device."""
-        want = self._adam_state()
-        if want != self._hyper_host:
-            self._hyper.copy_(torch.tensor(want, dtype=torch.float32))
+        """Eager-only: push changed hyper-parameters (lr_scale) / a changed step count (checkpoint restore) to the device.
+        The device advances the counter and the bias corrections itself; the host only mirrors the expected values."""
+        self._adam_state()
+        want = self._adam_host_state(self.t)
+        stale_t = self._step_dev_host != self.t - 1
+        if stale_t or want[:6] != self._hyper_host[:6]:
+            if stale_t:
+                self._step_dev.fill_(self.t - 1)
+                self._step_dev_host = self.t - 1
+                self._hyper.copy_(torch.tensor(want, dtype=torch.float32))
+            else:
+                self._hyper[:6].copy_(torch.tensor(want[:6], dtype=torch.float32))
             self._hyper_host = want
-        if self._step_dev_host != self.t - 1:
-            self._step_dev.fill_(self.t - 1)
-            self._step_dev_host = self.t - 1
 
     def _adam_dev_launch(self) -> None:
         P = _lib.ptr
         _lib.check(self.lib.gte_adam_step_dev(P(self.flat_param), P(self.flat_grad), P(self.exp_avg), P(self.exp_avg_sq),
-                                              self.flat_param.numel(), P(self._hyper), P(self._step_dev),
+                                              self.flat_param.numel(), P(self._hyper), P(self._step_dev), P(self._ticket),
                                               _lib.current_stream()), "gte_adam_step_dev")
         self._step_dev_host += 1
 

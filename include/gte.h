@@ -275,10 +275,13 @@ int gte_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                   float grad_scale, void* stream);
 /* The same update with everything that changes from step to step read from DEVICE memory, so the launch can be captured
- * in a HIP graph: hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale} (6 floats), t = *step_counter + 1; the call
- * also enqueues `*step_counter += 1` after the update.  Bias corrections in double like the host-scalar version. */
-int gte_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                      const float* hyper, int64_t* step_counter, void* stream);
+ * in a HIP graph.  state (8 floats, read AND advanced by the call) = {lr, beta1, beta2, eps, weight_decay, grad_scale,
+ * bc1 = 1 - beta1^t, sqrt(bc2) = sqrt(1 - beta2^t)} for t = *step_counter + 1; the last block to finish sets
+ * *step_counter = t and the two bias corrections for t + 1 (double arithmetic, like the host-scalar version).
+ * `ticket` is one zero-initialised uint32 of scratch that the call returns to zero.  The caller initialises state and
+ * counter consistently (and may rewrite lr at any time between launches). */
+int gte_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                      int64_t* step_counter, unsigned* ticket, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A13  multi-head graph attention (BASELINE.json configs[2]).  The reference has NO GAT: the
