@@ -646,27 +646,31 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
     if (N <= 32) { pl.bm = 128; pl.bn = 32; }
     else if (M <= 32) { pl.bm = 32; pl.bn = 128; }
     else {
-        // Tile quantisation: T tiles run ceil(T / CUs) rounds of one tile per CU (two co-resident workgroups share a
-        // CU's matrix pipe, so rounds count CUs, not slots) -- unless the tail split is available (plan_tail), which
-        // turns a short last round of r tiles into 1/S of a round.  Cost in units of one 128x128 tile time; a 64x128
-        // tile costs 0.57 (half the flops at ~117 instead of ~133 TF: smaller wave tiles, prologue/epilogue twice).
+        // Tile choice by a measured cost model.  T tiles run ceil(T / CUs) rounds of one tile per CU (two co-resident
+        // workgroups share a CU's matrix pipe, so rounds count CUs, not slots); a round costs F + s * K microseconds
+        // (linear fits over K at 768 tiles, profiles/r01/gemm_variants.md): 128x128: 8.07 + 0.0594 K, 64x128:
+        // 2.67 + 0.0335 K -- the big tile is 13 % cheaper per flop but pays three times the fixed cost (dispatch, prologue,
+        // the burst of C stores at the end of a round), and quantises coarser.  With the tail split available
+        // (plan_tail) a last round of r <= CUs/2 tiles costs one round over K/S plus the fix-up launch (~7 us).
         const int ktiles_all = (int)(gte::ceil_div(K1, BK) + gte::ceil_div(K2, BK));
+        const double Ktot = (double)(K1 + K2);
         const bool tail_ok = gte::tail_workspace().ptr != nullptr;
-        auto rounds = [&](int64_t T) -> double {
-            if (T <= cus) return 1.0;
+        auto cost = [&](int64_t T, double F, double sl) -> double {
+            const double round = F + sl * Ktot;
+            if (T <= cus) return round;
             const int64_t full = T / cus, r = T % cus;
-            if (r == 0) return (double)full;
+            if (r == 0) return (double)full * round;
             if (tail_ok && 2 * r <= cus) {
                 int64_t S = cus / r;
                 if (S > ktiles_all / 4) S = ktiles_all / 4;
-                if (S >= 2) return (double)full + 1.0 / (double)S + 0.08;     // + fix-up launch
+                if (S >= 2) return (double)full * round + F + sl * Ktot / (double)S + 7.0;
             }
-            return (double)(full + 1);
+            return (double)(full + 1) * round;
         };
         const int64_t ncol = Nseg > 0 ? 2 * gte::ceil_div(Nseg, 128) : gte::ceil_div(N, 128);
         const int64_t t128 = gte::ceil_div(M, 128) * ncol, t64 = gte::ceil_div(M, 64) * ncol;
         pl.bn = 128;
-        pl.bm = (t128 >= cus && rounds(t64) * 0.57 < rounds(t128) * 0.97) ? 64 : 128;
+        pl.bm = (t128 >= cus && cost(t64, 2.67, 0.0335) < cost(t128, 8.07, 0.0594)) ? 64 : 128;
         // split-K with very few output tiles (dW of a 256 x 256 layer: 4 tiles over 24 k nodes): smaller tiles ->
         // half the K splits -> half the slab bytes (measured 58 -> 44 us; at 14 tiles, 256 x 831, it loses: 147 -> 161)
         if (t128 <= 8 && M >= 64) pl.bm = 64;
