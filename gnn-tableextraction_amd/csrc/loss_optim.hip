@@ -9,6 +9,8 @@
 // is deterministic: per-block partial sums in a fixed order, one reducing block, no atomics.
 #include "gte_common.h"
 
+#include <stdint.h>
+
 #include <math.h>
 
 namespace {
@@ -156,15 +158,33 @@ adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __res
     const float lr = state[0], b1 = state[1], b2 = state[2], eps = state[3], wd = state[4], grad_scale = state[5];
     const float bc1 = state[6], bc2_sqrt = state[7];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float pi = p[i];
-        const float gi = fmaf(wd, pi, grad_scale * g[i]);
-        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
-        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
-        m[i] = mi;
-        v[i] = vi;
+    auto update = [&](float& pi, float gi_raw, float& mi_io, float& vi_io) {
+        const float gi = fmaf(wd, pi, grad_scale * gi_raw);
+        const float mi = fmaf(b1, mi_io, (1.f - b1) * gi);
+        const float vi = fmaf(b2, vi_io, (1.f - b2) * gi * gi);
+        mi_io = mi;
+        vi_io = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = pi - (lr / bc1) * (mi / denom);
+        pi = pi - (lr / bc1) * (mi / denom);
+    };
+    // 16-byte accesses over the aligned body (the flat buffers come from one allocation each: 16-byte aligned bases),
+    // scalar tail; the same per-element arithmetic as adam_kernel
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                         reinterpret_cast<uintptr_t>(v)) & 15) == 0 ? n / 4 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        update(pv.x, gv.x, mv.x, vv.x); update(pv.y, gv.y, mv.y, vv.y);
+        update(pv.z, gv.z, mv.z, vv.z); update(pv.w, gv.w, mv.w, vv.w);
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        reinterpret_cast<float4*>(p)[i] = pv;
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        update(pi, g[i], mi, vi);
+        m[i] = mi; v[i] = vi; p[i] = pi;
     }
     __syncthreads();                                         // the whole block is done with `state`
     if (threadIdx.x == 0) {
