@@ -219,25 +219,33 @@ narrow_fwd_mfma_kernel(const float* __restrict__ h, int64_t ldh, const float* __
     for (int rb = blockIdx.x * 4 + wave; rb < nblk; rb += gridDim.x * 4) {
         const int row = min(rb * 32 + i, n - 1);
         const float* hp = h + (int64_t)row * ldh + hh * 4;
-        f32x16 acc;
+        // all of the row's 16-byte loads are issued before the first MFMA (one wave per SIMD at 24 k rows: nothing else
+        // hides the latency); two accumulator chains (even / odd k-blocks) so consecutive MFMAs do not depend on each other
+        f32x16 acc, acc2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // 8 k-blocks (64 k values) per round: all eight 16-byte loads of the round are issued before its MFMAs
-        for (int kb0 = 0; kb0 < kbs; kb0 += 8) {
-            f4n a[8];
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+        f4n a[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f4n*>(hp + min(kb0 + u, kbs - 1) * 8);
+        for (int u = 0; u < 32; ++u) a[u] = *reinterpret_cast<const f4n*>(hp + min(u, kbs - 1) * 8);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (kb0 + u < kbs) {
-                    const f32x4n b = *reinterpret_cast<const f32x4n*>(wp + (kb0 + u) * 8);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b.w, acc, 0, 0, 0);
-                }
+        for (int u = 0; u < 32; u += 2) {
+            if (u < kbs) {
+                const f32x4n b = *reinterpret_cast<const f32x4n*>(wp + u * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b.w, acc, 0, 0, 0);
+            }
+            if (u + 1 < kbs) {
+                const f32x4n b = *reinterpret_cast<const f32x4n*>(wp + (u + 1) * 8);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u + 1].x, b.x, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u + 1].y, b.y, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u + 1].z, b.z, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u + 1].w, b.w, acc2, 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
         if (cv < C) {
             float* outp = seg ? t_neigh : t_self;
             const int64_t ldo = seg ? ldn : lds_;
