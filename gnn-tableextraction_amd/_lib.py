@@ -63,6 +63,13 @@ SIGNATURES = {
     "gte_sage_narrow_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                     c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                     c_void_p]),
+    "gte_head_supported": (c_int, [c_int64, c_int64]),
+    "gte_head_agg_ce_workspace_bytes": (c_int64, [c_int64]),
+    "gte_head_agg_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                                c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_sage_narrow_bwd_ce": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                       c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                       c_void_p, c_float, c_void_p, c_void_p]),
     "gte_ln_relu_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p,
                                 c_int64, c_int64, c_void_p]),
     "gte_ln_relu_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),

@@ -8,6 +8,7 @@
 // Both are HBM-bound and tiny next to the transforms (N x 9 logits; <= 4 M parameters).  The CE
 // is deterministic: per-block partial sums in a fixed order, one reducing block, no atomics.
 #include "gte_common.h"
+#include "ce_fold.h"
 
 #include <stdint.h>
 
@@ -15,10 +16,10 @@
 
 namespace {
 
-constexpr int kCeBlock = 256;
-
-template <typename L>
-__device__ __forceinline__ int label_of(const L* labels, int64_t i) { return (int)labels[i]; }
+using gte_ce::kCeBlock;
+using gte_ce::label_of;
+using gte_ce::ce_fold;
+using gte_ce::ce_write_out3;
 
 // pass 1: per-node nll / weight / correct, block-reduced into partial[block][3]
 template <typename L>
@@ -63,32 +64,6 @@ ce_partial_kernel(const float* __restrict__ logits, int64_t ld, const L* __restr
         partial[(int64_t)blockIdx.x * 3 + 1] = b;
         partial[(int64_t)blockIdx.x * 3 + 2] = d;
     }
-}
-
-// fold of the block partials in a fixed order (every thread of the block takes part; result in red[.][0])
-__device__ __forceinline__ void ce_fold(const float* __restrict__ partial, int64_t nblocks, double (&red)[3][kCeBlock]) {
-    double a = 0., b = 0., d = 0.;
-    for (int64_t i = threadIdx.x; i < nblocks; i += kCeBlock) {
-        a += partial[i * 3 + 0];
-        b += partial[i * 3 + 1];
-        d += partial[i * 3 + 2];
-    }
-    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = d;
-    __syncthreads();
-    for (int s = kCeBlock / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + s];
-            red[1][threadIdx.x] += red[1][threadIdx.x + s];
-            red[2][threadIdx.x] += red[2][threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-}
-
-__device__ __forceinline__ void ce_write_out3(const double (&red)[3][kCeBlock], float* __restrict__ out3) {
-    out3[0] = (float)(red[1][0] > 0. ? red[0][0] / red[1][0] : 0.);
-    out3[1] = (float)red[1][0];
-    out3[2] = (float)red[2][0];
 }
 
 // pass 2 (no gradient wanted): one block folds the partials -> out3 = {loss, sum w, #correct}

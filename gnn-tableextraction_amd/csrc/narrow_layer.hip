@@ -16,6 +16,7 @@
 // in registers over the rows a wave owns and are folded through LDS per block, then across blocks in a fixed
 // order (no atomics: deterministic).
 #include "gte_common.h"
+#include "ce_fold.h"
 
 #include <stdlib.h>
 
@@ -268,10 +269,21 @@ template <int NCT>
 __global__ void __launch_bounds__(256)
 narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* __restrict__ q, int64_t ldq,
                        const float* __restrict__ h, int64_t ldh, const float* __restrict__ W, int64_t ldw,
-                       float* __restrict__ dh, int64_t lddh, float* __restrict__ partial, int n, int F, int C) {
+                       float* __restrict__ dh, int64_t lddh, float* __restrict__ partial, int n, int F, int C,
+                       const float* __restrict__ ce_partial, int64_t ce_blocks, float grad_scale, float* __restrict__ out3) {
     constexpr int KD = 2 * NCT;                 // compact K of the dh product / M of the dW product
     constexpr int DP = KD + 1;                  // row stride of the DLQ image (odd: conflict-free read both ways)
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    // fused head (gte_head_agg_ce): dl / q arrive WITHOUT the 1 / sum(w) of the weighted cross-entropy; every block folds
+    // the CE partials itself (fixed order, same value everywhere) and scales its DLQ image; block 0 publishes out3
+    float alpha = 1.f;
+    if (ce_partial) {
+        __shared__ double ce_red[3][gte_ce::kCeBlock];
+        gte_ce::ce_fold(ce_partial, ce_blocks, ce_red);
+        const float wsum = (float)ce_red[1][0];
+        alpha = wsum > 0.f ? grad_scale / wsum : 0.f;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && out3) gte_ce::ce_write_out3(ce_red, out3);
+    }
     const int FP = F + 4;
     float* Wst = sm;                            // [KD][FP]: row kk < NCT -> W_s row kk, NCT + c -> W_n row c
     float* D = sm + KD * FP;                    // [32][DP]
@@ -303,7 +315,7 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
             const int r = idx / KD, kk = idx - r * KD, c = kk < NCT ? kk : kk - NCT;
             float v = 0.f;
             if (row0 + r < n && c < C) v = kk < NCT ? dl[(int64_t)(row0 + r) * lddl + c] : q[(int64_t)(row0 + r) * ldq + c];
-            D[r * DP + kk] = v;
+            D[r * DP + kk] = v * alpha;
         }
         __syncthreads();
         if (wave == 0 && i < C && hh == 0) {
@@ -391,6 +403,119 @@ narrow_fold16_kernel(const float* __restrict__ partial, int nblk, int F, int C, 
     }
 }
 
+// ---- fused head: logits = t_self + mean-aggregate(t_neigh), weighted cross-entropy, unnormalised gradient ------------
+// Replaces three launches (9-wide aggregation, CE partial, CE gradient) by one.  4 lanes per node row (lane l owns columns
+// l, l+4, l+8, l+12 < C <= 16), edges read four at a time and broadcast inside the group -- the same summation order as
+// spmm_csr_kernel<F32, 4, 1, true>, so the logits are bitwise those of the unfused path.  Per row: arg-max (first maximum),
+// log-sum-exp, nll = w_y (lse - z_y), and dl' = w_y (softmax - onehot) WITHOUT the 1 / sum(w): that factor needs all rows;
+// it is linear, so the transpose aggregation of dl' and narrow_bwd_mfma_kernel (alpha) apply it later.
+template <typename L>
+__global__ void __launch_bounds__(256)
+head_agg_ce_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ ew,
+                   const float* __restrict__ t_neigh, int64_t ldn, float* __restrict__ logits, int64_t ldl,
+                   const L* __restrict__ labels, const float* __restrict__ cw, int n, int C, int reduce,
+                   float* __restrict__ dl, int64_t lddl, float* __restrict__ partial) {
+    const int li = threadIdx.x & 3;
+    const int r = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool row_ok = r < n;
+    int lo = 0, hi = 0;
+    if (row_ok) { lo = indptr[r]; hi = indptr[r + 1]; }
+    const float scale = (reduce == GTE_REDUCE_MEAN) ? (hi > lo ? 1.0f / (float)(hi - lo) : 0.0f) : 1.0f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int eb = lo; eb < hi; eb += 4) {
+        const int my_e = eb + li;
+        int my_u = 0;
+        float my_w = 0.f;
+        if (my_e < hi) { my_u = indices[my_e]; my_w = ew ? ew[my_e] : 1.0f; }
+        const int cnt = min(4, hi - eb);
+        float v[4][4];
+        float w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int tt = min(t, cnt - 1);
+            const int u = __shfl(my_u, tt, 4);
+            w[t] = t < cnt ? __shfl(my_w, tt, 4) : 0.f;
+            const float* xr = t_neigh + (int64_t)u * ldn;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v[t][m] = (li + 4 * m < C) ? xr[li + 4 * m] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = fmaf(w[t], v[t][m], acc[m]);
+    }
+    float z[4];
+    float zmax = -INFINITY;
+    float* lrow = logits + (int64_t)(row_ok ? r : 0) * ldl;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int col = li + 4 * m;
+        z[m] = -INFINITY;
+        if (row_ok && col < C) {
+            z[m] = lrow[col] + acc[m] * scale;
+            lrow[col] = z[m];
+            zmax = fmaxf(zmax, z[m]);
+        }
+    }
+    zmax = fmaxf(zmax, __shfl_xor(zmax, 1, 4));
+    zmax = fmaxf(zmax, __shfl_xor(zmax, 2, 4));
+    int arg = 1 << 20;                                       // first column holding the maximum (torch.argmax)
+    float se = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int col = li + 4 * m;
+        if (row_ok && col < C) {
+            if (z[m] == zmax) arg = min(arg, col);
+            se += expf(z[m] - zmax);
+        }
+    }
+    arg = min(arg, __shfl_xor(arg, 1, 4));
+    arg = min(arg, __shfl_xor(arg, 2, 4));
+    se += __shfl_xor(se, 1, 4);
+    se += __shfl_xor(se, 2, 4);
+    const int y = row_ok ? gte_ce::label_of(labels, r) : -1;
+    const bool yok = row_ok && y >= 0 && y < C;
+    const float wy = yok ? (cw ? cw[y] : 1.0f) : 0.f;
+    float zy = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) if (yok && li + 4 * m == y) zy = z[m];
+    zy += __shfl_xor(zy, 1, 4);
+    zy += __shfl_xor(zy, 2, 4);
+    if (row_ok && dl) {
+        const float inv = 1.0f / se;
+        float* drow = dl + (int64_t)r * lddl;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int col = li + 4 * m;
+            if (col < C) drow[col] = wy * (expf(z[m] - zmax) * inv - (col == y ? 1.f : 0.f));
+        }
+    }
+    // block partial {sum w nll, sum w, #correct}: one lane per row contributes; wave shuffle, then the 4 waves in order
+    float loss = 0.f, wsum = 0.f, correct = 0.f;
+    if (yok && li == 0) {
+        loss = wy * (logf(se) + zmax - zy);
+        wsum = wy;
+        correct = (arg == y) ? 1.f : 0.f;
+    }
+    __shared__ float red[3][4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        loss += __shfl_down(loss, off, 64);
+        wsum += __shfl_down(wsum, off, 64);
+        correct += __shfl_down(correct, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = loss; red[1][wave] = wsum; red[2][wave] = correct; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f, d = 0.f;
+        for (int w = 0; w < 4; ++w) { a += red[0][w]; b += red[1][w]; d += red[2][w]; }
+        partial[(int64_t)blockIdx.x * 3 + 0] = a;
+        partial[(int64_t)blockIdx.x * 3 + 1] = b;
+        partial[(int64_t)blockIdx.x * 3 + 2] = d;
+    }
+}
+
 int narrow_blocks(int64_t n) {
     const int64_t b = gte::ceil_div(n, 4);
     return (int)(b < NB_MAX ? b : NB_MAX);
@@ -444,10 +569,11 @@ extern "C" int64_t gte_sage_narrow_bwd_workspace_bytes(int64_t n_nodes, int64_t 
     return gte::round_up((int64_t)narrow_blocks(n_nodes > 0 ? n_nodes : 1) * (2 * n_out * n_feat + n_out) * 4, 256);
 }
 
-extern "C" int gte_sage_narrow_bwd(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h,
-                                   int64_t ldh, int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dh,
-                                   int64_t lddh, float* dW, int64_t lddw, float* dbias, int64_t n_nodes,
-                                   void* workspace, int64_t workspace_bytes, void* stream) {
+namespace {
+int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh, int64_t n_feat,
+                    const float* W, int64_t ldw, int64_t n_out, float* dh, int64_t lddh, float* dW, int64_t lddw, float* dbias,
+                    int64_t n_nodes, void* workspace, int64_t workspace_bytes, const float* ce_partial, int64_t ce_blocks,
+                    float grad_scale, float* out3, void* stream) {
     if (!gte_sage_narrow_supported(n_feat, n_out) || n_nodes < 0 || n_nodes > INT32_MAX)
         return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd: needs n_out <= 16 and n_feat <= 256");
     if (n_nodes == 0) return GTE_OK;
@@ -464,7 +590,7 @@ extern "C" int gte_sage_narrow_bwd(const float* dl, int64_t lddl, const float* q
 #define GTE_NBM(NCT)                                                                                                  \
     hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT>), dim3((unsigned)nbm), dim3(256),                                \
                        (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1)) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, lddh, part, \
-                       (int)n_nodes, F, C)
+                       (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3)
         if (n_out <= 4) GTE_NBM(4); else if (n_out <= 8) GTE_NBM(8); else if (n_out <= 12) GTE_NBM(12); else GTE_NBM(16);
 #undef GTE_NBM
         const int64_t pstride = 2 * (int64_t)C * F + C;
@@ -477,6 +603,7 @@ extern "C" int gte_sage_narrow_bwd(const float* dl, int64_t lddl, const float* q
         }
         return gte::check_launch("sage_narrow_bwd");
     }
+    if (ce_partial) return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd_ce: needs n_feat %% 8 == 0");
     const int nb = narrow_blocks(n_nodes);
 #define GTE_NB2(NJ, NCT)                                                                                                  \
     hipLaunchKernelGGL((narrow_bwd_kernel<NJ, NCT>), dim3((unsigned)nb), dim3(256), (size_t)(2 * C * 64 * NJ + C) * 4, s, \
@@ -491,3 +618,61 @@ extern "C" int gte_sage_narrow_bwd(const float* dl, int64_t lddl, const float* q
                        dW, lddw, dbias);
     return gte::check_launch("sage_narrow_bwd");
 }
+}  // namespace
+
+extern "C" int gte_sage_narrow_bwd(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h,
+                                   int64_t ldh, int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dh,
+                                   int64_t lddh, float* dW, int64_t lddw, float* dbias, int64_t n_nodes,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+    return narrow_bwd_impl(dl, lddl, q, ldq, h, ldh, n_feat, W, ldw, n_out, dh, lddh, dW, lddw, dbias, n_nodes, workspace,
+                           workspace_bytes, nullptr, 0, 1.f, nullptr, stream);
+}
+
+extern "C" int gte_head_supported(int64_t n_feat, int64_t n_classes) {
+    return (gte_sage_narrow_supported(n_feat, n_classes) && n_feat % 8 == 0) ? 1 : 0;
+}
+
+extern "C" int64_t gte_head_agg_ce_workspace_bytes(int64_t n_nodes) {
+    return gte::round_up(gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64) * 3 * (int64_t)sizeof(float), 256);
+}
+
+extern "C" int gte_head_agg_ce(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* t_neigh,
+                               int64_t ld_neigh, float* logits, int64_t ld_logits, const void* labels, int labels_f32,
+                               const float* class_weight, int64_t n_nodes, int64_t n_classes, int reduce, float* dl_unscaled,
+                               int64_t lddl, void* ce_partial, int64_t ce_partial_bytes, void* stream) {
+    if (n_nodes <= 0 || n_nodes > INT32_MAX || n_classes < 1 || n_classes > NC_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "head_agg_ce: needs 1 <= n_classes <= 16 and n_nodes >= 1");
+    if (!indptr || !t_neigh || !logits || !labels || !ce_partial)          // indices may be NULL for an edgeless graph
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "head_agg_ce: null pointer");
+    if (ld_neigh < n_classes || ld_logits < n_classes || (dl_unscaled && lddl < n_classes))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "head_agg_ce: leading dimension too small");
+    if (reduce != GTE_REDUCE_SUM && reduce != GTE_REDUCE_MEAN)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "head_agg_ce: reduce must be 0 (sum) or 1 (mean)");
+    if (ce_partial_bytes < gte_head_agg_ce_workspace_bytes(n_nodes))
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "head_agg_ce: partial buffer too small");
+    hipStream_t s = gte::as_stream(stream);
+    const unsigned nb = (unsigned)gte::ceil_div(n_nodes, 64);
+    float* part = reinterpret_cast<float*>(ce_partial);
+    if (labels_f32)
+        hipLaunchKernelGGL(head_agg_ce_kernel<float>, dim3(nb), dim3(256), 0, s, indptr, indices, eweight, t_neigh, ld_neigh,
+                           logits, ld_logits, (const float*)labels, class_weight, (int)n_nodes, (int)n_classes, reduce,
+                           dl_unscaled, lddl, part);
+    else
+        hipLaunchKernelGGL(head_agg_ce_kernel<int64_t>, dim3(nb), dim3(256), 0, s, indptr, indices, eweight, t_neigh, ld_neigh,
+                           logits, ld_logits, (const int64_t*)labels, class_weight, (int)n_nodes, (int)n_classes, reduce,
+                           dl_unscaled, lddl, part);
+    return gte::check_launch("head_agg_ce");
+}
+
+extern "C" int gte_sage_narrow_bwd_ce(const float* dl_unscaled, int64_t lddl, const float* q_unscaled, int64_t ldq,
+                                      const float* h, int64_t ldh, int64_t n_feat, const float* W, int64_t ldw, int64_t n_out,
+                                      float* dh, int64_t lddh, float* dW, int64_t lddw, float* dbias, int64_t n_nodes,
+                                      void* workspace, int64_t workspace_bytes, const void* ce_partial, float grad_scale,
+                                      float* out3, void* stream) {
+    if (!ce_partial || !out3) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ce: null pointer");
+    if (!gte_head_supported(n_feat, n_out)) return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd_ce: see gte_head_supported");
+    return narrow_bwd_impl(dl_unscaled, lddl, q_unscaled, ldq, h, ldh, n_feat, W, ldw, n_out, dh, lddh, dW, lddw, dbias, n_nodes,
+                           workspace, workspace_bytes, reinterpret_cast<const float*>(ce_partial),
+                           gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream);
+}
+

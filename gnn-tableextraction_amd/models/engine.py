@@ -132,6 +132,8 @@ class FusedGcnSageStep(TrainStep):
         # the reference's aggregate-then-transform order everywhere (same math, different summation order)
         self.transform_first = os.environ.get("GTE_TRANSFORM_FIRST", "1") == "1"
         self.tail_split = os.environ.get("GTE_TAIL_SPLIT", "1") == "1"
+        self.fused_head = os.environ.get("GTE_FUSED_HEAD", "1") == "1"
+        self._head_scale = None
         self._tail_ws = None
 
     # -- buffers -------------------------------------------------------------------------------------
@@ -167,6 +169,7 @@ class FusedGcnSageStep(TrainStep):
         # in a workspace of its own until the flush
         b["ws_ln"] = [torch.empty(int(lib.gte_ln_relu_bwd_workspace_bytes(cap, dims[i + 1])), dtype=torch.uint8, device=dev)
                       for i in range(len(layers))]
+        b["ce_part"] = torch.empty(int(lib.gte_head_agg_ce_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
         b["ws_nar"] = torch.empty(int(lib.gte_sage_narrow_bwd_workspace_bytes(cap, min(dims[-2], 256), min(dims[-1], 16))),
                                   dtype=torch.uint8, device=dev)
         # one private workspace per layer for the dW GEMMs: they run on the side stream, several at once
@@ -194,11 +197,17 @@ class FusedGcnSageStep(TrainStep):
                 "stats": [None if t is None else t[:2 * n] for t in full["stats"]], "y": [v(t) for t in full["y"]],
                 "dy": [v(t) for t in full["dy"]], "dahn": v(full["dahn"]), "tn": v(full["tn"]), "q": v(full["q"]),
                 "out3": full["out3"], "ws": full["ws"], "ws_ln": full["ws_ln"], "ws_nar": full["ws_nar"],
+                "ce_part": full["ce_part"],
                 "ws_dw": full["ws_dw"]}
 
     def _narrow(self, layer, fin: int) -> bool:
         return (not isinstance(layer.lynorm, nn.LayerNorm) and layer.activation is None and layer.linear.bias is not None
                 and bool(self.lib.gte_sage_narrow_supported(fin, layer.out_feats)))
+
+    def _fused_head(self, i: int, layer, fin: int) -> bool:
+        """Output layer + weighted CE as gte_head_agg_ce / gte_sage_narrow_bwd_ce (the last, narrow layer only)."""
+        return (self.fused_head and i == len(self.model.layers) - 1 and self._narrow(layer, fin)
+                and bool(self.lib.gte_head_supported(fin, layer.out_feats)))
 
     def _transform_first(self, layer, fin: int) -> bool:
         """Forward as  z = h W_s^T + b + mean-aggregate(h W_n^T)  when the layer narrows (831 -> 256): the aggregation
@@ -263,6 +272,7 @@ class FusedGcnSageStep(TrainStep):
         ws, wsn = P(b["ws"]), b["ws"].numel()
         # ---------------- forward ----------------
         h = x
+        fused_head = False
         for i, L in enumerate(layers):
             fin, fout = h.shape[1], L.out_feats
             W, bias = L.linear.weight, L.linear.bias
@@ -274,7 +284,9 @@ class FusedGcnSageStep(TrainStep):
                 with timed("narrow_fwd", 2.0 * n * fin * 4):
                     check(lib.gte_sage_narrow_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(y), fout, P(b["tn"]),
                                                   fout, n, st), "gte_sage_narrow_fwd")
-                aggregate(csr, w_in, None, b["tn"], fout, y, fout, fout, _lib.REDUCE_MEAN, True)
+                fused_head = self._fused_head(i, L, fin)
+                if not fused_head:
+                    aggregate(csr, w_in, None, b["tn"], fout, y, fout, fout, _lib.REDUCE_MEAN, True)
                 h = y
                 continue
             if self._transform_first(L, fin):
@@ -312,9 +324,20 @@ class FusedGcnSageStep(TrainStep):
         # ---------------- loss ----------------
         lab = labels if labels.dtype in (torch.float32, torch.int64) else labels.to(torch.int64)
         dl = b["dy"][-1]
-        check(lib.gte_weighted_ce(P(logits), logits.shape[1], P(lab), int(lab.dtype == torch.float32),
-                                  P(self.class_weights), n, logits.shape[1], float(grad_scale), P(dl), dl.shape[1],
-                                  P(b["out3"]), ws, wsn, st), "gte_weighted_ce")
+        self._head_scale = None
+        if fused_head:
+            # one launch: logits += mean-aggregate(t_neigh), CE terms, UNNORMALISED gradient; 1 / sum(w) is applied (and
+            # the loss published) by the output layer's backward kernel -- see gte_head_agg_ce in include/gte.h
+            with timed("spmm_csr", 2.0 * n * logits.shape[1] * 4 + 8.0 * csr.indices.numel() + 4.0 * (n + 1)):
+                check(lib.gte_head_agg_ce(P(csr.indptr), P(csr.indices), P(w_in), P(b["tn"]), logits.shape[1], P(logits),
+                                          logits.shape[1], P(lab), int(lab.dtype == torch.float32), P(self.class_weights), n,
+                                          logits.shape[1], _lib.REDUCE_MEAN, P(dl), dl.shape[1], P(b["ce_part"]),
+                                          b["ce_part"].numel(), st), "gte_head_agg_ce")
+            self._head_scale = float(grad_scale)
+        else:
+            check(lib.gte_weighted_ce(P(logits), logits.shape[1], P(lab), int(lab.dtype == torch.float32),
+                                      P(self.class_weights), n, logits.shape[1], float(grad_scale), P(dl), dl.shape[1],
+                                      P(b["out3"]), ws, wsn, st), "gte_weighted_ce")
 
         # ---------------- backward ----------------
         side_used = False
@@ -349,9 +372,15 @@ class FusedGcnSageStep(TrainStep):
                 aggregate(rcsr, w_out, None, dy, fout, b["q"], fout, fout, _lib.REDUCE_SUM, False)
                 dh = b["dy"][i - 1] if i > 0 else None
                 with timed("narrow_bwd", 3.0 * n * fin * 4):
-                    check(lib.gte_sage_narrow_bwd(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,
-                                                  P(dh), fin, P(gW), 2 * fin, P(gb), n, P(b["ws_nar"]), b["ws_nar"].numel(), st),
-                          "gte_sage_narrow_bwd")
+                    if self._head_scale is not None and i == len(layers) - 1:
+                        check(lib.gte_sage_narrow_bwd_ce(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,
+                                                         P(dh), fin, P(gW), 2 * fin, P(gb), n, P(b["ws_nar"]),
+                                                         b["ws_nar"].numel(), P(b["ce_part"]), self._head_scale, P(b["out3"]),
+                                                         st), "gte_sage_narrow_bwd_ce")
+                    else:
+                        check(lib.gte_sage_narrow_bwd(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,
+                                                      P(dh), fin, P(gW), 2 * fin, P(gb), n, P(b["ws_nar"]),
+                                                      b["ws_nar"].numel(), st), "gte_sage_narrow_bwd")
                 continue
             tfirst, qform = self._transform_first(L, fin), self._qform(i, L, fin)
             zsrc = b["t"][i] if tfirst else (b["z"][i] if ln else b["y"][i])

@@ -222,6 +222,27 @@ int gte_sage_narrow_bwd(const float* dl, int64_t lddl, const float* q, int64_t l
                         float* dW, int64_t lddw, float* dbias, int64_t n_nodes,
                         void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The fused head of the train step (class-count-wide output layer + weighted cross-entropy, model_train.py:171,327-328
+ * after models.py:101-103).  gte_head_supported(n_feat, n_classes): n_classes <= 16, n_feat <= 256, n_feat % 8 == 0.
+ *   gte_head_agg_ce : logits[v,:] (in: t_self + bias from gte_sage_narrow_fwd) += scale_v * sum_e w[e] t_neigh[src,:]  (the
+ *        same sums, bit for bit, as gte_spmm_csr_accumulate), then per node the weighted CE terms and the UNNORMALISED
+ *        gradient dl'[v,:] = w_y (softmax - onehot); per-block partials {sum w nll, sum w, #correct} go to ce_partial
+ *        (>= gte_head_agg_ce_workspace_bytes(n_nodes), must stay untouched until gte_sage_narrow_bwd_ce has run).
+ *   caller: q' = gte_spmm_csr(out-edge CSR, mean weights, dl')   (linear: the missing 1 / sum(w) commutes with it)
+ *   gte_sage_narrow_bwd_ce : gte_sage_narrow_bwd on alpha * dl', alpha * q' with alpha = grad_scale / sum(w) folded from
+ *        ce_partial inside the kernel; also writes out3 = {loss, sum w, #correct} like gte_weighted_ce.
+ * Three launches (aggregation, CE partial, CE gradient) become one and the loss never needs a launch of its own. */
+int gte_head_supported(int64_t n_feat, int64_t n_classes);
+int64_t gte_head_agg_ce_workspace_bytes(int64_t n_nodes);
+int gte_head_agg_ce(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* t_neigh,
+                    int64_t ld_neigh, float* logits, int64_t ld_logits, const void* labels, int labels_f32,
+                    const float* class_weight, int64_t n_nodes, int64_t n_classes, int reduce, float* dl_unscaled,
+                    int64_t lddl, void* ce_partial, int64_t ce_partial_bytes, void* stream);
+int gte_sage_narrow_bwd_ce(const float* dl_unscaled, int64_t lddl, const float* q_unscaled, int64_t ldq, const float* h,
+                           int64_t ldh, int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dh,
+                           int64_t lddh, float* dW, int64_t lddw, float* dbias, int64_t n_nodes, void* workspace,
+                           int64_t workspace_bytes, const void* ce_partial, float grad_scale, float* out3, void* stream);
+
 /* LayerNorm + ReLU alone (row-wise over n_out):  y = relu?(gamma * (z - mean) * rstd + beta).
  * replaces models.py:64-66 when the caller ran the linear part separately.  In place (y == z) is
  * allowed.  stats (nullable): f32[2*M] = mean, rstd. */

@@ -290,6 +290,58 @@ def test_qform_entry_points_vs_float64(n, f, o):
     assert float(dx[:, f:].min()) == 5.0
 
 
+@pytest.mark.parametrize("n,f,c,weighted,flt", [(1500, 256, 9, True, True), (777, 64, 4, False, False), (65, 8, 16, True, False),
+                                                  (24495, 256, 9, False, True)])
+def test_fused_head_matches_the_separate_kernels(n, f, c, weighted, flt):
+    """gte_head_agg_ce + gte_sage_narrow_bwd_ce (aggregation + CE + unnormalised gradient in one launch, 1/sum(w) and the
+    loss inside the backward kernel) against gte_spmm_csr_accumulate + gte_weighted_ce + gte_sage_narrow_bwd."""
+    lib = gte._lib.load()
+    P, cs, check = gte._lib.ptr, gte._lib.current_stream, gte._lib.check
+    assert lib.gte_head_supported(f, c) and not lib.gte_head_supported(12, 9)
+    rng = np.random.default_rng(n + c)
+    e = 6 * n
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    dst[dst == 3] = 4                                                    # node 3: no in-edges
+    w = rng.random(e).astype(np.float32)
+    g = G.PageGraph(src, dst, n, device=DEV)
+    csr, rcsr = g.in_csr(), g.out_csr()
+    w_in, w_out = g.in_weights(dev(w)), g.out_weights(dev(w), True)
+    h = dev(rng.standard_normal((n, f)).astype(np.float32))
+    W = dev((rng.standard_normal((c, 2 * f)) / np.sqrt(2 * f)).astype(np.float32))
+    ts0, tn = dev(rng.standard_normal((n, c)).astype(np.float32)), dev(rng.standard_normal((n, c)).astype(np.float32))
+    y = rng.integers(0, c, n)
+    lab = dev(y.astype(np.float32)) if flt else dev(y.astype(np.int64))
+    cw = dev(rng.random(c).astype(np.float32) + 0.5) if weighted else None
+    gs = 0.37
+    new = lambda *s: torch.empty(*s, device=DEV)
+    # separate kernels
+    la = ts0.clone()
+    check(lib.gte_spmm_csr_accumulate(P(csr.indptr), P(csr.indices), P(w_in), P(tn), c, P(la), c, n, c, gte._lib.GTE_F32, 1, cs()), "agg")
+    dla, outa = new(n, c), new(3)
+    wsa = torch.empty(int(lib.gte_weighted_ce_workspace_bytes(n)), dtype=torch.uint8, device=DEV)
+    check(lib.gte_weighted_ce(P(la), c, P(lab), int(flt), P(cw), n, c, gs, P(dla), c, P(outa), P(wsa), wsa.numel(), cs()), "ce")
+    qa = ops.spmm_csr(rcsr.indptr, rcsr.indices, w_out, dla, n)
+    wsn = torch.empty(int(lib.gte_sage_narrow_bwd_workspace_bytes(n, f, c)), dtype=torch.uint8, device=DEV)
+    dha, dWa, dba = new(n, f), new(c, 2 * f), new(c)
+    check(lib.gte_sage_narrow_bwd(P(dla), c, P(qa), c, P(h), f, f, P(W), 2 * f, c, P(dha), f, P(dWa), 2 * f, P(dba), n, P(wsn),
+                                  wsn.numel(), cs()), "bwd")
+    # fused head
+    lb, dlb, outb = ts0.clone(), new(n, c), new(3)
+    part = torch.empty(int(lib.gte_head_agg_ce_workspace_bytes(n)), dtype=torch.uint8, device=DEV)
+    check(lib.gte_head_agg_ce(P(csr.indptr), P(csr.indices), P(w_in), P(tn), c, P(lb), c, P(lab), int(flt), P(cw), n, c, 1, P(dlb),
+                              c, P(part), part.numel(), cs()), "head")
+    qb = ops.spmm_csr(rcsr.indptr, rcsr.indices, w_out, dlb, n)
+    dhb, dWb, dbb = new(n, f), new(c, 2 * f), new(c)
+    check(lib.gte_sage_narrow_bwd_ce(P(dlb), c, P(qb), c, P(h), f, f, P(W), 2 * f, c, P(dhb), f, P(dWb), 2 * f, P(dbb), n, P(wsn),
+                                     wsn.numel(), P(part), gs, P(outb), cs()), "bwd_ce")
+    assert torch.equal(la, lb)                                             # same aggregation, bit for bit
+    np.testing.assert_allclose(outb.cpu().numpy(), outa.cpu().numpy(), rtol=2e-6, atol=0)
+    assert float(outb[2]) == float(outa[2])                                # identical arg-max decisions
+    for got, want in ((dhb, dha), (dWb, dWa), (dbb, dba)):
+        ref = want.cpu().numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=2e-6 * np.abs(ref).max() + 1e-12)
+
+
 @pytest.mark.parametrize("n,f,c", [(1000, 256, 9), (777, 64, 4), (333, 200, 16), (50, 13, 9), (2049, 128, 12), (31, 8, 1),
                                    (24495, 256, 9)])
 def test_narrow_layer_fwd_bwd_vs_float64(n, f, c):
