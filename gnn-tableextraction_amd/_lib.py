@@ -70,6 +70,11 @@ SIGNATURES = {
     "gte_sage_narrow_bwd_ce": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                        c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                        c_void_p, c_float, c_void_p, c_void_p]),
+    "gte_sage_narrow_bwd_ln_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "gte_sage_narrow_bwd_ln": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                       c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                       c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_ln_relu_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p,
                                 c_int64, c_int64, c_void_p]),
     "gte_ln_relu_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),

@@ -266,12 +266,20 @@ narrow_fwd_mfma_kernel(const float* __restrict__ h, int64_t ldh, const float* __
 // starting at 64 w, lane i of tile j holds column 64 w + 2 i + j), so a wave keeps 2 dW tiles + 2 dh tiles in
 // accumulators (~120 registers: 4 waves per SIMD hide the global latency) and the dW partials of a workgroup need no
 // fold across its waves.  NCT: compile-time bound on C (4, 8, 12, 16).
-template <int NCT>
+// Optional LayerNorm(+ReLU) backward of the layer BELOW, fused behind the dh product (LNB kernels): h = relu(LN(z)) was
+// that layer's output; instead of dh the kernel writes dz = LN'(z) . (relu mask . dh) and leaves the column partials
+// {sum g xhat, sum g, sum dz} per workgroup in lnpart[block][3][F] -- dh (25 MB at 24 k x 256) is never written or read.
+struct LnBackward {
+    const float* z; int64_t ldz; const float* stats; const float* gamma; const float* beta; int relu; float* lnpart;
+};
+
+template <int NCT, bool LNB = false>
 __global__ void __launch_bounds__(256)
 narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* __restrict__ q, int64_t ldq,
                        const float* __restrict__ h, int64_t ldh, const float* __restrict__ W, int64_t ldw,
                        float* __restrict__ dh, int64_t lddh, float* __restrict__ partial, int n, int F, int C,
-                       const float* __restrict__ ce_partial, int64_t ce_blocks, float grad_scale, float* __restrict__ out3) {
+                       const float* __restrict__ ce_partial, int64_t ce_blocks, float grad_scale, float* __restrict__ out3,
+                       const LnBackward lnb = LnBackward{}) {
     constexpr int KD = 2 * NCT;                 // compact K of the dh product / M of the dW product
     constexpr int DP = KD + 1;                  // row stride of the DLQ image (odd: conflict-free read both ways)
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -300,12 +308,30 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) gw[j][r] = 0.f;
     float gb = 0.f;                             // wave 0, lane c (< C): dbias[c]
+    struct __attribute__((packed, aligned(4))) f2n { float x, y; };
+    __shared__ float lnred[4][32][2];           // LNB: per wave, per row of the block: {sum dxhat, sum dxhat xhat}
+    float gam0 = 1.f, gam1 = 1.f, bet0 = 0.f, bet1 = 0.f;
+    float s_dg0 = 0.f, s_dg1 = 0.f, s_db0 = 0.f, s_db1 = 0.f, s_dz0 = 0.f, s_dz1 = 0.f;
+    if constexpr (LNB) {
+        if (colok) { gam0 = lnb.gamma[col]; gam1 = lnb.gamma[col + 1]; bet0 = lnb.beta[col]; bet1 = lnb.beta[col + 1]; }
+    }
 
     for (int rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
         const int row0 = rb * 32;
         // this block's h rows for the dW product: issued first, they land under the DLQ fill and the dh MFMAs
-        struct __attribute__((packed, aligned(4))) f2n { float x, y; };
         f2n hv[16];
+        f2n zv[LNB ? 16 : 1];                   // LNB: the z values under this lane's dh elements
+        float mu[LNB ? 16 : 1], rs[LNB ? 16 : 1];
+        if constexpr (LNB) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                zv[r] = f2n{0.f, 0.f};
+                const int rr = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * hh, n - 1);
+                if (colok) zv[r] = *reinterpret_cast<const f2n*>(lnb.z + (int64_t)rr * lnb.ldz + col);
+                mu[r] = lnb.stats[rr];
+                rs[r] = lnb.stats[n + rr];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             hv[s] = f2n{0.f, 0.f};
@@ -337,6 +363,60 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                 o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, o[0], 0, 0, 0);
                 o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, o[1], 0, 0, 0);
             }
+            if constexpr (LNB) {
+                // g = mask . dh, dxhat = g gamma; the row sums need all F columns: 32 lanes of this half-wave, then the
+                // four waves through LDS (fixed order)
+                float xh0[16], xh1[16], pa[16], pb[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const bool ok = colok && rr < n;
+                    xh0[r] = ok ? (zv[r].x - mu[r]) * rs[r] : 0.f;
+                    xh1[r] = ok ? (zv[r].y - mu[r]) * rs[r] : 0.f;
+                    float g0 = ok ? o[0][r] : 0.f, g1 = ok ? o[1][r] : 0.f;
+                    if (lnb.relu) {
+                        if (fmaf(xh0[r], gam0, bet0) <= 0.f) g0 = 0.f;
+                        if (fmaf(xh1[r], gam1, bet1) <= 0.f) g1 = 0.f;
+                    }
+                    o[0][r] = g0; o[1][r] = g1;
+                    const float d0 = g0 * gam0, d1 = g1 * gam1;
+                    pa[r] = d0 + d1;
+                    pb[r] = fmaf(d0, xh0[r], d1 * xh1[r]);
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        pa[r] += __shfl_xor(pa[r], off, 32);
+                        pb[r] += __shfl_xor(pb[r], off, 32);
+                    }
+                if (i == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        lnred[wave][rl][0] = pa[r];
+                        lnred[wave][rl][1] = pb[r];
+                    }
+                }
+                __syncthreads();
+                const float inv_f = 1.0f / (float)F;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int rr = row0 + rl;
+                    const float c1 = (((lnred[0][rl][0] + lnred[1][rl][0]) + lnred[2][rl][0]) + lnred[3][rl][0]) * inv_f;
+                    const float c2 = (((lnred[0][rl][1] + lnred[1][rl][1]) + lnred[2][rl][1]) + lnred[3][rl][1]) * inv_f;
+                    const float d0 = rs[r] * (o[0][r] * gam0 - c1 - xh0[r] * c2);
+                    const float d1 = rs[r] * (o[1][r] * gam1 - c1 - xh1[r] * c2);
+                    s_dg0 = fmaf(o[0][r], xh0[r], s_dg0); s_dg1 = fmaf(o[1][r], xh1[r], s_dg1);
+                    s_db0 += o[0][r]; s_db1 += o[1][r];
+                    if (colok && rr < n) {
+                        s_dz0 += d0; s_dz1 += d1;
+                        f2n v; v.x = d0; v.y = d1;
+                        *reinterpret_cast<f2n*>(dh + (int64_t)rr * lddh + col) = v;
+                    }
+                }
+            } else
             if (colok) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -371,6 +451,17 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
         }
     }
     if (wave == 0 && i < C && hh == 0) pp[2 * C * F + i] = gb;
+    if constexpr (LNB) {                        // the two half-waves hold different rows of the same columns
+        s_dg0 += __shfl_xor(s_dg0, 32, 64); s_dg1 += __shfl_xor(s_dg1, 32, 64);
+        s_db0 += __shfl_xor(s_db0, 32, 64); s_db1 += __shfl_xor(s_db1, 32, 64);
+        s_dz0 += __shfl_xor(s_dz0, 32, 64); s_dz1 += __shfl_xor(s_dz1, 32, 64);
+        if (colok && hh == 0) {
+            float* lp = lnb.lnpart + (int64_t)blockIdx.x * 3 * F + col;
+            lp[0] = s_dg0; lp[1] = s_dg1;
+            lp[F] = s_db0; lp[F + 1] = s_db1;
+            lp[2 * F] = s_dz0; lp[2 * F + 1] = s_dz1;
+        }
+    }
 }
 
 // dW[c, seg*F + k] = sum_b partial[b][(seg*C + c)*F + k];  dbias[c] = sum_b partial[b][2CF + c]   (fixed order)
@@ -577,7 +668,8 @@ namespace {
 int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh, int64_t n_feat,
                     const float* W, int64_t ldw, int64_t n_out, float* dh, int64_t lddh, float* dW, int64_t lddw, float* dbias,
                     int64_t n_nodes, void* workspace, int64_t workspace_bytes, const float* ce_partial, int64_t ce_blocks,
-                    float grad_scale, float* out3, void* stream) {
+                    float grad_scale, float* out3, void* stream, const LnBackward* lnb = nullptr, float* dgamma = nullptr,
+                    float* dbeta = nullptr, float* dbias_below = nullptr) {
     if (!gte_sage_narrow_supported(n_feat, n_out) || n_nodes < 0 || n_nodes > INT32_MAX)
         return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd: needs n_out <= 16 and n_feat <= 256");
     if (n_nodes == 0) return GTE_OK;
@@ -592,11 +684,36 @@ int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, 
     if (n_feat % 8 == 0) {                                 // matrix-pipe version
         const int nbm = narrow_mfma_blocks(n_nodes);
 #define GTE_NBM(NCT)                                                                                                  \
-    hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT>), dim3((unsigned)nbm), dim3(256),                                \
-                       (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1)) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, lddh, part, \
-                       (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3)
+    do {                                                                                                              \
+        if (lnb)                                                                                                      \
+            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, true>), dim3((unsigned)nbm), dim3(256),                   \
+                               (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1)) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, lddh, \
+                               part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, *lnb);              \
+        else                                                                                                          \
+            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, false>), dim3((unsigned)nbm), dim3(256),                  \
+                               (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1)) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, lddh, \
+                               part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, LnBackward{});      \
+    } while (0)
         if (n_out <= 4) GTE_NBM(4); else if (n_out <= 8) GTE_NBM(8); else if (n_out <= 12) GTE_NBM(12); else GTE_NBM(16);
 #undef GTE_NBM
+        if (lnb) {                                          // column sums of the fused LayerNorm backward
+            const bool own = !gte::defer_fold(lnb->lnpart, 3 * (int64_t)F, nbm, 1, F, dgamma, F);
+            if (own) {                                      // no deferral open: run the three folds now, as one launch
+                int rc = gte_fold_defer_begin(stream);
+                if (rc != GTE_OK) return rc;
+                gte::defer_fold(lnb->lnpart, 3 * (int64_t)F, nbm, 1, F, dgamma, F);
+            }
+            gte::defer_fold(lnb->lnpart + F, 3 * (int64_t)F, nbm, 1, F, dbeta, F);
+            gte::defer_fold(lnb->lnpart + 2 * F, 3 * (int64_t)F, nbm, 1, F, dbias_below, F);
+            if (own) {
+                // the narrow layer's own folds join the same launch
+                const int64_t ps = 2 * (int64_t)C * F + C;
+                gte::defer_fold(part, ps, nbm, C, F, dW, lddw);
+                gte::defer_fold(part + (int64_t)C * F, ps, nbm, C, F, dW + F, lddw);
+                gte::defer_fold(part + 2 * (int64_t)C * F, ps, nbm, 1, C, dbias, C);
+                return gte_fold_defer_flush();
+            }
+        }
         const int64_t pstride = 2 * (int64_t)C * F + C;
         if (gte::defer_fold(part, pstride, nbm, C, F, dW, lddw)) {                    // [dl^T h]
             gte::defer_fold(part + (int64_t)C * F, pstride, nbm, C, F, dW + F, lddw);   // [q^T h]
@@ -607,7 +724,7 @@ int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, 
         }
         return gte::check_launch("sage_narrow_bwd");
     }
-    if (ce_partial) return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd_ce: needs n_feat %% 8 == 0");
+    if (ce_partial || lnb) return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd_ce / _ln: needs n_feat %% 8 == 0");
     const int nb = narrow_blocks(n_nodes);
 #define GTE_NB2(NJ, NCT)                                                                                                  \
     hipLaunchKernelGGL((narrow_bwd_kernel<NJ, NCT>), dim3((unsigned)nb), dim3(256), (size_t)(2 * C * 64 * NJ + C) * 4, s, \
@@ -680,3 +797,27 @@ extern "C" int gte_sage_narrow_bwd_ce(const float* dl_unscaled, int64_t lddl, co
                            gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream);
 }
 
+
+extern "C" int64_t gte_sage_narrow_bwd_ln_workspace_bytes(int64_t n_nodes, int64_t n_feat) {
+    return gte::round_up((int64_t)narrow_mfma_blocks(n_nodes > 0 ? n_nodes : 1) * 3 * n_feat * 4, 256);
+}
+
+extern "C" int gte_sage_narrow_bwd_ln(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
+                                      int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dz_below, int64_t lddz,
+                                      float* dW, int64_t lddw, float* dbias, int64_t n_nodes, void* workspace,
+                                      int64_t workspace_bytes, const void* ce_partial, float grad_scale, float* out3,
+                                      const float* z_below, int64_t ldz, const float* stats_below, const float* gamma_below,
+                                      const float* beta_below, int relu_below, float* dgamma_below, float* dbeta_below,
+                                      float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes, void* stream) {
+    if (!gte_head_supported(n_feat, n_out)) return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd_ln: see gte_head_supported");
+    if (!dz_below || !z_below || !stats_below || !gamma_below || !beta_below || !ln_workspace || (ce_partial && !out3))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln: null pointer");
+    if (ldz < n_feat || lddz < n_feat) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln: leading dimension too small");
+    if (ln_workspace_bytes < gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_feat))
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd_ln: LayerNorm workspace too small");
+    const LnBackward lnb = {z_below, ldz, stats_below, gamma_below, beta_below, relu_below, reinterpret_cast<float*>(ln_workspace)};
+    return narrow_bwd_impl(dl, lddl, q, ldq, h, ldh, n_feat, W, ldw, n_out, dz_below, lddz, dW, lddw, dbias, n_nodes, workspace,
+                           workspace_bytes, reinterpret_cast<const float*>(ce_partial),
+                           gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream, &lnb, dgamma_below,
+                           dbeta_below, dbias_below);
+}

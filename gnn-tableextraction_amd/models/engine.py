@@ -133,6 +133,10 @@ class FusedGcnSageStep(TrainStep):
         self.transform_first = os.environ.get("GTE_TRANSFORM_FIRST", "1") == "1"
         self.tail_split = os.environ.get("GTE_TAIL_SPLIT", "1") == "1"
         self.fused_head = os.environ.get("GTE_FUSED_HEAD", "1") == "1"
+        # gte_sage_narrow_bwd_ln (LayerNorm backward of the layer below inside the output layer's backward kernel) saves
+        # 50 MB of traffic but serialises more work in one wave per SIMD: 41.6 us fused vs 22.4 + 16.6 us separate at
+        # 24 k nodes -- off by default, kept (and tested) for a later retune
+        self.fuse_ln_below = os.environ.get("GTE_FUSE_LN_BELOW", "0") == "1"
         self._head_scale = None
         self._tail_ws = None
 
@@ -167,8 +171,9 @@ class FusedGcnSageStep(TrainStep):
         b["ws"] = torch.empty(int(ws), dtype=torch.uint8, device=dev)
         # the backward defers its partial-sum folds to one launch (gte_fold_defer_*): every producer keeps its partials
         # in a workspace of its own until the flush
-        b["ws_ln"] = [torch.empty(int(lib.gte_ln_relu_bwd_workspace_bytes(cap, dims[i + 1])), dtype=torch.uint8, device=dev)
-                      for i in range(len(layers))]
+        b["ws_ln"] = [torch.empty(int(max(lib.gte_ln_relu_bwd_workspace_bytes(cap, dims[i + 1]),
+                                          lib.gte_sage_narrow_bwd_ln_workspace_bytes(cap, min(dims[i + 1], 256)))),
+                                  dtype=torch.uint8, device=dev) for i in range(len(layers))]
         b["ce_part"] = torch.empty(int(lib.gte_head_agg_ce_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
         b["ws_nar"] = torch.empty(int(lib.gte_sage_narrow_bwd_workspace_bytes(cap, min(dims[-2], 256), min(dims[-1], 16))),
                                   dtype=torch.uint8, device=dev)
@@ -203,6 +208,14 @@ class FusedGcnSageStep(TrainStep):
     def _narrow(self, layer, fin: int) -> bool:
         return (not isinstance(layer.lynorm, nn.LayerNorm) and layer.activation is None and layer.linear.bias is not None
                 and bool(self.lib.gte_sage_narrow_supported(fin, layer.out_feats)))
+
+    def _ln_below_fused(self, i: int, layers, fin: int) -> bool:
+        """The output layer's backward also runs the LayerNorm(+ReLU) backward of layer i-1 (gte_sage_narrow_bwd_ln)."""
+        if not self.fuse_ln_below or not self.fused_head or i == 0 or i != len(layers) - 1:
+            return False
+        Lb = layers[i - 1]
+        return (isinstance(Lb.lynorm, nn.LayerNorm) and self._narrow(layers[i], fin)
+                and bool(self.lib.gte_head_supported(fin, layers[i].out_feats)))
 
     def _fused_head(self, i: int, layer, fin: int) -> bool:
         """Output layer + weighted CE as gte_head_agg_ce / gte_sage_narrow_bwd_ce (the last, narrow layer only)."""
@@ -355,6 +368,7 @@ class FusedGcnSageStep(TrainStep):
         timed, ld = ops._timed, ops._ld
         ws, wsn = P(b["ws"]), b["ws"].numel()
         side_used = False
+        self._ln_done = None
         for i in range(len(layers) - 1, -1, -1):
             L = layers[i]
             hin = x if i == 0 else b["y"][i - 1]
@@ -371,8 +385,27 @@ class FusedGcnSageStep(TrainStep):
                 # q = A_w^T (norm * dlogits) on C columns; dW = [dl^T h | q^T h], dh = dl W_s + q W_n, dbias = colsum(dl)
                 aggregate(rcsr, w_out, None, dy, fout, b["q"], fout, fout, _lib.REDUCE_SUM, False)
                 dh = b["dy"][i - 1] if i > 0 else None
+                ln_below = self._ln_below_fused(i, layers, fin)
                 with timed("narrow_bwd", 3.0 * n * fin * 4):
-                    if self._head_scale is not None and i == len(layers) - 1:
+                    if ln_below:
+                        # ... and the LayerNorm(+ReLU) backward of layer i-1 in the same kernel: dz_{i-1} lands where dh
+                        # would have gone; that layer's own iteration below skips its gte_ln_relu_bwd
+                        Lb = layers[i - 1]
+                        tfb = self._transform_first(Lb, Lb.linear.weight.shape[1] // 2)
+                        zb = b["t"][i - 1] if tfb else b["z"][i - 1]
+                        gsl = self._gslice
+                        check(lib.gte_sage_narrow_bwd_ln(
+                            P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout, P(dh), fin, P(gW), 2 * fin,
+                            P(gb), n, P(b["ws_nar"]), b["ws_nar"].numel(),
+                            P(b["ce_part"]) if self._head_scale is not None else None,
+                            self._head_scale if self._head_scale is not None else 1.0,
+                            P(b["out3"]) if self._head_scale is not None else None,
+                            P(zb), 2 * fin if tfb else fin, P(b["stats"][i - 1]), P(Lb.lynorm.weight), P(Lb.lynorm.bias),
+                            int(Lb.activation is not None), P(gsl[id(Lb.lynorm.weight)]), P(gsl[id(Lb.lynorm.bias)]),
+                            P(gsl[id(Lb.linear.bias)]) if Lb.linear.bias is not None else None,
+                            P(b["ws_ln"][i - 1]), b["ws_ln"][i - 1].numel(), st), "gte_sage_narrow_bwd_ln")
+                        self._ln_done = i - 1
+                    elif self._head_scale is not None and i == len(layers) - 1:
                         check(lib.gte_sage_narrow_bwd_ce(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,
                                                          P(dh), fin, P(gW), 2 * fin, P(gb), n, P(b["ws_nar"]),
                                                          b["ws_nar"].numel(), P(b["ce_part"]), self._head_scale, P(b["out3"]),
@@ -384,11 +417,12 @@ class FusedGcnSageStep(TrainStep):
                 continue
             tfirst, qform = self._transform_first(L, fin), self._qform(i, L, fin)
             zsrc = b["t"][i] if tfirst else (b["z"][i] if ln else b["y"][i])
-            # dz in place of dy; column sums straight into the flat gradient
-            check(lib.gte_ln_relu_bwd(P(dy), fout, P(zsrc), 2 * fout if tfirst else fout, P(b["stats"][i]) if ln else None,
-                                      P(L.lynorm.weight) if ln else None, P(L.lynorm.bias) if ln else None, int(relu),
-                                      P(dy), fout, P(gg), P(gbe), P(gb), n, fout, P(b["ws_ln"][i]), b["ws_ln"][i].numel(), st),
-                  "gte_ln_relu_bwd")
+            # dz in place of dy; column sums straight into the flat gradient (unless the layer above already did it)
+            if self._ln_done != i:
+                check(lib.gte_ln_relu_bwd(P(dy), fout, P(zsrc), 2 * fout if tfirst else fout, P(b["stats"][i]) if ln else None,
+                                          P(L.lynorm.weight) if ln else None, P(L.lynorm.bias) if ln else None, int(relu),
+                                          P(dy), fout, P(gg), P(gbe), P(gb), n, fout, P(b["ws_ln"][i]), b["ws_ln"][i].numel(),
+                                          st), "gte_ln_relu_bwd")
             dz, ahn = dy, b["ahn"][i]
             if qform:
                 # q = A_w^T (norm * dz) into the dead right half of t (transform-first) or the dead ahn buffer

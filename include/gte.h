@@ -243,6 +243,21 @@ int gte_sage_narrow_bwd_ce(const float* dl_unscaled, int64_t lddl, const float* 
                            int64_t lddh, float* dW, int64_t lddw, float* dbias, int64_t n_nodes, void* workspace,
                            int64_t workspace_bytes, const void* ce_partial, float grad_scale, float* out3, void* stream);
 
+/* gte_sage_narrow_bwd_ce (ce_partial may be NULL: then dl / q are final and out3 is untouched) fused with the
+ * LayerNorm(+ReLU) backward of the layer below, whose output h = relu?(LN(z_below)) fed the output layer: instead of dh the
+ * call writes dz_below = LN'(z_below)(mask . dh) and the parameter gradients dgamma / dbeta / dbias of the layer below
+ * (each nullable) -- the [N, F] matrix dh is neither written nor read back by a separate gte_ln_relu_bwd.
+ * ln_workspace >= gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_feat); its folds join an open deferral
+ * (gte_fold_defer_begin) or run as one launch.  Same support rule as gte_head_supported. */
+int64_t gte_sage_narrow_bwd_ln_workspace_bytes(int64_t n_nodes, int64_t n_feat);
+int gte_sage_narrow_bwd_ln(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
+                           int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dz_below, int64_t lddz,
+                           float* dW, int64_t lddw, float* dbias, int64_t n_nodes, void* workspace, int64_t workspace_bytes,
+                           const void* ce_partial, float grad_scale, float* out3, const float* z_below, int64_t ldz,
+                           const float* stats_below, const float* gamma_below, const float* beta_below, int relu_below,
+                           float* dgamma_below, float* dbeta_below, float* dbias_below, void* ln_workspace,
+                           int64_t ln_workspace_bytes, void* stream);
+
 /* LayerNorm + ReLU alone (row-wise over n_out):  y = relu?(gamma * (z - mean) * rstd + beta).
  * replaces models.py:64-66 when the caller ran the linear part separately.  In place (y == z) is
  * allowed.  stats (nullable): f32[2*M] = mean, rstd. */

@@ -290,6 +290,41 @@ def test_qform_entry_points_vs_float64(n, f, o):
     assert float(dx[:, f:].min()) == 5.0
 
 
+@pytest.mark.parametrize("n,f,c,relu", [(1000, 256, 9, True), (333, 64, 4, False), (24495, 256, 9, True), (77, 128, 16, True)])
+def test_narrow_bwd_with_fused_layernorm_backward(n, f, c, relu):
+    """gte_sage_narrow_bwd_ln == gte_sage_narrow_bwd followed by gte_ln_relu_bwd of the layer below (dz, dgamma, dbeta,
+    dbias of that layer; dW / dbias of the output layer unchanged)."""
+    lib = gte._lib.load()
+    P, cs, check = gte._lib.ptr, gte._lib.current_stream, gte._lib.check
+    rng = np.random.default_rng(n + f)
+    new = lambda *s: torch.empty(*s, device=DEV)
+    z = dev(rng.standard_normal((n, f)).astype(np.float32))
+    gam, bet = dev(1 + 0.1 * rng.standard_normal(f).astype(np.float32)), dev(0.1 * rng.standard_normal(f).astype(np.float32))
+    h, stats = new(n, f), new(2 * n)
+    check(lib.gte_ln_relu_fwd(P(z), f, P(gam), P(bet), 1e-5, int(relu), P(h), f, P(stats), n, f, cs()), "ln fwd")
+    W = dev((rng.standard_normal((c, 2 * f)) / np.sqrt(2 * f)).astype(np.float32))
+    dl, q = dev(rng.standard_normal((n, c)).astype(np.float32) / n), dev(rng.standard_normal((n, c)).astype(np.float32) / n)
+    wsn = torch.empty(int(lib.gte_sage_narrow_bwd_workspace_bytes(n, f, c)), dtype=torch.uint8, device=DEV)
+    # separate
+    dh, dWa, dba = new(n, f), new(c, 2 * f), new(c)
+    check(lib.gte_sage_narrow_bwd(P(dl), c, P(q), c, P(h), f, f, P(W), 2 * f, c, P(dh), f, P(dWa), 2 * f, P(dba), n, P(wsn),
+                                  wsn.numel(), cs()), "bwd")
+    dga, dbea, dbia = new(f), new(f), new(f)
+    wl = torch.empty(int(lib.gte_ln_relu_bwd_workspace_bytes(n, f)), dtype=torch.uint8, device=DEV)
+    check(lib.gte_ln_relu_bwd(P(dh), f, P(z), f, P(stats), P(gam), P(bet), int(relu), P(dh), f, P(dga), P(dbea), P(dbia), n, f,
+                              P(wl), wl.numel(), cs()), "ln bwd")
+    # fused
+    dzb, dWb, dbb, dgb, dbeb, dbib = new(n, f), new(c, 2 * f), new(c), new(f), new(f), new(f)
+    wln = torch.empty(int(lib.gte_sage_narrow_bwd_ln_workspace_bytes(n, f)), dtype=torch.uint8, device=DEV)
+    check(lib.gte_sage_narrow_bwd_ln(P(dl), c, P(q), c, P(h), f, f, P(W), 2 * f, c, P(dzb), f, P(dWb), 2 * f, P(dbb), n, P(wsn),
+                                     wsn.numel(), None, 1.0, None, P(z), f, P(stats), P(gam), P(bet), int(relu), P(dgb), P(dbeb),
+                                     P(dbib), P(wln), wln.numel(), cs()), "bwd_ln")
+    # (dW / dbias: same partial sums, folded by a different kernel -> last-bit differences only)
+    for got, want in ((dWb, dWa), (dbb, dba), (dzb, dh), (dgb, dga), (dbeb, dbea), (dbib, dbia)):
+        ref = want.cpu().numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=3e-6 * np.abs(ref).max() + 1e-12)
+
+
 @pytest.mark.parametrize("n,f,c,weighted,flt", [(1500, 256, 9, True, True), (777, 64, 4, False, False), (65, 8, 16, True, False),
                                                   (24495, 256, 9, False, True)])
 def test_fused_head_matches_the_separate_kernels(n, f, c, weighted, flt):
