@@ -9,10 +9,16 @@
 // every wide operand is h itself: the forward reads h once, the backward reads h once and writes dh once.
 // The generic path needed 11 launches here (aggregate 256-wide, MFMA GEMM with N = 9 padded to 32, two skinny
 // dW GEMMs + reductions, two dX GEMMs, a 256-wide transpose aggregation) -- ~174 us per step at 24.5 k nodes
-// against ~55 us for this path.  Both kernels are HBM-bound (25 MB in, 25 MB out at F = 256).
+// against ~45 us for this path (forward 14, backward 22-25, 9-wide aggregations 2 x 6).  HBM-bound work: 25 MB in for
+// the forward, 25 MB in + 25 MB out for the backward at F = 256.
 //
-// Mapping: one wave64 per node row, lane l owns features l, l+64, ... (NJ <= 4, F <= 256); the 2C weight rows
-// live in registers (2C*NJ <= 128 VGPRs), row dot products are wave reductions, the dW partial sums accumulate
+// Kernels in this file:
+//   narrow_fwd_kernel / narrow_bwd_kernel<NJ, NCT>      plain FMA + wave reductions, any F <= 256   (fallback, F % 8 != 0)
+//   narrow_fwd_mfma_kernel / narrow_bwd_mfma_kernel     the same products on the matrix pipe        (F % 8 == 0: the shipped path)
+//   head_agg_ce_kernel                                  logits = t_self + aggregate(t_neigh), weighted CE, unnormalised gradient
+//   narrow_bwd_mfma_kernel<NCT, true>                   ... plus the LayerNorm backward of the layer below (built, off by default)
+// Plain-kernel mapping: one wave64 per node row, lane l owns features l, l+64, ... (NJ <= 4, F <= 256); the 2C weight
+// rows live in registers (2C*NJ <= 128 VGPRs), row dot products are wave reductions, the dW partial sums accumulate
 // in registers over the rows a wave owns and are folded through LDS per block, then across blocks in a fixed
 // order (no atomics: deterministic).
 #include "gte_common.h"
