@@ -851,6 +851,73 @@ ln_relu_fwd_kernel(const float* __restrict__ z, int64_t ldz, const float* __rest
     }
 }
 
+// 16-byte accesses, two rows in flight per wave: lane l owns columns 4 (l + 64 v) .. + 3 (n % 4 == 0, n <= 256 NV).
+// Same two-pass statistics.  (The scalar version above moves 4 bytes per lane per instruction: 13.9 us for 50 MB, a plain
+// device copy of the same bytes takes 8.3 us on this chip.)
+template <int NV>
+__global__ void __launch_bounds__(256)
+ln_relu_fwd_vec_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ gamma,
+                       const float* __restrict__ beta, float eps, int relu, float* __restrict__ y, int64_t ldy,
+                       float* __restrict__ stats, int M, int n) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= M) return;
+    float g[NV][4], b[NV][4];
+    bool okv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int j = 4 * (lane + 64 * v);
+        okv[v] = j < n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[v][e] = okv[v] ? gamma[j + e] : 0.f; b[v][e] = okv[v] ? beta[j + e] : 0.f; }
+    }
+    float c[2][NV][4];
+    bool rok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        rok[u] = row0 + u < M;
+        const int r = rok[u] ? row0 + u : row0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            f4u t{0.f, 0.f, 0.f, 0.f};
+            if (okv[v]) t = *reinterpret_cast<const f4u*>(z + (int64_t)r * ldz + 4 * (lane + 64 * v));
+            c[u][v][0] = t.x; c[u][v][1] = t.y; c[u][v][2] = t.z; c[u][v][3] = t.w;
+        }
+    }
+    const float inv_n = 1.0f / (float)n;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (!rok[u]) continue;                             // wave-uniform
+        const int r = row0 + u;
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += c[u][v][e];
+        const float mean = wave_sum(s) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = okv[v] ? c[u][v][e] - mean : 0.f; q = fmaf(d, d, q); }
+        const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+        if (stats && lane == 0) { stats[r] = mean; stats[M + r] = rstd; }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (okv[v]) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = ln_affine((c[u][v][e] - mean) * rstd, g[v][e], b[v][e]);
+                    if (relu) o[e] = fmaxf(o[e], 0.f);
+                }
+                f4u t; t.x = o[0]; t.y = o[1]; t.z = o[2]; t.w = o[3];
+                *reinterpret_cast<f4u*>(y + (int64_t)r * ldy + 4 * (lane + 64 * v)) = t;
+            }
+        }
+    }
+}
+
 // ------------------------------- LayerNorm + ReLU, backward ---------------------------------------
 // Per row: g = relu ? (pre > 0 ? dy : 0) : dy ; dxhat = g*gamma ;
 //          dz = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat))
@@ -1151,6 +1218,22 @@ int ln_bwd_blocks(int64_t M) {
     return (int)(b < LNB_MAX_BLOCKS ? b : LNB_MAX_BLOCKS);
 }
 
+void launch_ln_fwd(const float* z, int64_t ldz, const float* gamma, const float* beta, float eps, int relu, float* y,
+                   int64_t ldy, float* stats, int64_t M, int64_t n_out, hipStream_t s) {
+    if (n_out % 4 == 0 && n_out >= 128 && n_out <= 512) {          // 16-byte accesses, two rows per wave
+        const dim3 grid((unsigned)gte::ceil_div(M, 8)), block(256);
+        if (n_out <= 256)
+            hipLaunchKernelGGL((ln_relu_fwd_vec_kernel<1>), grid, block, 0, s, z, ldz, gamma, beta, eps, relu, y, ldy, stats, (int)M,
+                               (int)n_out);
+        else
+            hipLaunchKernelGGL((ln_relu_fwd_vec_kernel<2>), grid, block, 0, s, z, ldz, gamma, beta, eps, relu, y, ldy, stats, (int)M,
+                               (int)n_out);
+        return;
+    }
+    hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3((unsigned)gte::ceil_div(M, 4)), dim3(256), 0, s, z, ldz, gamma, beta, eps, relu, y,
+                       ldy, stats, (int)M, (int)n_out);
+}
+
 }  // namespace
 
 // ------------------------------------------ C ABI -------------------------------------------------
@@ -1352,8 +1435,7 @@ extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, co
         return gte::fail(GTE_ERR_UNSUPPORTED, "sage_linear_fwd: z_save without LayerNorm is not supported");
     }
     if (ln) {
-        hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3((unsigned)gte::ceil_div(M, 4)), dim3(256), 0, s, zbuf, ldzz, gamma,
-                           beta, eps, relu, y, ldy, stats, (int)M, (int)n_out);
+        launch_ln_fwd(zbuf, ldzz, gamma, beta, eps, relu, y, ldy, stats, M, n_out, s);
         return gte::check_launch("ln_relu_fwd");
     }
     return GTE_OK;
@@ -1366,8 +1448,7 @@ extern "C" int gte_ln_relu_fwd(const float* z, int64_t ldz, const float* gamma, 
     if (M == 0) return GTE_OK;
     if (!z || !y || !gamma || !beta) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_fwd: null pointer");
     if (ldz < n_out || ldy < n_out) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_fwd: ld < n_out");
-    hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3((unsigned)gte::ceil_div(M, 4)), dim3(256), 0, gte::as_stream(stream), z,
-                       ldz, gamma, beta, eps, relu, y, ldy, stats, (int)M, (int)n_out);
+    launch_ln_fwd(z, ldz, gamma, beta, eps, relu, y, ldy, stats, M, n_out, gte::as_stream(stream));
     return gte::check_launch("ln_relu_fwd");
 }
 
