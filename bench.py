@@ -46,8 +46,8 @@ def pmc_traffic():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=60)        # >= 50 timed steps after 10 warm-up
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--in-feats", type=int, default=831)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--layers", type=int, default=3)
