@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true")
     ap.add_argument("--gather-nodes", type=int, default=1_000_000)
+    ap.add_argument("--val-graph", type=int, default=0, metavar="PAGES",
+                    help="also time the forward-only pass over PAGES pages batched into one graph (cfg2 'val graph': 2000)")
     return ap.parse_args()
 
 
@@ -115,6 +117,39 @@ def cpu_baseline(args, host_batch, state):
                       f"{'OpenMP CSR SpMM' if oc.omp_available() else 'torch.sparse_csr'}, "
                       f"dense ops = torch CPU ({torch.get_num_threads()} threads)",
             "ms_per_step": med * 1e3}
+
+
+def val_graph_probe(args, gte, S, model, dev):
+    """SURVEY 8(d) cfg2, "val graph" case (model_train.py:349-370): every page of a validation set batched into ONE graph,
+    forward only (no_grad, eval mode) -- the reference evaluates on the single giant val_graph after each epoch.
+    Opt-in (--val-graph PAGES): building the synthetic pages on the host takes longer than the whole default bench."""
+    import time as _t
+    t0 = _t.perf_counter()
+    pages = S.make_pages(args.val_graph, in_feats=args.in_feats, first_id=10_000_000)
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    n = int(off[-1])
+    g = gte.PageGraph(src, dst, n, device=dev)
+    g.ndata["feat"] = torch.from_numpy(feat).to(dev)
+    g.edata["feat"] = torch.from_numpy(w).to(dev)
+    build_s = _t.perf_counter() - t0
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        for _ in range(3):
+            logits = model(g)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        s.record()
+        for _ in range(reps):
+            logits = model(g)
+        e.record()
+        torch.cuda.synchronize()
+    model.train(was_training)
+    ms = s.elapsed_time(e) / reps
+    return {"workload": f"val graph: {args.val_graph} pages in one graph, forward only (eval, no_grad), F0={args.in_feats}",
+            "nodes": n, "edges": int(len(src)), "ms_per_forward": ms, "nodes_per_s": n / (ms * 1e-3),
+            "host_build_s": build_s, "logits_finite": bool(torch.isfinite(logits).all())}
 
 
 def gather_probe(args, gte, S, dev):
@@ -288,6 +323,8 @@ def main():
         }
         if world == 1 and not args.no_gather_probe:
             line["gather"] = gather_probe(args, gte, S, dev)
+        if world == 1 and args.val_graph > 0:
+            line["val_graph"] = val_graph_probe(args, gte, S, model, dev)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args, batches[0][2], state0)
             line["cpu_baseline"] = cb

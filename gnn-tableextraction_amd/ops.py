@@ -449,7 +449,42 @@ def sage_layer(graph, h, weight, bias=None, gamma=None, beta=None, edge_weight=N
     if (gamma is None and not relu and not use_pp and bias is not None and h.dim() == 2
             and _lib.load().gte_sage_narrow_supported(h.shape[1], weight.shape[0])):
         return _NarrowSageLayer.apply(h, weight, bias, graph, edge_weight)
+    if (not use_pp and gamma is not None and bias is not None and h.dim() == 2 and h.shape[1] > weight.shape[0]
+            and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (h, weight, bias, gamma, beta)))):
+        y = _sage_layer_transform_first(graph, h, weight, bias, gamma, beta, edge_weight, relu, eps)
+        if y is not None:
+            return y
     return _SageLayer.apply(h, weight, bias, gamma, beta, graph, edge_weight, relu, eps, use_pp)
+
+
+def _sage_layer_transform_first(graph, h, weight, bias, gamma, beta, edge_weight, relu, eps):
+    """Inference-only forward of a narrowing layer (831 -> 256) in transform-then-aggregate order:
+    z = h W_s^T + b + mean-aggregate(h W_n^T) -- the aggregation moves out_feats columns instead of in_feats --
+    with LayerNorm(+ReLU) in the aggregation's epilogue.  Same math as models.py:53-72 by linearity (the step engine
+    trains this way too); used when nothing requires grad (eval / predict).  None -> caller takes the general path."""
+    lib = _lib.load()
+    h = _row_major(h)
+    n, fin = h.shape
+    fout = weight.shape[0]
+    if h.dtype != torch.float32:
+        return None
+    t = torch.empty((n, 2 * fout), dtype=torch.float32, device=h.device)
+    check(lib.gte_sage_transform_fwd(ptr(h), _ld(h), fin, ptr(weight), _ld(weight), ptr(bias), fout, ptr(t), 2 * fout, n,
+                                     current_stream()), "gte_sage_transform_fwd")
+    csr = graph.in_csr()
+    w = graph.in_weights(edge_weight)
+    y = torch.empty((n, fout), dtype=torch.float32, device=h.device)
+    if lib.gte_spmm_csr_accumulate_ln_supported(fout) and not use_tiled(n, fout):
+        check(lib.gte_spmm_csr_accumulate_ln(ptr(csr.indptr), ptr(csr.indices), ptr(w), ptr(t) + 4 * fout, 2 * fout, ptr(t),
+                                             2 * fout, n, fout, _lib.REDUCE_MEAN, ptr(gamma), ptr(beta), float(eps), int(relu),
+                                             ptr(y), fout, None, current_stream()), "gte_spmm_csr_accumulate_ln")
+        return y
+    # large graphs: LDS-staged aggregation (no LayerNorm epilogue there), then LayerNorm
+    spmm_csr(csr.indptr, csr.indices, w, t[:, fout:], n, mean=True, out=t[:, :fout], accumulate=True,
+             tiles=graph.in_tiles() if use_tiled(n, fout) else None)
+    check(lib.gte_ln_relu_fwd(ptr(t), 2 * fout, ptr(gamma), ptr(beta), float(eps), int(relu), ptr(y), fout, None, n, fout,
+                              current_stream()), "gte_ln_relu_fwd")
+    return y
 
 
 class _WeightedCE(torch.autograd.Function):
