@@ -14,7 +14,7 @@
 //   3. reduces every destination row from LDS (ds_read_b128, an 8-lane group reads one 128-B row) in CSR
 //      order -- same summation order as the plain kernel, bit-identical result,
 //   4. writes the 128-B output segments.
-// 19.5 KB of LDS per workgroup -> 8 workgroups (32 waves) per CU; occupancy, not traffic, is what the
+// 20 KB of LDS per workgroup -> 8 workgroups (32 waves) per CU; occupancy, not traffic, is what the
 // chunk width trades against (see FC below).  HBM-side traffic measured with rocprofv3 on cfg4:
 // 2.38 GB fetched + 2.0 GB written = 4.4 GB for 4.2 GB of algorithmic bytes (plain kernel: 10.7 GB).
 // The distinct-source lists are graph structure, built once per (batched) graph next to the CSR
@@ -28,12 +28,14 @@ namespace {
 
 constexpr int TILE_R = 32;        // destination rows per tile  (must match the host-side plan)
 constexpr int UMAX = 128;         // distinct source rows staged per tile
-constexpr int EMAX = 512;         // edges of a tile kept in LDS (32 rows x up to 16 in-edges)
+constexpr int EMAX = 448;         // edges of a tile kept in LDS (32 rows x up to 14 in-edges): 8-byte {weight, local index} entries
 #ifndef GTE_TILED_FC
 #define GTE_TILED_FC 32
 #endif
 constexpr int FC = GTE_TILED_FC;  // floats per feature chunk: 32 = one 128-B line per row and 8 workgroups per CU
-                                  // (measured on cfg4: FC 32 -> 3.97 TB/s, 64 -> 3.2-3.4, 128 -> 2.4; double-buffered LDS 3.0)
+                                  // (measured on cfg4: FC 32 -> 3.97 TB/s, 64 -> 3.2-3.4, 128 -> 2.4; double-buffered LDS 3.0;
+                                  //  64-row tiles (136 distinct sources instead of 2 x 84, 5 workgroups per CU) -> 3.55;
+                                  //  {weight, local index} packed into one 8-byte LDS entry: 3.90 -> 4.08)
 constexpr int LPR = FC / 4;       // lanes per staged row (16-byte pieces)
 constexpr int GPW = 64 / LPR;     // row groups per wave
 
@@ -64,8 +66,8 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
 #else
     __shared__ __attribute__((aligned(16))) float s_rows_all[UMAX * FC];       // staged source rows (one chunk)
 #endif
-    __shared__ float s_w[EMAX];
-    __shared__ uint16_t s_li[EMAX];
+    struct Edge { float w; int li; };                          // one ds_read_b64 per edge (two reads with separate arrays)
+    __shared__ __attribute__((aligned(8))) Edge s_e[EMAX];
     __shared__ int s_usrc[UMAX];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -80,7 +82,7 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
     const bool staged = (nu <= UMAX) && (ne <= EMAX);          // block-uniform
 
     if (staged) {
-        for (int i = tid; i < ne; i += 256) { s_li[i] = lidx[e0 + i]; s_w[i] = ew ? ew[e0 + i] : 1.0f; }
+        for (int i = tid; i < ne; i += 256) { s_e[i].li = lidx[e0 + i]; s_e[i].w = ew ? ew[e0 + i] : 1.0f; }
         for (int i = tid; i < nu; i += 256) s_usrc[i] = tile_src[u0 + i];
     }
     __syncthreads();
@@ -129,17 +131,19 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
                     int e = lo - e0;
                     const int eh = hi - e0;
                     for (; e + 1 < eh; e += 2) {             // two LDS rows in flight
-                        const float w0 = s_w[e], w1 = s_w[e + 1];
-                        const float4 a = *reinterpret_cast<const float4*>(&s_rows[(int)s_li[e] * FC + l16 * 4]);
-                        const float4 b = *reinterpret_cast<const float4*>(&s_rows[(int)s_li[e + 1] * FC + l16 * 4]);
+                        const Edge ea = s_e[e], eb = s_e[e + 1];
+                        const float w0 = ea.w, w1 = eb.w;
+                        const float4 a = *reinterpret_cast<const float4*>(&s_rows[ea.li * FC + l16 * 4]);
+                        const float4 b = *reinterpret_cast<const float4*>(&s_rows[eb.li * FC + l16 * 4]);
                         acc.x = fmaf(w0, a.x, acc.x); acc.y = fmaf(w0, a.y, acc.y);
                         acc.z = fmaf(w0, a.z, acc.z); acc.w = fmaf(w0, a.w, acc.w);
                         acc.x = fmaf(w1, b.x, acc.x); acc.y = fmaf(w1, b.y, acc.y);
                         acc.z = fmaf(w1, b.z, acc.z); acc.w = fmaf(w1, b.w, acc.w);
                     }
                     if (e < eh) {
-                        const float w0 = s_w[e];
-                        const float4 a = *reinterpret_cast<const float4*>(&s_rows[(int)s_li[e] * FC + l16 * 4]);
+                        const Edge ea = s_e[e];
+                        const float w0 = ea.w;
+                        const float4 a = *reinterpret_cast<const float4*>(&s_rows[ea.li * FC + l16 * 4]);
                         acc.x = fmaf(w0, a.x, acc.x); acc.y = fmaf(w0, a.y, acc.y);
                         acc.z = fmaf(w0, a.z, acc.z); acc.w = fmaf(w0, a.w, acc.w);
                     }
