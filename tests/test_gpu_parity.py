@@ -255,6 +255,37 @@ def test_gemm_tail_split_matches_unsplit_and_float64(ta, tb, m, n, k):
     np.testing.assert_allclose(plain.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
 
 
+def test_gemm_tail_split_keeps_the_epilogue_semantics():
+    """bias (whole / first N segment only) and ReLU are applied by the fix-up launch exactly as by the GEMM epilogue."""
+    lib = gte._lib.load()
+    P, cs, check = gte._lib.ptr, gte._lib.current_stream, gte._lib.check
+    rng = np.random.default_rng(7)
+    m, k, n_out = 128 * 264 - 3, 256, 128                    # 264 row tiles: the last 8 tiles split over the idle CUs
+    a1, a2 = dev(rng.standard_normal((m, k)).astype(np.float32)), dev(rng.standard_normal((m, k)).astype(np.float32))
+    w = dev((rng.standard_normal((n_out, 2 * k)) / np.sqrt(2 * k)).astype(np.float32))
+    b = dev(rng.standard_normal(n_out).astype(np.float32))
+    ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=DEV)
+
+    def run(split):
+        check(lib.gte_gemm_set_tail_workspace(P(ws) if split else None, ws.numel() if split else 0), "set")
+        try:
+            y, _, _ = ops.sage_linear_fwd(a1, a2, w, b, None, None, 1e-5, True, False)          # bias + ReLU, no LayerNorm
+            t = torch.empty(m, 2 * n_out, device=DEV)
+            check(lib.gte_sage_transform_fwd(P(a1), k, k, P(w), 2 * k, P(b), n_out, P(t), 2 * n_out, m, cs()), "transform")
+        finally:
+            lib.gte_gemm_set_tail_workspace(None, 0)
+        return y, t
+    y0, t0 = run(False)
+    y1, t1 = run(True)
+    want_y = torch.relu(torch.cat([a1, a2], 1).double().cpu() @ w.double().cpu().T + b.double().cpu())
+    want_t = torch.cat([a1.double().cpu() @ w.double().cpu()[:, :k].T + b.double().cpu(), a1.double().cpu() @ w.double().cpu()[:, k:].T], 1)
+    for got in (y0, y1):
+        np.testing.assert_allclose(got.cpu().numpy(), want_y.numpy(), rtol=1e-5, atol=1e-5)
+    for got in (t0, t1):
+        np.testing.assert_allclose(got.cpu().numpy(), want_t.numpy(), rtol=1e-5, atol=1e-5)
+    assert not torch.equal(y0, y1)                           # the split path ran (different summation order in the tail tiles)
+
+
 @pytest.mark.parametrize("n,f,o", [(1000, 831, 256), (513, 256, 256), (300, 13, 40), (77, 50, 33), (5, 3, 2), (24495, 831, 256)])
 def test_qform_entry_points_vs_float64(n, f, o):
     """gte_sage_transform_fwd / gte_sage_qform_dw / gte_sage_qform_dx (transform-then-aggregate form of a layer)
