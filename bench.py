@@ -221,12 +221,20 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    # Test hook for 1-GPU boxes (GTE_BENCH_SHARE_GPU=1): every rank uses cuda:0 and the ranks talk over gloo (RCCL refuses two
+    # ranks on one device) -- exercises the N > 1 code path of this file, not a measurement.
+    share_gpu = os.environ.get("GTE_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     import gnn_tableextraction_amd as gte
     from gnn_tableextraction_amd import ops
