@@ -120,6 +120,12 @@ class FusedGcnSageStep(TrainStep):
         for p in (q for q in model.parameters() if q.requires_grad):
             self._gslice[id(p)] = self.flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
+        # data-parallel overlap: the flat gradient is [layer 0 | layers 1..]; the upper slice is all-reduced while layer 0's
+        # backward (the longest: its dW GEMM alone is a quarter of the step) still runs.  GTE_DP_OVERLAP=0: one all-reduce.
+        self._n0 = sum(p.numel() for p in model.layers[0].parameters() if p.requires_grad)
+        first_upper = next((p for p in model.layers[1].parameters() if p.requires_grad), None) if len(model.layers) > 1 else None
+        self._dp_split = (os.environ.get("GTE_DP_OVERLAP", "1") == "1" and first_upper is not None
+                          and self._gslice[id(first_upper)].storage_offset() == self._n0)
         self._bufs = {}
         self._graph_bufs = {}
         self._private_key = None
@@ -236,7 +242,17 @@ class FusedGcnSageStep(TrainStep):
         return self._transform_first(layer, fin) or (self.transform_first and i > 0 and layer.out_feats <= fin)
 
     # -- the schedule ----------------------------------------------------------------------------------
-    def forward_backward(self, g, labels: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:
+    def forward_backward(self, g, labels: torch.Tensor, grad_scale: float = 1.0, upto_layer: int = 0) -> torch.Tensor:
+        """Forward, loss and the backward of layers n_layers-1 .. upto_layer (gradients of those layers final on return:
+        their folds are flushed).  upto_layer > 0 leaves the rest to :meth:`backward_rest` -- the data-parallel step
+        all-reduces the upper layers' gradient slice while the (longest) backward of layer 0 runs."""
+        return self._run(g, labels, grad_scale, len(self.model.layers) - 1, upto_layer, forward=True)
+
+    def backward_rest(self, g, from_layer: int) -> None:
+        """Backward of layers from_layer-1 .. 0 after ``forward_backward(..., upto_layer=from_layer)`` on the same batch."""
+        self._run(g, None, 1.0, from_layer - 1, 0, forward=False)
+
+    def _run(self, g, labels, grad_scale, hi, lo, forward):
         lib, P, check = self.lib, _lib.ptr, _lib.check
         st = _lib.current_stream()
         timed = ops._timed
@@ -274,12 +290,23 @@ class FusedGcnSageStep(TrainStep):
         check(lib.gte_gemm_set_tail_workspace(P(self._tail_ws) if self.tail_split else None,
                                               self._tail_ws.numel() if self.tail_split else 0), "gte_gemm_set_tail_workspace")
         try:
-            return self._forward_backward(g, labels, grad_scale, x, n, f0, b, layers, csr, rcsr, w_in, w_out, t_in, t_out,
-                                          aggregate, st)
+            if forward:
+                self._forward_loss(g, labels, grad_scale, x, n, f0, b, layers, csr, w_in, t_in, aggregate, st)
+                self._ln_done = None
+            # ---------------- backward of layers hi .. lo ----------------
+            side_used = False
+            check(lib.gte_fold_defer_begin(st), "gte_fold_defer_begin")
+            try:
+                side_used = self._backward(g, b, layers, x, n, aggregate, rcsr, w_out, t_out, st, hi, lo)
+            finally:
+                if side_used:
+                    torch.cuda.current_stream().wait_stream(self._side)  # join: the folds / Adam / all-reduce need every dW
+                check(lib.gte_fold_defer_flush(), "gte_fold_defer_flush")
+            return b["out3"]
         finally:
             lib.gte_gemm_set_tail_workspace(None, 0)
 
-    def _forward_backward(self, g, labels, grad_scale, x, n, f0, b, layers, csr, rcsr, w_in, w_out, t_in, t_out, aggregate, st):
+    def _forward_loss(self, g, labels, grad_scale, x, n, f0, b, layers, csr, w_in, t_in, aggregate, st):
         lib, P, check = self.lib, _lib.ptr, _lib.check
         timed, ld = ops._timed, ops._ld
         ws, wsn = P(b["ws"]), b["ws"].numel()
@@ -352,24 +379,12 @@ class FusedGcnSageStep(TrainStep):
                                       P(self.class_weights), n, logits.shape[1], float(grad_scale), P(dl), dl.shape[1],
                                       P(b["out3"]), ws, wsn, st), "gte_weighted_ce")
 
-        # ---------------- backward ----------------
-        side_used = False
-        check(lib.gte_fold_defer_begin(st), "gte_fold_defer_begin")
-        try:
-            side_used = self._backward(g, b, layers, x, n, aggregate, rcsr, w_out, t_out, st)
-        finally:
-            if side_used:
-                torch.cuda.current_stream().wait_stream(self._side)      # join: the folds / Adam / all-reduce need every dW
-            check(lib.gte_fold_defer_flush(), "gte_fold_defer_flush")
-        return b["out3"]
-
-    def _backward(self, g, b, layers, x, n, aggregate, rcsr, w_out, t_out, st) -> bool:
+    def _backward(self, g, b, layers, x, n, aggregate, rcsr, w_out, t_out, st, hi, lo) -> bool:
         lib, P, check = self.lib, _lib.ptr, _lib.check
         timed, ld = ops._timed, ops._ld
         ws, wsn = P(b["ws"]), b["ws"].numel()
         side_used = False
-        self._ln_done = None
-        for i in range(len(layers) - 1, -1, -1):
+        for i in range(hi, lo - 1, -1):
             L = layers[i]
             hin = x if i == 0 else b["y"][i - 1]
             fin, fout = hin.shape[1], L.out_feats
@@ -468,13 +483,25 @@ class FusedGcnSageStep(TrainStep):
 
     def step(self, g, labels: torch.Tensor, n_global: Optional[int] = None) -> torch.Tensor:
         scale = float(labels.shape[0]) / float(n_global) if (self.distributed and n_global) else 1.0
-        out3 = self.forward_backward(g, labels, scale)
-        if self.distributed:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self.distributed and self._dp_split:
+            out3 = self.forward_backward(g, labels, scale, upto_layer=1)
+            pending = [self._all_reduce_async(self.flat_grad[self._n0:])]    # layers 1.. : in flight under layer 0's backward
+            self.backward_rest(g, 1)
+            pending.append(self._all_reduce_async(self.flat_grad[:self._n0]))
+            for w in pending:
+                w.wait()
+        else:
+            out3 = self.forward_backward(g, labels, scale)
+            if self.distributed:
+                import torch.distributed as dist
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         self.t += 1
         self._optimizer_step()
         return out3
+
+    def _all_reduce_async(self, t):
+        import torch.distributed as dist
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     # -- optimiser: hyper-parameters and step count live on the device, so the launch is graph-capturable ----------
     def _adam_host_state(self, t_next: int):
@@ -542,11 +569,16 @@ class FusedGcnSageStep(TrainStep):
         torch.cuda.synchronize()
         self._adam_state()
         in_graph_adam = not self.distributed          # the all-reduce sits between backward and Adam, eagerly
+        split = self.distributed and self._dp_split
         graph = torch.cuda.CUDAGraph()
+        graph_b = torch.cuda.CUDAGraph() if split else None
         with torch.cuda.graph(graph):
-            out3 = self.forward_backward(g, labels, scale)
+            out3 = self.forward_backward(g, labels, scale, upto_layer=1 if split else 0)
             if in_graph_adam:
                 self._adam_dev_launch()               # reads lr / step count from device memory at replay time
+        if split:                                     # layer 0's backward: replayed while the upper slice is all-reduced
+            with torch.cuda.graph(graph_b, pool=graph.pool()):
+                self.backward_rest(g, 1)
         if in_graph_adam:
             self._step_dev_host -= 1                  # capturing did not run it
 
@@ -558,10 +590,17 @@ class FusedGcnSageStep(TrainStep):
                 self._step_dev_host += 1
                 return out3
             graph.replay()
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            if split:
+                pending = [self._all_reduce_async(self.flat_grad[self._n0:])]
+                graph_b.replay()
+                pending.append(self._all_reduce_async(self.flat_grad[:self._n0]))
+                for w in pending:
+                    w.wait()
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.t += 1
             self._optimizer_step()
             return out3
-        self._graphs[key] = graph
+        self._graphs[key] = (graph, graph_b)
         return replay
