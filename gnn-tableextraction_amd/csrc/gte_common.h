@@ -56,3 +56,27 @@ __device__ __forceinline__ unsigned gte_xcd_remap(unsigned bid, unsigned nblocks
     const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + bid / gte::kNumXcd;
 }
+
+// ---- lane-group sums on DPP modifiers (device) ------------------------------------------------------------------
+// Inside a row of 16 lanes the butterfly runs on DPP controls: xor 1 / xor 2 as quad permutes; once quads / octets are
+// uniform, the half-row and row mirrors act as xor 4 / xor 8.  Four VALU adds, no LDS-pipe instruction -- __shfl_xor
+// compiles to ds_bpermute_b32, one LDS round trip per level.  Result in every lane of the group.
+#define GTE_DPP_ADD(v, ctrl) \
+    (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
+
+template <int G>                       // G = 2 .. 64 lanes per group, power of two, groups aligned to G
+__device__ __forceinline__ float gte_group_sum(float v) {
+    if constexpr (G >= 2) GTE_DPP_ADD(v, 0xB1);          // quad_perm [1,0,3,2]: lane ^ 1
+    if constexpr (G >= 4) GTE_DPP_ADD(v, 0x4E);          // quad_perm [2,3,0,1]: lane ^ 2
+    if constexpr (G >= 8) GTE_DPP_ADD(v, 0x141);         // row_half_mirror (quads uniform: == lane ^ 4)
+    if constexpr (G >= 16) GTE_DPP_ADD(v, 0x140);        // row_mirror (octets uniform: == lane ^ 8)
+    if constexpr (G == 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (G == 64) {                             // four row sums through the scalar unit
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+        v = (r0 + r1) + (r2 + r3);
+    }
+    return v;
+}

@@ -798,11 +798,7 @@ int64_t gemm_workspace(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nse
 // variance, eps inside the sqrt: torch.nn.LayerNorm).  In place (y == z) is allowed.
 constexpr int LN_CACHE = 16;      // elements per lane kept in registers -> rows up to 1024 wide
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return gte_group_sum<64>(v); }
 
 __device__ __forceinline__ float ln_affine(float xhat, float g, float b) { return fmaf(xhat, g, b); }
 

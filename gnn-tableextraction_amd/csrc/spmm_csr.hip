@@ -85,11 +85,7 @@ struct LnEpilogue {
 };
 
 template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
-    return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return gte_group_sum<G>(v); }
 
 template <typename T, int G, int CPL, bool ACCUM, bool LNE = false>
 __global__ void __launch_bounds__(256)
