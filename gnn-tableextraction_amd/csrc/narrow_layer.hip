@@ -390,12 +390,10 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                     pb[r] = fmaf(d0, xh0[r], d1 * xh1[r]);
                 }
 #pragma unroll
-                for (int off = 16; off > 0; off >>= 1)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        pa[r] += __shfl_xor(pa[r], off, 32);
-                        pb[r] += __shfl_xor(pb[r], off, 32);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    pa[r] = gte_group_sum<32>(pa[r]);
+                    pb[r] = gte_group_sum<32>(pb[r]);
+                }
                 if (i == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
