@@ -80,3 +80,14 @@ __device__ __forceinline__ float gte_group_sum(float v) {
     }
     return v;
 }
+
+// value of lane T of every quad, in all four lanes of the quad (DPP quad_perm broadcast; T is a compile-time constant)
+template <int T>
+__device__ __forceinline__ int gte_quad_bcast(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, T | (T << 2) | (T << 4) | (T << 6), 0xf, 0xf, true);
+}
+template <int T>
+__device__ __forceinline__ float gte_quad_bcast(float v) {
+    return __builtin_bit_cast(float, gte_quad_bcast<T>(__builtin_bit_cast(int, v)));
+}
+

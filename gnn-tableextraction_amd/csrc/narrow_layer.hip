@@ -523,15 +523,16 @@ head_agg_ce_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict
         int my_u = 0;
         float my_w = 0.f;
         if (my_e < hi) { my_u = indices[my_e]; my_w = ew ? ew[my_e] : 1.0f; }
-        const int cnt = min(4, hi - eb);
         float v[4][4];
         float w[4];
+        // lanes past the end of the row hold (source 0, weight 0): a valid address whose contribution is + 0 * x.
+        // Quad broadcasts on DPP (a __shfl is a ds_bpermute: an LDS round trip per edge in the dependent chain)
+        int u[4];
+        u[0] = gte_quad_bcast<0>(my_u); u[1] = gte_quad_bcast<1>(my_u); u[2] = gte_quad_bcast<2>(my_u); u[3] = gte_quad_bcast<3>(my_u);
+        w[0] = gte_quad_bcast<0>(my_w); w[1] = gte_quad_bcast<1>(my_w); w[2] = gte_quad_bcast<2>(my_w); w[3] = gte_quad_bcast<3>(my_w);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int tt = min(t, cnt - 1);
-            const int u = __shfl(my_u, tt, 4);
-            w[t] = t < cnt ? __shfl(my_w, tt, 4) : 0.f;
-            const float* xr = t_neigh + (int64_t)u * ldn;
+            const float* xr = t_neigh + (int64_t)u[t] * ldn;
 #pragma unroll
             for (int m = 0; m < 4; ++m) v[t][m] = (li + 4 * m < C) ? xr[li + 4 * m] : 0.f;
         }
@@ -553,8 +554,8 @@ head_agg_ce_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict
             zmax = fmaxf(zmax, z[m]);
         }
     }
-    zmax = fmaxf(zmax, __shfl_xor(zmax, 1, 4));
-    zmax = fmaxf(zmax, __shfl_xor(zmax, 2, 4));
+    zmax = fmaxf(zmax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zmax), 0xB1, 0xf, 0xf, true)));
+    zmax = fmaxf(zmax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zmax), 0x4E, 0xf, 0xf, true)));
     int arg = 1 << 20;                                       // first column holding the maximum (torch.argmax)
     float se = 0.f;
 #pragma unroll
@@ -565,18 +566,16 @@ head_agg_ce_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict
             se += expf(z[m] - zmax);
         }
     }
-    arg = min(arg, __shfl_xor(arg, 1, 4));
-    arg = min(arg, __shfl_xor(arg, 2, 4));
-    se += __shfl_xor(se, 1, 4);
-    se += __shfl_xor(se, 2, 4);
+    arg = min(arg, __builtin_amdgcn_update_dpp(0, arg, 0xB1, 0xf, 0xf, true));
+    arg = min(arg, __builtin_amdgcn_update_dpp(0, arg, 0x4E, 0xf, 0xf, true));
+    se = gte_group_sum<4>(se);
     const int y = row_ok ? gte_ce::label_of(labels, r) : -1;
     const bool yok = row_ok && y >= 0 && y < C;
     const float wy = yok ? (cw ? cw[y] : 1.0f) : 0.f;
     float zy = 0.f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) if (yok && li + 4 * m == y) zy = z[m];
-    zy += __shfl_xor(zy, 1, 4);
-    zy += __shfl_xor(zy, 2, 4);
+    zy = gte_group_sum<4>(zy);
     if (row_ok && dl) {
         const float inv = 1.0f / se;
         float* drow = dl + (int64_t)r * lddl;

@@ -134,12 +134,20 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                 for (int t = 0; t < cnt; t += kEdgeUnroll) {
                     int u[kEdgeUnroll];
                     float w[kEdgeUnroll];
+                    if constexpr (G == 4 && kEdgeUnroll == 4) {
+                        // one quad per row: DPP quad broadcasts (lanes past the row end hold source 0 / weight 0)
+                        u[0] = gte_quad_bcast<0>(my_u); u[1] = gte_quad_bcast<1>(my_u);
+                        u[2] = gte_quad_bcast<2>(my_u); u[3] = gte_quad_bcast<3>(my_u);
+                        w[0] = gte_quad_bcast<0>(my_w); w[1] = gte_quad_bcast<1>(my_w);
+                        w[2] = gte_quad_bcast<2>(my_w); w[3] = gte_quad_bcast<3>(my_w);
+                    } else {
 #pragma unroll
                     for (int k = 0; k < kEdgeUnroll; ++k) {
                         // past the end of the row: re-use the last valid source (cache hit) with w = 0
                         const int tt = min(t + k, cnt - 1);
                         u[k] = __shfl(my_u, tt, G);
                         w[k] = (t + k < cnt) ? __shfl(my_w, tt, G) : 0.f;
+                    }
                     }
                     float v[kEdgeUnroll][CPL][EPC];
                     float tv[kEdgeUnroll];
