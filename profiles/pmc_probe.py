@@ -1,4 +1,4 @@
-"""Run ONE kernel shape a few times (for rocprofv3 --pmc passes).  usage: python3 profiles/pmc_probe.py <nt|tn|nn|spmm|lnbwd> [reps]"""
+"""Run ONE kernel shape a few times (for rocprofv3 --pmc passes).  usage: python3 profiles/pmc_probe.py <nt|tn|nn|spmm|spmm256> [reps]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,6 +28,15 @@ elif what == "spmm":
     x = torch.randn(n, f, device=dev); out = torch.empty_like(x)
     plan = ops.build_tile_plan(indptr, indices, n) if os.environ.get("GTE_TILED", "1") == "1" else None
     fn = lambda: ops.spmm_csr(indptr, indices, wout, x, n, mean=True, out=out, tiles=plan, force_tiled=True)
+if what == "spmm256":                      # the 256-wide aggregation of a cfg2 batch (L2-resident regime)
+    from gnn_tableextraction_amd.data import synthetic as S
+    pages = S.make_pages(100, in_feats=13)
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    N = int(off[-1])
+    graph = gte.PageGraph(src, dst, N, device=dev)
+    csr = graph.in_csr(); wt = graph.in_weights(torch.from_numpy(w).to(dev))
+    x = torch.randn(N, 256, device=dev); out = torch.empty_like(x)
+    fn = lambda: ops.spmm_csr(csr.indptr, csr.indices, wt, x, N, mean=True, out=out)
 for _ in range(reps):
     fn()
 torch.cuda.synchronize()
