@@ -281,9 +281,6 @@ class FusedGcnSageStep(TrainStep):
                 with timed("spmm_csr", nbytes):
                     check(fn(P(csr_.indptr), P(csr_.indices), P(w_), PP(src), ldsrc, PP(dst), lddst, n, f, _lib.GTE_F32,
                              reduce, st), "gte_spmm_csr")
-        ws, wsn = P(b["ws"]), b["ws"].numel()
-        ld = ops._ld
-
         # scratch for the GEMM tail split (see gte_gemm_set_tail_workspace): registered for this launch sequence only
         if self._tail_ws is None:
             self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=x.device)
