@@ -638,7 +638,7 @@ bool needs_small_path(bool ak, bool bkc, const GemmParams& p) {
     return a_run < 4 || b_run < 4;
 }
 
-struct Plan { int bm, bn, tiles, splits, tiles_per_split; };
+struct Plan { int bm, bn, tiles, splits, tiles_per_split, splits_bound; };
 
 Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
     Plan pl;
@@ -689,6 +689,10 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
     }
     pl.tiles_per_split = (int)gte::ceil_div(ktiles, splits);
     pl.splits = (int)gte::ceil_div(ktiles, pl.tiles_per_split);
+    // pl.splits <= splits, and `splits` never shrinks when K grows (the tile shape of a split-K plan does not depend on
+    // K): the bound a workspace query may use for "any K up to this one".  pl.splits itself is NOT monotonic in K
+    // (896 K tiles -> 35 splits, 846 -> 36): sizing a workspace from the capacity's exact plan came out 2.8 % short.
+    pl.splits_bound = splits;
     return pl;
 }
 
@@ -790,7 +794,7 @@ int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace
 int64_t gemm_workspace(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
     if (M <= 0 || N <= 0) return 256;
     const Plan pl = make_plan(M, N, K1, K2, Nseg);
-    return pl.splits > 1 ? gte::round_up((int64_t)pl.splits * M * N * 4, 256) : 256;
+    return pl.splits_bound > 1 ? gte::round_up((int64_t)pl.splits_bound * M * N * 4, 256) : 256;
 }
 
 // ------------------------------- LayerNorm + ReLU, forward ----------------------------------------

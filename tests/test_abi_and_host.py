@@ -46,6 +46,27 @@ def test_bad_arguments_return_error_codes_not_crashes():
         _lib.check(rc, "probe")
 
 
+def test_workspace_queries_cover_every_smaller_node_count():
+    """The step engine sizes its workspaces ONCE for a node capacity and runs any batch up to it: every workspace query
+    must be non-decreasing in the node count.  (The split-K slab count of a plan is not -- 896 K tiles give 35 splits,
+    846 give 36 -- so the queries answer with the plan's monotonic bound; a 64-wide hidden layer once came out 2.8 % short.)"""
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    queries = [
+        lambda n: lib.gte_sage_qform_dw_workspace_bytes(64, 831, n), lambda n: lib.gte_sage_qform_dw_workspace_bytes(256, 831, n),
+        lambda n: lib.gte_sage_qform_dw_workspace_bytes(256, 256, n), lambda n: lib.gte_sage_qform_dw_workspace_bytes(1000, 831, n),
+        lambda n: lib.gte_sage_linear_dw_workspace_bytes(256, 831, 831, n), lambda n: lib.gte_sage_linear_dw_workspace_bytes(64, 13, 13, n),
+        lambda n: lib.gte_gemm_workspace_bytes(256, 831, n), lambda n: lib.gte_gemm_workspace_bytes(9, 256, n),
+        lambda n: lib.gte_ln_relu_bwd_workspace_bytes(n, 256), lambda n: lib.gte_weighted_ce_workspace_bytes(n),
+        lambda n: lib.gte_sage_narrow_bwd_workspace_bytes(n, 256, 9), lambda n: lib.gte_head_agg_ce_workspace_bytes(n),
+        lambda n: lib.gte_sage_narrow_bwd_ln_workspace_bytes(n, 256),
+    ]
+    sizes = sorted(set(rng.integers(1, 120_000, 400).tolist() + [1, 31, 32, 33, 27060, 28672, 100_000]))
+    for q in queries:
+        vals = [q(n) for n in sizes]
+        assert all(a <= b for a, b in zip(vals, vals[1:])), [(n, v) for n, v in zip(sizes, vals)][:5]
+
+
 def test_no_cpu_fallback():
     g = G.PageGraph([0, 1], [1, 0], 2)
     g.ndata["h"] = torch.ones(2, 4)
