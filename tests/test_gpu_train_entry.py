@@ -73,3 +73,46 @@ def test_train_writes_reference_layout_and_learns(tmp_path):
     b = model_predict.test(data, cfg2, weights_path=w, save_predictions=False)
     for pa, pb in zip(a["all_pred"], b["all_pred"]):
         np.testing.assert_array_equal(pa, pb)                           # batching pages does not change predictions
+
+
+@pytest.mark.parametrize("seed", list(range(14)))
+def test_fused_step_equals_autograd_path_on_random_shapes(seed):
+    """Randomised cross-check of the hand-scheduled step engine (transform-first / q-form / narrow MFMA layer / fused head /
+    deferred folds / GEMM tail split / split-K) against the autograd path (`model(g)` + `loss.backward()`), which takes none
+    of those routes: same loss, same gradient, over random feature widths, hidden sizes, depths and batch sizes."""
+    import numpy as np
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import graph as G
+    from gnn_tableextraction_amd.data import synthetic as S
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep, TrainStep
+    rng = np.random.default_rng(1000 + seed)
+    f0 = int(rng.choice([3, 13, 50, 63, 64, 313, 363, 831]))
+    hid = int(rng.choice([8, 24, 64, 96, 128, 200, 256, 384]))
+    layers = int(rng.integers(2, 6))
+    pages = int(rng.choice([1, 2, 5, 17, 60]))
+    weighted = bool(rng.integers(0, 2))
+    dev = "cuda:0"
+    pg = S.make_pages(pages, in_feats=f0, first_id=7000 + 100 * seed)
+    src, dst, w, feat, label, off = S.concat_pages(pg)
+
+    def fresh():
+        torch.manual_seed(seed)
+        m = gte.GcnSAGE(f0, hid, 9, layers, torch.nn.functional.relu, 0).to(dev)
+        g = G.PageGraph(src, dst, int(off[-1]), device=dev)
+        g.ndata["feat"], g.edata["feat"] = torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev)
+        return m, g
+    cw = torch.from_numpy(rng.random(9).astype(np.float32) + 0.5).to(dev) if weighted else None
+    y = torch.from_numpy(label).to(dev)
+    ma, ga = fresh()
+    mb, gb = fresh()
+    fused = FusedGcnSageStep(ma, lr=0.01, weight_decay=5e-4, class_weights=cw)
+    auto = TrainStep(mb, lr=0.01, weight_decay=5e-4, class_weights=cw)
+    out_f = fused.forward_backward(ga, y)
+    auto.model.train()
+    auto.flat_grad.zero_()
+    loss, out_a = auto._loss(auto.model(gb), y)
+    loss.backward()
+    assert abs(float(out_f[0]) - float(out_a[0])) < 2e-5 * max(1.0, abs(float(out_a[0])))
+    assert float(out_f[2]) == float(out_a[2])                      # same arg-max decisions
+    gf, gr = fused.flat_grad.cpu().numpy(), auto.flat_grad.cpu().numpy()
+    np.testing.assert_allclose(gf, gr, rtol=2e-3, atol=2e-5 * np.abs(gr).max() + 1e-9)
