@@ -109,7 +109,19 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
         const int r = rbase + sub;
         const bool row_ok = r < row_end;
         int lo = 0, hi = 0;
-        if (row_ok) { lo = indptr[r]; hi = indptr[r + 1]; }
+        if constexpr (RPW <= 4) {
+            // few rows per wave: their indptr pairs through the scalar cache (uniform addresses -> s_load), the first link
+            // of the row's dependent chain indptr -> edge list -> source rows
+            const int rb_u = __builtin_amdgcn_readfirstlane(rbase);
+#pragma unroll
+            for (int s2 = 0; s2 < RPW; ++s2) {
+                int l = 0, h = 0;
+                if (rb_u + s2 < row_end) { l = indptr[rb_u + s2]; h = indptr[rb_u + s2 + 1]; }
+                if (sub == s2) { lo = l; hi = h; }
+            }
+        } else {
+            if (row_ok) { lo = indptr[r]; hi = indptr[r + 1]; }
+        }
         const float scale = (reduce == GTE_REDUCE_MEAN) ? (hi > lo ? 1.0f / (float)(hi - lo) : 0.0f) : 1.0f;
 
         for (int cb = 0; cb < nchunk || (cb == 0 && rem); cb += G * CPL) {
