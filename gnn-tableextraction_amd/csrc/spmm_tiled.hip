@@ -40,6 +40,30 @@ constexpr int LPR = FC / 4;       // lanes per staged row (16-byte pieces)
 constexpr int GPW = 64 / LPR;     // row groups per wave
 
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// 16-byte store the compiler's s_waitcnt pass does not see.  gfx9 counts loads and stores in ONE vmcnt; with both kinds
+// pending the pass treats the counter as unordered and drains it (vmcnt(0)) before the first use of any loaded register,
+// which would serialise the two prefetch sets of spmm_tiled_full_kernel.  With the stores hidden it counts the loads
+// alone: "at most NLD newer operations outstanding" is still sufficient for the older set (loads retire in order among
+// loads; an un-counted store in between only makes the wait slightly stricter).  The s_nop covers the hazard the
+// compiler would otherwise pad itself: a VALU write to the data registers of a >8-byte store right behind it.
+// The matching 16-byte load and the hand-counted wait.  The wait names the registers it releases as in/out operands, so no
+// use of them can be scheduled above it.
+__device__ __forceinline__ v4f ld4_hidden(const char* base /* wave-uniform */, uint32_t byte_off) {
+    v4f t;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(t) : "v"(byte_off), "s"(base) : "memory");
+    return t;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm(v4f& a, v4f& b, v4f& c, v4f& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
+__device__ __forceinline__ void st4_hidden(float* p, float4 v) {
+    const v4f t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid) {
     // nvalid in 0..4 valid floats at p (feature tail when F % 4 != 0)
@@ -61,11 +85,7 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
                   const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ tile_src,
                   const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
                   int n_rows, int n_feat, int reduce) {
-#ifdef GTE_TILED_DB
-    __shared__ __attribute__((aligned(16))) float s_rows_all[2 * UMAX * FC];   // two chunks: one barrier per chunk
-#else
     __shared__ __attribute__((aligned(16))) float s_rows_all[UMAX * FC];       // staged source rows (one chunk)
-#endif
     struct Edge { float w; int li; };                          // one ds_read_b64 per edge (two reads with separate arrays)
     __shared__ __attribute__((aligned(8))) Edge s_e[EMAX];
     __shared__ int s_usrc[UMAX];
@@ -87,11 +107,10 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
     }
     __syncthreads();
 
-    // Register-pipelined chunks: while chunk c is reduced from LDS, the distinct source rows of chunk c+1
-    // are already in flight into registers (8 x 16 B per lane = all UMAX rows of the tile at once).
+    // Register-pipelined chunks: while chunk c is reduced from LDS, the distinct source rows of chunks c+1 (and, with
+    // PF2, c+2) are already in flight into registers (4 x 16 B per lane per chunk = all UMAX rows of the tile at once).
     constexpr int NLD = UMAX / (4 * GPW);                            // loads per lane per chunk
-    float4 pre[NLD];
-    auto issue_chunk = [&](int c0) {
+    auto issue_chunk = [&](int c0, float4 (&pre)[NLD]) {
         const int col = c0 + l16 * 4;
         const int nvalid = min(max(n_feat - col, 0), 4);
 #pragma unroll
@@ -101,26 +120,17 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
             pre[k] = (ur < nu) ? ld4_guard(x + (int64_t)srow * ldx + col, nvalid) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    if (staged && n_feat > 0) issue_chunk(0);
-
-    for (int c0 = 0; c0 < n_feat; c0 += FC) {
+    auto stage_chunk = [&](float* s_rows, const float4 (&pre)[NLD]) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int ur = wave * GPW + g + 4 * GPW * k;
+            if (ur < nu) *reinterpret_cast<float4*>(&s_rows[ur * FC + l16 * 4]) = pre[k];
+        }
+    };
+    // ---- reduce: wave w owns rows row0 + 8w .. +7, one per 8-lane group
+    auto reduce_chunk = [&](int c0, const float* s_rows) {
         const int col = c0 + l16 * 4;
         const int nvalid = min(max(n_feat - col, 0), 4);
-#ifdef GTE_TILED_DB
-        float* s_rows = s_rows_all + ((c0 / FC) & 1) * (UMAX * FC);
-#else
-        float* s_rows = s_rows_all;
-#endif
-        if (staged) {
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int ur = wave * GPW + g + 4 * GPW * k;
-                if (ur < nu) *reinterpret_cast<float4*>(&s_rows[ur * FC + l16 * 4]) = pre[k];
-            }
-            __syncthreads();
-            if (c0 + FC < n_feat) issue_chunk(c0 + FC);          // lands under this chunk's reduction
-        }
-        // ---- reduce: wave w owns rows row0 + 8w .. +7, four rows at a time (one per 16-lane group)
 #pragma unroll
         for (int pass = 0; pass < TILE_R / (4 * GPW); ++pass) {
             const int r = row0 + wave * (TILE_R / 4) + pass * GPW + g;
@@ -165,9 +175,204 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
                 st4_guard(op, acc, nvalid);
             }
         }
-#ifndef GTE_TILED_DB
+    };
+
+    float* const s_rows = s_rows_all;
+#ifdef GTE_TILED_PF2
+    // prefetch distance 2: two register sets, the chunk loop unrolled by two so both are statically indexed
+    float4 preA[NLD], preB[NLD];
+    if (staged) { issue_chunk(0, preA); if (FC < n_feat) issue_chunk(FC, preB); }
+    for (int c0 = 0; c0 < n_feat; c0 += 2 * FC) {
+        if (staged) {
+            stage_chunk(s_rows, preA);
+            __syncthreads();
+            if (c0 + 2 * FC < n_feat) issue_chunk(c0 + 2 * FC, preA);
+        }
+        reduce_chunk(c0, s_rows);
+        if (staged) __syncthreads();
+        if (c0 + FC < n_feat) {
+            if (staged) {
+                stage_chunk(s_rows, preB);
+                __syncthreads();
+                if (c0 + 3 * FC < n_feat) issue_chunk(c0 + 3 * FC, preB);
+            }
+            reduce_chunk(c0 + FC, s_rows);
+            if (staged) __syncthreads();
+        }
+    }
+#else
+    float4 pre[NLD];
+    if (staged) issue_chunk(0, pre);
+    for (int c0 = 0; c0 < n_feat; c0 += FC) {
+        if (staged) {
+            stage_chunk(s_rows, pre);
+            __syncthreads();
+            if (c0 + FC < n_feat) issue_chunk(c0 + FC, pre);          // lands under this chunk's reduction
+        }
+        reduce_chunk(c0, s_rows);
         if (staged) __syncthreads();                          // s_rows is overwritten by the next chunk
+    }
 #endif
+}
+
+
+// Fast path for n_feat % FC == 0 (every lane owns a whole 16-byte piece in every chunk): the staged loop has NO branch
+// around a vector-memory instruction, so the compiler's s_waitcnt insertion can count -- the distinct source rows of the
+// next TWO chunks are in flight in two register sets (loop unrolled by two, both sets statically indexed) while the current
+// chunk is reduced from LDS; source row pointers, the row's edge range, its scale and its output pointer are hoisted out of
+// the chunk loop.  Same summation order as spmm_tiled_kernel / spmm_csr_kernel: bit-identical results.
+template <bool ACCUM>
+__global__ void __launch_bounds__(256)
+spmm_tiled_full_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                       const uint16_t* __restrict__ lidx, const float* __restrict__ ew,
+                       const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ tile_src,
+                       const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
+                       int n_rows, int n_feat, int reduce) {
+    __shared__ __attribute__((aligned(16))) float s_rows[UMAX * FC];
+    struct Edge { float w; int off; };                         // off = local index * FC (float offset of the staged row)
+    __shared__ __attribute__((aligned(8))) Edge s_e[EMAX];
+    __shared__ int s_usrc[UMAX];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane / LPR, l16 = lane % LPR;
+    const int ntiles = (n_rows + TILE_R - 1) / TILE_R;
+    const int tile = (int)gte_xcd_remap(blockIdx.x, (unsigned)ntiles);
+    const int row0 = tile * TILE_R;
+    const int row_end = min(row0 + TILE_R, n_rows);
+    const int e0 = indptr[row0], e1 = indptr[row_end];
+    const int u0 = tile_ptr[tile], nu = tile_ptr[tile + 1] - u0;
+    const int ne = e1 - e0;
+    // The tile's sources are addressed as {uniform base = row of the smallest source (tile_src is sorted), 32-bit byte
+    // offset}: no 64-bit address arithmetic in the chunk loop.  A tile whose sources span 4 GB or more is gathered directly.
+    const int src_lo = nu > 0 ? tile_src[u0] : 0, src_hi = nu > 0 ? tile_src[u0 + nu - 1] : 0;
+    const bool staged = (nu <= UMAX) && (ne <= EMAX) &&
+                        ((int64_t)(src_hi - src_lo + 1) * ldx * 4 < ((int64_t)1 << 32));   // block-uniform
+
+    static_assert(TILE_R == 4 * GPW, "one destination row per lane group");
+    const int r = row0 + wave * GPW + g;
+    const bool r_ok = r < row_end;
+    int lo = 0, hi = 0;
+    if (r_ok) { lo = indptr[r]; hi = indptr[r + 1]; }
+    const float scale = (reduce == GTE_REDUCE_MEAN) ? (hi > lo ? 1.0f / (float)(hi - lo) : 0.0f) : 1.0f;
+    float* const op = out + (int64_t)(r_ok ? r : row0) * ldo + l16 * 4;
+
+    if (!staged) {                                             // hub tile: gather straight from global memory
+        if (r_ok) {
+            for (int c0 = 0; c0 < n_feat; c0 += FC) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = lo; e < hi; ++e) {
+                    const float w0 = ew ? ew[e] : 1.0f;
+                    const f4u a = *reinterpret_cast<const f4u*>(x + (int64_t)indices[e] * ldx + c0 + l16 * 4);
+                    acc.x = fmaf(w0, a.x, acc.x); acc.y = fmaf(w0, a.y, acc.y);
+                    acc.z = fmaf(w0, a.z, acc.z); acc.w = fmaf(w0, a.w, acc.w);
+                }
+                acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+                if constexpr (ACCUM) {
+                    const f4u o = *reinterpret_cast<const f4u*>(op + c0);
+                    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+                }
+                st4_guard(op + c0, acc, 4);
+            }
+        }
+        return;
+    }
+
+    for (int i = tid; i < ne; i += 256) { s_e[i].off = (int)lidx[e0 + i] * FC; s_e[i].w = ew ? ew[e0 + i] : 1.0f; }
+    for (int i = tid; i < nu; i += 256) s_usrc[i] = tile_src[u0 + i];
+    __syncthreads();
+
+    constexpr int NLD = UMAX / (4 * GPW);                      // loads per lane per chunk
+    uint32_t so[NLD];                                          // byte offset of this lane's piece of its NLD source rows (slot
+#pragma unroll                                                 // clamped: a duplicate load lands in an LDS slot nobody reads)
+    for (int k = 0; k < NLD; ++k) {
+        const int ur = wave * GPW + g + 4 * GPW * k;
+        const int srow = nu > 0 ? s_usrc[min(ur, nu - 1)] : 0;
+        so[k] = (uint32_t)(((int64_t)(srow - src_lo) * ldx + l16 * 4) * 4);
+    }
+    const char* const xb = reinterpret_cast<const char*>(x + (int64_t)src_lo * ldx);      // uniform
+    float* const sw = &s_rows[(wave * GPW + g) * FC + l16 * 4];   // slot of load k: sw + k * 4 * GPW * FC
+    const float* const sr = &s_rows[l16 * 4];
+    const int eb = lo - e0, ee = hi - e0;
+
+    static_assert(NLD == 4, "wait_vm releases four registers sets");
+    auto issue = [&](v4f (&pre)[NLD], int c0) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) pre[k] = ld4_hidden(xb + (int64_t)c0 * 4, so[k]);
+    };
+    auto stage = [&](const v4f (&pre)[NLD]) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) *reinterpret_cast<v4f*>(sw + k * 4 * GPW * FC) = pre[k];
+    };
+    auto reduce_chunk = [&](int c0) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int e = eb;
+        for (; e + 1 < ee; e += 2) {                           // two LDS rows in flight
+            const Edge ea = s_e[e], eb2 = s_e[e + 1];
+            const float4 a = *reinterpret_cast<const float4*>(sr + ea.off);
+            const float4 b = *reinterpret_cast<const float4*>(sr + eb2.off);
+            acc.x = fmaf(ea.w, a.x, acc.x); acc.y = fmaf(ea.w, a.y, acc.y);
+            acc.z = fmaf(ea.w, a.z, acc.z); acc.w = fmaf(ea.w, a.w, acc.w);
+            acc.x = fmaf(eb2.w, b.x, acc.x); acc.y = fmaf(eb2.w, b.y, acc.y);
+            acc.z = fmaf(eb2.w, b.z, acc.z); acc.w = fmaf(eb2.w, b.w, acc.w);
+        }
+        if (e < ee) {
+            const Edge ea = s_e[e];
+            const float4 a = *reinterpret_cast<const float4*>(sr + ea.off);
+            acc.x = fmaf(ea.w, a.x, acc.x); acc.y = fmaf(ea.w, a.y, acc.y);
+            acc.z = fmaf(ea.w, a.z, acc.z); acc.w = fmaf(ea.w, a.w, acc.w);
+        }
+        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+        if (r_ok) {
+            if constexpr (ACCUM) {
+                const f4u o = *reinterpret_cast<const f4u*>(op + c0);
+                acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+            }
+            st4_hidden(op + c0, acc);
+        }
+    };
+
+    // Main loop: both issues unconditional, so "at most NLD newer operations outstanding" releases the older set while the
+    // newer one stays in flight (the row stores in between only make that wait stricter); the last one to three chunks are
+    // peeled and drain the counter.
+    v4f preA[NLD], preB[NLD];
+    const int nch = n_feat / FC;
+    issue(preA, 0);
+    if (nch > 1) issue(preB, FC);
+    int c = 0;
+    if (nch >= 4) {
+        for (; c + 4 <= nch; c += 2) {
+            wait_vm<NLD>(preA[0], preA[1], preA[2], preA[3]);
+            stage(preA);
+            __syncthreads();
+            issue(preA, (c + 2) * FC);
+            reduce_chunk(c * FC);
+            __syncthreads();
+            wait_vm<NLD>(preB[0], preB[1], preB[2], preB[3]);
+            stage(preB);
+            __syncthreads();
+            issue(preB, (c + 3) * FC);
+            reduce_chunk((c + 1) * FC);
+            __syncthreads();
+        }
+    }
+    wait_vm<0>(preA[0], preA[1], preA[2], preA[3]);
+    wait_vm<0>(preB[0], preB[1], preB[2], preB[3]);
+    stage(preA);
+    __syncthreads();
+    if (c + 2 < nch) issue(preA, (c + 2) * FC);
+    reduce_chunk(c * FC);
+    __syncthreads();
+    if (c + 1 < nch) {
+        stage(preB);
+        __syncthreads();
+        reduce_chunk((c + 1) * FC);
+        __syncthreads();
+    }
+    if (c + 2 < nch) {
+        wait_vm<0>(preA[0], preA[1], preA[2], preA[3]);
+        stage(preA);
+        __syncthreads();
+        reduce_chunk((c + 2) * FC);
     }
 }
 
@@ -190,6 +395,17 @@ extern "C" int gte_spmm_csr_tiled(const int32_t* indptr, const int32_t* indices,
     const int64_t ntiles = gte::ceil_div(n_rows, TILE_R);
     dim3 grid((unsigned)ntiles), block(256);
     hipStream_t s = gte::as_stream(stream);
+#ifndef GTE_TILED_NO_FULL
+    if (n_feat % FC == 0) {
+        if (accumulate)
+            hipLaunchKernelGGL(spmm_tiled_full_kernel<true>, grid, block, 0, s, indptr, indices, local_index, eweight,
+                               tile_ptr, tile_src, x, ldx, out, ldo, (int)n_rows, (int)n_feat, reduce);
+        else
+            hipLaunchKernelGGL(spmm_tiled_full_kernel<false>, grid, block, 0, s, indptr, indices, local_index, eweight,
+                               tile_ptr, tile_src, x, ldx, out, ldo, (int)n_rows, (int)n_feat, reduce);
+        return gte::check_launch("spmm_csr_tiled");
+    }
+#endif
     if (accumulate)
         hipLaunchKernelGGL(spmm_tiled_kernel<true>, grid, block, 0, s, indptr, indices, local_index, eweight, tile_ptr,
                            tile_src, x, ldx, out, ldo, (int)n_rows, (int)n_feat, reduce);

@@ -692,7 +692,7 @@ def test_fused_step_graph_replay_is_bitwise_the_eager_step():
 
 
 # ---------------------------------------------------------------- LDS-staged (tiled) aggregation
-@pytest.mark.parametrize("f", [32, 63, 64, 100, 256, 512, 831])
+@pytest.mark.parametrize("f", [32, 63, 64, 96, 100, 128, 160, 256, 512, 831])
 @pytest.mark.parametrize("mean", [False, True])
 def test_spmm_tiled_is_bitwise_the_plain_kernel(f, mean):
     """Same CSR order => the LDS-staged kernel must reproduce the row-per-wave kernel bit for bit,
@@ -721,6 +721,36 @@ def test_spmm_tiled_is_bitwise_the_plain_kernel(f, mean):
     ops.spmm_csr(ip, ix, wt, x, n, mean=mean, out=o1, accumulate=True)
     ops.spmm_csr(ip, ix, wt, x, n, mean=mean, out=o2, accumulate=True, tiles=plan, force_tiled=True)
     assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_spmm_tiled_full_chunk_kernel_randomised(seed):
+    """spmm_tiled_full_kernel (n_feat % 32 == 0: two register sets of hand-counted hidden loads in flight) against the
+    row-per-wave kernel, bit for bit, over random widths, page counts, strided inputs/outputs and repeated launches
+    (a wait released one load early would show up as run-to-run differences)."""
+    rng = np.random.default_rng(1000 + seed)
+    pages = S.make_pages(int(rng.integers(5, 60)), in_feats=13, first_id=int(rng.integers(0, 10_000)))
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    n = int(off[-1])
+    g = oc.OracleGraph(src, dst, n, w)
+    ip, ix, wt = dev(g.indptr), dev(g.indices), dev(g.weight)
+    plan = ops.build_tile_plan(ip, ix, n)
+    for f in rng.choice(np.arange(1, 17) * 32, size=4, replace=False):
+        f = int(f)
+        pad = int(rng.integers(0, 3)) * 4
+        xs = torch.randn(n, f + pad, device=DEV)
+        x = xs[:, :f]                                              # row stride > width
+        a = ops.spmm_csr(ip, ix, wt, x, n, mean=True)
+        outs = torch.zeros(n, f + pad, device=DEV)
+        for rep in range(3):
+            b = ops.spmm_csr(ip, ix, wt, x, n, mean=True, out=outs[:, :f], tiles=plan, force_tiled=True)
+            assert torch.equal(a, b), (f, pad, rep)
+        assert float(outs[:, f:].abs().sum()) == 0.0               # nothing written past the row
+        base = torch.randn(n, f, device=DEV)
+        o1, o2 = base.clone(), base.clone()
+        ops.spmm_csr(ip, ix, wt, x, n, mean=False, out=o1, accumulate=True)
+        ops.spmm_csr(ip, ix, wt, x, n, mean=False, out=o2, accumulate=True, tiles=plan, force_tiled=True)
+        assert torch.equal(o1, o2), (f, pad)
 
 
 def test_tile_plan_contract_and_oracle_parity():
