@@ -44,22 +44,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // 16-byte store the compiler's s_waitcnt pass does not see.  gfx9 counts loads and stores in ONE vmcnt; with both kinds
 // pending the pass treats the counter as unordered and drains it (vmcnt(0)) before the first use of any loaded register,
-// which would serialise the two prefetch sets of spmm_tiled_full_kernel.  With the stores hidden it counts the loads
-// alone: "at most NLD newer operations outstanding" is still sufficient for the older set (loads retire in order among
-// loads; an un-counted store in between only makes the wait slightly stricter).  The s_nop covers the hazard the
+// which would serialise the two prefetch sets of spmm_tiled_full_kernel.  With the stores hidden the pass sees loads only
+// and counts them itself ("at most NLD newer loads outstanding" releases the older set); a store it did not count only
+// makes such a wait stricter (loads retire in order among loads).  The loads stay ordinary C++ loads: the compiler knows
+// which registers are pending, so any copy it makes of them is preceded by its own wait.  The s_nop covers the hazard the
 // compiler would otherwise pad itself: a VALU write to the data registers of a >8-byte store right behind it.
-// The matching 16-byte load and the hand-counted wait.  The wait names the registers it releases as in/out operands, so no
-// use of them can be scheduled above it.
-__device__ __forceinline__ v4f ld4_hidden(const char* base /* wave-uniform */, uint32_t byte_off) {
-    v4f t;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(t) : "v"(byte_off), "s"(base) : "memory");
-    return t;
-}
-template <int N>
-__device__ __forceinline__ void wait_vm(v4f& a, v4f& b, v4f& c, v4f& d) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
-
 __device__ __forceinline__ void st4_hidden(float* p, float4 v) {
     const v4f t = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
@@ -107,8 +96,8 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
     }
     __syncthreads();
 
-    // Register-pipelined chunks: while chunk c is reduced from LDS, the distinct source rows of chunks c+1 (and, with
-    // PF2, c+2) are already in flight into registers (4 x 16 B per lane per chunk = all UMAX rows of the tile at once).
+    // Register-pipelined chunks: while chunk c is reduced from LDS, the distinct source rows of chunk c+1 are already in
+    // flight into registers (4 x 16 B per lane per chunk = all UMAX rows of the tile at once).
     constexpr int NLD = UMAX / (4 * GPW);                            // loads per lane per chunk
     auto issue_chunk = [&](int c0, float4 (&pre)[NLD]) {
         const int col = c0 + l16 * 4;
@@ -178,29 +167,6 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
     };
 
     float* const s_rows = s_rows_all;
-#ifdef GTE_TILED_PF2
-    // prefetch distance 2: two register sets, the chunk loop unrolled by two so both are statically indexed
-    float4 preA[NLD], preB[NLD];
-    if (staged) { issue_chunk(0, preA); if (FC < n_feat) issue_chunk(FC, preB); }
-    for (int c0 = 0; c0 < n_feat; c0 += 2 * FC) {
-        if (staged) {
-            stage_chunk(s_rows, preA);
-            __syncthreads();
-            if (c0 + 2 * FC < n_feat) issue_chunk(c0 + 2 * FC, preA);
-        }
-        reduce_chunk(c0, s_rows);
-        if (staged) __syncthreads();
-        if (c0 + FC < n_feat) {
-            if (staged) {
-                stage_chunk(s_rows, preB);
-                __syncthreads();
-                if (c0 + 3 * FC < n_feat) issue_chunk(c0 + 3 * FC, preB);
-            }
-            reduce_chunk(c0 + FC, s_rows);
-            if (staged) __syncthreads();
-        }
-    }
-#else
     float4 pre[NLD];
     if (staged) issue_chunk(0, pre);
     for (int c0 = 0; c0 < n_feat; c0 += FC) {
@@ -212,7 +178,6 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
         reduce_chunk(c0, s_rows);
         if (staged) __syncthreads();                          // s_rows is overwritten by the next chunk
     }
-#endif
 }
 
 
@@ -234,7 +199,7 @@ spmm_tiled_full_kernel(const int32_t* __restrict__ indptr, const int32_t* __rest
     __shared__ int s_usrc[UMAX];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane / LPR, l16 = lane % LPR;
+    const int g = lane / LPR, l16 = lane % LPR;               // 8 lanes per 128-byte row piece, 8 row groups per wave
     const int ntiles = (n_rows + TILE_R - 1) / TILE_R;
     const int tile = (int)gte_xcd_remap(blockIdx.x, (unsigned)ntiles);
     const int row0 = tile * TILE_R;
@@ -294,14 +259,17 @@ spmm_tiled_full_kernel(const int32_t* __restrict__ indptr, const int32_t* __rest
     const float* const sr = &s_rows[l16 * 4];
     const int eb = lo - e0, ee = hi - e0;
 
-    static_assert(NLD == 4, "wait_vm releases four registers sets");
-    auto issue = [&](v4f (&pre)[NLD], int c0) {
+    auto issue = [&](float4 (&pre)[NLD], int c0) {
+        const char* const xc = xb + (int64_t)c0 * 4;           // uniform
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) pre[k] = ld4_hidden(xb + (int64_t)c0 * 4, so[k]);
+        for (int k = 0; k < NLD; ++k) {
+            const f4u t = *reinterpret_cast<const f4u*>(xc + so[k]);
+            pre[k] = make_float4(t.x, t.y, t.z, t.w);
+        }
     };
-    auto stage = [&](const v4f (&pre)[NLD]) {
+    auto stage = [&](const float4 (&pre)[NLD]) {
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) *reinterpret_cast<v4f*>(sw + k * 4 * GPW * FC) = pre[k];
+        for (int k = 0; k < NLD; ++k) *reinterpret_cast<float4*>(sw + k * 4 * GPW * FC) = pre[k];
     };
     auto reduce_chunk = [&](int c0) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -331,32 +299,33 @@ spmm_tiled_full_kernel(const int32_t* __restrict__ indptr, const int32_t* __rest
         }
     };
 
-    // Main loop: both issues unconditional, so "at most NLD newer operations outstanding" releases the older set while the
-    // newer one stays in flight (the row stores in between only make that wait stricter); the last one to three chunks are
-    // peeled and drain the counter.
-    v4f preA[NLD], preB[NLD];
+    // Two register sets, the chunk loop unrolled by two so both are statically indexed.  The only way into the main loop
+    // has BOTH sets requested and every issue inside it is unconditional, so the wait in front of a stage is a counted
+    // vmcnt(NLD): the other set stays in flight.  Fewer than four chunks, and the last two or three, run a drained tail.
     const int nch = n_feat / FC;
-    issue(preA, 0);
-    if (nch > 1) issue(preB, FC);
+    float4 preA[NLD], preB[NLD];
     int c = 0;
     if (nch >= 4) {
+        issue(preA, 0);
+        __builtin_amdgcn_sched_barrier(0);                     // set A strictly older than set B (the scheduler would interleave them)
+        issue(preB, FC);
+        __builtin_amdgcn_sched_barrier(0);
         for (; c + 4 <= nch; c += 2) {
-            wait_vm<NLD>(preA[0], preA[1], preA[2], preA[3]);
             stage(preA);
             __syncthreads();
             issue(preA, (c + 2) * FC);
             reduce_chunk(c * FC);
             __syncthreads();
-            wait_vm<NLD>(preB[0], preB[1], preB[2], preB[3]);
             stage(preB);
             __syncthreads();
             issue(preB, (c + 3) * FC);
             reduce_chunk((c + 1) * FC);
             __syncthreads();
         }
+    } else {
+        issue(preA, 0);
+        if (nch > 1) issue(preB, FC);
     }
-    wait_vm<0>(preA[0], preA[1], preA[2], preA[3]);
-    wait_vm<0>(preB[0], preB[1], preB[2], preB[3]);
     stage(preA);
     __syncthreads();
     if (c + 2 < nch) issue(preA, (c + 2) * FC);
@@ -369,7 +338,6 @@ spmm_tiled_full_kernel(const int32_t* __restrict__ indptr, const int32_t* __rest
         __syncthreads();
     }
     if (c + 2 < nch) {
-        wait_vm<0>(preA[0], preA[1], preA[2], preA[3]);
         stage(preA);
         __syncthreads();
         reduce_chunk((c + 2) * FC);
@@ -395,8 +363,7 @@ extern "C" int gte_spmm_csr_tiled(const int32_t* indptr, const int32_t* indices,
     const int64_t ntiles = gte::ceil_div(n_rows, TILE_R);
     dim3 grid((unsigned)ntiles), block(256);
     hipStream_t s = gte::as_stream(stream);
-#ifndef GTE_TILED_NO_FULL
-    if (n_feat % FC == 0) {
+    if (n_feat % FC == 0 && n_feat >= 4 * FC) {                // the two-sets-in-flight loop needs four chunks
         if (accumulate)
             hipLaunchKernelGGL(spmm_tiled_full_kernel<true>, grid, block, 0, s, indptr, indices, local_index, eweight,
                                tile_ptr, tile_src, x, ldx, out, ldo, (int)n_rows, (int)n_feat, reduce);
@@ -405,7 +372,6 @@ extern "C" int gte_spmm_csr_tiled(const int32_t* indptr, const int32_t* indices,
                                tile_ptr, tile_src, x, ldx, out, ldo, (int)n_rows, (int)n_feat, reduce);
         return gte::check_launch("spmm_csr_tiled");
     }
-#endif
     if (accumulate)
         hipLaunchKernelGGL(spmm_tiled_kernel<true>, grid, block, 0, s, indptr, indices, local_index, eweight, tile_ptr,
                            tile_src, x, ldx, out, ldo, (int)n_rows, (int)n_feat, reduce);
