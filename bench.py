@@ -178,6 +178,18 @@ def gather_probe(args, gte, S, dev):
 
     ms_plain = timed(None)
     ms = timed(plan)
+    # yardstick: a plain device copy of the same feature matrix into the same output (reads X once, writes out once --
+    # the compulsory traffic of the aggregation minus the edge list)
+    for _ in range(3):
+        out.copy_(x)
+    torch.cuda.synchronize()
+    cs, ce = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cs.record()
+    for _ in range(10):
+        out.copy_(x)
+    ce.record()
+    torch.cuda.synchronize()
+    copy_ms = cs.elapsed_time(ce) / 10
     # (iii) of SURVEY 8(d) cfg4: one full GcnSAGELayer(512 -> 512) forward + backward on the same graph
     layer_ms = None
     if n == 1_000_000:
@@ -203,10 +215,11 @@ def gather_probe(args, gte, S, dev):
     alg_bytes = 2.0 * n * f * 4 + 8.0 * n * k + 4.0 * (n + 1)      # 2*F*s + 8*d + 4 per node
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return {"workload": f"cfg4: 1 graph, {n} nodes, in-degree {k}, F={f} fp32, k-NN of 2-D points in Morton order",
-            "kernel": "spmm_tiled_kernel (LDS-staged distinct sources)", "plain_kernel_ms": ms_plain,
+            "kernel": "spmm_tiled_full_kernel (LDS-staged distinct sources, two chunks in flight)", "plain_kernel_ms": ms_plain,
             "plain_kernel_GBs": alg_bytes / (ms_plain * 1e-3) / 1e9, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms_per_pass": ms, "algorithmic_bytes": alg_bytes,
             "nodes_per_s_per_pass": n / (ms * 1e-3),
+            "device_copy_same_matrix_ms": copy_ms, "device_copy_GBs": 2.0 * n * f * 4 / (copy_ms * 1e-3) / 1e9,
             "full_layer_512_fwd_bwd_ms": layer_ms,
             "full_layer_nodes_per_s": (n / (layer_ms * 1e-3)) if layer_ms else None,
             "traffic": pmc_traffic()[0].get("gather_cfg4_tiled_bytes_per_launch") if n == 1_000_000 else None,

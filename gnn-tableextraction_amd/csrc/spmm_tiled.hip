@@ -187,7 +187,7 @@ spmm_tiled_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict_
 // chunk is reduced from LDS; source row pointers, the row's edge range, its scale and its output pointer are hoisted out of
 // the chunk loop.  Same summation order as spmm_tiled_kernel / spmm_csr_kernel: bit-identical results.
 template <bool ACCUM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 7)   // 72 VGPRs: 7 workgroups per CU (LDS would allow 8)
 spmm_tiled_full_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                        const uint16_t* __restrict__ lidx, const float* __restrict__ ew,
                        const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ tile_src,
