@@ -231,7 +231,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # GTE_BENCH_FORCE_DIST=1 (test hook): run the data-parallel code path -- RCCL process group, flat-gradient all-reduces,
+    # HIP graph + eager collective + Adam -- even with one rank, so a 1-GPU box exercises RCCL next to graph capture.
+    distributed = world > 1 or os.environ.get("GTE_BENCH_FORCE_DIST", "0") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     # Test hook for 1-GPU boxes (GTE_BENCH_SHARE_GPU=1): every rank uses cuda:0 and the ranks talk over gloo (RCCL refuses two
@@ -244,6 +246,9 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if share_gpu:
             dist.init_process_group("gloo")
         else:

@@ -120,11 +120,14 @@ class FusedGcnSageStep(TrainStep):
         for p in (q for q in model.parameters() if q.requires_grad):
             self._gslice[id(p)] = self.flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
-        # data-parallel overlap: the flat gradient is [layer 0 | layers 1..]; the upper slice is all-reduced while layer 0's
-        # backward (the longest: its dW GEMM alone is a quarter of the step) still runs.  GTE_DP_OVERLAP=0: one all-reduce.
+        # data-parallel overlap (GTE_DP_OVERLAP=1): the flat gradient is [layer 0 | layers 1..]; the upper slice is all-reduced
+        # while layer 0's backward (the longest: its dW GEMM alone is a quarter of the step) still runs.  Off by default: with
+        # ONE rank (RCCL process group, trivial collective) the split step costs 0.804 ms against 0.760 ms for one all-reduce
+        # behind one graph (0.748 ms without data parallelism) -- cutting the graph and the second collective cost ~45 us,
+        # about what hiding a 0.5 MB all-reduce can win back on 8 GPUs.  To be re-measured on a multi-GPU node.
         self._n0 = sum(p.numel() for p in model.layers[0].parameters() if p.requires_grad)
         first_upper = next((p for p in model.layers[1].parameters() if p.requires_grad), None) if len(model.layers) > 1 else None
-        self._dp_split = (os.environ.get("GTE_DP_OVERLAP", "1") == "1" and first_upper is not None
+        self._dp_split = (os.environ.get("GTE_DP_OVERLAP", "0") == "1" and first_upper is not None
                           and self._gslice[id(first_upper)].storage_offset() == self._n0)
         self._bufs = {}
         self._graph_bufs = {}

@@ -1,7 +1,7 @@
 """Two data-parallel ranks of the REAL step engine (FusedGcnSageStep, HIP kernels) on one GPU over gloo -- the box has a
 single MI355X, RCCL refuses two ranks on one device, gloo all-reduces GPU tensors through the host.  Everything except
-the transport is the shipped multi-GPU path: per-rank loss scaling n_local / n_global, ONE all-reduce of the flat
-gradient, HIP-graph replay followed by the eager all-reduce + Adam.  Replicas must stay bit-identical and match the
+the transport is the shipped multi-GPU path: per-rank loss scaling n_local / n_global, one all-reduce of the flat
+gradient (or two around layer 0's backward, GTE_DP_OVERLAP=1), HIP-graph replay followed by the eager all-reduce + Adam.  Replicas must stay bit-identical and match the
 single-process step on the union batch (reference semantics: mean CE over all nodes of the step)."""
 import os
 import socket
@@ -32,8 +32,9 @@ def _graph(gte, G, S, pages, ids, dev):
     return g, torch.from_numpy(label).to(dev)
 
 
-def _worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, out_dir, overlap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      GTE_DP_OVERLAP=overlap)
     import torch.distributed as dist
     import gnn_tableextraction_amd as gte
     from gnn_tableextraction_amd import distributed as D, graph as G
@@ -65,13 +66,15 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path):
+@pytest.mark.parametrize("overlap", ["0", "1"])       # one all-reduce behind one graph (default) / two around layer 0's backward
+def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, overlap):
     import gnn_tableextraction_amd as gte
     from gnn_tableextraction_amd import distributed as D, graph as G
     from gnn_tableextraction_amd.data import synthetic as S
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
     world = 2
-    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), overlap), nprocs=world, join=True,
+                       start_method="spawn")
     p0, p1 = np.load(tmp_path / "param_0.npy"), np.load(tmp_path / "param_1.npy")
     np.testing.assert_array_equal(p0, p1)                        # replicas stay bit-identical
 
