@@ -267,14 +267,14 @@ class FusedGcnSageStep(TrainStep):
         ew = g.edata.get("feat")
         csr, rcsr = g.in_csr(), g.out_csr()
         w_in, w_out = g.in_weights(ew), g.out_weights(ew, True)
-        big = ops.use_tiled(n, max(f0, max(l.out_feats for l in self.model.layers)))
+        big = n * max(f0, max(l.out_feats for l in self.model.layers)) * 4 >= min(ops.TILED_FULL_MIN_BYTES, ops.TILED_MIN_BYTES)
         t_in, t_out = (g.in_tiles(), g.out_tiles()) if big else (None, None)
 
         PP = lambda a: a if isinstance(a, int) else P(a)           # tensor or raw device address (a column offset into one)
 
         def aggregate(csr_, w_, tiles_, src, ldsrc, dst, lddst, f, reduce, accumulate):
             nbytes = 2.0 * n * f * 4 + 8.0 * csr_.indices.numel() + 4.0 * (n + 1)
-            if tiles_ is not None and ops.use_tiled(n, f):
+            if tiles_ is not None and ops.use_tiled(n, f, csr_.indices.numel()):
                 with timed("spmm_tiled", nbytes):
                     check(lib.gte_spmm_csr_tiled(P(csr_.indptr), P(csr_.indices), P(tiles_.local_index), P(w_),
                                                  P(tiles_.tile_ptr), P(tiles_.tile_src), PP(src), ldsrc, PP(dst), lddst,
@@ -335,7 +335,7 @@ class FusedGcnSageStep(TrainStep):
                     for _ in tm.repeat():
                         check(lib.gte_sage_transform_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(t), 2 * fout, n,
                                                          st), "gte_sage_transform_fwd")
-                if lib.gte_spmm_csr_accumulate_ln_supported(fout) and not (t_in is not None and ops.use_tiled(n, fout)):
+                if lib.gte_spmm_csr_accumulate_ln_supported(fout) and not (t_in is not None and ops.use_tiled(n, fout, csr.indices.numel(), fused_ln=True)):
                     # z = t_self + mean-aggregate(t_neigh) and y = relu(LayerNorm(z)) in one pass over the rows
                     with timed("spmm_csr", 3.0 * n * fout * 4 + 8.0 * csr.indices.numel() + 4.0 * (n + 1)):
                         check(lib.gte_spmm_csr_accumulate_ln(P(csr.indptr), P(csr.indices), P(w_in), P(t) + 4 * fout, 2 * fout,

@@ -159,15 +159,27 @@ def build_tile_plan(indptr: torch.Tensor, indices: torch.Tensor, n_rows: int) ->
 
 
 TILED_MIN_FEATS = 32      # narrower rows (9, 13 features) leave most of a 16-lane row group idle: plain kernel
-# The LDS-staged kernel wins once the gathered matrix no longer lives in L2 / Infinity Cache (measured on
-# MI355X: 1 M x 512 fp32 = 2 GB: 1.06 ms vs 1.81 ms; 1 M x 64 = 256 MB: 176 vs 220 us; a 100-page batch,
-# 80 MB: 57 us vs 46 us for the plain
-# kernel, whose re-fetches are then L2 hits).  Below this size the plain row-per-wave kernel runs.
+# The LDS-staged kernels win once the gathered matrix no longer lives in L2 (measured on MI355X, profiles/debug/
+# tiled_crossover.py, page graphs of 200 ... 1600 pages):
+#   widths that are a multiple of 32 with >= 4 chunks (spmm_tiled_full_kernel, two chunks in flight): ahead from ~50 MB
+#     (48 k x 256: 20.8 vs 24.5 us; 191 k x 256: 88 vs 131 us; 389 k x 512: 316 vs 487 us; a 100-page batch, 25 MB: 15.3 vs 13.7);
+#     the threshold stays at the size from which graphs carry tile plans at all (PageGraph.TILES_MIN_NODES);
+#   other widths (spmm_tiled_kernel, one chunk in flight): behind the plain kernel on page graphs (in-degree ~6) at every size
+#     (389 k x 831: 1042 vs 874 us), ahead on high-degree graphs (cfg4, in-degree 12: 1.05 vs 1.81 ms) -> needs TILED_MIN_DEGREE;
+#   with the LayerNorm epilogue fused into the plain accumulating kernel the tiled route pays a separate LayerNorm pass:
+#     it keeps the higher threshold.
 TILED_MIN_BYTES = 192 << 20
+TILED_FULL_MIN_BYTES = 96 << 20
+TILED_MIN_DEGREE = 10
 
 
-def use_tiled(n_rows: int, n_feat: int) -> bool:
-    return n_feat >= TILED_MIN_FEATS and n_rows * n_feat * 4 >= TILED_MIN_BYTES
+def use_tiled(n_rows: int, n_feat: int, nnz: Optional[int] = None, fused_ln: bool = False) -> bool:
+    if n_feat < TILED_MIN_FEATS:
+        return False
+    nbytes = n_rows * n_feat * 4
+    if n_feat % 32 == 0 and n_feat >= 128:
+        return nbytes >= (TILED_MIN_BYTES if fused_ln else min(TILED_FULL_MIN_BYTES, TILED_MIN_BYTES))
+    return nbytes >= TILED_MIN_BYTES and (nnz is None or nnz >= TILED_MIN_DEGREE * n_rows)
 
 
 def spmm_csr(indptr, indices, weight, x: torch.Tensor, n_rows: int, mean: bool = False,
@@ -178,7 +190,7 @@ def spmm_csr(indptr, indices, weight, x: torch.Tensor, n_rows: int, mean: bool =
     require_device(x, "spmm_csr")
     lib = _lib.load()
     x = _row_major(x)
-    if tiles is not None and x.dtype == torch.float32 and (force_tiled or use_tiled(n_rows, x.shape[1])):
+    if tiles is not None and x.dtype == torch.float32 and (force_tiled or use_tiled(n_rows, x.shape[1], indices.numel())):
         f = x.shape[1]
         if out is None:
             if accumulate:
@@ -474,14 +486,14 @@ def _sage_layer_transform_first(graph, h, weight, bias, gamma, beta, edge_weight
     csr = graph.in_csr()
     w = graph.in_weights(edge_weight)
     y = torch.empty((n, fout), dtype=torch.float32, device=h.device)
-    if lib.gte_spmm_csr_accumulate_ln_supported(fout) and not use_tiled(n, fout):
+    if lib.gte_spmm_csr_accumulate_ln_supported(fout) and not use_tiled(n, fout, csr.indices.numel(), fused_ln=True):
         check(lib.gte_spmm_csr_accumulate_ln(ptr(csr.indptr), ptr(csr.indices), ptr(w), ptr(t) + 4 * fout, 2 * fout, ptr(t),
                                              2 * fout, n, fout, _lib.REDUCE_MEAN, ptr(gamma), ptr(beta), float(eps), int(relu),
                                              ptr(y), fout, None, current_stream()), "gte_spmm_csr_accumulate_ln")
         return y
     # large graphs: LDS-staged aggregation (no LayerNorm epilogue there), then LayerNorm
     spmm_csr(csr.indptr, csr.indices, w, t[:, fout:], n, mean=True, out=t[:, :fout], accumulate=True,
-             tiles=graph.in_tiles() if use_tiled(n, fout) else None)
+             tiles=graph.in_tiles() if use_tiled(n, fout, csr.indices.numel(), fused_ln=True) else None)
     check(lib.gte_ln_relu_fwd(ptr(t), 2 * fout, ptr(gamma), ptr(beta), float(eps), int(relu), ptr(y), fout, None, n, fout,
                               current_stream()), "gte_ln_relu_fwd")
     return y

@@ -780,8 +780,8 @@ def test_model_with_and_without_tiles_is_bitwise_identical():
     torch.manual_seed(3)
     model = gte.GcnSAGE(63, 128, 9, 3, torch.nn.functional.relu, 0).to(DEV)
     outs = []
-    monkey = (G.PageGraph.TILES_MIN_NODES, ops.TILED_MIN_BYTES)
-    G.PageGraph.TILES_MIN_NODES, ops.TILED_MIN_BYTES = 1, 1            # force the tiled path at test size
+    monkey = (G.PageGraph.TILES_MIN_NODES, ops.TILED_MIN_BYTES, ops.TILED_MIN_DEGREE)
+    G.PageGraph.TILES_MIN_NODES, ops.TILED_MIN_BYTES, ops.TILED_MIN_DEGREE = 1, 1, 0      # force the tiled path at test size
     for use in (True, False):
         g = G.PageGraph(src, dst, int(off[-1]), device=DEV)
         g.use_tiles = use
@@ -791,7 +791,7 @@ def test_model_with_and_without_tiles_is_bitwise_identical():
         outs.append((logits.detach().clone(), [p.grad.clone() for p in model.parameters()]))
         model.zero_grad()
         assert (g.in_tiles() is not None) == use
-    G.PageGraph.TILES_MIN_NODES, ops.TILED_MIN_BYTES = monkey
+    G.PageGraph.TILES_MIN_NODES, ops.TILED_MIN_BYTES, ops.TILED_MIN_DEGREE = monkey
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
