@@ -347,6 +347,19 @@ def main():
                        "nodes_per_step_per_gpu": int(np.mean(local_nodes)), "parallelism": f"dp{world}"},
             "final_loss": final_loss, "roofline": roofline, "kernels": per_kernel,
         }
+        # whole-step bounds of SURVEY 8(d): per node, layer l (F_l -> F_{l+1}, mean in-degree d), training mode, no recomputation
+        dims = [args.in_feats] + [args.hidden] * (args.layers - 1) + [9]
+        deg = float(np.mean([b[0].in_csr().indices.numel() / max(b[0].num_nodes(), 1) for b in batches]))
+        flops_node = sum(2.0 * 2 * dims[l] * dims[l + 1] * (3 if l > 0 else 2) for l in range(args.layers))
+        bytes_node = sum(4.0 * (2 * dims[l] + dims[l + 1]) + 8 * deg + 4 +                       # forward
+                         4.0 * (dims[l + 1] + 2 * dims[l] + (dims[l] if l > 0 else 0)) + 8 * deg + 4  # backward
+                         for l in range(args.layers))
+        mfma_bound = MFMA_F32_PEAK_TF * 1e12 / flops_node * world
+        hbm_bound = HBM_PEAK_GBS * 1e9 / bytes_node * world
+        line["step_roofline"] = {"flops_per_node": flops_node, "bytes_per_node": bytes_node, "mean_in_degree": deg,
+                                 "mfma_bound_nodes_per_s": mfma_bound, "hbm_bound_nodes_per_s": hbm_bound,
+                                 "bound": "mfma" if mfma_bound < hbm_bound else "hbm",
+                                 "frac": line["value"] / min(mfma_bound, hbm_bound)}
         if world == 1 and not args.no_gather_probe:
             line["gather"] = gather_probe(args, gte, S, dev)
         if world == 1 and args.val_graph > 0:
