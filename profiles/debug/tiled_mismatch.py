@@ -4,16 +4,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from gnn_tableextraction_amd import ops
 from gnn_tableextraction_amd.data import synthetic as S
-from oracle import gcnsage_cpu as oc
 dev = "cuda:0"
 rng = np.random.default_rng(1002)
 pages = S.make_pages(40, in_feats=13, first_id=77)
 src, dst, w, feat, label, off = S.concat_pages(pages)
 n = int(off[-1])
-g = oc.OracleGraph(src, dst, n, w)
-ip, ix, wt = [torch.from_numpy(a).to(dev) for a in (g.indptr, g.indices, g.weight)]
+ip, ix, perm, wt = ops.coo_to_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, torch.from_numpy(w).to(dev))
 plan = ops.build_tile_plan(ip, ix, n)
-tp = plan.tile_ptr.cpu().numpy(); ipn = g.indptr
+tp = plan.tile_ptr.cpu().numpy(); ipn = ip.cpu().numpy()
 nt = len(tp) - 1
 print("n", n, "tiles", nt, "nu", [int(tp[t + 1] - tp[t]) for t in range(nt)])
 print("ne", [int(ipn[min((t + 1) * 32, n)] - ipn[t * 32]) for t in range(nt)])
