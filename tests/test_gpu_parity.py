@@ -632,6 +632,30 @@ def test_large_graph_linearity_and_permutation_properties():
     assert torch.all(m1 == 1.0)
 
 
+def test_cfg4_full_size_tiled_equals_plain_and_properties():
+    """BASELINE cfg4 at its full size (1 M nodes, in-degree 12, F = 512 fp32, k-NN graph in Morton order): the LDS-staged
+    kernel (two chunks in flight) against the row-per-wave kernel bit for bit, forward and on the reversed graph, plus the
+    size-independent properties: mean of a constant, linearity."""
+    n, k, f = 1_000_000, 12, 512
+    src, dst, w = S.make_knn_stress_graph(n, k)
+    x = torch.randn(n, f, device=DEV)
+    for s_, d_ in ((src, dst), (dst, src)):                      # in-edge CSR (forward), out-edge CSR (backward)
+        ip, ix, perm, wt = ops.coo_to_csr(dev(d_, torch.int32), dev(s_, torch.int32), n, dev(w))
+        plan = ops.build_tile_plan(ip, ix, n)
+        a = ops.spmm_csr(ip, ix, wt, x, n, mean=True)
+        b = ops.spmm_csr(ip, ix, wt, x, n, mean=True, tiles=plan, force_tiled=True)
+        assert torch.equal(a, b)
+        del a
+        c = ops.spmm_csr(ip, ix, None, torch.full((n, 128), 3.0, device=DEV), n, mean=True, tiles=plan, force_tiled=True)
+        deg = (ip[1:] - ip[:-1]).unsqueeze(1)
+        assert torch.allclose(c, torch.where(deg > 0, 3.0, 0.0).expand(n, 128), rtol=1e-6, atol=0)   # mean of a constant
+        y = torch.randn(n, f, device=DEV)
+        by = ops.spmm_csr(ip, ix, wt, y, n, mean=True, tiles=plan, force_tiled=True)
+        bxy = ops.spmm_csr(ip, ix, wt, 2.0 * x - 3.0 * y, n, mean=True, tiles=plan, force_tiled=True)
+        assert torch.allclose(bxy, 2.0 * b - 3.0 * by, rtol=1e-4, atol=1e-4)
+        del b, by, bxy, y, c
+
+
 # ---------------------------------------------------------------- hand-scheduled step engine
 @pytest.mark.parametrize("name", ["page200_f13_l3_cw", "page300_f831_l3", "batch5_hetero", "single_node", "tiny_6n_10e"])
 def test_fused_step_matches_reference_golden_and_autograd_path(name):
