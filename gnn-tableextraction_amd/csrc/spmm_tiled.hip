@@ -14,9 +14,13 @@
 //   3. reduces every destination row from LDS (ds_read_b128, an 8-lane group reads one 128-B row) in CSR
 //      order -- same summation order as the plain kernel, bit-identical result,
 //   4. writes the 128-B output segments.
-// 20 KB of LDS per workgroup -> 8 workgroups (32 waves) per CU; occupancy, not traffic, is what the
-// chunk width trades against (see FC below).  HBM-side traffic measured with rocprofv3 on cfg4:
-// 2.38 GB fetched + 2.0 GB written = 4.4 GB for 4.2 GB of algorithmic bytes (plain kernel: 10.7 GB).
+// Two kernels share this structure:
+//   spmm_tiled_full_kernel  widths that are a multiple of FC with >= 4 chunks: TWO chunks of distinct source rows in flight
+//                           in two register sets (72 VGPRs, 7 workgroups per CU); cfg4: 0.90 ms per pass, 4.6-4.8 TB/s of
+//                           algorithmic bytes -- the rate of a device copy of the same matrix (profiles/r01/stream_bw.txt)
+//   spmm_tiled_kernel       any width (guarded 16-byte pieces, one chunk in flight, 8 workgroups per CU); cfg4: 1.05 ms
+// 20 KB of LDS per workgroup; occupancy, not traffic, is what the chunk width trades against (see FC below).  HBM-side
+// traffic measured with rocprofv3 on cfg4: 4.6 GB per launch for 4.2 GB of algorithmic bytes (plain kernel: 10.9 GB).
 // The distinct-source lists are graph structure, built once per (batched) graph next to the CSR
 // (tile_ptr / tile_src / local index per edge) and reused by every layer, forward and backward, and
 // every epoch.  Tiles that do not fit the LDS budget (more than UMAX distinct sources or EMAX edges:

@@ -76,8 +76,9 @@ int gte_spmm_csr_accumulate(const int32_t* indptr, const int32_t* indices, const
  *   tile_ptr    int32[n_tiles+1]  offsets into tile_src        (n_tiles = ceil(n_rows / tile_rows))
  *   tile_src    int32[...]        distinct source rows of each tile
  *   local_index uint16[nnz]       position of indices[e] inside its tile's tile_src segment
- * Tiles with more than 128 distinct sources or 512 edges are gathered directly (no size limit on the
- * graph).  fp32 only.  accumulate != 0: out += ... */
+ * Tiles with more than 128 distinct sources or 448 edges (or whose sources span 4 GB of x) are gathered directly (no size
+ * limit on the graph).  Widths that are a multiple of 32 with at least 128 columns keep two chunks in flight (faster).
+ * fp32 only.  accumulate != 0: out += ... */
 int gte_spmm_tile_rows(void);
 int gte_spmm_csr_tiled(const int32_t* indptr, const int32_t* indices, const uint16_t* local_index,
                        const float* eweight, const int32_t* tile_ptr, const int32_t* tile_src,
