@@ -106,7 +106,7 @@ def cpu_baseline(args, host_batch, state):
         tr.step(og, x, y)
     times = []
     t_all = time.time()
-    while len(times) < 5 or (time.time() - t_all < 10 and len(times) < 20):
+    while len(times) < 5 or (time.time() - t_all < 10 and len(times) < 200):      # ~10 s of CPU work
         t0 = time.time()
         tr.step(og, x, y)
         times.append(time.time() - t0)
