@@ -568,12 +568,18 @@ class FusedGcnSageStep(TrainStep):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._adam_state()
-        in_graph_adam = not self.distributed          # the all-reduce sits between backward and Adam, eagerly
-        split = self.distributed and self._dp_split
+        # GTE_DP_GRAPH_COLLECTIVE=1 (experimental, off): the RCCL all-reduce is captured INSIDE the step's HIP graph, so a
+        # data-parallel step is one graph launch like the single-GPU step.  Verified with one rank only (1-GPU boxes).
+        graph_coll = self.distributed and os.environ.get("GTE_DP_GRAPH_COLLECTIVE", "0") == "1"
+        in_graph_adam = (not self.distributed) or graph_coll   # otherwise the all-reduce sits between backward and Adam, eagerly
+        split = self.distributed and self._dp_split and not graph_coll
         graph = torch.cuda.CUDAGraph()
         graph_b = torch.cuda.CUDAGraph() if split else None
         with torch.cuda.graph(graph):
             out3 = self.forward_backward(g, labels, scale, upto_layer=1 if split else 0)
+            if graph_coll:
+                import torch.distributed as dist
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             if in_graph_adam:
                 self._adam_dev_launch()               # reads lr / step count from device memory at replay time
         if split:                                     # layer 0's backward: replayed while the upper slice is all-reduced
