@@ -343,12 +343,24 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
             hv[s] = f2n{0.f, 0.f};
             if (colok) hv[s] = *reinterpret_cast<const f2n*>(h + (int64_t)min(row0 + 2 * s + hh, n - 1) * ldh + col);
         }
-        __syncthreads();                        // the previous block's D reads are done (and W image staged)
-        for (int idx = threadIdx.x; idx < 32 * KD; idx += 256) {
+        // the block's dl / q values are requested with the h rows (before the barrier), not after it: one exposed global
+        // latency per row block less
+        constexpr int ND = (32 * KD + 255) / 256;
+        float dv[ND];
+#pragma unroll
+        for (int t = 0; t < ND; ++t) {
+            const int idx = threadIdx.x + 256 * t;
             const int r = idx / KD, kk = idx - r * KD, c = kk < NCT ? kk : kk - NCT;
-            float v = 0.f;
-            if (row0 + r < n && c < C) v = kk < NCT ? dl[(int64_t)(row0 + r) * lddl + c] : q[(int64_t)(row0 + r) * ldq + c];
-            D[r * DP + kk] = v * alpha;
+            dv[t] = 0.f;
+            if (idx < 32 * KD && row0 + r < n && c < C)
+                dv[t] = kk < NCT ? dl[(int64_t)(row0 + r) * lddl + c] : q[(int64_t)(row0 + r) * ldq + c];
+        }
+        __syncthreads();                        // the previous block's D reads are done (and W image staged)
+#pragma unroll
+        for (int t = 0; t < ND; ++t) {
+            const int idx = threadIdx.x + 256 * t;
+            const int r = idx / KD, kk = idx - r * KD;
+            if (idx < 32 * KD) D[r * DP + kk] = dv[t] * alpha;
         }
         __syncthreads();
         if (wave == 0 && i < C && hh == 0) {
