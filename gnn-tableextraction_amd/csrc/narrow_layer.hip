@@ -289,20 +289,9 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
     constexpr int KD = 2 * NCT;                 // compact K of the dh product / M of the dW product
     constexpr int DP = KD + 1;                  // row stride of the DLQ image (odd: conflict-free read both ways)
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    // fused head (gte_head_agg_ce): dl / q arrive WITHOUT the 1 / sum(w) of the weighted cross-entropy; every block folds
-    // the CE partials itself (fixed order, same value everywhere) and scales its DLQ image; block 0 publishes out3
-    float alpha = 1.f;
-    if (ce_partial) {
-        __shared__ double ce_red[3][gte_ce::kCeBlock];
-        gte_ce::ce_fold(ce_partial, ce_blocks, ce_red);
-        const float wsum = (float)ce_red[1][0];
-        alpha = wsum > 0.f ? grad_scale / wsum : 0.f;
-        if (blockIdx.x == 0 && threadIdx.x == 0 && out3) gte_ce::ce_write_out3(ce_red, out3);
-    }
     const int FP = F + 4;
     float* Wst = sm;                            // [KD][FP]: row kk < NCT -> W_s row kk, NCT + c -> W_n row c
     float* D = sm + KD * FP;                    // [32][DP]
-    stage_w_image<KD, NCT>(Wst, FP, W, ldw, F, C);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, hh = lane >> 5;
     const int nblk = (n + 31) / 32;
     const int col = 64 * wave + 2 * i;          // this lane's two columns: col, col + 1
@@ -322,10 +311,49 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
         if (colok) { gam0 = lnb.gamma[col]; gam1 = lnb.gamma[col + 1]; bet0 = lnb.beta[col]; bet1 = lnb.beta[col + 1]; }
     }
 
+    // Row-block pipeline: the h rows (for the dW product) and the dl / q values of the NEXT row block are requested before
+    // the current block is computed; the first block's requests go out before the CE fold and the W image are done.
+    constexpr int ND = (32 * KD + 255) / 256;
+    f2n hvn[16];
+    float dvn[ND];
+    auto request = [&](int rbn) {
+        const int r0 = rbn * 32;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            hvn[s] = f2n{0.f, 0.f};
+            if (colok) hvn[s] = *reinterpret_cast<const f2n*>(h + (int64_t)min(r0 + 2 * s + hh, n - 1) * ldh + col);
+        }
+#pragma unroll
+        for (int t = 0; t < ND; ++t) {
+            const int idx = threadIdx.x + 256 * t;
+            const int r = idx / KD, kk = idx - r * KD, c = kk < NCT ? kk : kk - NCT;
+            dvn[t] = 0.f;
+            if (idx < 32 * KD && r0 + r < n && c < C)
+                dvn[t] = kk < NCT ? dl[(int64_t)(r0 + r) * lddl + c] : q[(int64_t)(r0 + r) * ldq + c];
+        }
+    };
+    if ((int)blockIdx.x < nblk) request(blockIdx.x);
+    // fused head (gte_head_agg_ce): dl / q arrive WITHOUT the 1 / sum(w) of the weighted cross-entropy; every block folds
+    // the CE partials itself (fixed order, same value everywhere) and scales its DLQ image; block 0 publishes out3
+    float alpha = 1.f;
+    if (ce_partial) {
+        __shared__ double ce_red[3][gte_ce::kCeBlock];
+        gte_ce::ce_fold(ce_partial, ce_blocks, ce_red);
+        const float wsum = (float)ce_red[1][0];
+        alpha = wsum > 0.f ? grad_scale / wsum : 0.f;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && out3) gte_ce::ce_write_out3(ce_red, out3);
+    }
+    stage_w_image<KD, NCT>(Wst, FP, W, ldw, F, C);
+
     for (int rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
         const int row0 = rb * 32;
-        // this block's h rows for the dW product: issued first, they land under the DLQ fill and the dh MFMAs
         f2n hv[16];
+        float dv[ND];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) hv[s] = hvn[s];
+#pragma unroll
+        for (int t = 0; t < ND; ++t) dv[t] = dvn[t];
+        if (rb + (int)gridDim.x < nblk) request(rb + gridDim.x);
         f2n zv[LNB ? 16 : 1];                   // LNB: the z values under this lane's dh elements
         float mu[LNB ? 16 : 1], rs[LNB ? 16 : 1];
         if constexpr (LNB) {
@@ -337,23 +365,6 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                 mu[r] = lnb.stats[rr];
                 rs[r] = lnb.stats[n + rr];
             }
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            hv[s] = f2n{0.f, 0.f};
-            if (colok) hv[s] = *reinterpret_cast<const f2n*>(h + (int64_t)min(row0 + 2 * s + hh, n - 1) * ldh + col);
-        }
-        // the block's dl / q values are requested with the h rows (before the barrier), not after it: one exposed global
-        // latency per row block less
-        constexpr int ND = (32 * KD + 255) / 256;
-        float dv[ND];
-#pragma unroll
-        for (int t = 0; t < ND; ++t) {
-            const int idx = threadIdx.x + 256 * t;
-            const int r = idx / KD, kk = idx - r * KD, c = kk < NCT ? kk : kk - NCT;
-            dv[t] = 0.f;
-            if (idx < 32 * KD && row0 + r < n && c < C)
-                dv[t] = kk < NCT ? dl[(int64_t)(row0 + r) * lddl + c] : q[(int64_t)(row0 + r) * ldq + c];
         }
         __syncthreads();                        // the previous block's D reads are done (and W image staged)
 #pragma unroll
