@@ -127,7 +127,7 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
 //   state = {lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, sqrt(bc2)} for step t = *step_counter + 1.
 // The block that finishes LAST (ticket counter) advances the state to step t + 1: every block has read the state before it
 // takes its ticket, so the update cannot race with a reader.  bc in double like gte_adam_step's host side.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                 int64_t n, float* __restrict__ state, int64_t* __restrict__ step_counter, unsigned* __restrict__ ticket) {
     const float lr = state[0], b1 = state[1], b2 = state[2], eps = state[3], wd = state[4], grad_scale = state[5];
@@ -236,8 +236,10 @@ extern "C" int gte_adam_step_dev(float* param, const float* grad, float* exp_avg
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: null pointer");
     // one ticket atomic per block on a single address: 2048 blocks spent 25 us queueing on it; 256 blocks (a grid-stride
     // loop over ~2300 elements per block at 590 k parameters) keep the 16 MB update at ~5 us
-    const int64_t blocks = gte::ceil_div(n, 1024) < 256 ? gte::ceil_div(n, 1024) : 256;
-    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, gte::as_stream(stream), param, grad, exp_avg,
+    // 1024 threads per block: at 590 k parameters every thread updates ONE 16-byte group (a 256-thread block looped 2-3
+    // times through dependent load -> store chains: 10 us)
+    const int64_t blocks = gte::ceil_div(n, 4096) < 256 ? gte::ceil_div(n, 4096) : 256;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(1024), 0, gte::as_stream(stream), param, grad, exp_avg,
                        exp_avg_sq, n, state, step_counter, ticket);
     return gte::check_launch("adam_step_dev");
 }
