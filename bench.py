@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the F0=13 (BBOX features only) variant of cfg2")
     ap.add_argument("--gather-nodes", type=int, default=1_000_000)
     ap.add_argument("--val-graph", type=int, default=0, metavar="PAGES",
                     help="also time the forward-only pass over PAGES pages batched into one graph (cfg2 'val graph': 2000)")
@@ -150,6 +151,35 @@ def val_graph_probe(args, gte, S, model, dev):
     return {"workload": f"val graph: {args.val_graph} pages in one graph, forward only (eval, no_grad), F0={args.in_feats}",
             "nodes": n, "edges": int(len(src)), "ms_per_forward": ms, "nodes_per_s": n / (ms * 1e-3),
             "host_build_s": build_s, "logits_finite": bool(torch.isfinite(logits).all())}
+
+
+def secondary_probe(args, gte, S, dev):
+    """SURVEY 8(d) cfg2, secondary width: the same step with BBOX features only (F0 = 13; 16 of the reference's 96 ablation
+    runs).  Same pages, same model sizes otherwise; resident batches, HIP-graph replay; a short run of its own."""
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    a = argparse.Namespace(**vars(args))
+    a.in_feats, a.batches = 13, 2
+    batches = build_batches(S, gte, a, 0, dev)
+    torch.manual_seed(42)
+    model = gte.GcnSAGE(13, args.hidden, 9, args.layers, torch.nn.functional.relu, 0).to(dev)
+    trainer = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+    replays = [trainer.capture(g, y) for g, y, _ in batches]
+    for i in range(8):
+        replays[i % 2]()
+    torch.cuda.synchronize()
+    steps = 40
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out3 = replays[i % 2]()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    nodes = sum(batches[i % 2][0].num_nodes() for i in range(steps))
+    dims = [13] + [args.hidden] * (args.layers - 1) + [9]
+    flops_node = sum(2.0 * 2 * dims[l] * dims[l + 1] * (3 if l > 0 else 2) for l in range(args.layers))
+    return {"workload": f"cfg2 secondary: F0=13 (BBOX features only), {args.pages} pages per step, hidden={args.hidden}",
+            "value": nodes / el, "unit": "nodes/s", "steps": steps, "ms_per_step": el / steps * 1e3,
+            "final_loss": float(out3[0]), "mfma_bound_nodes_per_s": MFMA_F32_PEAK_TF * 1e12 / flops_node,
+            "frac_of_mfma_bound": nodes / el / (MFMA_F32_PEAK_TF * 1e12 / flops_node)}
 
 
 def gather_probe(args, gte, S, dev):
@@ -362,6 +392,8 @@ def main():
                                  "frac": line["value"] / min(mfma_bound, hbm_bound)}
         if world == 1 and not args.no_gather_probe:
             line["gather"] = gather_probe(args, gte, S, dev)
+        if world == 1 and not distributed and not args.no_secondary and args.in_feats != 13:
+            line["secondary"] = secondary_probe(args, gte, S, dev)
         if world == 1 and args.val_graph > 0:
             line["val_graph"] = val_graph_probe(args, gte, S, model, dev)
         if world == 1 and not args.no_cpu_baseline:

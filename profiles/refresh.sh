@@ -11,10 +11,10 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python3 $R/bench.py > $O/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/trace_step -o t -- python3 $R/bench.py --no-cpu-baseline --no-gather-probe > $O/bench_trace_step.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace_step -o t -- python3 $R/bench.py --no-cpu-baseline --no-gather-probe --no-secondary > $O/bench_trace_step.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $O/full/pmc_$C -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_$C.log 2>&1
-  rocprofv3 --pmc $C --kernel-trace -d $O/step/pmc_$C -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-gather-probe > $O/pmc_step_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace -d $O/full/pmc_$C -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-secondary > $O/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace -d $O/step/pmc_$C -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-gather-probe --no-secondary > $O/pmc_step_$C.log 2>&1
 done
 cd $R
 python3 profiles/rocpd_summary.py $(ls $O/trace/*.db | head -1) $O/final_kernel_stats.csv > /dev/null
