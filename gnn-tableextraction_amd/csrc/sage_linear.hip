@@ -1218,6 +1218,116 @@ int ln_bwd_blocks(int64_t M) {
     return (int)(b < LNB_MAX_BLOCKS ? b : LNB_MAX_BLOCKS);
 }
 
+// ---- short-K layer (BBOX features: 13 + 13 inputs): linear + bias + LayerNorm + ReLU in ONE pass ------------------------
+// z[r, :] = a1[r, 0:k1] W[:, 0:k1]^T + a2[r, 0:k2] W[:, k1:K]^T + bias,   K = k1 + k2 <= 64, n_out % 4 == 0, n_out <= 256.
+// As a tiled MFMA GEMM this shape is all fixed cost (one K stage per tile: 20.8 us at 24.5 k x 256, K = 26) and the LayerNorm
+// is a second pass over z (11.6 us).  Here W^T sits in LDS ([K][n_out], read as one ds_read_b128 per k for four rows), lane l
+// owns output columns 4 l .. 4 l + 3 of four rows at a time, the rows' inputs are fetched by lanes 0 .. K-1 (one coalesced load
+// per row) and broadcast with v_readlane (scalar operand of the FMAs); LayerNorm statistics, affine and ReLU follow in
+// registers with the arithmetic of ln_relu_fwd_vec_kernel.  HBM-bound: N (K + 2 n_out) 4 bytes.
+constexpr int SMALLK_MAX = 64;
+constexpr int SMALLK_ROWS = 4;
+
+__global__ void __launch_bounds__(256)
+sage_smallk_fwd_kernel(const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ a2, int64_t lda2, int k2,
+                       const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
+                       float* __restrict__ z_save, int64_t ldz, float* __restrict__ stats, float* __restrict__ y, int64_t ldy,
+                       int M, int n) {
+    extern __shared__ __attribute__((aligned(16))) float Wt[];         // [K][n]
+    const int K = k1 + k2;
+    for (int idx = threadIdx.x; idx < K * n; idx += 256) {
+        const int c = idx / K, k = idx - c * K;
+        Wt[k * n + c] = W[(int64_t)c * ldw + k];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = 4 * lane;
+    const bool ok = j < n;
+    const bool ln = gamma != nullptr;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f}, g4[4] = {0.f, 0.f, 0.f, 0.f}, be4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (bias) b4[e] = bias[j + e];
+            if (ln) { g4[e] = gamma[j + e]; be4[e] = beta[j + e]; }
+        }
+    }
+    const float inv_n = 1.0f / (float)n;
+    const float* wl = Wt + (ok ? j : 0);
+    const int nquad = (M + SMALLK_ROWS - 1) / SMALLK_ROWS;
+    for (int qd = blockIdx.x * 4 + wave; qd < nquad; qd += gridDim.x * 4) {
+        const int row0 = qd * SMALLK_ROWS;
+        float xv[SMALLK_ROWS];
+#pragma unroll
+        for (int u = 0; u < SMALLK_ROWS; ++u) {
+            const int r = min(row0 + u, M - 1);
+            xv[u] = 0.f;
+            if (lane < k1) xv[u] = a1[(int64_t)r * lda1 + lane];
+            else if (lane < K) xv[u] = a2[(int64_t)r * lda2 + (lane - k1)];
+        }
+        float acc[SMALLK_ROWS][4];
+#pragma unroll
+        for (int u = 0; u < SMALLK_ROWS; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[u][e] = b4[e];
+#pragma unroll
+        for (int k = 0; k < SMALLK_MAX; ++k) {
+            if (k < K) {                                               // wave-uniform
+                const float4 w4 = *reinterpret_cast<const float4*>(wl + k * n);
+#pragma unroll
+                for (int u = 0; u < SMALLK_ROWS; ++u) {
+                    const float xs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[u]), k));
+                    acc[u][0] = fmaf(xs, w4.x, acc[u][0]); acc[u][1] = fmaf(xs, w4.y, acc[u][1]);
+                    acc[u][2] = fmaf(xs, w4.z, acc[u][2]); acc[u][3] = fmaf(xs, w4.w, acc[u][3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SMALLK_ROWS; ++u) {
+            const int r = row0 + u;
+            if (r >= M) continue;                                      // wave-uniform
+            if (!ln) {
+                if (ok) {
+                    f4u t;
+                    t.x = relu ? fmaxf(acc[u][0], 0.f) : acc[u][0]; t.y = relu ? fmaxf(acc[u][1], 0.f) : acc[u][1];
+                    t.z = relu ? fmaxf(acc[u][2], 0.f) : acc[u][2]; t.w = relu ? fmaxf(acc[u][3], 0.f) : acc[u][3];
+                    *reinterpret_cast<f4u*>(y + (int64_t)r * ldy + j) = t;
+                }
+                continue;
+            }
+            if (z_save && ok) {
+                f4u t; t.x = acc[u][0]; t.y = acc[u][1]; t.z = acc[u][2]; t.w = acc[u][3];
+                *reinterpret_cast<f4u*>(z_save + (int64_t)r * ldz + j) = t;
+            }
+            float sm = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sm += ok ? acc[u][e] : 0.f;
+            const float mean = wave_sum(sm) * inv_n;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = ok ? acc[u][e] - mean : 0.f; q = fmaf(d, d, q); }
+            const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+            if (stats && lane == 0) { stats[r] = mean; stats[M + r] = rstd; }
+            if (ok) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = ln_affine((acc[u][e] - mean) * rstd, g4[e], be4[e]);
+                    if (relu) o[e] = fmaxf(o[e], 0.f);
+                }
+                f4u t; t.x = o[0]; t.y = o[1]; t.z = o[2]; t.w = o[3];
+                *reinterpret_cast<f4u*>(y + (int64_t)r * ldy + j) = t;
+            }
+        }
+    }
+}
+
+bool smallk_supported(int64_t K, int64_t n_out) {
+    static const bool off = getenv("GTE_SMALLK") && getenv("GTE_SMALLK")[0] == '0';
+    return !off && K >= 1 && K <= SMALLK_MAX && n_out % 4 == 0 && n_out >= 4 && n_out <= 256;
+}
+
 void launch_ln_fwd(const float* z, int64_t ldz, const float* gamma, const float* beta, float eps, int relu, float* y,
                    int64_t ldy, float* stats, int64_t M, int64_t n_out, hipStream_t s) {
     if (n_out % 4 == 0 && n_out >= 128 && n_out <= 512) {          // 16-byte accesses, two rows per wave
@@ -1408,6 +1518,15 @@ extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, co
     if (gamma && !beta) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: gamma without beta");
     hipStream_t s = gte::as_stream(stream);
     const bool ln = gamma != nullptr;
+    if (smallk_supported(k1 + k2, n_out) && !(!ln && z_save && z_save != y)) {
+        const int64_t quads = gte::ceil_div(M, SMALLK_ROWS);
+        const int64_t cap = 2 * (int64_t)gte::device_props().cus;
+        const unsigned blocks = (unsigned)(gte::ceil_div(quads, 4) < cap ? gte::ceil_div(quads, 4) : cap);
+        hipLaunchKernelGGL(sage_smallk_fwd_kernel, dim3(blocks), dim3(256), (size_t)((k1 + k2) * n_out) * sizeof(float), s, a1,
+                           lda1, (int)k1, a2, lda2, (int)k2, W, ldw, bias, gamma, beta, eps, relu, z_save, ldz, stats, y, ldy,
+                           (int)M, (int)n_out);
+        return gte::check_launch("sage_smallk_fwd");
+    }
     // z goes to z_save when the backward needs it, else straight into y (LayerNorm then runs in place)
     float* zbuf = (ln && z_save) ? z_save : y;
     const int64_t ldzz = (ln && z_save) ? ldz : ldy;
@@ -1440,6 +1559,8 @@ extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, co
     }
     return GTE_OK;
 }
+
+extern "C" int gte_sage_linear_fwd_fuses_ln(int64_t k_total, int64_t n_out) { return smallk_supported(k_total, n_out) ? 1 : 0; }
 
 extern "C" int gte_ln_relu_fwd(const float* z, int64_t ldz, const float* gamma, const float* beta, float eps, int relu,
                                float* y, int64_t ldy, float* stats, int64_t M, int64_t n_out, void* stream) {

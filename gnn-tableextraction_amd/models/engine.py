@@ -349,6 +349,13 @@ class FusedGcnSageStep(TrainStep):
                 h = y
                 continue
             aggregate(csr, w_in, t_in, h, ld(h), ahn, fin, fin, _lib.REDUCE_MEAN, False)
+            if ln and lib.gte_sage_linear_fwd_fuses_ln(2 * fin, fout):
+                # short K (BBOX features, 13 + 13 inputs): linear + LayerNorm + ReLU in one pass over the rows
+                check(lib.gte_sage_linear_fwd(P(h), ld(h), fin, P(ahn), fin, fin, P(W), 2 * fin, P(bias), P(L.lynorm.weight),
+                                              P(L.lynorm.bias), float(L.lynorm.eps), int(relu), P(b["z"][i]), fout,
+                                              P(b["stats"][i]), P(y), fout, n, fout, st), "gte_sage_linear_fwd")
+                h = y
+                continue
             lin_out = b["z"][i] if ln else y
             with timed("gemm_nt", 4.0 * n * fin * fout) as tm:
                 for _ in tm.repeat():

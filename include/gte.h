@@ -147,6 +147,9 @@ int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1,
                         const float* gamma, const float* beta, float eps, int relu,
                         float* z_save, int64_t ldz, float* stats,
                         float* y, int64_t ldy, int64_t M, int64_t n_out, void* stream);
+/* 1 when gte_sage_linear_fwd runs this shape as ONE pass (linear + LayerNorm + ReLU: k1 + k2 <= 64, n_out % 4 == 0,
+ * n_out <= 256 -- the BBOX-only input layer, F0 = 13), 0 when it is an MFMA GEMM followed by the LayerNorm launch. */
+int gte_sage_linear_fwd_fuses_ln(int64_t k_total, int64_t n_out);
 
 /* Weight gradient of the split-weight linear, both halves in ONE launch:
  *   dW[n_out, k1+k2] = dZ[M, n_out]^T * [x1[M,k1] | x2[M,k2]]        (autograd of models.py:63 w.r.t. the weight)

@@ -206,7 +206,10 @@ def test_gemm_exact_small_integers_and_strided_views():
 @pytest.mark.parametrize("m,k1,k2,n_out,ln,relu", [
     (500, 13, 13, 256, True, True), (500, 831, 831, 256, True, True), (333, 256, 256, 9, False, False),
     (100, 64, 0, 32, True, False), (77, 20, 20, 218, True, True), (64, 50, 50, 1000, True, True),
-    (40, 16, 16, 24, False, True), (3000, 96, 96, 96, True, True)])
+    (40, 16, 16, 24, False, True), (3000, 96, 96, 96, True, True),
+    # short K (k1 + k2 <= 64, n_out % 4 == 0, n_out <= 256): the one-pass linear + LayerNorm + ReLU kernel
+    (24495, 13, 13, 256, True, True), (1001, 32, 32, 128, True, False), (7, 5, 0, 8, True, True), (2, 1, 1, 4, False, False),
+    (333, 13, 13, 200, True, True), (64, 33, 32, 256, True, True)])
 def test_sage_linear_fwd_vs_torch(m, k1, k2, n_out, ln, relu):
     rng = np.random.default_rng(m + n_out)
     a1 = rng.standard_normal((m, k1)).astype(np.float32)
@@ -229,6 +232,7 @@ def test_sage_linear_fwd_vs_torch(m, k1, k2, n_out, ln, relu):
     if ln:
         np.testing.assert_allclose(zs.cpu().numpy(), z.numpy(), rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(st[:m].cpu().numpy(), z.mean(1).numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(st[m:2 * m].cpu().numpy(), (z.var(1, unbiased=False) + 1e-5).rsqrt().numpy(), rtol=1e-4)
 
 
 @pytest.mark.parametrize("ta,tb,m,n,k", [(False, True, 128 * 264, 128, 1024), (False, False, 64 * 520 - 5, 128, 831),
