@@ -1221,12 +1221,16 @@ int ln_bwd_blocks(int64_t M) {
 // ---- short-K layer (BBOX features: 13 + 13 inputs): linear + bias + LayerNorm + ReLU in ONE pass ------------------------
 // z[r, :] = a1[r, 0:k1] W[:, 0:k1]^T + a2[r, 0:k2] W[:, k1:K]^T + bias,   K = k1 + k2 <= 64, n_out % 4 == 0, n_out <= 256.
 // As a tiled MFMA GEMM this shape is all fixed cost (one K stage per tile: 20.8 us at 24.5 k x 256, K = 26) and the LayerNorm
-// is a second pass over z (11.6 us).  Here W^T sits in LDS ([K][n_out], read as one ds_read_b128 per k for four rows), lane l
-// owns output columns 4 l .. 4 l + 3 of four rows at a time, the rows' inputs are fetched by lanes 0 .. K-1 (one coalesced load
-// per row) and broadcast with v_readlane (scalar operand of the FMAs); LayerNorm statistics, affine and ReLU follow in
-// registers with the arithmetic of ln_relu_fwd_vec_kernel.  HBM-bound: N (K + 2 n_out) 4 bytes.
+// is a second pass over z (11.6 us).  Here a workgroup owns 64 consecutive rows: W^T ([Kp][n_out]) and the rows' inputs
+// ([64][Kp], Kp = K rounded up to 4, padding zero) are staged in LDS once -- every global latency of the workgroup is paid in
+// that prologue; lane l owns output columns 4 l .. 4 l + 3 of four rows at a time, a k step of four is 4 + 4 ds_read_b128
+// (the input reads are same-address broadcasts) and 32 packed FMAs; LayerNorm statistics, affine and ReLU follow in
+// registers with the arithmetic of ln_relu_fwd_vec_kernel.  HBM-bound in principle (N (K + 2 n_out) 4 bytes = 50 MB at 24.5 k x
+// 256); measured 24 us (GEMM + LayerNorm launches: 32 us) -- the per-workgroup transposing fill of W^T (each of 383
+// workgroups walks all 256 rows of W) and the short dependent phases of a 16-rows-per-wave workgroup are what is left.
 constexpr int SMALLK_MAX = 64;
-constexpr int SMALLK_ROWS = 4;
+constexpr int SMALLK_ROWS = 4;            // rows per wave step
+constexpr int SMALLK_BLOCK_ROWS = 64;     // rows per workgroup: 4 waves x 4 steps x 4 rows
 
 __global__ void __launch_bounds__(256)
 sage_smallk_fwd_kernel(const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ a2, int64_t lda2, int k2,
@@ -1234,11 +1238,43 @@ sage_smallk_fwd_kernel(const float* __restrict__ a1, int64_t lda1, int k1, const
                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
                        float* __restrict__ z_save, int64_t ldz, float* __restrict__ stats, float* __restrict__ y, int64_t ldy,
                        int M, int n) {
-    extern __shared__ __attribute__((aligned(16))) float Wt[];         // [K][n]
-    const int K = k1 + k2;
-    for (int idx = threadIdx.x; idx < K * n; idx += 256) {
-        const int c = idx / K, k = idx - c * K;
-        Wt[k * n + c] = W[(int64_t)c * ldw + k];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int K = k1 + k2, Kp = (K + 3) & ~3;
+    const int ns = n;                                                  // W^T row stride
+    float* Wt = sm;                                                    // [Kp][ns], rows K .. Kp-1 zero
+    float* xs = sm + Kp * ns;                                          // [64][Kp], columns K .. Kp-1 zero
+    const int brow0 = blockIdx.x * SMALLK_BLOCK_ROWS;
+    // Transposing fill without index divisions: thread c walks row c of W (its own 4 K-byte run: L1 hits after the first
+    // touch) and writes column c of W^T -- consecutive lanes, consecutive LDS words.  (Lanes along a W row instead: every LDS
+    // write of a wave hits one bank, 4 M conflict cycles per launch; a flat index with / and %: ~50 VALU per element.)
+    // All loads of a thread are requested before its first LDS store (unrolled to the maximal K with uniform guards): a
+    // load -> store loop with a runtime trip count paid one global latency per element (26 x ~0.5 us: most of the kernel).
+    {
+        float wv[SMALLK_MAX];
+        const float* wr = W + (int64_t)min((int)threadIdx.x, n - 1) * ldw;
+#pragma unroll
+        for (int k = 0; k < SMALLK_MAX; ++k) wv[k] = k < K ? wr[k] : 0.f;
+        float xv[SMALLK_MAX / 4];
+        const int rl = threadIdx.x >> 2, part = threadIdx.x & 3;       // 4 threads per input row
+        const int r = min(brow0 + rl, M - 1);
+        const float* r1 = a1 + (int64_t)r * lda1;
+        const float* r2 = a2 ? a2 + (int64_t)r * lda2 : a1;
+#pragma unroll
+        for (int i = 0; i < SMALLK_MAX / 4; ++i) {
+            const int k = part + 4 * i;
+            xv[i] = 0.f;
+            if (k < k1) xv[i] = r1[k];
+            else if (k < K) xv[i] = r2[k - k1];
+        }
+        if ((int)threadIdx.x < n) {
+#pragma unroll
+            for (int k = 0; k < SMALLK_MAX; ++k) if (k < Kp) Wt[k * ns + threadIdx.x] = wv[k];
+        }
+#pragma unroll
+        for (int i = 0; i < SMALLK_MAX / 4; ++i) {
+            const int k = part + 4 * i;
+            if (k < Kp) xs[rl * Kp + k] = xv[i];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1255,31 +1291,29 @@ sage_smallk_fwd_kernel(const float* __restrict__ a1, int64_t lda1, int k1, const
     }
     const float inv_n = 1.0f / (float)n;
     const float* wl = Wt + (ok ? j : 0);
-    const int nquad = (M + SMALLK_ROWS - 1) / SMALLK_ROWS;
-    for (int qd = blockIdx.x * 4 + wave; qd < nquad; qd += gridDim.x * 4) {
-        const int row0 = qd * SMALLK_ROWS;
-        float xv[SMALLK_ROWS];
-#pragma unroll
-        for (int u = 0; u < SMALLK_ROWS; ++u) {
-            const int r = min(row0 + u, M - 1);
-            xv[u] = 0.f;
-            if (lane < k1) xv[u] = a1[(int64_t)r * lda1 + lane];
-            else if (lane < K) xv[u] = a2[(int64_t)r * lda2 + (lane - k1)];
-        }
+    for (int step = 0; step < SMALLK_BLOCK_ROWS / (4 * SMALLK_ROWS); ++step) {
+        const int rl0 = (step * 4 + wave) * SMALLK_ROWS;              // first of this wave's four rows, workgroup-local
+        const int row0 = brow0 + rl0;
+        if (row0 >= M) break;                                          // wave-uniform
         float acc[SMALLK_ROWS][4];
 #pragma unroll
         for (int u = 0; u < SMALLK_ROWS; ++u)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[u][e] = b4[e];
+        const float* xq = xs + rl0 * Kp;
+        for (int kc = 0; kc < Kp; kc += 4) {
+            float4 w4[4], x4[SMALLK_ROWS];
 #pragma unroll
-        for (int k = 0; k < SMALLK_MAX; ++k) {
-            if (k < K) {                                               // wave-uniform
-                const float4 w4 = *reinterpret_cast<const float4*>(wl + k * n);
+            for (int u = 0; u < SMALLK_ROWS; ++u) x4[u] = *reinterpret_cast<const float4*>(xq + u * Kp + kc);    // broadcast
 #pragma unroll
-                for (int u = 0; u < SMALLK_ROWS; ++u) {
-                    const float xs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[u]), k));
-                    acc[u][0] = fmaf(xs, w4.x, acc[u][0]); acc[u][1] = fmaf(xs, w4.y, acc[u][1]);
-                    acc[u][2] = fmaf(xs, w4.z, acc[u][2]); acc[u][3] = fmaf(xs, w4.w, acc[u][3]);
+            for (int i = 0; i < 4; ++i) w4[i] = *reinterpret_cast<const float4*>(wl + (kc + i) * ns);
+#pragma unroll
+            for (int u = 0; u < SMALLK_ROWS; ++u) {
+                const float xk[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[u][0] = fmaf(xk[i], w4[i].x, acc[u][0]); acc[u][1] = fmaf(xk[i], w4[i].y, acc[u][1]);
+                    acc[u][2] = fmaf(xk[i], w4[i].z, acc[u][2]); acc[u][3] = fmaf(xk[i], w4[i].w, acc[u][3]);
                 }
             }
         }
@@ -1300,10 +1334,10 @@ sage_smallk_fwd_kernel(const float* __restrict__ a1, int64_t lda1, int k1, const
                 f4u t; t.x = acc[u][0]; t.y = acc[u][1]; t.z = acc[u][2]; t.w = acc[u][3];
                 *reinterpret_cast<f4u*>(z_save + (int64_t)r * ldz + j) = t;
             }
-            float sm = 0.f;
+            float sm_ = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sm += ok ? acc[u][e] : 0.f;
-            const float mean = wave_sum(sm) * inv_n;
+            for (int e = 0; e < 4; ++e) sm_ += ok ? acc[u][e] : 0.f;
+            const float mean = wave_sum(sm_) * inv_n;
             float q = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = ok ? acc[u][e] - mean : 0.f; q = fmaf(d, d, q); }
@@ -1519,12 +1553,10 @@ extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, co
     hipStream_t s = gte::as_stream(stream);
     const bool ln = gamma != nullptr;
     if (smallk_supported(k1 + k2, n_out) && !(!ln && z_save && z_save != y)) {
-        const int64_t quads = gte::ceil_div(M, SMALLK_ROWS);
-        const int64_t cap = 2 * (int64_t)gte::device_props().cus;
-        const unsigned blocks = (unsigned)(gte::ceil_div(quads, 4) < cap ? gte::ceil_div(quads, 4) : cap);
-        hipLaunchKernelGGL(sage_smallk_fwd_kernel, dim3(blocks), dim3(256), (size_t)((k1 + k2) * n_out) * sizeof(float), s, a1,
-                           lda1, (int)k1, a2, lda2, (int)k2, W, ldw, bias, gamma, beta, eps, relu, z_save, ldz, stats, y, ldy,
-                           (int)M, (int)n_out);
+        const int64_t kp = (k1 + k2 + 3) & ~(int64_t)3;
+        hipLaunchKernelGGL(sage_smallk_fwd_kernel, dim3((unsigned)gte::ceil_div(M, SMALLK_BLOCK_ROWS)), dim3(256),
+                           (size_t)(kp * n_out + SMALLK_BLOCK_ROWS * kp) * sizeof(float), s, a1, lda1, (int)k1, a2, lda2, (int)k2,
+                           W, ldw, bias, gamma, beta, eps, relu, z_save, ldz, stats, y, ldy, (int)M, (int)n_out);
         return gte::check_launch("sage_smallk_fwd");
     }
     // z goes to z_save when the backward needs it, else straight into y (LayerNorm then runs in place)
