@@ -60,6 +60,10 @@ SIGNATURES = {
     "gte_sage_narrow_supported": (c_int, [c_int64, c_int64]),
     "gte_sage_narrow_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                     c_void_p, c_int64, c_int64, c_void_p]),
+    "gte_sage_narrow_fwd_ln_supported": (c_int, [c_int64, c_int64]),
+    "gte_sage_narrow_fwd_ln": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p,
+                                       c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                       c_void_p]),
     "gte_sage_narrow_bwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "gte_sage_narrow_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                     c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,

@@ -212,13 +212,24 @@ __device__ __forceinline__ void stage_w_image(float* __restrict__ img, int FP, c
     }
 }
 
+// LNF: the input is the PRE-LayerNorm z of the layer below; the kernel normalises its rows in registers (statistics and
+// affine arithmetic of ln_relu_fwd_vec_kernel; a row's two halves sit in lanes i and i + 32), writes y = relu?(LN(z)) and the
+// row statistics for the backward, and feeds the products from the normalised registers: the layer below needs no
+// LayerNorm launch (gte_sage_narrow_fwd_ln).
+struct LnForward { const float* gamma; const float* beta; float eps; int relu; float* y; int64_t ldy; float* stats; };
+
+template <bool LNF>
 __global__ void __launch_bounds__(256)
 narrow_fwd_mfma_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ W, int64_t ldw,
                        const float* __restrict__ bias, float* __restrict__ t_self, int64_t lds_,
-                       float* __restrict__ t_neigh, int64_t ldn, int n, int F, int C) {
+                       float* __restrict__ t_neigh, int64_t ldn, int n, int F, int C, const LnForward lnf) {
     extern __shared__ __attribute__((aligned(16))) float Wl[];     // [32][F + 4]: col c < 16 -> W_s row c, 16 + c -> W_n row c
-    const int FP = F + 4;
+    const int FP = F + 4;                                          // LNF: + gamma[F], beta[F] behind the image
     stage_w_image<32, 16>(Wl, FP, W, ldw, F, C);
+    float* GB = Wl + 32 * FP;
+    if constexpr (LNF) {
+        for (int k = threadIdx.x; k < F; k += blockDim.x) { GB[k] = lnf.gamma[k]; GB[F + k] = lnf.beta[k]; }
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, hh = lane >> 5;
     const int nblk = (n + 31) / 32, kbs = F / 8;
@@ -237,6 +248,37 @@ narrow_fwd_mfma_kernel(const float* __restrict__ h, int64_t ldh, const float* __
         f4n a[32];
 #pragma unroll
         for (int u = 0; u < 32; ++u) a[u] = *reinterpret_cast<const f4n*>(hp + min(u, kbs - 1) * 8);
+        if constexpr (LNF) {
+            float sm = 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) if (u < kbs) sm += (a[u].x + a[u].y) + (a[u].z + a[u].w);
+            sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm * (1.0f / (float)F);
+            float q = 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (u < kbs) {
+                    const float d0 = a[u].x - mean, d1 = a[u].y - mean, d2 = a[u].z - mean, d3 = a[u].w - mean;
+                    q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
+                }
+            q += __shfl_xor(q, 32, 64);
+            const float rstd = rsqrtf(q * (1.0f / (float)F) + lnf.eps);
+            const bool rowok = rb * 32 + i < n;
+            if (rowok && hh == 0 && lnf.stats) { lnf.stats[row] = mean; lnf.stats[n + row] = rstd; }
+            float* yp = lnf.y + (int64_t)row * lnf.ldy + hh * 4;
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (u < kbs) {
+                    const f32x4n g = *reinterpret_cast<const f32x4n*>(GB + u * 8 + hh * 4);
+                    const f32x4n b = *reinterpret_cast<const f32x4n*>(GB + F + u * 8 + hh * 4);
+                    f4n o;
+                    o.x = fmaf((a[u].x - mean) * rstd, g.x, b.x); o.y = fmaf((a[u].y - mean) * rstd, g.y, b.y);
+                    o.z = fmaf((a[u].z - mean) * rstd, g.z, b.z); o.w = fmaf((a[u].w - mean) * rstd, g.w, b.w);
+                    if (lnf.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    a[u] = o;
+                    if (rowok) *reinterpret_cast<f4n*>(yp + u * 8) = o;
+                }
+        }
 #pragma unroll
         for (int u = 0; u < 32; u += 2) {
             if (u < kbs) {
@@ -669,8 +711,9 @@ extern "C" int gte_sage_narrow_fwd(const float* h, int64_t ldh, int64_t n_feat, 
         // workgroup's life at one row block per wave (measured at 24 k nodes: 4 waves 19.5 us, 2 waves 23.0, 1 wave 27.4)
         const int wpb = 4;
         const int mb = (int)(gte::ceil_div(nblk, wpb) < 2048 ? gte::ceil_div(nblk, wpb) : 2048);
-        hipLaunchKernelGGL(narrow_fwd_mfma_kernel, dim3((unsigned)mb), dim3(64 * wpb), (size_t)32 * (n_feat + 4) * 4, s, h, ldh, W,
-                           ldw, bias, t_self, ld_self, t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out);
+        hipLaunchKernelGGL(narrow_fwd_mfma_kernel<false>, dim3((unsigned)mb), dim3(64 * wpb), (size_t)32 * (n_feat + 4) * 4, s, h,
+                           ldh, W, ldw, bias, t_self, ld_self, t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out,
+                           LnForward{});
         return gte::check_launch("sage_narrow_fwd");
     }
     const int blocks = (int)(gte::ceil_div(n_nodes, 4) < 2048 ? gte::ceil_div(n_nodes, 4) : 2048);
@@ -684,6 +727,31 @@ extern "C" int gte_sage_narrow_fwd(const float* h, int64_t ldh, int64_t n_feat, 
 #undef GTE_NF
 #undef GTE_NF2
     return gte::check_launch("sage_narrow_fwd");
+}
+
+extern "C" int gte_sage_narrow_fwd_ln_supported(int64_t n_feat, int64_t n_out) {
+    return (gte_sage_narrow_supported(n_feat, n_out) && n_feat % 8 == 0) ? 1 : 0;
+}
+
+extern "C" int gte_sage_narrow_fwd_ln(const float* z, int64_t ldz, int64_t n_feat, const float* gamma, const float* beta,
+                                      float eps, int relu, float* y, int64_t ldy, float* stats, const float* W, int64_t ldw,
+                                      const float* bias, int64_t n_out, float* t_self, int64_t ld_self, float* t_neigh,
+                                      int64_t ld_neigh, int64_t n_nodes, void* stream) {
+    if (!gte_sage_narrow_fwd_ln_supported(n_feat, n_out) || n_nodes < 0 || n_nodes > INT32_MAX)
+        return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_fwd_ln: needs n_out <= 16, n_feat <= 256, n_feat % 8 == 0");
+    if (n_nodes == 0) return GTE_OK;
+    if (!z || !gamma || !beta || !y || !W || !t_self || !t_neigh)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_fwd_ln: null pointer");
+    if (ldz < n_feat || ldy < n_feat || ldw < 2 * n_feat || ld_self < n_out || ld_neigh < n_out)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_fwd_ln: leading dimension too small");
+    const int64_t nblk = gte::ceil_div(n_nodes, 32);
+    const int wpb = 4;
+    const int mb = (int)(gte::ceil_div(nblk, wpb) < 2048 ? gte::ceil_div(nblk, wpb) : 2048);
+    const LnForward lnf = {gamma, beta, eps, relu, y, ldy, stats};
+    hipLaunchKernelGGL(narrow_fwd_mfma_kernel<true>, dim3((unsigned)mb), dim3(64 * wpb),
+                       (size_t)(32 * (n_feat + 4) + 2 * n_feat) * 4, gte::as_stream(stream), z, ldz, W, ldw, bias, t_self, ld_self,
+                       t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out, lnf);
+    return gte::check_launch("sage_narrow_fwd_ln");
 }
 
 extern "C" int64_t gte_sage_narrow_bwd_workspace_bytes(int64_t n_nodes, int64_t n_feat, int64_t n_out) {

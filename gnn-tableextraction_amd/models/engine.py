@@ -146,6 +146,9 @@ class FusedGcnSageStep(TrainStep):
         # 50 MB of traffic but serialises more work in one wave per SIMD: 41.6 us fused vs 22.4 + 16.6 us separate at
         # 24 k nodes -- off by default, kept (and tested) for a later retune
         self.fuse_ln_below = os.environ.get("GTE_FUSE_LN_BELOW", "0") == "1"
+        # LayerNorm(+ReLU) forward of the last hidden layer inside the output layer's forward kernel (gte_sage_narrow_fwd_ln):
+        # one launch and one pass over [n, hidden] less
+        self.fuse_ln_fwd = os.environ.get("GTE_FUSE_LN_FWD", "1") == "1"
         self._head_scale = None
         self._tail_ws = None
 
@@ -313,6 +316,7 @@ class FusedGcnSageStep(TrainStep):
         # ---------------- forward ----------------
         h = x
         fused_head = False
+        pending_ln = None            # (layer, z, y, stats) of a LayerNorm left to the output layer's forward kernel
         for i, L in enumerate(layers):
             fin, fout = h.shape[1], L.out_feats
             W, bias = L.linear.weight, L.linear.bias
@@ -322,8 +326,17 @@ class FusedGcnSageStep(TrainStep):
             if self._narrow(L, fin):
                 # class-count-wide layer: logits = h W_s^T + b + mean-aggregate(h W_n^T)  (aggregation on C columns)
                 with timed("narrow_fwd", 2.0 * n * fin * 4):
-                    check(lib.gte_sage_narrow_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(y), fout, P(b["tn"]),
-                                                  fout, n, st), "gte_sage_narrow_fwd")
+                    if pending_ln is not None:
+                        # the layer below left its pre-LayerNorm z: normalise, write y / stats and multiply in one pass
+                        Lb, zb, yb, sb = pending_ln
+                        check(lib.gte_sage_narrow_fwd_ln(P(zb), ld(zb), fin, P(Lb.lynorm.weight), P(Lb.lynorm.bias),
+                                                         float(Lb.lynorm.eps), int(Lb.activation is not None), P(yb), fin, P(sb),
+                                                         P(W), 2 * fin, P(bias), fout, P(y), fout, P(b["tn"]), fout, n, st),
+                              "gte_sage_narrow_fwd_ln")
+                        pending_ln = None
+                    else:
+                        check(lib.gte_sage_narrow_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(y), fout, P(b["tn"]),
+                                                      fout, n, st), "gte_sage_narrow_fwd")
                 fused_head = self._fused_head(i, L, fin)
                 if not fused_head:
                     aggregate(csr, w_in, None, b["tn"], fout, y, fout, fout, _lib.REDUCE_MEAN, True)
@@ -363,8 +376,13 @@ class FusedGcnSageStep(TrainStep):
                                                   1e-5, int(relu and not ln), None, 0, None, P(lin_out), fout, n, fout, st),
                           "gte_sage_linear_fwd")
             if ln:
-                check(lib.gte_ln_relu_fwd(P(lin_out), fout, P(L.lynorm.weight), P(L.lynorm.bias), float(L.lynorm.eps),
-                                          int(relu), P(y), fout, P(b["stats"][i]), n, fout, st), "gte_ln_relu_fwd")
+                nxt = layers[i + 1] if i + 1 < len(layers) else None
+                if (self.fuse_ln_fwd and nxt is not None and i + 1 == len(layers) - 1 and self._narrow(nxt, fout)
+                        and lib.gte_sage_narrow_fwd_ln_supported(fout, nxt.out_feats)):
+                    pending_ln = (L, lin_out, y, b["stats"][i])
+                else:
+                    check(lib.gte_ln_relu_fwd(P(lin_out), fout, P(L.lynorm.weight), P(L.lynorm.bias), float(L.lynorm.eps),
+                                              int(relu), P(y), fout, P(b["stats"][i]), n, fout, st), "gte_ln_relu_fwd")
             h = y
         logits = h
 

@@ -220,6 +220,15 @@ int gte_sage_narrow_supported(int64_t n_feat, int64_t n_out);
 int gte_sage_narrow_fwd(const float* h, int64_t ldh, int64_t n_feat, const float* W, int64_t ldw, const float* bias,
                         int64_t n_out, float* t_self, int64_t ld_self, float* t_neigh, int64_t ld_neigh,
                         int64_t n_nodes, void* stream);
+/* gte_sage_narrow_fwd on the output of a LayerNorm(+ReLU) that has not been applied yet: z is the pre-LayerNorm output of
+ * the layer below (models.py:63); the kernel writes y = relu?(LN(z)) (models.py:64-66) and stats = {mean[n], rstd[n]} for the
+ * backward and multiplies the normalised rows in the same pass -- one launch and one pass over [n, n_feat] less than
+ * gte_ln_relu_fwd + gte_sage_narrow_fwd.  n_feat % 8 == 0 (gte_sage_narrow_fwd_ln_supported). */
+int gte_sage_narrow_fwd_ln_supported(int64_t n_feat, int64_t n_out);
+int gte_sage_narrow_fwd_ln(const float* z, int64_t ldz, int64_t n_feat, const float* gamma, const float* beta, float eps,
+                           int relu, float* y, int64_t ldy, float* stats, const float* W, int64_t ldw, const float* bias,
+                           int64_t n_out, float* t_self, int64_t ld_self, float* t_neigh, int64_t ld_neigh, int64_t n_nodes,
+                           void* stream);
 int64_t gte_sage_narrow_bwd_workspace_bytes(int64_t n_nodes, int64_t n_feat, int64_t n_out);
 int gte_sage_narrow_bwd(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
                         int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dh, int64_t lddh,

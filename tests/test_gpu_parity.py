@@ -325,6 +325,42 @@ def test_qform_entry_points_vs_float64(n, f, o):
     assert float(dx[:, f:].min()) == 5.0
 
 
+@pytest.mark.parametrize("n,f,c,relu", [(1000, 256, 9, True), (333, 64, 4, False), (24495, 256, 9, True), (77, 128, 16, True),
+                                        (31, 8, 1, True), (2049, 200, 12, True)])
+def test_narrow_fwd_with_fused_layernorm_forward(n, f, c, relu):
+    """gte_sage_narrow_fwd_ln (LayerNorm + ReLU of the layer below inside the output layer's forward) against float64 and
+    against the two separate launches it replaces (gte_ln_relu_fwd + gte_sage_narrow_fwd)."""
+    lib = gte._lib.load()
+    P, cs, check = gte._lib.ptr, gte._lib.current_stream, gte._lib.check
+    rng = np.random.default_rng(n + f + c)
+    zbuf = dev((rng.standard_normal((n, f + 4)) * 1.5 + 0.3).astype(np.float32))
+    z = zbuf[:, :f]                                                   # row stride > width
+    gam, bet = dev((1 + 0.1 * rng.standard_normal(f)).astype(np.float32)), dev((0.1 * rng.standard_normal(f)).astype(np.float32))
+    W = dev((rng.standard_normal((c, 2 * f)) / np.sqrt(2 * f)).astype(np.float32))
+    bias = dev(rng.standard_normal(c).astype(np.float32))
+    y = torch.full((n, f), 7.0, device=DEV); stats = torch.zeros(2 * n, device=DEV)
+    ts, tn = torch.zeros(n, c, device=DEV), torch.zeros(n, c, device=DEV)
+    check(lib.gte_sage_narrow_fwd_ln(P(z), z.stride(0), f, P(gam), P(bet), 1e-5, int(relu), P(y), f, P(stats), P(W), 2 * f, P(bias),
+                                     c, P(ts), c, P(tn), c, n, cs()), "narrow_fwd_ln")
+    zd = z.double().cpu()
+    want_y = torch.nn.functional.layer_norm(zd, (f,), gam.double().cpu(), bet.double().cpu(), 1e-5)
+    if relu:
+        want_y = torch.relu(want_y)
+    Wd = W.double().cpu()
+    np.testing.assert_allclose(y.cpu().numpy(), want_y.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(stats[:n].cpu().numpy(), zd.mean(1).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(stats[n:].cpu().numpy(), (zd.var(1, unbiased=False) + 1e-5).rsqrt().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(ts.cpu().numpy(), (want_y @ Wd[:, :f].T + bias.double().cpu()).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tn.cpu().numpy(), (want_y @ Wd[:, f:].T).numpy(), rtol=1e-5, atol=1e-5)
+    # the two launches it replaces
+    y2 = torch.empty(n, f, device=DEV); st2 = torch.zeros(2 * n, device=DEV)
+    ts2, tn2 = torch.zeros(n, c, device=DEV), torch.zeros(n, c, device=DEV)
+    check(lib.gte_ln_relu_fwd(P(z), z.stride(0), P(gam), P(bet), 1e-5, int(relu), P(y2), f, P(st2), n, f, cs()), "ln")
+    check(lib.gte_sage_narrow_fwd(P(y2), f, f, P(W), 2 * f, P(bias), c, P(ts2), c, P(tn2), c, n, cs()), "narrow_fwd")
+    np.testing.assert_allclose(y.cpu().numpy(), y2.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ts.cpu().numpy(), ts2.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("n,f,c,relu", [(1000, 256, 9, True), (333, 64, 4, False), (24495, 256, 9, True), (77, 128, 16, True)])
 def test_narrow_bwd_with_fused_layernorm_backward(n, f, c, relu):
     """gte_sage_narrow_bwd_ln == gte_sage_narrow_bwd followed by gte_ln_relu_bwd of the layer below (dz, dgamma, dbeta,
