@@ -801,7 +801,7 @@ def test_spmm_tiled_full_chunk_kernel_randomised(seed):
     plan = ops.build_tile_plan(ip, ix, n)
     for f in rng.choice(np.arange(1, 17) * 32, size=4, replace=False):
         f = int(f)
-        pad = int(rng.integers(0, 3)) * 4
+        pad = int(rng.choice([0, 4, 8, 1, 3]))                       # row strides that are / are not a multiple of 16 bytes
         xs = torch.randn(n, f + pad, device=DEV)
         x = xs[:, :f]                                              # row stride > width
         a = ops.spmm_csr(ip, ix, wt, x, n, mean=True)
