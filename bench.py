@@ -1,21 +1,29 @@
 """nodes/sec of the GcnSAGE train step (fwd + loss + bwd + Adam) on synthetic PubLayNet-style page
 graphs -- the metric of BASELINE.json -- on N MI355X GPUs of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 without a torchrun environment: this process starts N fresh ranks itself (torch.distributed.run,
+      one per GPU, RCCL over xGMI) BEFORE it touches any GPU, relays rank 0's JSON line and exits with their code.
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (the driver's form)
 
-Workload (BASELINE.json configs[1] / SURVEY 8(d) cfg2): batches of 100 page graphs, 3-layer
-GraphSAGE-GCN, F0 = 831 (BBOX+REPR+SCIBERT), hidden 256, 9 classes, fp32, Adam(lr 0.01, wd 5e-4),
-unweighted cross-entropy.  Every rank owns DISTINCT pages (weak scaling); the only collective is
-one RCCL all-reduce of the flat gradient per step.  The batched graphs (CSR, features, labels) are
-resident in HBM before the timed region; a "step" = forward + loss + backward + optimiser on one
-resident batch.  One JSON line is printed by rank 0.
+Workload (BASELINE.json configs[1] / SURVEY 8(d) cfg2): batches of 100 page graphs, 3-layer GraphSAGE-GCN, F0 = 831
+(BBOX+REPR+SCIBERT), hidden 256, 9 classes, fp32, Adam(lr 0.01, wd 5e-4), unweighted cross-entropy.
+
+What is timed is the loop ``models.model_train.train`` runs (``models/loop.py: run_steps``, the same function): every
+step takes a DIFFERENT set of 100 pages out of the rank's resident dataset (shuffled epochs of
+``distributed.plan_epoch``, as model_train.py:279-283), the batched graph is assembled on the device on a side stream
+while the previous step runs, then forward + loss + backward + (all-reduce) + Adam.  The pages (features, labels, CSRs)
+are resident in HBM before the timed region.  Every rank owns DISTINCT pages (weak scaling); the only collective is one
+RCCL all-reduce of the flat gradient per step.  One JSON line is printed by rank 0.
 
 Extra objects in the JSON line:
-  roofline      dominant kernel (fp32 MFMA forward GEMM), live HIP-event timing over the timed region
+  roofline      dominant kernel (fp32 MFMA forward GEMM), live HIP-event timing of the same steps
+  long_run      the same loop for >= 1 s of device time (the driver's 20-step region is ~15 ms)
+  replay        secondary: HIP-graph replay of pre-captured resident batches (round 1's headline mode)
   gather        the aggregation kernel on BASELINE cfg4 (1 M nodes, deg 12, F = 512): HBM GB/s
-  cpu_baseline  the CPU oracle (oracle/gcnsage_cpu.py: torch-CPU + OpenMP CSR SpMM) on the same
-                first batch, on this box's host cores ("port"; baseline only)
+  val_graph     cfg2 "val graph" case: every page of a validation set in ONE graph, forward only (model_train.py:349-353)
+  cpu_baseline  the CPU oracle (oracle/gcnsage_cpu.py: torch-CPU + OpenMP CSR SpMM) on one batch, on this box's
+                host cores ("port"; baseline only)
 """
 import argparse
 import json
@@ -52,29 +60,86 @@ def parse():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--pages", type=int, default=100, help="page graphs per batch per GPU")
-    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches cycled through")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of HIP-graph replay")
+    ap.add_argument("--resident-pages", type=int, default=1200,
+                    help="pages of the resident dataset per GPU; an epoch is resident-pages / pages steps")
+    ap.add_argument("--long-run-seconds", type=float, default=1.0, help="device time of the secondary long run (0: skip)")
+    ap.add_argument("--no-replay", action="store_true", help="skip the HIP-graph replay secondary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the F0=13 (BBOX features only) variant of cfg2")
     ap.add_argument("--gather-nodes", type=int, default=1_000_000)
-    ap.add_argument("--val-graph", type=int, default=0, metavar="PAGES",
-                    help="also time the forward-only pass over PAGES pages batched into one graph (cfg2 'val graph': 2000)")
+    ap.add_argument("--val-graph", type=int, default=2000, metavar="PAGES",
+                    help="forward-only pass over PAGES pages batched into one graph (cfg2 'val graph'; 0: skip)")
     return ap.parse_args()
 
 
-def build_batches(S, gte, args, rank, dev):
-    batches = []
-    for b in range(args.batches):
-        first = (rank * args.batches + b) * args.pages
-        pages = S.make_pages(args.pages, in_feats=args.in_feats, first_id=first)
-        src, dst, w, feat, label, off = S.concat_pages(pages)
-        g = gte.PageGraph(src, dst, int(off[-1]), device=dev)
-        g.ndata["feat"] = torch.from_numpy(feat).to(dev)
-        g.edata["feat"] = torch.from_numpy(w).to(dev)
-        g.batch_num_nodes_ = [p.num_nodes for p in pages]
-        batches.append((g, torch.from_numpy(label).to(dev), (src, dst, w, feat, label, off)))
-    return batches
+def maybe_spawn(args):
+    """``python bench.py --gpus N`` outside torchrun: start N fresh ranks (one per GPU) and relay them.  Runs before this
+    process has made any HIP call -- a process that has initialised the GPU must never be replaced or forked into ranks."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}; they must agree")
+        return
+    if args.gpus <= 1:
+        return
+    share = os.environ.get("GTE_BENCH_SHARE_GPU", "0") == "1"
+    have = torch.cuda.device_count()             # counting devices does not initialise the GPU
+    if have < args.gpus and not share:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s)")
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
+    rc = subprocess.call(cmd, env=env)                       # the ranks inherit stdout: rank 0's JSON line is relayed as is
+    sys.exit(rc)
+
+
+def _make_page_job(job):
+    from gnn_tableextraction_amd.data import synthetic as S
+    pid, in_feats = job
+    return S.make_page(pid, in_feats=in_feats)
+
+
+def make_pages_parallel(n_pages, in_feats, first_id, workers):
+    """Synthetic pages on a process pool.  Called BEFORE the GPU is initialised (fork is only safe then)."""
+    from gnn_tableextraction_amd.data import synthetic as S
+    if workers <= 1 or n_pages < 64:
+        return S.make_pages(n_pages, in_feats=in_feats, first_id=first_id)
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_make_page_job, [(first_id + i, in_feats) for i in range(n_pages)], chunksize=8)
+
+
+def to_page_graphs(gte, pages):
+    """Host PageGraph per page with the loader's output contract (ndata feat/label, edata feat): loader.py:332-354."""
+    out = []
+    for p in pages:
+        g = gte.PageGraph(p.src, p.dst, p.num_nodes)
+        g.ndata["feat"] = torch.from_numpy(p.feat)
+        g.ndata["label"] = torch.from_numpy(p.label.astype(np.float32))      # stored as float32 (loader.py:350-354)
+        g.edata["feat"] = torch.from_numpy(p.weight)
+        out.append(g)
+    return out
+
+
+def epoch_steps(sizes, pages_per_step, seed, first_epoch, n_steps):
+    """n_steps page-id lists, epoch by epoch (distributed.plan_epoch: the shuffle + tail drop of model_train.py:279-283),
+    as a list of per-epoch lists (the last one may be a partial epoch).  Returns (epochs, next epoch number)."""
+    from gnn_tableextraction_amd import distributed as D
+    out, e = [], first_epoch
+    left = n_steps
+    while left > 0:
+        plan = [ranks[0] for ranks in D.plan_epoch(sizes, pages_per_step, 1, seed=seed, epoch=e)]
+        out.append(plan[:left])
+        left -= len(out[-1])
+        e += 1
+    return out, e
 
 
 def usable_cores() -> int:
@@ -120,19 +185,14 @@ def cpu_baseline(args, host_batch, state):
             "ms_per_step": med * 1e3}
 
 
-def val_graph_probe(args, gte, S, model, dev):
-    """SURVEY 8(d) cfg2, "val graph" case (model_train.py:349-370): every page of a validation set batched into ONE graph,
-    forward only (no_grad, eval mode) -- the reference evaluates on the single giant val_graph after each epoch.
-    Opt-in (--val-graph PAGES): building the synthetic pages on the host takes longer than the whole default bench."""
-    import time as _t
-    t0 = _t.perf_counter()
-    pages = S.make_pages(args.val_graph, in_feats=args.in_feats, first_id=10_000_000)
+def val_graph_probe(args, gte, S, model, dev, pages):
+    """SURVEY 8(d) cfg2, "val graph" case (model_train.py:246,349-353): every page of a validation set batched into ONE
+    graph, forward only (no_grad, eval mode) -- the reference evaluates on the single giant val_graph after each epoch."""
     src, dst, w, feat, label, off = S.concat_pages(pages)
     n = int(off[-1])
     g = gte.PageGraph(src, dst, n, device=dev)
     g.ndata["feat"] = torch.from_numpy(feat).to(dev)
     g.edata["feat"] = torch.from_numpy(w).to(dev)
-    build_s = _t.perf_counter() - t0
     was_training = model.training
     model.eval()
     with torch.no_grad():
@@ -148,38 +208,63 @@ def val_graph_probe(args, gte, S, model, dev):
         torch.cuda.synchronize()
     model.train(was_training)
     ms = s.elapsed_time(e) / reps
-    return {"workload": f"val graph: {args.val_graph} pages in one graph, forward only (eval, no_grad), F0={args.in_feats}",
+    return {"workload": f"val graph: {len(pages)} pages in one graph, forward only (eval, no_grad), F0={args.in_feats}",
             "nodes": n, "edges": int(len(src)), "ms_per_forward": ms, "nodes_per_s": n / (ms * 1e-3),
-            "host_build_s": build_s, "logits_finite": bool(torch.isfinite(logits).all())}
+            "logits_finite": bool(torch.isfinite(logits).all())}
 
 
-def secondary_probe(args, gte, S, dev):
-    """SURVEY 8(d) cfg2, secondary width: the same step with BBOX features only (F0 = 13; 16 of the reference's 96 ablation
-    runs).  Same pages, same model sizes otherwise; resident batches, HIP-graph replay; a short run of its own."""
+def timed_loop(trainer, pipe, epochs, loop):
+    """run_steps over the given per-epoch page lists; returns (seconds, nodes, last out3).  Synchronises both ends."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nodes, out3 = 0, None
+    for plan in epochs:
+        out3 = loop.run_steps(trainer, pipe, plan)
+        nodes += sum(pipe.nodes(i) for i in range(len(plan)))
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, nodes, out3
+
+
+def secondary_probe(args, gte, S, dev, pages13):
+    """SURVEY 8(d) cfg2, secondary width: the same loop with BBOX features only (F0 = 13; 16 of the reference's 96
+    ablation runs).  Same model sizes otherwise; a short run of its own."""
+    from gnn_tableextraction_amd import graph as G
+    from gnn_tableextraction_amd.models import loop
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
-    a = argparse.Namespace(**vars(args))
-    a.in_feats, a.batches = 13, 2
-    batches = build_batches(S, gte, a, 0, dev)
+    resident = G.ResidentPages(to_page_graphs(gte, pages13), dev)
+    pipe = loop.BatchPipeline(resident)
     torch.manual_seed(42)
     model = gte.GcnSAGE(13, args.hidden, 9, args.layers, torch.nn.functional.relu, 0).to(dev)
     trainer = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
-    replays = [trainer.capture(g, y) for g, y, _ in batches]
+    sizes = resident.page_sizes()
+    warm, e = epoch_steps(sizes, args.pages, 42, 0, 8)
+    timed_loop(trainer, pipe, warm, loop)
+    steps = 40
+    epochs, e = epoch_steps(sizes, args.pages, 42, e, steps)
+    el, nodes, out3 = timed_loop(trainer, pipe, epochs, loop)
+    dims = [13] + [args.hidden] * (args.layers - 1) + [9]
+    flops_node = sum(2.0 * 2 * dims[l] * dims[l + 1] * (3 if l > 0 else 2) for l in range(args.layers))
+    out = {"workload": f"cfg2 secondary: F0=13 (BBOX features only), {args.pages} pages per step, hidden={args.hidden}; "
+                       f"train loop (a different device-built batch per step)",
+           "value": nodes / el, "unit": "nodes/s", "steps": steps, "ms_per_step": el / steps * 1e3,
+           "final_loss": float(out3[0]), "mfma_bound_nodes_per_s": MFMA_F32_PEAK_TF * 1e12 / flops_node,
+           "frac_of_mfma_bound": nodes / el / (MFMA_F32_PEAK_TF * 1e12 / flops_node)}
+    # HIP-graph replay of two resident batches (no batch assembly, no per-kernel launches): the device-time floor
+    fixed = [resident.batch(ids) for ids in epochs[0][:2]]
+    replays = [trainer.capture(g, g.ndata["label"]) for g in fixed]
     for i in range(8):
         replays[i % 2]()
     torch.cuda.synchronize()
-    steps = 40
     t0 = time.perf_counter()
     for i in range(steps):
-        out3 = replays[i % 2]()
+        replays[i % 2]()
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    nodes = sum(batches[i % 2][0].num_nodes() for i in range(steps))
-    dims = [13] + [args.hidden] * (args.layers - 1) + [9]
-    flops_node = sum(2.0 * 2 * dims[l] * dims[l + 1] * (3 if l > 0 else 2) for l in range(args.layers))
-    return {"workload": f"cfg2 secondary: F0=13 (BBOX features only), {args.pages} pages per step, hidden={args.hidden}",
-            "value": nodes / el, "unit": "nodes/s", "steps": steps, "ms_per_step": el / steps * 1e3,
-            "final_loss": float(out3[0]), "mfma_bound_nodes_per_s": MFMA_F32_PEAK_TF * 1e12 / flops_node,
-            "frac_of_mfma_bound": nodes / el / (MFMA_F32_PEAK_TF * 1e12 / flops_node)}
+    el2 = time.perf_counter() - t0
+    n2 = sum(fixed[i % 2].num_nodes() for i in range(steps))
+    out["replay_nodes_per_s"] = n2 / el2
+    out["replay_ms_per_step"] = el2 / steps * 1e3
+    trainer.release()
+    return out
 
 
 def gather_probe(args, gte, S, dev):
@@ -258,17 +343,36 @@ def gather_probe(args, gte, S, dev):
 
 def main():
     args = parse()
+    maybe_spawn(args)                       # --gpus N outside torchrun: N fresh ranks, before any GPU call (does not return)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # GTE_BENCH_FORCE_DIST=1 (test hook): run the data-parallel code path -- RCCL process group, flat-gradient all-reduces,
-    # HIP graph + eager collective + Adam -- even with one rank, so a 1-GPU box exercises RCCL next to graph capture.
+    # GTE_BENCH_FORCE_DIST=1 (test hook): run the data-parallel code path -- RCCL process group, flat-gradient all-reduce
+    # -- even with one rank, so a 1-GPU box exercises RCCL.
     distributed = world > 1 or os.environ.get("GTE_BENCH_FORCE_DIST", "0") == "1"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     # Test hook for 1-GPU boxes (GTE_BENCH_SHARE_GPU=1): every rank uses cuda:0 and the ranks talk over gloo (RCCL refuses two
     # ranks on one device) -- exercises the N > 1 code path of this file, not a measurement.
     share_gpu = os.environ.get("GTE_BENCH_SHARE_GPU", "0") == "1"
+
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd.data import synthetic as S
+
+    # ---- synthetic pages, on host cores, BEFORE the GPU is touched (the pool forks) ---------------------------------
+    t_gen = time.perf_counter()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    workers = max(1, usable_cores() // max(local_world, 1))
+    pages = make_pages_parallel(args.resident_pages, args.in_feats, rank * args.resident_pages, workers)
+    extras = rank == 0 and world == 1 and not distributed
+    pages13 = None
+    if extras and not args.no_secondary and args.in_feats != 13:
+        pages13 = make_pages_parallel(min(args.resident_pages, 600), 13, 0, workers)
+    val_pages = None
+    if rank == 0 and world == 1 and args.val_graph > 0:
+        val_pages = make_pages_parallel(args.val_graph, args.in_feats, 10_000_000, workers)
+    gen_s = time.perf_counter() - t_gen
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -283,65 +387,95 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if dist.get_world_size() != max(args.gpus, 1):
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+        world = dist.get_world_size()
 
-    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import graph as G
     from gnn_tableextraction_amd import ops
-    from gnn_tableextraction_amd.data import synthetic as S
+    from gnn_tableextraction_amd.models import loop
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
 
-    batches = build_batches(S, gte, args, rank, dev)
+    resident = G.ResidentPages(to_page_graphs(gte, pages), dev)        # this rank's pages, resident in HBM
+    pipe = loop.BatchPipeline(resident)
+    sizes = resident.page_sizes()
     torch.manual_seed(42)
     model = gte.GcnSAGE(args.in_feats, args.hidden, 9, args.layers, torch.nn.functional.relu, 0)
     state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     trainer = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4, distributed=distributed)
 
-    # global node count of step i (every rank can compute it: page sizes are seeded metadata)
-    local_nodes = [b[0].num_nodes() for b in batches]
-    if distributed:
-        t = torch.tensor(local_nodes, dtype=torch.int64, device=dev)
-        dist.all_reduce(t)
-        global_nodes = t.cpu().tolist()
-    else:
-        global_nodes = local_nodes
+    seed = 42 + rank                                   # every rank shuffles ITS pages
+    warm, ep = epoch_steps(sizes, args.pages, seed, 0, args.warmup)
+    timed, ep = epoch_steps(sizes, args.pages, seed, ep, args.steps)
+    prof, ep = epoch_steps(sizes, args.pages, seed, ep, 8)
+    n_long = 0
 
-    # one HIP graph per resident batch (forward + loss + backward); all-reduce and Adam follow eagerly
-    replays = None
-    if not args.no_graph:
-        replays = [trainer.capture(g, y, n_global=global_nodes[i]) for i, (g, y, _) in enumerate(batches)]
+    def node_counts(epochs):
+        return [[int(sum(sizes[i] for i in ids)) for ids in plan] for plan in epochs]
 
-    def run(i, eager=False):
-        j = i % len(batches)
-        if replays is not None and not eager:
-            return replays[j]()
-        g, y, _ = batches[j]
-        return trainer.step(g, y, n_global=global_nodes[j])
+    def global_counts(epochs):
+        """per-step node counts over all ranks (every rank plans its own pages: one small all-reduce, outside the timing)"""
+        local = node_counts(epochs)
+        if not distributed:
+            return local
+        flat = torch.tensor([c for plan in local for c in plan], dtype=torch.int64, device=dev)
+        dist.all_reduce(flat)
+        flat = flat.cpu().tolist()
+        out, k = [], 0
+        for plan in local:
+            out.append(flat[k:k + len(plan)])
+            k += len(plan)
+        return out
+
+    def run(epochs, counts):
+        nodes, out3 = 0, None
+        for plan, cnt in zip(epochs, counts):
+            out3 = loop.run_steps(trainer, pipe, plan, n_global=cnt if distributed else None)
+            nodes += sum(pipe.nodes(i) for i in range(len(plan)))
+        return nodes, out3
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        run(i)
+    warm_cnt, timed_cnt, prof_cnt = global_counts(warm), global_counts(timed), global_counts(prof)
+    run(warm, warm_cnt)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out3 = run(i)
+    nodes_local, out3 = run(timed, timed_cnt)
     barrier()
     elapsed = time.perf_counter() - t0
     final_loss = float(out3[0])
-    # per-kernel HIP-event timing: the SAME steps launched eagerly (events cannot sit between the nodes of
-    # a graph replay), on the launch stream, right after the timed region
-    for i in range(len(batches)):                # untimed: the eager launch pattern settles (clocks, caches)
-        run(i, eager=True)
+
+    # ---- secondary long run of the same loop: >= long_run_seconds of device time ------------------------------------
+    long_run = None
+    if args.long_run_seconds > 0:
+        n_long = max(args.steps, int(args.long_run_seconds / max(elapsed / args.steps, 1e-6)) + 1)
+        long_ep, ep = epoch_steps(sizes, args.pages, seed, ep, n_long)
+        long_cnt = global_counts(long_ep)
+        barrier()
+        t1 = time.perf_counter()
+        nodes_long, _ = run(long_ep, long_cnt)
+        barrier()
+        el_long = time.perf_counter() - t1
+        st = torch.tensor([el_long, float(nodes_long)], dtype=torch.float64, device=dev)
+        if distributed:
+            mx = st.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(st, op=dist.ReduceOp.SUM)
+            el_long, nodes_long = float(mx[0]), float(st[1])
+        long_run = {"steps": n_long, "seconds": el_long, "ms_per_step": el_long / n_long * 1e3,
+                    "value": nodes_long / el_long, "unit": "nodes/s"}
+
+    # ---- per-kernel HIP-event timing: the SAME loop with event pairs around the tagged launches, right after -------------
+    run(prof[:1], prof_cnt[:1])                  # untimed: settle
     ops.enable_kernel_timers(True)
-    for i in range(len(batches) * 2):
-        run(i, eager=True)
+    run(prof, prof_cnt)
     kt = ops.kernel_timer_report()
     ops.enable_kernel_timers(False)
 
-    nodes_local = sum(local_nodes[i % len(batches)] for i in range(args.steps))
     stat = torch.tensor([elapsed, float(nodes_local)], dtype=torch.float64, device=dev)
     if distributed:
         tmax = stat.clone()
@@ -362,26 +496,31 @@ def main():
                     "traffic_source": pmc_traffic()[1]}
         per_kernel = {}
         for tag, (n, tms, work) in kt.items():
-            unit = "GB/s" if tag == "spmm_csr" else "TFLOP/s"
-            rate = work / (tms * 1e-3) / (1e9 if tag == "spmm_csr" else 1e12) if tms > 0 else 0.0
+            unit = "GB/s" if tag.startswith("spmm") or tag.startswith("batch") else "TFLOP/s"
+            rate = work / (tms * 1e-3) / (1e9 if unit == "GB/s" else 1e12) if tms > 0 else 0.0
             per_kernel[tag] = {"launches": n, "total_ms": tms, "avg_ms": tms / max(n, 1), "rate": rate, "unit": unit}
+        mean_nodes = int(np.mean([c for plan in node_counts(timed) for c in plan]))
         line = {
             "metric": "nodes/sec (fwd+bwd node classification) on PubLayNet page graphs",
             "value": nodes_total / elapsed, "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg2: {args.pages} synthetic PubLayNet-style page graphs per GPU per step "
-                                   f"(~{int(np.mean(local_nodes))} nodes, k-NN k=5 bidirected), GcnSAGE "
+                                   f"(~{mean_nodes} nodes, k-NN k=5 bidirected), GcnSAGE "
                                    f"{args.layers} layers F0={args.in_feats} hidden={args.hidden} classes=9, "
-                                   f"CE + Adam(lr 0.01, wd 5e-4); batches resident in HBM; "
-                                   f"{'HIP-graph replay per batch' if replays is not None else 'eager launches'}",
+                                   f"CE + Adam(lr 0.01, wd 5e-4); the train loop of models/loop.py: a different batch "
+                                   f"every step, assembled on the device from {args.resident_pages} resident pages per GPU "
+                                   f"(shuffled epochs), eager launches",
                        "pages_per_gpu_per_step": args.pages, "global_pages_per_step": args.pages * world,
-                       "nodes_per_step_per_gpu": int(np.mean(local_nodes)), "parallelism": f"dp{world}"},
-            "final_loss": final_loss, "roofline": roofline, "kernels": per_kernel,
+                       "resident_pages_per_gpu": args.resident_pages, "nodes_per_step_per_gpu": mean_nodes,
+                       "parallelism": f"dp{world}"},
+            "final_loss": final_loss, "roofline": roofline, "kernels": per_kernel, "host_page_generation_s": gen_s,
         }
+        if long_run is not None:
+            line["long_run"] = long_run
         # whole-step bounds of SURVEY 8(d): per node, layer l (F_l -> F_{l+1}, mean in-degree d), training mode, no recomputation
         dims = [args.in_feats] + [args.hidden] * (args.layers - 1) + [9]
-        deg = float(np.mean([b[0].in_csr().indices.numel() / max(b[0].num_nodes(), 1) for b in batches]))
+        deg = float(sum(len(p.src) for p in pages)) / max(float(sum(p.num_nodes for p in pages)), 1.0)
         flops_node = sum(2.0 * 2 * dims[l] * dims[l + 1] * (3 if l > 0 else 2) for l in range(args.layers))
         bytes_node = sum(4.0 * (2 * dims[l] + dims[l + 1]) + 8 * deg + 4 +                       # forward
                          4.0 * (dims[l + 1] + 2 * dims[l] + (dims[l] if l > 0 else 0)) + 8 * deg + 4  # backward
@@ -392,14 +531,32 @@ def main():
                                  "mfma_bound_nodes_per_s": mfma_bound, "hbm_bound_nodes_per_s": hbm_bound,
                                  "bound": "mfma" if mfma_bound < hbm_bound else "hbm",
                                  "frac": line["value"] / min(mfma_bound, hbm_bound)}
+        if extras and not args.no_replay:
+            # round 1's headline mode, kept as a secondary: HIP-graph replay of 4 pre-captured resident batches
+            fixed = [resident.batch(ids) for ids in timed[0][:4]]
+            replays = [trainer.capture(g, g.ndata["label"]) for g in fixed]
+            for i in range(8):
+                replays[i % len(replays)]()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(args.steps):
+                replays[i % len(replays)]()
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t2
+            n2 = sum(fixed[i % len(fixed)].num_nodes() for i in range(args.steps))
+            line["replay"] = {"workload": "HIP-graph replay of 4 pre-captured resident batches (no batch assembly)",
+                              "value": n2 / el2, "unit": "nodes/s", "ms_per_step": el2 / args.steps * 1e3}
+            trainer.release()
+            del fixed, replays
         if world == 1 and not args.no_gather_probe:
             line["gather"] = gather_probe(args, gte, S, dev)
-        if world == 1 and not distributed and not args.no_secondary and args.in_feats != 13:
-            line["secondary"] = secondary_probe(args, gte, S, dev)
-        if world == 1 and args.val_graph > 0:
-            line["val_graph"] = val_graph_probe(args, gte, S, model, dev)
+        if pages13 is not None:
+            line["secondary"] = secondary_probe(args, gte, S, dev, pages13)
+        if val_pages is not None:
+            line["val_graph"] = val_graph_probe(args, gte, S, model, dev, val_pages)
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args, batches[0][2], state0)
+            ids = timed[0][0]
+            cb = cpu_baseline(args, S.concat_pages([pages[int(i)] for i in ids]), state0)
             line["cpu_baseline"] = cb
             line["gpu_over_cpu"] = line["value"] / cb["value"]
         print(json.dumps(line), flush=True)

@@ -72,6 +72,37 @@ batch_rows_kernel(const int32_t* __restrict__ pages, int nb, const int32_t* __re
     for (int j = lane; j < f; j += 64) dst[j] = src[j];
 }
 
+// the same with 16-byte accesses (rows need only 4-byte alignment on gfx950): lane l moves chunks l, l + 64, ... of the row,
+// every load of a row is requested before its first store; the f % 4 tail goes by dwords.  f <= 1024 NV / 4.
+struct __attribute__((packed, aligned(4))) brow4 { float x, y, z, w; };
+template <int NV>
+__global__ void __launch_bounds__(256)
+batch_rows_vec_kernel(const int32_t* __restrict__ pages, int nb, const int32_t* __restrict__ node_off,
+                      const int32_t* __restrict__ b_node_off, const float* __restrict__ in, int64_t ld_in,
+                      float* __restrict__ out, int64_t ld_out, int n_out, int f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= n_out) return;
+    const int i = seg_of(b_node_off, nb, r);
+    const float* src = in + (int64_t)(node_off[pages[i]] + (r - b_node_off[i])) * ld_in;
+    float* dst = out + (int64_t)r * ld_out;
+    const int nq = f >> 2;
+    brow4 v[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nq) v[u] = *reinterpret_cast<const brow4*>(src + 4 * c);
+    }
+    const int jt = 4 * nq + lane;
+    const float tail = jt < f ? src[jt] : 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nq) *reinterpret_cast<brow4*>(dst + 4 * c) = v[u];
+    }
+    if (jt < f) dst[jt] = tail;
+}
+
 // ---- edge weights from word boxes -----------------------------------------------------------------
 __device__ __forceinline__ int box_distance(const int4 a, const int4 b) {
     // graphs/utils.py:56-88: 0 if the boxes intersect (touching counts), the axis gap if they face each other,
@@ -137,8 +168,18 @@ extern "C" int gte_batch_rows(const int32_t* pages, int64_t n_batch, const int32
     if (n_out == 0) return GTE_OK;
     if (!pages || !node_off || !b_node_off || !in || !out) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_rows: null pointer");
     if (ld_in < n_cols || ld_out < n_cols) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_rows: ld < n_cols");
-    hipLaunchKernelGGL(batch_rows_kernel, dim3((unsigned)gte::ceil_div(n_out, 4)), dim3(256), 0, gte::as_stream(stream), pages,
-                       (int)n_batch, node_off, b_node_off, in, ld_in, out, ld_out, (int)n_out, (int)n_cols);
+    const dim3 grid((unsigned)gte::ceil_div(n_out, 4)), block(256);
+    hipStream_t s = gte::as_stream(stream);
+#define GTE_BROWS(NV)                                                                                                  \
+    hipLaunchKernelGGL((batch_rows_vec_kernel<NV>), grid, block, 0, s, pages, (int)n_batch, node_off, b_node_off, in, ld_in, \
+                       out, ld_out, (int)n_out, (int)n_cols)
+    if (n_cols >= 16 && n_cols <= 256) GTE_BROWS(1);
+    else if (n_cols > 256 && n_cols <= 512) GTE_BROWS(2);
+    else if (n_cols > 512 && n_cols <= 1024) GTE_BROWS(4);
+    else
+        hipLaunchKernelGGL(batch_rows_kernel, grid, block, 0, s, pages, (int)n_batch, node_off, b_node_off, in, ld_in, out,
+                           ld_out, (int)n_out, (int)n_cols);
+#undef GTE_BROWS
     return gte::check_launch("batch_rows");
 }
 

@@ -758,7 +758,10 @@ int run_small(bool ak, bool bkc, GemmParams p, hipStream_t s) {
     return gte::check_launch("gemm_small");
 }
 
-int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+// may_defer: only the weight-gradient entry points (gte_sage_linear_dw, gte_sage_qform_dw) hand their split-K fold to an
+// open deferral (gte_fold_defer_begin): nothing reads dW before the flush.  Every other caller -- gte_gemm_f32 in
+// particular, whose result (dh) the next kernel of a backward reads -- folds immediately.
+int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace_bytes, hipStream_t s, bool may_defer = false) {
     if (p.M == 0 || p.N == 0) return GTE_OK;
     if (needs_small_path(ak, bkc, p)) return run_small(ak, bkc, p, s);
     if (p.lda1 >= GEMM_MAX_LD || p.lda2 >= GEMM_MAX_LD || p.ldb >= GEMM_MAX_LD || p.ldbn2 >= GEMM_MAX_LD || p.ldan2 >= GEMM_MAX_LD)
@@ -783,7 +786,7 @@ int run_gemm(bool ak, bool bkc, GemmParams p, void* workspace, int64_t workspace
     if (rc != GTE_OK) return rc;
     if (pl.splits > 1) {
         const int64_t mn = (int64_t)p.M * p.N;
-        if (!p.bias && !accumulate && !relu && gte::defer_fold(p.slab, mn, pl.splits, p.M, p.N, p.C, p.ldc)) return GTE_OK;
+        if (may_defer && !p.bias && !accumulate && !relu && gte::defer_fold(p.slab, mn, pl.splits, p.M, p.N, p.C, p.ldc)) return GTE_OK;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gte::ceil_div(mn, RED_E)), dim3(RED_E * RED_S), 0, s, p.slab,
                            pl.splits, mn, p.N, p.C, p.ldc, p.bias, accumulate, relu, p.bias_cols);
         return gte::check_launch("gemm_f32 split-K reduce");
@@ -1387,9 +1390,9 @@ extern "C" int64_t gte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return mfma > skinny ? mfma : skinny;
 }
 
-extern "C" int gte_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                            const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate, void* workspace,
-                            int64_t workspace_bytes, void* stream) {
+static int gemm_f32_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                         const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate, void* workspace,
+                         int64_t workspace_bytes, void* stream, bool may_defer) {
     if (M < 0 || N < 0 || K < 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_f32: bad sizes");
     if (M == 0 || N == 0) return GTE_OK;
@@ -1421,7 +1424,14 @@ extern "C" int gte_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int6
     p.A1 = A; p.lda1 = lda; p.K1 = (int)K; p.A2 = nullptr; p.lda2 = 0; p.K2 = 0;
     p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = nullptr; p.M = (int)M; p.N = (int)N;
     p.relu = 0; p.accumulate = accumulate ? 1 : 0;
-    return run_gemm(!trans_a, trans_b != 0, p, workspace, workspace_bytes, s);
+    return run_gemm(!trans_a, trans_b != 0, p, workspace, workspace_bytes, s, may_defer);
+}
+
+extern "C" int gte_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                            const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+    return gemm_f32_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, accumulate, workspace, workspace_bytes, stream,
+                         false);
 }
 
 extern "C" int64_t gte_sage_linear_dw_workspace_bytes(int64_t n_out, int64_t k1, int64_t k2, int64_t n_nodes) {
@@ -1451,11 +1461,14 @@ extern "C" int gte_sage_linear_dw(const float* dz, int64_t lddz, const float* x1
         p.A1 = dz; p.lda1 = lddz; p.K1 = (int)n_nodes; p.A2 = nullptr; p.lda2 = 0; p.K2 = 0;
         p.B = x1; p.ldb = ldx1; p.Bn2 = x2; p.ldbn2 = ldx2; p.Nseg = (int)k1;
         p.C = dW; p.ldc = lddw; p.bias = nullptr; p.M = (int)n_out; p.N = (int)(2 * k1); p.relu = 0; p.accumulate = 0;
-        return run_gemm(false, false, p, workspace, workspace_bytes, gte::as_stream(stream));
+        return run_gemm(false, false, p, workspace, workspace_bytes, gte::as_stream(stream), true);
     }
-    int rc = gte_gemm_f32(1, 0, n_out, k1, n_nodes, dz, lddz, x1, ldx1, dW, lddw, 0, workspace, workspace_bytes, stream);
+    // two launches share ONE workspace: the first fold must have run before the second launch overwrites the slabs
+    int rc = gemm_f32_impl(1, 0, n_out, k1, n_nodes, dz, lddz, x1, ldx1, dW, lddw, 0, workspace, workspace_bytes, stream,
+                           k2 == 0);
     if (rc != GTE_OK || k2 == 0) return rc;
-    return gte_gemm_f32(1, 0, n_out, k2, n_nodes, dz, lddz, x2, ldx2, dW + k1, lddw, 0, workspace, workspace_bytes, stream);
+    return gemm_f32_impl(1, 0, n_out, k2, n_nodes, dz, lddz, x2, ldx2, dW + k1, lddw, 0, workspace, workspace_bytes, stream,
+                         true);
 }
 
 // ---- transform-then-aggregate ("q-form") entry points ---------------------------------------------------------
@@ -1512,7 +1525,7 @@ extern "C" int gte_sage_qform_dw(const float* dz, int64_t lddz, const float* q, 
     p.A1 = dz; p.lda1 = lddz; p.K1 = (int)n_nodes; p.An2 = q; p.ldan2 = ldq;
     p.B = x; p.ldb = ldx; p.Bn2 = x; p.ldbn2 = ldx; p.Nseg = (int)n_feat;
     p.C = dW; p.ldc = lddw; p.M = (int)n_out; p.N = (int)(2 * n_feat);
-    return run_gemm(false, false, p, workspace, workspace_bytes, gte::as_stream(stream));
+    return run_gemm(false, false, p, workspace, workspace_bytes, gte::as_stream(stream), true);
 }
 
 // dx[nodes, F] = dz W_s + q W_n   (W stored [n_out][2F]: W_s = W[:, 0:F], W_n = W[:, F:2F])

@@ -49,6 +49,12 @@ def plan_epoch(page_sizes: Sequence[int], batch_pages: int, world: int, seed: in
     perm = epoch_permutation(len(sizes), seed, epoch)
     per_step = batch_pages * world
     n_steps = len(perm) // per_step if drop_last else -(-len(perm) // per_step)
+    if n_steps == 0:
+        # the reference's `range(len(train_graphs) // batch_size)` (model_train.py:283) is empty too, and it then trains on
+        # nothing while still writing checkpoints; with several ranks the global batch is batch_pages * world pages, so a
+        # dataset that fills one single-GPU batch may not fill one here -- say so instead of running zero steps per epoch
+        raise ValueError(f"{len(sizes)} training pages do not fill one global batch of {batch_pages} pages x {world} rank(s); "
+                         f"lower TRAINING.batch_size (the global batch is batch_size * world_size pages)")
     plan = []
     for s in range(n_steps):
         ids = perm[s * per_step:(s + 1) * per_step]
@@ -65,3 +71,11 @@ def step_node_counts(plan: List[List[np.ndarray]], page_sizes: Sequence[int]) ->
     """[steps, ranks] node counts; row sums are the n_global of each step."""
     sizes = np.asarray(page_sizes)
     return np.array([[int(sizes[ids].sum()) for ids in step] for step in plan], dtype=np.int64)
+
+
+def step_weight_sums(plan: List[List[np.ndarray]], page_weight_sums: Sequence[float]) -> np.ndarray:
+    """[steps, ranks] sums of the per-node class weights w[y_i] (``page_weight_sums[p]`` = that sum over page p).
+    With ``nn.CrossEntropyLoss(weight)`` (model_train.py:171) a rank's loss is sum_local(w nll) / sum_local(w); scaling it by
+    sum_local(w) / sum_global(w) makes the all-reduced gradient the single-GPU gradient of sum_all(w nll) / sum_all(w)."""
+    ws = np.asarray(page_weight_sums, dtype=np.float64)
+    return np.array([[float(ws[ids].sum()) for ids in step] for step in plan], dtype=np.float64)

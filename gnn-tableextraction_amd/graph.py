@@ -322,8 +322,12 @@ class ResidentBatch(PageGraph):
     """A batched graph produced by :meth:`ResidentPages.batch`: the CSRs and the CSR-ordered edge weights are
     gathered on the device from the resident dataset instead of being rebuilt (no COO, no sort)."""
 
+    _empty = {}
+
     def __init__(self, n, n_edges, in_csr, out_csr, w_in, w_out_mean, device):
-        z = torch.zeros(0, dtype=torch.int32, device=device)
+        z = ResidentBatch._empty.get(device)
+        if z is None:
+            z = ResidentBatch._empty[device] = torch.zeros(0, dtype=torch.int32, device=device)
         super().__init__(z, z, n)
         self._in_csr, self._out_csr = in_csr, out_csr
         self._w_in, self._w_out_mean = w_in, w_out_mean
@@ -397,8 +401,10 @@ class ResidentPages:
     def page_sizes(self):
         return (self.node_off_host[1:] - self.node_off_host[:-1]).tolist()
 
-    def batch(self, page_ids) -> ResidentBatch:
-        lib, P, st = _lib.load(), _lib.ptr, _lib.current_stream()
+    # ---- batch assembly ------------------------------------------------------------------------
+    def batch_meta(self, page_ids):
+        """Host-side metadata of one batch: (int32 vector [ids | node offsets | in-edge offsets | out-edge offsets],
+        n_nodes, n_in_entries, n_out_entries, per-page node counts).  Pure index arithmetic on the page table."""
         ids = torch.as_tensor(page_ids, dtype=torch.int64)
         nb = ids.numel()
         n_sizes = self.node_off_host[ids + 1] - self.node_off_host[ids]
@@ -409,38 +415,68 @@ class ResidentPages:
             o = torch.zeros(nb + 1, dtype=torch.int64)
             o[1:] = torch.cumsum(eo[ids + 1] - eo[ids], 0)
             offs.append(o)
-        n_out, e_in, e_out = int(offs[0][-1]), int(offs[1][-1]), int(offs[2][-1])
-        meta = torch.cat([ids] + offs).to(torch.int32).to(self.device, non_blocking=True)     # one small H2D copy
-        pages = meta[:nb]
-        b_node, b_ein, b_eout = (meta[nb + i * (nb + 1): nb + (i + 1) * (nb + 1)] for i in range(3))
+        meta = torch.cat([ids] + offs).to(torch.int32)
+        return meta, int(offs[0][-1]), int(offs[1][-1]), int(offs[2][-1]), n_sizes
+
+    def alloc_batch_buffers(self, cap_nodes: int, cap_in: int, cap_out: int) -> dict:
+        """Output buffers of :meth:`assemble` for batches of up to the given sizes (views of them are handed out)."""
         dev = self.device
+        i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        return {"cap": (int(cap_nodes), int(cap_in), int(cap_out)),
+                "indptr": [i32(cap_nodes + 1), i32(cap_nodes + 1)], "indices": [i32(cap_in), i32(cap_out)],
+                "weight": [f32(max(int(cap_in), 1)) if self.weighted else None,
+                           f32(max(int(cap_out), 1)) if self._sets["out"]["weight"] is not None else None],
+                "feat": f32(max(int(cap_nodes), 1), self.feat.shape[1]),
+                "label": None if self.label is None else f32(max(int(cap_nodes), 1), 1)}
+
+    def assemble(self, meta_dev: torch.Tensor, nb: int, n_out: int, e_in: int, e_out: int, bufs: dict, n_sizes=None,
+                 stream=None) -> "ResidentBatch":
+        """Writes the block-diagonal union described by ``meta_dev`` (device copy of :meth:`batch_meta`'s vector) into
+        ``bufs`` with gte_batch_csr / gte_batch_rows on ``stream`` (default: the current stream) and returns it as a
+        graph whose tensors are row views of the buffers.  No allocation, no host synchronisation."""
+        lib, P = _lib.load(), _lib.ptr
+        st = _lib.current_stream() if stream is None else stream
+        cn, ci, co = bufs["cap"]
+        if n_out > cn or e_in > ci or e_out > co:
+            raise ValueError(f"batch of {n_out} nodes / {e_in}+{e_out} entries exceeds the buffers' capacity {bufs['cap']}")
+        pages = meta_dev[:nb]
+        b_node, b_ein, b_eout = (meta_dev[nb + i * (nb + 1): nb + (i + 1) * (nb + 1)] for i in range(3))
         csrs, weights = [], []
-        for name, b_eoff, e_cnt in (("in", b_ein, e_in), ("out", b_eout, e_out)):
+        for k, (name, b_eoff, e_cnt) in enumerate((("in", b_ein, e_in), ("out", b_eout, e_out))):
             s = self._sets[name]
-            indptr = torch.empty(n_out + 1, dtype=torch.int32, device=dev)
-            indices = torch.empty(e_cnt, dtype=torch.int32, device=dev)
-            wout = torch.empty(e_cnt, dtype=torch.float32, device=dev) if s["weight"] is not None else None
+            indptr, indices = bufs["indptr"][k][:n_out + 1], bufs["indices"][k][:e_cnt]
+            wout = bufs["weight"][k][:e_cnt] if s["weight"] is not None else None
             _lib.check(lib.gte_batch_csr(P(pages), nb, P(self.node_off), P(s["edge_off"]), P(b_node), P(b_eoff),
                                          P(s["indptr_loc"]), P(s["indices_loc"]), P(s["weight"]), P(indptr), P(indices),
                                          P(wout), n_out, e_cnt, st), "gte_batch_csr")
             csrs.append(CSR(indptr, indices, None))
             weights.append(wout)
-        g = ResidentBatch(n_out, e_in, csrs[0], csrs[1], weights[0], weights[1], dev)
-        g.batch_num_nodes_ = n_sizes.tolist()
+        g = ResidentBatch(n_out, e_in, csrs[0], csrs[1], weights[0], weights[1], self.device)
+        if n_sizes is not None:
+            g.batch_num_nodes_ = n_sizes.tolist() if hasattr(n_sizes, "tolist") else list(n_sizes)
         f = self.feat.shape[1]
-        feat = torch.empty((n_out, f), dtype=torch.float32, device=dev)
+        feat = bufs["feat"][:n_out]
         _lib.check(lib.gte_batch_rows(P(pages), nb, P(self.node_off), P(b_node), P(self.feat), self.feat.stride(0),
                                       P(feat), f, n_out, f, st), "gte_batch_rows feat")
         g.ndata["feat"] = feat
         if self.label is not None:
-            lab = torch.empty((n_out, 1), dtype=torch.float32, device=dev)
+            lab = bufs["label"][:n_out]
             _lib.check(lib.gte_batch_rows(P(pages), nb, P(self.node_off), P(b_node), P(self.label), 1, P(lab), 1, n_out, 1,
                                           st), "gte_batch_rows label")
             g.ndata["label"] = lab.reshape(-1)
         if self.weighted:
             g.edata["feat"] = weights[0]                # CSR order; ResidentBatch.in/out_weights ignore the argument
-        g._keepalive = meta
+        g._keepalive = (meta_dev, bufs)
         return g
+
+    def batch(self, page_ids) -> ResidentBatch:
+        """One batch into freshly allocated buffers (tests, one-off use).  The train loop goes through
+        ``models.loop.BatchPipeline``: epoch-wide metadata upload, reused buffers, assembly on a side stream."""
+        meta, n_out, e_in, e_out, n_sizes = self.batch_meta(page_ids)
+        nb = int(torch.as_tensor(page_ids).numel())
+        meta_dev = meta.to(self.device, non_blocking=True)                                    # one small H2D copy
+        return self.assemble(meta_dev, nb, n_out, e_in, e_out, self.alloc_batch_buffers(n_out, e_in, e_out), n_sizes)
 
 
 def edge_weights_from_boxes(bbox: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, graph_of_node: torch.Tensor,

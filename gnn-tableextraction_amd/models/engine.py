@@ -50,16 +50,32 @@ class TrainStep:
             import torch.distributed as dist
             dist.broadcast(self.flat_param, src=0, group=process_group)   # same initial weights everywhere
 
-    def step(self, g, labels: torch.Tensor, n_global: Optional[int] = None) -> torch.Tensor:
+    def _dp_scale(self, n_local: int, n_global: Optional[int], loss_scale: Optional[float]) -> float:
+        """Factor on the local loss so that the SUM of the ranks' gradients is the single-GPU gradient.
+        Unweighted CE is a mean over nodes: n_local / n_global.  With class weights the local loss is
+        sum(w nll) / sum_local(w) (nn.CrossEntropyLoss(weight), model_train.py:171) and the factor is
+        sum_local(w) / sum_global(w): the caller, who knows every rank's labels from the shared plan, passes it as
+        ``loss_scale`` -- a node-count ratio would silently optimise a different objective."""
+        if loss_scale is not None:
+            return float(loss_scale)
+        if not (self.distributed and n_global):
+            return 1.0
+        if self.class_weights is not None:
+            raise ValueError("data-parallel step with class weights needs loss_scale = sum_local(w) / sum_global(w) "
+                             "(distributed.step_weight_sums); n_local / n_global is only right for unweighted CE")
+        return float(n_local) / float(n_global)
+
+    def step(self, g, labels: torch.Tensor, n_global: Optional[int] = None,
+             loss_scale: Optional[float] = None) -> torch.Tensor:
         """Forward, loss, backward, (all-reduce), Adam.  Returns the device vector
         [loss (local mean), sum of class weights, #correct] without synchronising."""
         self.model.train()
         self.flat_grad.zero_()
         logits = self.model(g)
         loss, out3 = self._loss(logits, labels)
-        n_local = labels.shape[0]
-        if self.distributed and n_global:
-            loss = loss * (float(n_local) / float(n_global))
+        scale = self._dp_scale(labels.shape[0], n_global, loss_scale)
+        if scale != 1.0:
+            loss = loss * scale
         loss.backward()
         if self.distributed:
             import torch.distributed as dist
@@ -133,6 +149,7 @@ class FusedGcnSageStep(TrainStep):
         self._graph_bufs = {}
         self._private_key = None
         self._graphs = {}
+        self._graph_owner = {}
         self._side = torch.cuda.Stream(device=self.flat_param.device)
         # dW GEMMs on a side stream (GTE_OVERLAP_DW=1).  Off by default since the pipelined GEMM: with the matrix pipe at
         # 110-120 TF the HBM-bound kernels it would overlap with slow it down more than they hide (0.887 vs 0.862 ms/step)
@@ -204,6 +221,10 @@ class FusedGcnSageStep(TrainStep):
             full = self._graph_bufs.get(private)
             if full is None:
                 full = self._graph_bufs[private] = self._alloc(n, f0)
+                full["f0"] = f0
+            if full["cap"] < n or full["f0"] != f0:
+                raise RuntimeError(f"captured batch buffers hold {full['cap']} nodes x {full['f0']} features; "
+                                   f"asked for {n} x {f0} (a captured batch must not change)")
         else:
             full = self._bufs.get(f0)
             if full is None or full["cap"] < n:
@@ -506,8 +527,9 @@ class FusedGcnSageStep(TrainStep):
                 aggregate(rcsr, w_out, t_out, dahn, fin, dh, fin, fin, _lib.REDUCE_SUM, True)
         return side_used
 
-    def step(self, g, labels: torch.Tensor, n_global: Optional[int] = None) -> torch.Tensor:
-        scale = float(labels.shape[0]) / float(n_global) if (self.distributed and n_global) else 1.0
+    def step(self, g, labels: torch.Tensor, n_global: Optional[int] = None,
+             loss_scale: Optional[float] = None) -> torch.Tensor:
+        scale = self._dp_scale(labels.shape[0], n_global, loss_scale)
         if self.distributed and self._dp_split:
             out3 = self.forward_backward(g, labels, scale, upto_layer=1)
             pending = [self._all_reduce_async(self.flat_grad[self._n0:])]    # layers 1.. : in flight under layer 0's backward
@@ -571,18 +593,29 @@ class FusedGcnSageStep(TrainStep):
         self._adam_dev_launch()
 
     # -- HIP graph capture of a step on a RESIDENT batch ------------------------------------------------
-    def capture(self, g, labels: torch.Tensor, n_global: Optional[int] = None):
+    def capture(self, g, labels: torch.Tensor, n_global: Optional[int] = None, loss_scale: Optional[float] = None):
         """Returns ``replay() -> out3``: forward+backward of this batch as one HIP-graph launch, followed
         by Adam -- inside the same graph on one GPU (gte_adam_step_dev reads lr and the step count from device
         memory), eagerly after the all-reduce when distributed.  The batch's tensors must stay alive and unchanged
-        in place (resident pages)."""
-        scale = float(labels.shape[0]) / float(n_global) if (self.distributed and n_global) else 1.0
+        in place (resident pages): the cache entry holds a reference to the graph object, so its id cannot be
+        reused while the captured graph exists; :meth:`release` drops a captured batch and its ~300 MB of buffers."""
+        scale = self._dp_scale(labels.shape[0], n_global, loss_scale)
         key = id(g)
         self._private_key = key                       # this batch's buffers are private to its graph (never reallocated)
         try:
-            return self._capture(g, labels, scale, key)
+            replay = self._capture(g, labels, scale, key)
+            self._graph_owner[key] = (g, labels)
+            return replay
         finally:
             self._private_key = None
+
+    def release(self, g=None) -> None:
+        """Forget the HIP graph(s) and private buffers captured for ``g`` (all captured batches when None)."""
+        keys = list(self._graphs) if g is None else [id(g)]
+        for k in keys:
+            self._graphs.pop(k, None)
+            self._graph_bufs.pop(k, None)
+            self._graph_owner.pop(k, None)
 
     def _capture(self, g, labels, scale, key):
         side = torch.cuda.Stream()

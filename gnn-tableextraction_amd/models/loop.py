@@ -1,0 +1,157 @@
+"""The batch loop of ``train()`` (src/models/model_train.py:283-332 of the reference): a DIFFERENT batch of page
+graphs every step, built on the device from the resident dataset, one optimisation step on it.
+
+The reference does, per step, ``dgl.batch(train_batch).to(device)`` on the host (:286-298) and then the step
+(:320-332).  Here the pages live in HBM (``graph.ResidentPages``) and a step's batch is four launches of index / row
+copies -- and those launches do not sit on the step's critical path:
+
+  * the page lists of ALL steps of an epoch are known when the epoch starts (``distributed.plan_epoch``), so the
+    per-step metadata (page ids, node / edge offsets of the block-diagonal union) is computed once per epoch with
+    vectorised numpy and uploaded in ONE pinned host->device copy;
+  * batches are written into ``depth`` reused buffer sets (no allocation inside the loop);
+  * batch s+1 is assembled on a SIDE STREAM while step s runs: the assembly is HBM-bound index work, the step is
+    MFMA-bound, so they share the chip; two events per step order buffer reuse (HIP streams + events instead of
+    host synchronisation: the host never waits for the device inside an epoch).
+
+``bench.py`` times exactly this loop (``run_steps``); ``models.model_train.train`` runs it every epoch.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import graph as G
+
+
+class BatchPipeline:
+    def __init__(self, resident: G.ResidentPages, depth: int = 2):
+        if depth < 2:
+            raise ValueError("BatchPipeline needs at least two buffer sets (one being read, one being written)")
+        self.res, self.depth = resident, depth
+        self.device = resident.device
+        self.side = torch.cuda.Stream(device=self.device)
+        self._sets: List[dict] = []
+        self._free_ev: List[Optional[torch.cuda.Event]] = [None] * depth
+        self._pinned = None
+        self._meta_dev = None
+        self._meta_ev = None
+        self._info = None
+        self._ready = {}
+        # per-page entry counts of both CSRs, host side (numpy): the offsets of any batch are cumulative sums of these
+        self._page_nodes = (resident.node_off_host[1:] - resident.node_off_host[:-1]).numpy().astype(np.int64)
+        self._page_ent = []
+        for name in ("in", "out"):
+            eo = resident._sets[name]["edge_off_host"].numpy().astype(np.int64)
+            self._page_ent.append(eo[1:] - eo[:-1])
+
+    # ---- per epoch -------------------------------------------------------------------------------
+    def load(self, steps: Sequence[np.ndarray]) -> None:
+        """Metadata of every step of an epoch (``steps[s]`` = page ids of step s): one upload."""
+        self._ready = {}
+        self._info = []
+        if len(steps) == 0:
+            return
+        rows = []
+        for ids in steps:
+            ids = np.asarray(ids, dtype=np.int64)
+            if ids.size == 0:
+                raise ValueError("a step needs at least one page")
+            b_node = np.zeros(ids.size + 1, dtype=np.int64)
+            np.cumsum(self._page_nodes[ids], out=b_node[1:])
+            b_in = np.zeros(ids.size + 1, dtype=np.int64)
+            np.cumsum(self._page_ent[0][ids], out=b_in[1:])
+            b_out = np.zeros(ids.size + 1, dtype=np.int64)
+            np.cumsum(self._page_ent[1][ids], out=b_out[1:])
+            rows.append((ids, b_node, b_in, b_out))
+        total = sum(4 * r[0].size + 3 for r in rows)
+        if self._pinned is None or self._pinned.numel() < total:
+            if self._meta_ev is not None:
+                self._meta_ev.synchronize()                      # the previous upload still reads the old staging buffer
+            self._pinned = torch.empty(max(total, 4096), dtype=torch.int32).pin_memory()
+            self._meta_dev = torch.empty(self._pinned.numel(), dtype=torch.int32, device=self.device)
+        elif self._meta_ev is not None:
+            self._meta_ev.synchronize()
+        stage = self._pinned.numpy()
+        off = 0
+        cap = [0, 0, 0]
+        for ids, b_node, b_in, b_out in rows:
+            nb = ids.size
+            stage[off:off + nb] = ids
+            stage[off + nb:off + 2 * nb + 1] = b_node
+            stage[off + 2 * nb + 1:off + 3 * nb + 2] = b_in
+            stage[off + 3 * nb + 2:off + 4 * nb + 3] = b_out
+            self._info.append((off, nb, int(b_node[-1]), int(b_in[-1]), int(b_out[-1]), self._page_nodes[ids]))
+            cap = [max(cap[0], int(b_node[-1])), max(cap[1], int(b_in[-1])), max(cap[2], int(b_out[-1]))]
+            off += 4 * nb + 3
+        # the side stream runs in order: assemblies queued earlier read the old metadata before this copy overwrites it
+        with torch.cuda.stream(self.side):
+            self._meta_dev[:total].copy_(self._pinned[:total], non_blocking=True)
+            self._meta_ev = torch.cuda.Event()
+            self._meta_ev.record(self.side)
+        self._ensure_capacity(cap)
+
+    def _ensure_capacity(self, cap) -> None:
+        have = self._sets[0]["cap"] if self._sets else (0, 0, 0)
+        if self._sets and all(h >= c for h, c in zip(have, cap)):
+            return
+        torch.cuda.synchronize(self.device)                      # rare (first epoch / a larger batch than any before)
+        grow = [max(h, -(-int(c * 1.0625) // 1024) * 1024) for h, c in zip(have, cap)]
+        self._sets = [self.res.alloc_batch_buffers(*grow) for _ in range(self.depth)]
+        self._free_ev = [None] * self.depth
+
+    def __len__(self):
+        return len(self._info or [])
+
+    def nodes(self, s: int) -> int:
+        return self._info[s][2]
+
+    # ---- per step --------------------------------------------------------------------------------
+    def start(self, s: int) -> None:
+        """Queue the assembly of step s's batch on the side stream (returns immediately)."""
+        off, nb, n, e_in, e_out, n_sizes = self._info[s]
+        k = s % self.depth
+        if self._free_ev[k] is not None:
+            self.side.wait_event(self._free_ev[k])               # the step that last read this buffer set has finished
+        g = self.res.assemble(self._meta_dev[off:off + 4 * nb + 3], nb, n, e_in, e_out, self._sets[k], n_sizes,
+                              stream=self.side.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        self._ready[s] = (g, ev)
+
+    def get(self, s: int) -> G.ResidentBatch:
+        """The batch of step s; the CURRENT stream waits (on the device) for its assembly."""
+        g, ev = self._ready.pop(s)
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        return g
+
+    def release(self, s: int) -> None:
+        """Step s has been queued on the current stream: its buffer set may be rewritten once it is through."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._free_ev[s % self.depth] = ev
+
+
+def run_steps(step, pipe: BatchPipeline, page_steps: Sequence[np.ndarray], n_global: Optional[Sequence[int]] = None,
+              loss_scale: Optional[Sequence[float]] = None, on_step: Optional[Callable] = None):
+    """One optimisation step per entry of ``page_steps`` (this rank's page ids per step), batches assembled one step
+    ahead on the pipeline's side stream.  ``n_global[s]`` = node count of step s over all ranks, ``loss_scale[s]`` an
+    explicit local loss factor (class-weighted data parallelism).  Returns the last step's device vector
+    [loss, sum of class weights, #correct] (not synchronised)."""
+    pipe.load(page_steps)
+    n_steps = len(pipe)
+    out3 = None
+    if n_steps == 0:
+        return out3
+    pipe.start(0)
+    for s in range(n_steps):
+        if s + 1 < n_steps:
+            pipe.start(s + 1)
+        g = pipe.get(s)
+        out3 = step.step(g, g.ndata['label'], n_global=None if n_global is None else int(n_global[s]),
+                         loss_scale=None if loss_scale is None else float(loss_scale[s]))
+        pipe.release(s)
+        if on_step is not None:
+            on_step(s, g, out3)
+    return out3

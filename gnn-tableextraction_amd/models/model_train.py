@@ -26,8 +26,9 @@ from ..components.graphs.models import GcnSAGE
 from ..utils.config import AttrDict, logs_from_config
 from ..utils.training import EarlyStopping
 from .engine import FusedGcnSageStep, TrainStep
+from .loop import BatchPipeline, run_steps
 
-TABLE_TCELL, TABLE_COLH = 10, 8          # Categories_names values used for the printed F1s (const.py:4-18)
+TABLE_TCELL, TABLE_COLH = 10, 7          # Categories_names values used for the printed F1s (const.py:4-18; KAT: tests/test_aux_golden.py)
 
 
 class _ScalarLog:
@@ -167,6 +168,7 @@ def train(data, config, name_time=None):
     start_epoch = 0
     ckpt_path = os.path.join(ckpt_dir, logs)
     if config.GENERAL.from_checkpoint and os.path.isfile(ckpt_path):
+        # our own checkpoint (written below): a dict of tensors + python scalars + the metrics dict, hence weights_only=False
         ck = torch.load(ckpt_path, map_location='cpu', weights_only=False)
         start_epoch = ck['epoch']
         model.load_state_dict(ck['state_dict'])             # parameters are views of the flat buffer: copies in place
@@ -179,7 +181,12 @@ def train(data, config, name_time=None):
     # all training pages concatenated ONCE in HBM (features, labels, both CSRs, CSR-ordered weights); a batch is
     # four kernel launches of index arithmetic instead of dgl.batch(...).to(device) per step (:297)
     resident = G.ResidentPages(train_graphs, device)
+    pipe = BatchPipeline(resident)          # a step's batch is assembled on a side stream while the step before it runs
     sizes = resident.page_sizes()
+    # class-weighted data parallelism: every rank knows every page's labels, hence every step's weight sums (no exchange)
+    page_wsum = None
+    if distributed and cw is not None:
+        page_wsum = [float(np.asarray(cw, dtype=np.float64)[g.ndata['label'].long().numpy()].sum()) for g in train_graphs]
     val_shard = val_graphs[rank::world] if distributed else val_graphs
     val_graph = G.batch([g.to(device) for g in val_shard]) if val_shard else None
     val_labels = None if val_graph is None else val_graph.ndata['label']
@@ -190,10 +197,12 @@ def train(data, config, name_time=None):
     for epoch in range(start_epoch, config.TRAINING.n_epochs):
         plan = D.plan_epoch(sizes, batch_size, world, seed=config.PREPROCESS.get('seed', 42), epoch=epoch)
         counts = D.step_node_counts(plan, sizes)
-        out3 = None
-        for s, ranks in enumerate(plan):
-            bg = resident.batch(ranks[rank])
-            out3 = step.step(bg, bg.ndata['label'], n_global=int(counts[s].sum()))
+        scales = None
+        if page_wsum is not None:
+            wsums = D.step_weight_sums(plan, page_wsum)
+            scales = wsums[:, rank] / np.maximum(wsums.sum(axis=1), 1e-30)
+        # the same loop bench.py times: models/loop.py
+        out3 = run_steps(step, pipe, [ranks[rank] for ranks in plan], n_global=counts.sum(axis=1), loss_scale=scales)
         if out3 is not None:
             o = out3.cpu().tolist()
             train_loss, train_acc = o[0], o[2] / max(int(counts[-1][rank]), 1)

@@ -184,7 +184,8 @@ int gte_gemm_set_tail_workspace(void* workspace, int64_t workspace_bytes);
 
 /* ---- deferred folds -------------------------------------------------------------------------------------------
  * Several entry points end with a small "sum the per-block partials" kernel (gte_ln_relu_bwd: column sums;
- * gte_sage_narrow_bwd: dW / dbias; split-K GEMMs behind gte_sage_linear_dw / gte_sage_qform_dw / gte_gemm_f32).  Between
+ * gte_sage_narrow_bwd: dW / dbias; split-K GEMMs behind gte_sage_linear_dw / gte_sage_qform_dw).  gte_gemm_f32 NEVER defers:
+ * its result (e.g. dh of a backward) is read by the next kernel of the stream.  Between
  * gte_fold_defer_begin(stream) and gte_fold_defer_flush() (same host thread) those folds are queued instead of launched
  * and the flush runs all of them in ONE launch on `stream`.  While a deferral is open every such call needs its OWN
  * workspace (it holds the partials until the flush) and its results are not final before the flush.  Fixed summation

@@ -3,7 +3,10 @@
 Restates ``Bbox.__call__`` of the reference, src/components/nlp/bbox.py:49-124 (``get_shape`` :49-54,
 ``get_histogram`` :56-107), in plain Python with the same operations in the same order (float64 histogram,
 "largest bin absorbs 1 - sum", empty text -> [0, 0, 0, 1]).  The reference holds no test or golden vector for
-it; the restatement is line-by-line and is checked against hand-computed cases in tests/test_bbox_features.py.
+it; the restatement is pinned by tests/golden/aux_bbox_features.npz -- 1 500 words (ASCII and non-ASCII letters / digits,
+empty and blank texts, degenerate boxes) run through the reference's own nested ``get_shape`` / ``get_histogram``
+(ast-extracted by oracle/make_aux_golden.py) -- bit for bit (tests/test_aux_golden.py), plus hand cases in
+tests/test_bbox_features.py.
 """
 import numpy as np
 

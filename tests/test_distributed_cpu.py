@@ -31,9 +31,12 @@ class OracleModel(torch.nn.Module):
         return oc.gcnsage_forward(dict(zip(self.keys, self.params)), og, x)
 
 
+CW = np.array([1.0, 0.5, 2.0, 1.0, 0.1, 3.0, 2.0, 1.0, 0.7])     # class weights of the weighted variant
+
+
 class CpuTrainStep(TrainStep):
     def _loss(self, logits, labels):
-        loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss = torch.nn.functional.cross_entropy(logits, labels, weight=self.class_weights)   # nn.CrossEntropyLoss(weight)
         return loss, torch.stack([loss.detach(), torch.tensor(float(len(labels))), torch.tensor(0.0)])
 
     def _optimizer_step(self):
@@ -57,7 +60,7 @@ def free_port():
     return p
 
 
-def worker(rank, world, port, out_dir):
+def worker(rank, world, port, out_dir, weighted=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist = D.init_process_group("gloo")
@@ -67,11 +70,17 @@ def worker(rank, world, port, out_dir):
     counts = D.step_node_counts(plan, sizes)
     state = oc.init_state(F0, HID, 9, 3, seed=rank)               # different per rank: broadcast must fix it
     model = OracleModel(state)
-    tr = CpuTrainStep(model, lr=0.01, weight_decay=5e-4, distributed=True)
+    tr = CpuTrainStep(model, lr=0.01, weight_decay=5e-4, distributed=True,
+                      class_weights=torch.tensor(CW, dtype=torch.float32) if weighted else None)
+    wsums = D.step_weight_sums(plan, [float(CW[p.label].sum()) for p in pages])
     losses = []
     for s, step in enumerate(plan):
         g, y = make_inputs(step[rank], pages)
-        out3 = tr.step(g, y, n_global=int(counts[s].sum()))
+        if weighted and s == 0:
+            with pytest.raises(ValueError):                      # a node-count ratio would be the wrong objective
+                tr.step(g, y, n_global=int(counts[s].sum()))
+        out3 = tr.step(g, y, n_global=int(counts[s].sum()),
+                       loss_scale=float(wsums[s, rank] / wsums[s].sum()) if weighted else None)
         losses.append(float(out3[0]))
     np.save(os.path.join(out_dir, f"param_{rank}.npy"), tr.flat_param.detach().numpy())
     np.save(os.path.join(out_dir, f"loss_{rank}.npy"), np.array(losses))
@@ -96,10 +105,11 @@ def test_plan_is_balanced_and_complete():
     assert D.plan_epoch(sizes, 100, 1)[0][0].shape == (100,)
 
 
-def test_two_rank_dp_equals_single_process(tmp_path):
+@pytest.mark.parametrize("weighted", [False, True])
+def test_two_rank_dp_equals_single_process(tmp_path, weighted):
     world = 2
     port = free_port()
-    mp.start_processes(worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    mp.start_processes(worker, args=(world, port, str(tmp_path), weighted), nprocs=world, join=True, start_method="spawn")
     p0, p1 = np.load(tmp_path / "param_0.npy"), np.load(tmp_path / "param_1.npy")
     np.testing.assert_array_equal(p0, p1)                       # replicas stay bit-identical
 
@@ -108,10 +118,16 @@ def test_two_rank_dp_equals_single_process(tmp_path):
     sizes = [p.num_nodes for p in pages]
     plan = D.plan_epoch(sizes, BATCH, world, seed=42, epoch=0)
     model = OracleModel(oc.init_state(F0, HID, 9, 3, seed=0))   # rank 0's weights win the broadcast
-    tr = CpuTrainStep(model, lr=0.01, weight_decay=5e-4, distributed=False)
+    tr = CpuTrainStep(model, lr=0.01, weight_decay=5e-4, distributed=False,
+                      class_weights=torch.tensor(CW, dtype=torch.float32) if weighted else None)
     for step in plan:
         g, y = make_inputs(np.concatenate(step), pages)
         tr.step(g, y)
     np.testing.assert_allclose(p0, tr.flat_param.detach().numpy(), rtol=2e-4, atol=2e-5)
     l0, l1 = np.load(tmp_path / "loss_0.npy"), np.load(tmp_path / "loss_1.npy")
     assert len(l0) == len(plan) == 2 and np.isfinite(l0).all() and np.isfinite(l1).all()
+
+
+def test_empty_plan_is_an_error_not_a_silent_epoch():
+    with pytest.raises(ValueError):
+        D.plan_epoch([100] * 500, 100, 8)                       # 500 pages do not fill one global batch of 800

@@ -122,3 +122,73 @@ def test_fused_step_equals_autograd_path_on_random_shapes(seed):
     assert float(out_f[2]) == float(out_a[2])                      # same arg-max decisions
     gf, gr = fused.flat_grad.cpu().numpy(), auto.flat_grad.cpu().numpy()
     np.testing.assert_allclose(gf, gr, rtol=2e-3, atol=2e-5 * np.abs(gr).max() + 1e-9)
+
+
+@pytest.mark.parametrize("hid,pages", [(512, 2), (1000, 5), (640, 1)])
+def test_classic_backward_with_split_k_dh_gemms(monkeypatch, hid, pages):
+    """GTE_TRANSFORM_FIRST=0 keeps the reference's aggregate-then-transform order: the backward then runs the dh GEMMs
+    through gte_gemm_f32 while the step's fold deferral is open.  With a wide hidden layer and a SMALL batch those GEMMs
+    are split-K: their folds must run immediately (the next kernel reads dh), never join the deferred batch."""
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import graph as G
+    from gnn_tableextraction_amd.data import synthetic as S
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep, TrainStep
+    monkeypatch.setenv("GTE_TRANSFORM_FIRST", "0")
+    dev = "cuda:0"
+    pg = S.make_pages(pages, in_feats=63, first_id=9100)
+    src, dst, w, feat, label, off = S.concat_pages(pg)
+
+    def fresh():
+        torch.manual_seed(3)
+        m = gte.GcnSAGE(63, hid, 9, 3, torch.nn.functional.relu, 0).to(dev)
+        g = G.PageGraph(src, dst, int(off[-1]), device=dev)
+        g.ndata["feat"], g.edata["feat"] = torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev)
+        return m, g
+    y = torch.from_numpy(label).to(dev)
+    ma, ga = fresh()
+    mb, gb = fresh()
+    fused = FusedGcnSageStep(ma, lr=0.01, weight_decay=5e-4)
+    assert not fused.transform_first
+    auto = TrainStep(mb, lr=0.01, weight_decay=5e-4)
+    out_f = fused.forward_backward(ga, y)
+    auto.model.train()
+    auto.flat_grad.zero_()
+    loss, out_a = auto._loss(auto.model(gb), y)
+    loss.backward()
+    assert abs(float(out_f[0]) - float(out_a[0])) < 2e-5
+    gf, gr = fused.flat_grad.cpu().numpy(), auto.flat_grad.cpu().numpy()
+    np.testing.assert_allclose(gf, gr, rtol=2e-3, atol=2e-5 * np.abs(gr).max() + 1e-9)
+
+
+@pytest.mark.parametrize("f0", [13, 831])
+def test_pipelined_loop_equals_one_batch_at_a_time(f0):
+    """models/loop.py (what train() and bench.py run): epoch-wide metadata upload, reused buffer sets, batches assembled on
+    a side stream one step ahead.  Parameters after two shuffled epochs must be BITWISE those of the plain loop
+    `resident.batch(ids)` -> `step.step(...)` on the current stream."""
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import distributed as D, graph as G
+    from gnn_tableextraction_amd.models import loop
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    dev = torch.device("cuda", 0)
+    data = PrebuiltPages.synthetic(36, in_feats=f0)
+    res = G.ResidentPages(data.graphs, dev)
+    sizes = res.page_sizes()
+
+    def trainer():
+        torch.manual_seed(11)
+        m = gte.GcnSAGE(f0, 64, 9, 3, torch.nn.functional.relu, 0).to(dev)
+        return FusedGcnSageStep(m, lr=0.01, weight_decay=5e-4)
+    a, b = trainer(), trainer()
+    pipe = loop.BatchPipeline(res)
+    seen = []
+    for epoch in range(2):
+        plan = [r[0] for r in D.plan_epoch(sizes, 7, 1, seed=5, epoch=epoch)]
+        assert len(plan) == 5
+        out_a = loop.run_steps(a, pipe, plan, on_step=lambda s, g, o: seen.append(g.num_nodes()))
+        for ids in plan:
+            g = res.batch(ids)
+            out_b = b.step(g, g.ndata["label"])
+        assert torch.equal(out_a.cpu(), out_b.cpu())
+    torch.cuda.synchronize()
+    assert torch.equal(a.flat_param.cpu(), b.flat_param.cpu())
+    assert len(seen) == 10 and len(set(seen)) > 3                     # a different batch (size) nearly every step
