@@ -29,6 +29,8 @@ SIGNATURES = {
     "gte_coo_to_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_batch_csr": (c_int, [c_void_p, c_int64] + [c_void_p] * 10 + [c_int64, c_int64, c_void_p]),
+    "gte_batch_assemble": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                   c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_batch_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                c_int64, c_void_p]),
     "gte_edge_weights_workspace_bytes": (c_int64, [c_int64, c_int64]),
@@ -104,6 +106,12 @@ SIGNATURES = {
                               c_float, c_float, c_int64, c_float, c_void_p]),
     "gte_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
+
+class BatchArrays(ctypes.Structure):
+    """gte_batch_arrays of include/gte.h (one CSR direction of gte_batch_assemble)"""
+    _fields_ = [(n, c_void_p) for n in ("edge_off", "indptr_loc", "indices_loc", "weight", "b_edge_off", "indptr_out",
+                                        "indices_out", "weight_out")]
+
 
 GTE_F32, GTE_BF16 = 0, 1
 REDUCE_SUM, REDUCE_MEAN = 0, 1

@@ -433,7 +433,7 @@ class ResidentPages:
     def assemble(self, meta_dev: torch.Tensor, nb: int, n_out: int, e_in: int, e_out: int, bufs: dict, n_sizes=None,
                  stream=None) -> "ResidentBatch":
         """Writes the block-diagonal union described by ``meta_dev`` (device copy of :meth:`batch_meta`'s vector) into
-        ``bufs`` with gte_batch_csr / gte_batch_rows on ``stream`` (default: the current stream) and returns it as a
+        ``bufs`` with ONE launch of gte_batch_assemble on ``stream`` (default: the current stream) and returns it as a
         graph whose tensors are row views of the buffers.  No allocation, no host synchronisation."""
         lib, P = _lib.load(), _lib.ptr
         st = _lib.current_stream() if stream is None else stream
@@ -442,28 +442,28 @@ class ResidentPages:
             raise ValueError(f"batch of {n_out} nodes / {e_in}+{e_out} entries exceeds the buffers' capacity {bufs['cap']}")
         pages = meta_dev[:nb]
         b_node, b_ein, b_eout = (meta_dev[nb + i * (nb + 1): nb + (i + 1) * (nb + 1)] for i in range(3))
-        csrs, weights = [], []
+        csrs, weights, descs = [], [], []
         for k, (name, b_eoff, e_cnt) in enumerate((("in", b_ein, e_in), ("out", b_eout, e_out))):
             s = self._sets[name]
             indptr, indices = bufs["indptr"][k][:n_out + 1], bufs["indices"][k][:e_cnt]
             wout = bufs["weight"][k][:e_cnt] if s["weight"] is not None else None
-            _lib.check(lib.gte_batch_csr(P(pages), nb, P(self.node_off), P(s["edge_off"]), P(b_node), P(b_eoff),
-                                         P(s["indptr_loc"]), P(s["indices_loc"]), P(s["weight"]), P(indptr), P(indices),
-                                         P(wout), n_out, e_cnt, st), "gte_batch_csr")
+            descs.append(_lib.BatchArrays(P(s["edge_off"]), P(s["indptr_loc"]), P(s["indices_loc"]), P(s["weight"]) or None,
+                                          P(b_eoff), P(indptr), P(indices), P(wout) or None))
             csrs.append(CSR(indptr, indices, None))
             weights.append(wout)
+        f = self.feat.shape[1]
+        feat = bufs["feat"][:n_out]
+        lab = None if self.label is None else bufs["label"][:n_out]
+        # ONE launch: features, labels, both CSRs and their weights (per-page contiguous runs, 16-byte accesses)
+        import ctypes
+        _lib.check(lib.gte_batch_assemble(P(pages), nb, P(self.node_off), P(b_node), ctypes.addressof(descs[0]),
+                                          ctypes.addressof(descs[1]), P(self.feat), self.feat.stride(0), f, P(feat),
+                                          P(self.label) or None, P(lab) or None, n_out, st), "gte_batch_assemble")
         g = ResidentBatch(n_out, e_in, csrs[0], csrs[1], weights[0], weights[1], self.device)
         if n_sizes is not None:
             g.batch_num_nodes_ = n_sizes.tolist() if hasattr(n_sizes, "tolist") else list(n_sizes)
-        f = self.feat.shape[1]
-        feat = bufs["feat"][:n_out]
-        _lib.check(lib.gte_batch_rows(P(pages), nb, P(self.node_off), P(b_node), P(self.feat), self.feat.stride(0),
-                                      P(feat), f, n_out, f, st), "gte_batch_rows feat")
         g.ndata["feat"] = feat
-        if self.label is not None:
-            lab = bufs["label"][:n_out]
-            _lib.check(lib.gte_batch_rows(P(pages), nb, P(self.node_off), P(b_node), P(self.label), 1, P(lab), 1, n_out, 1,
-                                          st), "gte_batch_rows label")
+        if lab is not None:
             g.ndata["label"] = lab.reshape(-1)
         if self.weighted:
             g.edata["feat"] = weights[0]                # CSR order; ResidentBatch.in/out_weights ignore the argument

@@ -26,12 +26,13 @@ from .. import graph as G
 
 
 class BatchPipeline:
-    def __init__(self, resident: G.ResidentPages, depth: int = 2):
+    def __init__(self, resident: G.ResidentPages, depth: int = 2, side_stream: bool = True):
         if depth < 2:
             raise ValueError("BatchPipeline needs at least two buffer sets (one being read, one being written)")
         self.res, self.depth = resident, depth
         self.device = resident.device
-        self.side = torch.cuda.Stream(device=self.device)
+        # side_stream=False (measurements only): assemble on the caller's stream, i.e. in front of the step
+        self.side = torch.cuda.Stream(device=self.device) if side_stream else torch.cuda.current_stream(self.device)
         self._sets: List[dict] = []
         self._free_ev: List[Optional[torch.cuda.Event]] = [None] * depth
         self._pinned = None

@@ -111,6 +111,27 @@ int gte_batch_csr(const int32_t* pages, int64_t n_batch, const int32_t* node_off
                   const int32_t* b_node_off, const int32_t* b_edge_off, const int32_t* indptr_loc,
                   const int32_t* indices_loc, const float* weight, int32_t* indptr_out, int32_t* indices_out,
                   float* weight_out, int64_t n_out, int64_t e_out, void* stream);
+/* The whole batch in ONE launch (what the train loop calls every step; gte_batch_csr / gte_batch_rows are its pieces):
+ * a page's rows are CONTIGUOUS in the resident arrays and in the batch, so every array of the batch is the concatenation
+ * of per-page runs -- features and labels copied, indptr / indices copied with a per-page constant added.  Workgroup
+ * (page i, worker w) moves its share of each of page i's runs with 16-byte accesses (rows need only 4-byte alignment);
+ * no per-element search, no allocation, no synchronisation.  HBM-bound: 2 * n_out * n_cols * 4 bytes dominate.
+ * `in` / `out`: the two CSR directions (in-edge, out-edge); any weight pointer may be NULL (then the pair is skipped);
+ * label / label_out may be NULL.  feat_out has leading dimension n_cols (packed). */
+typedef struct gte_batch_arrays {
+    const int32_t* edge_off;      /* [P+1]  resident: first CSR entry of every page                                  */
+    const int32_t* indptr_loc;    /* packed per-page indptr (see gte_batch_csr)                                        */
+    const int32_t* indices_loc;   /* page-local column ids                                                             */
+    const float* weight;          /* CSR-ordered weights or NULL                                                       */
+    const int32_t* b_edge_off;    /* [n_batch+1] batch: first entry of every chosen page                               */
+    int32_t* indptr_out;          /* [n_out+1]                                                                         */
+    int32_t* indices_out;         /* [e_out]                                                                           */
+    float* weight_out;            /* [e_out] or NULL                                                                   */
+} gte_batch_arrays;
+int gte_batch_assemble(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,
+                       const gte_batch_arrays* in_edges, const gte_batch_arrays* out_edges,
+                       const float* feat, int64_t ld_feat, int64_t n_cols, float* feat_out,
+                       const float* label, float* label_out, int64_t n_out, void* stream);
 /* out[b_node_off[i] + r, 0:n_cols] = in[node_off[pages[i]] + r, 0:n_cols]  (features, labels stored as f32) */
 int gte_batch_rows(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,
                    const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t n_out, int64_t n_cols,
