@@ -168,6 +168,11 @@ class FusedGcnSageStep(TrainStep):
         self.fuse_ln_fwd = os.environ.get("GTE_FUSE_LN_FWD", "1") == "1"
         self._head_scale = None
         self._tail_ws = None
+        # called (once per step, no arguments) right before the LAST big kernel of a step is launched -- layer 0's dW GEMM,
+        # MFMA-bound, ~a quarter of the step.  The train loop hangs the assembly of the NEXT batch here (models/loop.py):
+        # it then runs on the side stream under that GEMM, and the batch is still in the Infinity Cache when the next
+        # step's first GEMM reads it.
+        self.before_last_gemm = None
 
     # -- buffers -------------------------------------------------------------------------------------
     def _alloc(self, cap: int, f0: int):
@@ -493,6 +498,8 @@ class FusedGcnSageStep(TrainStep):
             # transpose aggregation, the next LayerNorm backward) is mostly HBM-bound: run dW on the side stream so
             # the two kinds of work share the chip.  dz (= dy_i, final for this step) and ahn/h are read-only here.
             wdw = b["ws_dw"][i]
+            if i == 0 and self.before_last_gemm is not None:
+                self.before_last_gemm()
 
             def dw_launch(stream):
                 if qform:

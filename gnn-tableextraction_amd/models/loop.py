@@ -17,6 +17,7 @@ copies -- and those launches do not sit on the step's critical path:
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
@@ -109,12 +110,17 @@ class BatchPipeline:
         return self._info[s][2]
 
     # ---- per step --------------------------------------------------------------------------------
-    def start(self, s: int) -> None:
-        """Queue the assembly of step s's batch on the side stream (returns immediately)."""
+    def start(self, s: int, after_current: bool = False) -> None:
+        """Queue the assembly of step s's batch on the side stream (returns immediately).  ``after_current``: the assembly
+        additionally waits for everything queued on the CURRENT stream so far (used to place it under a chosen kernel)."""
         off, nb, n, e_in, e_out, n_sizes = self._info[s]
         k = s % self.depth
         if self._free_ev[k] is not None:
             self.side.wait_event(self._free_ev[k])               # the step that last read this buffer set has finished
+        if after_current and self.side is not torch.cuda.current_stream(self.device):
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(ev)
         g = self.res.assemble(self._meta_dev[off:off + 4 * nb + 3], nb, n, e_in, e_out, self._sets[k], n_sizes,
                               stream=self.side.cuda_stream)
         ev = torch.cuda.Event()
@@ -146,13 +152,33 @@ def run_steps(step, pipe: BatchPipeline, page_steps: Sequence[np.ndarray], n_glo
     if n_steps == 0:
         return out3
     pipe.start(0)
-    for s in range(n_steps):
-        if s + 1 < n_steps:
-            pipe.start(s + 1)
-        g = pipe.get(s)
-        out3 = step.step(g, g.ndata['label'], n_global=None if n_global is None else int(n_global[s]),
-                         loss_scale=None if loss_scale is None else float(loss_scale[s]))
-        pipe.release(s)
-        if on_step is not None:
-            on_step(s, g, out3)
+    # where the next batch is assembled: an engine with a `before_last_gemm` hook (FusedGcnSageStep) gets it under the last,
+    # MFMA-bound GEMM of the current step -- late enough that the batch is still cache-resident when the next step starts
+    # reading it, early enough to be off the critical path; other engines start it before the step
+    hooked = hasattr(step, "before_last_gemm") and os.environ.get("GTE_PIPE_LATE", "1") == "1"
+    pending = [None]
+
+    def late_start():
+        if pending[0] is not None:
+            pipe.start(pending[0], after_current=True)
+            pending[0] = None
+    if hooked:
+        step.before_last_gemm = late_start
+    try:
+        for s in range(n_steps):
+            if s + 1 < n_steps:
+                if hooked:
+                    pending[0] = s + 1
+                else:
+                    pipe.start(s + 1)
+            g = pipe.get(s)
+            out3 = step.step(g, g.ndata['label'], n_global=None if n_global is None else int(n_global[s]),
+                             loss_scale=None if loss_scale is None else float(loss_scale[s]))
+            late_start()                                 # engines / layouts that never reached the hook
+            pipe.release(s)
+            if on_step is not None:
+                on_step(s, g, out3)
+    finally:
+        if hooked:
+            step.before_last_gemm = None
     return out3
