@@ -2,11 +2,19 @@
 
 Restates ``src/models/model_predict.py:35-174``: rebuild ``GcnSAGE`` from the config, load the best
 weights ``WEIGHTS/{logs}.pt`` written by ``EarlyStopping`` (``src/utils/training.py:49``), run the forward
-on every page, collect per-page predictions (``all_pred``, what post-processing consumes:
-``postprocessing.py:199-224``) and per-class precision / recall / F1.  The reference runs ONE forward per
+on every page, collect the predictions and per-class precision / recall / F1.  The reference runs ONE forward per
 page (launch-latency bound at ~10^2-10^3 nodes); here pages are batched ``config.TRAINING.batch_size`` at a
 time (block-diagonal batching does not change a page's logits -- tested bitwise) and split per page after
 the arg-max.
+
+Output contract (what post-processing consumes):
+  ``{output}/all_pred/{logs}``        pickle of ONE FLAT python list of ints, the pages' node predictions concatenated in
+                                      ``data.graphs`` order -- exactly ``pickle.dump(all_pred, open(OUTPUT / 'all_pred' / logs,
+                                      'wb'))`` of model_predict.py:151,172-174; ``postprocessing.py:199-216`` slices it
+                                      back into pages by ``graph.num_nodes()``
+  ``{output}/predictions/{logs}.pkl`` extra, not in the reference: ``{'all_pred': [per-page lists], 'num_nodes': [...]}``
+The printed accuracy is the reference's "Mean Test Accuracy": the MEAN OVER PAGES of the per-page accuracy (:150,163),
+not the node-weighted accuracy (returned as ``accuracy_nodes``).
 """
 from __future__ import annotations
 
@@ -60,6 +68,7 @@ def test(data, config, weights_path=None, save_predictions=True):
 
     bs = max(1, int(config.TRAINING.batch_size))
     all_pred, all_true = [], []
+    mean_test_acc = 0.0
     with torch.no_grad():
         for b0 in range(0, len(data.graphs), bs):
             pages = [g.to(device) for g in data.graphs[b0:b0 + bs]]
@@ -67,15 +76,25 @@ def test(data, config, weights_path=None, save_predictions=True):
             pred = model(bg).argmax(dim=1).cpu().numpy()
             off = np.cumsum([0] + [g.num_nodes() for g in pages])
             for i, g in enumerate(pages):
-                all_pred.append(pred[off[i]:off[i + 1]])
-                all_true.append(g.ndata['label'].long().cpu().numpy())
+                pp, tt = pred[off[i]:off[i + 1]], g.ndata['label'].long().cpu().numpy()
+                all_pred.append(pp)
+                all_true.append(tt)
+                mean_test_acc += float((pp == tt).sum()) / max(g.num_nodes(), 1)          # per-page accuracy (:150)
     y_pred, y_true = np.concatenate(all_pred), np.concatenate(all_true)
     p, r, f1, conf = per_class_prf(y_true, y_pred, n_classes)
-    acc = float((y_pred == y_true).mean()) if len(y_true) else 0.0
-    print(" -> Test: Accuracy {:.4f} | macro-F1 {:.4f}".format(acc, float(f1.mean())))
+    acc_nodes = float((y_pred == y_true).mean()) if len(y_true) else 0.0
+    acc = mean_test_acc / max(len(data.graphs), 1)
+    print("Mean Test Accuracy {:.4f}".format(acc))                                        # :163
+    print(" -> node accuracy {:.4f} | macro-F1 {:.4f}".format(acc_nodes, float(f1.mean())))
+    flat = [int(v) for a in all_pred for v in a.tolist()]
     if save_predictions:
+        ap_dir = os.path.join(out_root, 'all_pred')                                       # OUTPUT / 'all_pred' (:172)
+        os.makedirs(ap_dir, exist_ok=True)
+        with open(os.path.join(ap_dir, logs), 'wb') as f:
+            pickle.dump(flat, f)                                                          # the reference's artefact (:174)
         pred_dir = os.path.join(out_root, 'predictions')
         os.makedirs(pred_dir, exist_ok=True)
         with open(os.path.join(pred_dir, f'{logs}.pkl'), 'wb') as f:
-            pickle.dump({'all_pred': [a.tolist() for a in all_pred]}, f)
-    return {'accuracy': acc, 'precision': p, 'recall': r, 'f1': f1, 'confusion': conf, 'all_pred': all_pred}
+            pickle.dump({'all_pred': [a.tolist() for a in all_pred], 'num_nodes': [len(a) for a in all_pred]}, f)
+    return {'accuracy': acc, 'accuracy_nodes': acc_nodes, 'precision': p, 'recall': r, 'f1': f1, 'confusion': conf,
+            'all_pred': all_pred, 'all_pred_flat': flat}

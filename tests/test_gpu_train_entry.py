@@ -64,6 +64,19 @@ def test_train_writes_reference_layout_and_learns(tmp_path):
     out = model_predict.test(data, cfg2)
     assert len(out["all_pred"]) == len(data) and out["accuracy"] > 0.3
     assert os.path.isfile(tmp_path / "predictions" / f"{logs}.pkl")
+    # the reference's artefact (model_predict.py:172-174): ONE flat list pickled to {output}/all_pred/{logs}, which
+    # post-processing slices back into pages by num_nodes (postprocessing.py:199-216)
+    import pickle
+    node_preds = pickle.load(open(tmp_path / "all_pred" / logs, "rb"))
+    assert isinstance(node_preds, list) and all(isinstance(v, int) for v in node_preds[:50])
+    assert len(node_preds) == sum(g.num_nodes() for g in data.graphs)
+    start_index = 0
+    for idx, graph in enumerate(data.graphs):
+        end_index = start_index + graph.num_nodes()
+        assert node_preds[start_index:end_index] == out["all_pred"][idx].tolist()
+        start_index = end_index
+    per_page = [float((out["all_pred"][i] == g.ndata["label"].long().numpy()).mean()) for i, g in enumerate(data.graphs)]
+    assert abs(out["accuracy"] - float(np.mean(per_page))) < 1e-12               # "Mean Test Accuracy" = mean over pages
     one_by_one = make_cfg(tmp_path, n_epochs=6, batch_size=1)
     one_by_one.TRAINING.batch_size = 8                                  # same run name (bt_8) -> same weights file
     cfg2.TRAINING.batch_size = 8
