@@ -29,6 +29,13 @@ SIGNATURES = {
     "gte_coo_to_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_batch_csr": (c_int, [c_void_p, c_int64] + [c_void_p] * 10 + [c_int64, c_int64, c_void_p]),
+    "gte_knn_max_k": (c_int, []),
+    "gte_knn_max_page_nodes": (c_int, []),
+    "gte_knn_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "gte_knn_csr_workspace_bytes": (c_int64, [c_int64]),
+    "gte_knn_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_int64, c_void_p]),
+    "gte_island_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_batch_assemble": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                    c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_batch_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,

@@ -79,5 +79,45 @@ class PrebuiltPages:
         return cls(pages, num_classes=int(z["num_classes"]), **kw)
 
     @classmethod
+    def from_boxes(cls, page_boxes, page_sizes, page_texts, page_labels, device, k: int = 5, max_dist: int = 500,
+                   bidirectional: bool = True, range_island: int = 0, extra_feats=None, **kw) -> "PrebuiltPages":
+        """Pages from word boxes with the graph stage on the DEVICE: k-NN edges, island removal,
+        to_simple + to_bidirected, edge weights (graph.knn_graph_from_boxes) and the 13 BBOX node features
+        (graph.bbox_features) -- what builder.get_graph + loader.modify_graphs + nlp/bbox.py do per page in Python.
+        ``page_boxes[p]`` int [n_p, 4], ``page_sizes[p]`` = (width, height), ``page_texts[p]`` the words (for the character
+        histogram; None -> empty texts), ``page_labels[p]`` converted class ids, ``extra_feats[p]`` optional float32 [n_p, F']
+        columns appended after the BBOX features (REPR / SPACY / SCIBERT embeddings stay pre-computed)."""
+        from ... import graph as G
+        from ..nlp.bbox import Bbox
+        device = torch.device(device)
+        n_pages = len(page_boxes)
+        sizes = [len(b) for b in page_boxes]
+        node_off = np.concatenate([[0], np.cumsum(sizes)])
+        bbox = torch.from_numpy(np.concatenate([np.asarray(b, dtype=np.int32).reshape(-1, 4) for b in page_boxes])).to(device)
+        labels = torch.from_numpy(np.concatenate([np.asarray(l, dtype=np.int64) for l in page_labels])).to(device)
+        g, keep = G.knn_graph_from_boxes(bbox, node_off, np.asarray(page_sizes, dtype=np.int32), k=k, max_dist=max_dist,
+                                         bidirectional=bidirectional, labels=labels, range_island=range_island)
+        texts = page_texts if page_texts is not None else [[""] * n for n in sizes]
+        feat = Bbox(device).features(page_boxes, texts)[keep]
+        if extra_feats is not None:
+            extra = torch.from_numpy(np.concatenate([np.asarray(e, dtype=np.float32) for e in extra_feats])).to(device)[keep]
+            feat = torch.cat([feat, extra], dim=1)
+        # per-page host arrays (the dataset object's contract: .graphs[i] with ndata feat/label, edata feat, .pages[i]['bboxs'])
+        src, dst = (t.cpu().numpy() for t in g.edges())
+        w = g.edata['feat'].cpu().numpy()
+        feat_h, lab_h, bbox_h = feat.cpu().numpy(), g.ndata['label'].cpu().numpy(), g.ndata['bbox'].cpu().numpy()
+        off = np.concatenate([[0], np.cumsum(g.batch_num_nodes_)])
+        eoff = np.searchsorted(dst, off)                   # edges are sorted by destination
+        pages = []
+        for p in range(n_pages):
+            n0, n1, e0, e1 = int(off[p]), int(off[p + 1]), int(eoff[p]), int(eoff[p + 1])
+            pages.append(S.Page((src[e0:e1] - n0).astype(np.int32), (dst[e0:e1] - n0).astype(np.int32), w[e0:e1],
+                                np.ascontiguousarray(feat_h[n0:n1]), lab_h[n0:n1].astype(np.int64), bbox_h[n0:n1]))
+        out = cls(pages, **kw)
+        g.ndata['feat'] = feat
+        out.whole = g                                       # the batched device graph, for callers that stay on the device
+        return out
+
+    @classmethod
     def synthetic(cls, n_pages: int, in_feats: int = 13, **kw) -> "PrebuiltPages":
         return cls(S.make_pages(n_pages, in_feats=in_feats), **kw)

@@ -495,3 +495,96 @@ def edge_weights_from_boxes(bbox: torch.Tensor, src: torch.Tensor, dst: torch.Te
                                          _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                "gte_edge_weights_bbox")
     return w
+
+
+# ================================================================================================
+# Page graphs from word boxes, on the device (SURVEY 8(f) N4 + N1 + N3)
+# ================================================================================================
+def bbox_features(bbox: torch.Tensor, char_counts: torch.Tensor) -> torch.Tensor:
+    """The 13 BBOX node features of src/components/nlp/bbox.py:49-124 (9 geometry values + the 4-bin character histogram)
+    as float32 [N, 13] -- ``_generate_features(...)`` + ``.float()`` of model_train.py:293-296 for the BBOX embedder.
+    ``char_counts`` int32 [N, 3] = (#letters, #digits, #others) of each word without spaces: classifying characters is
+    Unicode-table work (str.isalpha / str.isdigit) and stays on the host; every arithmetic step runs in gte_bbox_features."""
+    _lib.require_device(bbox, "bbox_features")
+    bbox = bbox.to(torch.int32).contiguous()
+    counts = char_counts.to(torch.int32).contiguous()
+    out = torch.empty((bbox.shape[0], 13), dtype=torch.float32, device=bbox.device)
+    _lib.check(_lib.load().gte_bbox_features(_lib.ptr(bbox), _lib.ptr(counts), _lib.ptr(out), 13, bbox.shape[0],
+                                             _lib.current_stream()), "gte_bbox_features")
+    return out
+
+
+def knn_graph_from_boxes(bbox: torch.Tensor, node_off, page_size, k: int = 5, max_dist: int = 500, bidirectional: bool = True,
+                         labels: Optional[torch.Tensor] = None, range_island: int = 0, text_label: int = 1,
+                         edge_features: bool = True):
+    """boxes -> batched k-NN page graph, entirely on the device.
+
+    What ``GraphBuilder.get_graph(mode='knn')`` (builder.py:240-292,383-411) and ``Papers2Graphs.modify_graphs``
+    (loader.py:296-344: fast_remove_islands, to_simple + to_bidirected, edge weights) do page by page in Python, for all pages
+    at once: gte_knn_select -> gte_knn_csr -> gte_island_mask (optional) -> gte_edge_weights_bbox.  ``bbox`` int32 [N, 4] (pages
+    concatenated), ``node_off`` [P + 1], ``page_size`` [P, 2] = (width, height) of each page image.
+    Returns (graph, keep): a block-diagonal :class:`PageGraph` whose in-edge CSR is already built (sources ascending inside a
+    row), ``edata['feat']`` = the edge weights, ``ndata['bbox']`` (and ``ndata['label']``) of the KEPT nodes; ``keep`` = bool [N]
+    over the input nodes (all True unless islands were removed).  One host synchronisation (the edge count)."""
+    from . import ops
+    _lib.require_device(bbox, "knn_graph_from_boxes")
+    lib, P = _lib.load(), _lib.ptr
+    dev = bbox.device
+    bbox = bbox.to(torch.int32).contiguous()
+    node_off_h = torch.as_tensor(node_off, dtype=torch.int64).cpu()
+    sizes = (node_off_h[1:] - node_off_h[:-1])
+    n, n_pages = int(node_off_h[-1]), sizes.numel()
+    if bbox.shape[0] != n:
+        raise ValueError(f"{bbox.shape[0]} boxes, node_off says {n}")
+    node_off_d = node_off_h.to(torch.int32).to(dev)
+    page_size_d = torch.as_tensor(page_size, dtype=torch.int32).reshape(-1, 2).to(dev).contiguous()
+    page_of_node = torch.repeat_interleave(torch.arange(n_pages, dtype=torch.int32, device=dev), sizes.to(dev))
+
+    def csr_of(sel, bidir):
+        indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        ws = ops._workspace(lib.gte_knn_csr_workspace_bytes(n), dev, "knn")
+        _lib.check(lib.gte_knn_csr(P(sel), P(node_off_d), P(page_of_node), n, k, int(bidir), 0, P(indptr), None, None, P(ws),
+                                   ws.numel(), _lib.current_stream()), "gte_knn_csr")
+        e = int(indptr[-1].item())                              # the one synchronisation: sizes of the edge arrays
+        indices = torch.empty(max(e, 1), dtype=torch.int32, device=dev)[:e]
+        dst_of = torch.empty(max(e, 1), dtype=torch.int32, device=dev)[:e]
+        if e:
+            _lib.check(lib.gte_knn_csr(P(sel), P(node_off_d), P(page_of_node), n, k, int(bidir), 1, P(indptr), P(indices),
+                                       P(dst_of), None, 0, _lib.current_stream()), "gte_knn_csr fill")
+        return indptr, indices, dst_of
+
+    sel = torch.empty((n, k), dtype=torch.int32, device=dev)
+    _lib.check(lib.gte_knn_select(P(bbox), P(node_off_d), P(page_size_d), n_pages, n, int(sizes.max()) if n_pages else 0, k,
+                                  int(max_dist), P(sel), _lib.current_stream()), "gte_knn_select")
+    indptr, indices, dst_of = csr_of(sel, bidirectional)
+    keep = torch.ones(n, dtype=torch.bool, device=dev)
+    if range_island and labels is not None:
+        lab32 = labels.to(dev).to(torch.int32).contiguous()
+        sym = (indptr, indices) if bidirectional else csr_of(sel, True)[:2]
+        island = torch.empty(n, dtype=torch.uint8, device=dev)
+        ws = ops._workspace(2 * n + 256, dev, "island")
+        _lib.check(lib.gte_island_mask(P(sym[0]), P(sym[1]), P(lab32), n, int(range_island), int(text_label), P(island), P(ws),
+                                       ws.numel(), _lib.current_stream()), "gte_island_mask")
+        keep = island == 0
+        if not bool(keep.all()):
+            # induced subgraph on the kept nodes (g.remove_nodes(to_remove), loader.py:300-301): index bookkeeping on the device
+            new_id = (torch.cumsum(keep.to(torch.int32), 0) - 1).to(torch.int32)
+            ok = keep[indices.long()] & keep[dst_of.long()]
+            indices, dst_of = new_id[indices[ok].long()].contiguous(), new_id[dst_of[ok].long()].contiguous()
+            kept_sizes = torch.zeros(n_pages, dtype=torch.int64, device=dev).index_add_(0, page_of_node.long(), keep.to(torch.int64))
+            sizes = kept_sizes.cpu()
+            bbox = bbox[keep].contiguous()
+            page_of_node = page_of_node[keep].contiguous()
+            n = int(sizes.sum())
+            deg = torch.zeros(n, dtype=torch.int32, device=dev).index_add_(0, dst_of.long(), torch.ones_like(dst_of))
+            indptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+            indptr[1:] = torch.cumsum(deg, 0)
+    g = PageGraph(indices, dst_of, n, device=dev)
+    g._in_csr = CSR(indptr, indices, torch.arange(indices.numel(), dtype=torch.int32, device=dev))   # COO is in row order
+    g.batch_num_nodes_ = sizes.tolist()
+    g.ndata["bbox"] = bbox
+    if labels is not None:
+        g.ndata["label"] = labels.to(dev)[keep] if not bool(keep.all()) else labels.to(dev)
+    if edge_features:
+        g.edata["feat"] = edge_weights_from_boxes(bbox, indices, dst_of, page_of_node, n_pages)
+    return g, keep

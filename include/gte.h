@@ -111,6 +111,33 @@ int gte_batch_csr(const int32_t* pages, int64_t n_batch, const int32_t* node_off
                   const int32_t* b_node_off, const int32_t* b_edge_off, const int32_t* indptr_loc,
                   const int32_t* indices_loc, const float* weight, int32_t* indptr_out, int32_t* indices_out,
                   float* weight_out, int64_t n_out, int64_t e_out, void* stream);
+/* ---- k-NN page-graph construction --------------------------------------------------------------
+ * Replaces GraphBuilder.get_graph(mode='knn') edge building (builder.py:240-292 over the projections of :383-395), dgl.to_simple +
+ * dgl.to_bidirected (loader.py:319-320) and fast_remove_islands (builder.py:567-582) for a whole set of pages at once.
+ * Inputs: bbox int32 [n_nodes, 4] (x0, y0, x1, y1; all pages concatenated, 16-byte aligned; boxes on the canvas:
+ * 0 <= x0 <= x1 <= width, 0 <= y0 <= y1 <= height), node_off[n_pages + 1], page_size int32 [n_pages, 2] = (width, height).
+ * Equal-distance candidates are ordered by (distance, node id) -- the reference's order among ties is an implementation detail
+ * of CPython sets and numpy's argsort (oracle/knn_graph.py, pinned on the reference's own output, does the same).
+ *   gte_knn_select  sel[n_nodes, k]: global ids of each node's selected neighbours (nearest first), -1 padded; k <= gte_knn_max_k(),
+ *                   pages of at most gte_knn_max_page_nodes() boxes.
+ *   gte_knn_csr     the in-edge CSR (rows = destinations, sources ascending, no duplicates) from sel: call with fill = 0 to get
+ *                   indptr[n_nodes + 1] (workspace >= gte_knn_csr_workspace_bytes), read E = indptr[n_nodes], then with fill = 1 to
+ *                   write indices[E] (sources) and dst_of[E] (the row of every entry: the COO form gte_edge_weights_bbox takes).
+ *                   bidirectional != 0: symmetric closure (to_simple + to_bidirected); else the reference's directed edge list.
+ *   gte_island_mask island[v] = 1 for nodes labelled text_label from which no walk of exactly khop steps over the (symmetric)
+ *                   CSR ends at a node with another label; workspace >= 2 * n_nodes bytes.
+ * Integer work only; no atomics, no sort: deterministic. */
+int gte_knn_max_k(void);
+int gte_knn_max_page_nodes(void);
+int gte_knn_select(const int32_t* bbox, const int32_t* node_off, const int32_t* page_size, int64_t n_pages, int64_t n_nodes,
+                   int64_t max_page_nodes, int k, int max_dist, int32_t* sel, void* stream);
+int64_t gte_knn_csr_workspace_bytes(int64_t n_nodes);
+int gte_knn_csr(const int32_t* sel, const int32_t* node_off, const int32_t* page_of_node, int64_t n_nodes, int k,
+                int bidirectional, int fill, int32_t* indptr, int32_t* indices, int32_t* dst_of, void* workspace,
+                int64_t workspace_bytes, void* stream);
+int gte_island_mask(const int32_t* indptr, const int32_t* indices, const int32_t* label, int64_t n_nodes, int khop,
+                    int text_label, uint8_t* island, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* The whole batch in ONE launch (what the train loop calls every step; gte_batch_csr / gte_batch_rows are its pieces):
  * a page's rows are CONTIGUOUS in the resident arrays and in the batch, so every array of the batch is the concatenation
  * of per-page runs -- features and labels copied, indptr / indices copied with a per-page constant added.  Workgroup

@@ -79,3 +79,98 @@ def test_island_removal_by_hand():
     labels = np.array([1, 1, 1, 1, 5])
     assert kg.island_nodes(src, dst, labels, 5, khop=2).tolist() == [0, 1, 3]
     assert kg.island_nodes(src, dst, labels, 5, khop=1).tolist() == [0, 1, 2]
+
+
+# ------------------------------------------------------------------------------------------------ HIP, through the C ABI
+def _device_graph(pages, bidirectional=True, labels=None, range_island=0):
+    import torch
+    from gnn_tableextraction_amd import graph as G
+    boxes = np.concatenate([p[0] for p in pages]).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in pages])])
+    sizes = np.array([p[1] for p in pages], dtype=np.int32)
+    ks, mds = {p[2] for p in pages}, {p[3] for p in pages}
+    assert len(ks) == 1 and len(mds) == 1
+    g, keep = G.knn_graph_from_boxes(torch.from_numpy(boxes).cuda(), off, sizes, k=ks.pop(), max_dist=mds.pop(),
+                                     bidirectional=bidirectional, labels=None if labels is None else torch.from_numpy(labels),
+                                     range_island=range_island)
+    return g, keep, off
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bidirectional", [True, False])
+def test_device_knn_graph_equals_the_oracle_bitwise(bidirectional):
+    """gte_knn_select + gte_knn_csr over several pages at once vs the oracle page by page: the same edge set, in (dst, src)
+    order; edge weights bit-exact against oracle/box_geometry.py."""
+    import torch
+    from oracle import box_geometry as bg
+    for k, maxd in ((5, 500), (3, 60), (8, 500)):
+        pages = [(b, s, k, maxd) for (b, s, _, _) in kg.fixture_pages(seed=21 + k)]
+        g, keep, off = _device_graph(pages, bidirectional)
+        assert bool(keep.all())
+        src, dst = (t.cpu().numpy().astype(np.int64) for t in g.edges())
+        w = g.edata["feat"].cpu().numpy()
+        assert (np.diff(dst) >= 0).all()
+        for p, (b, size, _, _) in enumerate(pages):
+            u, v = kg.knn_edges(b, size, k, maxd)
+            if bidirectional:
+                u, v = kg.to_simple_bidirected(u, v, len(b))
+            else:
+                order = np.lexsort((u, v))
+                u, v = u[order], v[order]
+            m = (dst >= off[p]) & (dst < off[p + 1])
+            np.testing.assert_array_equal(src[m] - off[p], u)
+            np.testing.assert_array_equal(dst[m] - off[p], v)
+            if len(u):
+                np.testing.assert_array_equal(w[m], bg.edge_weights(b, u, v))
+        ip = g.in_csr().indptr.cpu().numpy()
+        np.testing.assert_array_equal(np.diff(ip), np.bincount(dst, minlength=g.num_nodes()))
+
+
+@pytest.mark.gpu
+def test_device_knn_graph_equals_the_reference_fixture_where_unambiguous():
+    """Straight against the reference's own ``get_edges`` output (tests/golden/aux_knn_edges.npz): bidirected edge sets equal
+    at every node whose selection is unique."""
+    for i in PAGES:
+        b, size, k, maxd, ru, rv = _page(i)
+        g, keep, off = _device_graph([(b, size, k, maxd)])
+        src, dst = (t.cpu().numpy().astype(np.int64) for t in g.edges())
+        amb = np.array([s[2] for s in kg.knn_select(b, size, k, maxd)])
+        rs, rd = kg.to_simple_bidirected(ru, rv, len(b))
+        touched = lambda e: amb[e[0]] or amb[e[1]]
+        got = {e for e in zip(src.tolist(), dst.tolist()) if not touched(e)}
+        ref = {e for e in zip(rs.tolist(), rd.tolist()) if not touched(e)}
+        assert got == ref
+
+
+@pytest.mark.gpu
+def test_device_island_removal_and_loader_from_boxes():
+    import torch
+    from gnn_tableextraction_amd.components.graphs.loader import PrebuiltPages
+    from oracle import bbox_features as ob
+    pages = kg.fixture_pages(seed=5)[:6]
+    rng = np.random.default_rng(0)
+    labels = [np.where(rng.random(len(p[0])) < 0.08, 5, 1).astype(np.int64) for p in pages]     # mostly TEXT, a few FIGURE
+    texts = [["w%d." % j if j % 3 else "Ab12" for j in range(len(p[0]))] for p in pages]
+    data = PrebuiltPages.from_boxes([p[0] for p in pages], [p[1] for p in pages], texts, labels, "cuda:0", k=5, max_dist=500,
+                                    range_island=2)
+    removed = 0
+    for p, (b, size, _, _) in enumerate(pages):
+        u, v = kg.knn_edges(b, size, 5, 500)
+        s, d = kg.to_simple_bidirected(u, v, len(b))
+        isl = kg.island_nodes(s, d, labels[p], len(b), khop=2)
+        keep = np.ones(len(b), bool)
+        keep[isl] = False
+        removed += len(isl)
+        new_id = np.cumsum(keep) - 1
+        ok = keep[s] & keep[d]
+        want_s, want_d = new_id[s[ok]], new_id[d[ok]]
+        pg = data.page_arrays[p]
+        assert pg.num_nodes == int(keep.sum())
+        np.testing.assert_array_equal(pg.src, want_s)
+        np.testing.assert_array_equal(pg.dst, want_d)
+        np.testing.assert_array_equal(pg.label, labels[p][keep])
+        np.testing.assert_array_equal(pg.bbox, b[keep])
+        counts = np.array([ob.char_counts(t) for t in texts[p]])[keep]
+        np.testing.assert_array_equal(pg.feat, ob.bbox_features(b[keep], counts))          # BBOX features, bit-exact
+    assert removed > 0                                              # the case does exercise the removal
+    assert data.whole.num_nodes() == sum(pg.num_nodes for pg in data.page_arrays)
