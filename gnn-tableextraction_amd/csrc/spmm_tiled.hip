@@ -55,7 +55,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // compiler would otherwise pad itself: a VALU write to the data registers of a >8-byte store right behind it.
 __device__ __forceinline__ void st4_hidden(float* p, float4 v) {
     const v4f t = {v.x, v.y, v.z, v.w};
+    // nt: the output rows are written once and not read again by this kernel -- streaming stores leave L2 to the source rows
+    // that neighbouring tiles re-read (cfg4, same process, interleaved rounds: 841 -> 821 us; as a pure copy, self-loop graph:
+    // 5.37 -> 5.61 TB/s; bitwise identical output).  nt LOADS of the source rows lose that reuse: 841 -> 1205 us.
+#ifdef GTE_TILED_PLAIN_STORE
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#endif
 }
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid) {
@@ -267,7 +274,11 @@ spmm_tiled_full_kernel(const int32_t* __restrict__ indptr, const int32_t* __rest
         const char* const xc = xb + (int64_t)c0 * 4;           // uniform
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
+#ifdef GTE_TILED_NT_LOAD
+            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(xc + so[k]));
+#else
             const f4u t = *reinterpret_cast<const f4u*>(xc + so[k]);
+#endif
             pre[k] = make_float4(t.x, t.y, t.z, t.w);
         }
     };
@@ -278,6 +289,10 @@ spmm_tiled_full_kernel(const int32_t* __restrict__ indptr, const int32_t* __rest
     auto reduce_chunk = [&](int c0) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int e = eb;
+#ifdef GTE_TILED_NOREDUCE                                      // measurement build: one staged row per destination, no edge loop
+        if (e < ee) { const Edge ea = s_e[e]; acc = *reinterpret_cast<const float4*>(sr + ea.off); }
+        e = ee;
+#endif
         for (; e + 1 < ee; e += 2) {                           // two LDS rows in flight
             const Edge ea = s_e[e], eb2 = s_e[e + 1];
             const float4 a = *reinterpret_cast<const float4*>(sr + ea.off);
