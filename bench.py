@@ -21,6 +21,7 @@ Extra objects in the JSON line:
   long_run      the same loop for >= 1 s of device time (the driver's 20-step region is ~15 ms)
   replay        secondary: HIP-graph replay of pre-captured resident batches (round 1's headline mode)
   gather        the aggregation kernel on BASELINE cfg4 (1 M nodes, deg 12, F = 512): HBM GB/s
+  cfg3          BASELINE configs[2]: 4-head GAT, bf16 MFMA projection + bf16 gathers (no reference counterpart: parity unpinned)
   val_graph     cfg2 "val graph" case: every page of a validation set in ONE graph, forward only (model_train.py:349-353)
   cpu_baseline  the CPU oracle (oracle/gcnsage_cpu.py: torch-CPU + OpenMP CSR SpMM) on one batch, on this box's
                 host cores ("port"; baseline only)
@@ -67,6 +68,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the F0=13 (BBOX features only) variant of cfg2")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the GAT bf16 probe (BASELINE configs[2])")
     ap.add_argument("--gather-nodes", type=int, default=1_000_000)
     ap.add_argument("--val-graph", type=int, default=2000, metavar="PAGES",
                     help="forward-only pass over PAGES pages batched into one graph (cfg2 'val graph'; 0: skip)")
@@ -264,6 +266,95 @@ def secondary_probe(args, gte, S, dev, pages13):
     out["replay_nodes_per_s"] = n2 / el2
     out["replay_ms_per_step"] = el2 / steps * 1e3
     trainer.release()
+    return out
+
+
+def cfg3_probe(args, gte, dev):
+    """BASELINE configs[2]: "PubTables-1M table-structure graphs, 4-head GAT bf16" -- no reference counterpart (the
+    reference has no GAT and builds no table graphs), PARITY UNPINNED (oracle = oracle/gat_cpu.py, the build's own restatement).
+    Synthetic table-cell grids (R ~ U{3..40} rows x C ~ U{2..12} columns, edges to row / column neighbours, both directions),
+    GAT 3 layers x 4 heads x 64, bf16 projection (v_mfma_f32_32x32x16_bf16, fp32 accumulate) + bf16 gathers; a step = forward +
+    CE + backward + Adam."""
+    from gnn_tableextraction_amd import graph as G, ops, _lib
+    rng = np.random.default_rng(3)
+    srcs, dsts, off = [], [], 0
+    while off < 200_000:
+        R, C = int(rng.integers(3, 41)), int(rng.integers(2, 13))
+        idx = np.arange(R * C).reshape(R, C)
+        pairs = np.concatenate([np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()]), np.stack([idx[:-1].ravel(), idx[1:].ravel()])], 1)
+        pairs = np.concatenate([pairs, pairs[::-1]], 1)
+        srcs.append(pairs[0] + off); dsts.append(pairs[1] + off); off += R * C
+    src, dst, n = np.concatenate(srcs), np.concatenate(dsts), off
+    f_in, heads, hid, ncls = 32, 4, 64, 5
+    torch.manual_seed(0)
+    g = G.PageGraph(src, dst, n, device=dev)
+    x = torch.randn(n, f_in, device=dev)
+    y = torch.from_numpy(rng.integers(0, ncls, n)).to(dev)
+    out = {"workload": f"cfg3: {n} table-cell nodes / {len(src)} edges (synthetic grids), GAT 3 layers x {heads} heads x {hid}, "
+                       f"F0={f_in}, {ncls} classes; parity unpinned (no reference GAT)"}
+    for tag, cd, gd in (("bf16", torch.bfloat16, torch.bfloat16), ("f32", torch.float32, torch.float32)):
+        torch.manual_seed(1)
+        model = gte.GAT(f_in, hid, ncls, n_layers=3, heads=heads, gather_dtype=gd, compute_dtype=cd).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01)
+
+        def step():
+            loss, _ = ops.cross_entropy(model(g, x), y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            loss = step()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / 20
+        out[tag] = {"ms_per_step": el * 1e3, "nodes_per_s": n / el, "final_loss": float(loss)}
+    # the two kernels the precision choice changes, alone: hidden-layer projection (K = N = 256) and its aggregation
+    lib, P, st = _lib.load(), _lib.ptr, _lib.current_stream()
+    hd = heads * hid
+    h = torch.randn(n, hd, device=dev)
+    w = torch.randn(hd, hd, device=dev) * 0.05
+    from gnn_tableextraction_amd.components.graphs.gat import _bf16_copy
+    hb, wb = _bf16_copy(h), _bf16_copy(w)
+    z = torch.empty(n, hd, device=dev)
+
+    def ev_time(fn, reps=20):
+        for _ in range(5):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+    ms_b = ev_time(lambda: lib.gte_gemm_bf16_nt(P(hb), hd, P(wb), hd, P(z), hd, n, hd, hd, st))
+    ms_f = ev_time(lambda: ops.gemm(h, w, trans_b=True, out=z))
+    flops = 2.0 * n * hd * hd
+    bytes_b = n * hd * (2 + 4) + hd * hd * 2
+    out["projection_256x256"] = {"kernel": "gemm_bf16_nt_kernel (v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+                                 "bf16_ms": ms_b, "bf16_TFLOPs": flops / ms_b / 1e9, "f32_mfma_ms": ms_f, "f32_TFLOPs": flops / ms_f / 1e9,
+                                 "roofline": {"bound": "hbm", "achieved": bytes_b / ms_b / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": bytes_b / ms_b / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes": bytes_b,
+                                              "note": "2 K N flop per (2 K + 4 N) bytes = 85 flop/B, bf16 ridge ~310: HBM-bound"}}
+    csr = g.in_csr()
+    a_l, a_r = torch.randn(hd, device=dev) * 0.1, torch.randn(hd, device=dev) * 0.1
+    el_, er_ = torch.empty(n, heads, device=dev), torch.empty(n, heads, device=dev)
+    zb = torch.empty(n, hd, dtype=torch.bfloat16, device=dev)
+    lib.gte_gat_scores(P(z), hd, P(a_l), P(a_r), P(el_), P(er_), P(zb), hd, n, heads, hid, st)
+    o32, ob = torch.empty(n, hd, device=dev), torch.empty(n, hd, dtype=torch.bfloat16, device=dev)
+    smax, ssum = torch.empty_like(el_), torch.empty_like(el_)
+    ms_a = ev_time(lambda: lib.gte_gat_aggregate_fwd_ex(P(csr.indptr), P(csr.indices), P(zb), hd, 1, P(el_), P(er_), None, P(o32), hd,
+                                                        P(smax), P(ssum), n, heads, hid, 1, P(ob), hd, None, 0, None, st))
+    e_cnt = csr.indices.numel()
+    bytes_a = n * hd * (2 + 4 + 2) + e_cnt * (4 + heads * 4) + n * (4 + heads * 16)
+    out["aggregation_256"] = {"kernel": "gat_aggregate_fwd_kernel<bf16> (online edge softmax, ELU + bf16 copy in the epilogue)",
+                              "ms": ms_a, "roofline": {"bound": "hbm", "achieved": bytes_a / ms_a / 1e6, "peak": HBM_PEAK_GBS,
+                                                       "unit": "GB/s", "frac": bytes_a / ms_a / 1e6 / HBM_PEAK_GBS,
+                                                       "algorithmic_bytes": bytes_a}}
     return out
 
 
@@ -552,6 +643,8 @@ def main():
             line["gather"] = gather_probe(args, gte, S, dev)
         if pages13 is not None:
             line["secondary"] = secondary_probe(args, gte, S, dev, pages13)
+        if extras and not args.no_cfg3:
+            line["cfg3"] = cfg3_probe(args, gte, dev)
         if val_pages is not None:
             line["val_graph"] = val_graph_probe(args, gte, S, model, dev, val_pages)
         if world == 1 and not args.no_cpu_baseline:

@@ -29,6 +29,8 @@ SIGNATURES = {
     "gte_coo_to_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_batch_csr": (c_int, [c_void_p, c_int64] + [c_void_p] * 10 + [c_int64, c_int64, c_void_p]),
+    "gte_cast_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "gte_gemm_bf16_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "gte_knn_max_k": (c_int, []),
     "gte_knn_max_page_nodes": (c_int, []),
     "gte_knn_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
@@ -102,6 +104,11 @@ SIGNATURES = {
                                c_int, c_int, c_void_p]),
     "gte_gat_aggregate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "gte_gat_aggregate_fwd_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
+                                         c_void_p, c_int64, c_void_p, c_void_p]),
+    "gte_gat_dout_prepare": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                     c_void_p]),
     "gte_gat_bwd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "gte_gat_aggregate_bwd": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_void_p, c_int64] + [c_void_p] * 7 +
                               [c_int64] + [c_void_p] * 4 + [c_int64] + [c_void_p] * 3 + [c_int64, c_int, c_int,

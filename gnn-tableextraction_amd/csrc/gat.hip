@@ -21,11 +21,15 @@ namespace {
 constexpr int MAXH = 8;
 constexpr float kSlope = 0.2f;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+struct GatEpilogue {                  // optional epilogue of the forward aggregation (all NULL / 0: plain out = agg + bias)
+    int activation;                   // 1: ELU
+    unsigned short* out_bf16; int64_t ldob;        // bf16 copy of the (activated) output
+    float* out_mean; int64_t ldom; const float* mean_bias;   // mean over heads [n, D] (+ bias[D])
+};
+
+// wave-wide sum on DPP modifiers + four readlanes (gte_common.h): no LDS-pipe instruction.  (The __shfl_xor butterfly is six
+// ds_bpermute round trips; the backward takes heads x 2 of these per edge.)
+__device__ __forceinline__ float wave_sum(float v) { return gte_group_sum<64>(v); }
 __device__ __forceinline__ float leaky(float s) { return s > 0.f ? s : kSlope * s; }
 __device__ __forceinline__ float ldz(const float* p) { return *p; }
 __device__ __forceinline__ float ldz(const unsigned short* p) { return __uint_as_float(((unsigned)*p) << 16); }
@@ -58,7 +62,9 @@ __global__ void __launch_bounds__(256)
 gat_aggregate_fwd_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                          const T* __restrict__ z, int64_t ldzz, const float* __restrict__ el,
                          const float* __restrict__ er, const float* __restrict__ bias, float* __restrict__ out,
-                         int64_t ldo, float* __restrict__ smax, float* __restrict__ ssum, int n, int H, int D) {
+                         int64_t ldo, float* __restrict__ smax, float* __restrict__ ssum, int n, int H, int D,
+                         const GatEpilogue ep) {
+    extern __shared__ float s_mean[];                       // [4 waves][H * D], only with ep.out_mean
     const int lane = threadIdx.x & 63;
     const int v = (int)gte_xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     if (v >= n) return;
@@ -93,11 +99,41 @@ gat_aggregate_fwd_kernel(const int32_t* __restrict__ indptr, const int32_t* __re
     for (int j = 0; j < NJ; ++j) {
         const int f = lane + 64 * j;
         if (f < HD) {
-            const float o = (hi > lo ? acc[j] / l[j] : 0.f) + (bias ? bias[f] : 0.f);
-            out[(int64_t)v * ldo + f] = o;
+            float o = (hi > lo ? acc[j] / l[j] : 0.f) + (bias ? bias[f] : 0.f);
+            if (ep.activation == 1) o = o > 0.f ? o : expm1f(o);                     // ELU between GAT layers, in the epilogue
+            if (out) out[(int64_t)v * ldo + f] = o;
+            if (ep.out_bf16) {                                                        // the next layer's bf16 GEMM operand
+                __bf16 b = (__bf16)o;
+                ep.out_bf16[(int64_t)v * ep.ldob + f] = *reinterpret_cast<unsigned short*>(&b);
+            }
+            if (ep.out_mean) s_mean[(threadIdx.x >> 6) * HD + f] = o;
             if (f % D == 0) { smax[(int64_t)v * H + hj[j]] = m[j]; ssum[(int64_t)v * H + hj[j]] = l[j]; }
         }
     }
+    if (ep.out_mean) {                                     // output layer: mean over the heads (+ its bias), same wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float* sm = s_mean + (threadIdx.x >> 6) * HD;
+        for (int d = lane; d < D; d += 64) {
+            float s = 0.f;
+            for (int h = 0; h < H; ++h) s += sm[h * D + d];
+            ep.out_mean[(int64_t)v * ep.ldom + d] = s / (float)H + (ep.mean_bias ? ep.mean_bias[d] : 0.f);
+        }
+    }
+}
+
+// dfull[v, f] = (mean_heads ? dout[v, f % D] / H : dout[v, f]) * (act_out ? ELU'(from the activated output) : 1)
+__global__ void __launch_bounds__(256)
+gat_dout_prepare_kernel(const float* __restrict__ dout, int64_t lddo, const float* __restrict__ act_out, int64_t ldao,
+                        float* __restrict__ dfull, int64_t lddf, int64_t n, int H, int D, int mean_heads) {
+    const int HD = H * D;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * HD) return;
+    const int64_t v = i / HD;
+    const int f = (int)(i % HD);
+    float g = mean_heads ? dout[v * lddo + f % D] / (float)H : dout[v * lddo + f];
+    if (act_out) { const float o = act_out[v * ldao + f]; g *= o > 0.f ? 1.f : o + 1.f; }      // d ELU = 1 or exp(x) = out + 1
+    dfull[v * lddf + f] = g;
 }
 
 // Backward A: per destination row v -> ds[e, h] (in-CSR order) and der[v, h]
@@ -226,7 +262,7 @@ gat_bwd_src_kernel(const int32_t* __restrict__ rindptr, const int32_t* __restric
 }
 
 // column sums over the nodes: da_l[f] = sum_v del[v,h(f)] z[v,f], da_r[f] = sum_v der[v,h(f)] z[v,f], dbias[f] = sum_v dout[v,f]
-constexpr int GC_ROWS = 64;
+constexpr int GC_ROWS = 256;
 __global__ void __launch_bounds__(256)
 gat_colsum_kernel(const float* __restrict__ z, int64_t ldzf, const float* __restrict__ del, const float* __restrict__ der,
                   const float* __restrict__ dout, int64_t lddo, float* __restrict__ partial, int n, int H, int D) {
@@ -245,19 +281,32 @@ gat_colsum_kernel(const float* __restrict__ z, int64_t ldzf, const float* __rest
         pp[f] = a; pp[HD + f] = b; pp[2 * HD + f] = c;
     }
 }
-__global__ void __launch_bounds__(256)
+// fold the block partials in a fixed order: block = 64 columns x 16 slices of the block list, slice sums added in slice order
+// through LDS.  (One thread per column walking ALL block partials one load at a time -- 3 125 dependent iterations at 200 k
+// nodes -- took 800 us per layer, a quarter of the cfg3 step.)
+__global__ void __launch_bounds__(1024)
 gat_fold_kernel(const float* __restrict__ partial, int nblk, int HD, float* __restrict__ da_l, float* __restrict__ da_r,
                 float* __restrict__ dbias) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= HD) return;
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + lane;
     float a = 0.f, b = 0.f, c = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        const float* pp = partial + (int64_t)k * 3 * HD;
-        a += pp[f]; b += pp[HD + f]; c += pp[2 * HD + f];
+    if (f < HD) {
+#pragma unroll 4
+        for (int k = slice; k < nblk; k += 16) {
+            const float* pp = partial + (int64_t)k * 3 * HD;
+            a += pp[f]; b += pp[HD + f]; c += pp[2 * HD + f];
+        }
     }
-    if (da_l) da_l[f] = a;
-    if (da_r) da_r[f] = b;
-    if (dbias) dbias[f] = c;
+    red[0][slice][lane] = a; red[1][slice][lane] = b; red[2][slice][lane] = c;
+    __syncthreads();
+    if (slice < 3 && f < HD) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[slice][k][lane];
+        float* dst = slice == 0 ? da_l : slice == 1 ? da_r : dbias;
+        if (dst) dst[f] = s;
+    }
 }
 
 int check_dims(int64_t n, int H, int D, const char* who) {
@@ -285,26 +334,51 @@ extern "C" int gte_gat_scores(const float* z, int64_t ldz, const float* a_l, con
     return gte::check_launch("gat_scores");
 }
 
-extern "C" int gte_gat_aggregate_fwd(const int32_t* indptr, const int32_t* indices, const void* z, int64_t ldz, int dtype,
-                                     const float* el, const float* er, const float* bias, float* out, int64_t ldo,
-                                     float* smax, float* ssum, int64_t n_nodes, int heads, int dim, void* stream) {
+extern "C" int gte_gat_aggregate_fwd_ex(const int32_t* indptr, const int32_t* indices, const void* z, int64_t ldz, int dtype,
+                                        const float* el, const float* er, const float* bias, float* out, int64_t ldo,
+                                        float* smax, float* ssum, int64_t n_nodes, int heads, int dim, int activation,
+                                        void* out_bf16, int64_t ldob, float* out_mean, int64_t ldom, const float* mean_bias,
+                                        void* stream) {
     if (int rc = check_dims(n_nodes, heads, dim, "gat_aggregate_fwd")) return rc;
     if (n_nodes == 0) return GTE_OK;
-    if (!indptr || !z || !el || !er || !out || !smax || !ssum)
+    if (!indptr || !z || !el || !er || (!out && !out_mean) || !smax || !ssum)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gat_aggregate_fwd: null pointer");
+    if (activation != 0 && activation != 1) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gat_aggregate_fwd: activation 0 | 1 (ELU)");
     const int HD = heads * dim;
+    if ((out_bf16 && ldob < HD) || (out_mean && ldom < dim) || (out && ldo < HD))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gat_aggregate_fwd: leading dimension too small");
+    const GatEpilogue ep = {activation, (unsigned short*)out_bf16, ldob, out_mean, ldom, mean_bias};
+    const size_t shm = out_mean ? (size_t)4 * HD * sizeof(float) : 0;
     dim3 grid((unsigned)gte::ceil_div(n_nodes, 4)), block(256);
     hipStream_t s = gte::as_stream(stream);
 #define CALL(NJ)                                                                                                          \
     if (dtype == GTE_BF16)                                                                                                \
-        hipLaunchKernelGGL((gat_aggregate_fwd_kernel<unsigned short, NJ>), grid, block, 0, s, indptr, indices,           \
-                           (const unsigned short*)z, ldz, el, er, bias, out, ldo, smax, ssum, (int)n_nodes, heads, dim); \
+        hipLaunchKernelGGL((gat_aggregate_fwd_kernel<unsigned short, NJ>), grid, block, shm, s, indptr, indices,         \
+                           (const unsigned short*)z, ldz, el, er, bias, out, ldo, smax, ssum, (int)n_nodes, heads, dim, ep); \
     else                                                                                                                  \
-        hipLaunchKernelGGL((gat_aggregate_fwd_kernel<float, NJ>), grid, block, 0, s, indptr, indices, (const float*)z,   \
-                           ldz, el, er, bias, out, ldo, smax, ssum, (int)n_nodes, heads, dim)
+        hipLaunchKernelGGL((gat_aggregate_fwd_kernel<float, NJ>), grid, block, shm, s, indptr, indices, (const float*)z, \
+                           ldz, el, er, bias, out, ldo, smax, ssum, (int)n_nodes, heads, dim, ep)
     GTE_NJ_DISPATCH(HD, CALL)
 #undef CALL
     return gte::check_launch("gat_aggregate_fwd");
+}
+
+extern "C" int gte_gat_aggregate_fwd(const int32_t* indptr, const int32_t* indices, const void* z, int64_t ldz, int dtype,
+                                     const float* el, const float* er, const float* bias, float* out, int64_t ldo,
+                                     float* smax, float* ssum, int64_t n_nodes, int heads, int dim, void* stream) {
+    return gte_gat_aggregate_fwd_ex(indptr, indices, z, ldz, dtype, el, er, bias, out, ldo, smax, ssum, n_nodes, heads, dim, 0,
+                                    nullptr, 0, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int gte_gat_dout_prepare(const float* dout, int64_t lddo, const float* act_out, int64_t ldao, float* dfull,
+                                    int64_t lddf, int64_t n_nodes, int heads, int dim, int mean_heads, void* stream) {
+    if (int rc = check_dims(n_nodes, heads, dim, "gat_dout_prepare")) return rc;
+    if (n_nodes == 0) return GTE_OK;
+    if (!dout || !dfull) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gat_dout_prepare: null pointer");
+    const int64_t work = n_nodes * heads * dim;
+    hipLaunchKernelGGL(gat_dout_prepare_kernel, dim3((unsigned)gte::ceil_div(work, 256)), dim3(256), 0, gte::as_stream(stream), dout,
+                       lddo, act_out, ldao, dfull, lddf, n_nodes, heads, dim, mean_heads);
+    return gte::check_launch("gat_dout_prepare");
 }
 
 extern "C" int64_t gte_gat_bwd_workspace_bytes(int64_t n_nodes, int heads, int dim) {
@@ -343,7 +417,7 @@ extern "C" int gte_gat_aggregate_bwd(const int32_t* indptr, const int32_t* indic
     float* part = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(gat_colsum_kernel, dim3((unsigned)nblk), dim3(256), 0, s, z_f32, ldzf, del, der, dout, lddo, part,
                        (int)n_nodes, heads, dim);
-    hipLaunchKernelGGL(gat_fold_kernel, dim3((unsigned)gte::ceil_div(HD, 256)), dim3(256), 0, s, part, nblk, HD, da_l, da_r,
+    hipLaunchKernelGGL(gat_fold_kernel, dim3((unsigned)gte::ceil_div(HD, 64)), dim3(1024), 0, s, part, nblk, HD, da_l, da_r,
                        dbias);
     return gte::check_launch("gat_aggregate_bwd");
 }

@@ -111,6 +111,16 @@ int gte_batch_csr(const int32_t* pages, int64_t n_batch, const int32_t* node_off
                   const int32_t* b_node_off, const int32_t* b_edge_off, const int32_t* indptr_loc,
                   const int32_t* indices_loc, const float* weight, int32_t* indptr_out, int32_t* indices_out,
                   float* weight_out, int64_t n_out, int64_t e_out, void* stream);
+/* ---- bf16 projection of the GAT (BASELINE configs[2] "4-head GAT bf16"; SURVEY A13: no reference symbol, parity unpinned) ------
+ * gte_cast_bf16     y[r, :] = bf16(act(x[r, :])), act 0 = identity, 1 = ELU (the activation between GAT layers), zero padded to a
+ *                   multiple of 8 columns; y 16-byte aligned, ldy a multiple of 8.
+ * gte_gemm_bf16_nt  C[M, N] (fp32) = A[M, K] B[N, K]^T with bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+ *                   (z = X W^T of a GAT layer; W stored [heads * dim, in_feats] like nn.Linear).  Operands 16-byte aligned, K and
+ *                   the leading dimensions multiples of 8 (gte_cast_bf16 produces exactly that). */
+int gte_cast_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t rows, int64_t cols, int activation, void* stream);
+int gte_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                     int64_t K, void* stream);
+
 /* ---- k-NN page-graph construction --------------------------------------------------------------
  * Replaces GraphBuilder.get_graph(mode='knn') edge building (builder.py:240-292 over the projections of :383-395), dgl.to_simple +
  * dgl.to_bidirected (loader.py:319-320) and fast_remove_islands (builder.py:567-582) for a whole set of pages at once.
@@ -396,6 +406,17 @@ int gte_gat_scores(const float* z, int64_t ldz, const float* a_l, const float* a
 int gte_gat_aggregate_fwd(const int32_t* indptr, const int32_t* indices, const void* z, int64_t ldz, int dtype,
                           const float* el, const float* er, const float* bias /* nullable */, float* out, int64_t ldo,
                           float* smax, float* ssum, int64_t n_nodes, int heads, int dim, void* stream);
+/* The same with an epilogue (BASELINE configs[2]): activation 1 = ELU applied to (aggregate + bias) -- the activation between
+ * GAT layers; out_bf16 (nullable): bf16 copy of that output, the next layer's gte_gemm_bf16_nt operand; out_mean (nullable):
+ * [n, dim] mean over the heads + mean_bias[dim] -- the output layer (then `out` may be NULL).
+ * gte_gat_dout_prepare turns the gradient w.r.t. such an output back into the gradient gte_gat_aggregate_bwd takes:
+ * dfull[v, f] = (mean_heads ? dout[v, f % dim] / heads : dout[v, f]) * (act_out ? ELU'(act_out[v, f]) : 1). */
+int gte_gat_aggregate_fwd_ex(const int32_t* indptr, const int32_t* indices, const void* z, int64_t ldz, int dtype,
+                             const float* el, const float* er, const float* bias, float* out, int64_t ldo, float* smax,
+                             float* ssum, int64_t n_nodes, int heads, int dim, int activation, void* out_bf16, int64_t ldob,
+                             float* out_mean, int64_t ldom, const float* mean_bias, void* stream);
+int gte_gat_dout_prepare(const float* dout, int64_t lddo, const float* act_out, int64_t ldao, float* dfull, int64_t lddf,
+                         int64_t n_nodes, int heads, int dim, int mean_heads, void* stream);
 int64_t gte_gat_bwd_workspace_bytes(int64_t n_nodes, int heads, int dim);
 int gte_gat_aggregate_bwd(const int32_t* indptr, const int32_t* indices, const int32_t* rindptr, const int32_t* rindices,
                           const int32_t* pos_in, const void* z, int64_t ldz, int dtype, const float* z_f32, int64_t ldzf,

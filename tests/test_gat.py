@@ -38,15 +38,18 @@ def test_oracle_gat_layer_matches_dense_fp64():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,e,f,hid,heads,bf16", [(300, 2500, 13, 64, 4, False), (257, 1500, 40, 16, 2, False),
-                                                  (300, 2500, 13, 64, 4, True), (120, 900, 9, 7, 3, False)])
-def test_gat_matches_oracle_forward_and_backward(n, e, f, hid, heads, bf16):
+@pytest.mark.parametrize("n,e,f,hid,heads,bf16,mfma", [(300, 2500, 13, 64, 4, False, False), (257, 1500, 40, 16, 2, False, False),
+                                                       (300, 2500, 13, 64, 4, True, False), (120, 900, 9, 7, 3, False, False),
+                                                       (300, 2500, 13, 64, 4, True, True), (1000, 9000, 64, 64, 4, True, True),
+                                                       (257, 1500, 40, 16, 2, False, True)])
+def test_gat_matches_oracle_forward_and_backward(n, e, f, hid, heads, bf16, mfma):
     import gnn_tableextraction_amd as gte
     from gnn_tableextraction_amd import graph as G
     dev = "cuda:0"
     src, dst = random_graph(n, e, n)
     torch.manual_seed(1)
-    model = gte.GAT(f, hid, 9, n_layers=3, heads=heads, gather_dtype=torch.bfloat16 if bf16 else torch.float32)
+    model = gte.GAT(f, hid, 9, n_layers=3, heads=heads, gather_dtype=torch.bfloat16 if bf16 else torch.float32,
+                    compute_dtype=torch.bfloat16 if mfma else torch.float32)
     x = torch.randn(n, f)
     up = torch.randn(n, 9)
     params = [dict(w=l.fc.detach().clone().requires_grad_(True), a_l=l.attn_l.detach().clone().requires_grad_(True),
@@ -59,14 +62,18 @@ def test_gat_matches_oracle_forward_and_backward(n, e, f, hid, heads, bf16):
     got = model(g, x.to(dev))
     (got * up.to(dev)).sum().backward()
     tol = 2e-2 if bf16 else 2e-4                      # cfg3: 2e-2 with bf16 storage of the gathered features
+    if mfma:                                          # bf16 operands in the projection (fp32 accumulate): 8-bit mantissas on
+        tol = 3e-2 * float(want.detach().abs().max()) # every product of three stacked layers -- 3 % of the largest logit
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=tol, atol=tol)
     # gradients: attention-parameter grads are sums with heavy cancellation; with bf16-rounded gathers compare
     # against the largest entry (15 %), fp32 at 1e-3
     gtol = 0.15 if bf16 else 1e-3
+    if mfma:
+        gtol = 0.2
     for layer, p in zip(model.layers, params):
         for mine, ref in ((layer.fc, p["w"]), (layer.attn_l, p["a_l"]), (layer.attn_r, p["a_r"]), (layer.bias, p["bias"])):
             r = ref.grad.numpy()
-            np.testing.assert_allclose(mine.grad.cpu().numpy(), r, rtol=0 if bf16 else gtol, atol=gtol * (np.abs(r).max() + 1e-6))
+            np.testing.assert_allclose(mine.grad.cpu().numpy(), r, rtol=0 if (bf16 or mfma) else gtol, atol=gtol * (np.abs(r).max() + 1e-6))
 
 
 @pytest.mark.gpu
@@ -86,7 +93,7 @@ def test_gat_cfg3_shape_trains():
     src, dst = np.concatenate(srcs), np.concatenate(dsts)
     n = off
     torch.manual_seed(0)
-    model = gte.GAT(16, 64, 5, n_layers=3, heads=4, gather_dtype=torch.bfloat16).to(dev)
+    model = gte.GAT(16, 64, 5, n_layers=3, heads=4, gather_dtype=torch.bfloat16, compute_dtype=torch.bfloat16).to(dev)
     g = G.PageGraph(src, dst, n, device=dev)
     x = torch.randn(n, 16, device=dev)
     y = torch.from_numpy(rng.integers(0, 5, n)).to(dev)
@@ -98,3 +105,22 @@ def test_gat_cfg3_shape_trains():
         opt.zero_grad(); loss.backward(); opt.step()
         losses.append(loss.item())
     assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses[::10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(1000, 256, 64), (777, 36, 256), (129, 130, 8), (5000, 256, 256), (64, 256, 13)])
+def test_bf16_mfma_projection_is_exact_on_bf16_inputs(m, n, k):
+    """gte_gemm_bf16_nt: with operands that are exactly representable in bf16 (small integers) fp32 accumulation is exact --
+    the result must equal the fp64 product bit for bit; random operands against fp64 of the ROUNDED operands at 1e-6 relative."""
+    from gnn_tableextraction_amd.components.graphs.gat import _Linear, _bf16_copy
+    dev = "cuda:0"
+    rng = np.random.default_rng(m + n + k)
+    a = torch.from_numpy(rng.integers(-8, 9, (m, k)).astype(np.float32)).to(dev)
+    w = torch.from_numpy(rng.integers(-8, 9, (n, k)).astype(np.float32)).to(dev)
+    got = _Linear.apply(a, w, None, True).cpu().numpy()
+    np.testing.assert_array_equal(got, (a.cpu().double() @ w.cpu().double().t()).float().numpy())
+    a, w = torch.randn(m, k, device=dev), torch.randn(n, k, device=dev)
+    got = _Linear.apply(a, w, None, True).cpu().double()
+    ab, wb = _bf16_copy(a)[:, :k].float().cpu().double(), _bf16_copy(w)[:, :k].float().cpu().double()
+    np.testing.assert_allclose(got.numpy(), (ab @ wb.t()).numpy(), rtol=1e-5, atol=1e-5 * np.sqrt(k))
+    assert torch.equal(_bf16_copy(a, 1)[:, :k].float(), torch.nn.functional.elu(a).to(torch.bfloat16).float())   # ELU + cast
