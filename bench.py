@@ -18,7 +18,9 @@ RCCL all-reduce of the flat gradient per step.  One JSON line is printed by rank
 
 Extra objects in the JSON line:
   roofline      dominant kernel (fp32 MFMA forward GEMM), live HIP-event timing of the same steps
-  long_run      the same loop for >= 1 s of device time (the driver's 20-step region is ~15 ms)
+  long_run      the same loop for >= 1 s of device time, run BEFORE the W warm-up + K timed steps (the driver's 20-step
+                region is ~15 ms; measured right after an idle GPU woke up it reads ~7 % low: the chip has not reached its
+                sustained clocks -- a training run is at them)
   replay        secondary: HIP-graph replay of pre-captured resident batches (round 1's headline mode)
   gather        the aggregation kernel on BASELINE cfg4 (1 M nodes, deg 12, F = 512): HBM GB/s
   cfg3          BASELINE configs[2]: 4-head GAT, bf16 MFMA projection + bf16 gathers (no reference counterpart: parity unpinned)
@@ -519,10 +521,18 @@ def main():
             k += len(plan)
         return out
 
+    step_events = [] if os.environ.get("GTE_BENCH_STEP_TIMES") else None      # debug: per-step device times on stderr
+
+    def _mark(s, g, o):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        step_events.append((ev, g.num_nodes()))
+
     def run(epochs, counts):
         nodes, out3 = 0, None
         for plan, cnt in zip(epochs, counts):
-            out3 = loop.run_steps(trainer, pipe, plan, n_global=cnt if distributed else None)
+            out3 = loop.run_steps(trainer, pipe, plan, n_global=cnt if distributed else None,
+                                  on_step=_mark if step_events is not None else None)
             nodes += sum(pipe.nodes(i) for i in range(len(plan)))
         return nodes, out3
 
@@ -532,18 +542,25 @@ def main():
         torch.cuda.synchronize()
 
     warm_cnt, timed_cnt, prof_cnt = global_counts(warm), global_counts(timed), global_counts(prof)
-    run(warm, warm_cnt)
-    barrier()
-    t0 = time.perf_counter()
-    nodes_local, out3 = run(timed, timed_cnt)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    final_loss = float(out3[0])
-
+    # The other workloads of the line (cfg4 aggregation, validation graph) run FIRST: they are independent measurements, and
+    # the GPU reaches its sustained clocks under them -- a training run is at those clocks; a 20-step region measured
+    # seconds after an idle GPU woke up is not (measured: the same 20 steps take 7 % longer right after start-up).
+    pre = {}
+    if rank == 0 and world == 1 and not args.no_gather_probe:
+        pre["gather"] = gather_probe(args, gte, S, dev)
+    if val_pages is not None:
+        pre["val_graph"] = val_graph_probe(args, gte, S, model, dev, val_pages)
+        val_pages = None
+    torch.cuda.empty_cache()
+    # (all host-side planning for the warm-up and the timed steps is done above: nothing slow sits between the probes and them)
     # ---- secondary long run of the same loop: >= long_run_seconds of device time ------------------------------------
     long_run = None
     if args.long_run_seconds > 0:
-        n_long = max(args.steps, int(args.long_run_seconds / max(elapsed / args.steps, 1e-6)) + 1)
+        # sized from the step's algorithmic work at the fp32 matrix peak (a lower bound of its time): >= long_run_seconds
+        dims_ = [args.in_feats] + [args.hidden] * (args.layers - 1) + [9]
+        flops_node_ = sum(2.0 * 2 * dims_[l] * dims_[l + 1] * (3 if l > 0 else 2) for l in range(args.layers))
+        t_floor = float(np.mean(sizes)) * args.pages * flops_node_ / (MFMA_F32_PEAK_TF * 1e12)
+        n_long = max(args.steps, int(args.long_run_seconds / max(t_floor, 1e-6)) + 1)
         long_ep, ep = epoch_steps(sizes, args.pages, seed, ep, n_long)
         long_cnt = global_counts(long_ep)
         barrier()
@@ -559,6 +576,19 @@ def main():
             el_long, nodes_long = float(mx[0]), float(st[1])
         long_run = {"steps": n_long, "seconds": el_long, "ms_per_step": el_long / n_long * 1e3,
                     "value": nodes_long / el_long, "unit": "nodes/s"}
+
+    run(warm, warm_cnt)
+    barrier()
+    t0 = time.perf_counter()
+    nodes_local, out3 = run(timed, timed_cnt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    final_loss = float(out3[0])
+    if step_events is not None:
+        evs = step_events[-(args.steps + 1):]
+        print("per-step us / nodes:", " ".join(f"{evs[i][0].elapsed_time(evs[i + 1][0]) * 1e3:.0f}/{evs[i + 1][1]}"
+                                               for i in range(len(evs) - 1)), file=sys.stderr)
+        step_events = None
 
     # ---- per-kernel HIP-event timing: the SAME loop with event pairs around the tagged launches, right after -------------
     run(prof[:1], prof_cnt[:1])                  # untimed: settle
@@ -639,14 +669,13 @@ def main():
                               "value": n2 / el2, "unit": "nodes/s", "ms_per_step": el2 / args.steps * 1e3}
             trainer.release()
             del fixed, replays
-        if world == 1 and not args.no_gather_probe:
-            line["gather"] = gather_probe(args, gte, S, dev)
+        line.update(pre)
+        line["order"] = ("gather / val_graph probes, long_run (>= 1 s of the same loop), THEN W warm-up + K timed steps = value, "
+                         "then kernel timers, replay, secondary, cfg3, cpu_baseline")
         if pages13 is not None:
             line["secondary"] = secondary_probe(args, gte, S, dev, pages13)
         if extras and not args.no_cfg3:
             line["cfg3"] = cfg3_probe(args, gte, dev)
-        if val_pages is not None:
-            line["val_graph"] = val_graph_probe(args, gte, S, model, dev, val_pages)
         if world == 1 and not args.no_cpu_baseline:
             ids = timed[0][0]
             cb = cpu_baseline(args, S.concat_pages([pages[int(i)] for i in ids]), state0)

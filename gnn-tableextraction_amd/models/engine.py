@@ -243,6 +243,15 @@ class FusedGcnSageStep(TrainStep):
                 "ce_part": full["ce_part"],
                 "ws_dw": full["ws_dw"]}
 
+    def reserve(self, n_nodes: int, f0: int) -> None:
+        """Size the shared per-batch buffers for batches of up to ``n_nodes`` nodes now (the train loop knows the largest batch
+        its page table can produce): no reallocation -- a device synchronisation plus ~12 KB per node of new buffers -- later,
+        in the middle of an epoch."""
+        full = self._bufs.get(f0)
+        if n_nodes > 0 and (full is None or full["cap"] < n_nodes):
+            self._bufs[f0] = None                      # drop the old set first: both need not be alive at once
+            self._bufs[f0] = self._alloc(-(-int(n_nodes) // 4096) * 4096, f0)
+
     def _narrow(self, layer, fin: int) -> bool:
         return (not isinstance(layer.lynorm, nn.LayerNorm) and layer.activation is None and layer.linear.bias is not None
                 and bool(self.lib.gte_sage_narrow_supported(fin, layer.out_feats)))

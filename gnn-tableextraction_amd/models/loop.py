@@ -92,7 +92,18 @@ class BatchPipeline:
             self._meta_dev[:total].copy_(self._pinned[:total], non_blocking=True)
             self._meta_ev = torch.cuda.Event()
             self._meta_ev.record(self.side)
-        self._ensure_capacity(cap)
+        # Capacity for ANY batch of this many pages (the nb largest pages of the dataset), not just this epoch's largest: a
+        # later epoch with a bigger batch would otherwise reallocate (synchronise + allocate ~1 ms) in the middle of the loop.
+        nb_max = max(r[0].size for r in rows)
+        if nb_max != getattr(self, "_bound_nb", None):
+            top = lambda a: int(np.sort(a)[-nb_max:].sum())
+            self._bound = [top(self._page_nodes), top(self._page_ent[0]), top(self._page_ent[1])]
+            self._bound_nb = nb_max
+        self._ensure_capacity([max(c, b) for c, b in zip(cap, self._bound)])
+
+    def max_batch_nodes(self) -> int:
+        """Upper bound of the node count of any batch the loaded plan's batch size can produce."""
+        return int(self._bound[0]) if getattr(self, "_bound", None) else 0
 
     def _ensure_capacity(self, cap) -> None:
         have = self._sets[0]["cap"] if self._sets else (0, 0, 0)
@@ -151,6 +162,8 @@ def run_steps(step, pipe: BatchPipeline, page_steps: Sequence[np.ndarray], n_glo
     out3 = None
     if n_steps == 0:
         return out3
+    if hasattr(step, "reserve"):                 # the engine's per-batch buffers: sized once for the largest possible batch
+        step.reserve(pipe.max_batch_nodes(), pipe.res.feat.shape[1])
     pipe.start(0)
     # where the next batch is assembled: an engine with a `before_last_gemm` hook (FusedGcnSageStep) gets it under the last,
     # MFMA-bound GEMM of the current step -- late enough that the batch is still cache-resident when the next step starts
