@@ -1,0 +1,29 @@
+"""pmc_traffic.json (what bench.py reads for roofline.traffic) from the per-kernel PMC tables of profiles/pmc_traffic_summary.py.
+usage: python profiles/make_pmc_traffic.py <step per-kernel json> <full per-kernel json> <out json>"""
+import json, sys
+step, full = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+
+
+def fam(table, pred):
+    n = sum(v["launches"] for k, v in table.items() if pred(k))
+    b = sum(v["bytes_per_launch"] * v["launches"] for k, v in table.items() if pred(k))
+    return (b / n if n else None), n
+
+
+out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (csv output, kernel trace only) over `python3 bench.py "
+                 "--steps 4 --warmup 2 --long-run-seconds 0 ...`; bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of "
+                 "the kernel family (FETCH_SIZE x2: gfx950 counts the 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md HBM "
+                 "section); the counters sit on the L2's memory side, so Infinity-Cache hits are included.  Scripts: profiles/refresh.sh, "
+                 "pmc_traffic_summary.py, make_pmc_traffic.py", "round": 2}
+for tag, pred in (("gemm_nt", lambda k: "gemm_f32_mfma_kernel<true, true" in k), ("gemm_tn", lambda k: "gemm_f32_mfma_kernel<false, false" in k),
+                  ("gemm_nn", lambda k: "gemm_f32_mfma_kernel<true, false" in k), ("batch_assemble", lambda k: "batch_assemble" in k),
+                  ("spmm_csr", lambda k: k.startswith("spmm_csr_kernel"))):
+    b, n = fam(step, pred)
+    out[f"{tag}_bytes_per_launch"], out[f"{tag}_launches_sampled"] = b, n
+b, n = fam(full, lambda k: "spmm_tiled_full_kernel" in k)
+out["gather_cfg4_tiled_bytes_per_launch"], out["gather_cfg4_tiled_launches_sampled"] = b, n
+b, n = fam(full, lambda k: k.startswith("spmm_csr_kernel<F32, 64") or k.startswith("spmm_csr_kernel<F32; 64"))
+out["kernel_names"] = {"gemm_nt": "gemm_f32_mfma_kernel<true, true, ...> (A and B K-contiguous: forward)",
+                       "gemm_tn": "gemm_f32_mfma_kernel<false, false, ...> (dW, split-K)", "gemm_nn": "gemm_f32_mfma_kernel<true, false, ...> (dX)"}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))

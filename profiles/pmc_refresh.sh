@@ -1,0 +1,19 @@
+#!/bin/bash
+# HBM-side traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, kernel trace only) of the train loop's kernels and of the cfg4
+# aggregation: gpurun --timeout 900 -- 'bash profiles/pmc_refresh.sh r02pmc'
+set -u
+TAG=${1:-pmc}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --pmc $C --kernel-trace -d $O/step/pmc_$C -o p --output-format csv -- python3 $R/profiles/pmc_step.py 4 > $O/pmc_step_$C.log 2>&1
+  timeout 200 rocprofv3 --pmc $C --kernel-trace -d $O/full/pmc_$C -o p --output-format csv -- python3 $R/profiles/pmc_probe.py spmm 4 > $O/pmc_$C.log 2>&1
+done
+cd $R
+python3 profiles/pmc_traffic_summary.py $O/full $O/pmc_per_kernel.json > $O/pmc_per_kernel.txt
+python3 profiles/pmc_traffic_summary.py $O/step $O/pmc_per_kernel_step.json > $O/pmc_per_kernel_step.txt
+python3 profiles/make_pmc_traffic.py $O/pmc_per_kernel_step.json $O/pmc_per_kernel.json $O/pmc_traffic.json > /dev/null
+rm -rf $O/full $O/step
+cat $O/pmc_per_kernel_step.txt | head -20; cat $O/pmc_per_kernel.txt | head -5
