@@ -10,8 +10,8 @@ def fam(table, pred):
     return (b / n if n else None), n
 
 
-out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (csv output, kernel trace only) over `python3 bench.py "
-                 "--steps 4 --warmup 2 --long-run-seconds 0 ...`; bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of "
+out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (csv output, kernel trace only) over profiles/pmc_step.py (four steps of the train loop) and "
+                 "profiles/pmc_probe.py spmm (cfg4); bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of "
                  "the kernel family (FETCH_SIZE x2: gfx950 counts the 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md HBM "
                  "section); the counters sit on the L2's memory side, so Infinity-Cache hits are included.  Scripts: profiles/refresh.sh, "
                  "pmc_traffic_summary.py, make_pmc_traffic.py", "round": 2}
