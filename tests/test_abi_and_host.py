@@ -189,3 +189,38 @@ def test_parameter_init_reproduces_the_reference_rng_stream(name, seed):
     assert sorted(sd.keys()) == ref_keys                  # checkpoint-compatible key set
     for k in ref_keys:
         np.testing.assert_array_equal(sd[k].numpy(), z["state0." + k])
+
+
+# ---------------------------------------------------------------- bench.py host logic (no GPU)
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_gpus_flag_must_agree_with_the_launcher(monkeypatch):
+    import argparse
+    b = _bench()
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit):
+        b.maybe_spawn(argparse.Namespace(gpus=2))            # torchrun started 4 ranks, the flag says 2: loud, not silent
+    b.maybe_spawn(argparse.Namespace(gpus=4))                # agreeing: returns, the rank continues
+    monkeypatch.delenv("WORLD_SIZE")
+    b.maybe_spawn(argparse.Namespace(gpus=1))                # one GPU: nothing to start
+    monkeypatch.setattr(b.torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit):
+        b.maybe_spawn(argparse.Namespace(gpus=8))            # more ranks than GPUs on this node
+
+
+def test_bench_epoch_steps_follow_the_train_loop_plan():
+    b = _bench()
+    from gnn_tableextraction_amd import distributed as D
+    sizes = list(np.random.default_rng(0).integers(20, 2000, 530))
+    epochs, nxt = b.epoch_steps(sizes, 100, 42, 3, 12)       # 5 steps per epoch (tail of 30 pages dropped), 12 steps wanted
+    assert [len(e) for e in epochs] == [5, 5, 2] and nxt == 6
+    want = [r[0] for r in D.plan_epoch(sizes, 100, 1, seed=42, epoch=3)]
+    assert all((a == w).all() for a, w in zip(epochs[0], want))
+    flat = [i for e in epochs[:1] for ids in e for i in ids.tolist()]
+    assert len(set(flat)) == len(flat) == 500                # an epoch never revisits a page
