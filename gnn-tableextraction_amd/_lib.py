@@ -59,6 +59,8 @@ SIGNATURES = {
                                            c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "gte_gemm_tail_workspace_bytes": (c_int64, []),
     "gte_gemm_set_tail_workspace": (c_int, [c_void_p, c_int64]),
+    "gte_gemm_set_mode": (c_int, [c_int]),
+    "gte_gemm_get_mode": (c_int, []),
     "gte_fold_defer_begin": (c_int, [c_void_p]),
     "gte_fold_defer_flush": (c_int, []),
     "gte_sage_transform_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,

@@ -24,6 +24,8 @@
 #include "gte_common.h"
 
 #include <stdlib.h>
+#include <string.h>
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -453,6 +455,8 @@ gemm_f32_mfma_kernel(const GemmParams p) {
     }
 }
 
+#include "gemm_split.h"
+
 // Finishes the tail tiles of a split launch: C tile = bias + sum over the pieces (piece order: deterministic), with the
 // same bias / accumulate / relu rules as the GEMM epilogue.  grid = (tail tiles, BM * BN / 1024), 4 elements per thread.
 template <int BM, int BN>
@@ -638,6 +642,19 @@ bool needs_small_path(bool ak, bool bkc, const GemmParams& p) {
     return a_run < 4 || b_run < 4;
 }
 
+// GEMM arithmetic mode (gte_gemm_set_mode): process-wide -- autograd runs the backward GEMMs on another host thread.
+// -1 = not yet read from the environment (GTE_GEMM_MODE=split | bf16x3 selects the split mode, anything else fp32).
+std::atomic<int> g_gemm_mode{-1};
+int gemm_mode() {
+    int m = g_gemm_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("GTE_GEMM_MODE");
+        m = (e && (!strcmp(e, "split") || !strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? GTE_GEMM_SPLIT_BF16 : GTE_GEMM_F32;
+        g_gemm_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
 struct Plan { int bm, bn, tiles, splits, tiles_per_split, splits_bound; };
 
 Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
@@ -733,6 +750,21 @@ void launch_tile(GemmParams p, dim3 grid, hipStream_t s) {
     }
     const int tiles = (int)grid.x;
     const bool tail = plan_tail<BM, BN>(p, tiles, grid);
+    if constexpr (BN == 128 && (BM == 128 || BM == 64) && WM == 2 && WN == 2) {
+        if (gemm_mode() == GTE_GEMM_SPLIT_BF16) {
+            constexpr int shm_s = gemm_split_lds_bytes<AK, BKC, BM, BN>();
+            static bool configured_s = false;
+            if (!configured_s) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BKC, BM, BN>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, shm_s);
+                configured_s = true;
+            }
+            hipLaunchKernelGGL((gemm_split_kernel<AK, BKC, BM, BN>), grid, dim3(256), shm_s, s, p);
+            if (tail)
+                hipLaunchKernelGGL((gemm_tail_fixup_kernel<BM, BN>), dim3((unsigned)(tiles - p.sk_full), BM * BN / 1024), dim3(256), 0, s, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, BM, BN, WM, WN>), grid, dim3(256), shm, s, p);
     if (tail)
         hipLaunchKernelGGL((gemm_tail_fixup_kernel<BM, BN>), dim3((unsigned)(tiles - p.sk_full), BM * BN / 1024), dim3(256), 0, s, p);
@@ -1384,6 +1416,14 @@ void launch_ln_fwd(const float* z, int64_t ldz, const float* gamma, const float*
 }  // namespace
 
 // ------------------------------------------ C ABI -------------------------------------------------
+extern "C" int gte_gemm_set_mode(int mode) {
+    if (mode != GTE_GEMM_F32 && mode != GTE_GEMM_SPLIT_BF16) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_set_mode: unknown mode %d", mode);
+    g_gemm_mode.store(mode, std::memory_order_relaxed);
+    return GTE_OK;
+}
+
+extern "C" int gte_gemm_get_mode(void) { return gemm_mode(); }
+
 extern "C" int64_t gte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t mfma = gemm_workspace(M, N, K, 0);
     const int64_t skinny = (M > 0 && M <= SK_MAX) ? gte::round_up(gte::ceil_div(K > 0 ? K : 1, SK_ROWS) * M * N * 4, 256) : 0;

@@ -516,3 +516,21 @@ class _WeightedCE(torch.autograd.Function):
 def cross_entropy(logits, labels, class_weight=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(loss, out3) -- ``nn.CrossEntropyLoss(weight)(logits, labels.long())`` (model_train.py:171,327)."""
     return _WeightedCE.apply(logits, labels, class_weight)
+
+
+GEMM_F32, GEMM_SPLIT_BF16 = 0, 1
+
+
+def set_gemm_mode(mode) -> int:
+    """Arithmetic of the fp32 transform GEMMs, process-wide (gte_gemm_set_mode): ``"f32"`` (v_mfma_f32_32x32x2_f32, the
+    default) or ``"split_bf16"`` (three exact bf16 pieces per operand, six bf16 MFMA products, fp32 accumulation: fp32 in and
+    out at fp32 accuracy, csrc/gemm_split.h).  Returns the previous mode."""
+    lib = _lib.load()
+    code = {"f32": GEMM_F32, "split_bf16": GEMM_SPLIT_BF16, "split": GEMM_SPLIT_BF16}.get(mode, mode)
+    prev = lib.gte_gemm_get_mode()
+    check(lib.gte_gemm_set_mode(int(code)), "gte_gemm_set_mode")
+    return prev
+
+
+def get_gemm_mode() -> int:
+    return _lib.load().gte_gemm_get_mode()

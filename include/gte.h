@@ -240,6 +240,20 @@ int gte_spmm_csr_accumulate_ln(const int32_t* indptr, const int32_t* indices, co
 int64_t gte_gemm_tail_workspace_bytes(void);
 int gte_gemm_set_tail_workspace(void* workspace, int64_t workspace_bytes);
 
+/* ---- GEMM arithmetic mode ------------------------------------------------------------------------------------------
+ * How the fp32 transform GEMMs (every entry point of this section and gte_gemm_f32) multiply.  Process-wide.
+ *   GTE_GEMM_F32        (default) v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA chains.
+ *   GTE_GEMM_SPLIT_BF16 every fp32 operand is cut exactly into three bf16 pieces (24 significand bits) in the kernel and the
+ *                       product is six v_mfma_f32_32x32x16_bf16 partial products accumulated in fp32 (csrc/gemm_split.h):
+ *                       fp32 in, fp32 out, error against fp64 not above the fp32 kernel's, 2.67x its matrix-pipe rate.
+ *                       Tiles narrower than 128 columns and the small-shape path stay on the fp32 kernel.  Non-finite
+ *                       operands give NaN where the fp32 kernel returns inf.
+ * The environment variable GTE_GEMM_MODE=split selects the split mode before the first call; gte_gemm_set_mode overrides. */
+#define GTE_GEMM_F32 0
+#define GTE_GEMM_SPLIT_BF16 1
+int gte_gemm_set_mode(int mode);
+int gte_gemm_get_mode(void);
+
 /* ---- deferred folds -------------------------------------------------------------------------------------------
  * Several entry points end with a small "sum the per-block partials" kernel (gte_ln_relu_bwd: column sums;
  * gte_sage_narrow_bwd: dW / dbias; split-K GEMMs behind gte_sage_linear_dw / gte_sage_qform_dw).  gte_gemm_f32 NEVER defers:
