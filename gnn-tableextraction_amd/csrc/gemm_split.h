@@ -29,20 +29,28 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KS = 16;                                     // k per stage (one 32x32x16 MFMA step)
+#ifndef SPLIT_PIN
+#define SPLIT_PIN 1                                        // 0: compiler's own schedule, 2: nothing moves across the barrier
+#endif
+#ifndef SPLIT_NQ1
+#define SPLIT_NQ1 4                                        // products of a stage issued before its barrier (of 6)
+#endif
 
-// two fp32 -> their packed bf16 pieces
-__device__ __forceinline__ void split_pair(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
-    h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
-    f32x2 hf;
-    hf.x = __builtin_bit_cast(float, h << 16);
-    hf.y = __builtin_bit_cast(float, h & 0xffff0000u);
-    const f32x2 r1 = x - hf;
-    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-    f32x2 mf;
-    mf.x = __builtin_bit_cast(float, m << 16);
-    mf.y = __builtin_bit_cast(float, m & 0xffff0000u);
-    const f32x2 r2 = r1 - mf;
-    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+// two fp32 -> their packed bf16 pieces.  The residuals are separate scalar subtractions on purpose: a packed fp32 add
+// (v_pk_add_f32, what a 2-vector subtraction compiles to) issued beside MFMAs costs ~13 cycles more than two plain ones.
+__device__ __forceinline__ float plain_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split_pair(const float x0, const float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{x0, x1}), bf16x2));
+    const float r10 = plain_sub(x0, __builtin_bit_cast(float, h << 16));
+    const float r11 = plain_sub(x1, __builtin_bit_cast(float, h & 0xffff0000u));
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{r10, r11}), bf16x2));
+    const float r20 = plain_sub(r10, __builtin_bit_cast(float, m << 16));
+    const float r21 = plain_sub(r11, __builtin_bit_cast(float, m & 0xffff0000u));
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{r20, r21}), bf16x2));
 }
 
 // One operand of the block tile, ROWS rows x KS.  KC: stored [rows][K] in memory, else [K][rows].
@@ -118,8 +126,8 @@ struct SplitOperand {
             v.w = vc[SET] > 3 ? v.w : 0.f;
         }
         uint2 h, m, l;
-        split_pair(f32x2{v.x, v.y}, h.x, m.x, l.x);
-        split_pair(f32x2{v.z, v.w}, h.y, m.y, l.y);
+        split_pair(v.x, v.y, h.x, m.x, l.x);
+        split_pair(v.z, v.w, h.y, m.y, l.y);
         char* dst = planes + wofs + i * CHUNK_STRIDE;
         *reinterpret_cast<uint2*>(dst) = h;
         *reinterpret_cast<uint2*>(dst + PLANE) = m;
@@ -283,33 +291,45 @@ gemm_split_kernel(const GemmParams p) {
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    using I4 = std::integral_constant<int, 4>;
+    using IQ = std::integral_constant<int, SPLIT_NQ1>;
     using I6 = std::integral_constant<int, 6>;
-    constexpr int NMF1 = 4 * TM * TN, NMF2 = 2 * TM * TN;
-    constexpr int NVALU = NC * 22 + 24;                        // split + tail masks + window arithmetic's vector part
+    constexpr int NMF1 = SPLIT_NQ1 * TM * TN, NMF2 = (6 - SPLIT_NQ1) * TM * TN;
+    constexpr int NVALU = NC * 25 + 16;                        // split (22 / chunk) + tail masks + window arithmetic's vector part
+    constexpr int VSLOTS = NMF1 > 4 ? NMF1 - 4 : NMF1;         // the vector work ends 4 MFMAs before the barrier: the LDS stores land
+    constexpr int NFR = 3 * (TM * (AK ? 1 : 2) + TN * (BKC ? 1 : 2));   // fragment read instructions per stage
+    StageDesc D;                                               // the tile the NEXT stage requests (described one stage ahead)
     // stage: multiply the tile in `cur` (fragments f); the tile in register set R^1 goes to `nxt`; set R takes tile t+2
     auto stage = [&](Frags& f, Frags& fn, char* nxt, auto R) {
         constexpr int rr = decltype(R)::value;
-        const StageDesc d = describe();
-        issue_loads(std::integral_constant<int, rr>{}, d);
+        issue_loads(std::integral_constant<int, rr>{}, D);
         store_stage(std::integral_constant<int, rr ^ 1>{}, nxt);
-        products(f, I0{}, I4{});
+        products(f, I0{}, IQ{});
+        D = describe();
+#if SPLIT_PIN
 #pragma unroll
         for (int i = 0; i < NMF1; ++i) {
             GTE_SGB(SG_MFMA, 1);
-            GTE_SGB(SG_SALU, (48 + NMF1 - 1) / NMF1);
-            GTE_SGB(SG_VALU, (NVALU + NMF1 - 1) / NMF1);
-            GTE_SGB(SG_DS_W, (3 * NC + NMF1 - 1) / NMF1);
-            GTE_SGB(SG_VMEM_R, 1);
+            if (i == 0) GTE_SGB(SG_VMEM_R, NC);
+            if (i < VSLOTS) {
+                GTE_SGB(SG_VALU, (NVALU + VSLOTS - 1) / VSLOTS);
+                GTE_SGB(SG_DS_W, (3 * NC + VSLOTS - 1) / VSLOTS);
+            }
+            GTE_SGB(SG_SALU, (56 + NMF1 - 1) / NMF1);
         }
+#endif
+#if SPLIT_PIN == 2
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         read_frags(fn, nxt);
-        products(f, I4{}, I6{});
+        products(f, IQ{}, I6{});
+#if SPLIT_PIN
 #pragma unroll
         for (int i = 0; i < NMF2; ++i) {
             GTE_SGB(SG_MFMA, 1);
-            GTE_SGB(SG_DS_R, (3 * (TM * (AK ? 1 : 2) + TN * (BKC ? 1 : 2)) + NMF2 - 1) / NMF2);
+            GTE_SGB(SG_DS_R, (NFR + NMF2 - 1) / NMF2);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -322,6 +342,7 @@ gemm_split_kernel(const GemmParams p) {
             const StageDesc d1 = describe();
             issue_loads(I1{}, d1);
             store_stage(I0{}, s0);
+            D = describe();
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         Frags f0, f1;
