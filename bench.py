@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # fp32 matrix peak (dense)
+MFMA_BF16_PEAK_TF = 2500.0   # bf16 matrix peak (dense; the headline figures with 2:1 sparsity are not used)
 
 
 def pmc_traffic():
@@ -71,6 +72,10 @@ def parse():
     ap.add_argument("--no-gather-probe", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the F0=13 (BBOX features only) variant of cfg2")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the GAT bf16 probe (BASELINE configs[2])")
+    ap.add_argument("--gemm-mode", choices=["f32", "split_bf16"], default=None,
+                    help="arithmetic of the transform GEMMs for the headline loop (default: GTE_GEMM_MODE or f32)")
+    ap.add_argument("--no-split-probe", action="store_true",
+                    help="skip the secondary run of the same loop in the split-bf16 GEMM mode")
     ap.add_argument("--gather-nodes", type=int, default=1_000_000)
     ap.add_argument("--val-graph", type=int, default=2000, metavar="PAGES",
                     help="forward-only pass over PAGES pages batched into one graph (cfg2 'val graph'; 0: skip)")
@@ -227,6 +232,50 @@ def timed_loop(trainer, pipe, epochs, loop):
         nodes += sum(pipe.nodes(i) for i in range(len(plan)))
     torch.cuda.synchronize()
     return time.perf_counter() - t0, nodes, out3
+
+
+def gemm_mode_probe(ops, run, epochs, counts, dev):
+    """The SAME train loop in the OTHER arithmetic mode of the transform GEMMs (csrc/gemm_split.h; include/gte.h "GEMM
+    arithmetic mode"), plus both modes' error against fp64 on one forward-shaped product -- measured here, every run."""
+    cur = ops.get_gemm_mode()
+    other = ops.GEMM_F32 if cur == ops.GEMM_SPLIT_BF16 else ops.GEMM_SPLIT_BF16
+    names = {ops.GEMM_F32: "f32 (v_mfma_f32_32x32x2_f32)", ops.GEMM_SPLIT_BF16: "split_bf16 (3 exact bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)"}
+    out = {"headline_mode": names[cur]}
+    # error of X W^T against fp64, in units of 2^-24 sum_k |x_k w_k| (one fp32 rounding of the product's magnitude)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(2048, 831, generator=g) * (1 + torch.arange(831) % 7)
+    w = torch.randn(512, 831, generator=g) * 0.05
+    ref = x.double() @ w.double().t()
+    unit = (x.double().abs() @ w.double().abs().t()) * 2.0 ** -24
+    xd, wd = x.to(dev), w.to(dev)
+    err = {}
+    for m in (ops.GEMM_F32, ops.GEMM_SPLIT_BF16):
+        ops.set_gemm_mode(m)
+        e = ((ops.gemm(xd, wd, trans_b=True).double().cpu() - ref).abs() / unit)
+        err["f32" if m == ops.GEMM_F32 else "split_bf16"] = {"max": float(e.max()), "rms": float(e.pow(2).mean().sqrt())}
+    out["error_vs_fp64"] = {"unit": "2^-24 * sum_k |x_k w_k|", "shape": "2048 x 831 @ 831 x 512", **err}
+    ops.set_gemm_mode(other)
+    flat = [(plan, cnt) for plan, cnt in zip(epochs, counts)]
+    # warm-up: the first 8 steps; timed: the rest
+    warm_e, warm_c, timed_e, timed_c, left = [], [], [], [], 8
+    for plan, cnt in flat:
+        k = min(left, len(plan))
+        if k:
+            warm_e.append(plan[:k]); warm_c.append(cnt[:k])
+        if len(plan) > k:
+            timed_e.append(plan[k:]); timed_c.append(cnt[k:])
+        left -= k
+    run(warm_e, warm_c)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nodes, out3 = run(timed_e, timed_c)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    steps = sum(len(p) for p in timed_e)
+    out["other_mode"] = {"mode": names[other], "value": nodes / el, "unit": "nodes/s", "steps": steps,
+                         "ms_per_step": el / steps * 1e3, "final_loss": float(out3[0])}
+    ops.set_gemm_mode(cur)
+    return out
 
 
 def secondary_probe(args, gte, S, dev, pages13):
@@ -489,6 +538,9 @@ def main():
     from gnn_tableextraction_amd.models import loop
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
 
+    if args.gemm_mode is not None:
+        ops.set_gemm_mode(args.gemm_mode)
+    split_mode = ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16
     resident = G.ResidentPages(to_page_graphs(gte, pages), dev)        # this rank's pages, resident in HBM
     pipe = loop.BatchPipeline(resident)
     sizes = resident.page_sizes()
@@ -502,6 +554,7 @@ def main():
     warm, ep = epoch_steps(sizes, args.pages, seed, 0, args.warmup)
     timed, ep = epoch_steps(sizes, args.pages, seed, ep, args.steps)
     prof, ep = epoch_steps(sizes, args.pages, seed, ep, 8)
+    alt, ep = epoch_steps(sizes, args.pages, seed, ep, 8 + 200)       # the other GEMM mode: 8 warm-up + 200 timed steps
     n_long = 0
 
     def node_counts(epochs):
@@ -609,8 +662,13 @@ def main():
     if rank == 0:
         n_launch, ms, flops = kt.get("gemm_nt", (0, 0.0, 0.0))
         tf = (flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel<NT> (layer transforms, forward)",
-                    "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+        # split mode: fp32-equivalent flops (2 M N K) against the bf16 matrix peak / 6 (six bf16 MFMA products per fp32 product)
+        gemm_peak = MFMA_BF16_PEAK_TF / 6.0 if split_mode else MFMA_F32_PEAK_TF
+        roofline = {"bound": "mfma",
+                    "kernel": ("gemm_split_kernel<NT> (layer transforms, forward; fp32 operands as 3 exact bf16 pieces, 6 bf16 "
+                               "MFMA products, fp32 accumulate; peak = bf16 dense / 6)") if split_mode
+                              else "gemm_f32_mfma_kernel<NT> (layer transforms, forward)",
+                    "achieved": tf, "peak": gemm_peak, "unit": "TFLOP/s", "frac": tf / gemm_peak,
                     "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
                     "algorithmic_flops_per_launch": flops / max(n_launch, 1),
                     "traffic": pmc_traffic()[0].get("gemm_nt_bytes_per_launch") if args.in_feats == 831 else None,
@@ -625,7 +683,9 @@ def main():
             "metric": "nodes/sec (fwd+bwd node classification) on PubLayNet page graphs",
             "value": nodes_total / elapsed, "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (GEMM operands split exactly into 3 bf16 pieces, fp32 accumulate)" if split_mode else "f32",
+            "data": "synthetic",
             "config": {"workload": f"cfg2: {args.pages} synthetic PubLayNet-style page graphs per GPU per step "
                                    f"(~{mean_nodes} nodes, k-NN k=5 bidirected), GcnSAGE "
                                    f"{args.layers} layers F0={args.in_feats} hidden={args.hidden} classes=9, "
@@ -646,7 +706,7 @@ def main():
         bytes_node = sum(4.0 * (2 * dims[l] + dims[l + 1]) + 8 * deg + 4 +                       # forward
                          4.0 * (dims[l + 1] + 2 * dims[l] + (dims[l] if l > 0 else 0)) + 8 * deg + 4  # backward
                          for l in range(args.layers))
-        mfma_bound = MFMA_F32_PEAK_TF * 1e12 / flops_node * world
+        mfma_bound = gemm_peak * 1e12 / flops_node * world
         hbm_bound = HBM_PEAK_GBS * 1e9 / bytes_node * world
         line["step_roofline"] = {"flops_per_node": flops_node, "bytes_per_node": bytes_node, "mean_in_degree": deg,
                                  "mfma_bound_nodes_per_s": mfma_bound, "hbm_bound_nodes_per_s": hbm_bound,
@@ -669,9 +729,11 @@ def main():
                               "value": n2 / el2, "unit": "nodes/s", "ms_per_step": el2 / args.steps * 1e3}
             trainer.release()
             del fixed, replays
+        if extras and not args.no_split_probe:
+            line["gemm_modes"] = gemm_mode_probe(ops, run, alt, global_counts(alt), dev)
         line.update(pre)
         line["order"] = ("gather / val_graph probes, long_run (>= 1 s of the same loop), THEN W warm-up + K timed steps = value, "
-                         "then kernel timers, replay, secondary, cfg3, cpu_baseline")
+                         "then kernel timers, replay, the other GEMM mode, secondary, cfg3, cpu_baseline")
         if pages13 is not None:
             line["secondary"] = secondary_probe(args, gte, S, dev, pages13)
         if extras and not args.no_cfg3:
