@@ -687,10 +687,16 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
         const int64_t ncol = Nseg > 0 ? 2 * gte::ceil_div(Nseg, 128) : gte::ceil_div(N, 128);
         const int64_t t128 = gte::ceil_div(M, 128) * ncol, t64 = gte::ceil_div(M, 64) * ncol;
         pl.bn = 128;
-        pl.bm = (t128 >= cus && cost(t64, 2.67, 0.0335) < cost(t128, 8.07, 0.0594)) ? 64 : 128;
+        // split mode (gemm_split.h): 128x128: 6.9 + 0.0464 K, 64x128: 3.86 + 0.0282 K (profiles/debug/gemm_split_tiles.py)
+        const bool split = gemm_mode() == GTE_GEMM_SPLIT_BF16;
+        const double c64 = split ? cost(t64, 3.86, 0.0282) : cost(t64, 2.67, 0.0335);
+        const double c128 = split ? cost(t128, 6.9, 0.0464) : cost(t128, 8.07, 0.0594);
+        pl.bm = (t128 >= cus && c64 < c128) ? 64 : 128;
         // split-K with very few output tiles (dW of a 256 x 256 layer: 4 tiles over 24 k nodes): smaller tiles ->
         // half the K splits -> half the slab bytes (measured 58 -> 44 us; at 14 tiles, 256 x 831, it loses: 147 -> 161)
         if (t128 <= 8 && M >= 64) pl.bm = 64;
+        static const int force_bm = getenv("GTE_GEMM_BM") ? atoi(getenv("GTE_GEMM_BM")) : 0;   // measurement only
+        if (force_bm == 64 || force_bm == 128) pl.bm = force_bm;
     }
     pl.tiles = (int)(gte::ceil_div(M, pl.bm) * (Nseg > 0 ? 2 * gte::ceil_div(Nseg, pl.bn) : gte::ceil_div(N, pl.bn)));
     const int ktiles = (int)(gte::ceil_div(K1, BK) + gte::ceil_div(K2, BK));
