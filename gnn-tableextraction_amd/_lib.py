@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GTE_LIB_PATH: profiling builds of the same ABI (e.g. ablation variants); default = the in-tree library
@@ -63,6 +63,7 @@ SIGNATURES = {
     "gte_gemm_get_mode": (c_int, []),
     "gte_fold_defer_begin": (c_int, [c_void_p]),
     "gte_fold_defer_flush": (c_int, []),
+    "gte_fold_defer_flush_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "gte_sage_transform_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                        c_int64, c_void_p]),
     "gte_sage_qform_dw_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),

@@ -46,6 +46,41 @@ inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
 }  // namespace gte
 
+// ---- Adam on the device-resident optimiser state (shared by adam_dev_kernel and the fold kernel's optimiser tail) ----
+// state = {lr, b1, b2, eps, wd, grad_scale, bc1, sqrt(bc2)}; torch.optim.Adam's update with L2 weight decay.
+namespace gte {
+struct AdamCoef { float lr, b1, b2, eps, wd, grad_scale, bc1, bc2_sqrt; };
+__device__ __forceinline__ AdamCoef adam_coef(const float* __restrict__ state) {
+    return AdamCoef{state[0], state[1], state[2], state[3], state[4], state[5], state[6], state[7]};
+}
+__device__ __forceinline__ void adam_update(const AdamCoef& c, float& pi, float gi_raw, float& mi_io, float& vi_io) {
+    const float gi = fmaf(c.wd, pi, c.grad_scale * gi_raw);
+    const float mi = fmaf(c.b1, mi_io, (1.f - c.b1) * gi);
+    const float vi = fmaf(c.b2, vi_io, (1.f - c.b2) * gi * gi);
+    mi_io = mi;
+    vi_io = vi;
+    const float denom = sqrtf(vi) / c.bc2_sqrt + c.eps;
+    pi = pi - (c.lr / c.bc1) * (mi / denom);
+}
+// End of a launch that applied one optimiser step: the LAST workgroup to finish advances the step count and the bias
+// corrections for the next step (every workgroup has read `state` before it takes its ticket).  bc in double.
+__device__ __forceinline__ void adam_advance(float* __restrict__ state, long long* __restrict__ step_counter,
+                                             unsigned* __restrict__ ticket) {
+    __syncthreads();                                         // the whole block is done with `state`
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(ticket, 1u);
+        if (t == gridDim.x - 1) {
+            *ticket = 0;
+            const long long done = *step_counter + 1;
+            *step_counter = done;
+            const double tn = (double)(done + 1);
+            state[6] = (float)(1.0 - pow((double)state[1], tn));
+            state[7] = (float)sqrt(1.0 - pow((double)state[2], tn));
+        }
+    }
+}
+}  // namespace gte
+
 // XCD-aware block remap (device).  Workgroups are dealt round-robin over the 8 XCDs, so
 // blocks b and b+8 share an L2.  Give each XCD a contiguous range of logical blocks so that
 // neighbouring rows/tiles (which share gathered source rows / operand panels) hit one L2.

@@ -3,6 +3,10 @@
 
 #include <string.h>
 
+#include <algorithm>
+#include <utility>
+#include <vector>
+
 namespace gte {
 
 char* error_buffer() {
@@ -47,9 +51,17 @@ struct FoldDesc {
     const float* src; long long stride; float* dst; long long ld;
     int count, rows, rowlen, first_block, slices, vec;
 };
-struct FoldBatch { FoldDesc d[kMaxFolds]; int n; };
+// Optional optimiser tail of the batch (gte_fold_defer_flush_adam): when `param` is set every folded element is a gradient
+// element of the flat buffer starting at `grad`, and the thread that writes it applies the Adam update of that element.
+struct FoldAdam { float* param; float* grad; float* exp_avg; float* exp_avg_sq; float* state; long long* step; unsigned* ticket; };
+struct FoldBatch { FoldDesc d[kMaxFolds]; int n; FoldAdam adam; };
 
-struct FoldQueue { FoldBatch batch; bool open = false; hipStream_t stream = nullptr; int blocks = 0; };
+struct FoldQueue {
+    FoldBatch batch; bool open = false; hipStream_t stream = nullptr; int blocks = 0;
+    bool spilled = false;                 // a full batch was flushed early: the queued folds no longer cover the whole deferral
+    // coverage cache of gte_fold_defer_flush_adam: the descriptor signature it was computed for and its verdict
+    unsigned long long cover_key = 0; bool cover_ok = false;
+};
 static FoldQueue& fold_queue() {
     static thread_local FoldQueue q;
     return q;
@@ -68,6 +80,16 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
 #pragma unroll 1
     for (int i = 1; i < fb.n; ++i) if ((int)blockIdx.x >= fb.d[i].first_block) di = i;
     const gte::FoldDesc d = fb.d[di];
+    const gte::FoldAdam ad = fb.adam;
+    gte::AdamCoef co;
+    if (ad.param) co = gte::adam_coef(ad.state);
+    auto put = [&](float* dst, float v) {
+        *dst = v;
+        if (ad.param) {
+            const long long i = dst - ad.grad;
+            gte::adam_update(co, ad.param[i], v, ad.exp_avg[i], ad.exp_avg_sq[i]);
+        }
+    };
     const int epb = 256 / d.slices;
     const int el = threadIdx.x % epb, sl = threadIdx.x / epb;
     const long long total = (long long)d.rows * d.rowlen;
@@ -101,9 +123,10 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const long long ee = e + j, r = ee / d.rowlen;
-                d.dst[r * d.ld + (ee - r * d.rowlen)] = vv[j];
+                put(&d.dst[r * d.ld + (ee - r * d.rowlen)], vv[j]);
             }
         }
+        if (ad.param) gte::adam_advance(ad.state, ad.step, ad.ticket);
         return;
     }
     const long long e = (long long)((int)blockIdx.x - d.first_block) * epb + el;
@@ -124,14 +147,16 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
         float v = 0.f;
         for (int t = 0; t < d.slices; ++t) v += part[t * epb + el];
         const long long r = e / d.rowlen;
-        d.dst[r * d.ld + (e - r * d.rowlen)] = v;
+        put(&d.dst[r * d.ld + (e - r * d.rowlen)], v);
     }
+    if (ad.param) gte::adam_advance(ad.state, ad.step, ad.ticket);
 }
 
 namespace gte {
 
-static int flush_folds(FoldQueue& q) {
+static int flush_folds(FoldQueue& q, const FoldAdam* adam = nullptr) {
     if (q.batch.n == 0) return GTE_OK;
+    q.batch.adam = adam ? *adam : FoldAdam{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(gte_fold_batch_kernel, dim3((unsigned)q.blocks), dim3(256), 0, q.stream, q.batch);
     q.batch.n = 0;
     q.blocks = 0;
@@ -142,7 +167,7 @@ bool defer_fold(const float* src, int64_t stride, int count, int rows, int rowle
     FoldQueue& q = fold_queue();
     if (!q.open) return false;
     if (!dst || rows <= 0 || rowlen <= 0) return true;
-    if (q.batch.n == kMaxFolds) (void)flush_folds(q);
+    if (q.batch.n == kMaxFolds) { (void)flush_folds(q); q.spilled = true; }
     FoldDesc& d = q.batch.d[q.batch.n++];
     d.src = src; d.stride = stride; d.dst = dst; d.ld = ld;
     d.count = count; d.rows = rows; d.rowlen = rowlen; d.first_block = q.blocks;
@@ -189,7 +214,65 @@ extern "C" int gte_fold_defer_flush(void) {
     gte::FoldQueue& q = gte::fold_queue();
     if (!q.open) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush: no deferral is open on this thread");
     q.open = false;
+    q.spilled = false;
     return gte::flush_folds(q);
+}
+
+namespace gte {
+// Do the queued folds write every element of [grad, grad + n) exactly once?  Rows of a fold are intervals
+// [off + r ld, off + r ld + rowlen); sorted and walked once.  The answer is cached on a signature of the descriptors (the
+// same step queues the same folds), so the steady state costs one pass over <= 24 descriptors.
+static bool folds_cover(FoldQueue& q, const float* grad, int64_t n) {
+    unsigned long long key = 1469598103934665603ull;
+    auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
+    mix((unsigned long long)(uintptr_t)grad); mix((unsigned long long)n); mix((unsigned long long)q.batch.n);
+    for (int i = 0; i < q.batch.n; ++i) {
+        const FoldDesc& d = q.batch.d[i];
+        mix((unsigned long long)(uintptr_t)d.dst); mix((unsigned long long)d.ld);
+        mix(((unsigned long long)d.rows << 32) | (unsigned)d.rowlen);
+    }
+    if (key == q.cover_key) return q.cover_ok;
+    std::vector<std::pair<int64_t, int64_t>> iv;
+    bool ok = true;
+    for (int i = 0; i < q.batch.n && ok; ++i) {
+        const FoldDesc& d = q.batch.d[i];
+        const int64_t off = d.dst - grad;
+        if (d.dst < grad || off + (int64_t)(d.rows - 1) * d.ld + d.rowlen > n) { ok = false; break; }
+        if (d.ld == d.rowlen) iv.emplace_back(off, off + (int64_t)d.rows * d.rowlen);
+        else for (int r = 0; r < d.rows; ++r) iv.emplace_back(off + (int64_t)r * d.ld, off + (int64_t)r * d.ld + d.rowlen);
+    }
+    if (ok) {
+        std::sort(iv.begin(), iv.end());
+        int64_t at = 0;
+        for (const auto& v : iv) {
+            if (v.first != at) { ok = false; break; }      // a gap (an element no fold writes) or an overlap
+            at = v.second;
+        }
+        ok = ok && at == n;
+    }
+    q.cover_key = key;
+    q.cover_ok = ok;
+    return ok;
+}
+}  // namespace gte
+
+extern "C" int gte_fold_defer_flush_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                         int64_t* step_counter, unsigned* ticket, int* fused) {
+    gte::FoldQueue& q = gte::fold_queue();
+    if (fused) *fused = 0;
+    if (!q.open) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam: no deferral is open on this thread");
+    q.open = false;
+    const bool spilled = q.spilled;
+    q.spilled = false;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state || !step_counter || !ticket || !fused || n <= 0) {
+        (void)gte::flush_folds(q);
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam: null pointer or n <= 0");
+    }
+    if (spilled || q.batch.n == 0 || !gte::folds_cover(q, grad, n)) return gte::flush_folds(q);   // caller runs gte_adam_step_dev
+    const gte::FoldAdam ad = {param, grad, exp_avg, exp_avg_sq, state, reinterpret_cast<long long*>(step_counter), ticket};
+    const int rc = gte::flush_folds(q, &ad);
+    if (rc == GTE_OK) *fused = 1;
+    return rc;
 }
 
 extern "C" int gte_version(void) { return GTE_VERSION; }

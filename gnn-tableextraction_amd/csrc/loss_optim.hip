@@ -130,18 +130,9 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
 __global__ void __launch_bounds__(1024)
 adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                 int64_t n, float* __restrict__ state, int64_t* __restrict__ step_counter, unsigned* __restrict__ ticket) {
-    const float lr = state[0], b1 = state[1], b2 = state[2], eps = state[3], wd = state[4], grad_scale = state[5];
-    const float bc1 = state[6], bc2_sqrt = state[7];
+    const gte::AdamCoef co = gte::adam_coef(state);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    auto update = [&](float& pi, float gi_raw, float& mi_io, float& vi_io) {
-        const float gi = fmaf(wd, pi, grad_scale * gi_raw);
-        const float mi = fmaf(b1, mi_io, (1.f - b1) * gi);
-        const float vi = fmaf(b2, vi_io, (1.f - b2) * gi * gi);
-        mi_io = mi;
-        vi_io = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi = pi - (lr / bc1) * (mi / denom);
-    };
+    auto update = [&](float& pi, float gi_raw, float& mi_io, float& vi_io) { gte::adam_update(co, pi, gi_raw, mi_io, vi_io); };
     // 16-byte accesses over the aligned body (the flat buffers come from one allocation each: 16-byte aligned bases),
     // scalar tail; the same per-element arithmetic as adam_kernel
     const int64_t n4 = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
@@ -161,18 +152,7 @@ adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __res
         update(pi, g[i], mi, vi);
         m[i] = mi; v[i] = vi; p[i] = pi;
     }
-    __syncthreads();                                         // the whole block is done with `state`
-    if (threadIdx.x == 0) {
-        const unsigned t = atomicAdd(ticket, 1u);
-        if (t == gridDim.x - 1) {
-            *ticket = 0;
-            const int64_t done = *step_counter + 1;
-            *step_counter = done;
-            const double tn = (double)(done + 1);
-            state[6] = (float)(1.0 - pow((double)b1, tn));
-            state[7] = (float)sqrt(1.0 - pow((double)b2, tn));
-        }
-    }
+    gte::adam_advance(state, reinterpret_cast<long long*>(step_counter), ticket);
 }
 
 }  // namespace

@@ -13,6 +13,7 @@ over ONE flat fp32 parameter buffer and ONE flat gradient buffer:
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import Optional
 
@@ -158,6 +159,10 @@ class FusedGcnSageStep(TrainStep):
         # the reference's aggregate-then-transform order everywhere (same math, different summation order)
         self.transform_first = os.environ.get("GTE_TRANSFORM_FIRST", "1") == "1"
         self.tail_split = os.environ.get("GTE_TAIL_SPLIT", "1") == "1"
+        # single-GPU steps: the Adam update runs inside the gradient-fold launch (gte_fold_defer_flush_adam)
+        self.fuse_adam = os.environ.get("GTE_FUSE_ADAM", "1") == "1"
+        self._fuse_adam_req, self._adam_fused = False, False
+        self.adam_fused_steps = 0                     # steps whose optimiser update ran inside the fold launch
         self.fused_head = os.environ.get("GTE_FUSED_HEAD", "1") == "1"
         # gte_sage_narrow_bwd_ln (LayerNorm backward of the layer below inside the output layer's backward kernel) saves
         # 50 MB of traffic but serialises more work in one wave per SIMD: 41.6 us fused vs 22.4 + 16.6 us separate at
@@ -339,7 +344,16 @@ class FusedGcnSageStep(TrainStep):
             finally:
                 if side_used:
                     torch.cuda.current_stream().wait_stream(self._side)  # join: the folds / Adam / all-reduce need every dW
-                check(lib.gte_fold_defer_flush(), "gte_fold_defer_flush")
+                if self._fuse_adam_req and lo == 0:
+                    # the folds produce every gradient element: the optimiser step rides in the same launch (falls back to a
+                    # plain flush, fused = 0, when some gradient was written directly)
+                    fused = ctypes.c_int(0)
+                    check(lib.gte_fold_defer_flush_adam(P(self.flat_param), P(self.flat_grad), P(self.exp_avg), P(self.exp_avg_sq),
+                                                        self.flat_param.numel(), P(self._hyper), P(self._step_dev),
+                                                        P(self._ticket), ctypes.byref(fused)), "gte_fold_defer_flush_adam")
+                    self._adam_fused = bool(fused.value)
+                else:
+                    check(lib.gte_fold_defer_flush(), "gte_fold_defer_flush")
             return b["out3"]
         finally:
             lib.gte_gemm_set_tail_workspace(None, 0)
@@ -553,13 +567,39 @@ class FusedGcnSageStep(TrainStep):
             pending.append(self._all_reduce_async(self.flat_grad[:self._n0]))
             for w in pending:
                 w.wait()
-        else:
+        elif self.distributed:
             out3 = self.forward_backward(g, labels, scale)
-            if self.distributed:
-                import torch.distributed as dist
-                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            # one GPU: nothing sits between the gradient folds and Adam, so the optimiser state is brought up to date FIRST
+            # and the step is applied by the fold launch itself (gte_fold_defer_flush_adam)
+            self.t += 1
+            try:
+                self._sync_adam_state()
+                out3 = self._forward_backward_adam(g, labels, scale)
+            except BaseException:
+                self.t -= 1
+                raise
+            return out3
         self.t += 1
         self._optimizer_step()
+        return out3
+
+    def _forward_backward_adam(self, g, labels, scale):
+        """forward + backward + optimiser step with self.t already advanced and the device state synced: Adam inside the fold
+        launch when the folds cover the whole gradient, its own launch otherwise."""
+        self._fuse_adam_req, self._adam_fused = self.fuse_adam, False
+        try:
+            out3 = self.forward_backward(g, labels, scale)
+        finally:
+            self._fuse_adam_req = False
+        if self._adam_fused:
+            self._step_dev_host += 1
+            self._adam_fused = False
+            self.adam_fused_steps += 1
+        else:
+            self._adam_dev_launch()
         return out3
 
     def _all_reduce_async(self, t):
@@ -650,11 +690,16 @@ class FusedGcnSageStep(TrainStep):
         graph = torch.cuda.CUDAGraph()
         graph_b = torch.cuda.CUDAGraph() if split else None
         with torch.cuda.graph(graph):
-            out3 = self.forward_backward(g, labels, scale, upto_layer=1 if split else 0)
+            if in_graph_adam and not graph_coll:
+                out3 = self._forward_backward_adam(g, labels, scale)
+            else:
+                out3 = self.forward_backward(g, labels, scale, upto_layer=1 if split else 0)
             if graph_coll:
                 import torch.distributed as dist
                 dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-            if in_graph_adam:
+            if in_graph_adam and not graph_coll:
+                pass                                  # (applied below, fused into the fold launch when possible)
+            elif in_graph_adam:
                 self._adam_dev_launch()               # reads lr / step count from device memory at replay time
         if split:                                     # layer 0's backward: replayed while the upper slice is all-reduced
             with torch.cuda.graph(graph_b, pool=graph.pool()):

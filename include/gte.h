@@ -264,6 +264,13 @@ int gte_gemm_get_mode(void);
  * order: deterministic.  No counterpart in the reference (torch autograd launches one reduction per parameter). */
 int gte_fold_defer_begin(void* stream);
 int gte_fold_defer_flush(void);
+/* Close the deferral and, when the queued folds write every element of the flat gradient [grad, grad + n) exactly once,
+ * run them AND the optimiser step of gte_adam_step_dev (same state / step_counter / ticket contract, same arithmetic) in
+ * ONE launch: the thread that folds a gradient element applies its Adam update.  *fused = 1 then.  Otherwise (a gradient
+ * some producer wrote directly, a deferral that overflowed) the folds run as gte_fold_defer_flush would, *fused = 0, and the
+ * caller launches gte_adam_step_dev itself.  grad still receives the folded gradient either way. */
+int gte_fold_defer_flush_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                              int64_t* step_counter, unsigned* ticket, int* fused);
 
 /* ---- transform-then-aggregate ("q-form") of a GcnSAGELayer --------------------------------------------------
  * replaces (reference src/components/graphs/models.py:53-72, `torch.cat((h, ah * norm), 1)` -> nn.Linear) where the

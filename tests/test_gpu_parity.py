@@ -946,6 +946,44 @@ def test_fused_step_buffers_do_not_grow_with_distinct_batch_sizes():
     assert np.isfinite(float(out3[0]))
 
 
+def test_adam_inside_the_fold_launch_is_bitwise_the_separate_launch():
+    """gte_fold_defer_flush_adam: when the deferred folds produce every gradient element (the cfg2 step: split-K dW, LayerNorm
+    column sums, the narrow layer's dW) the optimiser step rides in the fold launch.  Same parameters, moments and step
+    count, bit for bit, as fold launch + gte_adam_step_dev; a model whose dW GEMM writes its gradient directly (few nodes:
+    no split-K) falls back to the separate launch."""
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    pages = S.make_pages(40, in_feats=200)
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    g = G.PageGraph(src, dst, int(off[-1]), device=DEV)
+    g.ndata["feat"], g.edata["feat"] = dev(feat), dev(w)
+    y = dev(label).float()
+    states = {}
+    for fuse in (True, False):
+        torch.manual_seed(3)
+        model = gte.GcnSAGE(200, 256, 9, 3, torch.nn.functional.relu, 0).to(DEV)
+        eng = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+        eng.fuse_adam = fuse
+        for _ in range(4):
+            eng.step(g, y)
+        torch.cuda.synchronize()
+        assert eng.adam_fused_steps == (4 if fuse else 0)
+        assert int(eng._step_dev.item()) == 4
+        states[fuse] = (eng.flat_param.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), eng.flat_grad.clone(), eng._hyper.clone())
+    for a, b in zip(states[True], states[False]):
+        assert torch.equal(a, b)
+    # a graph too small for split-K: some gradients are written by their GEMM directly -> no fusion, same results as ever
+    small = S.make_pages(1, in_feats=200)
+    src, dst, w, feat, label, off = S.concat_pages(small)
+    gs = G.PageGraph(src, dst, int(off[-1]), device=DEV)
+    gs.ndata["feat"], gs.edata["feat"] = dev(feat), dev(w)
+    torch.manual_seed(3)
+    model = gte.GcnSAGE(200, 256, 9, 3, torch.nn.functional.relu, 0).to(DEV)
+    eng = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+    eng.step(gs, dev(label).float())
+    torch.cuda.synchronize()
+    assert int(eng._step_dev.item()) == 1 and bool(torch.isfinite(eng.flat_param).all())
+
+
 # ---------------------------------------------------------------- the headline model at full width, whole model
 def test_headline_shape_case_matches_reference_golden():
     """GcnSAGE(831, 256, 9, 3) on a 2 000-node graph against the reference's own vectors (trimmed fixture):
