@@ -310,6 +310,102 @@ narrow_fwd_mfma_kernel(const float* __restrict__ h, int64_t ldh, const float* __
     }
 }
 
+// The same forward on v_mfma_f32_16x16x4_f32 with 16-row blocks, one per wave, 8 waves per workgroup (F % 16 == 0): twice
+// the waves of the 32-row version for the same matrix-pipe time per row (32 cycles per 16x16x4 against 64 per 32x32x2), so
+// a SIMD holds two waves and one wave's row loads / y stores run under the other's MFMAs -- the 32-row version is a single
+// serial chain per SIMD (load 32 KB, normalise, 128 MFMAs, store): 22 us at 24.5 k rows against ~10 us of HBM time.
+//   lane = (row i = lane & 15, k-quarter kq = lane >> 4): a[u] = row i, k = 16 u + 4 kq .. + 3 (one 16-byte load);
+//   MFMA t of k-block u multiplies k = 16 u + 4 kq + t: A and B agree on that order.  C/D: col = lane & 15,
+//   row = 4 (lane >> 4) + r.  Two column tiles: W_s rows (image rows 0..15) and W_n rows (16..31).
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+
+template <bool LNF>
+__global__ void __launch_bounds__(512)
+narrow_fwd_mfma16_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ W, int64_t ldw,
+                         const float* __restrict__ bias, float* __restrict__ t_self, int64_t lds_,
+                         float* __restrict__ t_neigh, int64_t ldn, int n, int F, int C, const LnForward lnf) {
+    extern __shared__ __attribute__((aligned(16))) float Wl[];
+    const int FP = F + 4;
+    stage_w_image<32, 16>(Wl, FP, W, ldw, F, C);
+    float* GB = Wl + 32 * FP;
+    if constexpr (LNF) {
+        for (int k = threadIdx.x; k < F; k += blockDim.x) { GB[k] = lnf.gamma[k]; GB[F + k] = lnf.beta[k]; }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
+    const int nblk = (n + 15) / 16, kbs = F / 16;
+    const float* wps = Wl + i * FP + kq * 4;
+    const float* wpn = Wl + (16 + i) * FP + kq * 4;
+    const float bv = (bias && i < C) ? bias[i] : 0.f;
+    const int wpb = blockDim.x >> 6;
+    for (int rb = blockIdx.x * wpb + wave; rb < nblk; rb += gridDim.x * wpb) {
+        const int row = min(rb * 16 + i, n - 1);
+        const float* hp = h + (int64_t)row * ldh + kq * 4;
+        f4n a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = *reinterpret_cast<const f4n*>(hp + min(u, kbs - 1) * 16);
+        if constexpr (LNF) {
+            float sm = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (u < kbs) sm += (a[u].x + a[u].y) + (a[u].z + a[u].w);
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm * (1.0f / (float)F);
+            float q = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (u < kbs) {
+                    const float d0 = a[u].x - mean, d1 = a[u].y - mean, d2 = a[u].z - mean, d3 = a[u].w - mean;
+                    q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
+                }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            const float rstd = rsqrtf(q * (1.0f / (float)F) + lnf.eps);
+            const bool rowok = rb * 16 + i < n;
+            if (rowok && kq == 0 && lnf.stats) { lnf.stats[row] = mean; lnf.stats[n + row] = rstd; }
+            float* yp = lnf.y + (int64_t)row * lnf.ldy + kq * 4;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (u < kbs) {
+                    const f32x4n g = *reinterpret_cast<const f32x4n*>(GB + u * 16 + kq * 4);
+                    const f32x4n b = *reinterpret_cast<const f32x4n*>(GB + F + u * 16 + kq * 4);
+                    f4n o;
+                    o.x = fmaf((a[u].x - mean) * rstd, g.x, b.x); o.y = fmaf((a[u].y - mean) * rstd, g.y, b.y);
+                    o.z = fmaf((a[u].z - mean) * rstd, g.z, b.z); o.w = fmaf((a[u].w - mean) * rstd, g.w, b.w);
+                    if (lnf.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    a[u] = o;
+                    if (rowok) *reinterpret_cast<f4n*>(yp + u * 16) = o;
+                }
+        }
+        f32x4acc as = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (u < kbs) {
+                const f32x4n bs = *reinterpret_cast<const f32x4n*>(wps + u * 16);
+                const f32x4n bn = *reinterpret_cast<const f32x4n*>(wpn + u * 16);
+                as = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, bs.x, as, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, bn.x, an, 0, 0, 0);
+                as = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, bs.y, as, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, bn.y, an, 0, 0, 0);
+                as = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, bs.z, as, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, bn.z, an, 0, 0, 0);
+                as = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, bs.w, as, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, bn.w, an, 0, 0, 0);
+            }
+        }
+        if (i < C) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = rb * 16 + 4 * kq + r;
+                if (rr < n) {
+                    t_self[(int64_t)rr * lds_ + i] = as[r] + bv;
+                    t_neigh[(int64_t)rr * ldn + i] = an[r];
+                }
+            }
+        }
+    }
+}
+
 // Backward.  A workgroup walks 32-row blocks; its four waves split the F columns (wave w owns the 64-column slice
 // starting at 64 w, lane i of tile j holds column 64 w + 2 i + j), so a wave keeps 2 dW tiles + 2 dh tiles in
 // accumulators (~120 registers: 4 waves per SIMD hide the global latency) and the dW partials of a workgroup need no
@@ -691,6 +787,12 @@ int narrow_mfma_blocks(int64_t n) {
 
 }  // namespace
 
+// 16-row-block forward (narrow_fwd_mfma16_kernel): F a multiple of 16; GTE_NARROW_FWD16=0 keeps the 32-row kernel (A/B)
+static bool narrow_fwd16(int64_t n_feat) {
+    static const bool on = !(getenv("GTE_NARROW_FWD16") && atoi(getenv("GTE_NARROW_FWD16")) == 0);
+    return on && n_feat % 16 == 0;
+}
+
 extern "C" int gte_sage_narrow_supported(int64_t n_feat, int64_t n_out) {
     return (n_out >= 1 && n_out <= NC_MAX && n_feat >= 1 && n_feat <= 256) ? 1 : 0;
 }
@@ -711,6 +813,13 @@ extern "C" int gte_sage_narrow_fwd(const float* h, int64_t ldh, int64_t n_feat, 
         // workgroup's life at one row block per wave (measured at 24 k nodes: 4 waves 19.5 us, 2 waves 23.0, 1 wave 27.4)
         const int wpb = 4;
         const int mb = (int)(gte::ceil_div(nblk, wpb) < 2048 ? gte::ceil_div(nblk, wpb) : 2048);
+        if (narrow_fwd16(n_feat)) {
+            const int64_t nb16 = gte::ceil_div(gte::ceil_div(n_nodes, 16), 8);
+            hipLaunchKernelGGL(narrow_fwd_mfma16_kernel<false>, dim3((unsigned)(nb16 < 2048 ? nb16 : 2048)), dim3(512),
+                               (size_t)32 * (n_feat + 4) * 4, s, h, ldh, W, ldw, bias, t_self, ld_self, t_neigh, ld_neigh,
+                               (int)n_nodes, (int)n_feat, (int)n_out, LnForward{});
+            return gte::check_launch("sage_narrow_fwd");
+        }
         hipLaunchKernelGGL(narrow_fwd_mfma_kernel<false>, dim3((unsigned)mb), dim3(64 * wpb), (size_t)32 * (n_feat + 4) * 4, s, h,
                            ldh, W, ldw, bias, t_self, ld_self, t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out,
                            LnForward{});
@@ -748,6 +857,13 @@ extern "C" int gte_sage_narrow_fwd_ln(const float* z, int64_t ldz, int64_t n_fea
     const int wpb = 4;
     const int mb = (int)(gte::ceil_div(nblk, wpb) < 2048 ? gte::ceil_div(nblk, wpb) : 2048);
     const LnForward lnf = {gamma, beta, eps, relu, y, ldy, stats};
+    if (narrow_fwd16(n_feat)) {
+        const int64_t nb16 = gte::ceil_div(gte::ceil_div(n_nodes, 16), 8);
+        hipLaunchKernelGGL(narrow_fwd_mfma16_kernel<true>, dim3((unsigned)(nb16 < 2048 ? nb16 : 2048)), dim3(512),
+                           (size_t)(32 * (n_feat + 4) + 2 * n_feat) * 4, gte::as_stream(stream), z, ldz, W, ldw, bias, t_self,
+                           ld_self, t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out, lnf);
+        return gte::check_launch("sage_narrow_fwd_ln");
+    }
     hipLaunchKernelGGL(narrow_fwd_mfma_kernel<true>, dim3((unsigned)mb), dim3(64 * wpb),
                        (size_t)(32 * (n_feat + 4) + 2 * n_feat) * 4, gte::as_stream(stream), z, ldz, W, ldw, bias, t_self, ld_self,
                        t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out, lnf);
