@@ -671,7 +671,8 @@ def main():
                     "achieved": tf, "peak": gemm_peak, "unit": "TFLOP/s", "frac": tf / gemm_peak,
                     "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
                     "algorithmic_flops_per_launch": flops / max(n_launch, 1),
-                    "traffic": pmc_traffic()[0].get("gemm_nt_bytes_per_launch") if args.in_feats == 831 else None,
+                    "traffic": pmc_traffic()[0].get("gemm_nt_split_bytes_per_launch" if split_mode else "gemm_nt_bytes_per_launch")
+                               if args.in_feats == 831 else None,
                     "traffic_source": pmc_traffic()[1]}
         per_kernel = {}
         for tag, (n, tms, work) in kt.items():

@@ -1,5 +1,5 @@
 """pmc_traffic.json (what bench.py reads for roofline.traffic) from the per-kernel PMC tables of profiles/pmc_traffic_summary.py.
-usage: python profiles/make_pmc_traffic.py <step per-kernel json> <full per-kernel json> <out json>"""
+usage: python profiles/make_pmc_traffic.py <step per-kernel json> <full per-kernel json> <out json> [<step per-kernel json, split GEMM mode>]"""
 import json, sys
 step, full = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
 
@@ -20,6 +20,11 @@ for tag, pred in (("gemm_nt", lambda k: "gemm_f32_mfma_kernel<true, true" in k),
                   ("spmm_csr", lambda k: k.startswith("spmm_csr_kernel"))):
     b, n = fam(step, pred)
     out[f"{tag}_bytes_per_launch"], out[f"{tag}_launches_sampled"] = b, n
+if len(sys.argv) > 4:
+    split = json.load(open(sys.argv[4]))
+    for tag, pat in (("gemm_nt", "gemm_split_kernel<true, true"), ("gemm_tn", "gemm_split_kernel<false, false"), ("gemm_nn", "gemm_split_kernel<true, false")):
+        b, n = fam(split, lambda k, pat=pat: pat in k)
+        out[f"{tag}_split_bytes_per_launch"], out[f"{tag}_split_launches_sampled"] = b, n
 b, n = fam(full, lambda k: "spmm_tiled_full_kernel" in k)
 out["gather_cfg4_tiled_bytes_per_launch"], out["gather_cfg4_tiled_launches_sampled"] = b, n
 b, n = fam(full, lambda k: k.startswith("spmm_csr_kernel<F32, 64") or k.startswith("spmm_csr_kernel<F32; 64"))

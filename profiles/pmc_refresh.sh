@@ -11,9 +11,15 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $C --kernel-trace -d $O/step/pmc_$C -o p --output-format csv -- python3 $R/profiles/pmc_step.py 4 > $O/pmc_step_$C.log 2>&1
   timeout 200 rocprofv3 --pmc $C --kernel-trace -d $O/full/pmc_$C -o p --output-format csv -- python3 $R/profiles/pmc_probe.py spmm 4 > $O/pmc_$C.log 2>&1
 done
+export GTE_GEMM_MODE=split        # the same four steps with the transform GEMMs in the split-bf16 mode
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --pmc $C --kernel-trace -d $O/step_split/pmc_$C -o p --output-format csv -- python3 $R/profiles/pmc_step.py 4 > $O/pmc_step_split_$C.log 2>&1
+done
+unset GTE_GEMM_MODE
 cd $R
 python3 profiles/pmc_traffic_summary.py $O/full $O/pmc_per_kernel.json > $O/pmc_per_kernel.txt
 python3 profiles/pmc_traffic_summary.py $O/step $O/pmc_per_kernel_step.json > $O/pmc_per_kernel_step.txt
-python3 profiles/make_pmc_traffic.py $O/pmc_per_kernel_step.json $O/pmc_per_kernel.json $O/pmc_traffic.json > /dev/null
-rm -rf $O/full $O/step
+python3 profiles/pmc_traffic_summary.py $O/step_split $O/pmc_per_kernel_step_split.json > $O/pmc_per_kernel_step_split.txt
+python3 profiles/make_pmc_traffic.py $O/pmc_per_kernel_step.json $O/pmc_per_kernel.json $O/pmc_traffic.json $O/pmc_per_kernel_step_split.json > /dev/null
+rm -rf $O/full $O/step $O/step_split
 cat $O/pmc_per_kernel_step.txt | head -20; cat $O/pmc_per_kernel.txt | head -5
