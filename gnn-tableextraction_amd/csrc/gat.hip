@@ -16,6 +16,9 @@
 // sums (d a_l, d a_r, d bias) folded deterministically.  No float atomics.  Roofline: HBM (gathers).
 #include "gte_common.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
 namespace {
 
 constexpr int MAXH = 8;
@@ -309,6 +312,14 @@ gat_fold_kernel(const float* __restrict__ partial, int nblk, int HD, float* __re
     }
 }
 
+#include "gat_rows.h"
+
+// GTE_GAT_ROWS=0 keeps the lane-per-feature kernels (A/B measurements)
+bool gat_rows_enabled() {                   // read per call: tests switch it inside one process
+    const char* e = getenv("GTE_GAT_ROWS");
+    return !(e && atoi(e) == 0);
+}
+
 int check_dims(int64_t n, int H, int D, const char* who) {
     if (n < 0 || n > INT32_MAX || H <= 0 || H > MAXH || D <= 0 || (int64_t)H * D > 1024)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "%s: need 1 <= heads <= 8 and heads*dim <= 1024", who);
@@ -351,6 +362,18 @@ extern "C" int gte_gat_aggregate_fwd_ex(const int32_t* indptr, const int32_t* in
     const size_t shm = out_mean ? (size_t)4 * HD * sizeof(float) : 0;
     dim3 grid((unsigned)gte::ceil_div(n_nodes, 4)), block(256);
     hipStream_t s = gte::as_stream(stream);
+    if (const int vec = gat_rows_enabled() ? gat_rows_vec(heads, dim, ldz, ldz, 0) : 0) {
+#define ROWS(VEC)                                                                                                          \
+    if (dtype == GTE_BF16)                                                                                                 \
+        hipLaunchKernelGGL((gat_rows_fwd_kernel<unsigned short, VEC>), grid, block, 0, s, indptr, indices,                \
+                           (const unsigned short*)z, ldz, el, er, bias, out, ldo, smax, ssum, (int)n_nodes, heads, dim, ep); \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((gat_rows_fwd_kernel<float, VEC>), grid, block, 0, s, indptr, indices, (const float*)z, ldz, el, \
+                           er, bias, out, ldo, smax, ssum, (int)n_nodes, heads, dim, ep)
+        if (vec == 4) { ROWS(4); } else if (vec == 2) { ROWS(2); } else { ROWS(1); }
+#undef ROWS
+        return gte::check_launch("gat_aggregate_fwd");
+    }
 #define CALL(NJ)                                                                                                          \
     if (dtype == GTE_BF16)                                                                                                \
         hipLaunchKernelGGL((gat_aggregate_fwd_kernel<unsigned short, NJ>), grid, block, shm, s, indptr, indices,         \
@@ -402,6 +425,20 @@ extern "C" int gte_gat_aggregate_bwd(const int32_t* indptr, const int32_t* indic
     const int HD = heads * dim;
     dim3 grid((unsigned)gte::ceil_div(n_nodes, 4)), block(256);
     hipStream_t s = gte::as_stream(stream);
+    const int vec = gat_rows_enabled() ? gat_rows_vec(heads, dim, ldz, lddo, 0) : 0;
+    if (vec) {
+#define ROWS(VEC)                                                                                                          \
+    if (dtype == GTE_BF16)                                                                                                 \
+        hipLaunchKernelGGL((gat_rows_bwd_dst_kernel<unsigned short, VEC>), grid, block, 0, s, indptr, indices,            \
+                           (const unsigned short*)z, ldz, el, er, smax, ssum, dout, lddo, ds, der, (int)n_nodes, heads, dim); \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((gat_rows_bwd_dst_kernel<float, VEC>), grid, block, 0, s, indptr, indices, (const float*)z, ldz, \
+                           el, er, smax, ssum, dout, lddo, ds, der, (int)n_nodes, heads, dim);                             \
+    hipLaunchKernelGGL((gat_rows_bwd_src_kernel<VEC>), grid, block, 0, s, rindptr, rindices, pos_in, el, er, smax, ssum,  \
+                       dout, lddo, ds, der, a_l, a_r, dz, lddz, del, (int)n_nodes, heads, dim)
+        if (vec == 4) { ROWS(4); } else if (vec == 2) { ROWS(2); } else { ROWS(1); }
+#undef ROWS
+    } else {
 #define CALL(NJ)                                                                                                           \
     if (dtype == GTE_BF16)                                                                                                 \
         hipLaunchKernelGGL((gat_bwd_dst_kernel<unsigned short, NJ>), grid, block, 0, s, indptr, indices,                  \
@@ -413,6 +450,7 @@ extern "C" int gte_gat_aggregate_bwd(const int32_t* indptr, const int32_t* indic
                        lddo, ds, der, a_l, a_r, dz, lddz, del, (int)n_nodes, heads, dim)
     GTE_NJ_DISPATCH(HD, CALL)
 #undef CALL
+    }
     const int nblk = (int)gte::ceil_div(n_nodes, GC_ROWS);
     float* part = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(gat_colsum_kernel, dim3((unsigned)nblk), dim3(256), 0, s, z_f32, ldzf, del, der, dout, lddo, part,

@@ -53,7 +53,7 @@ struct FoldDesc {
 };
 // Optional optimiser tail of the batch (gte_fold_defer_flush_adam): when `param` is set every folded element is a gradient
 // element of the flat buffer starting at `grad`, and the thread that writes it applies the Adam update of that element.
-struct FoldAdam { float* param; float* grad; float* exp_avg; float* exp_avg_sq; float* state; long long* step; unsigned* ticket; };
+struct FoldAdam { float* param; float* grad; float* exp_avg; float* exp_avg_sq; float* state; long long* step; unsigned* ticket; int vec_ok; };
 struct FoldBatch { FoldDesc d[kMaxFolds]; int n; FoldAdam adam; };
 
 struct FoldQueue {
@@ -98,6 +98,18 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
         const long long e = ((long long)((int)blockIdx.x - d.first_block) * epb + el) * 4;
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
         auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+        // contiguous, 16-byte aligned destination with the optimiser tail: the four elements' parameter and moments move as
+        // 16-byte accesses, requested BEFORE the partials are streamed (one memory round trip less on the critical path)
+        float* d0 = d.dst + e;
+        const bool writer = sl == 0 && e < total;
+        const bool fast = writer && ad.param && ad.vec_ok && d.ld == d.rowlen && (reinterpret_cast<uintptr_t>(d0) & 15) == 0;
+        const long long ai = fast ? d0 - ad.grad : 0;
+        float4 pv = s0, mv = s0, qv = s0;
+        if (fast) {
+            pv = *reinterpret_cast<const float4*>(ad.param + ai);
+            mv = *reinterpret_cast<const float4*>(ad.exp_avg + ai);
+            qv = *reinterpret_cast<const float4*>(ad.exp_avg_sq + ai);
+        }
         if (e < total) {
             const float* p = d.src + e;
             const long long st = d.stride * d.slices;
@@ -116,14 +128,23 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
         t.z = (s0.z + s1.z) + (s2.z + s3.z); t.w = (s0.w + s1.w) + (s2.w + s3.w);
         reinterpret_cast<float4*>(part)[threadIdx.x] = t;
         __syncthreads();
-        if (sl == 0 && e < total) {
+        if (writer) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int u = 0; u < d.slices; ++u) add(v, reinterpret_cast<const float4*>(part)[u * epb + el]);
-            const float vv[4] = {v.x, v.y, v.z, v.w};
+            if (fast) {
+                *reinterpret_cast<float4*>(d0) = v;
+                gte::adam_update(co, pv.x, v.x, mv.x, qv.x); gte::adam_update(co, pv.y, v.y, mv.y, qv.y);
+                gte::adam_update(co, pv.z, v.z, mv.z, qv.z); gte::adam_update(co, pv.w, v.w, mv.w, qv.w);
+                *reinterpret_cast<float4*>(ad.exp_avg + ai) = mv;
+                *reinterpret_cast<float4*>(ad.exp_avg_sq + ai) = qv;
+                *reinterpret_cast<float4*>(ad.param + ai) = pv;
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long long ee = e + j, r = ee / d.rowlen;
-                put(&d.dst[r * d.ld + (ee - r * d.rowlen)], vv[j]);
+                for (int j = 0; j < 4; ++j) {
+                    const long long ee = e + j, r = ee / d.rowlen;
+                    put(&d.dst[r * d.ld + (ee - r * d.rowlen)], vv[j]);
+                }
             }
         }
         if (ad.param) gte::adam_advance(ad.state, ad.step, ad.ticket);
@@ -156,7 +177,7 @@ namespace gte {
 
 static int flush_folds(FoldQueue& q, const FoldAdam* adam = nullptr) {
     if (q.batch.n == 0) return GTE_OK;
-    q.batch.adam = adam ? *adam : FoldAdam{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    q.batch.adam = adam ? *adam : FoldAdam{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     hipLaunchKernelGGL(gte_fold_batch_kernel, dim3((unsigned)q.blocks), dim3(256), 0, q.stream, q.batch);
     q.batch.n = 0;
     q.blocks = 0;
@@ -269,7 +290,9 @@ extern "C" int gte_fold_defer_flush_adam(float* param, float* grad, float* exp_a
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam: null pointer or n <= 0");
     }
     if (spilled || q.batch.n == 0 || !gte::folds_cover(q, grad, n)) return gte::flush_folds(q);   // caller runs gte_adam_step_dev
-    const gte::FoldAdam ad = {param, grad, exp_avg, exp_avg_sq, state, reinterpret_cast<long long*>(step_counter), ticket};
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+                         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
+    const gte::FoldAdam ad = {param, grad, exp_avg, exp_avg_sq, state, reinterpret_cast<long long*>(step_counter), ticket, vec_ok};
     const int rc = gte::flush_folds(q, &ad);
     if (rc == GTE_OK) *fused = 1;
     return rc;

@@ -13,7 +13,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --val-graph 0"
 timeout 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python3 $R/bench.py --long-run-seconds 0.2 --no-cpu-baseline > $O/bench_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python3 $R/bench.py --long-run-seconds 0.2 --no-cpu-baseline > $O/bench_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_step -o t -- python3 $R/bench.py --long-run-seconds 0.2 $STEP_ONLY > $O/bench_trace_step.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_split -o t -- python3 $R/bench.py --gemm-mode split_bf16 --long-run-seconds 0.2 $STEP_ONLY > $O/bench_trace_split.log 2>&1
 cd $R

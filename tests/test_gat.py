@@ -124,3 +124,31 @@ def test_bf16_mfma_projection_is_exact_on_bf16_inputs(m, n, k):
     ab, wb = _bf16_copy(a)[:, :k].float().cpu().double(), _bf16_copy(w)[:, :k].float().cpu().double()
     np.testing.assert_allclose(got.numpy(), (ab @ wb.t()).numpy(), rtol=1e-5, atol=1e-5 * np.sqrt(k))
     assert torch.equal(_bf16_copy(a, 1)[:, :k].float(), torch.nn.functional.elu(a).to(torch.bfloat16).float())   # ELU + cast
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,e,hid,heads,bf16", [(100, 4000, 64, 4, False), (100, 4000, 64, 4, True), (150, 3000, 20, 4, False),
+                                                (400, 2000, 32, 3, True), (90, 2500, 5, 2, False)])
+def test_gat_row_layout_kernels_match_the_lane_per_feature_kernels(n, e, hid, heads, bf16, monkeypatch):
+    """csrc/gat_rows.h (head per DPP row; chosen when heads <= 4 and dim <= 64) against the lane-per-feature kernels of gat.hip
+    (GTE_GAT_ROWS=0): forward output and every gradient, on graphs whose rows span several 16-edge chunks (mean in-degree
+    up to 40) and rows without in-edges; same edge order, different rescaling points of the online softmax: agreement to
+    2e-4 of each tensor's largest entry (three stacked layers, fp32 accumulation)."""
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import graph as G
+    dev = "cuda:0"
+    src, dst = random_graph(n, e, n + e)
+    g = G.PageGraph(src, dst, n, device=dev)
+    x = torch.randn(n, 24, generator=torch.Generator().manual_seed(2)).to(dev)
+    up = torch.randn(n, 9, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = {}
+    for rows in ("1", "0"):
+        monkeypatch.setenv("GTE_GAT_ROWS", rows)
+        torch.manual_seed(1)
+        model = gte.GAT(24, hid, 9, n_layers=3, heads=heads, gather_dtype=torch.bfloat16 if bf16 else torch.float32).to(dev)
+        out = model(g, x)
+        (out * up).sum().backward()
+        res[rows] = [out.detach().cpu()] + [p.grad.detach().cpu() for p in model.parameters()]
+    for a, b in zip(res["1"], res["0"]):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-4 * scale, (float((a - b).abs().max()), scale)
