@@ -117,10 +117,11 @@ struct SplitOperand {
         r[SET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, KC ? (vo | oob) : vo, 0, 0));
     }
     // chunk i of set SET -> its three pieces in the planes at `planes`
-    template <int SET, int i>
+    // MASK: the K ranges are not multiples of 4, so a chunk can straddle the end of its row: keep the valid prefix
+    template <int SET, int i, bool MASK>
     __device__ __forceinline__ void store(char* __restrict__ planes) const {
         f32x4 v = r[SET][i];
-        if constexpr (KC) {
+        if constexpr (KC && MASK) {
             v.y = vc[SET] > 1 ? v.y : 0.f;
             v.z = vc[SET] > 2 ? v.z : 0.f;
             v.w = vc[SET] > 3 ? v.w : 0.f;
@@ -155,7 +156,9 @@ struct SplitFrags { bf16x8 a[3][TM], b[3][TN]; };
 
 // Same contract as gemm_f32_mfma_kernel (tile mapping, K segments, split-K slabs, tail pieces, epilogue): the two are
 // interchangeable per launch.
-template <bool AK, bool BKC, int BM, int BN>
+// KTAIL: some K segment length is not a multiple of 4 (only then K-contiguous chunks need their tail masks: 3 selects per
+// chunk and stage; the 256- and 512-deep GEMMs of the step run without them)
+template <bool AK, bool BKC, int BM, int BN, bool KTAIL>
 __global__ void __launch_bounds__(256, 2)
 gemm_split_kernel(const GemmParams p) {
     constexpr int WN = 2;
@@ -254,8 +257,8 @@ gemm_split_kernel(const GemmParams p) {
         constexpr int st = decltype(SET)::value;
         static_for<NC>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            if constexpr (j < NCA) opa.template store<st, j>(buf);
-            else opb.template store<st, j - NCA>(buf + OpA::LDS_BYTES);
+            if constexpr (j < NCA) opa.template store<st, j, KTAIL>(buf);
+            else opb.template store<st, j - NCA, KTAIL>(buf + OpA::LDS_BYTES);
         });
     };
 

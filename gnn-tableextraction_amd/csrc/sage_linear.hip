@@ -761,11 +761,16 @@ void launch_tile(GemmParams p, dim3 grid, hipStream_t s) {
             constexpr int shm_s = gemm_split_lds_bytes<AK, BKC, BM, BN>();
             static bool configured_s = false;
             if (!configured_s) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BKC, BM, BN>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BKC, BM, BN, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, shm_s);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BKC, BM, BN, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, shm_s);
                 configured_s = true;
             }
-            hipLaunchKernelGGL((gemm_split_kernel<AK, BKC, BM, BN>), grid, dim3(256), shm_s, s, p);
+            // K-contiguous operands with a K range that is not a multiple of 4 need the chunk tail masks
+            const bool ktail = (AK || BKC) && (p.K1 % 4 != 0 || p.K2 % 4 != 0);
+            if (ktail) hipLaunchKernelGGL((gemm_split_kernel<AK, BKC, BM, BN, true>), grid, dim3(256), shm_s, s, p);
+            else hipLaunchKernelGGL((gemm_split_kernel<AK, BKC, BM, BN, false>), grid, dim3(256), shm_s, s, p);
             if (tail)
                 hipLaunchKernelGGL((gemm_tail_fixup_kernel<BM, BN>), dim3((unsigned)(tiles - p.sk_full), BM * BN / 1024), dim3(256), 0, s, p);
             return;

@@ -141,6 +141,11 @@ def train(data, config, name_time=None):
     if distributed:
         D.init_process_group("nccl", device)
     class_weights = None if cw is None else torch.tensor(cw, dtype=torch.float32, device=device)
+    # optional: arithmetic of the transform GEMMs (config.TRAINING.gemm_mode = "f32" | "split_bf16"; default: GTE_GEMM_MODE / f32)
+    gemm_mode = config.TRAINING.get('gemm_mode', None) if hasattr(config.TRAINING, 'get') else getattr(config.TRAINING, 'gemm_mode', None)
+    if gemm_mode is not None:
+        ops.set_gemm_mode(gemm_mode)
+        say(f"MODE: transform GEMMs in {gemm_mode} arithmetic")
 
     logs = logs_from_config(config)
     out_root = config.GENERAL.get('output_dir', 'output')
@@ -194,6 +199,12 @@ def train(data, config, name_time=None):
 
     say("\n### START TRAINING ###\n")
     train_loss = train_acc = float('nan')
+    # The resident dataset leaves a large population of long-lived Python objects; a full garbage collection in the middle of
+    # an epoch stalls the host for tens of ms while the step needs a launch every ~30 us (measured in bench.py: 0.62 -> 0.78-1.0
+    # ms/step).  Collect once, then keep the survivors out of the collector's sight.
+    import gc
+    gc.collect()
+    gc.freeze()
     for epoch in range(start_epoch, config.TRAINING.n_epochs):
         plan = D.plan_epoch(sizes, batch_size, world, seed=config.PREPROCESS.get('seed', 42), epoch=epoch)
         counts = D.step_node_counts(plan, sizes)
