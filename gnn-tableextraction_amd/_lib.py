@@ -116,6 +116,9 @@ SIGNATURES = {
     "gte_gat_aggregate_bwd": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_void_p, c_int64] + [c_void_p] * 7 +
                               [c_int64] + [c_void_p] * 4 + [c_int64] + [c_void_p] * 3 + [c_int64, c_int, c_int,
                                                                                         c_void_p, c_int64, c_void_p]),
+    "gte_gat_aggregate_bwd_ex": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_void_p, c_int64] + [c_void_p] * 7 +
+                                 [c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64] + [c_void_p] * 4 + [c_int64] +
+                                 [c_void_p] * 3 + [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "gte_weighted_ce_workspace_bytes": (c_int64, [c_int64]),
     "gte_weighted_ce": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int, c_float,
                                 c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -102,12 +102,10 @@ class _GatAggregate(torch.autograd.Function):
         dev = z.device
         dout = ops._row_major(dout.contiguous())
         dmean_bias = dout.sum(0) if ctx.has_mean_bias else None
-        if ctx.elu or ctx.mean_heads:
-            # gradient w.r.t. the pre-epilogue aggregate: broadcast of the head mean (/ heads) and ELU' from the saved output
-            dfull = torch.empty((n, hd), dtype=torch.float32, device=dev)
-            _lib.check(lib.gte_gat_dout_prepare(P(dout), ops._ld(dout), P(act_out), hd, P(dfull), hd, n, heads, dim,
-                                                int(ctx.mean_heads), st), "gte_gat_dout_prepare")
-            dout = dfull
+        # gradient w.r.t. the pre-epilogue aggregate (broadcast of the head mean / heads, ELU' from the saved output): formed
+        # inside the backward's first kernel and left in `dfull` for the others (gte_gat_aggregate_bwd_ex)
+        prep = ctx.elu or ctx.mean_heads
+        dfull = torch.empty((n, hd), dtype=torch.float32, device=dev) if prep else None
         csr, rcsr = g.in_csr(), g.out_csr()
         e = csr.indices.numel()
         ds = torch.empty((max(e, 1), heads), dtype=torch.float32, device=dev)
@@ -116,12 +114,13 @@ class _GatAggregate(torch.autograd.Function):
         da_l, da_r = torch.empty_like(a_l), torch.empty_like(a_r)
         dbias = torch.empty(hd, dtype=torch.float32, device=dev) if ctx.has_bias else None
         ws = ops._workspace(lib.gte_gat_bwd_workspace_bytes(n, heads, dim), dev, "gat")
-        _lib.check(lib.gte_gat_aggregate_bwd(P(csr.indptr), P(csr.indices), P(rcsr.indptr), P(rcsr.indices),
-                                             P(g.out_to_in_pos()), P(zg), ops._ld(zg),
-                                             _lib.GTE_BF16 if ctx.bf16 else _lib.GTE_F32, P(z), ops._ld(z), P(el), P(er),
-                                             P(smax), P(ssum), P(a_l), P(a_r), P(dout), ops._ld(dout), P(ds), P(der),
-                                             P(dele), P(dz), hd, P(da_l), P(da_r), P(dbias), n, heads, dim, P(ws),
-                                             ws.numel(), st), "gte_gat_aggregate_bwd")
+        _lib.check(lib.gte_gat_aggregate_bwd_ex(P(csr.indptr), P(csr.indices), P(rcsr.indptr), P(rcsr.indices),
+                                                P(g.out_to_in_pos()), P(zg), ops._ld(zg),
+                                                _lib.GTE_BF16 if ctx.bf16 else _lib.GTE_F32, P(z), ops._ld(z), P(el), P(er),
+                                                P(smax), P(ssum), P(a_l), P(a_r), P(dout), ops._ld(dout),
+                                                P(act_out) if ctx.elu else None, hd, int(ctx.mean_heads), P(dfull), hd,
+                                                P(ds), P(der), P(dele), P(dz), hd, P(da_l), P(da_r), P(dbias), n, heads, dim,
+                                                P(ws), ws.numel(), st), "gte_gat_aggregate_bwd_ex")
         return dz, da_l, da_r, dbias, dmean_bias, None, None, None, None, None, None
 
 

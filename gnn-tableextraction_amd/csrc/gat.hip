@@ -274,7 +274,22 @@ gat_colsum_kernel(const float* __restrict__ z, int64_t ldzf, const float* __rest
     for (int f = threadIdx.x; f < HD; f += 256) {
         const int h = f / D;
         float a = 0.f, b = 0.f, c = 0.f;
-        for (int v = r0; v < r1; ++v) {
+        int v = r0;
+        // eight rows' loads in flight per thread (the one-row-at-a-time loop was latency-bound: 115 us at 200 k x 256);
+        // the sums keep the row order
+        for (; v + 8 <= r1; v += 8) {
+            float x[8], dl[8], dr[8], dd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                x[u] = z[(int64_t)(v + u) * ldzf + f];
+                dl[u] = del[(int64_t)(v + u) * H + h];
+                dr[u] = der[(int64_t)(v + u) * H + h];
+                dd[u] = dout[(int64_t)(v + u) * lddo + f];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a = fmaf(dl[u], x[u], a); b = fmaf(dr[u], x[u], b); c += dd[u]; }
+        }
+        for (; v < r1; ++v) {
             const float x = z[(int64_t)v * ldzf + f];
             a = fmaf(del[(int64_t)v * H + h], x, a);
             b = fmaf(der[(int64_t)v * H + h], x, b);
@@ -415,9 +430,27 @@ extern "C" int gte_gat_aggregate_bwd(const int32_t* indptr, const int32_t* indic
                                      const float* dout, int64_t lddo, float* ds, float* der, float* del, float* dz,
                                      int64_t lddz, float* da_l, float* da_r, float* dbias, int64_t n_nodes, int heads,
                                      int dim, void* workspace, int64_t workspace_bytes, void* stream) {
+    return gte_gat_aggregate_bwd_ex(indptr, indices, rindptr, rindices, pos_in, z, ldz, dtype, z_f32, ldzf, el, er, smax, ssum, a_l,
+                                    a_r, dout, lddo, nullptr, 0, 0, nullptr, 0, ds, der, del, dz, lddz, da_l, da_r, dbias, n_nodes,
+                                    heads, dim, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gte_gat_aggregate_bwd_ex(const int32_t* indptr, const int32_t* indices, const int32_t* rindptr,
+                                        const int32_t* rindices, const int32_t* pos_in, const void* z, int64_t ldz,
+                                        int dtype, const float* z_f32, int64_t ldzf, const float* el, const float* er,
+                                        const float* smax, const float* ssum, const float* a_l, const float* a_r,
+                                        const float* dout_in, int64_t lddo_in, const float* act_out, int64_t ldao, int mean_heads,
+                                        float* dfull, int64_t lddf, float* ds, float* der, float* del, float* dz,
+                                        int64_t lddz, float* da_l, float* da_r, float* dbias, int64_t n_nodes, int heads,
+                                        int dim, void* workspace, int64_t workspace_bytes, void* stream) {
     if (int rc = check_dims(n_nodes, heads, dim, "gat_aggregate_bwd")) return rc;
     if (n_nodes == 0) return GTE_OK;
-    if (!indptr || !rindptr || !z || !z_f32 || !el || !er || !smax || !ssum || !a_l || !a_r || !dout || !ds || !der ||
+    if (dfull && lddf < (int64_t)heads * dim) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gat_aggregate_bwd: lddf too small");
+    // effective dout: dfull when given (formed by the destination-side kernel, or by the prepare kernel where that kernel
+    // is not the row-layout one), else dout_in
+    const float* dout = dfull ? dfull : dout_in;
+    const int64_t lddo = dfull ? lddf : lddo_in;
+    if (!indptr || !rindptr || !z || !z_f32 || !el || !er || !smax || !ssum || !a_l || !a_r || !dout_in || !ds || !der ||
         !del || !dz || !workspace)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gat_aggregate_bwd: null pointer");
     if (workspace_bytes < gte_gat_bwd_workspace_bytes(n_nodes, heads, dim))
@@ -426,14 +459,25 @@ extern "C" int gte_gat_aggregate_bwd(const int32_t* indptr, const int32_t* indic
     dim3 grid((unsigned)gte::ceil_div(n_nodes, 4)), block(256);
     hipStream_t s = gte::as_stream(stream);
     const int vec = gat_rows_enabled() ? gat_rows_vec(heads, dim, ldz, lddo, 0) : 0;
+    GatDoutPrepare pp = {act_out, ldao, dfull, lddf, mean_heads};
+    const bool fuse_prepare = vec && dfull && lddo_in % vec == 0 && (!act_out || ldao % vec == 0) && lddf % vec == 0;
+    if (dfull && !fuse_prepare) {                          // the prepare pass as its own launch (lane-per-feature kernels, odd strides)
+        const int64_t work = n_nodes * heads * dim;
+        hipLaunchKernelGGL(gat_dout_prepare_kernel, dim3((unsigned)gte::ceil_div(work, 256)), dim3(256), 0, s, dout_in, lddo_in,
+                           act_out, ldao, dfull, lddf, n_nodes, heads, dim, mean_heads);
+        pp.dfull = nullptr;
+    }
+    const float* dout_dst = fuse_prepare ? dout_in : dout;   // what the destination-side kernel reads
+    const int64_t lddo_dst = fuse_prepare ? lddo_in : lddo;
     if (vec) {
 #define ROWS(VEC)                                                                                                          \
     if (dtype == GTE_BF16)                                                                                                 \
         hipLaunchKernelGGL((gat_rows_bwd_dst_kernel<unsigned short, VEC>), grid, block, 0, s, indptr, indices,            \
-                           (const unsigned short*)z, ldz, el, er, smax, ssum, dout, lddo, ds, der, (int)n_nodes, heads, dim); \
+                           (const unsigned short*)z, ldz, el, er, smax, ssum, dout_dst, lddo_dst, ds, der, (int)n_nodes, heads, \
+                           dim, pp);                                                                                       \
     else                                                                                                                   \
         hipLaunchKernelGGL((gat_rows_bwd_dst_kernel<float, VEC>), grid, block, 0, s, indptr, indices, (const float*)z, ldz, \
-                           el, er, smax, ssum, dout, lddo, ds, der, (int)n_nodes, heads, dim);                             \
+                           el, er, smax, ssum, dout_dst, lddo_dst, ds, der, (int)n_nodes, heads, dim, pp);                 \
     hipLaunchKernelGGL((gat_rows_bwd_src_kernel<VEC>), grid, block, 0, s, rindptr, rindices, pos_in, el, er, smax, ssum,  \
                        dout, lddo, ds, der, a_l, a_r, dz, lddz, del, (int)n_nodes, heads, dim)
         if (vec == 4) { ROWS(4); } else if (vec == 2) { ROWS(2); } else { ROWS(1); }

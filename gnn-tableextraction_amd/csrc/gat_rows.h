@@ -32,6 +32,11 @@ template <int VEC> struct RowVec<float, VEC> {
         else if constexpr (VEC == 2) { const float2 v = *reinterpret_cast<const float2*>(p); o[0] = v.x; o[1] = v.y; }
         else o[0] = *p;
     }
+    static __device__ __forceinline__ void store(float* p, const float (&o)[VEC]) {
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+        else if constexpr (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(o[0], o[1]);
+        else *p = o[0];
+    }
 };
 template <int VEC> struct RowVec<unsigned short, VEC> {
     static __device__ __forceinline__ void load(const unsigned short* p, float (&o)[VEC]) {
@@ -128,6 +133,9 @@ gat_rows_fwd_kernel(const int32_t* __restrict__ indptr, const int32_t* __restric
     }
 }
 
+// optional: form the effective dout in the destination-side kernel (all NULL / 0: dout is used as given)
+struct GatDoutPrepare { const float* act_out; int64_t ldao; float* dfull; int64_t lddf; int mean_heads; };
+
 // Backward, destination side: ds[e, h] = alpha (d alpha - sum_e' alpha d alpha) leaky'(s),  der[v, h] = sum_e ds[e, h];
 // d alpha_e,h = <dout[v, h, :], z[u_e, h, :]>: ONE gather pass when the row has <= 16 in-edges (d alpha stays in the edge lanes).
 template <typename T, int VEC>
@@ -135,15 +143,32 @@ __global__ void __launch_bounds__(256)
 gat_rows_bwd_dst_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, const T* __restrict__ z,
                         int64_t ldzz, const float* __restrict__ el, const float* __restrict__ er,
                         const float* __restrict__ smax, const float* __restrict__ ssum, const float* __restrict__ dout,
-                        int64_t lddo, float* __restrict__ ds, float* __restrict__ der, int n, int H, int D) {
+                        int64_t lddo, float* __restrict__ ds, float* __restrict__ der, int n, int H, int D,
+                        const GatDoutPrepare pp) {
     const int lane = threadIdx.x & 63, h = lane >> 4, i = lane & 15;
     const int v = (int)gte_xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     if (v >= n) return;
     const bool hv = h < H, fv = hv && VEC * i < D;
     const int f0 = (hv ? h : 0) * D + (fv ? VEC * i : 0);
     float dv[VEC];
+    if (pp.dfull) {
+        // the gradient w.r.t. the pre-epilogue aggregate, formed here (gat_dout_prepare_kernel's arithmetic) and left in
+        // dfull for the source-side kernel and the column sums: the separate 600 MB pass disappears.  Vector accesses:
+        // the lane's VEC features are consecutive in all three arrays.
+        float g[VEC], o[VEC];
+        RowVec<float, VEC>::load(dout + (int64_t)v * lddo + (pp.mean_heads ? (fv ? VEC * i : 0) : f0), g);
+        if (pp.act_out) RowVec<float, VEC>::load(pp.act_out + (int64_t)v * pp.ldao + f0, o);
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) dv[c] = fv ? dout[(int64_t)v * lddo + f0 + c] : 0.f;
+        for (int c = 0; c < VEC; ++c) {
+            if (pp.mean_heads) g[c] /= (float)H;
+            if (pp.act_out) g[c] *= o[c] > 0.f ? 1.f : o[c] + 1.f;
+            dv[c] = fv ? g[c] : 0.f;
+        }
+        if (fv) RowVec<float, VEC>::store(pp.dfull + (int64_t)v * pp.lddf + f0, dv);
+    } else {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) dv[c] = fv ? dout[(int64_t)v * lddo + f0 + c] : 0.f;
+    }
     const float erv = hv ? er[(int64_t)v * H + h] : 0.f;
     const float mv = hv ? smax[(int64_t)v * H + h] : 0.f, lv = hv ? ssum[(int64_t)v * H + h] : 1.f;
     const int lo = indptr[v], hi = indptr[v + 1];

@@ -446,6 +446,18 @@ int gte_gat_aggregate_bwd(const int32_t* indptr, const int32_t* indices, const i
                           float* ds, float* der, float* del, float* dz, int64_t lddz,
                           float* da_l, float* da_r, float* dbias, int64_t n_nodes, int heads, int dim,
                           void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with gte_gat_dout_prepare folded in: dfull (nullable; [n, heads * dim] scratch) receives the effective gradient
+ * (mean_heads ? dout[v, f % dim] / heads : dout[v, f]) * (act_out ? ELU'(act_out[v, f]) : 1), formed by the destination-side
+ * kernel itself where the row-layout kernels apply (heads <= 4, dim <= 64: no separate pass over the three [n, heads * dim]
+ * arrays) and by a gte_gat_dout_prepare launch otherwise.  dfull == NULL: dout is used as given (gte_gat_aggregate_bwd). */
+int gte_gat_aggregate_bwd_ex(const int32_t* indptr, const int32_t* indices, const int32_t* rindptr, const int32_t* rindices,
+                             const int32_t* pos_in, const void* z, int64_t ldz, int dtype, const float* z_f32, int64_t ldzf,
+                             const float* el, const float* er, const float* smax, const float* ssum,
+                             const float* a_l, const float* a_r, const float* dout, int64_t lddo,
+                             const float* act_out, int64_t ldao, int mean_heads, float* dfull, int64_t lddf,
+                             float* ds, float* der, float* del, float* dz, int64_t lddz,
+                             float* da_l, float* da_r, float* dbias, int64_t n_nodes, int heads, int dim,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }
