@@ -61,6 +61,7 @@ SIGNATURES = {
     "gte_gemm_set_tail_workspace": (c_int, [c_void_p, c_int64]),
     "gte_gemm_set_mode": (c_int, [c_int]),
     "gte_gemm_get_mode": (c_int, []),
+    "gte_gemm_set_thread_mode": (c_int, [c_int]),
     "gte_fold_defer_begin": (c_int, [c_void_p]),
     "gte_fold_defer_flush": (c_int, []),
     "gte_fold_defer_flush_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),

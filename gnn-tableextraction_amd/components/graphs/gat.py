@@ -9,7 +9,8 @@ Precision modes (``GAT(..., gather_dtype=, compute_dtype=)``):
   compute_dtype = bfloat16   the projection z = X W^T runs on ``v_mfma_f32_32x32x16_bf16`` with bf16 operands and fp32
                              accumulation (csrc/gemm_bf16.hip); X's bf16 copy is written by the PREVIOUS layer's aggregation
                              epilogue together with the ELU (no separate activation or cast pass); the output layer's mean
-                             over heads + bias is that kernel's epilogue too.  The backward GEMMs (dX, dW) stay fp32 MFMA.
+                             over heads + bias is that kernel's epilogue too.  The backward GEMMs (dX, dW) take fp32 operands and run in the split mode of
+                             the fp32 GEMM (csrc/gemm_split.h: six bf16 MFMA products of exact bf16 pieces, fp32-accurate).
 With both fp32 (the default) every step is fp32.
 """
 import math
@@ -38,6 +39,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, x_bf16, bf16):
         ctx.save_for_backward(x, w)
+        ctx.bf16 = bool(bf16)
         if not bf16:
             return ops.gemm(x, w, trans_b=True)
         lib, P = _lib.load(), _lib.ptr
@@ -53,8 +55,20 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = ops.gemm(dy, w) if ctx.needs_input_grad[0] else None
-        dw = ops.gemm(dy, x, trans_a=True) if ctx.needs_input_grad[1] else None
+        if not ctx.bf16:
+            dx = ops.gemm(dy, w) if ctx.needs_input_grad[0] else None
+            dw = ops.gemm(dy, x, trans_a=True) if ctx.needs_input_grad[1] else None
+            return dx, dw, None, None
+        # bf16 configuration: dX / dW on the bf16 matrix pipe too, through the split mode of the fp32 GEMM (three exact bf16
+        # pieces per fp32 operand, fp32 accumulate: fp32-accurate results at 1.3-1.5x the fp32 MFMA rate) -- for this
+        # thread's two launches only
+        lib = _lib.load()
+        _lib.check(lib.gte_gemm_set_thread_mode(ops.GEMM_SPLIT_BF16), "gte_gemm_set_thread_mode")
+        try:
+            dx = ops.gemm(dy, w) if ctx.needs_input_grad[0] else None
+            dw = ops.gemm(dy, x, trans_a=True) if ctx.needs_input_grad[1] else None
+        finally:
+            lib.gte_gemm_set_thread_mode(-1)
         return dx, dw, None, None
 
 

@@ -645,7 +645,11 @@ bool needs_small_path(bool ak, bool bkc, const GemmParams& p) {
 // GEMM arithmetic mode (gte_gemm_set_mode): process-wide -- autograd runs the backward GEMMs on another host thread.
 // -1 = not yet read from the environment (GTE_GEMM_MODE=split | bf16x3 selects the split mode, anything else fp32).
 std::atomic<int> g_gemm_mode{-1};
+// per-thread override (gte_gemm_set_thread_mode): -1 = none.  Lets one caller (the GAT's bf16 configuration) run ITS GEMMs in
+// the split mode without changing what other threads / modules get.
+thread_local int t_gemm_mode = -1;
 int gemm_mode() {
+    if (t_gemm_mode >= 0) return t_gemm_mode;
     int m = g_gemm_mode.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("GTE_GEMM_MODE");
@@ -1434,6 +1438,13 @@ extern "C" int gte_gemm_set_mode(int mode) {
 }
 
 extern "C" int gte_gemm_get_mode(void) { return gemm_mode(); }
+
+extern "C" int gte_gemm_set_thread_mode(int mode) {
+    if (mode != -1 && mode != GTE_GEMM_F32 && mode != GTE_GEMM_SPLIT_BF16)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_set_thread_mode: unknown mode %d", mode);
+    t_gemm_mode = mode;
+    return GTE_OK;
+}
 
 extern "C" int64_t gte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t mfma = gemm_workspace(M, N, K, 0);

@@ -253,6 +253,9 @@ int gte_gemm_set_tail_workspace(void* workspace, int64_t workspace_bytes);
 #define GTE_GEMM_SPLIT_BF16 1
 int gte_gemm_set_mode(int mode);
 int gte_gemm_get_mode(void);
+/* Override for the calling host thread only (-1: none, the process-wide mode applies): one caller's GEMMs in another mode
+ * without touching what other threads get.  gte_gemm_get_mode reports the mode the calling thread would run in. */
+int gte_gemm_set_thread_mode(int mode);
 
 /* ---- deferred folds -------------------------------------------------------------------------------------------
  * Several entry points end with a small "sum the per-block partials" kernel (gte_ln_relu_bwd: column sums;

@@ -152,6 +152,22 @@ def test_gemm_mode_switch_validates_and_round_trips():
     assert ops.get_gemm_mode() == prev
 
 
+def test_thread_mode_override_wins_over_the_process_mode_for_this_thread_only():
+    import threading
+    lib = gte._lib.load()
+    prev = ops.get_gemm_mode()
+    assert lib.gte_gemm_set_thread_mode(5) != 0
+    try:
+        assert lib.gte_gemm_set_thread_mode(ops.GEMM_SPLIT_BF16) == 0 and ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(lib.gte_gemm_get_mode()))
+        t.start(); t.join()
+        assert seen == [prev]                               # another thread still sees the process-wide mode
+    finally:
+        lib.gte_gemm_set_thread_mode(-1)
+    assert ops.get_gemm_mode() == prev
+
+
 def test_headline_width_model_matches_the_reference_golden_in_split_mode(split_mode):
     from tests import test_gpu_parity as T
     T.test_headline_shape_case_matches_reference_golden()
