@@ -627,6 +627,12 @@ def main():
         flops_node_ = sum(2.0 * 2 * dims_[l] * dims_[l + 1] * (3 if l > 0 else 2) for l in range(args.layers))
         t_floor = float(np.mean(sizes)) * args.pages * flops_node_ / (MFMA_F32_PEAK_TF * 1e12)
         n_long = max(args.steps, int(args.long_run_seconds / max(t_floor, 1e-6)) + 1)
+        if distributed:
+            # every rank generates ITS pages, so the mean page size -- and with it this step count -- differs by rank; the
+            # ranks must run the same number of steps (one all-reduce per step): take the largest
+            nl = torch.tensor([n_long], dtype=torch.int64, device=dev)
+            dist.all_reduce(nl, op=dist.ReduceOp.MAX)
+            n_long = int(nl.item())
         long_ep, ep = epoch_steps(sizes, args.pages, seed, ep, n_long)
         long_cnt = global_counts(long_ep)
         barrier()

@@ -95,3 +95,25 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, overlap):
     assert bad.mean() < 1e-3 and np.abs(p0 - want).max() < 5e-3
     l0 = np.load(tmp_path / "loss_0.npy")
     assert len(l0) == STEPS and np.isfinite(l0).all()
+
+
+def test_bench_self_spawned_two_ranks_share_the_gpu():
+    """`python bench.py --gpus 2` starts its own two ranks (here: both on the one GPU over gloo, GTE_BENCH_SHARE_GPU=1 -- the
+    N > 1 code path of bench.py, not a measurement) and prints ONE line with n_gpus = 2.  The long run is on: its step count is
+    derived from the rank's own pages and must be agreed between the ranks (an all-reduce per step: a rank that plans one step
+    more hangs or trips the transport's size check -- round 2 shipped that bug for an hour)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GTE_BENCH_SHARE_GPU="1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--long-run-seconds", "0.05", "--resident-pages", "300", "--no-cpu-baseline"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{\"metric\"")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["long_run"]["steps"] >= 4
+    assert d["value"] > 0 and np.isfinite(d["final_loss"])
