@@ -10,7 +10,8 @@
 // below the rounding an fp32 FMA chain commits on every step.  Measured against fp64 on random and on training operands
 // (profiles/r02/gemm_split.md, tests/test_gemm_split.py): error <= the native fp32 MFMA kernel's on every shape.
 // Six 32-cycle MFMAs per K = 16 against eight 64-cycle MFMAs: 2.67x the matrix-pipe rate at the same accuracy class.
-// Non-finite operands: inf - inf in the split makes NaN where the fp32 kernel would return inf.
+// Non-finite operands: inf - inf in the split makes NaN where the fp32 kernel would return inf.  Operands below ~2^-109 in
+// magnitude: the low piece (2^-17 of the operand) leaves bf16's normal range; tests cover operand scales 2^-60 .. 2^60.
 //
 // Structure (one workgroup = 4 waves as 2 x 2, block tile BM x 128, 2 workgroups per CU):
 //   stage = 16 k.  global -> registers: buffer loads through the same range-checked windows as the fp32 kernel (zero fill

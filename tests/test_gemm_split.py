@@ -67,6 +67,38 @@ def test_split_gemm_error_against_fp64_not_above_the_fp32_kernel(ta, tb, m, n, k
     _check(res)
 
 
+def test_split_gemm_randomised_shapes_strides_and_layouts():
+    """60 random (M, N, K, layout) with operands and outputs that are column slices of wider buffers (leading dimensions that
+    are not multiples of 4, unaligned row starts): the split kernel's windows, K tails, row tails and tile shapes."""
+    rng = np.random.default_rng(20260)
+    g = torch.Generator().manual_seed(9)
+    for case in range(60):
+        m = int(rng.choice([1, 31, 64, 65, 127, 128, 129, 200, 513, 1000, 2049]))
+        n = int(rng.choice([33, 64, 100, 128, 129, 255, 256, 300, 512]))
+        k = int(rng.choice([1, 3, 4, 15, 16, 17, 31, 33, 64, 100, 255, 256, 831, 1100]))
+        ta, tb = bool(rng.integers(2)), bool(rng.integers(2))
+        pa, pb, pc = int(rng.integers(0, 4)), int(rng.integers(0, 4)), int(rng.integers(0, 4))     # column offsets
+        wa, wb = int(rng.integers(0, 7)), int(rng.integers(0, 7))                                   # extra row width
+        A = torch.randn((k, pa + m + wa) if ta else (m, pa + k + wa), generator=g).to(DEV)
+        B = torch.randn((n, pb + k + wb) if tb else (k, pb + n + wb), generator=g).to(DEV)
+        a = A[:, pa:pa + (m if ta else k)]
+        b = B[:, pb:pb + (k if tb else n)]
+        Cbuf = torch.full((m, pc + n + 3), 7.0, device=DEV)
+        a64, b64 = (a.t() if ta else a).double().cpu(), (b.t() if tb else b).double().cpu()
+        ref, unit = a64 @ b64, (a64.abs() @ b64.abs()) * 2.0 ** -24
+        res = {}
+        for mode in ("f32", "split_bf16"):
+            prev = ops.set_gemm_mode(mode)
+            try:
+                Cbuf.fill_(7.0)
+                ops.gemm(a, b, trans_a=ta, trans_b=tb, out=Cbuf[:, pc:pc + n])
+            finally:
+                ops.set_gemm_mode(prev)
+            res[mode] = _err_units(Cbuf[:, pc:pc + n], ref, unit)
+            assert bool((Cbuf[:, :pc] == 7.0).all()) and bool((Cbuf[:, pc + n:] == 7.0).all()), (case, mode, "wrote outside C")
+        assert res["split_bf16"] <= 1.25 * res["f32"] + 2.5 and res["split_bf16"] < 12.0, (case, m, n, k, ta, tb, res)
+
+
 def test_split_gemm_wide_dynamic_range_and_exact_cases():
     """Operands spanning 2^-60 .. 2^60 (the pieces keep fp32's exponent range); small integers come out exact."""
     g = torch.Generator().manual_seed(3)
