@@ -34,6 +34,7 @@ SIGNATURES = {
     "gte_knn_max_k": (c_int, []),
     "gte_knn_max_page_nodes": (c_int, []),
     "gte_knn_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "gte_visibility_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "gte_knn_csr_workspace_bytes": (c_int64, [c_int64]),
     "gte_knn_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_int64, c_void_p]),

@@ -80,7 +80,8 @@ class PrebuiltPages:
 
     @classmethod
     def from_boxes(cls, page_boxes, page_sizes, page_texts, page_labels, device, k: int = 5, max_dist: int = 500,
-                   bidirectional: bool = True, range_island: int = 0, extra_feats=None, **kw) -> "PrebuiltPages":
+                   bidirectional: bool = True, range_island: int = 0, extra_feats=None, mode: str = "knn",
+                   **kw) -> "PrebuiltPages":
         """Pages from word boxes with the graph stage on the DEVICE: k-NN edges, island removal,
         to_simple + to_bidirected, edge weights (graph.knn_graph_from_boxes) and the 13 BBOX node features
         (graph.bbox_features) -- what builder.get_graph + loader.modify_graphs + nlp/bbox.py do per page in Python.
@@ -96,7 +97,8 @@ class PrebuiltPages:
         bbox = torch.from_numpy(np.concatenate([np.asarray(b, dtype=np.int32).reshape(-1, 4) for b in page_boxes])).to(device)
         labels = torch.from_numpy(np.concatenate([np.asarray(l, dtype=np.int64) for l in page_labels])).to(device)
         g, keep = G.knn_graph_from_boxes(bbox, node_off, np.asarray(page_sizes, dtype=np.int32), k=k, max_dist=max_dist,
-                                         bidirectional=bidirectional, labels=labels, range_island=range_island)
+                                         bidirectional=bidirectional, labels=labels, range_island=range_island,
+                                         mode=mode)                  # PREPROCESS.mode: 'knn' | 'visibility' (loader.py:80)
         texts = page_texts if page_texts is not None else [[""] * n for n in sizes]
         feat = Bbox(device).features(page_boxes, texts)[keep]
         if extra_feats is not None:

@@ -174,6 +174,106 @@ island_final_kernel(const int32_t* __restrict__ label, int text, const uint8_t* 
     if (v < n) island[v] = (!reach[v]) && label[v] == text;
 }
 
+// ---- visibility graph (builder.py:294-379): nearest visible box per direction, crossing vertical edges removed ---------------
+// sel[i * 4 + {0, 1, 2, 3}] = global id of node i's top / right / bottom / left neighbour, -1 none.  One thread per node scans
+// the page's boxes IN INDEX ORDER (the reference's updates are order dependent: a box intersecting the node's box takes the
+// top / bottom slot at distance 0 unconditionally, later candidates must beat the current distance strictly; the top and
+// right slots also require height / 2 (width / 2) > current distance, the bottom and left slots do not).  Comparisons of
+// box centres and of the halves run on doubled integers (exact).  oracle/visibility_graph.py is pinned on the reference's
+// own output.
+__global__ void __launch_bounds__(256)
+vis_select_kernel(const int32_t* __restrict__ bbox, const int32_t* __restrict__ node_off, const int32_t* __restrict__ page_size,
+                  int max_dist, int32_t* __restrict__ sel) {
+    extern __shared__ Box boxes[];
+    const int page = blockIdx.y;
+    const int n0 = node_off[page], np = node_off[page + 1] - n0;
+    if ((int)blockIdx.x * 256 >= np) return;
+    const int width = page_size[2 * page], height = page_size[2 * page + 1];
+    for (int j = threadIdx.x; j < np; j += 256) {
+        const int4 v = *reinterpret_cast<const int4*>(bbox + (int64_t)(n0 + j) * 4);
+        boxes[j] = Box{v.x, v.y, v.z, v.w};
+    }
+    __syncthreads();
+    const int li = blockIdx.x * 256 + threadIdx.x;
+    if (li >= np) return;
+    const Box a = boxes[li];
+    const int acx = a.x0 + a.x1, acy = a.y0 + a.y1;
+    int nb0 = -1, nb1 = -1, nb2 = -1, nb3 = -1;
+    int c0 = max_dist, c1 = max_dist, c2 = max_dist, c3 = max_dist;
+    for (int j = 0; j < np; ++j) {
+        if (j == li) continue;
+        const Box b = boxes[j];
+        const int bcx = b.x0 + b.x1, bcy = b.y0 + b.y1;
+        const bool top = bcy < acy, bottom = acy < bcy, right = acx < bcx, left = bcx < acx;
+        const bool vp = a.x0 <= b.x1 && b.x0 <= a.x1, hp = a.y0 <= b.y1 && b.y0 <= a.y1;
+        if (vp && hp) {
+            if (top) { nb0 = j; c0 = 0; }
+            else if (bottom) { nb2 = j; c2 = 0; }
+        } else if (vp) {
+            const int dt = a.y0 - b.y1, db = b.y0 - a.y1;
+            if (top && height > 2 * c0 && c0 > dt) { nb0 = j; c0 = dt; }
+            else if (bottom && c2 > db) { nb2 = j; c2 = db; }
+        } else if (hp) {
+            const int dr = b.x0 - a.x1, dl = a.x0 - b.x1;
+            if (right && width > 2 * c1 && c1 > dr) { nb1 = j; c1 = dr; }
+            else if (left && c3 > dl) { nb3 = j; c3 = dl; }
+        }
+    }
+    int4 o;
+    o.x = nb0 < 0 ? -1 : n0 + nb0; o.y = nb1 < 0 ? -1 : n0 + nb1; o.z = nb2 < 0 ? -1 : n0 + nb2; o.w = nb3 < 0 ? -1 : n0 + nb3;
+    *reinterpret_cast<int4*>(sel + (int64_t)(n0 + li) * 4) = o;
+}
+
+struct VisNode { int cx, cy, right, left; };              // doubled centre, horizontal neighbours (page-local ids, -1 none)
+
+__device__ __forceinline__ bool vis_ccw(int ax, int ay, int bx, int by, int cx, int cy) {
+    return (long long)(cy - ay) * (bx - ax) > (long long)(by - ay) * (cx - ax);
+}
+// builder.py:358-363: do the segments AB and CD cross?
+__device__ __forceinline__ bool vis_cross(int ax, int ay, int bx, int by, int cx, int cy, int dx, int dy) {
+    return vis_ccw(ax, ay, cx, cy, dx, dy) != vis_ccw(bx, by, cx, cy, dx, dy) &&
+           vis_ccw(ax, ay, bx, by, cx, cy) != vis_ccw(ax, ay, bx, by, dx, dy);
+}
+
+// remove_vertical(): node i's top edge (top -> i) and bottom edge (i -> bottom) are dropped when their centre-to-centre segment
+// crosses the segment of any horizontal edge of the page whose END point differs from the vertical edge's START point.
+__global__ void __launch_bounds__(256)
+vis_prune_kernel(const int32_t* __restrict__ bbox, const int32_t* __restrict__ node_off, int32_t* __restrict__ sel) {
+    extern __shared__ VisNode vn[];
+    const int page = blockIdx.y;
+    const int n0 = node_off[page], np = node_off[page + 1] - n0;
+    if ((int)blockIdx.x * 256 >= np) return;
+    for (int j = threadIdx.x; j < np; j += 256) {
+        const int4 v = *reinterpret_cast<const int4*>(bbox + (int64_t)(n0 + j) * 4);
+        const int4 sj = *reinterpret_cast<const int4*>(sel + (int64_t)(n0 + j) * 4);
+        vn[j] = VisNode{v.x + v.z, v.y + v.w, sj.y < 0 ? -1 : sj.y - n0, sj.w < 0 ? -1 : sj.w - n0};
+    }
+    __syncthreads();
+    const int li = blockIdx.x * 256 + threadIdx.x;
+    if (li >= np) return;
+    int32_t* mine = sel + (int64_t)(n0 + li) * 4;
+    const int top = mine[0], bot = mine[2];
+    for (int side = 0; side < 2; ++side) {
+        const int other = side == 0 ? top : bot;
+        if (other < 0) continue;
+        const int s = side == 0 ? other - n0 : li, d = side == 0 ? li : other - n0;       // top -> i, i -> bottom
+        const int v1x = vn[s].cx, v1y = vn[s].cy, v2x = vn[d].cx, v2y = vn[d].cy;
+        bool crossed = false;
+        for (int j = 0; j < np && !crossed; ++j) {
+            const VisNode h = vn[j];
+            if (h.left >= 0) {                               // left -> j: h1 = centre(left), h2 = centre(j)
+                const VisNode l = vn[h.left];
+                crossed = (v1x != h.cx || v1y != h.cy) && vis_cross(v1x, v1y, v2x, v2y, l.cx, l.cy, h.cx, h.cy);
+            }
+            if (!crossed && h.right >= 0) {                  // j -> right: h1 = centre(j), h2 = centre(right)
+                const VisNode r = vn[h.right];
+                crossed = (v1x != r.cx || v1y != r.cy) && vis_cross(v1x, v1y, v2x, v2y, h.cx, h.cy, r.cx, r.cy);
+            }
+        }
+        if (crossed) mine[side == 0 ? 0 : 2] = -1;
+    }
+}
+
 size_t scan_temp_bytes(int64_t n) {
     size_t bytes = 0;
     (void)rocprim::exclusive_scan(nullptr, bytes, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)n, rocprim::plus<int32_t>(),
@@ -205,6 +305,34 @@ extern "C" int gte_knn_select(const int32_t* bbox, const int32_t* node_off, cons
     hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)gte::ceil_div(max_page_nodes > 0 ? max_page_nodes : 1, 256), (unsigned)n_pages),
                        dim3(256), shm, gte::as_stream(stream), bbox, node_off, page_size, k, max_dist, sel);
     return gte::check_launch("knn_select");
+}
+
+// sel[n_nodes, 4]: top / right / bottom / left neighbour of every node (global ids, -1 none) after remove_vertical(); the graph
+// is then gte_knn_csr(sel, k = 4, bidirectional = 1).
+extern "C" int gte_visibility_select(const int32_t* bbox, const int32_t* node_off, const int32_t* page_size, int64_t n_pages,
+                                     int64_t n_nodes, int64_t max_page_nodes, int max_dist, int32_t* sel, void* stream) {
+    if (n_pages <= 0 || n_nodes < 0 || n_pages > 65535 || n_nodes >= INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "visibility_select: bad sizes");
+    if (max_page_nodes > KNN_PAGE_MAX)
+        return gte::fail(GTE_ERR_UNSUPPORTED, "visibility_select: a page of %lld boxes exceeds %d", (long long)max_page_nodes, KNN_PAGE_MAX);
+    if (n_nodes == 0) return GTE_OK;
+    if (!bbox || !node_off || !page_size || !sel) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "visibility_select: null pointer");
+    if ((((uintptr_t)bbox | (uintptr_t)sel) & 15) != 0)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "visibility_select: bbox and sel must be 16-byte aligned");
+    const size_t shm = (size_t)(max_page_nodes > 0 ? max_page_nodes : 1) * sizeof(Box);
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  KNN_PAGE_MAX * (int)sizeof(Box));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_prune_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  KNN_PAGE_MAX * (int)sizeof(VisNode));
+        configured = true;
+    }
+    const dim3 grid((unsigned)gte::ceil_div(max_page_nodes > 0 ? max_page_nodes : 1, 256), (unsigned)n_pages);
+    hipStream_t s = gte::as_stream(stream);
+    hipLaunchKernelGGL(vis_select_kernel, grid, dim3(256), shm, s, bbox, node_off, page_size, max_dist, sel);
+    hipLaunchKernelGGL(vis_prune_kernel, grid, dim3(256), shm, s, bbox, node_off, sel);
+    return gte::check_launch("visibility_select");
 }
 
 extern "C" int64_t gte_knn_csr_workspace_bytes(int64_t n_nodes) {

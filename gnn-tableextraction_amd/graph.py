@@ -516,8 +516,12 @@ def bbox_features(bbox: torch.Tensor, char_counts: torch.Tensor) -> torch.Tensor
 
 def knn_graph_from_boxes(bbox: torch.Tensor, node_off, page_size, k: int = 5, max_dist: int = 500, bidirectional: bool = True,
                          labels: Optional[torch.Tensor] = None, range_island: int = 0, text_label: int = 1,
-                         edge_features: bool = True):
-    """boxes -> batched k-NN page graph, entirely on the device.
+                         edge_features: bool = True, mode: str = "knn"):
+    """boxes -> batched page graph (``PREPROCESS.mode`` = 'knn' or 'visibility'), entirely on the device.
+
+    mode='visibility' (builder.py:294-379): every node's nearest visible box to the top / right / bottom / left, vertical edges
+    that cross a horizontal edge removed (gte_visibility_select), then the same to_simple + to_bidirected CSR, island removal
+    and edge weights as the k-NN mode; ``k`` is ignored, the graph is always bidirected.
 
     What ``GraphBuilder.get_graph(mode='knn')`` (builder.py:240-292,383-411) and ``Papers2Graphs.modify_graphs``
     (loader.py:296-344: fast_remove_islands, to_simple + to_bidirected, edge weights) do page by page in Python, for all pages
@@ -553,9 +557,19 @@ def knn_graph_from_boxes(bbox: torch.Tensor, node_off, page_size, k: int = 5, ma
                                        P(dst_of), None, 0, _lib.current_stream()), "gte_knn_csr fill")
         return indptr, indices, dst_of
 
-    sel = torch.empty((n, k), dtype=torch.int32, device=dev)
-    _lib.check(lib.gte_knn_select(P(bbox), P(node_off_d), P(page_size_d), n_pages, n, int(sizes.max()) if n_pages else 0, k,
-                                  int(max_dist), P(sel), _lib.current_stream()), "gte_knn_select")
+    if mode == "visibility":
+        if not bidirectional:
+            raise ValueError("the visibility graph is built bidirected (loader.py:319-320); bidirectional=False is a k-NN option")
+        k = 4                                                    # top, right, bottom, left
+        sel = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        _lib.check(lib.gte_visibility_select(P(bbox), P(node_off_d), P(page_size_d), n_pages, n, int(sizes.max()) if n_pages else 0,
+                                             int(max_dist), P(sel), _lib.current_stream()), "gte_visibility_select")
+    elif mode == "knn":
+        sel = torch.empty((n, k), dtype=torch.int32, device=dev)
+        _lib.check(lib.gte_knn_select(P(bbox), P(node_off_d), P(page_size_d), n_pages, n, int(sizes.max()) if n_pages else 0, k,
+                                      int(max_dist), P(sel), _lib.current_stream()), "gte_knn_select")
+    else:
+        raise ValueError("mode should be either 'visibility' or 'knn'")        # builder.py:409
     indptr, indices, dst_of = csr_of(sel, bidirectional)
     keep = torch.ones(n, dtype=torch.bool, device=dev)
     if range_island and labels is not None:

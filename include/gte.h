@@ -137,6 +137,12 @@ int gte_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
  *   gte_island_mask island[v] = 1 for nodes labelled text_label from which no walk of exactly khop steps over the (symmetric)
  *                   CSR ends at a node with another label; workspace >= 2 * n_nodes bytes.
  * Integer work only; no atomics, no sort: deterministic. */
+/* Visibility mode of the same builder (builder.py:294-379): sel[n_nodes, 4] = every node's nearest visible box to the top /
+ * right / bottom / left (global ids, -1 none; the reference's order-dependent update rules, restated in
+ * oracle/visibility_graph.py and pinned on its own output) with the vertical edges that cross a horizontal edge removed
+ * (remove_vertical()).  The graph is gte_knn_csr(sel, k = 4, bidirectional = 1).  bbox and sel 16-byte aligned. */
+int gte_visibility_select(const int32_t* bbox, const int32_t* node_off, const int32_t* page_size, int64_t n_pages,
+                          int64_t n_nodes, int64_t max_page_nodes, int max_dist, int32_t* sel, void* stream);
 int gte_knn_max_k(void);
 int gte_knn_max_page_nodes(void);
 int gte_knn_select(const int32_t* bbox, const int32_t* node_off, const int32_t* page_size, int64_t n_pages, int64_t n_nodes,

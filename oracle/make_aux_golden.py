@@ -11,6 +11,8 @@ shipped to the GPU box) on seeded inputs and writes small fixtures under tests/g
                          ``LableModification`` maps                      src/components/graphs/labels.py:7-27
                          ``calculate_hidden`` / ``get_in_feats_`` answers  src/components/features/utils.py:71-101
   aux_knn_edges.npz      the k-NN edge builder of ``GraphBuilder.get_graph`` (mode 'knn')  builder.py:240-292
+  aux_visibility_edges.npz   the same function in mode 'visibility' (nearest visible box per direction, crossing
+                         vertical edges removed)  builder.py:294-379
                          on seeded pages (ties included; how they are compared: oracle/knn_graph.py)
 
 The modules these live in import packages that are absent here (dgl, seaborn, attrdict, fitz, a hard-coded path check
@@ -168,6 +170,9 @@ def main(out=OUT):
     sys.path.insert(0, ROOT)
     from oracle import knn_graph
     knn_graph.write_reference_fixture(os.path.join(out, "aux_knn_edges.npz"))
+    # ---- visibility edges (builder.py:294-379) ------------------------------------------------------------------------
+    from oracle import visibility_graph
+    visibility_graph.write_reference_fixture(os.path.join(out, "aux_visibility_edges.npz"))
     print("wrote", sorted(f for f in os.listdir(out) if f.startswith("aux_")))
 
 

@@ -174,3 +174,87 @@ def test_device_island_removal_and_loader_from_boxes():
         np.testing.assert_array_equal(pg.feat, ob.bbox_features(b[keep], counts))          # BBOX features, bit-exact
     assert removed > 0                                              # the case does exercise the removal
     assert data.whole.num_nodes() == sum(pg.num_nodes for pg in data.page_arrays)
+
+
+# ---------------------------------------------------------------- visibility mode (builder.py:294-379)
+from oracle import visibility_graph as vg
+
+ZV = np.load(os.path.join(GOLDEN_DIR, "aux_visibility_edges.npz"))
+VPAGES = list(range(int(ZV["n_pages"])))
+
+
+@pytest.mark.parametrize("i", VPAGES)
+def test_visibility_oracle_equals_the_reference_output_exactly(i):
+    """oracle/visibility_graph.py against the edges the REFERENCE's own ``get_edges('visibility')`` produced on seeded pages
+    (overlapping and empty boxes included): the same (u, v), in the same order, duplicates included."""
+    b, size, maxd = ZV[f"bbox{i}"].astype(np.int64), tuple(int(x) for x in ZV[f"size{i}"]), int(ZV[f"maxd{i}"])
+    u, v = vg.visibility_edges(b, size, maxd)
+    np.testing.assert_array_equal(u, ZV[f"u{i}"])
+    np.testing.assert_array_equal(v, ZV[f"v{i}"])
+    # the per-node table + crossing removal (what the device builds) gives the same undirected graph
+    sel, _ = vg.visibility_select(b, size, maxd)
+    sel = vg.crossing_removed(sel, b)
+    pairs = {(int(min(i_, j)), int(max(i_, j))) for i_ in range(len(sel)) for j in sel[i_] if j >= 0}
+    assert pairs == {(int(min(a, c)), int(max(a, c))) for a, c in zip(u.tolist(), v.tolist())}
+
+
+def test_visibility_quirks_of_the_reference_are_kept():
+    """height / 2 > max_dist is required before any non-intersecting box can become the TOP neighbour (the bottom slot has no
+    such test); an intersecting box takes the slot at distance 0 and only another intersecting box replaces it."""
+    b = np.array([[100, 100, 140, 110], [100, 60, 140, 70], [100, 140, 140, 150]])       # middle, above, below
+    sel, _ = vg.visibility_select(b, (400, 400), 500)                  # height / 2 = 200 < 500: no top neighbours at all
+    assert sel[0].tolist() == [-1, -1, 2, -1] and sel[2].tolist() == [-1, -1, -1, -1] and sel[1].tolist() == [-1, -1, 0, -1]
+    sel, _ = vg.visibility_select(b, (400, 1200), 500)                 # height / 2 = 600 > 500: tops appear
+    assert sel[0].tolist() == [1, -1, 2, -1] and sel[2].tolist() == [0, -1, -1, -1]
+    b2 = np.array([[100, 100, 140, 120], [100, 95, 140, 104], [100, 60, 140, 70]])       # node, an intersecting box above, a free box above
+    sel, d = vg.visibility_select(b2, (400, 1200), 500)
+    assert sel[0, 0] == 1 and d[0, 0] == 0                             # the intersecting one, at distance 0, keeps the slot
+
+
+@pytest.mark.gpu
+def test_device_visibility_graph_equals_the_oracle_and_the_reference_fixture():
+    """gte_visibility_select + gte_knn_csr(k = 4) over all fixture pages at once: the bidirected simple graph of the reference's
+    own edge list, page by page, in (dst, src) order, with the edge weights of oracle/box_geometry.py; then 40 random pages
+    (dense overlaps, degenerate boxes) against the oracle."""
+    import torch
+    from gnn_tableextraction_amd import graph as G
+    from oracle import box_geometry as bg
+
+    def device(pages, maxd):
+        boxes = np.concatenate([p[0] for p in pages]).astype(np.int32)
+        off = np.concatenate([[0], np.cumsum([len(p[0]) for p in pages])])
+        sizes = np.array([p[1] for p in pages], dtype=np.int32)
+        g, keep = G.knn_graph_from_boxes(torch.from_numpy(boxes).cuda(), off, sizes, max_dist=maxd, mode="visibility")
+        assert bool(keep.all())
+        src, dst = (t.cpu().numpy().astype(np.int64) for t in g.edges())
+        return g, src, dst, off
+
+    for maxd in (60, 500):
+        idx = [i for i in VPAGES if int(ZV[f"maxd{i}"]) == maxd]
+        pages = [(ZV[f"bbox{i}"].astype(np.int64), tuple(int(x) for x in ZV[f"size{i}"])) for i in idx]
+        g, src, dst, off = device(pages, maxd)
+        w = g.edata["feat"].cpu().numpy()
+        for p, i in enumerate(idx):
+            rs, rd = kg.to_simple_bidirected(ZV[f"u{i}"].astype(np.int64), ZV[f"v{i}"].astype(np.int64), len(pages[p][0]))
+            m = (dst >= off[p]) & (dst < off[p + 1])
+            np.testing.assert_array_equal(src[m] - off[p], rs)
+            np.testing.assert_array_equal(dst[m] - off[p], rd)
+            if len(rs):
+                np.testing.assert_array_equal(w[m], bg.edge_weights(pages[p][0], rs, rd))
+    rng = np.random.default_rng(3)
+    pages = []
+    for _ in range(40):
+        n = int(rng.integers(1, 120))
+        W, H = int(rng.integers(300, 900)), int(rng.integers(300, 2400))
+        x0, y0 = rng.integers(0, W - 40, n), rng.integers(0, H - 30, n)
+        b = np.stack([x0, y0, x0 + rng.integers(0, 40, n), y0 + rng.integers(0, 30, n)], 1).astype(np.int64)
+        pages.append((b, (W, H)))
+    g, src, dst, off = device(pages, 500)
+    for p, (b, size) in enumerate(pages):
+        u, v = vg.visibility_edges(b, size, 500)
+        rs, rd = kg.to_simple_bidirected(u, v, len(b))
+        m = (dst >= off[p]) & (dst < off[p + 1])
+        np.testing.assert_array_equal(src[m] - off[p], rs)
+        np.testing.assert_array_equal(dst[m] - off[p], rd)
+    with pytest.raises(ValueError):
+        G.knn_graph_from_boxes(torch.zeros((1, 4), dtype=torch.int32).cuda(), [0, 1], [[10, 10]], mode="delaunay")
