@@ -408,7 +408,7 @@ def cfg3_probe(args, gte, dev):
                                                         P(smax), P(ssum), n, heads, hid, 1, P(ob), hd, None, 0, None, st))
     e_cnt = csr.indices.numel()
     bytes_a = n * hd * (2 + 4 + 2) + e_cnt * (4 + heads * 4) + n * (4 + heads * 16)
-    out["aggregation_256"] = {"kernel": "gat_aggregate_fwd_kernel<bf16> (online edge softmax, ELU + bf16 copy in the epilogue)",
+    out["aggregation_256"] = {"kernel": "gat_rows_fwd_kernel<bf16, 4> (head per DPP row, online edge softmax per 16-edge chunk, ELU + bf16 copy in the epilogue)",
                               "ms": ms_a, "roofline": {"bound": "hbm", "achieved": bytes_a / ms_a / 1e6, "peak": HBM_PEAK_GBS,
                                                        "unit": "GB/s", "frac": bytes_a / ms_a / 1e6 / HBM_PEAK_GBS,
                                                        "algorithmic_bytes": bytes_a}}
