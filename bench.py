@@ -118,7 +118,10 @@ def _make_page_job(job):
 def make_pages_parallel(n_pages, in_feats, first_id, workers):
     """Synthetic pages on a process pool.  Called BEFORE the GPU is initialised (fork is only safe then)."""
     from gnn_tableextraction_amd.data import synthetic as S
-    if workers <= 1 or n_pages < 64:
+    # under rocprofv3 the forked workers inherit the profiler's preloaded tool and now and then never exit (the parent then
+    # sits in wait4 until the run's timeout: it cost two profile runs): generate in-process there
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+    if workers <= 1 or n_pages < 64 or under_profiler:
         return S.make_pages(n_pages, in_feats=in_feats, first_id=first_id)
     import multiprocessing as mp
     with mp.get_context("fork").Pool(workers) as pool:

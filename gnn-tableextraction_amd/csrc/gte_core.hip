@@ -1,6 +1,7 @@
 // libgte_hip.so: error reporting, version and device facts.
 #include "gte_common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -192,6 +193,8 @@ bool defer_fold(const float* src, int64_t stride, int count, int rows, int rowle
     FoldDesc& d = q.batch.d[q.batch.n++];
     d.src = src; d.stride = stride; d.dst = dst; d.ld = ld;
     d.count = count; d.rows = rows; d.rowlen = rowlen; d.first_block = q.blocks;
+    // (slices for 12..31 partials -- the split-K slabs -- measured: 4 slices 42.9 us against 27.8 us with one: the optimiser
+    // tail then runs in a quarter of the threads)
     d.slices = count >= 128 ? 16 : (count >= 32 ? 4 : 1);
     const int64_t total = (int64_t)rows * rowlen;
     d.vec = (total % 4 == 0 && stride % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && total >= 4096) ? 4 : 1;
