@@ -205,3 +205,33 @@ def test_pipelined_loop_equals_one_batch_at_a_time(f0):
     torch.cuda.synchronize()
     assert torch.equal(a.flat_param.cpu(), b.flat_param.cpu())
     assert len(seen) == 10 and len(set(seen)) > 3                     # a different batch (size) nearly every step
+
+
+def test_bench_line_keeps_the_driver_contract():
+    """`python bench.py --steps K --warmup W` prints ONE JSON line with the keys the driver and the judge read (metric / value /
+    unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload,
+    a `roofline` object priced against the guide's peak and a `cpu_baseline` object measured on the host cores)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--resident-pages", "300",
+                        "--long-run-seconds", "0.05", "--val-graph", "200", "--gather-nodes", "100000", "--no-cfg3"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("nodes/sec") and d["unit"] == "nodes/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"].startswith("f32") and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["nodes_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 0.05 * d["value"]
+    ro = d["roofline"]
+    assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s") and ro["peak"] > 0
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and 0 < ro["frac"] < 1 and "traffic" in ro
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "nodes/s" and cb["sample"]
+    gm = d["gemm_modes"]
+    assert gm["other_mode"]["value"] > 0 and gm["error_vs_fp64"]["split_bf16"]["max"] <= 1.25 * gm["error_vs_fp64"]["f32"]["max"] + 2.5
+    assert d["gather"]["bound"] == "hbm" and d["val_graph"]["logits_finite"] is True
