@@ -76,7 +76,10 @@ struct SplitOperand {
 
     __device__ __forceinline__ void init(int64_t ld0, int64_t ld1, int tid, int lane, int blk_row0) {
         if constexpr (KC) {
-            const int kq = tid & 3, r0 = tid >> 2;
+            // rows of a 16-lane group (the unit a ds_write_b64 is served in) are 2 apart: with 48-byte rows the four 32-byte
+            // row segments of rows r, r+2, r+4, r+6 fall on disjoint bank octets (consecutive rows: r and r+3 overlap --
+            // SQ_LDS_BANK_CONFLICT 7.8 M cycles per layer-0 forward launch, 0 after)
+            const int kq = tid & 3, r0 = 8 * (tid >> 5) + ((tid >> 4) & 1) + 2 * ((tid >> 2) & 3);
             kpos = kq * 4;
             wofs = r0 * 48 + kq * 8;
 #pragma unroll

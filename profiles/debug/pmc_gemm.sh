@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ counters of the step's GEMM launches: bash profiles/debug/pmc_gemm.sh <outdir>   (on the GPU box)
+# SQ counters of the step's GEMM launches: bash profiles/debug/pmc_gemm.sh <outdir>   (on the GPU box; export GTE_GEMM_MODE=split
+# first for the split kernels)
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/${1:-pmc_gemm}; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 for C in l0fwd l1fwd l1dx l0dw; do
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES --kernel-trace -d $O/a_$C -o p --output-format csv -- python3 $R/profiles/debug/gemm_case.py $C 6 > /dev/null 2>&1
