@@ -376,6 +376,45 @@ gemm_split_kernel(const GemmParams p) {
     }
     float* outp = p.splits > 1 ? p.slab + (int64_t)split * p.M * p.N : p.C;
     const int64_t ldo = p.splits > 1 ? p.N : p.ldc;
+    const bool post = p.splits <= 1 && (p.accumulate || p.relu);
+    // Branch-free stores through a buffer descriptor over the output: rows past M and columns past the tile's segment get an
+    // offset outside the window and are dropped by the range check -- no per-element compare / exec mask / 64-bit address
+    // (the guarded pointer version below executes ~11 vector instructions and 2 branches per element: a third of the
+    // vector instructions of a 256-deep GEMM).  Needs every offset of the padded tile grid to fit 32 bits.
+    const int64_t extent = ((int64_t)p.M + BM) * ldo * 4;
+    if (extent < ((int64_t)1 << 31)) {
+        const int ncols_out = p.splits > 1 ? p.N : (p.Bn2 ? 2 * seg_cols : p.N);
+        const __amdgpu_buffer_rsrc_t c_srd =
+            __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)(((int64_t)(p.M - 1) * ldo + ncols_out) * 4), SRD_FLAGS);
+        const int ld4 = (int)ldo * 4;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col_in_seg = n0 + (wn * TN + b) * 32 + col_l;
+            const int col = nseg * seg_cols + col_in_seg;
+            const int coff = col_in_seg < seg_cols ? col * 4 : (int)0x80000000;          // out of the window
+            const float bv = (p.bias && p.splits <= 1 && col_in_seg < seg_cols && (p.bias_cols <= 0 || col < p.bias_cols)) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int roff0 = (m0 + (wm * TM + a) * 32 + hrow) * ld4 + coff;
+                if (!post) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[a][b][r] + bv), c_srd,
+                                                              roff0 + ((r & 3) + 8 * (r >> 2)) * ld4, 0, 0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int off = roff0 + ((r & 3) + 8 * (r >> 2)) * ld4;
+                        float v = acc[a][b][r] + bv;
+                        if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_srd, off, 0, 0));
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_srd, off, 0, 0);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int col_in_seg = n0 + (wn * TN + b) * 32 + col_l;
