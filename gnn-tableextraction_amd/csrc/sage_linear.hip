@@ -731,10 +731,12 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
         const int64_t ncol = Nseg > 0 ? 2 * gte::ceil_div(Nseg, 128) : gte::ceil_div(N, 128);
         const int64_t t128 = gte::ceil_div(M, 128) * ncol, t64 = gte::ceil_div(M, 64) * ncol;
         pl.bn = 128;
-        // split mode (gemm_split.h): 128x128: 6.9 + 0.0464 K, 64x128: 3.86 + 0.0282 K (profiles/debug/gemm_split_tiles.py)
+        // Re-fitted after the branch-free store epilogue (round 2, profiles/debug/gemm_split_tiles.py, 512 / 1024 tiles over K =
+        // 128 .. 1662): fp32 MFMA 128x128: 4.7 + 0.0589 K, 64x128: 2.5 + 0.0315 K (the fixed cost of the big tile was 8.07);
+        // split mode (gemm_split.h) 128x128: 3.8 + 0.0458 K, 64x128: 2.2 + 0.0273 K.
         const bool split = gemm_mode() == GTE_GEMM_SPLIT_BF16;
-        const double c64 = split ? cost(t64, 3.86, 0.0282) : cost(t64, 2.67, 0.0335);
-        const double c128 = split ? cost(t128, 6.9, 0.0464) : cost(t128, 8.07, 0.0594);
+        const double c64 = split ? cost(t64, 2.2, 0.0273) : cost(t64, 2.5, 0.0315);
+        const double c128 = split ? cost(t128, 3.8, 0.0458) : cost(t128, 4.7, 0.0589);
         pl.bm = (t128 >= cus && c64 < c128) ? 64 : 128;
         // split-K with very few output tiles (dW of a 256 x 256 layer: 4 tiles over 24 k nodes): smaller tiles ->
         // half the K splits -> half the slab bytes (measured 58 -> 44 us; at 14 tiles, 256 x 831, it loses: 147 -> 161)
