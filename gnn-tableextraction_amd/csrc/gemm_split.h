@@ -374,6 +374,9 @@ gemm_split_kernel(const GemmParams p) {
                     sp[((wm * TM + a) * 32 + hrow + (r & 3) + 8 * (r >> 2)) * BN + (wn * TN + b) * 32 + col_l] = acc[a][b][r];
         return;
     }
+#ifdef SPLIT_NOSTORE                                        // measurement only: what the epilogue costs (results are not written)
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     float* outp = p.splits > 1 ? p.slab + (int64_t)split * p.M * p.N : p.C;
     const int64_t ldo = p.splits > 1 ? p.N : p.ldc;
     const bool post = p.splits <= 1 && (p.accumulate || p.relu);
