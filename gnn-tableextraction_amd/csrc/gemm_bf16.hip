@@ -104,6 +104,31 @@ gemm_bf16_nt_kernel(const u16* __restrict__ A, int64_t lda, const u16* __restric
     }
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const int hrow = (lane >> 5) * 4;
+    // branch-free stores through a buffer descriptor over C (rows past M / columns past N fall outside the window and are
+    // dropped): see the store epilogue of sage_linear.hip
+    if (((int64_t)M + BM) * ldc * 4 < ((int64_t)1 << 31)) {
+        const __amdgpu_buffer_rsrc_t c_srd = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(((int64_t)(M - 1) * ldc + N) * 4), 0x00020000u);
+        const int ld4 = (int)ldc * 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + (wn * 2 + b) * 32 + i32;
+            const int coff = col < N ? col * 4 : (int)0x80000000;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int roff0 = (m0 + (wm * 2 + a) * 32 + hrow) * ld4 + coff;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // through a VGPR: with the accumulator element (an AGPR) as the store's data operand hipcc 7.2 emitted
+                    // the SAME register (element 0) for all sixteen stores
+                    float v = acc[a][b][r];
+                    asm volatile("" : "+v"(v));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_srd,
+                                                          roff0 + ((r & 3) + 8 * (r >> 2)) * ld4, 0, 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll

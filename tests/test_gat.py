@@ -152,3 +152,24 @@ def test_gat_row_layout_kernels_match_the_lane_per_feature_kernels(n, e, hid, he
     for a, b in zip(res["1"], res["0"]):
         scale = float(b.abs().max()) + 1e-6
         assert float((a - b).abs().max()) <= 2e-4 * scale, (float((a - b).abs().max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,out", [(300, 13, 256), (300, 256, 36), (1000, 64, 256), (257, 40, 32), (5000, 256, 256), (129, 8, 130)])
+def test_bf16_projection_gemm_is_exact_on_bf16_operands(n, k, out):
+    """gte_gemm_bf16_nt against fp32 matmul of the SAME bf16-rounded operands (products exact in fp32, so only the summation
+    order differs) incl. ragged M / N / K and the branch-free store epilogue: nothing outside [n, out] is written."""
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import _lib
+    from gnn_tableextraction_amd.components.graphs import gat
+    lib, P = _lib.load(), _lib.ptr
+    g = torch.Generator().manual_seed(n + k)
+    x, w = torch.randn(n, k, generator=g).cuda(), torch.randn(out, k, generator=g).cuda()
+    xb, wb = gat._bf16_copy(x), gat._bf16_copy(w)
+    buf = torch.full((n + 3, out + 5), 7.0, device="cuda")
+    z = buf[:n, :out]
+    _lib.check(lib.gte_gemm_bf16_nt(P(xb), xb.stride(0), P(wb), wb.stride(0), P(z), buf.stride(0), n, out, wb.shape[1],
+                                    _lib.current_stream()), "gte_gemm_bf16_nt")
+    ref = xb.float() @ wb.float().t()
+    assert float((z - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-5
+    assert bool((buf[n:] == 7.0).all()) and bool((buf[:, out:] == 7.0).all())
