@@ -63,6 +63,14 @@ SIGNATURES = {
     "gte_gemm_set_mode": (c_int, [c_int]),
     "gte_gemm_get_mode": (c_int, []),
     "gte_gemm_set_thread_mode": (c_int, [c_int]),
+    "gte_p3_row_bytes": (c_int64, [c_int64]),
+    "gte_p3_from_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "gte_p3_to_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_gemm_p3_nt": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                               c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "gte_gemm_p3_tn_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
+    "gte_gemm_p3_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                               c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gte_fold_defer_begin": (c_int, [c_void_p]),
     "gte_fold_defer_flush": (c_int, []),
     "gte_fold_defer_flush_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),

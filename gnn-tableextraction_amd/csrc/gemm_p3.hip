@@ -1,0 +1,552 @@
+// fp32 GEMMs on the bf16 matrix pipe with PRODUCER-SPLIT operands ("planes" GEMMs; the format is csrc/p3.h).
+//
+// replaces (reference src/components/graphs/models.py): :63 nn.Linear(2F, out) and its autograd (dX, dW) -- the same products
+// as csrc/sage_linear.hip / csrc/gemm_split.h, with the operands already cut into three bf16 planes by the kernel that wrote
+// them (aggregation / LayerNorm epilogues, the optimiser's tail, the batch assembly).
+//
+// Why a third GEMM: gemm_split.h cuts every fp32 tile into its bf16 pieces when the tile goes registers -> LDS, i.e. once per
+// workgroup that touches it (the weights: ~190 times per launch) -- ~100 VALU instructions per K stage share the issue port
+// with 24 MFMAs (profiles/r02/c_pmc_gemm_split.txt: 6.6 VALU per MFMA, matrix pipe busy 28-48 %).  Here a K stage is
+// 6 LDS-DMA instructions (buffer_load ... lds: memory -> LDS, no registers, no VALU), 12 fragment reads and 24 MFMAs per wave.
+// Same pieces, same six products per fragment pair in the same order (hl, lh, mm, hm, mh, hh), fp32 accumulate: the result is
+// bit-identical to gemm_split_kernel on the fp32 operands (tests/test_gemm_p3.py).
+//
+// Roofline: MFMA bf16 (2.5 PF dense; six products per fp32 product => 417 TF fp32-equivalent).
+//
+// NT kernel (K = feature index; both operands K-contiguous: C = A B^T, A = [M rows], B = [N rows]):
+//   block tile BM x BN (128 x 128 or 64 x 128), 4 waves as 2 x 2, stage = 16 k = one P3 block = 96 bytes per row.
+//   LDS image of a stage: [rows][96 bytes], filled by LDS-DMA in linear order (lane -> 16-byte slot); the two 16-byte halves
+//   of a plane are swapped in rows with bit 3 set (on the SOURCE address, the destination of an LDS-DMA is linear): the 16
+//   lanes a ds_read_b128 is served in then hit 16 distinct 16-byte bank groups (row stride 96 bytes = 24 banks).
+// TN kernel (K = row index; dW = dZ^T X, split over the rows): block tile 128 x 128, stage = 16 rows; LDS image
+//   [16 k][8 blocks x 96 bytes] in memory order, the block position rotated by 2 (k mod 4) (again on the source side) so the
+//   four k rows a transposing read (ds_read_b64_tr_b16) touches fall on disjoint banks.
+#include "gte_common.h"
+#include "p3.h"
+
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned SRD_FLAGS = 0x00020000u;      // gfx9 raw buffer, 32-bit data format
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+struct P3Gemm {
+    const char* A1; const char* A2; const char* B;       // P3 images (csrc/p3.h)
+    const char* An2; const char* Bn2;                    // TN: operands of N segment 1 (nullptr: those of segment 0)
+    long long lda1, lda2, ldb, ldan2, ldbn2;             // row strides in bytes
+    int KB1, KB2;                                        // NT: 16-wide K blocks of the two A segments (B: KB1 + KB2 blocks per row)
+    int M, N, K;                                         // TN: K = rows reduced over
+    int Nseg;                                            // TN with two N segments: columns per segment (N == 2 Nseg)
+    float* C; long long ldc;
+    const float* bias; int bias_cols;                    // bias covers columns [0, bias_cols) (<= 0: all)
+    int relu, accumulate;
+    int splits, stages_per_split;                        // TN split-K over the rows
+    float* slab;                                         // [splits][M][N] (ld = N) when splits > 1
+};
+
+
+// 64 lanes x 16 bytes memory -> LDS (buffer_load_dwordx4 ... lds): lane l's 16 bytes land at dst + 16 l; dst wave-uniform.
+// A plain (non-template) function on purpose: inside a kernel TEMPLATE whose body depends on the template parameters the
+// HOST pass of hipcc 7.2 failed to instantiate the kernel -- silently: no diagnostic, an undefined symbol at load time.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t srd, char* dst, int voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)dst, 16, voffset, 0, 0, 0);
+}
+
+template <int TM, int TN>
+struct Frags { bf16x8 a[3][TM], b[3][TN]; };
+
+template <int TM, int TN>
+__device__ __forceinline__ void products(f32x16 (&acc)[TM][TN], const Frags<TM, TN>& f) {
+    // the six piece products of a fragment pair, smallest terms first (0 = h, 1 = m, 2 = l): hl, lh, mm, hm, mh, hh
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[q]][a], f.b[PB[q]][b], acc[a][b], 0, 0, 0);
+}
+
+// Store epilogue of a wave's TM x TN accumulator tiles through a buffer descriptor over the output: rows past M and columns
+// past `cols_valid` get an offset outside the window and are dropped by the range check (branch-free; sage_linear.hip).
+// The stored value goes through a VGPR on purpose: with an accumulator element as the store's data operand hipcc 7.2 emitted
+// element 0 for all sixteen stores (gemm_bf16.hip).
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM][TN], float* outp, long long ldo, int M, int cols_total,
+                                           int row0, int col0, int cols_valid_end, const float* bias, int bias_cols, int relu,
+                                           int accumulate, int lane) {
+    const int col_l = lane & 31, hrow = (lane >> 5) * 4;
+    const __amdgpu_buffer_rsrc_t c_srd =
+        __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)(((long long)(M - 1) * ldo + cols_total) * 4), SRD_FLAGS);
+    const int ld4 = (int)ldo * 4;
+    const bool post = accumulate || relu;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = col0 + b * 32 + col_l;
+        const bool cok = col < cols_valid_end;
+        const int coff = cok ? col * 4 : (int)0x80000000;
+        const float bv = (bias && cok && (bias_cols <= 0 || col < bias_cols)) ? bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int roff0 = (row0 + a * 32 + hrow) * ld4 + coff;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = roff0 + ((r & 3) + 8 * (r >> 2)) * ld4;
+                float v = acc[a][b][r] + bv;
+                if (post) {
+                    if (accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_srd, off, 0, 0));
+                    if (relu) v = fmaxf(v, 0.f);
+                }
+                asm volatile("" : "+v"(v));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_srd, off, 0, 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// NT: C[m][n] = sum_k A[m][k] B[n][k]
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGS>
+__global__ void __launch_bounds__(256, WGS)
+gemm_p3_nt_kernel(const P3Gemm p) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_BYTES = BM * 96, B_BYTES = BN * 96, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INST = A_BYTES / 1024, B_INST = B_BYTES / 1024;        // 1 KiB LDS-DMA instructions per stage
+    constexpr int NIA = (A_INST + 3) / 4, NIB = (B_INST + 3) / 4;          // per wave
+    static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "tile rows");
+    extern __shared__ __attribute__((aligned(16))) char lds[];             // two stages
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const unsigned lb = gte_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = (int)(lb / (unsigned)tiles_n), tn = (int)(lb % (unsigned)tiles_n);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int rowsA = min(BM, p.M - m0), rowsB = min(BN, p.N - n0);
+
+    const int lda1 = (int)p.lda1, lda2 = (int)(p.A2 ? p.lda2 : p.lda1), ldb = (int)p.ldb;
+    const __amdgpu_buffer_rsrc_t srdA1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A1 + (long long)m0 * p.lda1), 0, rowsA * lda1, SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t srdA2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.A2 ? p.A2 + (long long)m0 * p.lda2 : p.A1 + (long long)m0 * p.lda1), 0, rowsA * lda2, SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t srdB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B + (long long)n0 * p.ldb), 0, rowsB * ldb, SRD_FLAGS);
+
+    // LDS-DMA slots: instruction ii of an operand fills bytes [1024 ii, 1024 ii + 1024) of its image; lane -> slot s = 64 ii + lane
+    // = (row s / 6, part s % 6), part = 2 plane + half; the source half is swapped in rows with bit 3 set
+    int voa1[NIA], voa2[NIA], vob[NIB];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int s = (i * 4 + wave) * 64 + lane, row = s / 6, part = s - row * 6, sp = part ^ ((row >> 3) & 1);
+        voa1[i] = row * lda1 + sp * 16;
+        voa2[i] = row * lda2 + sp * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        const int s = (i * 4 + wave) * 64 + lane, row = s / 6, part = s - row * 6, sp = part ^ ((row >> 3) & 1);
+        vob[i] = row * ldb + sp * 16;
+    }
+    const int KB1 = p.KB1, T = p.KB1 + p.KB2;
+    auto issue = [&](int t, char* buf) {
+        const bool seg = t >= KB1;
+        const int soa = (seg ? t - KB1 : t) * 96, sob = t * 96;
+        const __amdgpu_buffer_rsrc_t sa = seg ? srdA2 : srdA1;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i)
+            if (A_INST % 4 == 0 || i * 4 + wave < A_INST)
+                dma16(sa, buf + (i * 4 + wave) * 1024, (seg ? voa2[i] : voa1[i]) + soa);
+#pragma unroll
+        for (int i = 0; i < NIB; ++i)
+            if (B_INST % 4 == 0 || i * 4 + wave < B_INST)
+                dma16(srdB, buf + A_BYTES + (i * 4 + wave) * 1024, vob[i] + sob);
+    };
+
+    // fragment of plane pl, 32-row block blk: lane (r = lane & 31, h = lane >> 5) reads the 16 bytes (row r, k = 8 h .. 8 h + 7)
+    const int r = lane & 31, hs = ((lane >> 5) ^ ((r >> 3) & 1)) * 16;
+    const int a_rd = (wm * TM * 32 + r) * 96 + hs;
+    const int b_rd = A_BYTES + (wn * TN * 32 + r) * 96 + hs;
+    using F = Frags<TM, TN>;
+    auto read_frags = [&](F& f, const char* buf) {
+#pragma unroll
+        for (int pc = 2; pc >= 0; --pc) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) f.a[pc][a] = *reinterpret_cast<const bf16x8*>(buf + a_rd + a * 32 * 96 + pc * 32);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) f.b[pc][b] = *reinterpret_cast<const bf16x8*>(buf + b_rd + b * 32 * 96 + pc * 32);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    char* s0 = lds;
+    char* s1 = lds + STAGE;
+    if (T > 0) {
+        issue(0, s0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // one stage: the next stage's tile is requested first (its buffer was last read a full stage ago), then this stage's
+        // fragments and products; the wait for the DMA and the barrier close the stage
+        auto stage = [&](int t, char* cur, char* nxt) {
+            if (t + 1 < T) issue(t + 1, nxt);
+            F f;
+            read_frags(f, cur);
+            products<TM, TN>(acc, f);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        int t = 0;
+        for (; t + 1 < T; t += 2) {
+            stage(t, s0, s1);
+            stage(t + 1, s1, s0);
+        }
+        if (t < T) stage(t, s0, s1);
+    }
+    store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
+                       p.accumulate, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// TN: C[m][n] = sum_k A[k][m] B[k][n], split over k
+// ---------------------------------------------------------------------------------------------------------------
+template <int WGS>
+__global__ void __launch_bounds__(256, WGS)
+gemm_p3_tn_kernel(const P3Gemm p) {
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+    constexpr int OP_BYTES = 16 * 768, STAGE = 2 * OP_BYTES;               // 16 k rows x 8 blocks x 96 bytes, per operand
+    constexpr int NI = OP_BYTES / 1024 / 4;                                // LDS-DMA instructions per wave, operand and stage
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nsegs = p.Nseg > 0 ? 2 : 1, seg_cols = p.Nseg > 0 ? p.Nseg : p.N;
+    const int seg_tiles = (seg_cols + BN - 1) / BN, tiles_n = nsegs * seg_tiles, tiles_m = (p.M + BM - 1) / BM;
+    const unsigned ntile = (unsigned)(tiles_m * tiles_n);
+    const unsigned lu = gte_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = (int)(lu / ntile);
+    const unsigned lb = lu % ntile;
+    const int tm = (int)(lb / (unsigned)tiles_n), tn = (int)(lb % (unsigned)tiles_n);
+    const int nseg = tn / seg_tiles;
+    const int m0 = tm * BM, n0 = (tn % seg_tiles) * BN;
+    const char* Am = (nseg && p.An2) ? p.An2 : p.A1;
+    const char* Bm = (nseg && p.Bn2) ? p.Bn2 : p.B;
+    const int lda = (int)((nseg && p.An2) ? p.ldan2 : p.lda1), ldb = (int)((nseg && p.Bn2) ? p.ldbn2 : p.ldb);
+
+    const int total_stages = (p.K + 15) / 16;
+    const int st_begin = split * p.stages_per_split;
+    const int st_end = min(total_stages, st_begin + p.stages_per_split);
+    const int coa = (m0 >> 4) * 96, cob = (n0 >> 4) * 96;
+
+    // slot s = 64 ii + lane of an operand's stage image: k row s / 48, position block (s % 48) / 6, part (s % 48) % 6; the
+    // position block jb of row k holds the tile's block (jb - 2 (k & 3)) mod 8
+    int voa[NI], vob[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int s = (i * 4 + wave) * 64 + lane, k = s / 48, w = s - k * 48, jb = w / 6, part = w - jb * 6;
+        const int fb = (jb - 2 * (k & 3)) & 7;
+        voa[i] = k * lda + fb * 96 + part * 16;
+        vob[i] = k * ldb + fb * 96 + part * 16;
+    }
+    auto issue = [&](int st, char* buf) {
+        const int k0 = st * 16;
+        const int rows = min(16, p.K - k0);
+        const __amdgpu_buffer_rsrc_t sa =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Am + (long long)k0 * lda + coa), 0, max(rows * lda - coa, 0), SRD_FLAGS);
+        const __amdgpu_buffer_rsrc_t sb =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Bm + (long long)k0 * ldb + cob), 0, max(rows * ldb - cob, 0), SRD_FLAGS);
+        static_for<NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            dma16(sa, buf + (i * 4 + wave) * 1024, voa[i]);
+        });
+        static_for<NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            dma16(sb, buf + OP_BYTES + (i * 4 + wave) * 1024, vob[i]);
+        });
+    };
+
+    // transposing fragment reads: lane 32 h + 16 g + 4 q + pp supplies the address of k row 8 h + q (+ 4 for the second read),
+    // columns 16 g + 4 pp .. + 3 of the 32-column block; lane i of a 16-lane group receives column i
+    const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+    int a_rd[TM], b_rd[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) a_rd[a] = (8 * h + q) * 768 + ((2 * (wm * TM + a) + g + 2 * q) & 7) * 96 + pp * 8;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) b_rd[b] = OP_BYTES + (8 * h + q) * 768 + ((2 * (wn * TN + b) + g + 2 * q) & 7) * 96 + pp * 8;
+    using F = Frags<TM, TN>;
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    auto tr_frag = [&](const char* at) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at + 4 * 768));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto read_frags = [&](F& f, const char* buf) {
+#pragma unroll
+        for (int pc = 2; pc >= 0; --pc) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) f.a[pc][a] = tr_frag(buf + a_rd[a] + pc * 32);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) f.b[pc][b] = tr_frag(buf + b_rd[b] + pc * 32);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    char* s0 = lds;
+    char* s1 = lds + STAGE;
+    if (st_begin < st_end) {
+        issue(st_begin, s0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        auto stage = [&](int st, char* cur, char* nxt) {
+            if (st + 1 < st_end) issue(st + 1, nxt);
+            F f;
+            read_frags(f, cur);
+            products<TM, TN>(acc, f);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        int st = st_begin;
+        for (; st + 1 < st_end; st += 2) {
+            stage(st, s0, s1);
+            stage(st + 1, s1, s0);
+        }
+        if (st < st_end) stage(st, s0, s1);
+    }
+    float* outp = p.splits > 1 ? p.slab + (long long)split * p.M * p.N : p.C;
+    const long long ldo = p.splits > 1 ? p.N : p.ldc;
+    const int cbase = nseg * seg_cols;
+    store_tile<TM, TN>(acc, outp, ldo, p.M, p.N, m0 + wm * TM * 32, cbase + n0 + wn * TN * 32, cbase + seg_cols, nullptr, 0,
+                       p.splits > 1 ? 0 : p.relu, p.splits > 1 ? 0 : p.accumulate, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 <-> P3
+// ---------------------------------------------------------------------------------------------------------------
+// dst (P3, [rows][cols]) element (r, c) = transpose ? src[c * ld + r] : src[r * ld + c].  One thread per half block (8 features).
+__global__ void __launch_bounds__(256)
+p3_from_f32_kernel(const float* __restrict__ src, long long ld, int rows, int cols, int transpose, char* __restrict__ dst,
+                   long long ldp) {
+    const int hb = (int)((cols + 7) / 8);                 // half blocks per row that hold data
+    const int hbt = (int)p3::blocks(cols) * 2;            // half blocks per row (the last may be all padding)
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)rows * hbt) return;
+    const int r = (int)(idx / hbt), j = (int)(idx - (long long)r * hbt);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = j * 8 + e;
+        x[e] = 0.f;
+        if (j < hb && c < cols) x[e] = transpose ? src[(long long)c * ld + r] : src[(long long)r * ld + c];
+    }
+    p3::store8(dst + (long long)r * ldp, j * 8, x);
+}
+
+__global__ void __launch_bounds__(256)
+p3_to_f32_kernel(const char* __restrict__ src, long long ldp, int rows, int cols, float* __restrict__ dst, long long ld) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)rows * cols) return;
+    const int r = (int)(idx / cols), c = (int)(idx - (long long)r * cols);
+    dst[(long long)r * ld + c] = p3::load1(src + (long long)r * ldp, c);
+}
+
+int tn_wgs() {
+    static const int v = getenv("GTE_P3_TN_WGS") ? atoi(getenv("GTE_P3_TN_WGS")) : 2;
+    return v == 3 ? 3 : 2;
+}
+int nt_wgs() {
+    static const int v = getenv("GTE_P3_NT_WGS") ? atoi(getenv("GTE_P3_NT_WGS")) : 3;
+    return v == 2 ? 2 : 3;
+}
+
+struct TnPlan { int splits, stages_per_split, splits_bound; };
+TnPlan tn_plan(int64_t M, int64_t N, int64_t Nseg, int64_t K) {
+    const int cus = gte::device_props().cus;
+    const int64_t tiles = gte::ceil_div(M, 128) * (Nseg > 0 ? 2 * gte::ceil_div(Nseg, 128) : gte::ceil_div(N, 128));
+    const int64_t stages = gte::ceil_div(K > 0 ? K : 1, 16);
+    // fill the resident slots exactly or stay below (a straggler round costs a whole unit time); >= 8 stages per split
+    int64_t splits = ((int64_t)tn_wgs() * cus) / tiles;
+    if (splits > stages / 8) splits = stages / 8;
+    if (splits < 1) splits = 1;
+    TnPlan pl;
+    pl.splits_bound = (int)splits;
+    pl.stages_per_split = (int)gte::ceil_div(stages, splits);
+    pl.splits = (int)gte::ceil_div(stages, pl.stages_per_split);
+    return pl;
+}
+
+#define GTE_SET_LDS(kernel, bytes) \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))
+
+}  // namespace
+
+extern "C" int64_t gte_p3_row_bytes(int64_t cols) { return cols > 0 ? p3::row_bytes(cols) : 0; }
+
+extern "C" int gte_p3_from_f32(const float* src, int64_t ld, int64_t rows, int64_t cols, int transpose, void* dst, int64_t ldp,
+                               void* stream) {
+    if (rows < 0 || cols < 0 || rows > INT32_MAX || cols > INT32_MAX) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_from_f32: bad sizes");
+    if (rows == 0 || cols == 0) return GTE_OK;
+    if (!src || !dst) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_from_f32: null pointer");
+    if (ld < (transpose ? rows : cols) || ldp < p3::row_bytes(cols) || ldp % 16 != 0 || (reinterpret_cast<uintptr_t>(dst) & 15))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_from_f32: leading dimension too small or image not 16-byte aligned");
+    const int64_t work = rows * p3::blocks(cols) * 2;
+    hipLaunchKernelGGL(p3_from_f32_kernel, dim3((unsigned)gte::ceil_div(work, 256)), dim3(256), 0, gte::as_stream(stream), src,
+                       (long long)ld, (int)rows, (int)cols, transpose ? 1 : 0, reinterpret_cast<char*>(dst), (long long)ldp);
+    return gte::check_launch("p3_from_f32");
+}
+
+extern "C" int gte_p3_to_f32(const void* src, int64_t ldp, int64_t rows, int64_t cols, float* dst, int64_t ld, void* stream) {
+    if (rows < 0 || cols < 0 || rows > INT32_MAX || cols > INT32_MAX) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_to_f32: bad sizes");
+    if (rows == 0 || cols == 0) return GTE_OK;
+    if (!src || !dst) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_to_f32: null pointer");
+    if (ld < cols || ldp < p3::row_bytes(cols)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_to_f32: leading dimension too small");
+    hipLaunchKernelGGL(p3_to_f32_kernel, dim3((unsigned)gte::ceil_div(rows * cols, 256)), dim3(256), 0, gte::as_stream(stream),
+                       reinterpret_cast<const char*>(src), (long long)ldp, (int)rows, (int)cols, dst, (long long)ld);
+    return gte::check_launch("p3_to_f32");
+}
+
+// C[m, n] (+)= [a1 | a2] b^T (+ bias): a1 = P3 [m][k1], a2 = P3 [m][k2] (nullable, k2 = 0), b = P3 [n][ceil16(k1) + k2]
+// (the K blocks of the second segment follow the ceil(k1 / 16) blocks of the first in every row of b)
+extern "C" int gte_gemm_p3_nt(const void* a1, int64_t lda1, int64_t k1, const void* a2, int64_t lda2, int64_t k2, const void* b,
+                              int64_t ldb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
+                              int relu, int accumulate, void* stream) {
+    if (m < 0 || n < 0 || k1 <= 0 || k2 < 0 || m > INT32_MAX || n > INT32_MAX || k1 + k2 > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt: bad sizes");
+    if (m == 0 || n == 0) return GTE_OK;
+    if (!a1 || !b || !c || (k2 > 0 && !a2)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt: null pointer");
+    const int64_t kb1 = p3::blocks(k1), kb2 = p3::blocks(k2);
+    if (lda1 < kb1 * 96 || (k2 > 0 && lda2 < kb2 * 96) || ldb < (kb1 + kb2) * 96 || ldc < n)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt: leading dimension too small");
+    if (lda1 >= (1 << 23) || lda2 >= (1 << 23) || ldb >= (1 << 23) || (m + 128) * ldc * 4 >= ((int64_t)1 << 31))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt: row strides must be < 8 MB and the output < 2 GB");
+    P3Gemm p = {};
+    p.A1 = (const char*)a1; p.lda1 = lda1; p.KB1 = (int)kb1;
+    p.A2 = k2 > 0 ? (const char*)a2 : nullptr; p.lda2 = lda2; p.KB2 = (int)kb2;
+    p.B = (const char*)b; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.bias_cols = (int)bias_cols;
+    p.M = (int)m; p.N = (int)n; p.relu = relu; p.accumulate = accumulate; p.splits = 1;
+    hipStream_t s = gte::as_stream(stream);
+    const int cus = gte::device_props().cus;
+    // 64-row tiles when 128-row tiles would leave the resident slots under-filled
+    const int64_t t128 = gte::ceil_div(m, 128) * gte::ceil_div(n, 128);
+    const bool small = t128 < (int64_t)2 * cus;
+    static bool configured = false;
+    if (!configured) {
+        GTE_SET_LDS((gemm_p3_nt_kernel<128, 128, 3>), 2 * 256 * 96);
+        GTE_SET_LDS((gemm_p3_nt_kernel<128, 128, 2>), 2 * 256 * 96);
+        GTE_SET_LDS((gemm_p3_nt_kernel<64, 128, 3>), 2 * 192 * 96);
+        configured = true;
+    }
+    if (small) {
+        const dim3 grid((unsigned)(gte::ceil_div(m, 64) * gte::ceil_div(n, 128)));
+        hipLaunchKernelGGL((gemm_p3_nt_kernel<64, 128, 3>), grid, dim3(256), 2 * 192 * 96, s, p);
+    } else {
+        const dim3 grid((unsigned)t128);
+        if (nt_wgs() == 3) hipLaunchKernelGGL((gemm_p3_nt_kernel<128, 128, 3>), grid, dim3(256), 2 * 256 * 96, s, p);
+        else hipLaunchKernelGGL((gemm_p3_nt_kernel<128, 128, 2>), grid, dim3(256), 2 * 256 * 96, s, p);
+    }
+    return gte::check_launch("gemm_p3_nt");
+}
+
+extern "C" int64_t gte_gemm_p3_tn_workspace_bytes(int64_t m, int64_t n, int64_t nseg, int64_t k) {
+    if (m <= 0 || n <= 0) return 256;
+    const TnPlan pl = tn_plan(m, n, nseg, k);
+    return pl.splits_bound > 1 ? gte::round_up((int64_t)pl.splits_bound * m * n * 4, 256) : 256;
+}
+
+// C[m, n] = a^T b over k rows: a = P3 [k][m], b = P3 [k][n].  nseg > 0: two column segments of nseg columns (n == 2 nseg),
+// C[:, 0:nseg] = a^T b, C[:, nseg:] = a2^T b2 (a2 / b2 nullable: the operand of segment 0).  The split-K fold joins an open
+// fold deferral (gte_fold_defer_begin), else it runs as its own launch.
+extern "C" int gte_gemm_p3_tn(const void* a, int64_t lda, const void* a2, int64_t lda2, const void* b, int64_t ldb, const void* b2,
+                              int64_t ldb2, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
+namespace {
+__global__ void __launch_bounds__(256)
+p3_fold_kernel(const float* __restrict__ slab, int splits, long long mn, int N, float* __restrict__ C, long long ldc) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mn) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slab[(long long)k * mn + i];
+    const long long r = i / N;
+    C[r * ldc + (i - r * N)] = s;
+}
+}  // namespace
+
+extern "C" int gte_gemm_p3_tn(const void* a, int64_t lda, const void* a2, int64_t lda2, const void* b, int64_t ldb, const void* b2,
+                              int64_t ldb2, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    if (m <= 0 || n <= 0 || k < 0 || nseg < 0 || m > INT32_MAX || n > INT32_MAX || k > INT32_MAX || (nseg > 0 && n != 2 * nseg))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_tn: bad sizes");
+    if (!a || !b || !c) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_tn: null pointer");
+    const int64_t bcols = nseg > 0 ? nseg : n;
+    if (lda < p3::row_bytes(m) || ldb < p3::row_bytes(bcols) || (a2 && lda2 < p3::row_bytes(m)) || (b2 && ldb2 < p3::row_bytes(bcols)) ||
+        ldc < n)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_tn: leading dimension too small");
+    if (lda >= (1 << 23) || ldb >= (1 << 23) || lda2 >= (1 << 23) || ldb2 >= (1 << 23) || (m + 128) * n * 4 >= ((int64_t)1 << 31) ||
+        (m + 128) * ldc * 4 >= ((int64_t)1 << 31))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_tn: row strides must be < 8 MB and the output < 2 GB");
+    hipStream_t s = gte::as_stream(stream);
+    if (k == 0) {
+        for (int64_t r = 0; r < m; ++r)
+            if (hipMemsetAsync(c + r * ldc, 0, (size_t)n * 4, s) != hipSuccess) return gte::fail(GTE_ERR_LAUNCH, "gemm_p3_tn: memset failed");
+        return GTE_OK;
+    }
+    const TnPlan pl = tn_plan(m, n, nseg, k);
+    P3Gemm p = {};
+    p.A1 = (const char*)a; p.lda1 = lda; p.An2 = (const char*)a2; p.ldan2 = lda2;
+    p.B = (const char*)b; p.ldb = ldb; p.Bn2 = (const char*)b2; p.ldbn2 = ldb2;
+    p.Nseg = (int)nseg; p.M = (int)m; p.N = (int)n; p.K = (int)k; p.C = c; p.ldc = ldc;
+    p.splits = pl.splits; p.stages_per_split = pl.stages_per_split;
+    if (pl.splits > 1) {
+        const int64_t need = (int64_t)pl.splits * m * n * 4;
+        if (!workspace || workspace_bytes < need)
+            return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "gemm_p3_tn: split-K needs %lld workspace bytes, got %lld", (long long)need,
+                             (long long)workspace_bytes);
+        p.slab = reinterpret_cast<float*>(workspace);
+    }
+    const int64_t tiles = gte::ceil_div(m, 128) * (nseg > 0 ? 2 * gte::ceil_div(nseg, 128) : gte::ceil_div(n, 128));
+    static bool configured = false;
+    if (!configured) {
+        GTE_SET_LDS((gemm_p3_tn_kernel<2>), 2 * 2 * 16 * 768);
+        GTE_SET_LDS((gemm_p3_tn_kernel<3>), 2 * 2 * 16 * 768);
+        configured = true;
+    }
+    const dim3 grid((unsigned)(tiles * pl.splits));
+    if (tn_wgs() == 3) hipLaunchKernelGGL((gemm_p3_tn_kernel<3>), grid, dim3(256), 2 * 2 * 16 * 768, s, p);
+    else hipLaunchKernelGGL((gemm_p3_tn_kernel<2>), grid, dim3(256), 2 * 2 * 16 * 768, s, p);
+    int rc = gte::check_launch("gemm_p3_tn");
+    if (rc != GTE_OK || pl.splits <= 1) return rc;
+    const int64_t mn = m * n;
+    if (gte::defer_fold(p.slab, mn, pl.splits, (int)m, (int)n, c, ldc)) return GTE_OK;
+    hipLaunchKernelGGL(p3_fold_kernel, dim3((unsigned)gte::ceil_div(mn, 256)), dim3(256), 0, s, p.slab, pl.splits, (long long)mn, (int)n,
+                       c, (long long)ldc);
+    return gte::check_launch("gemm_p3_tn fold");
+}

@@ -534,3 +534,78 @@ def set_gemm_mode(mode) -> int:
 
 def get_gemm_mode() -> int:
     return _lib.load().gte_gemm_get_mode()
+
+
+# --------------------------------------------------------------------------------------------------
+# P3 operands (three bf16 planes of an fp32 matrix, csrc/p3.h) and the planes GEMMs
+# --------------------------------------------------------------------------------------------------
+class P3:
+    """Device image of a logical fp32 matrix [rows][cols] in the P3 format: ``data`` is a uint8 tensor [rows_cap, ldp]."""
+    __slots__ = ("data", "rows", "cols")
+
+    def __init__(self, data: torch.Tensor, rows: int, cols: int):
+        self.data, self.rows, self.cols = data, rows, cols
+
+    @property
+    def ldp(self) -> int:
+        return self.data.stride(0)
+
+    @staticmethod
+    def empty(rows: int, cols: int, device, rows_cap: Optional[int] = None) -> "P3":
+        ldp = _lib.load().gte_p3_row_bytes(cols)
+        return P3(torch.empty((max(rows_cap or rows, 1), ldp), dtype=torch.uint8, device=device), rows, cols)
+
+    def view_rows(self, rows: int) -> "P3":
+        return P3(self.data, rows, self.cols)
+
+
+def p3_from_f32(src: torch.Tensor, transpose: bool = False, out: Optional[P3] = None, row0: int = 0) -> P3:
+    """P3 image of ``src`` ([rows][cols], or its transpose).  ``out``/``row0``: write rows [row0, row0 + rows) of an existing image
+    (how the weight arrangement [W_s ; W_n] of a transform-first layer is put together)."""
+    require_device(src, "p3_from_f32")
+    lib = _lib.load()
+    src = _row_major(src)
+    rows, cols = (src.shape[1], src.shape[0]) if transpose else src.shape
+    if out is None:
+        out = P3.empty(rows, cols, src.device)
+    check(lib.gte_p3_from_f32(ptr(src), _ld(src), rows, cols, int(transpose), out.data.data_ptr() + row0 * out.ldp, out.ldp,
+                              current_stream()), "gte_p3_from_f32")
+    return out
+
+
+def p3_to_f32(img: P3) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty((img.rows, img.cols), dtype=torch.float32, device=img.data.device)
+    check(lib.gte_p3_to_f32(ptr(img.data), img.ldp, img.rows, img.cols, ptr(out), max(img.cols, 1), current_stream()), "gte_p3_to_f32")
+    return out
+
+
+def gemm_p3_nt(a1: P3, b: P3, a2: Optional[P3] = None, bias: Optional[torch.Tensor] = None, bias_cols: int = 0,
+               out: Optional[torch.Tensor] = None, relu: bool = False, accumulate: bool = False) -> torch.Tensor:
+    """out[m, n] (+)= [a1 | a2] b^T (+ bias): gte_gemm_p3_nt"""
+    lib = _lib.load()
+    m, n = a1.rows, b.rows
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a1.data.device)
+    with _timed("gemm_nt", 2.0 * m * n * (a1.cols + (a2.cols if a2 is not None else 0))):
+        check(lib.gte_gemm_p3_nt(ptr(a1.data), a1.ldp, a1.cols, ptr(a2.data) if a2 is not None else None,
+                                 a2.ldp if a2 is not None else 0, a2.cols if a2 is not None else 0, ptr(b.data), b.ldp, ptr(bias),
+                                 bias_cols, ptr(out), _ld(out), m, n, int(relu), int(accumulate), current_stream()), "gte_gemm_p3_nt")
+    return out
+
+
+def gemm_p3_tn(a: P3, b: P3, a2: Optional[P3] = None, b2: Optional[P3] = None, two_segments: bool = False,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m, n] = a^T b over the rows (two_segments: out = [a^T b | a2^T b2], a2 / b2 default to a / b): gte_gemm_p3_tn"""
+    lib = _lib.load()
+    m, k = a.cols, a.rows
+    nseg = b.cols if two_segments else 0
+    n = 2 * b.cols if two_segments else b.cols
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.data.device)
+    ws = _workspace(lib.gte_gemm_p3_tn_workspace_bytes(m, n, nseg, k), a.data.device, "gemm_p3")
+    with _timed("gemm_tn", 2.0 * m * n * k):
+        check(lib.gte_gemm_p3_tn(ptr(a.data), a.ldp, ptr(a2.data) if a2 is not None else None, a2.ldp if a2 is not None else 0,
+                                 ptr(b.data), b.ldp, ptr(b2.data) if b2 is not None else None, b2.ldp if b2 is not None else 0,
+                                 nseg, ptr(out), _ld(out), m, n, k, ptr(ws), ws.numel(), current_stream()), "gte_gemm_p3_tn")
+    return out

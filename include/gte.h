@@ -263,6 +263,34 @@ int gte_gemm_get_mode(void);
  * without touching what other threads get.  gte_gemm_get_mode reports the mode the calling thread would run in. */
 int gte_gemm_set_thread_mode(int mode);
 
+/* ---- planes GEMMs (P3 operands) --------------------------------------------------------------------------------------
+ * The same transform GEMMs (models.py:63 nn.Linear and its autograd) on operands their PRODUCER has already cut into the
+ * three bf16 planes of the split mode (csrc/p3.h): the GEMM then moves bf16 planes memory -> LDS (LDS-DMA) and spends its
+ * issue slots on the six v_mfma_f32_32x32x16_bf16 products per fragment pair only.  Results are bit-identical to the split
+ * mode on the fp32 operand (same pieces, same products, same order).
+ * P3 image of a logical fp32 matrix [rows][cols]: row r at byte r * ldp (ldp >= gte_p3_row_bytes(cols), a multiple of 16; the
+ * image 16-byte aligned); 16-feature block fb at + 96 fb; in a block plane h (16 bf16), plane m, plane l; x = h + m + l
+ * exactly; features >= cols are zero.  "ldp*" arguments of this section are row strides in BYTES. */
+int64_t gte_p3_row_bytes(int64_t cols);
+/* dst(r, c) = transpose ? src[c * ld + r] : src[r * ld + c]  for r < rows, c < cols (ld in elements) */
+int gte_p3_from_f32(const float* src, int64_t ld, int64_t rows, int64_t cols, int transpose, void* dst, int64_t ldp,
+                    void* stream);
+int gte_p3_to_f32(const void* src, int64_t ldp, int64_t rows, int64_t cols, float* dst, int64_t ld, void* stream);
+/* c[m, n] (+)= [a1 | a2] b^T (+ bias on columns < bias_cols; <= 0: all), optional relu.  a1: P3 [m][k1]; a2: P3 [m][k2]
+ * (NULL, k2 = 0: one K segment); b: P3 [n][...] whose rows hold the ceil(k1 / 16) blocks of segment 1 followed by the blocks
+ * of segment 2.  replaces models.py:69-72 + :63 (forward; transform-first layers use b = [W_s ; W_n] as 2 out rows) and
+ * the dX product of its backward (a1 = dz, a2 = q, b = [W_s^T | W_n^T]). */
+int gte_gemm_p3_nt(const void* a1, int64_t ldpa1, int64_t k1, const void* a2, int64_t ldpa2, int64_t k2, const void* b,
+                   int64_t ldpb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n, int relu,
+                   int accumulate, void* stream);
+/* c[m, n] = a^T b over k rows (dW = dZ^T X; split over the rows, partial slabs in `workspace`, folded in a fixed order --
+ * inside an open fold deferral by gte_fold_defer_flush).  a: P3 [k][m], b: P3 [k][n].  nseg > 0: two column segments of
+ * nseg columns (n == 2 nseg): c[:, 0:nseg] = a^T b, c[:, nseg:] = a2^T b2 (a2 / b2 NULL: the operand of segment 0). */
+int64_t gte_gemm_p3_tn_workspace_bytes(int64_t m, int64_t n, int64_t nseg, int64_t k);
+int gte_gemm_p3_tn(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, const void* b, int64_t ldpb, const void* b2,
+                   int64_t ldpb2, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
 /* ---- deferred folds -------------------------------------------------------------------------------------------
  * Several entry points end with a small "sum the per-block partials" kernel (gte_ln_relu_bwd: column sums;
  * gte_sage_narrow_bwd: dW / dbias; split-K GEMMs behind gte_sage_linear_dw / gte_sage_qform_dw).  gte_gemm_f32 NEVER defers:
