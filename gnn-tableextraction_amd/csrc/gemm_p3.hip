@@ -49,6 +49,7 @@ struct P3Gemm {
     const char* A1; const char* A2; const char* B;       // P3 images (csrc/p3.h)
     const char* An2; const char* Bn2;                    // TN: operands of N segment 1 (nullptr: those of segment 0)
     long long lda1, lda2, ldb, ldan2, ldbn2;             // row strides in bytes
+    long long bsa1, bsa2, bsb, bsan2, bsbn2;             // block strides in bytes (96: row-major image; rows * 96: block-major image)
     int KB1, KB2;                                        // NT: 16-wide K blocks of the two A segments (B: KB1 + KB2 blocks per row)
     int M, N, K;                                         // TN: K = rows reduced over
     int Nseg;                                            // TN with two N segments: columns per segment (N == 2 Nseg)
@@ -124,19 +125,44 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM][TN], float* o
 // ---------------------------------------------------------------------------------------------------------------
 // NT: C[m][n] = sum_k A[m][k] B[n][k]
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGS>
-__global__ void __launch_bounds__(256, WGS)
-gemm_p3_nt_kernel(const P3Gemm p) {
-    constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int A_BYTES = BM * 96, B_BYTES = BN * 96, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INST = A_BYTES / 1024, B_INST = B_BYTES / 1024;        // 1 KiB LDS-DMA instructions per stage
-    constexpr int NIA = (A_INST + 3) / 4, NIB = (B_INST + 3) / 4;          // per wave
-    static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "tile rows");
-    extern __shared__ __attribute__((aligned(16))) char lds[];             // two stages
+// s_waitcnt vmcnt(N) lgkmcnt(0) + s_barrier, N a compile-time count of LDS-DMA instructions allowed to stay in flight
+template <int N>
+__device__ __forceinline__ void wait_dma_barrier() {
+    static_assert(N >= 0 && N <= 24, "vmcnt");
+#define GTE_W(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    GTE_W(1); GTE_W(2); GTE_W(3); GTE_W(4); GTE_W(5); GTE_W(6); GTE_W(7); GTE_W(8); GTE_W(9); GTE_W(10); GTE_W(11); GTE_W(12);
+    GTE_W(13); GTE_W(14); GTE_W(15); GTE_W(16); GTE_W(17); GTE_W(18); GTE_W(19); GTE_W(20); GTE_W(21); GTE_W(22); GTE_W(23); GTE_W(24);
+#undef GTE_W
+}
+
+#ifndef P3_ABL
+#define P3_ABL 0          // measurement builds only (profiles/micro/gemm_p3_abl.hip): 1 no DMA, 2 no barrier, 4 fragments read once,
+#endif                    // 8 no MFMA, 16 clock stamps into p.slab; results are wrong by construction when a bit is set
+
+// WM x WN waves (4 or 8), every wave TM x TN accumulator tiles of 32 x 32; block tile BM x BN = (32 TM WM) x (32 TN WN).
+// The stage images live in a ring of NBUF LDS buffers and the LDS-DMA of stage t + NBUF - 1 is requested at the start of
+// stage t: with NBUF = 3 two stages are in flight while one is multiplied, and the wait that closes a stage is COUNTED
+// (vmcnt = the instructions of the newest NBUF - 2 stages), never a drain.  Every wave issues the same number NI of DMA
+// instructions per stage (the image is padded to NI * waves KiB; the padding instructions are out of range of their
+// descriptor and move nothing), so the count is a compile-time constant.
+// What the tile size buys: a stage moves (BM + BN) * 96 bytes into LDS for BM * BN * 16 * 2 * 6 flop, i.e. at the full matrix
+// rate a CU has to take in 2048 (1 / BM + 1 / BN) bytes per cycle: 32 at 128 x 128, 18.7 at 192 x 256, 16 at 256 x 256.
+template <int WM, int WN, int TM, int TN, int NBUF, int WGS>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN * WGS + 3) / 4)
+gemm_p3_nt_ring_kernel(const P3Gemm p) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_INST = BM * 96 / 1024, B_INST = BN * 96 / 1024, N_INST = A_INST + B_INST;
+    constexpr int A_BYTES = BM * 96;
+    constexpr int NI = (N_INST + NW - 1) / NW;
+    constexpr int STAGE = NI * NW * 1024;
+    static_assert((BM * 96) % 1024 == 0 && (BN * 96) % 1024 == 0, "tile rows");
+    extern __shared__ __attribute__((aligned(16))) char lds[];             // NBUF stage images
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int tiles_n = (p.N + BN - 1) / BN;
     const unsigned lb = gte_xcd_remap(blockIdx.x, gridDim.x);
@@ -145,40 +171,38 @@ gemm_p3_nt_kernel(const P3Gemm p) {
     const int rowsA = min(BM, p.M - m0), rowsB = min(BN, p.N - n0);
 
     const int lda1 = (int)p.lda1, lda2 = (int)(p.A2 ? p.lda2 : p.lda1), ldb = (int)p.ldb;
-    const __amdgpu_buffer_rsrc_t srdA1 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A1 + (long long)m0 * p.lda1), 0, rowsA * lda1, SRD_FLAGS);
-    const __amdgpu_buffer_rsrc_t srdA2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(p.A2 ? p.A2 + (long long)m0 * p.lda2 : p.A1 + (long long)m0 * p.lda1), 0, rowsA * lda2, SRD_FLAGS);
-    const __amdgpu_buffer_rsrc_t srdB =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B + (long long)n0 * p.ldb), 0, rowsB * ldb, SRD_FLAGS);
+    const char* baseA1 = p.A1 + (long long)m0 * p.lda1;
+    const char* baseA2 = p.A2 ? p.A2 + (long long)m0 * p.lda2 : baseA1;
+    const char* baseB = p.B + (long long)n0 * p.ldb;
+    const long long bsa1 = p.bsa1, bsa2 = p.A2 ? p.bsa2 : p.bsa1, bsb = p.bsb;
 
-    // LDS-DMA slots: instruction ii of an operand fills bytes [1024 ii, 1024 ii + 1024) of its image; lane -> slot s = 64 ii + lane
-    // = (row s / 6, part s % 6), part = 2 plane + half; the source half is swapped in rows with bit 3 set
-    int voa1[NIA], voa2[NIA], vob[NIB];
+    // LDS-DMA slots: instruction ii of a stage fills bytes [1024 ii, 1024 ii + 1024) of the stage image (A rows, then B rows,
+    // then padding); lane -> slot s = 64 ii + lane = (row s / 6, part s % 6), part = 2 plane + half; the source half is swapped
+    // in rows with bit 3 set
+    constexpr int OOB = 0x7f000000;                  // a vector offset past every window (rows x stride < 2^30)
+    int vo1[NI], vo2[NI], isb[NI];
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) {
-        const int s = (i * 4 + wave) * 64 + lane, row = s / 6, part = s - row * 6, sp = part ^ ((row >> 3) & 1);
-        voa1[i] = row * lda1 + sp * 16;
-        voa2[i] = row * lda2 + sp * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < NIB; ++i) {
-        const int s = (i * 4 + wave) * 64 + lane, row = s / 6, part = s - row * 6, sp = part ^ ((row >> 3) & 1);
-        vob[i] = row * ldb + sp * 16;
+    for (int i = 0; i < NI; ++i) {
+        const int ii = i * NW + wave;
+        const bool b = ii >= A_INST;
+        const int s = (b ? ii - A_INST : ii) * 64 + lane, row = s / 6, part = s - row * 6, sp = part ^ ((row >> 3) & 1);
+        isb[i] = b ? 1 : 0;
+        vo1[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda1) + sp * 16;
+        vo2[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda2) + sp * 16;
     }
     const int KB1 = p.KB1, T = p.KB1 + p.KB2;
+    // the window of a stage: base moved to the stage's K block on the scalar unit, rows past the tile's valid rows (and every
+    // row of a stage past the end of K) out of range
     auto issue = [&](int t, char* buf) {
         const bool seg = t >= KB1;
-        const int soa = (seg ? t - KB1 : t) * 96, sob = t * 96;
-        const __amdgpu_buffer_rsrc_t sa = seg ? srdA2 : srdA1;
+        const int live = t < T ? 1 : 0;
+        const char* pa = seg ? baseA2 + (long long)(t - KB1) * bsa2 : baseA1 + (long long)t * bsa1;
+        const __amdgpu_buffer_rsrc_t sa =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, rowsA * (seg ? lda2 : lda1) * live, SRD_FLAGS);
+        const __amdgpu_buffer_rsrc_t sb =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
 #pragma unroll
-        for (int i = 0; i < NIA; ++i)
-            if (A_INST % 4 == 0 || i * 4 + wave < A_INST)
-                dma16(sa, buf + (i * 4 + wave) * 1024, (seg ? voa2[i] : voa1[i]) + soa);
-#pragma unroll
-        for (int i = 0; i < NIB; ++i)
-            if (B_INST % 4 == 0 || i * 4 + wave < B_INST)
-                dma16(srdB, buf + A_BYTES + (i * 4 + wave) * 1024, vob[i] + sob);
+        for (int i = 0; i < NI; ++i) dma16(isb[i] ? sb : sa, buf + (i * NW + wave) * 1024, seg ? vo2[i] : vo1[i]);
     };
 
     // fragment of plane pl, 32-row block blk: lane (r = lane & 31, h = lane >> 5) reads the 16 bytes (row r, k = 8 h .. 8 h + 7)
@@ -204,27 +228,54 @@ gemm_p3_nt_kernel(const P3Gemm p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    char* s0 = lds;
-    char* s1 = lds + STAGE;
-    if (T > 0) {
-        issue(0, s0);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        // one stage: the next stage's tile is requested first (its buffer was last read a full stage ago), then this stage's
-        // fragments and products; the wait for the DMA and the barrier close the stage
-        auto stage = [&](int t, char* cur, char* nxt) {
-            if (t + 1 < T) issue(t + 1, nxt);
-            F f;
-            read_frags(f, cur);
-            products<TM, TN>(acc, f);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        };
-        int t = 0;
-        for (; t + 1 < T; t += 2) {
-            stage(t, s0, s1);
-            stage(t + 1, s1, s0);
-        }
-        if (t < T) stage(t, s0, s1);
+    int next = 0, wr = 0;
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d) {
+        issue(next, lds + wr * STAGE);
+        ++next;
+        wr = wr + 1 == NBUF ? 0 : wr + 1;
     }
+    wait_dma_barrier<(NBUF - 2) * NI>();
+    int rd = 0;
+#if P3_ABL & 16
+    const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if P3_ABL & 4
+    F f;
+    read_frags(f, lds);
+#endif
+    for (int t = 0; t < T; ++t) {
+#if !(P3_ABL & 1)
+        issue(next, lds + wr * STAGE);
+#endif
+        ++next;
+        wr = wr + 1 == NBUF ? 0 : wr + 1;
+#if !(P3_ABL & 4)
+        F f;
+        read_frags(f, lds + rd * STAGE);
+#endif
+#if P3_ABL & 8
+        static_for<3>([&](auto P) {
+            static_for<TM>([&](auto A) { asm volatile("" ::"v"(f.a[decltype(P)::value][decltype(A)::value])); });
+            static_for<TN>([&](auto B) { asm volatile("" ::"v"(f.b[decltype(P)::value][decltype(B)::value])); });
+        });
+#else
+        products<TM, TN>(acc, f);
+#endif
+#if P3_ABL & 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+        wait_dma_barrier<(NBUF - 2) * NI>();
+#endif
+        rd = rd + 1 == NBUF ? 0 : rd + 1;
+    }
+#if P3_ABL & 16
+    if (tid == 0 && p.slab) {
+        long long* st = reinterpret_cast<long long*>(p.slab) + 2 * blockIdx.x;
+        st[0] = __builtin_amdgcn_s_memtime() - c0;
+        st[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+#endif
     store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
                        p.accumulate, lane);
 }
@@ -382,10 +433,6 @@ int tn_wgs() {
     static const int v = getenv("GTE_P3_TN_WGS") ? atoi(getenv("GTE_P3_TN_WGS")) : 2;
     return v == 3 ? 3 : 2;
 }
-int nt_wgs() {
-    static const int v = getenv("GTE_P3_NT_WGS") ? atoi(getenv("GTE_P3_NT_WGS")) : 3;
-    return v == 2 ? 2 : 3;
-}
 
 struct TnPlan { int splits, stages_per_split, splits_bound; };
 TnPlan tn_plan(int64_t M, int64_t N, int64_t Nseg, int64_t K) {
@@ -407,6 +454,8 @@ TnPlan tn_plan(int64_t M, int64_t N, int64_t Nseg, int64_t K) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))
 
 }  // namespace
+
+namespace { int launch_nt(const P3Gemm& p, hipStream_t s); }
 
 extern "C" int64_t gte_p3_row_bytes(int64_t cols) { return cols > 0 ? p3::row_bytes(cols) : 0; }
 
@@ -445,35 +494,64 @@ extern "C" int gte_gemm_p3_nt(const void* a1, int64_t lda1, int64_t k1, const vo
     const int64_t kb1 = p3::blocks(k1), kb2 = p3::blocks(k2);
     if (lda1 < kb1 * 96 || (k2 > 0 && lda2 < kb2 * 96) || ldb < (kb1 + kb2) * 96 || ldc < n)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt: leading dimension too small");
-    if (lda1 >= (1 << 23) || lda2 >= (1 << 23) || ldb >= (1 << 23) || (m + 128) * ldc * 4 >= ((int64_t)1 << 31))
-        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt: row strides must be < 8 MB and the output < 2 GB");
+    if (lda1 >= (1 << 22) || lda2 >= (1 << 22) || ldb >= (1 << 22) || (m + 256) * ldc * 4 >= ((int64_t)1 << 31))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt: row strides must be < 4 MB and the output < 2 GB");
     P3Gemm p = {};
     p.A1 = (const char*)a1; p.lda1 = lda1; p.KB1 = (int)kb1;
     p.A2 = k2 > 0 ? (const char*)a2 : nullptr; p.lda2 = lda2; p.KB2 = (int)kb2;
     p.B = (const char*)b; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.bias_cols = (int)bias_cols;
+    p.bsa1 = p.bsa2 = p.bsb = 96;
     p.M = (int)m; p.N = (int)n; p.relu = relu; p.accumulate = accumulate; p.splits = 1;
-    hipStream_t s = gte::as_stream(stream);
-    const int cus = gte::device_props().cus;
-    // 64-row tiles when 128-row tiles would leave the resident slots under-filled
-    const int64_t t128 = gte::ceil_div(m, 128) * gte::ceil_div(n, 128);
-    const bool small = t128 < (int64_t)2 * cus;
+    return launch_nt(p, gte::as_stream(stream));
+}
+
+namespace {
+// ring configurations: block tile and workgroups per CU
+struct NtCfg { int bm, bn, wgs; };
+constexpr NtCfg kNtCfg[] = {{256, 256, 1}, {192, 256, 1}, {128, 256, 1}, {128, 128, 2}, {128, 128, 3}, {64, 128, 3}};
+template <int WM, int WN, int TM, int TN, int NBUF, int WGS>
+void launch_ring(const P3Gemm& p, hipStream_t s) {
+    constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int NI = ((BM + BN) * 96 / 1024 + NW - 1) / NW, shm = NBUF * NI * NW * 1024;
     static bool configured = false;
     if (!configured) {
-        GTE_SET_LDS((gemm_p3_nt_kernel<128, 128, 3>), 2 * 256 * 96);
-        GTE_SET_LDS((gemm_p3_nt_kernel<128, 128, 2>), 2 * 256 * 96);
-        GTE_SET_LDS((gemm_p3_nt_kernel<64, 128, 3>), 2 * 192 * 96);
+        GTE_SET_LDS((gemm_p3_nt_ring_kernel<WM, WN, TM, TN, NBUF, WGS>), shm);
         configured = true;
     }
-    if (small) {
-        const dim3 grid((unsigned)(gte::ceil_div(m, 64) * gte::ceil_div(n, 128)));
-        hipLaunchKernelGGL((gemm_p3_nt_kernel<64, 128, 3>), grid, dim3(256), 2 * 192 * 96, s, p);
-    } else {
-        const dim3 grid((unsigned)t128);
-        if (nt_wgs() == 3) hipLaunchKernelGGL((gemm_p3_nt_kernel<128, 128, 3>), grid, dim3(256), 2 * 256 * 96, s, p);
-        else hipLaunchKernelGGL((gemm_p3_nt_kernel<128, 128, 2>), grid, dim3(256), 2 * 256 * 96, s, p);
+    const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
+    hipLaunchKernelGGL((gemm_p3_nt_ring_kernel<WM, WN, TM, TN, NBUF, WGS>), grid, dim3(NW * 64), shm, s, p);
+}
+int nt_choose(const P3Gemm& p) {
+    static const int forced = getenv("GTE_P3_NT_CFG") ? atoi(getenv("GTE_P3_NT_CFG")) : -1;
+    if (forced >= 0 && forced <= 5) return forced;
+    const int cus = gte::device_props().cus;
+    // per-CU time of a configuration ~ rounds x max(matrix time, load time) of a tile: matrix time ~ BM BN, load time ~ (BM + BN)
+    // at ~16 bytes / cycle / CU; rounds count workgroups per CU slot
+    double best = 1e30;
+    int bi = 3;
+    for (int i = 0; i < 4; ++i) {
+        const NtCfg c = kNtCfg[i];
+        if (p.N <= 128 && c.bn > 128) continue;
+        const int64_t tiles = gte::ceil_div(p.M, c.bm) * gte::ceil_div(p.N, c.bn);
+        const int64_t rounds = gte::ceil_div(tiles, (int64_t)cus * c.wgs);
+        const double mfma = (double)c.bm * c.bn * (16 * 2 * 6) / 4096.0, load = (c.bm + c.bn) * 96 / 16.0;
+        const double t = rounds * c.wgs * (mfma > load ? mfma : load) + 600.0 * rounds;
+        if (t < best) { best = t; bi = i; }
+    }
+    return bi;
+}
+int launch_nt(const P3Gemm& p, hipStream_t s) {
+    switch (nt_choose(p)) {
+        case 0: launch_ring<2, 4, 4, 2, 3, 1>(p, s); break;
+        case 1: launch_ring<2, 4, 3, 2, 3, 1>(p, s); break;
+        case 2: launch_ring<2, 4, 2, 2, 3, 1>(p, s); break;
+        case 3: launch_ring<2, 2, 2, 2, 3, 2>(p, s); break;
+        case 4: launch_ring<2, 2, 2, 2, 2, 3>(p, s); break;
+        default: launch_ring<2, 2, 1, 2, 2, 3>(p, s); break;
     }
     return gte::check_launch("gemm_p3_nt");
 }
+}  // namespace
 
 extern "C" int64_t gte_gemm_p3_tn_workspace_bytes(int64_t m, int64_t n, int64_t nseg, int64_t k) {
     if (m <= 0 || n <= 0) return 256;
