@@ -136,6 +136,11 @@ __device__ __forceinline__ void wait_dma_barrier() {
 #undef GTE_W
 }
 
+#ifndef P3_SCHED
+#define P3_SCHED 1        // 0: the compiler's own order inside a stage
+#endif
+#define GTE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_VALU = 0x002, SG_SALU = 0x004, SG_MFMA = 0x008, SG_VMEM_R = 0x020, SG_DS_R = 0x100, SG_DS_W = 0x200;
 #ifndef P3_ABL
 #define P3_ABL 0          // measurement builds only (profiles/micro/gemm_p3_abl.hip): 1 no DMA, 2 no barrier, 4 fragments read once,
 #endif                    // 8 no MFMA, 16 clock stamps into p.slab; results are wrong by construction when a bit is set
@@ -181,15 +186,15 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
     // in rows with bit 3 set
     constexpr int OOB = 0x7f000000;                  // a vector offset past every window (rows x stride < 2^30)
     int vo1[NI], vo2[NI], isb[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
+    static_for<NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
         const int ii = i * NW + wave;
         const bool b = ii >= A_INST;
         const int s = (b ? ii - A_INST : ii) * 64 + lane, row = s / 6, part = s - row * 6, sp = part ^ ((row >> 3) & 1);
         isb[i] = b ? 1 : 0;
         vo1[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda1) + sp * 16;
         vo2[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda2) + sp * 16;
-    }
+    });
     const int KB1 = p.KB1, T = p.KB1 + p.KB2;
     // the window of a stage: base moved to the stage's K block on the scalar unit, rows past the tile's valid rows (and every
     // row of a stage past the end of K) out of range
@@ -201,8 +206,10 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, rowsA * (seg ? lda2 : lda1) * live, SRD_FLAGS);
         const __amdgpu_buffer_rsrc_t sb =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) dma16(isb[i] ? sb : sa, buf + (i * NW + wave) * 1024, seg ? vo2[i] : vo1[i]);
+        static_for<NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            dma16(isb[i] ? sb : sa, buf + (i * NW + wave) * 1024, seg ? vo2[i] : vo1[i]);
+        });
     };
 
     // fragment of plane pl, 32-row block blk: lane (r = lane & 31, h = lane >> 5) reads the 16 bytes (row r, k = 8 h .. 8 h + 7)
@@ -211,13 +218,19 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
     const int b_rd = A_BYTES + (wn * TN * 32 + r) * 96 + hs;
     using F = Frags<TM, TN>;
     auto read_frags = [&](F& f, const char* buf) {
-#pragma unroll
-        for (int pc = 2; pc >= 0; --pc) {
-#pragma unroll
-            for (int a = 0; a < TM; ++a) f.a[pc][a] = *reinterpret_cast<const bf16x8*>(buf + a_rd + a * 32 * 96 + pc * 32);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) f.b[pc][b] = *reinterpret_cast<const bf16x8*>(buf + b_rd + b * 32 * 96 + pc * 32);
-        }
+        // in the order the products need them: (a_h, b_l), (a_l, b_h), (a_m, b_m)
+        static_for<3>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            constexpr int oa = g == 0 ? 0 : (g == 1 ? 2 : 1), ob = g == 0 ? 2 : (g == 1 ? 0 : 1);
+            static_for<TM>([&](auto A) {
+                constexpr int a = decltype(A)::value;
+                f.a[oa][a] = *reinterpret_cast<const bf16x8*>(buf + a_rd + a * 32 * 96 + oa * 32);
+            });
+            static_for<TN>([&](auto B) {
+                constexpr int b = decltype(B)::value;
+                f.b[ob][b] = *reinterpret_cast<const bf16x8*>(buf + b_rd + b * 32 * 96 + ob * 32);
+            });
+        });
     };
 
     f32x16 acc[TM][TN];
@@ -262,10 +275,27 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
 #else
         products<TM, TN>(acc, f);
 #endif
+#if P3_SCHED
+        // Issue order of a stage, pinned: the fragments of the first two products, then per product its TM x TN MFMAs with
+        // one LDS-DMA instruction of the next-but-one stage in front (a burst of NI DMA instructions at the head of the stage
+        // held the wave's issue port for several hundred cycles with the matrix pipe idle) and the third product's fragments
+        // behind the first product.
+        GTE_SGB(SG_DS_R, 2 * (TM + TN));
+        static_for<6>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            constexpr int ndma = (NI * (q + 1)) / 6 - (NI * q) / 6;
+            if constexpr (ndma > 0 && !(P3_ABL & 1)) GTE_SGB(SG_VMEM_R, ndma);
+            GTE_SGB(SG_MFMA, TM * TN);
+            if constexpr (q == 0) GTE_SGB(SG_DS_R, TM + TN);
+        });
+#endif
 #if P3_ABL & 2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
         wait_dma_barrier<(NBUF - 2) * NI>();
+#endif
+#if P3_SCHED
+        __builtin_amdgcn_sched_barrier(0);
 #endif
         rd = rd + 1 == NBUF ? 0 : rd + 1;
     }
@@ -276,6 +306,116 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
         st[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 #endif
+    store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
+                       p.accumulate, lane);
+}
+
+// NT with LOADER WAVES: WM x WN compute waves (fragment reads + MFMAs only) and NL loader waves that issue every LDS-DMA
+// instruction of the workgroup.  In the ring kernel above each wave spends ~NI x 60-100 issue cycles per stage on its DMA
+// instructions, in order, in front of its MFMAs: 21 of 97 us on the layer-0 forward (profiles/r03/gemm_p3.md, ablation "no
+// DMA").  A loader wave's stream is: request stage t + 2, wait until stage t + 1 has landed (counted vmcnt), barrier; a compute
+// wave's: 3 (TM + TN) fragment reads, 6 TM TN MFMAs, barrier.  One barrier per stage for all waves.
+template <int WM, int WN, int TM, int TN, int NL>
+__global__ void __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL + 3) / 4)
+gemm_p3_nt_lw_kernel(const P3Gemm p) {
+    constexpr int NW = WM * WN, NBUF = 3;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_INST = BM * 96 / 1024, B_INST = BN * 96 / 1024, N_INST = A_INST + B_INST;
+    constexpr int A_BYTES = BM * 96;
+    constexpr int NI = (N_INST + NL - 1) / NL;                             // DMA instructions per loader wave and stage
+    constexpr int STAGE = NI * NL * 1024;
+    extern __shared__ __attribute__((aligned(16))) char lds[];             // NBUF stage images
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const unsigned lb = gte_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = (int)(lb / (unsigned)tiles_n), tn = (int)(lb % (unsigned)tiles_n);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int T = p.KB1 + p.KB2;
+
+    if (wave >= NW) {
+        // ---------------- loader ----------------
+        const int lw = wave - NW;
+        const int rowsA = min(BM, p.M - m0), rowsB = min(BN, p.N - n0);
+        const int lda1 = (int)p.lda1, lda2 = (int)(p.A2 ? p.lda2 : p.lda1), ldb = (int)p.ldb;
+        const char* baseA1 = p.A1 + (long long)m0 * p.lda1;
+        const char* baseA2 = p.A2 ? p.A2 + (long long)m0 * p.lda2 : baseA1;
+        const char* baseB = p.B + (long long)n0 * p.ldb;
+        const long long bsa1 = p.bsa1, bsa2 = p.A2 ? p.bsa2 : p.bsa1, bsb = p.bsb;
+        constexpr int OOB = 0x7f000000;
+        int vo1[NI], vo2[NI], isb[NI];
+        static_for<NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int ii = i * NL + lw;
+            const bool b = ii >= A_INST;
+            const int s = (b ? ii - A_INST : ii) * 64 + lane, row = s / 6, part = s - row * 6, sp = part ^ ((row >> 3) & 1);
+            isb[i] = b ? 1 : 0;
+            vo1[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda1) + sp * 16;
+            vo2[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda2) + sp * 16;
+        });
+        const int KB1 = p.KB1;
+        auto issue = [&](int t, char* buf) {
+            const bool seg = t >= KB1;
+            const int live = t < T ? 1 : 0;
+            const char* pa = seg ? baseA2 + (long long)(t - KB1) * bsa2 : baseA1 + (long long)t * bsa1;
+            const __amdgpu_buffer_rsrc_t sa =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, rowsA * (seg ? lda2 : lda1) * live, SRD_FLAGS);
+            const __amdgpu_buffer_rsrc_t sb =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
+            static_for<NI>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                dma16(isb[i] ? sb : sa, buf + (i * NL + lw) * 1024, seg ? vo2[i] : vo1[i]);
+            });
+        };
+        issue(0, lds);
+        issue(1, lds + STAGE);
+        wait_dma_barrier<NI>();
+        int wr = 2;
+        for (int t = 0; t < T; ++t) {
+            issue(t + 2, lds + wr * STAGE);
+            wr = wr + 1 == NBUF ? 0 : wr + 1;
+            wait_dma_barrier<NI>();
+        }
+        return;
+    }
+    // ---------------- compute ----------------
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, hs = ((lane >> 5) ^ ((r >> 3) & 1)) * 16;
+    const int a_rd = (wm * TM * 32 + r) * 96 + hs;
+    const int b_rd = A_BYTES + (wn * TN * 32 + r) * 96 + hs;
+    using F = Frags<TM, TN>;
+    auto read_frags = [&](F& f, const char* buf) {
+        static_for<3>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            constexpr int oa = g == 0 ? 0 : (g == 1 ? 2 : 1), ob = g == 0 ? 2 : (g == 1 ? 0 : 1);
+            static_for<TM>([&](auto A) {
+                constexpr int a = decltype(A)::value;
+                f.a[oa][a] = *reinterpret_cast<const bf16x8*>(buf + a_rd + a * 32 * 96 + oa * 32);
+            });
+            static_for<TN>([&](auto B) {
+                constexpr int b = decltype(B)::value;
+                f.b[ob][b] = *reinterpret_cast<const bf16x8*>(buf + b_rd + b * 32 * 96 + ob * 32);
+            });
+        });
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    asm volatile("s_barrier" ::: "memory");
+    int rd = 0;
+    for (int t = 0; t < T; ++t) {
+        F f;
+        read_frags(f, lds + rd * STAGE);
+        products<TM, TN>(acc, f);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        rd = rd + 1 == NBUF ? 0 : rd + 1;
+    }
     store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
                        p.accumulate, lane);
 }
@@ -325,7 +465,7 @@ gemm_p3_tn_kernel(const P3Gemm p) {
     }
     auto issue = [&](int st, char* buf) {
         const int k0 = st * 16;
-        const int rows = min(16, p.K - k0);
+        const int rows = st < st_end ? min(16, p.K - k0) : 0;
         const __amdgpu_buffer_rsrc_t sa =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Am + (long long)k0 * lda + coa), 0, max(rows * lda - coa, 0), SRD_FLAGS);
         const __amdgpu_buffer_rsrc_t sb =
@@ -373,24 +513,26 @@ gemm_p3_tn_kernel(const P3Gemm p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    char* s0 = lds;
-    char* s1 = lds + STAGE;
-    if (st_begin < st_end) {
-        issue(st_begin, s0);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        auto stage = [&](int st, char* cur, char* nxt) {
-            if (st + 1 < st_end) issue(st + 1, nxt);
-            F f;
-            read_frags(f, cur);
-            products<TM, TN>(acc, f);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        };
-        int st = st_begin;
-        for (; st + 1 < st_end; st += 2) {
-            stage(st, s0, s1);
-            stage(st + 1, s1, s0);
-        }
-        if (st < st_end) stage(st, s0, s1);
+    // ring of NBUF stage images, two stages requested ahead, counted waits (as the NT kernel)
+    constexpr int NBUF = 3;
+    int next = st_begin, wr = 0;
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d) {
+        issue(next, lds + wr * STAGE);
+        ++next;
+        wr = wr + 1 == NBUF ? 0 : wr + 1;
+    }
+    wait_dma_barrier<(NBUF - 2) * 2 * NI>();
+    int rd = 0;
+    for (int st = st_begin; st < st_end; ++st) {
+        issue(next, lds + wr * STAGE);
+        ++next;
+        wr = wr + 1 == NBUF ? 0 : wr + 1;
+        F f;
+        read_frags(f, lds + rd * STAGE);
+        products<TM, TN>(acc, f);
+        wait_dma_barrier<(NBUF - 2) * 2 * NI>();
+        rd = rd + 1 == NBUF ? 0 : rd + 1;
     }
     float* outp = p.splits > 1 ? p.slab + (long long)split * p.M * p.N : p.C;
     const long long ldo = p.splits > 1 ? p.N : p.ldc;
@@ -506,9 +648,6 @@ extern "C" int gte_gemm_p3_nt(const void* a1, int64_t lda1, int64_t k1, const vo
 }
 
 namespace {
-// ring configurations: block tile and workgroups per CU
-struct NtCfg { int bm, bn, wgs; };
-constexpr NtCfg kNtCfg[] = {{256, 256, 1}, {192, 256, 1}, {128, 256, 1}, {128, 128, 2}, {128, 128, 3}, {64, 128, 3}};
 template <int WM, int WN, int TM, int TN, int NBUF, int WGS>
 void launch_ring(const P3Gemm& p, hipStream_t s) {
     constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
@@ -521,33 +660,50 @@ void launch_ring(const P3Gemm& p, hipStream_t s) {
     const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
     hipLaunchKernelGGL((gemm_p3_nt_ring_kernel<WM, WN, TM, TN, NBUF, WGS>), grid, dim3(NW * 64), shm, s, p);
 }
+template <int WM, int WN, int TM, int TN, int NL>
+void launch_lw(const P3Gemm& p, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int NI = ((BM + BN) * 96 / 1024 + NL - 1) / NL, shm = 3 * NI * NL * 1024;
+    static bool configured = false;
+    if (!configured) {
+        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL>), shm);
+        configured = true;
+    }
+    const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
+    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
+}
+// Configurations (measured on the step's shapes, profiles/r03/gemm_p3.md): the kernel runs at the chip's power limit
+// (~1.3 PF bf16 whatever the tile), so what matters is ONE balanced round of tiles: the row tile is the smallest of
+// 128 / 160 / 192 / 224 / 256 that covers M with at most one tile per CU; N is cut in 256-column tiles.
+struct NtCfg { int id, bm, bn, wgs; };
+constexpr NtCfg kNtCfg[] = {{0, 64, 128, 3}, {1, 128, 128, 2}, {2, 128, 256, 1}, {3, 160, 256, 1}, {4, 192, 256, 1}, {5, 224, 256, 1},
+                            {6, 256, 256, 1}};
 int nt_choose(const P3Gemm& p) {
     static const int forced = getenv("GTE_P3_NT_CFG") ? atoi(getenv("GTE_P3_NT_CFG")) : -1;
-    if (forced >= 0 && forced <= 5) return forced;
+    if (forced >= 0 && forced <= 6) return forced;
     const int cus = gte::device_props().cus;
-    // per-CU time of a configuration ~ rounds x max(matrix time, load time) of a tile: matrix time ~ BM BN, load time ~ (BM + BN)
-    // at ~16 bytes / cycle / CU; rounds count workgroups per CU slot
     double best = 1e30;
-    int bi = 3;
-    for (int i = 0; i < 4; ++i) {
-        const NtCfg c = kNtCfg[i];
+    int bi = 0;
+    for (const NtCfg& c : kNtCfg) {
         if (p.N <= 128 && c.bn > 128) continue;
         const int64_t tiles = gte::ceil_div(p.M, c.bm) * gte::ceil_div(p.N, c.bn);
         const int64_t rounds = gte::ceil_div(tiles, (int64_t)cus * c.wgs);
-        const double mfma = (double)c.bm * c.bn * (16 * 2 * 6) / 4096.0, load = (c.bm + c.bn) * 96 / 16.0;
-        const double t = rounds * c.wgs * (mfma > load ? mfma : load) + 600.0 * rounds;
-        if (t < best) { best = t; bi = i; }
+        // makespan in units of tile area; small tiles pay for their operand traffic (load-bound below ~128 x 256)
+        const double penalty = c.bm * c.bn >= 128 * 256 ? 1.0 : (c.bm * c.bn >= 128 * 128 ? 1.15 : 1.35);
+        const double t = (double)rounds * c.wgs * c.bm * c.bn * penalty;
+        if (t < best) { best = t; bi = c.id; }
     }
     return bi;
 }
 int launch_nt(const P3Gemm& p, hipStream_t s) {
     switch (nt_choose(p)) {
-        case 0: launch_ring<2, 4, 4, 2, 3, 1>(p, s); break;
-        case 1: launch_ring<2, 4, 3, 2, 3, 1>(p, s); break;
-        case 2: launch_ring<2, 4, 2, 2, 3, 1>(p, s); break;
-        case 3: launch_ring<2, 2, 2, 2, 3, 2>(p, s); break;
-        case 4: launch_ring<2, 2, 2, 2, 2, 3>(p, s); break;
-        default: launch_ring<2, 2, 1, 2, 2, 3>(p, s); break;
+        case 0: launch_ring<2, 2, 1, 2, 2, 3>(p, s); break;    //  64 x 128, three workgroups per CU
+        case 1: launch_ring<2, 2, 2, 2, 3, 2>(p, s); break;    // 128 x 128, two
+        case 2: launch_lw<2, 4, 2, 2, 4>(p, s); break;         // 128 x 256: 8 compute + 4 loader waves
+        case 3: launch_ring<1, 8, 5, 1, 3, 1>(p, s); break;    // 160 x 256: 1 x 8 waves of 160 x 32
+        case 4: launch_lw<2, 4, 3, 2, 4>(p, s); break;         // 192 x 256: 8 compute + 4 loader waves
+        case 5: launch_ring<1, 8, 7, 1, 3, 1>(p, s); break;    // 224 x 256
+        default: launch_ring<2, 4, 4, 2, 3, 1>(p, s); break;   // 256 x 256
     }
     return gte::check_launch("gemm_p3_nt");
 }
@@ -613,13 +769,13 @@ extern "C" int gte_gemm_p3_tn(const void* a, int64_t lda, const void* a2, int64_
     const int64_t tiles = gte::ceil_div(m, 128) * (nseg > 0 ? 2 * gte::ceil_div(nseg, 128) : gte::ceil_div(n, 128));
     static bool configured = false;
     if (!configured) {
-        GTE_SET_LDS((gemm_p3_tn_kernel<2>), 2 * 2 * 16 * 768);
-        GTE_SET_LDS((gemm_p3_tn_kernel<3>), 2 * 2 * 16 * 768);
+        GTE_SET_LDS((gemm_p3_tn_kernel<2>), 3 * 2 * 16 * 768);
+        GTE_SET_LDS((gemm_p3_tn_kernel<3>), 3 * 2 * 16 * 768);
         configured = true;
     }
     const dim3 grid((unsigned)(tiles * pl.splits));
-    if (tn_wgs() == 3) hipLaunchKernelGGL((gemm_p3_tn_kernel<3>), grid, dim3(256), 2 * 2 * 16 * 768, s, p);
-    else hipLaunchKernelGGL((gemm_p3_tn_kernel<2>), grid, dim3(256), 2 * 2 * 16 * 768, s, p);
+    if (tn_wgs() == 3) hipLaunchKernelGGL((gemm_p3_tn_kernel<2>), grid, dim3(256), 3 * 2 * 16 * 768, s, p);
+    else hipLaunchKernelGGL((gemm_p3_tn_kernel<2>), grid, dim3(256), 3 * 2 * 16 * 768, s, p);
     int rc = gte::check_launch("gemm_p3_tn");
     if (rc != GTE_OK || pl.splits <= 1) return rc;
     const int64_t mn = m * n;

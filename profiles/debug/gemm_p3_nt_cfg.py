@@ -6,8 +6,8 @@ ops = importlib.import_module("gnn-tableextraction_amd.ops")
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 cfg = os.environ.get("GTE_P3_NT_CFG", "auto")
-def timeit(fn, n=40):
-    for _ in range(8): fn()
+def timeit(fn, n=200):
+    for _ in range(2000): fn()          # ~0.2 s of back-to-back launches first: sustained clocks
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
