@@ -66,6 +66,14 @@ SIGNATURES = {
     "gte_p3_row_bytes": (c_int64, [c_int64]),
     "gte_p3_from_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "gte_p3_to_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_p3_from_f32_batch": (c_int, [c_void_p, c_int, c_void_p]),
+    "gte_spmm_csr_p3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "gte_spmm_csr_accumulate_ln_p3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                              c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p, c_int64,
+                                              c_void_p, c_void_p]),
+    "gte_ln_relu_bwd_p3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                   c_void_p, c_int64, c_void_p]),
     "gte_gemm_p3_nt": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "gte_gemm_p3_tn_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
@@ -136,6 +144,12 @@ SIGNATURES = {
                               c_float, c_float, c_int64, c_float, c_void_p]),
     "gte_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
+
+class P3Desc(ctypes.Structure):
+    """gte_p3_desc of include/gte.h"""
+    _fields_ = [("src", c_void_p), ("ld", c_int64), ("rows", c_int64), ("cols", c_int64), ("transpose", c_int),
+                ("dst", c_void_p), ("ldp", c_int64)]
+
 
 class BatchArrays(ctypes.Structure):
     """gte_batch_arrays of include/gte.h (one CSR direction of gte_batch_assemble)"""

@@ -563,6 +563,26 @@ p3_from_f32_kernel(const float* __restrict__ src, long long ld, int rows, int co
     p3::store8(dst + (long long)r * ldp, j * 8, x);
 }
 
+// several small matrices in one launch (the weight images of every layer after an optimiser step): blockIdx.y = matrix
+constexpr int kMaxP3Batch = 16;
+struct P3BatchArgs { gte_p3_desc d[kMaxP3Batch]; };
+__global__ void __launch_bounds__(256)
+p3_from_f32_batch_kernel(const P3BatchArgs a) {
+    const gte_p3_desc d = a.d[blockIdx.y];
+    const int hb = (int)((d.cols + 7) / 8), hbt = (int)p3::blocks(d.cols) * 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (long long)d.rows * hbt; idx += (long long)gridDim.x * 256) {
+        const int r = (int)(idx / hbt), j = (int)(idx - (long long)r * hbt);
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long long c = j * 8 + e;
+            x[e] = 0.f;
+            if (j < hb && c < d.cols) x[e] = d.transpose ? d.src[c * d.ld + r] : d.src[(long long)r * d.ld + c];
+        }
+        p3::store8(reinterpret_cast<char*>(d.dst) + (long long)r * d.ldp, j * 8, x);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 p3_to_f32_kernel(const char* __restrict__ src, long long ldp, int rows, int cols, float* __restrict__ dst, long long ld) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -612,6 +632,26 @@ extern "C" int gte_p3_from_f32(const float* src, int64_t ld, int64_t rows, int64
     hipLaunchKernelGGL(p3_from_f32_kernel, dim3((unsigned)gte::ceil_div(work, 256)), dim3(256), 0, gte::as_stream(stream), src,
                        (long long)ld, (int)rows, (int)cols, transpose ? 1 : 0, reinterpret_cast<char*>(dst), (long long)ldp);
     return gte::check_launch("p3_from_f32");
+}
+
+extern "C" int gte_p3_from_f32_batch(const gte_p3_desc* descs, int n, void* stream) {
+    if (n < 0 || n > kMaxP3Batch || (n > 0 && !descs)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_from_f32_batch: 0 <= n <= %d", kMaxP3Batch);
+    if (n == 0) return GTE_OK;
+    P3BatchArgs a;
+    int64_t work = 1;
+    for (int i = 0; i < n; ++i) {
+        const gte_p3_desc& d = descs[i];
+        if (!d.src || !d.dst || d.rows <= 0 || d.cols <= 0 || d.ld < (d.transpose ? d.rows : d.cols) || d.ldp < p3::row_bytes(d.cols) ||
+            d.ldp % 16 != 0 || (reinterpret_cast<uintptr_t>(d.dst) & 15))
+            return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_from_f32_batch: bad descriptor %d", i);
+        a.d[i] = d;
+        const int64_t w = d.rows * p3::blocks(d.cols) * 2;
+        if (w > work) work = w;
+    }
+    int64_t bx = gte::ceil_div(work, 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(p3_from_f32_batch_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, gte::as_stream(stream), a);
+    return gte::check_launch("p3_from_f32_batch");
 }
 
 extern "C" int gte_p3_to_f32(const void* src, int64_t ldp, int64_t rows, int64_t cols, float* dst, int64_t ld, void* stream) {

@@ -22,6 +22,7 @@
 //   Row-contiguous operands ([K][rows]) keep [BK][rows+4] images read with conflict-free ds_read_b32.
 //   blockIdx is remapped so that the tiles sharing an A row-panel run on one XCD (its L2 keeps it).
 #include "gte_common.h"
+#include "p3.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -683,7 +684,7 @@ bool needs_small_path(bool ak, bool bkc, const GemmParams& p) {
 }
 
 // GEMM arithmetic mode (gte_gemm_set_mode): process-wide -- autograd runs the backward GEMMs on another host thread.
-// -1 = not yet read from the environment (GTE_GEMM_MODE=split | bf16x3 selects the split mode, anything else fp32).
+// -1 = not yet read from the environment (GTE_GEMM_MODE=f32 selects the fp32 MFMA kernel, anything else the split mode).
 std::atomic<int> g_gemm_mode{-1};
 // per-thread override (gte_gemm_set_thread_mode): -1 = none.  Lets one caller (the GAT's bf16 configuration) run ITS GEMMs in
 // the split mode without changing what other threads / modules get.
@@ -692,8 +693,10 @@ int gemm_mode() {
     if (t_gemm_mode >= 0) return t_gemm_mode;
     int m = g_gemm_mode.load(std::memory_order_relaxed);
     if (m < 0) {
+        // default since round 3: the split mode (three exact bf16 pieces per operand: not narrower than fp32, error against fp64
+        // below the fp32 MFMA kernel's, every reference golden test green in it); GTE_GEMM_MODE=f32 selects the fp32 MFMA kernel
         const char* e = getenv("GTE_GEMM_MODE");
-        m = (e && (!strcmp(e, "split") || !strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? GTE_GEMM_SPLIT_BF16 : GTE_GEMM_F32;
+        m = (e && (!strcmp(e, "f32") || !strcmp(e, "fp32") || !strcmp(e, "0"))) ? GTE_GEMM_F32 : GTE_GEMM_SPLIT_BF16;
         g_gemm_mode.store(m, std::memory_order_relaxed);
     }
     return m;
@@ -1105,7 +1108,8 @@ template <int NV>
 __global__ void __launch_bounds__(256)
 ln_relu_bwd_vec_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ z, int64_t ldz,
                        const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-                       int relu, float* __restrict__ dz, int64_t lddz, float* __restrict__ partial, int M, int n) {
+                       int relu, float* __restrict__ dz, int64_t lddz, float* __restrict__ partial, int M, int n,
+                       char* __restrict__ dzp3 = nullptr, int64_t ldp3 = 0) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [4 waves][3][NV*256]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool has_ln = gamma != nullptr;
@@ -1180,6 +1184,8 @@ ln_relu_bwd_vec_kernel(const float* __restrict__ dy, int64_t lddy, const float* 
                     if (okv[v]) {
                         f4u o; o.x = d[0]; o.y = d[1]; o.z = d[2]; o.w = d[3];
                         *reinterpret_cast<f4u*>(dzr + 4 * (lane + 64 * v)) = o;
+                        // ... and as a P3 image: dz is the A operand of the dX and dW planes GEMMs
+                        if (dzp3) p3::store4(dzp3 + (int64_t)(row + u * stride) * ldp3, 4 * (lane + 64 * v), d[0], d[1], d[2], d[3]);
                     }
                 }
             } else {
@@ -1194,6 +1200,7 @@ ln_relu_bwd_vec_kernel(const float* __restrict__ dy, int64_t lddy, const float* 
                     if (okv[v]) {
                         f4u o; o.x = d[0]; o.y = d[1]; o.z = d[2]; o.w = d[3];
                         *reinterpret_cast<f4u*>(dzr + 4 * (lane + 64 * v)) = o;
+                        if (dzp3) p3::store4(dzp3 + (int64_t)(row + u * stride) * ldp3, 4 * (lane + 64 * v), d[0], d[1], d[2], d[3]);
                     }
                 }
             }
@@ -1726,10 +1733,10 @@ extern "C" int64_t gte_ln_relu_bwd_workspace_bytes(int64_t M, int64_t n_out) {
     return gte::round_up((int64_t)ln_bwd_blocks(M > 0 ? M : 1) * 3 * (n_out > 0 ? n_out : 1) * 4, 256);
 }
 
-extern "C" int gte_ln_relu_bwd(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* stats,
-                               const float* gamma, const float* beta, int relu, float* dz, int64_t lddz,
-                               float* dgamma, float* dbeta, float* dbias, int64_t M, int64_t n_out, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
+static int ln_relu_bwd_impl(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* stats,
+                            const float* gamma, const float* beta, int relu, float* dz, int64_t lddz,
+                            float* dgamma, float* dbeta, float* dbias, int64_t M, int64_t n_out, void* workspace,
+                            int64_t workspace_bytes, void* stream, char* dzp3, int64_t ldp3) {
     if (M < 0 || n_out <= 0 || M > INT32_MAX || n_out > INT32_MAX)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: bad sizes");
     if (M == 0) return GTE_OK;
@@ -1751,7 +1758,9 @@ extern "C" int gte_ln_relu_bwd(const float* dy, int64_t lddy, const float* z, in
                        zz, ldzz, stats, gamma, beta, relu, dz, lddz, part, (int)M, (int)n_out)
 #define GTE_LNV(NV)                                                                                                 \
     hipLaunchKernelGGL((ln_relu_bwd_vec_kernel<NV>), grid, block, (size_t)(4 * 3 * NV * 256) * sizeof(float), s, dy, lddy, \
-                       zz, ldzz, stats, gamma, beta, relu, dz, lddz, part, (int)M, (int)n_out)
+                       zz, ldzz, stats, gamma, beta, relu, dz, lddz, part, (int)M, (int)n_out, dzp3, ldp3)
+    if (dzp3 && !(n_out % 16 == 0 && n_out >= 128 && n_out <= 512 && ldp3 >= p3::row_bytes(n_out) && ldp3 % 16 == 0))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "ln_relu_bwd: the P3 image needs 128 <= n_out <= 512, n_out %% 16 == 0");
     if (n_out % 4 == 0 && n_out >= 128 && n_out <= 512) {              // 16-byte accesses
         if (n_out <= 256) GTE_LNV(1); else GTE_LNV(2);
     } else
@@ -1776,4 +1785,22 @@ extern "C" int gte_ln_relu_bwd(const float* dy, int64_t lddy, const float* z, in
         }
     }
     return gte::check_launch("ln_relu_bwd");
+}
+
+extern "C" int gte_ln_relu_bwd(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* stats,
+                               const float* gamma, const float* beta, int relu, float* dz, int64_t lddz,
+                               float* dgamma, float* dbeta, float* dbias, int64_t M, int64_t n_out, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    return ln_relu_bwd_impl(dy, lddy, z, ldz, stats, gamma, beta, relu, dz, lddz, dgamma, dbeta, dbias, M, n_out, workspace,
+                            workspace_bytes, stream, nullptr, 0);
+}
+
+// ... dz additionally as a P3 image (csrc/p3.h): the A operand of the layer's dX / dW planes GEMMs
+extern "C" int gte_ln_relu_bwd_p3(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* stats,
+                                  const float* gamma, const float* beta, int relu, float* dz, int64_t lddz, void* dzp3,
+                                  int64_t ldp3, float* dgamma, float* dbeta, float* dbias, int64_t M, int64_t n_out,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!dzp3) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd_p3: null image");
+    return ln_relu_bwd_impl(dy, lddy, z, ldz, stats, gamma, beta, relu, dz, lddz, dgamma, dbeta, dbias, M, n_out, workspace,
+                            workspace_bytes, stream, reinterpret_cast<char*>(dzp3), ldp3);
 }

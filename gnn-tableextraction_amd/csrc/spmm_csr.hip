@@ -22,8 +22,10 @@
 //   * blocks take contiguous row ranges and blockIdx is remapped so each XCD's L2 serves one
 //     contiguous 1/8 of the (reading-order) node range: neighbouring rows share sources.
 #include "gte_common.h"
+#include "p3.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -82,6 +84,7 @@ constexpr int kEdgeUnroll = 4;   // source rows in flight per lane group
 struct LnEpilogue {
     const float* gamma; const float* beta; float eps; int relu;
     float* y; int64_t ldy; float* stats;                 // stats[row] = mean, stats[n_rows + row] = rstd
+    char* yp3; int64_t ldyp3;                            // optional P3 image of y (csrc/p3.h) for the next layer's planes GEMM
 };
 
 template <int G>
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(256)
 spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                 const float* __restrict__ ew, const typename T::elem* __restrict__ x, int64_t ldx,
                 typename T::elem* __restrict__ out, int64_t ldo, int n_rows, int n_feat, int reduce,
-                int rows_per_block, const LnEpilogue ln = LnEpilogue{}) {
+                int rows_per_block, const LnEpilogue ln = LnEpilogue{}, char* __restrict__ outp3 = nullptr, int64_t ldp3 = 0) {
     using elem = typename T::elem;
     constexpr int EPC = T::EPC;
     constexpr int RPW = gte::kWave / G;                 // rows per wave per pass
@@ -203,7 +206,13 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
 #pragma unroll
                             for (int q = 0; q < EPC; ++q) o[q] = acc[j][q] * scale;
                         }
-                        T::store(orow + (int64_t)c * EPC, o);
+                        if constexpr (std::is_same<T, F32>::value && !ACCUM && !LNE) {
+                            // the result as a P3 image (the operand of a planes GEMM) instead of fp32
+                            if (outp3) p3::store4(outp3 + (int64_t)r * ldp3, c * 4, o[0], o[1], o[2], o[3]);
+                            else T::store(orow + (int64_t)c * EPC, o);
+                        } else {
+                            T::store(orow + (int64_t)c * EPC, o);
+                        }
                         if constexpr (LNE) {
 #pragma unroll
                             for (int q = 0; q < EPC; ++q) acc[j][q] = o[q];          // keep z for the epilogue
@@ -231,7 +240,10 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                             float v = fmaf((acc[0][q] - mean) * rstd, ln.gamma[col], ln.beta[col]);
                             yv[q] = ln.relu ? fmaxf(v, 0.f) : v;
                         }
-                        F32::store(ln.y + (int64_t)r * ln.ldy + (int64_t)li * EPC, yv);
+                        if (ln.y) F32::store(ln.y + (int64_t)r * ln.ldy + (int64_t)li * EPC, yv);
+                        if constexpr (EPC == 4) {
+                            if (ln.yp3) p3::store4(ln.yp3 + (int64_t)r * ln.ldyp3, li * 4, yv[0], yv[1], yv[2], yv[3]);
+                        }
                     }
                     if (li == 0 && ln.stats) { ln.stats[r] = mean; ln.stats[n_rows + r] = rstd; }
                 }
@@ -247,7 +259,8 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
 
 template <typename T, int G, int CPL, bool ACCUM>
 int launch_g(const int32_t* indptr, const int32_t* indices, const float* ew, const void* x, int64_t ldx,
-             void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, hipStream_t s) {
+             void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, hipStream_t s, char* outp3 = nullptr,
+             int64_t ldp3 = 0) {
     using elem = typename T::elem;
     constexpr int RPW = gte::kWave / G;
     // 4 waves x RPW rows x `passes` passes, contiguous.  A wave walks its passes one after the other, each a chain of
@@ -260,15 +273,17 @@ int launch_g(const int32_t* indptr, const int32_t* indices, const float* ew, con
     const int64_t nblocks = gte::ceil_div(n_rows, rows_per_block);
     dim3 grid((unsigned)nblocks), block(256);
     hipLaunchKernelGGL((spmm_csr_kernel<T, G, CPL, ACCUM>), grid, block, 0, s, indptr, indices, ew,
-                       (const elem*)x, ldx, (elem*)out, ldo, (int)n_rows, (int)n_feat, reduce, rows_per_block);
+                       (const elem*)x, ldx, (elem*)out, ldo, (int)n_rows, (int)n_feat, reduce, rows_per_block, LnEpilogue{}, outp3,
+                       ldp3);
     return gte::check_launch("spmm_csr");
 }
 
 template <typename T, bool ACCUM>
 int dispatch(const int32_t* indptr, const int32_t* indices, const float* ew, const void* x, int64_t ldx,
-             void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, hipStream_t s) {
+             void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, hipStream_t s, char* outp3 = nullptr,
+             int64_t ldp3 = 0) {
     const int64_t nchunk = n_feat / T::EPC;
-#define GTE_L(G, CPL) return launch_g<T, G, CPL, ACCUM>(indptr, indices, ew, x, ldx, out, ldo, n_rows, n_feat, reduce, s)
+#define GTE_L(G, CPL) return launch_g<T, G, CPL, ACCUM>(indptr, indices, ew, x, ldx, out, ldo, n_rows, n_feat, reduce, s, outp3, ldp3)
     if (nchunk <= 8 && T::EPC <= 8) {
         if (nchunk <= 4 && T::EPC == 4) GTE_L(4, 1);
         GTE_L(8, 1);
@@ -329,23 +344,41 @@ extern "C" int gte_spmm_csr_accumulate(const int32_t* indptr, const int32_t* ind
     return spmm_entry(true, indptr, indices, eweight, x, ldx, out, ldo, n_rows, n_feat, dtype, reduce, stream);
 }
 
+// out (P3 image, csrc/p3.h) = scale_v * sum w x[u]: the aggregation whose result only feeds planes GEMMs (q = A_w^T (norm dz), the
+// aggregated input of an aggregate-first layer).  n_feat % 4 == 0; columns up to the next multiple of 16 must be zero in the
+// image already or are written as zero here when n_feat % 16 != 0 is not supported: n_feat % 16 == 0 required.
+extern "C" int gte_spmm_csr_p3(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x, int64_t ldx,
+                               void* outp3, int64_t ldp, int64_t n_rows, int64_t n_feat, int reduce, void* stream) {
+    if (n_rows < 0 || n_feat <= 0 || n_rows > INT32_MAX || n_feat > INT32_MAX) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_p3: bad sizes");
+    if (n_feat % 16 != 0) return gte::fail(GTE_ERR_UNSUPPORTED, "spmm_csr_p3: n_feat must be a multiple of 16");
+    if (n_rows == 0) return GTE_OK;
+    if (!indptr || !x || !outp3) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_p3: null pointer");
+    if (ldx < n_feat || ldp < p3::row_bytes(n_feat) || ldp % 16 != 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_p3: leading dimension too small");
+    if (reduce != GTE_REDUCE_SUM && reduce != GTE_REDUCE_MEAN) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_p3: reduce must be 0 or 1");
+    // `out` of the fp32 path is unused when the image is written; pass x (never dereferenced for stores)
+    return dispatch<F32, false>(indptr, indices, eweight, x, ldx, const_cast<float*>(x), ldx, n_rows, n_feat, reduce,
+                                gte::as_stream(stream), reinterpret_cast<char*>(outp3), ldp);
+}
+
 extern "C" int gte_spmm_csr_accumulate_ln_supported(int64_t n_feat) {
     return (n_feat >= 4 && n_feat % 4 == 0 && n_feat <= 256) ? 1 : 0;
 }
 
-extern "C" int gte_spmm_csr_accumulate_ln(const int32_t* indptr, const int32_t* indices, const float* eweight,
-                                          const float* x, int64_t ldx, float* z, int64_t ldz, int64_t n_rows,
-                                          int64_t n_feat, int reduce, const float* gamma, const float* beta, float eps,
-                                          int relu, float* y, int64_t ldy, float* stats, void* stream) {
+static int accumulate_ln_impl(const int32_t* indptr, const int32_t* indices, const float* eweight,
+                              const float* x, int64_t ldx, float* z, int64_t ldz, int64_t n_rows,
+                              int64_t n_feat, int reduce, const float* gamma, const float* beta, float eps,
+                              int relu, float* y, int64_t ldy, float* stats, void* yp3, int64_t ldyp3, void* stream) {
     if (n_rows < 0 || n_rows > INT32_MAX) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: bad n_rows");
     if (!gte_spmm_csr_accumulate_ln_supported(n_feat))
         return gte::fail(GTE_ERR_UNSUPPORTED, "spmm_csr_accumulate_ln: needs n_feat %% 4 == 0 and n_feat <= 256");
     if (n_rows == 0) return GTE_OK;
-    if (!indptr || !x || !z || !gamma || !beta || !y) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: null pointer");
-    if (ldx < n_feat || ldz < n_feat || ldy < n_feat) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: ld < n_feat");
+    if (!indptr || !x || !z || !gamma || !beta || (!y && !yp3)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: null pointer");
+    if (ldx < n_feat || ldz < n_feat || (y && ldy < n_feat)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: ld < n_feat");
+    if (yp3 && (n_feat % 16 != 0 || ldyp3 < p3::row_bytes(n_feat) || ldyp3 % 16 != 0))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: the P3 image needs n_feat %% 16 == 0 and ldp >= 96 n_feat / 16");
     if (reduce != GTE_REDUCE_SUM && reduce != GTE_REDUCE_MEAN)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: reduce must be 0 (sum) or 1 (mean)");
-    const LnEpilogue ln = {gamma, beta, eps, relu, y, ldy, stats};
+    const LnEpilogue ln = {gamma, beta, eps, relu, y, ldy, stats, reinterpret_cast<char*>(yp3), ldyp3};
     hipStream_t s = gte::as_stream(stream);
     const int64_t nchunk = n_feat / 4;
 #define GTE_LN(G) return launch_ln<G>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, n_feat, reduce, ln, s)
@@ -355,4 +388,22 @@ extern "C" int gte_spmm_csr_accumulate_ln(const int32_t* indptr, const int32_t* 
     if (nchunk <= 32) GTE_LN(32);
     GTE_LN(64);
 #undef GTE_LN
+}
+
+extern "C" int gte_spmm_csr_accumulate_ln(const int32_t* indptr, const int32_t* indices, const float* eweight,
+                                          const float* x, int64_t ldx, float* z, int64_t ldz, int64_t n_rows,
+                                          int64_t n_feat, int reduce, const float* gamma, const float* beta, float eps,
+                                          int relu, float* y, int64_t ldy, float* stats, void* stream) {
+    if (!y) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: null pointer");
+    return accumulate_ln_impl(indptr, indices, eweight, x, ldx, z, ldz, n_rows, n_feat, reduce, gamma, beta, eps, relu, y, ldy, stats,
+                              nullptr, 0, stream);
+}
+
+// ... with y written as a P3 image (yp3; the operand of the next layer's planes GEMM) and / or as fp32 (y, nullable)
+extern "C" int gte_spmm_csr_accumulate_ln_p3(const int32_t* indptr, const int32_t* indices, const float* eweight,
+                                             const float* x, int64_t ldx, float* z, int64_t ldz, int64_t n_rows,
+                                             int64_t n_feat, int reduce, const float* gamma, const float* beta, float eps,
+                                             int relu, float* y, int64_t ldy, void* yp3, int64_t ldyp3, float* stats, void* stream) {
+    return accumulate_ln_impl(indptr, indices, eweight, x, ldx, z, ldz, n_rows, n_feat, reduce, gamma, beta, eps, relu, y, ldy, stats,
+                              yp3, ldyp3, stream);
 }

@@ -371,6 +371,7 @@ class ResidentPages:
         n = whole.num_nodes()
         self.n_pages, self.n_nodes = len(graphs), n
         self.feat = whole.ndata[feat_key].to(torch.float32).contiguous()
+        self.feat_p3, self.p3_mode = None, False
         lab = whole.ndata.get(label_key)
         self.label = None if lab is None else lab.to(torch.float32).reshape(-1, 1).contiguous()
         w = whole.edata.get(weight_key)
@@ -394,6 +395,19 @@ class ResidentPages:
             self._sets[name] = dict(edge_off=edge_off.to(torch.int32).contiguous(), edge_off_host=edge_off.cpu(),
                                     indices_loc=indices_loc, indptr_loc=indptr_loc,
                                     weight=None if wt is None else wt.contiguous())
+
+    def enable_p3(self) -> None:
+        """Keep the features as a P3 image (three bf16 planes per value, csrc/p3.h: the operand format of the planes GEMMs)
+        and assemble batches of image rows from now on: a batch then carries ``feat_p3`` instead of ``ndata['feat']``.
+        Called by the train loop when layer 0 of the step engine takes its input as an image."""
+        if self.feat_p3 is None:
+            from . import ops
+            self.feat_p3 = ops.p3_from_f32(self.feat)
+        self.p3_mode = True
+
+    def disable_p3(self) -> None:
+        """batches carry fp32 ``ndata['feat']`` again (the image stays cached for the next switch)"""
+        self.p3_mode = False
 
     def __len__(self):
         return self.n_pages
@@ -427,7 +441,8 @@ class ResidentPages:
                 "indptr": [i32(cap_nodes + 1), i32(cap_nodes + 1)], "indices": [i32(cap_in), i32(cap_out)],
                 "weight": [f32(max(int(cap_in), 1)) if self.weighted else None,
                            f32(max(int(cap_out), 1)) if self._sets["out"]["weight"] is not None else None],
-                "feat": f32(max(int(cap_nodes), 1), self.feat.shape[1]),
+                "feat": None if self.p3_mode else f32(max(int(cap_nodes), 1), self.feat.shape[1]),
+                "feat_p3": torch.empty((max(int(cap_nodes), 1), self.feat_p3.ldp), dtype=torch.uint8, device=dev) if self.p3_mode else None,
                 "label": None if self.label is None else f32(max(int(cap_nodes), 1), 1)}
 
     def assemble(self, meta_dev: torch.Tensor, nb: int, n_out: int, e_in: int, e_out: int, bufs: dict, n_sizes=None,
@@ -452,17 +467,28 @@ class ResidentPages:
             csrs.append(CSR(indptr, indices, None))
             weights.append(wout)
         f = self.feat.shape[1]
-        feat = bufs["feat"][:n_out]
+        p3 = bufs.get("feat_p3") is not None
         lab = None if self.label is None else bufs["label"][:n_out]
-        # ONE launch: features, labels, both CSRs and their weights (per-page contiguous runs, 16-byte accesses)
+        # ONE launch: features, labels, both CSRs and their weights (per-page contiguous runs, 16-byte accesses).  In image
+        # mode a feature row is the ldp bytes of its P3 image, moved as ldp / 4 words.
         import ctypes
+        if p3:
+            src, feat = self.feat_p3.data, bufs["feat_p3"]
+            fsrc, fld, fcols, fdst = P(src), src.stride(0) // 4, src.stride(0) // 4, P(feat)
+        else:
+            feat = bufs["feat"][:n_out]
+            fsrc, fld, fcols, fdst = P(self.feat), self.feat.stride(0), f, P(feat)
         _lib.check(lib.gte_batch_assemble(P(pages), nb, P(self.node_off), P(b_node), ctypes.addressof(descs[0]),
-                                          ctypes.addressof(descs[1]), P(self.feat), self.feat.stride(0), f, P(feat),
+                                          ctypes.addressof(descs[1]), fsrc, fld, fcols, fdst,
                                           P(self.label) or None, P(lab) or None, n_out, st), "gte_batch_assemble")
         g = ResidentBatch(n_out, e_in, csrs[0], csrs[1], weights[0], weights[1], self.device)
         if n_sizes is not None:
             g.batch_num_nodes_ = n_sizes.tolist() if hasattr(n_sizes, "tolist") else list(n_sizes)
-        g.ndata["feat"] = feat
+        if p3:
+            from . import ops
+            g.feat_p3 = ops.P3(feat, n_out, f)           # no ndata['feat']: a consumer that needs fp32 rows fails loudly
+        else:
+            g.ndata["feat"] = feat
         if lab is not None:
             g.ndata["label"] = lab.reshape(-1)
         if self.weighted:

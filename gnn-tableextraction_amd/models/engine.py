@@ -173,6 +173,10 @@ class FusedGcnSageStep(TrainStep):
         self.fuse_ln_fwd = os.environ.get("GTE_FUSE_LN_FWD", "1") == "1"
         self._head_scale = None
         self._tail_ws = None
+        # planes path (GTE_PLANES=0 disables): in the split-bf16 GEMM mode the operands of the transform GEMMs are written as P3
+        # images (three bf16 planes, csrc/p3.h) by their producers and multiplied by the planes GEMMs (csrc/gemm_p3.hip)
+        self.use_planes = os.environ.get("GTE_PLANES", "1") == "1"
+        self._wimg = {}                               # layer index -> (forward image, backward image or None)
         # called (once per step, no arguments) right before the LAST big kernel of a step is launched -- layer 0's dW GEMM,
         # MFMA-bound, ~a quarter of the step.  The train loop hangs the assembly of the NEXT batch here (models/loop.py):
         # it then runs on the side stream under that GEMM, and the batch is still in the Infinity Cache when the next
@@ -202,6 +206,18 @@ class FusedGcnSageStep(TrainStep):
              "tn": new(cap, dims[-1]), "q": new(cap, dims[-1]),       # narrow (class-count-wide) output layer
              "out3": new(3)}
         lib = self.lib
+        # planes layers: P3 images of the layer input (layer 0: only when the batch does not bring one), of dz and of q, and
+        # the split-K workspace of the dW planes GEMM
+        pl = [self._planes_layer(i, l, dims[i]) for i, l in enumerate(layers)]
+        b["pl"] = pl
+        b["hp"] = [ops.P3.empty(cap, dims[i], dev) if pl[i] else None for i in range(len(layers))]
+        b["dzp"] = [ops.P3.empty(cap, dims[i + 1], dev) if pl[i] else None for i in range(len(layers))]
+        b["qp"] = [ops.P3.empty(cap, dims[i + 1], dev) if pl[i] else None for i in range(len(layers))]
+        b["ws_p3"] = [torch.empty(int(lib.gte_gemm_p3_tn_workspace_bytes(dims[i + 1], 2 * dims[i], dims[i], cap)), dtype=torch.uint8,
+                                  device=dev) if pl[i] else None for i in range(len(layers))]
+        for i in range(len(layers)):
+            if pl[i] and b["t"][i] is None:
+                b["t"][i] = new(cap, 2 * dims[i + 1])
         # every workspace requirement grows with the node count, so the capacity's requirement covers any n <= cap
         ws = max([lib.gte_weighted_ce_workspace_bytes(cap)] +
                  [lib.gte_ln_relu_bwd_workspace_bytes(cap, d) for d in dims[1:]] +
@@ -236,26 +252,32 @@ class FusedGcnSageStep(TrainStep):
                 raise RuntimeError(f"captured batch buffers hold {full['cap']} nodes x {full['f0']} features; "
                                    f"asked for {n} x {f0} (a captured batch must not change)")
         else:
-            full = self._bufs.get(f0)
+            key = (f0, self._planes_on())              # the layer plan (which layers take P3 operands) depends on the GEMM mode
+            full = self._bufs.get(key)
             if full is None or full["cap"] < n:
                 cap = -(-int(n * 1.125) // 4096) * 4096
-                full = self._bufs[f0] = self._alloc(cap, f0)
+                self._bufs = {k: v for k, v in self._bufs.items() if k[0] != f0}     # one set per input width alive
+                full = self._bufs[key] = self._alloc(cap, f0)
         v = lambda t: None if t is None else t[:n]
         return {"ahn": [v(t) for t in full["ahn"]], "t": [v(t) for t in full["t"]], "z": [v(t) for t in full["z"]],
                 "stats": [None if t is None else t[:2 * n] for t in full["stats"]], "y": [v(t) for t in full["y"]],
                 "dy": [v(t) for t in full["dy"]], "dahn": v(full["dahn"]), "tn": v(full["tn"]), "q": v(full["q"]),
                 "out3": full["out3"], "ws": full["ws"], "ws_ln": full["ws_ln"], "ws_nar": full["ws_nar"],
                 "ce_part": full["ce_part"],
-                "ws_dw": full["ws_dw"]}
+                "ws_dw": full["ws_dw"], "pl": full["pl"], "ws_p3": full["ws_p3"],
+                "hp": [None if t is None else t.view_rows(n) for t in full["hp"]],
+                "dzp": [None if t is None else t.view_rows(n) for t in full["dzp"]],
+                "qp": [None if t is None else t.view_rows(n) for t in full["qp"]]}
 
     def reserve(self, n_nodes: int, f0: int) -> None:
         """Size the shared per-batch buffers for batches of up to ``n_nodes`` nodes now (the train loop knows the largest batch
         its page table can produce): no reallocation -- a device synchronisation plus ~12 KB per node of new buffers -- later,
         in the middle of an epoch."""
-        full = self._bufs.get(f0)
+        key = (f0, self._planes_on())
+        full = self._bufs.get(key)
         if n_nodes > 0 and (full is None or full["cap"] < n_nodes):
-            self._bufs[f0] = None                      # drop the old set first: both need not be alive at once
-            self._bufs[f0] = self._alloc(-(-int(n_nodes) // 4096) * 4096, f0)
+            self._bufs = {k: v for k, v in self._bufs.items() if k[0] != f0}    # drop the old set first: both need not be alive
+            self._bufs[key] = self._alloc(-(-int(n_nodes) // 4096) * 4096, f0)
 
     def _narrow(self, layer, fin: int) -> bool:
         return (not isinstance(layer.lynorm, nn.LayerNorm) and layer.activation is None and layer.linear.bias is not None
@@ -287,6 +309,58 @@ class FusedGcnSageStep(TrainStep):
             return False
         return self._transform_first(layer, fin) or (self.transform_first and i > 0 and layer.out_feats <= fin)
 
+    # -- planes path ---------------------------------------------------------------------------------
+    def _planes_on(self) -> bool:
+        return self.use_planes and self.transform_first and ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16
+
+    def _planes_layer(self, i: int, layer, fin: int, n: int = 0) -> bool:
+        """Layer i runs  t = h [W_s ; W_n]^T (planes GEMM),  z = t_self + b + mean-aggregate(t_neigh), LayerNorm, ReLU  with P3
+        operands: a LayerNorm layer that does not widen (the aggregation then moves out_feats <= fin columns), 16-aligned
+        widths the fused aggregation + LayerNorm kernel and the P3 LayerNorm backward cover."""
+        fout = layer.out_feats
+        return (self._planes_on() and isinstance(layer.lynorm, nn.LayerNorm) and layer.linear.bias is not None
+                and not self._narrow(layer, fin) and fin >= fout and fin >= 16 and fout % 16 == 0 and 128 <= fout <= 256
+                and bool(self.lib.gte_spmm_csr_accumulate_ln_supported(fout))
+                and not (n and ops.use_tiled(n, fout, None, fused_ln=True)))
+
+    def wants_p3_features(self, f0: int) -> bool:
+        """True when layer 0 takes its input as a P3 image: the train loop then keeps the resident features as images and
+        assembles batches of image rows (graph.ResidentPages.enable_p3)."""
+        L = self.model.layers[0]
+        return self._planes_layer(0, L, f0)
+
+    def _weight_images(self, dims):
+        """P3 images of the planes layers' weights: forward [W_s rows ; W_n rows] x fin, backward (dX) [fin rows] x [W_s^T | W_n^T].
+        ONE launch in front of every forward (the parameters change every step; the launch is part of a captured step)."""
+        layers = self.model.layers
+        descs = []
+        for i, L in enumerate(layers):
+            fin, fout = dims[i], L.out_feats
+            if not self._planes_layer(i, L, fin):
+                continue
+            img = self._wimg.get(i)
+            if img is None:
+                fwd = ops.P3.empty(2 * fout, fin, self.flat_param.device)
+                fwd.data.zero_()
+                bwd = None
+                if i > 0:
+                    bwd = ops.P3.empty(fin, 2 * fout, self.flat_param.device)
+                    bwd.data.zero_()
+                img = self._wimg[i] = (fwd, bwd)
+            fwd, bwd = img
+            W = L.linear.weight
+            wp, ld = W.data_ptr(), W.stride(0)
+            descs.append(_lib.P3Desc(wp, ld, fout, fin, 0, fwd.data.data_ptr(), fwd.ldp))
+            descs.append(_lib.P3Desc(wp + 4 * fin, ld, fout, fin, 0, fwd.data.data_ptr() + fout * fwd.ldp, fwd.ldp))
+            if bwd is not None:
+                descs.append(_lib.P3Desc(wp, ld, fin, fout, 1, bwd.data.data_ptr(), bwd.ldp))
+                descs.append(_lib.P3Desc(wp + 4 * fin, ld, fin, fout, 1, bwd.data.data_ptr() + (fout // 16) * 96, bwd.ldp))
+        st = _lib.current_stream()
+        for k in range(0, len(descs), 16):
+            chunk = descs[k:k + 16]
+            arr = (_lib.P3Desc * len(chunk))(*chunk)
+            _lib.check(self.lib.gte_p3_from_f32_batch(ctypes.addressof(arr), len(chunk), st), "gte_p3_from_f32_batch")
+
     # -- the schedule ----------------------------------------------------------------------------------
     def forward_backward(self, g, labels: torch.Tensor, grad_scale: float = 1.0, upto_layer: int = 0) -> torch.Tensor:
         """Forward, loss and the backward of layers n_layers-1 .. upto_layer (gradients of those layers final on return:
@@ -302,14 +376,24 @@ class FusedGcnSageStep(TrainStep):
         lib, P, check = self.lib, _lib.ptr, _lib.check
         st = _lib.current_stream()
         timed = ops._timed
-        x = ops._row_major(g.ndata['feat'])
-        _lib.require_device(x, "FusedGcnSageStep")
-        n, f0 = x.shape
+        xp = getattr(g, "feat_p3", None)              # resident batches in image mode bring the features as a P3 image only
+        if xp is not None:
+            x, n, f0 = None, xp.rows, xp.cols
+            if not self.wants_p3_features(f0):
+                raise _lib.GteError("the batch holds its features as a P3 image, but layer 0 of this step does not take one "
+                                    "(GEMM mode / GTE_PLANES changed after the resident pages were converted?)")
+        else:
+            x = ops._row_major(g.ndata['feat'])
+            _lib.require_device(x, "FusedGcnSageStep")
+            n, f0 = x.shape
         b = self._buffers(n, f0, self._private_key)
+        b["xp"] = xp
         layers = list(self.model.layers)
         ew = g.edata.get("feat")
         csr, rcsr = g.in_csr(), g.out_csr()
         w_in, w_out = g.in_weights(ew), g.out_weights(ew, True)
+        if forward and any(b["pl"]):
+            self._weight_images([f0] + [l.out_feats for l in layers])
         big = n * max(f0, max(l.out_feats for l in self.model.layers)) * 4 >= min(ops.TILED_FULL_MIN_BYTES, ops.TILED_MIN_BYTES)
         t_in, t_out = (g.in_tiles(), g.out_tiles()) if big else (None, None)
 
@@ -329,7 +413,7 @@ class FusedGcnSageStep(TrainStep):
                              reduce, st), "gte_spmm_csr")
         # scratch for the GEMM tail split (see gte_gemm_set_tail_workspace): registered for this launch sequence only
         if self._tail_ws is None:
-            self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=x.device)
+            self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=self.flat_param.device)
         check(lib.gte_gemm_set_tail_workspace(P(self._tail_ws) if self.tail_split else None,
                                               self._tail_ws.numel() if self.tail_split else 0), "gte_gemm_set_tail_workspace")
         try:
@@ -364,14 +448,44 @@ class FusedGcnSageStep(TrainStep):
         ws, wsn = P(b["ws"]), b["ws"].numel()
         # ---------------- forward ----------------
         h = x
+        b["hp_used"] = [None] * len(layers)
         fused_head = False
         pending_ln = None            # (layer, z, y, stats) of a LayerNorm left to the output layer's forward kernel
+        hp_in = None                 # P3 image of the current layer's input (set by the producer of h)
         for i, L in enumerate(layers):
-            fin, fout = h.shape[1], L.out_feats
+            fin, fout = (f0 if i == 0 else layers[i - 1].out_feats), L.out_feats
             W, bias = L.linear.weight, L.linear.bias
             ln = isinstance(L.lynorm, nn.LayerNorm)
             relu = L.activation is not None
             ahn, y = b["ahn"][i], b["y"][i]
+            if b["pl"][i]:
+                # ---- planes layer: t = h [W_s ; W_n]^T + [b | 0] (planes GEMM), then z = t_self + mean-aggregate(t_neigh),
+                # LayerNorm, ReLU in ONE pass that writes y as the next planes layer's input image (and / or fp32)
+                if hp_in is None:
+                    hp_in = b["xp"] if (i == 0 and b["xp"] is not None) else b["hp"][i]
+                    if not (i == 0 and b["xp"] is not None):
+                        check(lib.gte_p3_from_f32(P(h), ld(h), n, fin, 0, P(hp_in.data), hp_in.ldp, st), "gte_p3_from_f32")
+                b["hp_used"][i] = hp_in
+                wf = self._wimg[i][0]
+                t = b["t"][i]
+                with timed("gemm_nt", 4.0 * n * fin * fout) as tm:
+                    for _ in tm.repeat():
+                        check(lib.gte_gemm_p3_nt(P(hp_in.data), hp_in.ldp, fin, None, 0, 0, P(wf.data), wf.ldp, P(bias), fout, P(t),
+                                                 2 * fout, n, 2 * fout, 0, 0, st), "gte_gemm_p3_nt")
+                nxt_planes = i + 1 < len(layers) and b["pl"][i + 1]
+                yp = b["hp"][i + 1] if nxt_planes else None
+                with timed("spmm_csr", 3.0 * n * fout * 4 + 8.0 * csr.indices.numel() + 4.0 * (n + 1)):
+                    check(lib.gte_spmm_csr_accumulate_ln_p3(P(csr.indptr), P(csr.indices), P(w_in), P(t) + 4 * fout, 2 * fout, P(t),
+                                                            2 * fout, n, fout, _lib.REDUCE_MEAN, P(L.lynorm.weight),
+                                                            P(L.lynorm.bias), float(L.lynorm.eps), int(relu),
+                                                            None if nxt_planes else P(y), fout,
+                                                            P(yp.data) if yp is not None else None, yp.ldp if yp is not None else 0,
+                                                            P(b["stats"][i]), st), "gte_spmm_csr_accumulate_ln_p3")
+                h, hp_in = y, yp
+                continue
+            hp_in = None
+            if i > 0 and b["pl"][i - 1] and i < len(layers) and not b["pl"][i]:
+                pass                                     # the planes layer below wrote fp32 y for this layer
             if self._narrow(L, fin):
                 # class-count-wide layer: logits = h W_s^T + b + mean-aggregate(h W_n^T)  (aggregation on C columns)
                 with timed("narrow_fwd", 2.0 * n * fin * 4):
@@ -461,7 +575,7 @@ class FusedGcnSageStep(TrainStep):
         for i in range(hi, lo - 1, -1):
             L = layers[i]
             hin = x if i == 0 else b["y"][i - 1]
-            fin, fout = hin.shape[1], L.out_feats
+            fin, fout = (L.linear.weight.shape[1] // 2), L.out_feats
             W = L.linear.weight
             ln = isinstance(L.lynorm, nn.LayerNorm)
             relu = L.activation is not None
@@ -503,6 +617,33 @@ class FusedGcnSageStep(TrainStep):
                         check(lib.gte_sage_narrow_bwd(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,
                                                       P(dh), fin, P(gW), 2 * fin, P(gb), n, P(b["ws_nar"]),
                                                       b["ws_nar"].numel(), st), "gte_sage_narrow_bwd")
+                continue
+            if b["pl"][i]:
+                # ---- planes layer: dz (fp32 for the transpose aggregation + image), q = A_w^T (norm dz) as an image,
+                # dW = [dz^T h | q^T h] and dh = dz W_s + q W_n on the planes GEMMs
+                t, dzp, qp, hp = b["t"][i], b["dzp"][i], b["qp"][i], b["hp_used"][i]
+                if self._ln_done != i:
+                    check(lib.gte_ln_relu_bwd_p3(P(dy), fout, P(t), 2 * fout, P(b["stats"][i]), P(L.lynorm.weight),
+                                                 P(L.lynorm.bias), int(relu), P(dy), fout, P(dzp.data), dzp.ldp, P(gg), P(gbe), P(gb),
+                                                 n, fout, P(b["ws_ln"][i]), b["ws_ln"][i].numel(), st), "gte_ln_relu_bwd_p3")
+                else:
+                    check(lib.gte_p3_from_f32(P(dy), fout, n, fout, 0, P(dzp.data), dzp.ldp, st), "gte_p3_from_f32")
+                with timed("spmm_csr", 2.0 * n * fout * 4 + 8.0 * rcsr.indices.numel() + 4.0 * (n + 1)):
+                    check(lib.gte_spmm_csr_p3(P(rcsr.indptr), P(rcsr.indices), P(w_out), P(dy), fout, P(qp.data), qp.ldp, n, fout,
+                                              _lib.REDUCE_SUM, st), "gte_spmm_csr_p3")
+                if i == 0 and self.before_last_gemm is not None:
+                    self.before_last_gemm()
+                wsp = b["ws_p3"][i]
+                with timed("gemm_tn", 4.0 * n * fin * fout) as tm:
+                    for _ in tm.repeat():
+                        check(lib.gte_gemm_p3_tn(P(dzp.data), dzp.ldp, P(qp.data), qp.ldp, P(hp.data), hp.ldp, None, 0, fin, P(gW),
+                                                 2 * fin, fout, 2 * fin, n, P(wsp), wsp.numel(), st), "gte_gemm_p3_tn")
+                if i > 0:
+                    wb = self._wimg[i][1]
+                    with timed("gemm_nn", 4.0 * n * fin * fout) as tm:
+                        for _ in tm.repeat():
+                            check(lib.gte_gemm_p3_nt(P(dzp.data), dzp.ldp, fout, P(qp.data), qp.ldp, fout, P(wb.data), wb.ldp, None, 0,
+                                                     P(b["dy"][i - 1]), fin, n, fin, 0, 0, st), "gte_gemm_p3_nt dX")
                 continue
             tfirst, qform = self._transform_first(L, fin), self._qform(i, L, fin)
             zsrc = b["t"][i] if tfirst else (b["z"][i] if ln else b["y"][i])

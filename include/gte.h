@@ -248,13 +248,13 @@ int gte_gemm_set_tail_workspace(void* workspace, int64_t workspace_bytes);
 
 /* ---- GEMM arithmetic mode ------------------------------------------------------------------------------------------
  * How the fp32 transform GEMMs (every entry point of this section and gte_gemm_f32) multiply.  Process-wide.
- *   GTE_GEMM_F32        (default) v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA chains.
- *   GTE_GEMM_SPLIT_BF16 every fp32 operand is cut exactly into three bf16 pieces (24 significand bits) in the kernel and the
+ *   GTE_GEMM_F32        v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA chains.
+ *   GTE_GEMM_SPLIT_BF16 (default since round 3) every fp32 operand is cut exactly into three bf16 pieces (24 significand bits) in the kernel and the
  *                       product is six v_mfma_f32_32x32x16_bf16 partial products accumulated in fp32 (csrc/gemm_split.h):
  *                       fp32 in, fp32 out, error against fp64 not above the fp32 kernel's, 2.67x its matrix-pipe rate.
  *                       Tiles narrower than 128 columns and the small-shape path stay on the fp32 kernel.  Non-finite
  *                       operands give NaN where the fp32 kernel returns inf.
- * The environment variable GTE_GEMM_MODE=split selects the split mode before the first call; gte_gemm_set_mode overrides. */
+ * The environment variable GTE_GEMM_MODE=f32 selects the fp32 MFMA kernel before the first call; gte_gemm_set_mode overrides. */
 #define GTE_GEMM_F32 0
 #define GTE_GEMM_SPLIT_BF16 1
 int gte_gemm_set_mode(int mode);
@@ -276,6 +276,28 @@ int64_t gte_p3_row_bytes(int64_t cols);
 int gte_p3_from_f32(const float* src, int64_t ld, int64_t rows, int64_t cols, int transpose, void* dst, int64_t ldp,
                     void* stream);
 int gte_p3_to_f32(const void* src, int64_t ldp, int64_t rows, int64_t cols, float* dst, int64_t ld, void* stream);
+/* up to 16 of them in ONE launch (the weight images of every layer, after an optimiser step) */
+typedef struct gte_p3_desc {
+    const float* src; int64_t ld;      /* fp32 source, leading dimension in elements */
+    int64_t rows, cols;                /* of the IMAGE: dst(r, c) = transpose ? src[c * ld + r] : src[r * ld + c] */
+    int transpose;
+    void* dst; int64_t ldp;            /* image (first byte of its row 0 / column block 0), row stride in bytes */
+} gte_p3_desc;
+int gte_p3_from_f32_batch(const gte_p3_desc* descs, int n, void* stream);
+/* Producers that write their result as a P3 image: the aggregation (q = A_w^T (norm dz), aggregated inputs; n_feat % 16 == 0),
+ * the fused aggregation + LayerNorm(+ReLU) (y as image and / or fp32: either may be NULL) and the LayerNorm backward (dz as
+ * fp32 AND image: fp32 feeds the transpose aggregation, the image the dX / dW GEMMs).  Same arithmetic as their fp32
+ * forms (gte_spmm_csr, gte_spmm_csr_accumulate_ln, gte_ln_relu_bwd); the image holds exactly the fp32 values. */
+int gte_spmm_csr_p3(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x, int64_t ldx,
+                    void* outp3, int64_t ldp, int64_t n_rows, int64_t n_feat, int reduce, void* stream);
+int gte_spmm_csr_accumulate_ln_p3(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x,
+                                  int64_t ldx, float* z, int64_t ldz, int64_t n_rows, int64_t n_feat, int reduce,
+                                  const float* gamma, const float* beta, float eps, int relu, float* y, int64_t ldy,
+                                  void* yp3, int64_t ldyp3, float* stats, void* stream);
+int gte_ln_relu_bwd_p3(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* stats, const float* gamma,
+                       const float* beta, int relu, float* dz, int64_t lddz, void* dzp3, int64_t ldp3, float* dgamma,
+                       float* dbeta, float* dbias, int64_t M, int64_t n_out, void* workspace, int64_t workspace_bytes,
+                       void* stream);
 /* c[m, n] (+)= [a1 | a2] b^T (+ bias on columns < bias_cols; <= 0: all), optional relu.  a1: P3 [m][k1]; a2: P3 [m][k2]
  * (NULL, k2 = 0: one K segment); b: P3 [n][...] whose rows hold the ceil(k1 / 16) blocks of segment 1 followed by the blocks
  * of segment 2.  replaces models.py:69-72 + :63 (forward; transform-first layers use b = [W_s ; W_n] as 2 out rows) and
