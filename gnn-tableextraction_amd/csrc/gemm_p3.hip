@@ -423,17 +423,25 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
 // ---------------------------------------------------------------------------------------------------------------
 // TN: C[m][n] = sum_k A[k][m] B[k][n], split over k
 // ---------------------------------------------------------------------------------------------------------------
-template <int WGS>
-__global__ void __launch_bounds__(256, WGS)
+// WM x WN waves of 64 x 64 (TM = TN = 2): block tile (64 WM) x (64 WN).  4 x 2 waves (256 x 128, one workgroup per CU) take in
+// 23 bytes per cycle and CU at the full matrix rate against 32 for 2 x 2 (128 x 128, two workgroups per CU) at the same slab
+// bytes per CU: the operand tile of the 256-wide side is shared by eight waves.
+template <int WM, int WN, int WGS>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN * WGS + 3) / 4)
 gemm_p3_tn_kernel(const P3Gemm p) {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
-    constexpr int OP_BYTES = 16 * 768, STAGE = 2 * OP_BYTES;               // 16 k rows x 8 blocks x 96 bytes, per operand
-    constexpr int NI = OP_BYTES / 1024 / 4;                                // LDS-DMA instructions per wave, operand and stage
+    constexpr int NW = WM * WN, TM = 2, TN = 2;
+    constexpr int BM = WM * 64, BN = WN * 64, NBA = BM / 16, NBB = BN / 16;        // 16-feature blocks per k row
+    constexpr int RSA = NBA * 96, RSB = NBB * 96;                                  // k-row strides of the stage images
+    constexpr int A_BYTES = 16 * RSA, B_BYTES = 16 * RSB;
+    constexpr int A_INST = A_BYTES / 1024, B_INST = B_BYTES / 1024, N_INST = A_INST + B_INST;
+    constexpr int NI = (N_INST + NW - 1) / NW;                                     // LDS-DMA instructions per wave and stage
+    constexpr int STAGE = NI * NW * 1024;
+    static_assert((NBA & (NBA - 1)) == 0 && (NBB & (NBB - 1)) == 0 && NBA >= 8 && NBB >= 8, "blocks per row: a power of two >= 8");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int nsegs = p.Nseg > 0 ? 2 : 1, seg_cols = p.Nseg > 0 ? p.Nseg : p.N;
     const int seg_tiles = (seg_cols + BN - 1) / BN, tiles_n = nsegs * seg_tiles, tiles_m = (p.M + BM - 1) / BM;
@@ -453,16 +461,21 @@ gemm_p3_tn_kernel(const P3Gemm p) {
     const int st_end = min(total_stages, st_begin + p.stages_per_split);
     const int coa = (m0 >> 4) * 96, cob = (n0 >> 4) * 96;
 
-    // slot s = 64 ii + lane of an operand's stage image: k row s / 48, position block (s % 48) / 6, part (s % 48) % 6; the
-    // position block jb of row k holds the tile's block (jb - 2 (k & 3)) mod 8
-    int voa[NI], vob[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int s = (i * 4 + wave) * 64 + lane, k = s / 48, w = s - k * 48, jb = w / 6, part = w - jb * 6;
-        const int fb = (jb - 2 * (k & 3)) & 7;
-        voa[i] = k * lda + fb * 96 + part * 16;
-        vob[i] = k * ldb + fb * 96 + part * 16;
-    }
+    // instruction ii of a stage fills bytes [1024 ii, + 1024) of the stage image (A rows, B rows, padding).  Slot s of an
+    // operand's image: k row s / (6 NB), position block (s % (6 NB)) / 6, part s % 6; position block jb of row k holds the tile's
+    // block (jb - 2 (k & 3)) mod NB (the four k rows of a transposing read then fall on disjoint banks)
+    constexpr int OOB = 0x7f000000;
+    int vo[NI], isb[NI];
+    static_for<NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int ii = i * NW + wave;
+        const bool b = ii >= A_INST;
+        const int nb = b ? NBB : NBA;
+        const int s = (b ? ii - A_INST : ii) * 64 + lane, k = s / (6 * nb), w = s - k * (6 * nb), jb = w / 6, part = w - jb * 6;
+        const int fb = (jb - 2 * (k & 3)) & (nb - 1);
+        isb[i] = b ? 1 : 0;
+        vo[i] = ii >= N_INST ? OOB : k * (b ? ldb : lda) + fb * 96 + part * 16;
+    });
     auto issue = [&](int st, char* buf) {
         const int k0 = st * 16;
         const int rows = st < st_end ? min(16, p.K - k0) : 0;
@@ -472,11 +485,7 @@ gemm_p3_tn_kernel(const P3Gemm p) {
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Bm + (long long)k0 * ldb + cob), 0, max(rows * ldb - cob, 0), SRD_FLAGS);
         static_for<NI>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            dma16(sa, buf + (i * 4 + wave) * 1024, voa[i]);
-        });
-        static_for<NI>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            dma16(sb, buf + OP_BYTES + (i * 4 + wave) * 1024, vob[i]);
+            dma16(isb[i] ? sb : sa, buf + (i * NW + wave) * 1024, vo[i]);
         });
     };
 
@@ -485,23 +494,23 @@ gemm_p3_tn_kernel(const P3Gemm p) {
     const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
     int a_rd[TM], b_rd[TN];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) a_rd[a] = (8 * h + q) * 768 + ((2 * (wm * TM + a) + g + 2 * q) & 7) * 96 + pp * 8;
+    for (int a = 0; a < TM; ++a) a_rd[a] = (8 * h + q) * RSA + ((2 * (wm * TM + a) + g + 2 * q) & (NBA - 1)) * 96 + pp * 8;
 #pragma unroll
-    for (int b = 0; b < TN; ++b) b_rd[b] = OP_BYTES + (8 * h + q) * 768 + ((2 * (wn * TN + b) + g + 2 * q) & 7) * 96 + pp * 8;
+    for (int b = 0; b < TN; ++b) b_rd[b] = A_BYTES + (8 * h + q) * RSB + ((2 * (wn * TN + b) + g + 2 * q) & (NBB - 1)) * 96 + pp * 8;
     using F = Frags<TM, TN>;
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-    auto tr_frag = [&](const char* at) -> bf16x8 {
+    auto tr_frag = [&](const char* at, int rs4) -> bf16x8 {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at + 4 * 768));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at + rs4));
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     auto read_frags = [&](F& f, const char* buf) {
 #pragma unroll
         for (int pc = 2; pc >= 0; --pc) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) f.a[pc][a] = tr_frag(buf + a_rd[a] + pc * 32);
+            for (int a = 0; a < TM; ++a) f.a[pc][a] = tr_frag(buf + a_rd[a] + pc * 32, 4 * RSA);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) f.b[pc][b] = tr_frag(buf + b_rd[b] + pc * 32);
+            for (int b = 0; b < TN; ++b) f.b[pc][b] = tr_frag(buf + b_rd[b] + pc * 32, 4 * RSB);
         }
     };
 
@@ -522,7 +531,7 @@ gemm_p3_tn_kernel(const P3Gemm p) {
         ++next;
         wr = wr + 1 == NBUF ? 0 : wr + 1;
     }
-    wait_dma_barrier<(NBUF - 2) * 2 * NI>();
+    wait_dma_barrier<(NBUF - 2) * NI>();
     int rd = 0;
     for (int st = st_begin; st < st_end; ++st) {
         issue(next, lds + wr * STAGE);
@@ -531,7 +540,7 @@ gemm_p3_tn_kernel(const P3Gemm p) {
         F f;
         read_frags(f, lds + rd * STAGE);
         products<TM, TN>(acc, f);
-        wait_dma_barrier<(NBUF - 2) * 2 * NI>();
+        wait_dma_barrier<(NBUF - 2) * NI>();
         rd = rd + 1 == NBUF ? 0 : rd + 1;
     }
     float* outp = p.splits > 1 ? p.slab + (long long)split * p.M * p.N : p.C;
@@ -591,18 +600,22 @@ p3_to_f32_kernel(const char* __restrict__ src, long long ldp, int rows, int cols
     dst[(long long)r * ld + c] = p3::load1(src + (long long)r * ldp, c);
 }
 
-int tn_wgs() {
-    static const int v = getenv("GTE_P3_TN_WGS") ? atoi(getenv("GTE_P3_TN_WGS")) : 2;
-    return v == 3 ? 3 : 2;
+// TN tile: 128 x 128 (4 waves, two workgroups per CU).  The 256 x 128 tile (8 waves, one per CU; GTE_P3_TN_BIG=1) needs a
+// quarter less operand traffic per flop but measured slower on both dW shapes of the step (126 vs 115 us, 59 vs 55 us).
+int tn_big(int64_t M) {
+    static const int forced = getenv("GTE_P3_TN_BIG") ? atoi(getenv("GTE_P3_TN_BIG")) : 0;
+    return forced == 1 && M > 128 ? 1 : 0;
 }
 
 struct TnPlan { int splits, stages_per_split, splits_bound; };
 TnPlan tn_plan(int64_t M, int64_t N, int64_t Nseg, int64_t K) {
     const int cus = gte::device_props().cus;
-    const int64_t tiles = gte::ceil_div(M, 128) * (Nseg > 0 ? 2 * gte::ceil_div(Nseg, 128) : gte::ceil_div(N, 128));
+    const int big = tn_big(M);
+    const int64_t bm = big ? 256 : 128, slots = big ? cus : 2 * cus;
+    const int64_t tiles = gte::ceil_div(M, bm) * (Nseg > 0 ? 2 * gte::ceil_div(Nseg, 128) : gte::ceil_div(N, 128));
     const int64_t stages = gte::ceil_div(K > 0 ? K : 1, 16);
     // fill the resident slots exactly or stay below (a straggler round costs a whole unit time); >= 8 stages per split
-    int64_t splits = ((int64_t)tn_wgs() * cus) / tiles;
+    int64_t splits = slots / tiles;
     if (splits > stages / 8) splits = stages / 8;
     if (splits < 1) splits = 1;
     TnPlan pl;
@@ -806,16 +819,18 @@ extern "C" int gte_gemm_p3_tn(const void* a, int64_t lda, const void* a2, int64_
                              (long long)workspace_bytes);
         p.slab = reinterpret_cast<float*>(workspace);
     }
-    const int64_t tiles = gte::ceil_div(m, 128) * (nseg > 0 ? 2 * gte::ceil_div(nseg, 128) : gte::ceil_div(n, 128));
+    const int big = tn_big(m);
+    const int64_t tiles = gte::ceil_div(m, big ? 256 : 128) * (nseg > 0 ? 2 * gte::ceil_div(nseg, 128) : gte::ceil_div(n, 128));
+    constexpr int shm_big = 3 * 5 * 8 * 1024, shm_small = 3 * 6 * 4 * 1024;
     static bool configured = false;
     if (!configured) {
-        GTE_SET_LDS((gemm_p3_tn_kernel<2>), 3 * 2 * 16 * 768);
-        GTE_SET_LDS((gemm_p3_tn_kernel<3>), 3 * 2 * 16 * 768);
+        GTE_SET_LDS((gemm_p3_tn_kernel<4, 2, 1>), shm_big);
+        GTE_SET_LDS((gemm_p3_tn_kernel<2, 2, 2>), shm_small);
         configured = true;
     }
     const dim3 grid((unsigned)(tiles * pl.splits));
-    if (tn_wgs() == 3) hipLaunchKernelGGL((gemm_p3_tn_kernel<2>), grid, dim3(256), 3 * 2 * 16 * 768, s, p);
-    else hipLaunchKernelGGL((gemm_p3_tn_kernel<2>), grid, dim3(256), 3 * 2 * 16 * 768, s, p);
+    if (big) hipLaunchKernelGGL((gemm_p3_tn_kernel<4, 2, 1>), grid, dim3(512), shm_big, s, p);
+    else hipLaunchKernelGGL((gemm_p3_tn_kernel<2, 2, 2>), grid, dim3(256), shm_small, s, p);
     int rc = gte::check_launch("gemm_p3_tn");
     if (rc != GTE_OK || pl.splits <= 1) return rc;
     const int64_t mn = m * n;
