@@ -40,6 +40,16 @@ __device__ __forceinline__ int box_dist(const Box a, const Box b) {          // 
     return max(dx, dy);
 }
 
+// Does a box with pixels [lo, hi) own a projection slot inside [w0, w1)?  builder.py:386-394 files pixel hp under slot hp, pixels
+// >= extent under the LAST slot (`if hp >= width: hp = width - 1`) and -- Python indexing -- a negative pixel hp under slot
+// extent + hp.  For boxes wholly on the canvas this is the plain interval overlap.
+__device__ __forceinline__ bool projection_hits(int lo, int hi, int w0, int w1, int extent) {
+    const bool inside = max(max(lo, 0), w0) < min(min(hi, extent), w1);
+    const bool over = hi > max(lo, extent) && w0 <= extent - 1 && extent - 1 < w1;
+    const bool neg = lo < 0 && max(lo + extent, w0) < min(min(hi, 0) + extent, w1);
+    return inside || over || neg;
+}
+
 // does box b have a pixel column in [wx0, wx1) and a pixel row in [wy0, wy1) of node a's window of multiplier m?
 __device__ __forceinline__ bool in_window(const Box a, const Box b, int m, int width, int height) {
     const int w = a.x1 - a.x0, h = a.y1 - a.y0;
@@ -48,7 +58,7 @@ __device__ __forceinline__ bool in_window(const Box a, const Box b, int m, int w
     const int vo = w > h ? h * m : (h * m) >> 2;
     const int wx0 = max(a.x0 - ho, 0), wy0 = max(a.y0 - vo, 0);
     const int wx1 = min(max(a.x1 + ho, 0), width), wy1 = min(max(a.y1 + vo, 0), height);
-    return max(b.x0, wx0) < min(b.x1, wx1) && max(b.y0, wy0) < min(b.y1, wy1);
+    return projection_hits(b.x0, b.x1, wx0, wx1, width) && projection_hits(b.y0, b.y1, wy0, wy1, height);
 }
 
 __device__ __forceinline__ int enter_multiplier(const Box a, const Box b, int width, int height) {

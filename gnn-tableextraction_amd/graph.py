@@ -600,6 +600,14 @@ def knn_graph_from_boxes(bbox: torch.Tensor, node_off, page_size, k: int = 5, ma
     keep = torch.ones(n, dtype=torch.bool, device=dev)
     if range_island and labels is not None:
         lab32 = labels.to(dev).to(torch.int32).contiguous()
+        # fast_remove_islands asserts that a page has a non-TEXT node (builder.py:576: 'only text in graph'); without the check
+        # every node of such a page would be an island and the page would silently vanish
+        non_text = torch.zeros(n_pages, dtype=torch.int64, device=dev).index_add_(0, page_of_node.long(), (lab32 != int(text_label)).to(torch.int64))
+        empty_ok = torch.as_tensor(sizes).to(dev) == 0
+        bad = torch.nonzero((non_text == 0) & ~empty_ok).flatten()
+        if bad.numel():
+            raise ValueError(f"ERROR - only text in graph -> what to do? (page {int(bad[0])}: island removal needs a non-TEXT node; "
+                             f"builder.py:576 asserts the same)")
         sym = (indptr, indices) if bidirectional else csr_of(sel, True)[:2]
         island = torch.empty(n, dtype=torch.uint8, device=dev)
         ws = ops._workspace(2 * n + 256, dev, "island")

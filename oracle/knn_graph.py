@@ -20,7 +20,9 @@ equal (ties INSIDE the first k do not change the selected set).  ``tests/test_kn
 reference's own output (fixture written by oracle/make_aux_golden.py from the ast-extracted ``get_edges``): identical
 edges at every unambiguous node, identical selected DISTANCES at ambiguous ones.
 
-Boxes must lie on the canvas (0 <= x0 <= x1 <= width, same for y): the reference indexes a per-pixel list with them.
+Boxes that leave the canvas are kept the way the reference's per-pixel lists keep them (``projection_hits``): pixels past
+the right / bottom edge count for the last column / row, negative pixels wrap around (Python indexing; below -extent the
+reference raises IndexError -- not reproduced).
 """
 import numpy as np
 
@@ -49,8 +51,19 @@ def candidates(bboxs, i, m, width, height):
     """ids of the boxes with a pixel column in [x0, x1) and a pixel row in [y0, y1) of node i's window (builder.py:266-271)"""
     b = np.asarray(bboxs, dtype=np.int64)
     x0, y0, x1, y1 = window_of(b[i], m, width, height)
-    ok = (np.maximum(b[:, 0], x0) < np.minimum(b[:, 2], x1)) & (np.maximum(b[:, 1], y0) < np.minimum(b[:, 3], y1))
+    ok = projection_hits(b[:, 0], b[:, 2], x0, x1, width) & projection_hits(b[:, 1], b[:, 3], y0, y1, height)
     return np.nonzero(ok)[0]
+
+
+def projection_hits(lo, hi, w0, w1, extent):
+    """Does a box with pixels range(lo, hi) own a projection slot inside [w0, w1)?  builder.py:386-394 files pixel hp under
+    slot hp, pixels >= extent under the LAST slot (``if hp >= width: hp = width - 1``) and -- Python indexing -- a negative
+    pixel hp under slot extent + hp.  Boxes wholly on the canvas: the plain interval overlap."""
+    lo, hi = np.asarray(lo, dtype=np.int64), np.asarray(hi, dtype=np.int64)
+    inside = np.maximum(np.maximum(lo, 0), w0) < np.minimum(np.minimum(hi, extent), w1)
+    over = (hi > np.maximum(lo, extent)) & (w0 <= extent - 1) & (extent - 1 < w1)
+    neg = (lo < 0) & (np.maximum(lo + extent, w0) < np.minimum(np.minimum(hi, 0) + extent, w1))
+    return inside | over | neg
 
 
 def knn_select(bboxs, size, k, max_dist):
@@ -156,9 +169,53 @@ def fixture_pages(seed=7):
     return pages
 
 
+def big_fixture_pages(seed=23, sizes=(300, 700, 1500, 3000)):
+    """Pages at the workload's real sizes (LogNormal(200) words up to 2 000; here up to 3 000) on an A4 canvas
+    at 1/SCALE_FACTOR (1654 x 2339): the device kernels then run several workgroups per page (256 nodes each) and stage
+    thousands of boxes in LDS.  Word sizes shrink with the word count so the page fills without wrapping around."""
+    rng = np.random.default_rng(seed)
+    pages = []
+    for p, n in enumerate(sizes):
+        width, height = 1654, 2339
+        dense = n > 1000
+        boxes, x, y = [], 30, 40
+        lh = int(rng.integers(7, 11)) if dense else int(rng.integers(10, 22))
+        for _ in range(n):
+            w = int(rng.integers(6, 40)) if dense else int(rng.integers(12, 90))
+            if x + w > width - 30:
+                x = 30 + int(rng.integers(0, 25))
+                y += lh + (int(rng.integers(1, 6)) if dense else int(rng.integers(2, 40)))
+                lh = int(rng.integers(7, 11)) if dense else int(rng.integers(10, 22))
+            if y + lh > height - 20:
+                y = 40 + int(rng.integers(0, 9))                       # wrap: overlapping lines (scanned two-column pages do this)
+            boxes.append([x, y, x + w, y + lh])
+            x += w + (int(rng.integers(2, 14)) if dense else int(rng.integers(3, 40)))
+        b = np.asarray(boxes, dtype=np.int64)
+        if p % 2 == 1:
+            b[1] = b[0]
+            b[7, 2] = b[7, 0]
+        pages.append((b, (width, height), 5, 500))
+    return pages
+
+
+def out_of_canvas_page(seed=31):
+    """OCR boxes that leave the page: past the right and the bottom edge (clamped into the last projection slot by the
+    reference) and slightly negative (Python's negative indexing wraps them to the far side)."""
+    b, size, k, md = fixture_pages(seed)[3]
+    b = b.copy()
+    w, h = size
+    b[2, 2] = w + 25                      # sticks out to the right
+    b[4, [0, 2]] = [w + 5, w + 40]        # entirely to the right of the canvas
+    b[6, 3] = h + 12
+    b[9, [1, 3]] = [h + 3, h + 20]        # entirely below
+    b[0, 0] = -4                          # starts left of the canvas
+    b[11, 1] = -2
+    return (b, size, 5, 500)
+
+
 def write_reference_fixture(path):
     out = {}
-    pages = fixture_pages()
+    pages = fixture_pages() + big_fixture_pages() + [out_of_canvas_page()]
     for i, (b, size, k, max_dist) in enumerate(pages):
         u, v = reference_get_edges(b, size, k, max_dist)
         out[f"bbox{i}"], out[f"size{i}"] = b.astype(np.int32), np.asarray(size, dtype=np.int32)

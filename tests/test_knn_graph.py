@@ -258,3 +258,99 @@ def test_device_visibility_graph_equals_the_oracle_and_the_reference_fixture():
         np.testing.assert_array_equal(dst[m] - off[p], rd)
     with pytest.raises(ValueError):
         G.knn_graph_from_boxes(torch.zeros((1, 4), dtype=torch.int32).cuda(), [0, 1], [[10, 10]], mode="delaunay")
+
+
+# ---------------------------------------------------------------- real page sizes (pages up to 2 000 words)
+@pytest.mark.gpu
+def test_device_graphs_at_real_page_sizes_equal_the_oracle():
+    """Pages of 300 / 700 / 1 500 / 3 000 boxes in ONE call, both modes: several workgroups per page (256 nodes each, blockIdx.x
+    > 0) and thousands of boxes staged in LDS.  The k-NN graph equals the oracle bitwise (which equals the reference's own
+    edges on these very pages wherever the selection is unique: the fixture test above); the visibility graph equals the
+    reference's edge list exactly."""
+    import torch
+    from gnn_tableextraction_amd import graph as G
+    from oracle import box_geometry as bg
+    pages = kg.big_fixture_pages()
+    g, keep, off = _device_graph(pages)
+    assert bool(keep.all()) and max(len(p[0]) for p in pages) == 3000
+    src, dst = (t.cpu().numpy().astype(np.int64) for t in g.edges())
+    w = g.edata["feat"].cpu().numpy()
+    for p, (b, size, k, maxd) in enumerate(pages):
+        u, v = kg.to_simple_bidirected(*kg.knn_edges(b, size, k, maxd), len(b))
+        m = (dst >= off[p]) & (dst < off[p + 1])
+        np.testing.assert_array_equal(src[m] - off[p], u)
+        np.testing.assert_array_equal(dst[m] - off[p], v)
+        np.testing.assert_array_equal(w[m], bg.edge_weights(b, u, v))
+    # visibility: the reference's own (u, v) of the big pages of the fixture
+    big = [i for i in VPAGES if len(ZV[f"bbox{i}"]) >= 300]
+    assert [len(ZV[f"bbox{i}"]) for i in big] == [300, 700, 1500, 3000]
+    vp = [(ZV[f"bbox{i}"].astype(np.int64), tuple(int(x) for x in ZV[f"size{i}"])) for i in big]
+    boxes = np.concatenate([p[0] for p in vp]).astype(np.int32)
+    voff = np.concatenate([[0], np.cumsum([len(p[0]) for p in vp])])
+    gv, keepv = G.knn_graph_from_boxes(torch.from_numpy(boxes).cuda(), voff, np.array([p[1] for p in vp], dtype=np.int32),
+                                       max_dist=500, mode="visibility")
+    vs, vd = (t.cpu().numpy().astype(np.int64) for t in gv.edges())
+    for p, i in enumerate(big):
+        rs, rd = kg.to_simple_bidirected(ZV[f"u{i}"].astype(np.int64), ZV[f"v{i}"].astype(np.int64), len(vp[p][0]))
+        m = (vd >= voff[p]) & (vd < voff[p + 1])
+        np.testing.assert_array_equal(vs[m] - voff[p], rs)
+        np.testing.assert_array_equal(vd[m] - voff[p], rd)
+
+
+@pytest.mark.gpu
+def test_device_island_mask_on_a_2000_node_page():
+    """gte_island_mask on a 2 000-word page (8 workgroups of nodes, khop 1..3) against the oracle's exact-k-step reachability."""
+    import torch
+    from gnn_tableextraction_amd import graph as G
+    (b, size, k, maxd), = kg.big_fixture_pages(seed=41, sizes=(2000,))
+    rng = np.random.default_rng(1)
+    labels = np.where(rng.random(len(b)) < 0.02, 5, 1).astype(np.int64)           # 2 % FIGURE words among TEXT
+    u, v = kg.to_simple_bidirected(*kg.knn_edges(b, size, k, maxd), len(b))
+    for khop in (1, 2, 3):
+        g, keep = G.knn_graph_from_boxes(torch.from_numpy(b.astype(np.int32)).cuda(), [0, len(b)], [list(size)], k=k, max_dist=maxd,
+                                         labels=torch.from_numpy(labels), range_island=khop)
+        isl = kg.island_nodes(u, v, labels, len(b), khop=khop)
+        want = np.ones(len(b), bool)
+        want[isl] = False
+        np.testing.assert_array_equal(keep.cpu().numpy(), want)
+        assert 0 < len(isl) < len(b)
+        assert g.num_nodes() == int(want.sum())
+
+
+@pytest.mark.gpu
+def test_a_page_over_the_lds_limit_is_refused_and_an_only_text_page_raises():
+    import torch
+    from gnn_tableextraction_amd import _lib
+    from gnn_tableextraction_amd import graph as G
+    lim = _lib.load().gte_knn_max_page_nodes()
+    assert lim == 4096
+    rng = np.random.default_rng(0)
+    n = lim + 1
+    x0, y0 = rng.integers(0, 1500, n), rng.integers(0, 2200, n)
+    b = np.stack([x0, y0, x0 + rng.integers(1, 40, n), y0 + rng.integers(1, 12, n)], 1).astype(np.int32)
+    for mode in ("knn", "visibility"):
+        with pytest.raises(_lib.GteError, match="(?i)unsupported|4096|page"):
+            G.knn_graph_from_boxes(torch.from_numpy(b).cuda(), [0, n], [[1654, 2339]], mode=mode)
+        G.knn_graph_from_boxes(torch.from_numpy(b[:lim]).cuda(), [0, lim], [[1654, 2339]], mode=mode)      # 4 096 boxes fit
+    # fast_remove_islands asserts 'only text in graph' (builder.py:576)
+    pages = kg.fixture_pages(seed=5)[:2]
+    boxes = np.concatenate([p[0] for p in pages]).astype(np.int32)
+    off = [0, len(pages[0][0]), len(boxes)]
+    labels = np.ones(len(boxes), dtype=np.int64)
+    labels[3] = 5                                                     # page 0 has a FIGURE word, page 1 is text only
+    with pytest.raises(ValueError, match="only text"):
+        G.knn_graph_from_boxes(torch.from_numpy(boxes).cuda(), off, np.array([p[1] for p in pages], dtype=np.int32),
+                               labels=torch.from_numpy(labels), range_island=2)
+
+
+@pytest.mark.gpu
+def test_device_knn_graph_with_boxes_off_the_canvas_equals_the_reference():
+    """boxes past the right / bottom edge and slightly negative ones (fixture's last page): the reference files their pixels
+    under the last projection slot / wraps them around; device == oracle bitwise, == the reference where unambiguous (above)."""
+    b, size, k, maxd = kg.out_of_canvas_page()
+    g, keep, off = _device_graph([(b, size, k, maxd)])
+    src, dst = (t.cpu().numpy().astype(np.int64) for t in g.edges())
+    u, v = kg.to_simple_bidirected(*kg.knn_edges(b, size, k, maxd), len(b))
+    np.testing.assert_array_equal(src, u)
+    np.testing.assert_array_equal(dst, v)
+    assert (b[:, 2] > size[0]).any() and (b[:, 0] < 0).any()
