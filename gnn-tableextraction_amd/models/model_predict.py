@@ -51,6 +51,75 @@ def per_class_prf(y_true: np.ndarray, y_pred: np.ndarray, n_classes: int):
     return p, r, f1, conf
 
 
+# ---- one forward per page without the per-page launch bill ------------------------------------------------------------
+# The reference runs ONE forward per page (model_predict.py:130-154): ~15 launches of a few microseconds of work each --
+# launch latency, not arithmetic.  PageForwardGraphs keeps, per size bucket, the page's tensors in fixed
+# buffers and the model's forward captured in a HIP graph: a page is one assembly launch (gte_batch_assemble straight from the
+# resident dataset into the bucket's buffers), one tiny fill and one graph launch.  Rows past the page's nodes have no edges
+# and are ignored.
+class PageForwardGraphs:
+    BUCKETS = (64, 128, 256, 512, 1024, 2048, 4096)
+    EDGES_PER_NODE = 16                                   # k = 5 bidirected: <= 10 in-edges on average
+
+    def __init__(self, model, resident: "G.ResidentPages"):
+        if resident.p3_mode:
+            raise ValueError("PageForwardGraphs reads fp32 features (ResidentPages not in image mode)")
+        self.model, self.res, self.device = model, resident, resident.device
+        self._b = {}
+
+    def _bucket(self, n: int, e: int):
+        for cap in self.BUCKETS:
+            if n <= cap and e <= cap * self.EDGES_PER_NODE:
+                return cap
+        return None
+
+    def _build(self, cap: int):
+        res, dev = self.res, self.device
+        bufs = res.alloc_batch_buffers(cap, cap * self.EDGES_PER_NODE, cap * self.EDGES_PER_NODE)
+        bufs["indptr"][0].zero_()
+        bufs["feat"].zero_()
+        g = G.ResidentBatch(cap, cap * self.EDGES_PER_NODE, G.CSR(bufs["indptr"][0], bufs["indices"][0], None),
+                            G.CSR(bufs["indptr"][1], bufs["indices"][1], None), bufs["weight"][0], bufs["weight"][1], dev)
+        g.ndata["feat"] = bufs["feat"]
+        if res.weighted:
+            g.edata["feat"] = bufs["weight"][0]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                self.model(g)                             # warm-up outside the capture: workspaces, lazy state
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            logits = self.model(g)
+            pred = logits.argmax(dim=1)
+        meta = torch.empty(7, dtype=torch.int32, device=dev)
+        self._b[cap] = dict(bufs=bufs, graph=graph, logits=logits, pred=pred, meta=meta, g=g)
+        return self._b[cap]
+
+    def forward(self, page_id: int):
+        """(logits [n, C], predictions [n]) of one page: views of the bucket's buffers, valid until its next use."""
+        res = self.res
+        n = int(res.node_off_host[page_id + 1] - res.node_off_host[page_id])
+        eo = res._sets["in"]["edge_off_host"]
+        e = int(eo[page_id + 1] - eo[page_id])
+        cap = self._bucket(n, e)
+        if cap is None:                                   # larger than the largest bucket: the eager path
+            g = res.batch([page_id])
+            with torch.no_grad():
+                logits = self.model(g)
+            return logits, logits.argmax(dim=1)
+        b = self._b.get(cap) or self._build(cap)
+        e_out = int(res._sets["out"]["edge_off_host"][page_id + 1] - res._sets["out"]["edge_off_host"][page_id])
+        meta_h = torch.tensor([page_id, 0, n, 0, e, 0, e_out], dtype=torch.int32)
+        b["meta"].copy_(meta_h, non_blocking=True)
+        res.assemble(b["meta"], 1, n, e, e_out, b["bufs"])
+        b["bufs"]["indptr"][0][n + 1:].fill_(e)           # rows past the page: empty
+        b["graph"].replay()
+        return b["logits"][:n], b["pred"][:n]
+
+
 def test(data, config, weights_path=None, save_predictions=True):
     if not (config.TRAINING.gpu >= 0 and torch.cuda.is_available()):
         raise RuntimeError("model_predict runs on the MI355X HIP path only (no CPU fallback)")
