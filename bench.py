@@ -25,6 +25,7 @@ Extra objects in the JSON line:
   gather        the aggregation kernel on BASELINE cfg4 (1 M nodes, deg 12, F = 512): HBM GB/s
   cfg3          BASELINE configs[2]: 4-head GAT, bf16 MFMA projection + bf16 gathers (no reference counterpart: parity unpinned)
   val_graph     cfg2 "val graph" case: every page of a validation set in ONE graph, forward only (model_train.py:349-353)
+  inference     model_predict.py:130-154: one forward per page (eager / one HIP-graph launch per page) and 100 pages per forward
   cpu_baseline  the CPU oracle (oracle/gcnsage_cpu.py: torch-CPU + OpenMP CSR SpMM) on one batch, on this box's
                 host cores ("port"; baseline only)
 """
@@ -70,6 +71,7 @@ def parse():
     ap.add_argument("--no-replay", action="store_true", help="skip the HIP-graph replay secondary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true")
+    ap.add_argument("--no-inference", action="store_true", help="skip the inference probe (one forward per page / batched)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the F0=13 (BBOX features only) variant of cfg2")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the GAT bf16 probe (BASELINE configs[2])")
     ap.add_argument("--gemm-mode", choices=["f32", "split_bf16"], default=None,
@@ -223,6 +225,43 @@ def val_graph_probe(args, gte, S, model, dev, pages):
     return {"workload": f"val graph: {len(pages)} pages in one graph, forward only (eval, no_grad), F0={args.in_feats}",
             "nodes": n, "edges": int(len(src)), "ms_per_forward": ms, "nodes_per_s": n / (ms * 1e-3),
             "logits_finite": bool(torch.isfinite(logits).all())}
+
+
+def inference_probe(args, gte, model, dev, pages):
+    """SURVEY 8(f) N2 / model_predict.py:130-154.  (i) the reference's shape: ONE forward per page (batch = 1), eager and as
+    one HIP-graph launch per page (models.model_predict.PageForwardGraphs: size buckets, the page assembled into the bucket's
+    buffers); (ii) batched: 100 pages per forward.  Pages are resident in HBM with their CSRs prepared (the reference rebuilds
+    them per forward inside DGL); host-synchronised wall time over all pages."""
+    from gnn_tableextraction_amd import graph as G
+    from gnn_tableextraction_amd.models.model_predict import PageForwardGraphs
+    n_pages = min(len(pages), 400)
+    res = G.ResidentPages(to_page_graphs(gte, pages[:n_pages]), dev)
+    sizes = res.page_sizes()
+    was_training = model.training
+    model.eval()
+    out = {"workload": f"inference: {n_pages} pages ({int(sum(sizes))} nodes), F0={args.in_feats}, hidden={args.hidden}, forward + argmax"}
+    with torch.no_grad():
+        def eager_all():
+            for pid in range(n_pages):
+                model(res.batch([pid])).argmax(dim=1)
+        runner = PageForwardGraphs(model, res)
+        def graph_all():
+            for pid in range(n_pages):
+                runner.forward(pid)
+        def batched_all():
+            for b0 in range(0, n_pages, 100):
+                model(res.batch(list(range(b0, min(b0 + 100, n_pages))))).argmax(dim=1)
+        for name, fn in (("per_page_eager", eager_all), ("per_page_hip_graph", graph_all), ("batched_100", batched_all)):
+            fn()                                                # warm-up (captures the buckets' graphs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            out[name] = {"ms_per_page": el * 1e3 / n_pages, "pages_per_s": n_pages / el, "nodes_per_s": float(sum(sizes)) / el}
+        out["hip_graph_buckets"] = sorted(runner._b)
+    model.train(was_training)
+    return out
 
 
 def timed_loop(trainer, pipe, epochs, loop):
@@ -764,7 +803,9 @@ def main():
             line["gemm_modes"] = gemm_mode_probe(ops, run, alt, global_counts(alt), dev)
         line.update(pre)
         line["order"] = ("gather / val_graph probes, long_run (>= 1 s of the same loop), THEN W warm-up + K timed steps = value, "
-                         "then kernel timers, replay, the other GEMM mode, secondary, cfg3, cpu_baseline")
+                         "then kernel timers, replay, the other GEMM mode, inference, secondary, cfg3, cpu_baseline")
+        if extras and not args.no_inference:
+            line["inference"] = inference_probe(args, gte, model, dev, pages)
         if pages13 is not None:
             line["secondary"] = secondary_probe(args, gte, S, dev, pages13)
         if extras and not args.no_cfg3:

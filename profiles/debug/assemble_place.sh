@@ -1,4 +1,4 @@
-STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --val-graph 0"
+STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --no-inference --val-graph 0"
 for late in 1 0; do for rows in 0 48 192 768; do
   r=$( GTE_PIPE_LATE=$late GTE_ASSEMBLE_ROWS=$rows timeout 120 python bench.py $STEP_ONLY 2>/dev/null | python -c "
 import sys, json

@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --val-graph 0"
+STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --no-inference --val-graph 0"
 timeout 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python3 $R/bench.py --long-run-seconds 0.2 --no-cpu-baseline > $O/bench_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_step -o t -- python3 $R/bench.py --long-run-seconds 0.2 $STEP_ONLY > $O/bench_trace_step.log 2>&1
