@@ -401,9 +401,14 @@ gemm_split_kernel(const GemmParams p) {
                 const int roff0 = (m0 + (wm * TM + a) * 32 + hrow) * ld4 + coff;
                 if (!post) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[a][b][r] + bv), c_srd,
+                    for (int r = 0; r < 16; ++r) {
+                        // through a VGPR on purpose: with an accumulator element as the store's data operand hipcc 7.2 emitted
+                        // element 0 for all sixteen stores (gemm_bf16.hip); the add alone is not a guarantee
+                        float v = acc[a][b][r] + bv;
+                        asm volatile("" : "+v"(v));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_srd,
                                                               roff0 + ((r & 3) + 8 * (r >> 2)) * ld4, 0, 0);
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -411,6 +416,7 @@ gemm_split_kernel(const GemmParams p) {
                         float v = acc[a][b][r] + bv;
                         if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_srd, off, 0, 0));
                         if (p.relu) v = fmaxf(v, 0.f);
+                        asm volatile("" : "+v"(v));
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_srd, off, 0, 0);
                     }
                 }

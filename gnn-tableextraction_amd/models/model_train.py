@@ -205,68 +205,71 @@ def train(data, config, name_time=None):
     import gc
     gc.collect()
     gc.freeze()
-    for epoch in range(start_epoch, config.TRAINING.n_epochs):
-        plan = D.plan_epoch(sizes, batch_size, world, seed=config.PREPROCESS.get('seed', 42), epoch=epoch)
-        counts = D.step_node_counts(plan, sizes)
-        scales = None
-        if page_wsum is not None:
-            wsums = D.step_weight_sums(plan, page_wsum)
-            scales = wsums[:, rank] / np.maximum(wsums.sum(axis=1), 1e-30)
-        # the same loop bench.py times: models/loop.py
-        out3 = run_steps(step, pipe, [ranks[rank] for ranks in plan], n_global=counts.sum(axis=1), loss_scale=scales)
-        if out3 is not None:
-            o = out3.cpu().tolist()
-            train_loss, train_acc = o[0], o[2] / max(int(counts[-1][rank]), 1)
+    try:
+        for epoch in range(start_epoch, config.TRAINING.n_epochs):
+            plan = D.plan_epoch(sizes, batch_size, world, seed=config.PREPROCESS.get('seed', 42), epoch=epoch)
+            counts = D.step_node_counts(plan, sizes)
+            scales = None
+            if page_wsum is not None:
+                wsums = D.step_weight_sums(plan, page_wsum)
+                scales = wsums[:, rank] / np.maximum(wsums.sum(axis=1), 1e-30)
+            # the same loop bench.py times: models/loop.py
+            out3 = run_steps(step, pipe, [ranks[rank] for ranks in plan], n_global=counts.sum(axis=1), loss_scale=scales)
+            if out3 is not None:
+                o = out3.cpu().tolist()
+                train_loss, train_acc = o[0], o[2] / max(int(counts[-1][rank]), 1)
 
-        # ---- validation on the (sharded) batched val graph -------------------------------------------
-        if val_graph is not None:
-            vl, va, pred = evaluate(model, val_graph, val_labels, class_weights)
-            n_val = val_labels.shape[0]
-            y_true, y_pred = val_labels.long().cpu().numpy(), pred.cpu().numpy()
-        else:
-            vl, va, n_val, y_true, y_pred = 0.0, 0.0, 0, np.zeros(0, np.int64), np.zeros(0, np.int64)
-        conf = np.zeros((n_classes, n_classes), dtype=np.float64)
-        np.add.at(conf, (y_true, y_pred), 1.0)
-        red = torch.tensor([vl * n_val, va * n_val, float(n_val)] + conf.reshape(-1).tolist(), dtype=torch.float64,
-                           device=device)
-        if distributed:
-            import torch.distributed as dist
-            dist.all_reduce(red)                              # one small vector: loss sum, correct, n, confusion
-        red = red.cpu().numpy()
-        n_tot = max(red[2], 1.0)
-        val_loss, val_acc = float(red[0] / n_tot), float(red[1] / n_tot)
-        conf = red[3:].reshape(n_classes, n_classes)
-        tp = np.diag(conf)
-        denom = conf.sum(0) + conf.sum(1)
-        f1_vect = np.where(denom > 0, 2 * tp / np.maximum(denom, 1), 0.0)   # per-class F1, zero_division=0
+            # ---- validation on the (sharded) batched val graph -------------------------------------------
+            if val_graph is not None:
+                vl, va, pred = evaluate(model, val_graph, val_labels, class_weights)
+                n_val = val_labels.shape[0]
+                y_true, y_pred = val_labels.long().cpu().numpy(), pred.cpu().numpy()
+            else:
+                vl, va, n_val, y_true, y_pred = 0.0, 0.0, 0, np.zeros(0, np.int64), np.zeros(0, np.int64)
+            conf = np.zeros((n_classes, n_classes), dtype=np.float64)
+            np.add.at(conf, (y_true, y_pred), 1.0)
+            red = torch.tensor([vl * n_val, va * n_val, float(n_val)] + conf.reshape(-1).tolist(), dtype=torch.float64,
+                               device=device)
+            if distributed:
+                import torch.distributed as dist
+                dist.all_reduce(red)                              # one small vector: loss sum, correct, n, confusion
+            red = red.cpu().numpy()
+            n_tot = max(red[2], 1.0)
+            val_loss, val_acc = float(red[0] / n_tot), float(red[1] / n_tot)
+            conf = red[3:].reshape(n_classes, n_classes)
+            tp = np.diag(conf)
+            denom = conf.sum(0) + conf.sum(1)
+            f1_vect = np.where(denom > 0, 2 * tp / np.maximum(denom, 1), 0.0)   # per-class F1, zero_division=0
 
-        scheduler.step(val_loss)
-        step.lr = _lr_holder.param_groups[0]['lr']
-        early_stop, counter = (stopper.step(val_loss, model) if rank == 0 else (False, 0))
-        if distributed:
-            flag = torch.tensor([1.0 if early_stop else 0.0], device=device)
-            dist.broadcast(flag, src=0)
-            early_stop = bool(flag.item())
-        conv = data.label_tranformer.origin_to_conv
-        say(" -> Epoch {} | Train: Loss {:.4f} Acc {:.4f} | Validation: Loss {:.4f} | Accuracy {:.4f} | Cell F1 {:.4f}"
-            " | Table Header F1 {:.4f}".format(epoch + 1, train_loss, train_acc, val_loss, val_acc,
-                                               f1_vect[conv[TABLE_TCELL]], f1_vect[conv[TABLE_COLH]]))
-        if writer is not None:
-            for tag, v in (('Loss/train', train_loss), ('Accuracy/train', train_acc), ('Loss/val', val_loss),
-                           ('Accuracy/val', val_acc), ('f1/t-cell', f1_vect[conv[TABLE_TCELL]]),
-                           ('f1/h-cell', f1_vect[conv[TABLE_COLH]]), ('Accuracy/counter', counter)):
-                writer.add_scalar(tag, v, epoch + 1)
-        if early_stop:
-            break
-        if val_loss < metrics.val.loss:
-            metrics['train']['loss'], metrics['train']['acc'] = train_loss, train_acc
-            metrics['val']['loss'], metrics['val']['acc'] = val_loss, val_acc
-            metrics['f1_vect'] = f1_vect.tolist()
-        if rank == 0:
-            os.makedirs(ckpt_dir, exist_ok=True)
-            torch.save({'epoch': epoch + 1,
-                        'state_dict': {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
-                        'optimizer': adam_state_dict(step, model), 'metrics': dict(metrics)}, ckpt_path)
+            scheduler.step(val_loss)
+            step.lr = _lr_holder.param_groups[0]['lr']
+            early_stop, counter = (stopper.step(val_loss, model) if rank == 0 else (False, 0))
+            if distributed:
+                flag = torch.tensor([1.0 if early_stop else 0.0], device=device)
+                dist.broadcast(flag, src=0)
+                early_stop = bool(flag.item())
+            conv = data.label_tranformer.origin_to_conv
+            say(" -> Epoch {} | Train: Loss {:.4f} Acc {:.4f} | Validation: Loss {:.4f} | Accuracy {:.4f} | Cell F1 {:.4f}"
+                " | Table Header F1 {:.4f}".format(epoch + 1, train_loss, train_acc, val_loss, val_acc,
+                                                   f1_vect[conv[TABLE_TCELL]], f1_vect[conv[TABLE_COLH]]))
+            if writer is not None:
+                for tag, v in (('Loss/train', train_loss), ('Accuracy/train', train_acc), ('Loss/val', val_loss),
+                               ('Accuracy/val', val_acc), ('f1/t-cell', f1_vect[conv[TABLE_TCELL]]),
+                               ('f1/h-cell', f1_vect[conv[TABLE_COLH]]), ('Accuracy/counter', counter)):
+                    writer.add_scalar(tag, v, epoch + 1)
+            if early_stop:
+                break
+            if val_loss < metrics.val.loss:
+                metrics['train']['loss'], metrics['train']['acc'] = train_loss, train_acc
+                metrics['val']['loss'], metrics['val']['acc'] = val_loss, val_acc
+                metrics['f1_vect'] = f1_vect.tolist()
+            if rank == 0:
+                os.makedirs(ckpt_dir, exist_ok=True)
+                torch.save({'epoch': epoch + 1,
+                            'state_dict': {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                            'optimizer': adam_state_dict(step, model), 'metrics': dict(metrics)}, ckpt_path)
+    finally:
+        gc.unfreeze()          # a library entry point must not leave the caller's objects in the permanent generation
 
     say("\n### TRAINING ENDED ###\n")
     if rank == 0:

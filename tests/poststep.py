@@ -4,9 +4,10 @@ The first Adam step maps a (weight-decayed) gradient g to  lr * g / (|g| + eps) 
 update is +-lr whatever the last bits of g are, but entries whose true gradient is ~0 get a gradient of +-1e-9 from
 summation-order noise alone, and their update lands anywhere in [-lr, lr] -- between two runs of the REFERENCE on different
 thread counts too.  So:
-  * every parameter whose decayed gradient is resolved (|g + wd p| >= 1e-5) must equal the reference's post-step value to
-    1e-5; the others (a fraction < 1e-2: at full size ~0.4 % of layer 0's weights have a gradient that cancels against the
-    weight-decay term to < 5e-7) may differ by at most 2 lr;
+  * every parameter must equal the reference's post-step value within ``step_tolerance``: 1e-5 wherever its decayed gradient
+    is resolved against the summation noise, opening up continuously (to at most 2 lr) only where it is not; the entries
+    beyond 1e-5 must stay below 2 % of each tensor (at full size ~0.4 % of layer 0's weights have a gradient that cancels
+    against the weight-decay term to < 5e-7);
   * the logits after the step are compared at 1e-4 against the reference forward (the CPU oracle, itself pinned to the
     reference's forward at 1e-5) run on the reference's post-step state with exactly those ill-conditioned entries taken
     from the state under test -- i.e. everything except the entries that are noise in the reference itself is checked tight."""
@@ -16,21 +17,36 @@ import torch
 from oracle import gcnsage_cpu as oc
 
 
-def hybrid_state(want: dict, got: dict, g_eff: dict, lr=0.01):
-    """want/got/g_eff: name -> ndarray (reference post-step params, ours, |decayed gradient|)."""
-    hyb, n_bad, n_tot = {}, 0, 0
+NOISE = 2.0 ** -18        # bound on the summation-order noise of a gradient entry, relative to the tensor's largest entry
+                          # (measured between the reference's own runs: ~2^-21; fp32 sums over 10^3 - 10^4 nodes)
+
+
+def step_tolerance(g_eff, g_absmax, lr=0.01, eps=1e-8):
+    """Allowed |difference| of a parameter after ONE Adam step, per entry.  The step maps the decayed gradient g to
+    u(g) = lr g / (|g| + eps); a perturbation dg of the gradient moves it by  u'(g) dg = lr eps / (|g| + eps)^2 dg.  With dg
+    bounded by NOISE x the tensor's largest gradient entry this is 1e-5 for every resolved gradient and opens up -- continuously,
+    up to 2 lr -- only where |g| is itself of the size of the noise.  A wrong-sign update at |g| = 1e-6 (error ~ 2 lr) is ~1000x
+    outside it (the flat |g| < 1e-5 mask of round 2 let it through)."""
+    g = np.abs(np.asarray(g_eff, dtype=np.float64))
+    sens = lr * eps / (g + eps) ** 2
+    return 1e-5 + np.minimum(2 * lr * (1 + 1e-4), sens * NOISE * float(g_absmax))
+
+
+def hybrid_state(want: dict, got: dict, g_eff: dict, lr=0.01, g_absmax: dict = None):
+    """want/got/g_eff: name -> ndarray (reference post-step params, ours, decayed gradient).  Entries that differ by more than
+    1e-5 must be inside ``step_tolerance`` and stay below 2 % of their tensor; they are taken from the state under test."""
+    hyb = {}
     for k, w in want.items():
         o = np.asarray(got[k])
+        amax = float(np.abs(g_eff[k]).max()) if g_absmax is None else float(g_absmax[k])
+        diff = np.abs(o.astype(np.float64) - w)
+        assert (diff <= step_tolerance(g_eff[k], amax, lr) + 1e-5 * np.abs(w)).all(), \
+            f"{k}: a parameter differs after the step by more than its gradient's conditioning allows (max {diff.max():.3e})"
         bad = ~np.isclose(o, w, rtol=1e-5, atol=1e-5)
-        if bad.any():
-            assert (np.abs(g_eff[k])[bad] < 1e-5).all(), f"{k}: a parameter with a resolved gradient differs after the step"
-            assert np.abs(o - w).max() <= 2 * lr * (1 + 1e-4), f"{k}: update larger than 2 lr"
+        assert bad.sum() <= 2e-2 * bad.size + 2, f"{k}: {int(bad.sum())} of {bad.size} entries are ill-conditioned"
         h = w.copy()
         h[bad] = o[bad]
         hyb[k] = torch.from_numpy(h)
-        n_bad += int(bad.sum())
-        n_tot += bad.size
-    assert n_bad <= 1e-2 * n_tot + 2, f"{n_bad} of {n_tot} parameters differ after the step"
     return hyb
 
 
@@ -87,22 +103,22 @@ def check_headline(z, logits, hidden, loss, grads: dict, params_after: dict, log
             np.testing.assert_allclose(g.reshape(-1)[idx], ref, rtol=1e-4, atol=1e-6 + 1e-4 * amax)
             assert abs(float(g.astype(np.float64).sum()) - float(z["grad_sum." + k])) < 1e-4 * amax * np.sqrt(g.size)
             assert abs(float(np.abs(g).max()) - amax) <= 1e-4 * amax
-    n_bad = n_tot = 0
     for k, p in params_after.items():
         p = np.asarray(p)
         if ("state1." + k) in z.files:
             want, got, p0 = z["state1." + k], p, state0[k].numpy()
-            ge = np.abs(z["grad." + k] + 5e-4 * p0) if ("grad." + k) in z.files else np.zeros_like(want)
+            ge = (z["grad." + k] + 5e-4 * p0) if ("grad." + k) in z.files else np.zeros_like(want)
+            amax = float(np.abs(z["grad." + k]).max()) if ("grad." + k) in z.files else 0.0
         else:
             idx = z["state1_idx." + k]
             want, got = z["state1_val." + k], p.reshape(-1)[idx]
             # the decayed gradient at the sampled state entries, from OUR gradient (checked against the reference above)
-            ge = np.abs(np.asarray(grads[k]).reshape(-1)[idx] + 5e-4 * state0[k].numpy().reshape(-1)[idx])
+            ge = np.asarray(grads[k]).reshape(-1)[idx] + 5e-4 * state0[k].numpy().reshape(-1)[idx]
+            amax = float(z["grad_absmax." + k])
+        diff = np.abs(got.astype(np.float64) - want)
+        assert (diff <= step_tolerance(ge, amax) + 1e-5 * np.abs(want)).all(), f"{k}: post-step parameter off by {diff.max():.3e}"
         bad = ~np.isclose(got, want, rtol=1e-5, atol=1e-5)
-        assert (ge[bad] < 1e-5).all() and (np.abs(got - want).max() <= 0.02 * (1 + 1e-4) if bad.any() else True), k
-        n_bad += int(bad.sum())
-        n_tot += bad.size
-    assert n_bad <= 1e-2 * n_tot + 2
+        assert bad.sum() <= 2e-2 * bad.size + 2, f"{k}: {int(bad.sum())} of {bad.size} entries are ill-conditioned"
     assert np.abs(np.asarray(logits_after) - z["logits_after_step"]).max() < 5e-3
     if oracle_after is not None:          # forward of the reference restatement on OUR post-step state: forward parity after the step
         assert np.abs(np.asarray(logits_after) - oracle_after).max() < 1e-4
