@@ -114,6 +114,9 @@ def evaluate(model, graph, labels, class_weights=None):
     return o[0], o[2] / max(labels.shape[0], 1), pred
 
 
+LAST_RUN = None          # {"model", "step", "rank", "world"} of the last train() call in this process
+
+
 def train(data, config, name_time=None):
     rank, local_rank, world = D.env_world()
     distributed = world > 1
@@ -272,6 +275,8 @@ def train(data, config, name_time=None):
         gc.unfreeze()          # a library entry point must not leave the caller's objects in the permanent generation
 
     say("\n### TRAINING ENDED ###\n")
+    global LAST_RUN
+    LAST_RUN = {"model": model, "step": step, "rank": rank, "world": world}     # inspection handle (tests: replicas identical)
     if rank == 0:
         os.makedirs(res_dir, exist_ok=True)
         path = os.path.join(res_dir, f'{logs}.json')

@@ -117,3 +117,49 @@ def test_bench_self_spawned_two_ranks_share_the_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["long_run"]["steps"] >= 4
     assert d["value"] > 0 and np.isfinite(d["final_loss"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# train() end to end with two ranks (the box has one GPU: both ranks on cuda:0, gloo): the eval confusion-matrix all-reduce
+# and the early-stop broadcast of model_train.py:230-249 run every epoch
+def _train_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from gnn_tableextraction_amd.components.graphs.loader import PrebuiltPages
+    from gnn_tableextraction_amd.models import model_train
+    from gnn_tableextraction_amd.parsers.graphs import parse_args_ModelTrain
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # train() finds the group initialised and keeps it
+    data = PrebuiltPages.synthetic(40, in_feats=13)
+    for p, g in zip(data.page_arrays, data.graphs):                   # learnable labels (as test_gpu_train_entry.py)
+        y = (p.feat[:, 1] // 260).astype(np.int64).clip(0, 8)
+        p.label[:] = y
+        g.ndata['label'] = torch.from_numpy(y.astype(np.float32))
+    cfg = parse_args_ModelTrain(argv=["--mode=knn", "--features", "BBOX", "--n_layers=3", "--mode_params=fixed", "--h_layer_dim=64",
+                                      "--batch_size=4", "--n_epochs=3", "--lr=0.01", "--output_dir", os.path.join(out_dir, f"rank{rank}")])
+    metrics = model_train.train(data, cfg)
+    run = model_train.LAST_RUN
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"train_param_{rank}.npy"), run["step"].flat_param.detach().cpu().numpy())
+    np.save(os.path.join(out_dir, f"train_m_{rank}.npy"), run["step"].exp_avg.detach().cpu().numpy())
+    np.save(os.path.join(out_dir, f"train_metrics_{rank}.npy"),
+            np.array([metrics.val.loss, metrics.val.acc, metrics.train.loss] + list(metrics.f1_vect)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_end_to_end_with_two_ranks_keeps_the_replicas_identical(tmp_path):
+    """train(data, config) under WORLD_SIZE = 2: pages sharded per step, flat-gradient all-reduce, validation sharded with one
+    all-reduce of (loss sum, correct, n, confusion matrix), early-stop flag broadcast from rank 0.  Both ranks end with the
+    same parameters and optimiser state bit for bit and report the same (all-reduced) validation metrics; rank 0 alone
+    writes the checkpoint, weights and results files."""
+    world = 2
+    mp.start_processes(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    for name in ("train_param", "train_m"):
+        a, b = np.load(tmp_path / f"{name}_0.npy"), np.load(tmp_path / f"{name}_1.npy")
+        np.testing.assert_array_equal(a, b)
+    m0, m1 = np.load(tmp_path / "train_metrics_0.npy"), np.load(tmp_path / "train_metrics_1.npy")
+    np.testing.assert_array_equal(m0[:2], m1[:2])                       # all-reduced validation loss / accuracy
+    np.testing.assert_array_equal(m0[3:], m1[3:])                       # per-class F1 from the all-reduced confusion matrix
+    assert np.isfinite(m0).all() and m0[0] < np.log(9.0)
+    assert os.path.isdir(tmp_path / "rank0" / "checkpoints") and os.path.isdir(tmp_path / "rank0" / "weights")
+    assert not os.path.exists(tmp_path / "rank1" / "checkpoints") and not os.path.exists(tmp_path / "rank1" / "results")

@@ -631,6 +631,38 @@ def test_meansage_matches_reference_golden():
     np.testing.assert_allclose(out, z["out"], rtol=1e-5, atol=1e-5)
 
 
+def test_meansage_backward_matches_the_oracles_autograd():
+    """MeanSAGE (models.py:118-170; never instantiated by the reference's scripts, golden forward above): every parameter
+    gradient and the input gradient of sum(out * up) against the CPU oracle's autograd on the same weights -- 1e-4 of each
+    tensor's largest entry."""
+    z = np.load(os.path.join(GOLDEN_DIR, "meansage_120.npz"))
+    n, f0, hid, ncls, nl, _ = (int(v) for v in z["meta"])
+    m = gte.MeanSAGE(f0, hid, ncls, nl)
+    m.load_state_dict({k[len("state0."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("state0.")})
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    names = sorted({k.rsplit(".", 1)[0] for k in sd})            # one prefix per linear
+    order = sorted(names, key=lambda s: [int(t) for t in s.split(".") if t.isdigit()])
+    ws = [(sd[p + ".weight"].clone().requires_grad_(True), sd[p + ".bias"].clone().requires_grad_(True)) for p in order]
+    xo = torch.from_numpy(z["x"]).clone().requires_grad_(True)
+    up = torch.randn(n, ncls, generator=torch.Generator().manual_seed(9))
+    og = oc.OracleGraph(z["src"], z["dst"], n, z["w"])
+    want = oc.meansage_forward(ws, og, xo)
+    np.testing.assert_allclose(want.detach().numpy(), z["out"], rtol=1e-5, atol=1e-5)   # the oracle reproduces the golden forward
+    (want * up).sum().backward()
+    m = m.to(DEV)
+    g = G.PageGraph(z["src"], z["dst"], n, device=DEV)
+    xd = dev(z["x"]).requires_grad_(True)
+    out = m(g, xd, dev(z["w"]))
+    (out * up.to(DEV)).sum().backward()
+    got = dict(m.named_parameters())
+    for p, (w, b) in zip(order, ws):
+        for name, ref in ((p + ".weight", w.grad), (p + ".bias", b.grad)):
+            r = ref.numpy()
+            np.testing.assert_allclose(got[name].grad.cpu().numpy(), r, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(r).max())
+    r = xo.grad.numpy()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), r, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(r).max())
+
+
 def test_batched_pages_vs_oracle_and_per_page_equivalence():
     """100-page batch (BASELINE cfg2 shape, F0=13): forward vs the CPU oracle; and batching must not
     change a page's logits (block-diagonal: no edge crosses pages)."""
