@@ -79,6 +79,7 @@ SIGNATURES = {
     "gte_gemm_p3_tn_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
     "gte_gemm_p3_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_gcnsage_step": (c_int, [c_void_p, c_int, POINTER(c_int), c_void_p]),
     "gte_fold_defer_begin": (c_int, [c_void_p]),
     "gte_fold_defer_flush": (c_int, []),
     "gte_fold_defer_flush_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
@@ -149,6 +150,36 @@ class P3Desc(ctypes.Structure):
     """gte_p3_desc of include/gte.h"""
     _fields_ = [("src", c_void_p), ("ld", c_int64), ("rows", c_int64), ("cols", c_int64), ("transpose", c_int),
                 ("dst", c_void_p), ("ldp", c_int64)]
+
+
+class StepLayer(ctypes.Structure):
+    """gte_step_layer of include/gte.h"""
+    _fields_ = [("kind", c_int), ("fin", c_int64), ("fout", c_int64),
+                ("W", c_void_p), ("bias", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("relu", c_int),
+                ("gW", c_void_p), ("gbias", c_void_p), ("ggamma", c_void_p), ("gbeta", c_void_p),
+                ("wimg_fwd", c_void_p), ("ldp_wfwd", c_int64), ("wimg_bwd", c_void_p), ("ldp_wbwd", c_int64),
+                ("x", c_void_p), ("ldx", c_int64), ("hp", c_void_p), ("ldp_h", c_int64), ("make_hp", c_int),
+                ("ahn", c_void_p), ("t", c_void_p), ("stats", c_void_p), ("y", c_void_p), ("yp", c_void_p), ("ldp_y", c_int64),
+                ("dy", c_void_p), ("dzp", c_void_p), ("qp", c_void_p), ("ldp_o", c_int64),
+                ("ws_ln", c_void_p), ("ws_ln_bytes", c_int64), ("ws_dw", c_void_p), ("ws_dw_bytes", c_int64)]
+
+
+class StepPlan(ctypes.Structure):
+    """gte_step_plan of include/gte.h"""
+    _fields_ = [("n_hidden", c_int), ("layer", StepLayer * 7),
+                ("out_fin", c_int64), ("n_classes", c_int64),
+                ("W_out", c_void_p), ("b_out", c_void_p), ("gW_out", c_void_p), ("gb_out", c_void_p),
+                ("h_out", c_void_p), ("ld_h_out", c_int64),
+                ("logits", c_void_p), ("tn", c_void_p), ("q_out", c_void_p), ("dl", c_void_p), ("dh_out", c_void_p),
+                ("ce_part", c_void_p), ("ce_part_bytes", c_int64), ("ws_nar", c_void_p), ("ws_nar_bytes", c_int64),
+                ("indptr", c_void_p), ("indices", c_void_p), ("w_in", c_void_p),
+                ("rindptr", c_void_p), ("rindices", c_void_p), ("w_out", c_void_p),
+                ("n_nodes", c_int64),
+                ("labels", c_void_p), ("labels_f32", c_int), ("class_weights", c_void_p), ("grad_scale", c_float), ("out3", c_void_p),
+                ("wimg_descs", c_void_p), ("n_wimg_descs", c_int),
+                ("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n_param", c_int64),
+                ("hyper", c_void_p), ("step_counter", c_void_p), ("ticket", c_void_p),
+                ("tail_ws", c_void_p), ("tail_ws_bytes", c_int64)]
 
 
 class BatchArrays(ctypes.Structure):

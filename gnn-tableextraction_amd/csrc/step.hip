@@ -1,0 +1,119 @@
+// One optimisation step of GcnSAGE from a prepared plan: gte_gcnsage_step (include/gte.h).
+//
+// replaces the batch loop body of the reference (src/models/model_train.py:320-332) as ONE host call.  Host code only: the
+// arithmetic is the library's own entry points, issued in the order models/engine.py issues them (the two paths are
+// interchangeable and bit-identical: tests/test_gpu_step_plan.py).  What this buys is host time: a step is ~17 launches; from
+// Python through ctypes each costs ~10 us of interpreter + marshalling, which bounded the BBOX-only configurations (F0 = 13:
+// ~0.25 ms of host time per 0.37 ms step).
+#include "gte_common.h"
+
+namespace {
+
+#define GTE_TRY(call)            \
+    do {                         \
+        const int rc_ = (call);  \
+        if (rc_ != GTE_OK) return rc_; \
+    } while (0)
+
+int forward(const gte_step_plan& p, void* st) {
+    const int64_t n = p.n_nodes;
+    if (p.n_wimg_descs > 0)
+        GTE_TRY(gte_p3_from_f32_batch(reinterpret_cast<const gte_p3_desc*>(p.wimg_descs), p.n_wimg_descs, st));
+    for (int i = 0; i < p.n_hidden; ++i) {
+        const gte_step_layer& L = p.layer[i];
+        if (L.kind == GTE_LAYER_SMALLK) {
+            GTE_TRY(gte_spmm_csr(p.indptr, p.indices, p.w_in, L.x, L.ldx, L.ahn, L.fin, n, L.fin, GTE_F32, GTE_REDUCE_MEAN, st));
+            GTE_TRY(gte_sage_linear_fwd(L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.eps, L.relu, L.t,
+                                        L.fout, L.stats, L.y, L.fout, n, L.fout, st));
+            if (L.yp) GTE_TRY(gte_p3_from_f32(L.y, L.fout, n, L.fout, 0, L.yp, L.ldp_y, st));
+            continue;
+        }
+        if (L.make_hp) GTE_TRY(gte_p3_from_f32(L.x, L.ldx, n, L.fin, 0, L.hp, L.ldp_h, st));
+        GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, nullptr, 0, 0, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * L.fout, n, 2 * L.fout,
+                               0, 0, st));
+        GTE_TRY(gte_spmm_csr_accumulate_ln_p3(p.indptr, p.indices, p.w_in, L.t + L.fout, 2 * L.fout, L.t, 2 * L.fout, n, L.fout,
+                                              GTE_REDUCE_MEAN, L.gamma, L.beta, L.eps, L.relu, L.y, L.fout, L.yp, L.ldp_y, L.stats, st));
+    }
+    const int64_t C = p.n_classes;
+    GTE_TRY(gte_sage_narrow_fwd(p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, p.b_out, C, p.logits, C, p.tn, C, n, st));
+    GTE_TRY(gte_head_agg_ce(p.indptr, p.indices, p.w_in, p.tn, C, p.logits, C, p.labels, p.labels_f32, p.class_weights, n, C,
+                            GTE_REDUCE_MEAN, p.dl, C, p.ce_part, p.ce_part_bytes, st));
+    return GTE_OK;
+}
+
+// backward of the output layer and of hidden layers n_hidden - 1 .. 1, and of layer 0 up to its weight-gradient GEMM
+int backward_a(const gte_step_plan& p, void* st) {
+    const int64_t n = p.n_nodes, C = p.n_classes;
+    GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
+    GTE_TRY(gte_sage_narrow_bwd_ce(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C, p.dh_out, p.out_fin,
+                                   p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes, p.ce_part, p.grad_scale, p.out3, st));
+    for (int i = p.n_hidden - 1; i >= 0; --i) {
+        const gte_step_layer& L = p.layer[i];
+        if (L.kind == GTE_LAYER_SMALLK) {
+            GTE_TRY(gte_ln_relu_bwd(L.dy, L.fout, L.t, L.fout, L.stats, L.gamma, L.beta, L.relu, L.dy, L.fout, L.ggamma, L.gbeta, L.gbias, n,
+                                    L.fout, L.ws_ln, L.ws_ln_bytes, st));
+            continue;                                  // (layer 0: its dW is phase 2)
+        }
+        GTE_TRY(gte_ln_relu_bwd_p3(L.dy, L.fout, L.t, 2 * L.fout, L.stats, L.gamma, L.beta, L.relu, L.dy, L.fout, L.dzp, L.ldp_o, L.ggamma,
+                                   L.gbeta, L.gbias, n, L.fout, L.ws_ln, L.ws_ln_bytes, st));
+        GTE_TRY(gte_spmm_csr_p3(p.rindptr, p.rindices, p.w_out, L.dy, L.fout, L.qp, L.ldp_o, n, L.fout, GTE_REDUCE_SUM, st));
+        if (i == 0) break;                             // layer 0's dW is the step's last GEMM: phase 2
+        GTE_TRY(gte_gemm_p3_tn(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, nullptr, 0, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n, L.ws_dw,
+                               L.ws_dw_bytes, st));
+        GTE_TRY(gte_gemm_p3_nt(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, nullptr, 0, p.layer[i - 1].dy, L.fin, n,
+                               L.fin, 0, 0, st));
+    }
+    return GTE_OK;
+}
+
+int backward_b(const gte_step_plan& p, void* st) {
+    const int64_t n = p.n_nodes;
+    const gte_step_layer& L = p.layer[0];
+    if (L.kind == GTE_LAYER_SMALLK)
+        return gte_sage_linear_dw(L.dy, L.fout, L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.gW, 2 * L.fin, L.fout, n, L.ws_dw, L.ws_dw_bytes, st);
+    return gte_gemm_p3_tn(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, nullptr, 0, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n, L.ws_dw,
+                          L.ws_dw_bytes, st);
+}
+
+int flush(const gte_step_plan& p, int* adam_fused) {
+    if (adam_fused) *adam_fused = 0;
+    if (p.param) {
+        int fused = 0;
+        const int rc = gte_fold_defer_flush_adam(p.param, p.grad, p.exp_avg, p.exp_avg_sq, p.n_param, p.hyper, p.step_counter, p.ticket, &fused);
+        if (adam_fused) *adam_fused = fused;
+        return rc;
+    }
+    return gte_fold_defer_flush();
+}
+
+}  // namespace
+
+extern "C" int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream) {
+    if (!plan) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: null plan");
+    const gte_step_plan& p = *plan;
+    if (phase < 0 || phase > 2) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: phase must be 0, 1 or 2");
+    if (p.n_hidden < 1 || p.n_hidden > 7 || p.n_nodes < 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: bad plan");
+    for (int i = 0; i < p.n_hidden; ++i) {
+        const gte_step_layer& L = p.layer[i];
+        if (L.kind != GTE_LAYER_PLANES && L.kind != GTE_LAYER_SMALLK) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: layer kind");
+        if (L.kind == GTE_LAYER_SMALLK && i != 0) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: a short-input layer must be layer 0");
+        if (!L.gamma || !L.beta || !L.bias) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: hidden layers need bias and LayerNorm");
+    }
+    if (p.n_nodes == 0) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: empty batch");
+    if (phase != 2) {
+        GTE_TRY(gte_gemm_set_tail_workspace(p.tail_ws, p.tail_ws ? p.tail_ws_bytes : 0));
+        int rc = forward(p, stream);
+        if (rc == GTE_OK) rc = gte_fold_defer_begin(stream);
+        if (rc == GTE_OK) {
+            rc = backward_a(p, stream);
+            if (rc != GTE_OK) (void)gte_fold_defer_flush();        // leave no deferral open behind an error
+        }
+        if (rc != GTE_OK) { (void)gte_gemm_set_tail_workspace(nullptr, 0); return rc; }
+        if (phase == 1) return GTE_OK;
+    }
+    int rc = backward_b(p, stream);
+    if (rc != GTE_OK) { (void)gte_fold_defer_flush(); (void)gte_gemm_set_tail_workspace(nullptr, 0); return rc; }
+    rc = flush(p, adam_fused);
+    (void)gte_gemm_set_tail_workspace(nullptr, 0);
+    return rc;
+}

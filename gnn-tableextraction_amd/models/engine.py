@@ -177,6 +177,8 @@ class FusedGcnSageStep(TrainStep):
         # images (three bf16 planes, csrc/p3.h) by their producers and multiplied by the planes GEMMs (csrc/gemm_p3.hip)
         self.use_planes = os.environ.get("GTE_PLANES", "1") == "1"
         self._wimg = {}                               # layer index -> (forward image, backward image or None)
+        # the whole step through ONE C entry point (gte_gcnsage_step) when the configuration allows (GTE_C_STEP=0: call by call)
+        self.use_c_step = os.environ.get("GTE_C_STEP", "1") == "1"
         # called (once per step, no arguments) right before the LAST big kernel of a step is launched -- layer 0's dW GEMM,
         # MFMA-bound, ~a quarter of the step.  The train loop hangs the assembly of the NEXT batch here (models/loop.py):
         # it then runs on the side stream under that GEMM, and the batch is still in the Infinity Cache when the next
@@ -264,7 +266,7 @@ class FusedGcnSageStep(TrainStep):
                 "dy": [v(t) for t in full["dy"]], "dahn": v(full["dahn"]), "tn": v(full["tn"]), "q": v(full["q"]),
                 "out3": full["out3"], "ws": full["ws"], "ws_ln": full["ws_ln"], "ws_nar": full["ws_nar"],
                 "ce_part": full["ce_part"],
-                "ws_dw": full["ws_dw"], "pl": full["pl"], "ws_p3": full["ws_p3"],
+                "ws_dw": full["ws_dw"], "pl": full["pl"], "ws_p3": full["ws_p3"], "_full": full,
                 "hp": [None if t is None else t.view_rows(n) for t in full["hp"]],
                 "dzp": [None if t is None else t.view_rows(n) for t in full["dzp"]],
                 "qp": [None if t is None else t.view_rows(n) for t in full["qp"]]}
@@ -329,7 +331,7 @@ class FusedGcnSageStep(TrainStep):
         L = self.model.layers[0]
         return self._planes_layer(0, L, f0)
 
-    def _weight_images(self, dims):
+    def _weight_images(self, dims, launch=True):
         """P3 images of the planes layers' weights: forward [W_s rows ; W_n rows] x fin, backward (dX) [fin rows] x [W_s^T | W_n^T].
         ONE launch in front of every forward (the parameters change every step; the launch is part of a captured step)."""
         layers = self.model.layers
@@ -355,17 +357,159 @@ class FusedGcnSageStep(TrainStep):
             if bwd is not None:
                 descs.append(_lib.P3Desc(wp, ld, fin, fout, 1, bwd.data.data_ptr(), bwd.ldp))
                 descs.append(_lib.P3Desc(wp + 4 * fin, ld, fin, fout, 1, bwd.data.data_ptr() + (fout // 16) * 96, bwd.ldp))
+        self._wimg_descs = descs
+        if launch:
+            st = _lib.current_stream()
+            for k in range(0, len(descs), 16):
+                chunk = descs[k:k + 16]
+                arr = (_lib.P3Desc * len(chunk))(*chunk)
+                _lib.check(self.lib.gte_p3_from_f32_batch(ctypes.addressof(arr), len(chunk), st), "gte_p3_from_f32_batch")
+
+    # -- the whole step as one host call (gte_gcnsage_step) ---------------------------------------------
+    def _plan_kinds(self, f0: int, n: int):
+        """Layer kinds of the one-call step (gte_gcnsage_step) or None when the configuration needs the call-by-call path."""
+        layers = list(self.model.layers)
+        if (not self.use_c_step or not self._planes_on() or len(layers) < 2 or len(layers) > 8 or self.overlap_dw or self.fuse_ln_below
+                or ops._timers is not None):
+            return None
+        dims = [f0] + [l.out_feats for l in layers]
+        last = len(layers) - 1
+        if not (self._narrow(layers[last], dims[last]) and self._fused_head(last, layers[last], dims[last])):
+            return None
+        kinds = []
+        for i, L in enumerate(layers[:-1]):
+            fin = dims[i]
+            if self._planes_layer(i, L, fin, n):
+                kinds.append(0)
+            elif (i == 0 and isinstance(L.lynorm, nn.LayerNorm) and L.linear.bias is not None and not self._transform_first(L, fin)
+                  and bool(self.lib.gte_sage_linear_fwd_fuses_ln(2 * fin, L.out_feats))
+                  and not ops.use_tiled(n, fin, None)):
+                kinds.append(1)
+            else:
+                return None
+            if L.activation is not None and not _is_relu(L.activation):
+                return None
+        return kinds
+
+    def _c_step(self, g, labels, grad_scale, kinds, with_adam: bool):
+        """forward + loss + backward (+ Adam inside the fold launch) through gte_gcnsage_step: two host calls (the next batch's
+        assembly is queued between them) instead of ~19."""
+        lib, P = self.lib, _lib.ptr
         st = _lib.current_stream()
-        for k in range(0, len(descs), 16):
-            chunk = descs[k:k + 16]
-            arr = (_lib.P3Desc * len(chunk))(*chunk)
-            _lib.check(self.lib.gte_p3_from_f32_batch(ctypes.addressof(arr), len(chunk), st), "gte_p3_from_f32_batch")
+        xp = getattr(g, "feat_p3", None)
+        if xp is not None:
+            x, n, f0 = None, xp.rows, xp.cols
+        else:
+            x = ops._row_major(g.ndata['feat'])
+            _lib.require_device(x, "FusedGcnSageStep")
+            n, f0 = x.shape
+        b = self._buffers(n, f0, self._private_key)
+        layers = list(self.model.layers)
+        dims = [f0] + [l.out_feats for l in layers]
+        ew = g.edata.get("feat")
+        csr, rcsr = g.in_csr(), g.out_csr()
+        w_in, w_out = g.in_weights(ew), g.out_weights(ew, True)
+        plans = b["_full"].setdefault("_plans", {})       # cached with the buffer set whose addresses they hold
+        key = (tuple(kinds), with_adam)
+        cached = plans.get(key)
+        if cached is None:
+            self._weight_images(dims, launch=False)
+            descs = self._wimg_descs
+            if len(descs) > 16:
+                raise _lib.GteError("gte_gcnsage_step: more than 16 weight images")
+            arr = (_lib.P3Desc * max(len(descs), 1))(*descs)
+            plan = _lib.StepPlan()
+            plan.n_hidden = len(layers) - 1
+            for i, L in enumerate(layers[:-1]):
+                sl = plan.layer[i]
+                fin, fout = dims[i], L.out_feats
+                sl.kind, sl.fin, sl.fout = kinds[i], fin, fout
+                sl.W, sl.bias, sl.gamma, sl.beta = P(L.linear.weight), P(L.linear.bias), P(L.lynorm.weight), P(L.lynorm.bias)
+                sl.eps, sl.relu = float(L.lynorm.eps), int(L.activation is not None)
+                gs = self._gslice
+                sl.gW, sl.gbias = P(gs[id(L.linear.weight)]), P(gs[id(L.linear.bias)])
+                sl.ggamma, sl.gbeta = P(gs[id(L.lynorm.weight)]), P(gs[id(L.lynorm.bias)])
+                nxt_planes = i + 1 < len(layers) - 1 and kinds[i + 1] == 0
+                if kinds[i] == 0:
+                    wf, wb = self._wimg[i]
+                    sl.wimg_fwd, sl.ldp_wfwd = P(wf.data), wf.ldp
+                    if wb is not None:
+                        sl.wimg_bwd, sl.ldp_wbwd = P(wb.data), wb.ldp
+                    sl.hp, sl.ldp_h = P(b["hp"][i].data), b["hp"][i].ldp
+                    sl.t = P(b["t"][i])
+                    sl.dzp, sl.qp, sl.ldp_o = P(b["dzp"][i].data), P(b["qp"][i].data), b["dzp"][i].ldp
+                    sl.ws_dw, sl.ws_dw_bytes = P(b["ws_p3"][i]), b["ws_p3"][i].numel()
+                    sl.y = None if nxt_planes else P(b["y"][i])
+                else:
+                    sl.ahn, sl.t, sl.y = P(b["ahn"][i]), P(b["z"][i]), P(b["y"][i])
+                    sl.ws_dw, sl.ws_dw_bytes = P(b["ws_dw"][i]), b["ws_dw"][i].numel()
+                if nxt_planes:
+                    sl.yp, sl.ldp_y = P(b["hp"][i + 1].data), b["hp"][i + 1].ldp
+                sl.stats, sl.dy = P(b["stats"][i]), P(b["dy"][i])
+                sl.ws_ln, sl.ws_ln_bytes = P(b["ws_ln"][i]), b["ws_ln"][i].numel()
+            Lo = layers[-1]
+            plan.out_fin, plan.n_classes = dims[-2], Lo.out_feats
+            plan.W_out, plan.b_out = P(Lo.linear.weight), P(Lo.linear.bias)
+            plan.gW_out, plan.gb_out = P(self._gslice[id(Lo.linear.weight)]), P(self._gslice[id(Lo.linear.bias)])
+            plan.h_out, plan.ld_h_out = P(b["y"][-2]), dims[-2]
+            plan.logits, plan.tn, plan.q_out = P(b["y"][-1]), P(b["tn"]), P(b["q"])
+            plan.dl, plan.dh_out = P(b["dy"][-1]), P(b["dy"][-2])
+            plan.ce_part, plan.ce_part_bytes = P(b["ce_part"]), b["ce_part"].numel()
+            plan.ws_nar, plan.ws_nar_bytes = P(b["ws_nar"]), b["ws_nar"].numel()
+            plan.class_weights = P(self.class_weights)
+            plan.out3 = P(b["out3"])
+            plan.wimg_descs, plan.n_wimg_descs = ctypes.addressof(arr), len(descs)
+            if with_adam:
+                plan.param, plan.grad, plan.exp_avg, plan.exp_avg_sq = (P(self.flat_param), P(self.flat_grad), P(self.exp_avg),
+                                                                        P(self.exp_avg_sq))
+                plan.n_param = self.flat_param.numel()
+                plan.hyper, plan.step_counter, plan.ticket = P(self._hyper), P(self._step_dev), P(self._ticket)
+            if self._tail_ws is None:
+                self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=self.flat_param.device)
+            if self.tail_split:
+                plan.tail_ws, plan.tail_ws_bytes = P(self._tail_ws), self._tail_ws.numel()
+            cached = plans[key] = (plan, arr, ctypes.c_int(0))
+        plan, _arr, fused = cached
+        # per batch: the graph, the features, the labels
+        L0 = plan.layer[0]
+        if kinds[0] == 0:
+            if xp is not None:
+                L0.hp, L0.ldp_h, L0.make_hp, L0.x = P(xp.data), xp.ldp, 0, None
+            else:
+                L0.hp, L0.ldp_h, L0.make_hp = P(b["hp"][0].data), b["hp"][0].ldp, 1
+                L0.x, L0.ldx = P(x), ops._ld(x)
+        else:
+            if x is None:
+                raise _lib.GteError("the batch holds its features as a P3 image, but layer 0 reads fp32 rows")
+            L0.x, L0.ldx = P(x), ops._ld(x)
+        plan.indptr, plan.indices, plan.w_in = P(csr.indptr), P(csr.indices), P(w_in)
+        plan.rindptr, plan.rindices, plan.w_out = P(rcsr.indptr), P(rcsr.indices), P(w_out)
+        plan.n_nodes = n
+        lab = labels if labels.dtype in (torch.float32, torch.int64) else labels.to(torch.int64)
+        plan.labels, plan.labels_f32 = P(lab), int(lab.dtype == torch.float32)
+        plan.grad_scale = float(grad_scale)
+        addr = ctypes.addressof(plan)
+        if self.before_last_gemm is not None:
+            _lib.check(lib.gte_gcnsage_step(addr, 1, ctypes.byref(fused), st), "gte_gcnsage_step")
+            self.before_last_gemm()
+            _lib.check(lib.gte_gcnsage_step(addr, 2, ctypes.byref(fused), st), "gte_gcnsage_step")
+        else:
+            _lib.check(lib.gte_gcnsage_step(addr, 0, ctypes.byref(fused), st), "gte_gcnsage_step")
+        self._adam_fused = bool(fused.value)
+        self._keep = (lab, csr, rcsr, w_in, w_out)                     # alive until the next step
+        return b["out3"]
 
     # -- the schedule ----------------------------------------------------------------------------------
     def forward_backward(self, g, labels: torch.Tensor, grad_scale: float = 1.0, upto_layer: int = 0) -> torch.Tensor:
         """Forward, loss and the backward of layers n_layers-1 .. upto_layer (gradients of those layers final on return:
         their folds are flushed).  upto_layer > 0 leaves the rest to :meth:`backward_rest` -- the data-parallel step
         all-reduces the upper layers' gradient slice while the (longest) backward of layer 0 runs."""
+        if upto_layer == 0:
+            xp = getattr(g, "feat_p3", None)
+            n, f0 = (xp.rows, xp.cols) if xp is not None else g.ndata['feat'].shape
+            kinds = self._plan_kinds(f0, n)
+            if kinds is not None:
+                return self._c_step(g, labels, grad_scale, kinds, with_adam=bool(self._fuse_adam_req))
         return self._run(g, labels, grad_scale, len(self.model.layers) - 1, upto_layer, forward=True)
 
     def backward_rest(self, g, from_layer: int) -> None:

@@ -313,6 +313,58 @@ int gte_gemm_p3_tn(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, c
                    int64_t ldpb2, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* ---- one optimisation step from a prepared plan -------------------------------------------------------------------------
+ * replaces the batch loop body of model_train.py:320-332 (logits = model(g); loss; zero_grad; backward; optimizer.step())
+ * for the configuration every shipped run of the reference uses -- GcnSAGE with ReLU + LayerNorm hidden layers, dropout 0,
+ * a class-count-wide output layer -- as ONE host call: the launches of a step (see models/engine.py for the same sequence
+ * issued call by call) are issued from here, so the host cost of a step no longer grows with its ~17 launches (the
+ * BBOX-only configurations, F0 = 13, were host-bound at ~0.25 ms of ctypes calls per 0.37 ms step).
+ * The plan only borrows device pointers; nothing is allocated or synchronised.  Layer kinds:
+ *   GTE_LAYER_PLANES  t = h [W_s ; W_n]^T on the planes GEMM, z = t_self + b + mean-aggregate(t_neigh), LayerNorm, ReLU;
+ *                     input / dz / q as P3 images (needs fin >= fout, fout % 16 == 0, 128 <= fout <= 256)
+ *   GTE_LAYER_SMALLK  input layer with k = 2 fin <= 64 (BBOX features): aggregate-first, linear + LayerNorm + ReLU in one pass
+ * followed by the output layer (gte_sage_narrow_*, gte_head_agg_ce).  phase: 0 the whole step; 1 everything up to the last
+ * weight-gradient GEMM, 2 the rest (the train loop queues the NEXT batch's assembly on its side stream in between). */
+enum gte_layer_kind { GTE_LAYER_PLANES = 0, GTE_LAYER_SMALLK = 1 };
+typedef struct gte_step_layer {
+    int kind;
+    int64_t fin, fout;
+    const float* W; const float* bias; const float* gamma; const float* beta; float eps; int relu;
+    float* gW; float* gbias; float* ggamma; float* gbeta;
+    void* wimg_fwd; int64_t ldp_wfwd;      /* PLANES: P3 [2 fout][fin]   = [W_s rows ; W_n rows]            */
+    void* wimg_bwd; int64_t ldp_wbwd;      /* PLANES, layer > 0: P3 [fin][2 fout] = [W_s^T | W_n^T]         */
+    const float* x; int64_t ldx;           /* fp32 input rows (SMALLK; PLANES layer 0 when hp must be made) */
+    void* hp; int64_t ldp_h;               /* PLANES: P3 image of the input [n][fin]                        */
+    int make_hp;                           /* PLANES: 1 = convert x (fp32) into hp first                    */
+    float* ahn;                            /* SMALLK: aggregated input [n][fin]                             */
+    float* t;                              /* PLANES: [n][2 fout]; SMALLK: z [n][fout]                      */
+    float* stats;                          /* [2 n]                                                         */
+    float* y;                              /* fp32 output [n][fout] (NULL when only the next image is needed) */
+    void* yp; int64_t ldp_y;               /* P3 image of the output for the next PLANES layer (or NULL)    */
+    float* dy;                             /* [n][fout] gradient w.r.t. the output; dz in place             */
+    void* dzp; void* qp; int64_t ldp_o;    /* PLANES: images [n][fout]                                      */
+    void* ws_ln; int64_t ws_ln_bytes;      /* gte_ln_relu_bwd workspace                                     */
+    void* ws_dw; int64_t ws_dw_bytes;      /* split-K workspace of the layer's dW                           */
+} gte_step_layer;
+typedef struct gte_step_plan {
+    int n_hidden;                          /* hidden layers (1 .. 7), followed by the output layer          */
+    gte_step_layer layer[7];
+    int64_t out_fin, n_classes;            /* output layer                                                  */
+    const float* W_out; const float* b_out; float* gW_out; float* gb_out;
+    const float* h_out; int64_t ld_h_out;  /* fp32 input of the output layer (= y of the last hidden layer) */
+    float* logits; float* tn; float* q_out; float* dl; float* dh_out;
+    void* ce_part; int64_t ce_part_bytes; void* ws_nar; int64_t ws_nar_bytes;
+    const int32_t* indptr; const int32_t* indices; const float* w_in;         /* in-edge CSR                */
+    const int32_t* rindptr; const int32_t* rindices; const float* w_out;      /* out-edge CSR, weights x 1 / in_degree(dst) */
+    int64_t n_nodes;
+    const void* labels; int labels_f32; const float* class_weights; float grad_scale; float* out3;
+    const void* wimg_descs; int n_wimg_descs;                                /* gte_p3_desc[]: the weight images */
+    float* param; float* grad; float* exp_avg; float* exp_avg_sq; int64_t n_param;   /* fused Adam (NULL param: plain flush) */
+    float* hyper; int64_t* step_counter; uint32_t* ticket;
+    void* tail_ws; int64_t tail_ws_bytes;
+} gte_step_plan;
+int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
+
 /* ---- deferred folds -------------------------------------------------------------------------------------------
  * Several entry points end with a small "sum the per-block partials" kernel (gte_ln_relu_bwd: column sums;
  * gte_sage_narrow_bwd: dW / dbias; split-K GEMMs behind gte_sage_linear_dw / gte_sage_qform_dw).  gte_gemm_f32 NEVER defers:

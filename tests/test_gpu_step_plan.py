@@ -1,0 +1,73 @@
+"""gte_gcnsage_step (the whole optimisation step as one host call) against the call-by-call schedule of models/engine.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(monkeypatch, c_step, f0, hid, weighted, n_pages=12, steps=3, resident=False):
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import graph as G
+    from gnn_tableextraction_amd.data import synthetic as S
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    monkeypatch.setenv("GTE_C_STEP", "1" if c_step else "0")
+    dev = "cuda:0"
+    pages = S.make_pages(n_pages, in_feats=f0)
+    torch.manual_seed(7)
+    model = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0).to(dev)
+    cw = torch.linspace(0.5, 2.0, 9, device=dev) if weighted else None
+    tr = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4, class_weights=cw)
+    assert tr.use_c_step == c_step
+    outs = []
+    if resident:
+        graphs = []
+        for p in pages:
+            g = gte.PageGraph(p.src, p.dst, p.num_nodes)
+            g.ndata["feat"], g.ndata["label"] = torch.from_numpy(p.feat), torch.from_numpy(p.label.astype(np.float32))
+            g.edata["feat"] = torch.from_numpy(p.weight)
+            graphs.append(g)
+        res = G.ResidentPages(graphs, dev)
+        if tr.wants_p3_features(f0):
+            res.enable_p3()
+    for s in range(steps):
+        ids = [(3 * s + j) % n_pages for j in range(6)]
+        if resident:
+            g = res.batch(ids)
+            y = g.ndata["label"]
+        else:
+            src, dst, w, feat, label, off = S.concat_pages([pages[i] for i in ids])
+            g = G.PageGraph(src, dst, int(off[-1]), device=dev)
+            g.ndata["feat"], g.edata["feat"] = torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev)
+            y = torch.from_numpy(label).to(dev)
+        outs.append(tr.step(g, y).cpu().numpy().copy())
+    used = any(k for full in tr._bufs.values() for k in full.get("_plans", {}))
+    return np.stack(outs), tr.flat_param.detach().cpu().numpy(), tr.flat_grad.detach().cpu().numpy(), tr.exp_avg_sq.detach().cpu().numpy(), used
+
+
+@pytest.mark.parametrize("f0,hid,weighted,resident", [(831, 256, False, False), (831, 256, True, True), (13, 256, False, False),
+                                                      (13, 256, True, True), (363, 128, False, False)])
+def test_one_call_step_is_bitwise_the_call_by_call_step(monkeypatch, f0, hid, weighted, resident):
+    """Same launches in the same order from C: losses, gradients, parameters and optimiser state after three steps are bit for
+    bit those of the Python-issued schedule (planes input layer, BBOX-only input layer, class weights, resident batches with
+    image features)."""
+    a = _run(monkeypatch, True, f0, hid, weighted, resident=resident)
+    b = _run(monkeypatch, False, f0, hid, weighted, resident=resident)
+    assert a[4] and not b[4]                                     # the one-call path really ran / really did not
+    for x, y in zip(a[:4], b[:4]):
+        np.testing.assert_array_equal(x, y)
+    assert np.isfinite(a[0]).all()
+
+
+def test_step_plan_rejects_bad_plans():
+    import ctypes
+    from gnn_tableextraction_amd import _lib
+    lib = _lib.load()
+    plan = _lib.StepPlan()
+    fused = ctypes.c_int(0)
+    assert lib.gte_gcnsage_step(None, 0, ctypes.byref(fused), None) == -1
+    assert lib.gte_gcnsage_step(ctypes.addressof(plan), 0, ctypes.byref(fused), None) == -1      # n_hidden = 0
+    plan.n_hidden, plan.n_nodes = 1, 10
+    assert lib.gte_gcnsage_step(ctypes.addressof(plan), 3, ctypes.byref(fused), None) == -1      # phase
+    assert lib.gte_gcnsage_step(ctypes.addressof(plan), 0, ctypes.byref(fused), None) == -4      # no LayerNorm / bias: unsupported
+    assert b"LayerNorm" in lib.gte_last_error()
