@@ -52,6 +52,9 @@ SIGNATURES = {
                                     c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                     c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "gte_sage_linear_fwd_fuses_ln": (c_int, [c_int64, c_int64]),
+    "gte_sage_linear_fwd_p3": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                       c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                       c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "gte_sage_linear_dw_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
     "gte_sage_linear_dw": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                    c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),

@@ -1342,7 +1342,7 @@ sage_smallk_fwd_kernel(const float* __restrict__ a1, int64_t lda1, int k1, const
                        const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
                        float* __restrict__ z_save, int64_t ldz, float* __restrict__ stats, float* __restrict__ y, int64_t ldy,
-                       int M, int n) {
+                       int M, int n, char* __restrict__ yp3 = nullptr, int64_t ldyp3 = 0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int K = k1 + k2, Kp = (K + 3) & ~3;
     const int ns = n;                                                  // W^T row stride
@@ -1456,7 +1456,9 @@ sage_smallk_fwd_kernel(const float* __restrict__ a1, int64_t lda1, int k1, const
                     if (relu) o[e] = fmaxf(o[e], 0.f);
                 }
                 f4u t; t.x = o[0]; t.y = o[1]; t.z = o[2]; t.w = o[3];
-                *reinterpret_cast<f4u*>(y + (int64_t)r * ldy + j) = t;
+                if (y) *reinterpret_cast<f4u*>(y + (int64_t)r * ldy + j) = t;
+                // the next (planes) layer's input image, written here instead of by a conversion pass over y
+                if (yp3) p3::store4(yp3 + (int64_t)r * ldyp3, j, o[0], o[1], o[2], o[3]);
             }
         }
     }
@@ -1669,16 +1671,19 @@ extern "C" int gte_sage_qform_dx(const float* dz, int64_t lddz, const float* q, 
     return launch_shape<true, false>(p, pl, s);
 }
 
-extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2,
-                                   int64_t k2, const float* W, int64_t ldw, const float* bias, const float* gamma,
-                                   const float* beta, float eps, int relu, float* z_save, int64_t ldz, float* stats,
-                                   float* y, int64_t ldy, int64_t M, int64_t n_out, void* stream) {
+static int sage_linear_fwd_impl(const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2,
+                                int64_t k2, const float* W, int64_t ldw, const float* bias, const float* gamma,
+                                const float* beta, float eps, int relu, float* z_save, int64_t ldz, float* stats,
+                                float* y, int64_t ldy, int64_t M, int64_t n_out, void* stream, char* yp3, int64_t ldyp3) {
     if (M < 0 || n_out <= 0 || k1 <= 0 || k2 < 0 || M > INT32_MAX || n_out > INT32_MAX || k1 + k2 > INT32_MAX)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: bad sizes");
     if (M == 0) return GTE_OK;
-    if (!a1 || !W || !y || (k2 > 0 && !a2)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: null pointer");
-    if (lda1 < k1 || (k2 > 0 && lda2 < k2) || ldw < k1 + k2 || ldy < n_out || (z_save && ldz < n_out))
+    if (!a1 || !W || (!y && !yp3) || (k2 > 0 && !a2)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: null pointer");
+    if (lda1 < k1 || (k2 > 0 && lda2 < k2) || ldw < k1 + k2 || (y && ldy < n_out) || (z_save && ldz < n_out))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: leading dimension too small");
+    if (yp3 && !(gamma && smallk_supported(k1 + k2, n_out) && n_out % 16 == 0 && ldyp3 >= p3::row_bytes(n_out) && ldyp3 % 16 == 0))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "sage_linear_fwd_p3: the image output needs the one-pass form (k1 + k2 <= 64, LayerNorm) "
+                                              "and n_out %% 16 == 0");
     if (gamma && !beta) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: gamma without beta");
     hipStream_t s = gte::as_stream(stream);
     const bool ln = gamma != nullptr;
@@ -1686,7 +1691,7 @@ extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, co
         const int64_t kp = (k1 + k2 + 3) & ~(int64_t)3;
         hipLaunchKernelGGL(sage_smallk_fwd_kernel, dim3((unsigned)gte::ceil_div(M, SMALLK_BLOCK_ROWS)), dim3(256),
                            (size_t)(kp * n_out + SMALLK_BLOCK_ROWS * kp) * sizeof(float), s, a1, lda1, (int)k1, a2, lda2, (int)k2,
-                           W, ldw, bias, gamma, beta, eps, relu, z_save, ldz, stats, y, ldy, (int)M, (int)n_out);
+                           W, ldw, bias, gamma, beta, eps, relu, z_save, ldz, stats, y, ldy, (int)M, (int)n_out, yp3, ldyp3);
         return gte::check_launch("sage_smallk_fwd");
     }
     // z goes to z_save when the backward needs it, else straight into y (LayerNorm then runs in place)
@@ -1809,4 +1814,24 @@ extern "C" int gte_ln_relu_bwd_p3(const float* dy, int64_t lddy, const float* z,
     if (!dzp3) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd_p3: null image");
     return ln_relu_bwd_impl(dy, lddy, z, ldz, stats, gamma, beta, relu, dz, lddz, dgamma, dbeta, dbias, M, n_out, workspace,
                             workspace_bytes, stream, reinterpret_cast<char*>(dzp3), ldp3);
+}
+
+extern "C" int gte_sage_linear_fwd(const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2,
+                                   int64_t k2, const float* W, int64_t ldw, const float* bias, const float* gamma,
+                                   const float* beta, float eps, int relu, float* z_save, int64_t ldz, float* stats,
+                                   float* y, int64_t ldy, int64_t M, int64_t n_out, void* stream) {
+    if (!y) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd: null pointer");
+    return sage_linear_fwd_impl(a1, lda1, k1, a2, lda2, k2, W, ldw, bias, gamma, beta, eps, relu, z_save, ldz, stats, y, ldy, M, n_out,
+                                stream, nullptr, 0);
+}
+
+// ... the one-pass form (gte_sage_linear_fwd_fuses_ln) with y written as a P3 image for the next layer's planes GEMM (y itself
+// may then be NULL)
+extern "C" int gte_sage_linear_fwd_p3(const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2,
+                                      int64_t k2, const float* W, int64_t ldw, const float* bias, const float* gamma,
+                                      const float* beta, float eps, int relu, float* z_save, int64_t ldz, float* stats,
+                                      float* y, int64_t ldy, void* yp3, int64_t ldyp3, int64_t M, int64_t n_out, void* stream) {
+    if (!yp3) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_linear_fwd_p3: null image");
+    return sage_linear_fwd_impl(a1, lda1, k1, a2, lda2, k2, W, ldw, bias, gamma, beta, eps, relu, z_save, ldz, stats, y, ldy, M, n_out,
+                                stream, reinterpret_cast<char*>(yp3), ldyp3);
 }

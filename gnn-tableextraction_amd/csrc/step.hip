@@ -23,9 +23,12 @@ int forward(const gte_step_plan& p, void* st) {
         const gte_step_layer& L = p.layer[i];
         if (L.kind == GTE_LAYER_SMALLK) {
             GTE_TRY(gte_spmm_csr(p.indptr, p.indices, p.w_in, L.x, L.ldx, L.ahn, L.fin, n, L.fin, GTE_F32, GTE_REDUCE_MEAN, st));
-            GTE_TRY(gte_sage_linear_fwd(L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.eps, L.relu, L.t,
-                                        L.fout, L.stats, L.y, L.fout, n, L.fout, st));
-            if (L.yp) GTE_TRY(gte_p3_from_f32(L.y, L.fout, n, L.fout, 0, L.yp, L.ldp_y, st));
+            if (L.yp)          // the next layer's input image straight from this kernel (y itself is not needed then)
+                GTE_TRY(gte_sage_linear_fwd_p3(L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.eps, L.relu,
+                                               L.t, L.fout, L.stats, L.y, L.fout, L.yp, L.ldp_y, n, L.fout, st));
+            else
+                GTE_TRY(gte_sage_linear_fwd(L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.eps, L.relu, L.t,
+                                            L.fout, L.stats, L.y, L.fout, n, L.fout, st));
             continue;
         }
         if (L.make_hp) GTE_TRY(gte_p3_from_f32(L.x, L.ldx, n, L.fin, 0, L.hp, L.ldp_h, st));

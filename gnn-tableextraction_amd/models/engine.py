@@ -322,6 +322,7 @@ class FusedGcnSageStep(TrainStep):
         fout = layer.out_feats
         return (self._planes_on() and isinstance(layer.lynorm, nn.LayerNorm) and layer.linear.bias is not None
                 and not self._narrow(layer, fin) and fin >= fout and fin >= 16 and fout % 16 == 0 and 128 <= fout <= 256
+                and (i == 0 or fin % 16 == 0)              # inner layers get their input image from a producer epilogue
                 and bool(self.lib.gte_spmm_csr_accumulate_ln_supported(fout))
                 and not (n and ops.use_tiled(n, fout, None, fused_ln=True)))
 
@@ -441,7 +442,8 @@ class FusedGcnSageStep(TrainStep):
                     sl.ws_dw, sl.ws_dw_bytes = P(b["ws_p3"][i]), b["ws_p3"][i].numel()
                     sl.y = None if nxt_planes else P(b["y"][i])
                 else:
-                    sl.ahn, sl.t, sl.y = P(b["ahn"][i]), P(b["z"][i]), P(b["y"][i])
+                    sl.ahn, sl.t = P(b["ahn"][i]), P(b["z"][i])
+                    sl.y = None if (nxt_planes and fout % 16 == 0) else P(b["y"][i])
                     sl.ws_dw, sl.ws_dw_bytes = P(b["ws_dw"][i]), b["ws_dw"][i].numel()
                 if nxt_planes:
                     sl.yp, sl.ldp_y = P(b["hp"][i + 1].data), b["hp"][i + 1].ldp
@@ -628,8 +630,6 @@ class FusedGcnSageStep(TrainStep):
                 h, hp_in = y, yp
                 continue
             hp_in = None
-            if i > 0 and b["pl"][i - 1] and i < len(layers) and not b["pl"][i]:
-                pass                                     # the planes layer below wrote fp32 y for this layer
             if self._narrow(L, fin):
                 # class-count-wide layer: logits = h W_s^T + b + mean-aggregate(h W_n^T)  (aggregation on C columns)
                 with timed("narrow_fwd", 2.0 * n * fin * 4):
@@ -670,7 +670,16 @@ class FusedGcnSageStep(TrainStep):
                 continue
             aggregate(csr, w_in, t_in, h, ld(h), ahn, fin, fin, _lib.REDUCE_MEAN, False)
             if ln and lib.gte_sage_linear_fwd_fuses_ln(2 * fin, fout):
-                # short K (BBOX features, 13 + 13 inputs): linear + LayerNorm + ReLU in one pass over the rows
+                # short K (BBOX features, 13 + 13 inputs): linear + LayerNorm + ReLU in one pass over the rows; when the next
+                # layer is a planes layer its input image is written by the same pass (and y itself is not needed)
+                if i + 1 < len(layers) and b["pl"][i + 1] and fout % 16 == 0:
+                    yp = b["hp"][i + 1]
+                    check(lib.gte_sage_linear_fwd_p3(P(h), ld(h), fin, P(ahn), fin, fin, P(W), 2 * fin, P(bias), P(L.lynorm.weight),
+                                                     P(L.lynorm.bias), float(L.lynorm.eps), int(relu), P(b["z"][i]), fout,
+                                                     P(b["stats"][i]), None, fout, P(yp.data), yp.ldp, n, fout, st),
+                          "gte_sage_linear_fwd_p3")
+                    h, hp_in = y, yp
+                    continue
                 check(lib.gte_sage_linear_fwd(P(h), ld(h), fin, P(ahn), fin, fin, P(W), 2 * fin, P(bias), P(L.lynorm.weight),
                                               P(L.lynorm.bias), float(L.lynorm.eps), int(relu), P(b["z"][i]), fout,
                                               P(b["stats"][i]), P(y), fout, n, fout, st), "gte_sage_linear_fwd")

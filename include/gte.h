@@ -288,6 +288,10 @@ int gte_p3_from_f32_batch(const gte_p3_desc* descs, int n, void* stream);
  * the fused aggregation + LayerNorm(+ReLU) (y as image and / or fp32: either may be NULL) and the LayerNorm backward (dz as
  * fp32 AND image: fp32 feeds the transpose aggregation, the image the dX / dW GEMMs).  Same arithmetic as their fp32
  * forms (gte_spmm_csr, gte_spmm_csr_accumulate_ln, gte_ln_relu_bwd); the image holds exactly the fp32 values. */
+int gte_sage_linear_fwd_p3(const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2, int64_t k2, const float* W,
+                           int64_t ldw, const float* bias, const float* gamma, const float* beta, float eps, int relu,
+                           float* z_save, int64_t ldz, float* stats, float* y /* nullable */, int64_t ldy, void* yp3,
+                           int64_t ldyp3, int64_t M, int64_t n_out, void* stream);   /* one-pass form only (fuses_ln) */
 int gte_spmm_csr_p3(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x, int64_t ldx,
                     void* outp3, int64_t ldp, int64_t n_rows, int64_t n_feat, int reduce, void* stream);
 int gte_spmm_csr_accumulate_ln_p3(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x,
