@@ -17,7 +17,8 @@ are resident in HBM before the timed region.  Every rank owns DISTINCT pages (we
 RCCL all-reduce of the flat gradient per step.  One JSON line is printed by rank 0.
 
 Extra objects in the JSON line:
-  roofline      dominant kernel (fp32 MFMA forward GEMM), live HIP-event timing of the same steps
+  roofline      dominant kernel (the forward transform GEMMs: planes GEMM on the bf16 matrix pipe by default), live HIP-event
+                timing of the same steps
   long_run      the same loop for >= 1 s of device time, run BEFORE the W warm-up + K timed steps (the driver's 20-step
                 region is ~15 ms; measured right after an idle GPU woke up it reads ~7 % low: the chip has not reached its
                 sustained clocks -- a training run is at them)
@@ -734,13 +735,17 @@ def main():
         # split mode: fp32-equivalent flops (2 M N K) against the bf16 matrix peak / 6 (six bf16 MFMA products per fp32 product)
         gemm_peak = MFMA_BF16_PEAK_TF / 6.0 if split_mode else MFMA_F32_PEAK_TF
         roofline = {"bound": "mfma",
-                    "kernel": ("gemm_split_kernel<NT> (layer transforms, forward; fp32 operands as 3 exact bf16 pieces, 6 bf16 "
-                               "MFMA products, fp32 accumulate; peak = bf16 dense / 6)") if split_mode
+                    "kernel": (("gemm_p3_nt_lw_kernel / gemm_p3_nt_ring_kernel (layer transforms, forward; operands as P3 images -- 3 exact "
+                                "bf16 planes written by their producers --, LDS-DMA operand loads, 6 bf16 MFMA products, fp32 accumulate; "
+                                "peak = bf16 dense / 6)") if trainer._planes_on() else
+                               ("gemm_split_kernel<NT> (layer transforms, forward; fp32 operands as 3 exact bf16 pieces, 6 bf16 "
+                                "MFMA products, fp32 accumulate; peak = bf16 dense / 6)")) if split_mode
                               else "gemm_f32_mfma_kernel<NT> (layer transforms, forward)",
                     "achieved": tf, "peak": gemm_peak, "unit": "TFLOP/s", "frac": tf / gemm_peak,
                     "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
                     "algorithmic_flops_per_launch": flops / max(n_launch, 1),
-                    "traffic": pmc_traffic()[0].get("gemm_nt_split_bytes_per_launch" if split_mode else "gemm_nt_bytes_per_launch")
+                    "traffic": pmc_traffic()[0].get(("gemm_nt_p3_bytes_per_launch" if trainer._planes_on() else "gemm_nt_split_bytes_per_launch")
+                                                    if split_mode else "gemm_nt_bytes_per_launch")
                                if args.in_feats == 831 else None,
                     "traffic_source": pmc_traffic()[1]}
         per_kernel = {}

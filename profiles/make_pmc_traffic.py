@@ -14,7 +14,7 @@ out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pa
                  "profiles/pmc_probe.py spmm (cfg4); bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of "
                  "the kernel family (FETCH_SIZE x2: gfx950 counts the 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md HBM "
                  "section); the counters sit on the L2's memory side, so Infinity-Cache hits are included.  Scripts: profiles/refresh.sh, "
-                 "pmc_traffic_summary.py, make_pmc_traffic.py", "round": 2}
+                 "pmc_traffic_summary.py, make_pmc_traffic.py", "round": 3}
 for tag, pred in (("gemm_nt", lambda k: "gemm_f32_mfma_kernel<true, true" in k), ("gemm_tn", lambda k: "gemm_f32_mfma_kernel<false, false" in k),
                   ("gemm_nn", lambda k: "gemm_f32_mfma_kernel<true, false" in k), ("batch_assemble", lambda k: "batch_assemble" in k),
                   ("spmm_csr", lambda k: k.startswith("spmm_csr_kernel"))):
@@ -25,6 +25,13 @@ if len(sys.argv) > 4:
     for tag, pat in (("gemm_nt", "gemm_split_kernel<true, true"), ("gemm_tn", "gemm_split_kernel<false, false"), ("gemm_nn", "gemm_split_kernel<true, false")):
         b, n = fam(split, lambda k, pat=pat: pat in k)
         out[f"{tag}_split_bytes_per_launch"], out[f"{tag}_split_launches_sampled"] = b, n
+    # round 3: the default step multiplies P3 images (planes GEMMs, csrc/gemm_p3.hip)
+    for tag, pat in (("gemm_nt", "gemm_p3_nt"), ("gemm_tn", "gemm_p3_tn")):
+        b, n = fam(split, lambda k, pat=pat: pat in k)
+        out[f"{tag}_p3_bytes_per_launch"], out[f"{tag}_p3_launches_sampled"] = b, n
+    for tag, pat in (("batch_assemble_p3", "batch_assemble"), ("ln_relu_bwd_p3", "ln_relu_bwd_vec_kernel"), ("fold_adam", "gte_fold_batch_kernel")):
+        b, n = fam(split, lambda k, pat=pat: pat in k)
+        out[f"{tag}_bytes_per_launch"], out[f"{tag}_launches_sampled"] = b, n
 b, n = fam(full, lambda k: "spmm_tiled_full_kernel" in k)
 out["gather_cfg4_tiled_bytes_per_launch"], out["gather_cfg4_tiled_launches_sampled"] = b, n
 b, n = fam(full, lambda k: k.startswith("spmm_csr_kernel<F32, 64") or k.startswith("spmm_csr_kernel<F32; 64"))

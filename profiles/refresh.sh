@@ -2,7 +2,7 @@
 # Refresh the measurements under profiles/ on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash profiles/refresh.sh r02x'
 # writes gpurun_out/<tag>/: bench.json (the default command), kernel stats of the default command and of the train loop alone
-# (rocprofv3 --kernel-trace --stats; the >= 1 s long run shortened to 0.2 s under the profiler; the train loop also in the split-bf16 GEMM mode), FETCH_SIZE / WRITE_SIZE
+# (rocprofv3 --kernel-trace --stats; the >= 1 s long run shortened to 0.2 s under the profiler; the train loop also in the fp32 MFMA GEMM mode and at F0 = 13), FETCH_SIZE / WRITE_SIZE
 # passes (separate --pmc runs, kernel trace only, over the short drivers profiles/pmc_step.py / pmc_probe.py: counter collection
 # serialises every dispatch, bench.py under it runs for many minutes), copy yardsticks.  Every command is bounded by `timeout`.
 set -u
@@ -15,9 +15,13 @@ STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-rep
 timeout 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python3 $R/bench.py --long-run-seconds 0.2 --no-cpu-baseline > $O/bench_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_step -o t -- python3 $R/bench.py --long-run-seconds 0.2 $STEP_ONLY > $O/bench_trace_step.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_split -o t -- python3 $R/bench.py --gemm-mode split_bf16 --long-run-seconds 0.2 $STEP_ONLY > $O/bench_trace_split.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_f32 -o t -- python3 $R/bench.py --gemm-mode f32 --long-run-seconds 0.2 $STEP_ONLY > $O/bench_trace_f32.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_13 -o t -- python3 $R/bench.py --in-feats 13 --long-run-seconds 0.2 $STEP_ONLY > $O/bench_trace_13.log 2>&1
 cd $R
-python3 profiles/rocpd_summary.py $(ls $O/trace_split/*.db | head -1) $O/split_step_kernel_stats.csv > /dev/null
+python3 profiles/rocpd_summary.py $(ls $O/trace_f32/*.db | head -1) $O/f32_step_kernel_stats.csv > /dev/null
+python3 profiles/rocpd_summary.py $(ls $O/trace_13/*.db | head -1) $O/f13_step_kernel_stats.csv > /dev/null
+timeout 200 python3 profiles/debug/gemm_p3_check.py > $O/gemm_p3_check.txt 2>&1
+for c in 1 2 3 4 5 6; do GTE_P3_NT_CFG=$c timeout 200 python3 profiles/debug/gemm_p3_nt_cfg.py 2>&1 | grep -v "amdgpu.ids\|bitwise" >> $O/gemm_p3_nt_cfg.txt; done
 timeout 200 python3 profiles/debug/gemm_step_shapes.py > $O/gemm_step_shapes.txt 2>&1
 timeout 300 python3 profiles/debug/gemm_split_check.py > $O/gemm_split_check.txt 2>&1
 python3 profiles/rocpd_summary.py $(ls $O/trace/*.db | head -1) $O/final_kernel_stats.csv > /dev/null
@@ -25,5 +29,5 @@ python3 profiles/rocpd_summary.py $(ls $O/trace_step/*.db | head -1) $O/step_ker
 bash profiles/pmc_refresh.sh $TAG > /dev/null       # FETCH_SIZE / WRITE_SIZE passes over profiles/pmc_step.py and the cfg4 probe
 [ -x profiles/micro/stream_bw ] && timeout 60 ./profiles/micro/stream_bw 2048 > $O/stream_bw.txt
 [ -x profiles/micro/copy_variants ] && timeout 60 ./profiles/micro/copy_variants 2048 > $O/copy_variants.txt
-rm -rf $O/trace $O/trace_step $O/trace_split
+rm -rf $O/trace $O/trace_step $O/trace_f32 $O/trace_13
 du -sh $O; tail -c 300 $O/bench.json
