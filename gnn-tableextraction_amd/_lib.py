@@ -41,6 +41,8 @@ SIGNATURES = {
     "gte_island_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_batch_assemble": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                    c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gte_batch_assemble_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                        c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p]),
     "gte_batch_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                c_int64, c_void_p]),
     "gte_edge_weights_workspace_bytes": (c_int64, [c_int64, c_int64]),
@@ -79,6 +81,10 @@ SIGNATURES = {
                                    c_void_p, c_int64, c_void_p]),
     "gte_gemm_p3_nt": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "gte_gemm_p3_nt_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                    c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "gte_gemm_p3_tn_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                    c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gte_gemm_p3_tn_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
     "gte_gemm_p3_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
@@ -161,7 +167,8 @@ class StepLayer(ctypes.Structure):
                 ("W", c_void_p), ("bias", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("relu", c_int),
                 ("gW", c_void_p), ("gbias", c_void_p), ("ggamma", c_void_p), ("gbeta", c_void_p),
                 ("wimg_fwd", c_void_p), ("ldp_wfwd", c_int64), ("wimg_bwd", c_void_p), ("ldp_wbwd", c_int64),
-                ("x", c_void_p), ("ldx", c_int64), ("hp", c_void_p), ("ldp_h", c_int64), ("make_hp", c_int),
+                ("x", c_void_p), ("ldx", c_int64), ("hp", c_void_p), ("ldp_h", c_int64), ("h_rows", c_void_p), ("n_res_rows", c_int64),
+                ("make_hp", c_int),
                 ("ahn", c_void_p), ("t", c_void_p), ("stats", c_void_p), ("y", c_void_p), ("yp", c_void_p), ("ldp_y", c_int64),
                 ("dy", c_void_p), ("dzp", c_void_p), ("qp", c_void_p), ("ldp_o", c_int64),
                 ("ws_ln", c_void_p), ("ws_ln_bytes", c_int64), ("ws_dw", c_void_p), ("ws_dw_bytes", c_int64)]

@@ -152,6 +152,7 @@ struct AssembleArgs {
     const float* feat; float* feat_out; int64_t n_cols;
     const float* label; float* label_out;
     int nb;
+    int32_t* row_map; int row_map_pad; int n_res;      // optional: resident row of every batch row (+ row_map_pad entries = n_res)
 };
 
 // 1-D grid: [0, feat_wgs): workgroup b moves the feature rows [b, b + 1) * rows_per_wg of the BATCH -- equal bytes per
@@ -175,13 +176,21 @@ batch_assemble_kernel(const AssembleArgs a, const int feat_wgs, const int rows_p
         return;
     }
     const int u = (int)blockIdx.x - feat_wgs;
-    const int i = u / 7, job = u % 7;                        // job 0: label; 1..3: in-edge CSR; 4..6: out-edge CSR
+    const int i = u / 7, job = u % 7;                        // job 0: label (+ row map); 1..3: in-edge CSR; 4..6: out-edge CSR
     const int p = a.pages[i];
     const int64_t r0 = a.node_off[p], n_i = a.node_off[p + 1] - r0;
     const int64_t o0 = a.b_node_off[i];
     if (job == 0) {
         if (a.label)
             copy_run<false>(reinterpret_cast<const uint32_t*>(a.label + r0), reinterpret_cast<uint32_t*>(a.label_out + o0), n_i, 0u, 0, 1);
+        if (a.row_map) {
+            // batch row o0 + r  <-  resident row r0 + r: the planes GEMMs read the resident feature image through this map
+            // instead of a per-batch copy of the rows; the entries past the batch name a row past the resident image
+            // (out of the GEMM's buffer window: zeros)
+            for (int64_t r = threadIdx.x; r < n_i; r += 256) a.row_map[o0 + r] = (int32_t)(r0 + r);
+            if (i == a.nb - 1)
+                for (int r = threadIdx.x; r < a.row_map_pad; r += 256) a.row_map[n_out + r] = a.n_res;
+        }
         return;
     }
     const gte_batch_arrays& g = a.dir[(job - 1) / 3];
@@ -204,18 +213,21 @@ batch_assemble_kernel(const AssembleArgs a, const int feat_wgs, const int rows_p
 }
 }  // namespace
 
-extern "C" int gte_batch_assemble(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,
-                                  const gte_batch_arrays* in_edges, const gte_batch_arrays* out_edges, const float* feat,
-                                  int64_t ld_feat, int64_t n_cols, float* feat_out, const float* label, float* label_out,
-                                  int64_t n_out, void* stream) {
-    if (n_batch <= 0 || n_batch > 65535 || n_out < 0 || n_cols <= 0 || n_out >= INT32_MAX)
+static int batch_assemble_impl(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,
+                               const gte_batch_arrays* in_edges, const gte_batch_arrays* out_edges, const float* feat,
+                               int64_t ld_feat, int64_t n_cols, float* feat_out, const float* label, float* label_out,
+                               int64_t n_out, void* stream, int32_t* row_map, int64_t row_map_pad, int64_t n_res) {
+    if (n_batch <= 0 || n_batch > 65535 || n_out < 0 || n_out >= INT32_MAX || (feat && n_cols <= 0))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_assemble: bad sizes");
-    if (!pages || !node_off || !b_node_off || !feat || !feat_out) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_assemble: null pointer");
-    if (ld_feat != n_cols) return gte::fail(GTE_ERR_UNSUPPORTED, "batch_assemble: resident features must be packed (ld == n_cols)");
+    if (!pages || !node_off || !b_node_off || ((feat == nullptr) != (feat_out == nullptr)) || (!feat && !row_map))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_assemble: null pointer");
+    if (feat && ld_feat != n_cols) return gte::fail(GTE_ERR_UNSUPPORTED, "batch_assemble: resident features must be packed (ld == n_cols)");
+    if (row_map && (row_map_pad < 0 || n_res < 0 || n_res > INT32_MAX)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_assemble: row map");
     if ((label == nullptr) != (label_out == nullptr)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_assemble: label / label_out");
     AssembleArgs a = {};
     a.pages = pages; a.node_off = node_off; a.b_node_off = b_node_off; a.nb = (int)n_batch;
     a.feat = feat; a.feat_out = feat_out; a.n_cols = n_cols; a.label = label; a.label_out = label_out;
+    a.row_map = row_map; a.row_map_pad = (int)row_map_pad; a.n_res = (int)n_res;
     const gte_batch_arrays* dirs[2] = {in_edges, out_edges};
     for (int d = 0; d < 2; ++d) {
         if (!dirs[d]) continue;
@@ -226,14 +238,36 @@ extern "C" int gte_batch_assemble(const int32_t* pages, int64_t n_batch, const i
     }
     if (n_out == 0) return GTE_OK;
     // ~32 KB of feature rows per workgroup (at least one row): ~2 500 workgroups for a 100-page batch of 831-wide rows
-    int64_t rows_per_wg = 32768 / (n_cols * 4);
+    int64_t rows_per_wg = feat ? 32768 / (n_cols * 4) : 1;
     if (rows_per_wg < 1) rows_per_wg = 1;
     static const int forced = getenv("GTE_ASSEMBLE_ROWS") ? atoi(getenv("GTE_ASSEMBLE_ROWS")) : 0;      // measurements only
     if (forced > 0) rows_per_wg = forced;
-    const int64_t feat_wgs = gte::ceil_div(n_out, rows_per_wg);
+    const int64_t feat_wgs = feat ? gte::ceil_div(n_out, rows_per_wg) : 0;
     hipLaunchKernelGGL(batch_assemble_kernel, dim3((unsigned)(feat_wgs + 7 * n_batch)), dim3(256), 0, gte::as_stream(stream), a,
                        (int)feat_wgs, (int)rows_per_wg, (int)n_out);
     return gte::check_launch("batch_assemble");
+}
+
+extern "C" int gte_batch_assemble(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,
+                                  const gte_batch_arrays* in_edges, const gte_batch_arrays* out_edges, const float* feat,
+                                  int64_t ld_feat, int64_t n_cols, float* feat_out, const float* label, float* label_out,
+                                  int64_t n_out, void* stream) {
+    if (!feat || !feat_out) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_assemble: null pointer");
+    return batch_assemble_impl(pages, n_batch, node_off, b_node_off, in_edges, out_edges, feat, ld_feat, n_cols, feat_out, label, label_out,
+                               n_out, stream, nullptr, 0, 0);
+}
+
+// ... with a ROW MAP instead of (feat == NULL) or next to the copied feature rows: row_map[r] = resident row of batch row r for
+// r < n_out, and row_map[n_out .. n_out + row_map_pad) = n_res_rows (a row past the resident matrix).  The planes GEMMs of the
+// input layer read the resident feature image through the map (gte_gemm_p3_nt_rows / gte_gemm_p3_tn_rows): a batch then costs
+// no feature traffic at all.
+extern "C" int gte_batch_assemble_rows(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,
+                                       const gte_batch_arrays* in_edges, const gte_batch_arrays* out_edges, const float* feat,
+                                       int64_t ld_feat, int64_t n_cols, float* feat_out, const float* label, float* label_out,
+                                       int64_t n_out, int32_t* row_map, int64_t row_map_pad, int64_t n_res_rows, void* stream) {
+    if (!row_map) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "batch_assemble_rows: null row map");
+    return batch_assemble_impl(pages, n_batch, node_off, b_node_off, in_edges, out_edges, feat, ld_feat, n_cols, feat_out, label, label_out,
+                               n_out, stream, row_map, row_map_pad, n_res_rows);
 }
 
 // ---- edge weights from word boxes -----------------------------------------------------------------

@@ -58,6 +58,10 @@ struct P3Gemm {
     int relu, accumulate;
     int splits, stages_per_split;                        // TN split-K over the rows
     float* slab;                                         // [splits][M][N] (ld = N) when splits > 1
+    // row maps (the input layer reads the RESIDENT feature image instead of a per-batch copy of its rows): NT: A1 is the
+    // resident image and row m of the product is its row rowsA[m]; TN: B is the resident image and k row k is its row rowsB[k]
+    // (entries past K name a row past the image).  res_bytes = size of the image (< 4 GB: 32-bit buffer offsets)
+    const int* rowsA; const int* rowsB; long long res_bytes;
 };
 
 
@@ -176,8 +180,9 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
     const int rowsA = min(BM, p.M - m0), rowsB = min(BN, p.N - n0);
 
     const int lda1 = (int)p.lda1, lda2 = (int)(p.A2 ? p.lda2 : p.lda1), ldb = (int)p.ldb;
-    const char* baseA1 = p.A1 + (long long)m0 * p.lda1;
+    const char* baseA1 = p.rowsA ? p.A1 : p.A1 + (long long)m0 * p.lda1;
     const char* baseA2 = p.A2 ? p.A2 + (long long)m0 * p.lda2 : baseA1;
+    const int recA1 = p.rowsA ? (int)(unsigned)p.res_bytes : rowsA * (int)p.lda1;     // window of segment 1
     const char* baseB = p.B + (long long)n0 * p.ldb;
     const long long bsa1 = p.bsa1, bsa2 = p.A2 ? p.bsa2 : p.bsa1, bsb = p.bsb;
 
@@ -194,6 +199,10 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
         isb[i] = b ? 1 : 0;
         vo1[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda1) + sp * 16;
         vo2[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda2) + sp * 16;
+        if (p.rowsA && !b && ii < N_INST) {             // row m0 + row of the product = row rowsA[.] of the resident image
+            const int rr = row < rowsA ? p.rowsA[m0 + row] : -1;
+            vo1[i] = rr < 0 ? (int)0xfffffff0u : (int)((unsigned)rr * (unsigned)lda1 + (unsigned)(sp * 16));
+        }
     });
     const int KB1 = p.KB1, T = p.KB1 + p.KB2;
     // the window of a stage: base moved to the stage's K block on the scalar unit, rows past the tile's valid rows (and every
@@ -203,7 +212,7 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
         const int live = t < T ? 1 : 0;
         const char* pa = seg ? baseA2 + (long long)(t - KB1) * bsa2 : baseA1 + (long long)t * bsa1;
         const __amdgpu_buffer_rsrc_t sa =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, rowsA * (seg ? lda2 : lda1) * live, SRD_FLAGS);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? rowsA * lda2 : recA1) * live, SRD_FLAGS);
         const __amdgpu_buffer_rsrc_t sb =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
         static_for<NI>([&](auto I) {
@@ -342,8 +351,9 @@ gemm_p3_nt_ring16_kernel(const P3Gemm p) {
     const int rowsA = min(BM, p.M - m0), rowsB = min(BN, p.N - n0);
 
     const int lda1 = (int)p.lda1, lda2 = (int)(p.A2 ? p.lda2 : p.lda1), ldb = (int)p.ldb;
-    const char* baseA1 = p.A1 + (long long)m0 * p.lda1;
+    const char* baseA1 = p.rowsA ? p.A1 : p.A1 + (long long)m0 * p.lda1;
     const char* baseA2 = p.A2 ? p.A2 + (long long)m0 * p.lda2 : baseA1;
+    const int recA1 = p.rowsA ? (int)(unsigned)p.res_bytes : rowsA * (int)p.lda1;     // window of segment 1
     const char* baseB = p.B + (long long)n0 * p.ldb;
     const long long bsa1 = p.bsa1, bsa2 = p.A2 ? p.bsa2 : p.bsa1, bsb = p.bsb;
 
@@ -364,7 +374,7 @@ gemm_p3_nt_ring16_kernel(const P3Gemm p) {
         const int live = t < T ? 1 : 0;
         const char* pa = seg ? baseA2 + (long long)(t - KB1) * bsa2 : baseA1 + (long long)t * bsa1;
         const __amdgpu_buffer_rsrc_t sa =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, rowsA * (seg ? lda2 : lda1) * live, SRD_FLAGS);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? rowsA * lda2 : recA1) * live, SRD_FLAGS);
         const __amdgpu_buffer_rsrc_t sb =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
         static_for<NI>([&](auto I) {
@@ -488,8 +498,9 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         const int lw = wave - NW;
         const int rowsA = min(BM, p.M - m0), rowsB = min(BN, p.N - n0);
         const int lda1 = (int)p.lda1, lda2 = (int)(p.A2 ? p.lda2 : p.lda1), ldb = (int)p.ldb;
-        const char* baseA1 = p.A1 + (long long)m0 * p.lda1;
+        const char* baseA1 = p.rowsA ? p.A1 : p.A1 + (long long)m0 * p.lda1;
         const char* baseA2 = p.A2 ? p.A2 + (long long)m0 * p.lda2 : baseA1;
+        const int recA1 = p.rowsA ? (int)(unsigned)p.res_bytes : rowsA * (int)p.lda1;     // window of segment 1
         const char* baseB = p.B + (long long)n0 * p.ldb;
         const long long bsa1 = p.bsa1, bsa2 = p.A2 ? p.bsa2 : p.bsa1, bsb = p.bsb;
         constexpr int OOB = 0x7f000000;
@@ -502,6 +513,10 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
             isb[i] = b ? 1 : 0;
             vo1[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda1) + sp * 16;
             vo2[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda2) + sp * 16;
+            if (p.rowsA && !b && ii < N_INST) {             // row m0 + row of the product = row rowsA[.] of the resident image
+                const int rr = row < rowsA ? p.rowsA[m0 + row] : -1;
+                vo1[i] = rr < 0 ? (int)0xfffffff0u : (int)((unsigned)rr * (unsigned)lda1 + (unsigned)(sp * 16));
+            }
         });
         const int KB1 = p.KB1;
         auto issue = [&](int t, char* buf) {
@@ -509,7 +524,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
             const int live = t < T ? 1 : 0;
             const char* pa = seg ? baseA2 + (long long)(t - KB1) * bsa2 : baseA1 + (long long)t * bsa1;
             const __amdgpu_buffer_rsrc_t sa =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, rowsA * (seg ? lda2 : lda1) * live, SRD_FLAGS);
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? rowsA * lda2 : recA1) * live, SRD_FLAGS);
             const __amdgpu_buffer_rsrc_t sb =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
             static_for<NI>([&](auto I) {
@@ -574,9 +589,10 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
 // WM x WN waves of 64 x 64 (TM = TN = 2): block tile (64 WM) x (64 WN).  4 x 2 waves (256 x 128, one workgroup per CU) take in
 // 23 bytes per cycle and CU at the full matrix rate against 32 for 2 x 2 (128 x 128, two workgroups per CU) at the same slab
 // bytes per CU: the operand tile of the 256-wide side is shared by eight waves.
-template <int WM, int WN, int WGS>
+template <int WM, int WN, int WGS, bool MAP = false>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN * WGS + 3) / 4)
 gemm_p3_tn_kernel(const P3Gemm p) {
+    static_assert(!MAP || (WM == 2 && WN == 2), "row map: the 128 x 128 tile");
     constexpr int NW = WM * WN, TM = 2, TN = 2;
     constexpr int BM = WM * 64, BN = WN * 64, NBA = BM / 16, NBB = BN / 16;        // 16-feature blocks per k row
     constexpr int RSA = NBA * 96, RSB = NBB * 96;                                  // k-row strides of the stage images
@@ -613,7 +629,7 @@ gemm_p3_tn_kernel(const P3Gemm p) {
     // operand's image: k row s / (6 NB), position block (s % (6 NB)) / 6, part s % 6; position block jb of row k holds the tile's
     // block (jb - 2 (k & 3)) mod NB (the four k rows of a transposing read then fall on disjoint banks)
     constexpr int OOB = 0x7f000000;
-    int vo[NI], isb[NI];
+    int vo[NI], isb[NI], kb[NI], vc[NI];
     static_for<NI>([&](auto I) {
         constexpr int i = decltype(I)::value;
         const int ii = i * NW + wave;
@@ -621,14 +637,61 @@ gemm_p3_tn_kernel(const P3Gemm p) {
         const int nb = b ? NBB : NBA;
         const int s = (b ? ii - A_INST : ii) * 64 + lane, k = s / (6 * nb), w = s - k * (6 * nb), jb = w / 6, part = w - jb * 6;
         const int fb = (jb - 2 * (k & 3)) & (nb - 1);
-        isb[i] = b ? 1 : 0;
+        isb[i] = (b && ii < N_INST) ? 1 : 0;            // (padding instructions: any window, offset out of range)
         vo[i] = ii >= N_INST ? OOB : k * (b ? ldb : lda) + fb * 96 + part * 16;
+        // B through a row map: the lane's slot lies in k row kb of the stage; it reads that row's resident id itself
+        kb[i] = k;
+        vc[i] = fb * 96 + part * 16;
     });
+    const int* rmap = p.rowsB;
+    int rid[3] = {0, 0, 0};                                    // resident rows of the next stage to be issued (this lane's slots)
+    if constexpr (MAP)
+        if (st_begin < st_end) {
+            rid[0] = rmap[st_begin * 16 + kb[3]];
+            rid[1] = rmap[st_begin * 16 + kb[4]];
+            rid[2] = rmap[st_begin * 16 + kb[5]];
+        }
     auto issue = [&](int st, char* buf) {
         const int k0 = st * 16;
         const int rows = st < st_end ? min(16, p.K - k0) : 0;
         const __amdgpu_buffer_rsrc_t sa =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Am + (long long)k0 * lda + coa), 0, max(rows * lda - coa, 0), SRD_FLAGS);
+        if constexpr (MAP) {                                   // (2 x 2 waves: instructions 0..2 of a wave are A, 3..5 are B)
+            {
+                static_assert(!MAP || (A_INST == 12 && NI == 6), "row map: 128 x 128 tile");
+                const int live = rows > 0 ? 1 : 0;
+                const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(Bm + cob), 0, (int)(unsigned)max(p.res_bytes - cob, 0ll) * live, SRD_FLAGS);
+                // the resident row ids of THIS stage were loaded while the previous stage was issued; the loads of the NEXT
+                // stage's ids go out first, so that they are older than this stage's LDS-DMA: when they are needed, the counted
+                // wait that lets stage st + 1 be issued has long covered them (a load placed after the DMA, or waited for at
+                // once -- a scalar load as much as a vector one --, stalls the issue by a memory latency per stage)
+                // The ids of THIS stage were requested by the previous issue(), ahead of its six LDS-DMA requests: vmcnt(6) covers
+                // them (in the loop the ring's counted wait has passed long ago).  The loads are inline assembly, with their wait
+                // here: left to the compiler, the loop-carried ids are copied at the END of a round -- behind a wait for the load
+                // just issued and everything older --, volatile loads become system-scope flat loads with vmcnt(0) each, and
+                // scalar loads stall the issue by their latency (all three measured / read off the ISA, profiles/r03/gemm_p3.md).
+                asm volatile("s_waitcnt vmcnt(6)" : "+v"(rid[0]), "+v"(rid[1]), "+v"(rid[2])::"memory");
+                const int o0 = (int)((unsigned)rid[0] * (unsigned)ldb + (unsigned)vc[3]);
+                const int o1 = (int)((unsigned)rid[1] * (unsigned)ldb + (unsigned)vc[4]);
+                const int o2 = (int)((unsigned)rid[2] * (unsigned)ldb + (unsigned)vc[5]);
+                const int kn = st + 1 < st_end ? k0 + 16 : 0;
+                const int* q0 = rmap + kn + kb[3];
+                const int* q1 = rmap + kn + kb[4];
+                const int* q2 = rmap + kn + kb[5];
+                asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
+                             : "=&v"(rid[0]), "=&v"(rid[1]), "=&v"(rid[2])
+                             : "v"(q0), "v"(q1), "v"(q2), "v"(o0), "v"(o1), "v"(o2)       // (o*: the old ids are consumed first)
+                             : "memory");
+                dma16(sa, buf + (0 * NW + wave) * 1024, vo[0]);
+                dma16(sa, buf + (1 * NW + wave) * 1024, vo[1]);
+                dma16(sa, buf + (2 * NW + wave) * 1024, vo[2]);
+                dma16(sb, buf + (3 * NW + wave) * 1024, o0);
+                dma16(sb, buf + (4 * NW + wave) * 1024, o1);
+                dma16(sb, buf + (5 * NW + wave) * 1024, o2);
+                return;
+            }
+        }
         const __amdgpu_buffer_rsrc_t sb =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Bm + (long long)k0 * ldb + cob), 0, max(rows * ldb - cob, 0), SRD_FLAGS);
         static_for<NI>([&](auto I) {
@@ -646,20 +709,33 @@ gemm_p3_tn_kernel(const P3Gemm p) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) b_rd[b] = A_BYTES + (8 * h + q) * RSB + ((2 * (wn * TN + b) + g + 2 * q) & (NBB - 1)) * 96 + pp * 8;
     using F = Frags<TM, TN>;
-    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-    auto tr_frag = [&](const char* at, int rs4) -> bf16x8 {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at + rs4));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-    };
-    auto read_frags = [&](F& f, const char* buf) {
-#pragma unroll
-        for (int pc = 2; pc >= 0; --pc) {
-#pragma unroll
-            for (int a = 0; a < TM; ++a) f.a[pc][a] = tr_frag(buf + a_rd[a] + pc * 32, 4 * RSA);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) f.b[pc][b] = tr_frag(buf + b_rd[b] + pc * 32, 4 * RSB);
-        }
+    // The reads are inline assembly: the compiler orders a ds_read_b64_tr_b16 it can see behind ALL LDS-DMA in flight
+    // (s_waitcnt vmcnt(0) -- it cannot tell which stage image the read touches), i.e. behind the two stages requested ahead: one
+    // memory latency per stage on the critical path.  The ring's own counted wait + barrier is the ordering that is needed.
+    typedef char __attribute__((address_space(3))) * lds_char;
+    const unsigned lds_base = (unsigned)(__SIZE_TYPE__)(lds_char)lds;
+    auto read_frags = [&](F& f, int slot) {
+        const unsigned sbase = lds_base + (unsigned)slot * STAGE;
+        static_for<3>([&](auto PC) {
+            constexpr int pc = 2 - decltype(PC)::value;
+            static_for<TM + TN>([&](auto X) {
+                constexpr int x = decltype(X)::value;
+                constexpr bool isb = x >= TM;
+                constexpr int lo_off = pc * 32, hi_off = pc * 32 + 4 * (isb ? RSB : RSA);
+                const unsigned at = sbase + (unsigned)(isb ? b_rd[isb ? x - TM : 0] : a_rd[isb ? 0 : x]);
+                s16x4 lo, hi;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(at), "n"(lo_off) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(at), "n"(hi_off) : "memory");
+                const bf16x8 v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                if constexpr (isb) f.b[pc][isb ? x - TM : 0] = v; else f.a[pc][isb ? 0 : x] = v;
+            });
+        });
+        static_assert(TM == 2 && TN == 2, "the wait below names the twelve fragments");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[2][0]), "+v"(f.a[2][1]),
+                       "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1]), "+v"(f.b[2][0]), "+v"(f.b[2][1])
+                     :
+                     : "memory");
     };
 
     f32x16 acc[TM][TN];
@@ -686,7 +762,7 @@ gemm_p3_tn_kernel(const P3Gemm p) {
         ++next;
         wr = wr + 1 == NBUF ? 0 : wr + 1;
         F f;
-        read_frags(f, lds + rd * STAGE);
+        read_frags(f, rd);
         products<TM, TN>(acc, f);
         wait_dma_barrier<(NBUF - 2) * NI>();
         rd = rd + 1 == NBUF ? 0 : rd + 1;
@@ -827,9 +903,9 @@ extern "C" int gte_p3_to_f32(const void* src, int64_t ldp, int64_t rows, int64_t
 
 // C[m, n] (+)= [a1 | a2] b^T (+ bias): a1 = P3 [m][k1], a2 = P3 [m][k2] (nullable, k2 = 0), b = P3 [n][ceil16(k1) + k2]
 // (the K blocks of the second segment follow the ceil(k1 / 16) blocks of the first in every row of b)
-extern "C" int gte_gemm_p3_nt(const void* a1, int64_t lda1, int64_t k1, const void* a2, int64_t lda2, int64_t k2, const void* b,
-                              int64_t ldb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
-                              int relu, int accumulate, void* stream) {
+static int gemm_p3_nt_impl(const void* a1, int64_t lda1, int64_t k1, const void* a2, int64_t lda2, int64_t k2, const void* b,
+                           int64_t ldb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
+                           int relu, int accumulate, void* stream, const int32_t* a_rows, int64_t n_res_rows) {
     if (m < 0 || n < 0 || k1 <= 0 || k2 < 0 || m > INT32_MAX || n > INT32_MAX || k1 + k2 > INT32_MAX)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt: bad sizes");
     if (m == 0 || n == 0) return GTE_OK;
@@ -845,7 +921,28 @@ extern "C" int gte_gemm_p3_nt(const void* a1, int64_t lda1, int64_t k1, const vo
     p.B = (const char*)b; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.bias_cols = (int)bias_cols;
     p.bsa1 = p.bsa2 = p.bsb = 96;
     p.M = (int)m; p.N = (int)n; p.relu = relu; p.accumulate = accumulate; p.splits = 1;
+    if (a_rows) {
+        if (k2 > 0) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_rows: one K segment only");
+        if (n_res_rows <= 0 || n_res_rows * lda1 >= ((int64_t)1 << 32) - 4096)
+            return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_rows: the resident image must be smaller than 4 GB (32-bit buffer offsets)");
+        p.rowsA = a_rows; p.res_bytes = n_res_rows * lda1;
+    }
     return launch_nt(p, gte::as_stream(stream));
+}
+
+extern "C" int gte_gemm_p3_nt(const void* a1, int64_t lda1, int64_t k1, const void* a2, int64_t lda2, int64_t k2, const void* b,
+                              int64_t ldb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
+                              int relu, int accumulate, void* stream) {
+    return gemm_p3_nt_impl(a1, lda1, k1, a2, lda2, k2, b, ldb, bias, bias_cols, c, ldc, m, n, relu, accumulate, stream, nullptr, 0);
+}
+
+// c[m, n] (+)= A b^T with A = the rows a_rows[0 .. m) of a RESIDENT P3 image a_res [n_res_rows][k]: the input layer's forward
+// transform straight from the resident features (no per-batch copy of the rows).  One K segment; the image < 4 GB.
+extern "C" int gte_gemm_p3_nt_rows(const void* a_res, int64_t ldpa, int64_t k, const int32_t* a_rows, int64_t n_res_rows, const void* b,
+                                   int64_t ldpb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
+                                   int relu, int accumulate, void* stream) {
+    if (!a_rows) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_rows: null row map");
+    return gemm_p3_nt_impl(a_res, ldpa, k, nullptr, 0, 0, b, ldpb, bias, bias_cols, c, ldc, m, n, relu, accumulate, stream, a_rows, n_res_rows);
 }
 
 namespace {
@@ -909,7 +1006,9 @@ int nt_choose(const P3Gemm& p) {
     return bi;
 }
 int launch_nt(const P3Gemm& p, hipStream_t s) {
-    switch (nt_choose(p)) {
+    int cfg = nt_choose(p);
+    if (p.rowsA && cfg >= 10) cfg = 4;            // (the 16 x 16 x 32 measurement variants do not take a row map)
+    switch (cfg) {
         case 10: launch_ring16<2, 4, 3, 2, 3, 1>(p, s); break;  // measurement: 192 x 256 on the 16 x 16 x 32 MFMA
         case 11: launch_ring16<2, 4, 2, 2, 3, 1>(p, s); break;  // 128 x 256
         case 12: launch_ring16<2, 2, 2, 2, 3, 2>(p, s); break;  // 128 x 128
@@ -951,9 +1050,9 @@ p3_fold_kernel(const float* __restrict__ slab, int splits, long long mn, int N, 
 }
 }  // namespace
 
-extern "C" int gte_gemm_p3_tn(const void* a, int64_t lda, const void* a2, int64_t lda2, const void* b, int64_t ldb, const void* b2,
-                              int64_t ldb2, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, void* workspace,
-                              int64_t workspace_bytes, void* stream) {
+static int gemm_p3_tn_impl(const void* a, int64_t lda, const void* a2, int64_t lda2, const void* b, int64_t ldb, const void* b2,
+                           int64_t ldb2, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, void* workspace,
+                           int64_t workspace_bytes, void* stream, const int32_t* b_rows, int64_t n_res_rows) {
     if (m <= 0 || n <= 0 || k < 0 || nseg < 0 || m > INT32_MAX || n > INT32_MAX || k > INT32_MAX || (nseg > 0 && n != 2 * nseg))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_tn: bad sizes");
     if (!a || !b || !c) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_tn: null pointer");
@@ -976,6 +1075,12 @@ extern "C" int gte_gemm_p3_tn(const void* a, int64_t lda, const void* a2, int64_
     p.B = (const char*)b; p.ldb = ldb; p.Bn2 = (const char*)b2; p.ldbn2 = ldb2;
     p.Nseg = (int)nseg; p.M = (int)m; p.N = (int)n; p.K = (int)k; p.C = c; p.ldc = ldc;
     p.splits = pl.splits; p.stages_per_split = pl.stages_per_split;
+    if (b_rows) {
+        if (b2 || tn_big(m)) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_tn_rows: one B image, 128 x 128 tiles");
+        if (n_res_rows <= 0 || (n_res_rows + 1) * ldb >= ((int64_t)1 << 32) - 4096)
+            return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_tn_rows: the resident image must be smaller than 4 GB (32-bit buffer offsets)");
+        p.rowsB = b_rows; p.res_bytes = n_res_rows * ldb;
+    }
     if (pl.splits > 1) {
         const int64_t need = (int64_t)pl.splits * m * n * 4;
         if (!workspace || workspace_bytes < need)
@@ -990,10 +1095,12 @@ extern "C" int gte_gemm_p3_tn(const void* a, int64_t lda, const void* a2, int64_
     if (!configured) {
         GTE_SET_LDS((gemm_p3_tn_kernel<4, 2, 1>), shm_big);
         GTE_SET_LDS((gemm_p3_tn_kernel<2, 2, 2>), shm_small);
+        GTE_SET_LDS((gemm_p3_tn_kernel<2, 2, 2, true>), shm_small);
         configured = true;
     }
     const dim3 grid((unsigned)(tiles * pl.splits));
     if (big) hipLaunchKernelGGL((gemm_p3_tn_kernel<4, 2, 1>), grid, dim3(512), shm_big, s, p);
+    else if (p.rowsB) hipLaunchKernelGGL((gemm_p3_tn_kernel<2, 2, 2, true>), grid, dim3(256), shm_small, s, p);
     else hipLaunchKernelGGL((gemm_p3_tn_kernel<2, 2, 2>), grid, dim3(256), shm_small, s, p);
     int rc = gte::check_launch("gemm_p3_tn");
     if (rc != GTE_OK || pl.splits <= 1) return rc;
@@ -1002,4 +1109,21 @@ extern "C" int gte_gemm_p3_tn(const void* a, int64_t lda, const void* a2, int64_
     hipLaunchKernelGGL(p3_fold_kernel, dim3((unsigned)gte::ceil_div(mn, 256)), dim3(256), 0, s, p.slab, pl.splits, (long long)mn, (int)n,
                        c, (long long)ldc);
     return gte::check_launch("gemm_p3_tn fold");
+}
+
+extern "C" int gte_gemm_p3_tn(const void* a, int64_t lda, const void* a2, int64_t lda2, const void* b, int64_t ldb, const void* b2,
+                              int64_t ldb2, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    return gemm_p3_tn_impl(a, lda, a2, lda2, b, ldb, b2, ldb2, nseg, c, ldc, m, n, k, workspace, workspace_bytes, stream, nullptr, 0);
+}
+
+// ... with b = the rows b_rows[0 .. k) of a RESIDENT P3 image b_res [n_res_rows][.] (the input layer's dW straight from the
+// resident features).  b_rows must hold k rounded up to 16, plus 1, entries; the entries past k = n_res_rows (a row past the
+// image: zeros).  Both column segments read the same image; the image < 4 GB.
+extern "C" int gte_gemm_p3_tn_rows(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, const void* b_res, int64_t ldpb,
+                                   const int32_t* b_rows, int64_t n_res_rows, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n,
+                                   int64_t k, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!b_rows) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_tn_rows: null row map");
+    return gemm_p3_tn_impl(a, ldpa, a2, ldpa2, b_res, ldpb, nullptr, 0, nseg, c, ldc, m, n, k, workspace, workspace_bytes, stream, b_rows,
+                           n_res_rows);
 }

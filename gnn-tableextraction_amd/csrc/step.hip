@@ -32,8 +32,12 @@ int forward(const gte_step_plan& p, void* st) {
             continue;
         }
         if (L.make_hp) GTE_TRY(gte_p3_from_f32(L.x, L.ldx, n, L.fin, 0, L.hp, L.ldp_h, st));
-        GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, nullptr, 0, 0, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * L.fout, n, 2 * L.fout,
-                               0, 0, st));
+        if (L.h_rows)
+            GTE_TRY(gte_gemm_p3_nt_rows(L.hp, L.ldp_h, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * L.fout,
+                                        n, 2 * L.fout, 0, 0, st));
+        else
+            GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, nullptr, 0, 0, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * L.fout, n,
+                                   2 * L.fout, 0, 0, st));
         GTE_TRY(gte_spmm_csr_accumulate_ln_p3(p.indptr, p.indices, p.w_in, L.t + L.fout, 2 * L.fout, L.t, 2 * L.fout, n, L.fout,
                                               GTE_REDUCE_MEAN, L.gamma, L.beta, L.eps, L.relu, L.y, L.fout, L.yp, L.ldp_y, L.stats, st));
     }
@@ -74,6 +78,9 @@ int backward_b(const gte_step_plan& p, void* st) {
     const gte_step_layer& L = p.layer[0];
     if (L.kind == GTE_LAYER_SMALLK)
         return gte_sage_linear_dw(L.dy, L.fout, L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.gW, 2 * L.fin, L.fout, n, L.ws_dw, L.ws_dw_bytes, st);
+    if (L.h_rows)
+        return gte_gemm_p3_tn_rows(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, L.h_rows, L.n_res_rows, L.fin, L.gW, 2 * L.fin, L.fout,
+                                   2 * L.fin, n, L.ws_dw, L.ws_dw_bytes, st);
     return gte_gemm_p3_tn(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, nullptr, 0, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n, L.ws_dw,
                           L.ws_dw_bytes, st);
 }

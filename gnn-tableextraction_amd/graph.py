@@ -17,11 +17,15 @@ the user set it; the CSR-ordered copies are cached per tensor version.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
 from . import _lib
+
+ROW_MAP_PAD = 33       # entries past a batch's row map that name the row past the resident image (gte_gemm_p3_tn_rows reads
+                       # the map up to k rounded up to 16, plus 1)
 
 
 class _FrameDict(dict):
@@ -403,7 +407,12 @@ class ResidentPages:
         if self.feat_p3 is None:
             from . import ops
             self.feat_p3 = ops.p3_from_f32(self.feat)
-        self.p3_mode = True
+        # "rows": a batch names its rows of the RESIDENT image through a row map (no copy of the image rows at all; the input
+        # layer's two GEMMs read the image through the map); "copy": the batch holds a copy of its image rows.  The map needs
+        # 32-bit byte offsets into the image.
+        rows_ok = self.feat_p3.data.numel() + self.feat_p3.ldp < (1 << 32) - 4096
+        want = os.environ.get("GTE_P3_ROWS", "1").lower() not in ("0", "off", "false")
+        self.p3_mode = "rows" if (rows_ok and want) else "copy"
 
     def disable_p3(self) -> None:
         """batches carry fp32 ``ndata['feat']`` again (the image stays cached for the next switch)"""
@@ -442,7 +451,9 @@ class ResidentPages:
                 "weight": [f32(max(int(cap_in), 1)) if self.weighted else None,
                            f32(max(int(cap_out), 1)) if self._sets["out"]["weight"] is not None else None],
                 "feat": None if self.p3_mode else f32(max(int(cap_nodes), 1), self.feat.shape[1]),
-                "feat_p3": torch.empty((max(int(cap_nodes), 1), self.feat_p3.ldp), dtype=torch.uint8, device=dev) if self.p3_mode else None,
+                "feat_p3": torch.empty((max(int(cap_nodes), 1), self.feat_p3.ldp), dtype=torch.uint8, device=dev)
+                if self.p3_mode == "copy" else None,
+                "feat_rows": i32(cap_nodes + ROW_MAP_PAD) if self.p3_mode == "rows" else None,
                 "label": None if self.label is None else f32(max(int(cap_nodes), 1), 1)}
 
     def assemble(self, meta_dev: torch.Tensor, nb: int, n_out: int, e_in: int, e_out: int, bufs: dict, n_sizes=None,
@@ -468,23 +479,35 @@ class ResidentPages:
             weights.append(wout)
         f = self.feat.shape[1]
         p3 = bufs.get("feat_p3") is not None
+        rows = bufs.get("feat_rows")
         lab = None if self.label is None else bufs["label"][:n_out]
         # ONE launch: features, labels, both CSRs and their weights (per-page contiguous runs, 16-byte accesses).  In image
         # mode a feature row is the ldp bytes of its P3 image, moved as ldp / 4 words.
         import ctypes
-        if p3:
+        if rows is not None:
+            fsrc, fld, fcols, fdst = None, 0, 0, None
+        elif p3:
             src, feat = self.feat_p3.data, bufs["feat_p3"]
             fsrc, fld, fcols, fdst = P(src), src.stride(0) // 4, src.stride(0) // 4, P(feat)
         else:
             feat = bufs["feat"][:n_out]
             fsrc, fld, fcols, fdst = P(self.feat), self.feat.stride(0), f, P(feat)
-        _lib.check(lib.gte_batch_assemble(P(pages), nb, P(self.node_off), P(b_node), ctypes.addressof(descs[0]),
-                                          ctypes.addressof(descs[1]), fsrc, fld, fcols, fdst,
-                                          P(self.label) or None, P(lab) or None, n_out, st), "gte_batch_assemble")
+        if rows is not None:
+            _lib.check(lib.gte_batch_assemble_rows(P(pages), nb, P(self.node_off), P(b_node), ctypes.addressof(descs[0]),
+                                                   ctypes.addressof(descs[1]), fsrc, fld, fcols, fdst,
+                                                   P(self.label) or None, P(lab) or None, n_out, P(rows), ROW_MAP_PAD, self.n_nodes, st),
+                       "gte_batch_assemble_rows")
+        else:
+            _lib.check(lib.gte_batch_assemble(P(pages), nb, P(self.node_off), P(b_node), ctypes.addressof(descs[0]),
+                                              ctypes.addressof(descs[1]), fsrc, fld, fcols, fdst,
+                                              P(self.label) or None, P(lab) or None, n_out, st), "gte_batch_assemble")
         g = ResidentBatch(n_out, e_in, csrs[0], csrs[1], weights[0], weights[1], self.device)
         if n_sizes is not None:
             g.batch_num_nodes_ = n_sizes.tolist() if hasattr(n_sizes, "tolist") else list(n_sizes)
-        if p3:
+        if rows is not None:
+            from . import ops
+            g.feat_p3 = ops.P3(self.feat_p3.data, n_out, f, row_map=rows, res_rows=self.n_nodes)
+        elif p3:
             from . import ops
             g.feat_p3 = ops.P3(feat, n_out, f)           # no ndata['feat']: a consumer that needs fp32 rows fails loudly
         else:

@@ -477,8 +477,10 @@ class FusedGcnSageStep(TrainStep):
         if kinds[0] == 0:
             if xp is not None:
                 L0.hp, L0.ldp_h, L0.make_hp, L0.x = P(xp.data), xp.ldp, 0, None
+                L0.h_rows, L0.n_res_rows = (P(xp.row_map), xp.res_rows) if xp.row_map is not None else (None, 0)
             else:
                 L0.hp, L0.ldp_h, L0.make_hp = P(b["hp"][0].data), b["hp"][0].ldp, 1
+                L0.h_rows, L0.n_res_rows = None, 0
                 L0.x, L0.ldx = P(x), ops._ld(x)
         else:
             if x is None:
@@ -616,8 +618,13 @@ class FusedGcnSageStep(TrainStep):
                 t = b["t"][i]
                 with timed("gemm_nt", 4.0 * n * fin * fout) as tm:
                     for _ in tm.repeat():
-                        check(lib.gte_gemm_p3_nt(P(hp_in.data), hp_in.ldp, fin, None, 0, 0, P(wf.data), wf.ldp, P(bias), fout, P(t),
-                                                 2 * fout, n, 2 * fout, 0, 0, st), "gte_gemm_p3_nt")
+                        if hp_in.row_map is not None:      # the RESIDENT image through the batch's row map
+                            check(lib.gte_gemm_p3_nt_rows(P(hp_in.data), hp_in.ldp, fin, P(hp_in.row_map), hp_in.res_rows, P(wf.data),
+                                                          wf.ldp, P(bias), fout, P(t), 2 * fout, n, 2 * fout, 0, 0, st),
+                                  "gte_gemm_p3_nt_rows")
+                        else:
+                            check(lib.gte_gemm_p3_nt(P(hp_in.data), hp_in.ldp, fin, None, 0, 0, P(wf.data), wf.ldp, P(bias), fout, P(t),
+                                                     2 * fout, n, 2 * fout, 0, 0, st), "gte_gemm_p3_nt")
                 nxt_planes = i + 1 < len(layers) and b["pl"][i + 1]
                 yp = b["hp"][i + 1] if nxt_planes else None
                 with timed("spmm_csr", 3.0 * n * fout * 4 + 8.0 * csr.indices.numel() + 4.0 * (n + 1)):
@@ -789,8 +796,13 @@ class FusedGcnSageStep(TrainStep):
                 wsp = b["ws_p3"][i]
                 with timed("gemm_tn", 4.0 * n * fin * fout) as tm:
                     for _ in tm.repeat():
-                        check(lib.gte_gemm_p3_tn(P(dzp.data), dzp.ldp, P(qp.data), qp.ldp, P(hp.data), hp.ldp, None, 0, fin, P(gW),
-                                                 2 * fin, fout, 2 * fin, n, P(wsp), wsp.numel(), st), "gte_gemm_p3_tn")
+                        if hp.row_map is not None:
+                            check(lib.gte_gemm_p3_tn_rows(P(dzp.data), dzp.ldp, P(qp.data), qp.ldp, P(hp.data), hp.ldp, P(hp.row_map),
+                                                          hp.res_rows, fin, P(gW), 2 * fin, fout, 2 * fin, n, P(wsp), wsp.numel(), st),
+                                  "gte_gemm_p3_tn_rows")
+                        else:
+                            check(lib.gte_gemm_p3_tn(P(dzp.data), dzp.ldp, P(qp.data), qp.ldp, P(hp.data), hp.ldp, None, 0, fin, P(gW),
+                                                     2 * fin, fout, 2 * fin, n, P(wsp), wsp.numel(), st), "gte_gemm_p3_tn")
                 if i > 0:
                     wb = self._wimg[i][1]
                     with timed("gemm_nn", 4.0 * n * fin * fout) as tm:

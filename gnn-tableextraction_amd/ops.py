@@ -541,10 +541,13 @@ def get_gemm_mode() -> int:
 # --------------------------------------------------------------------------------------------------
 class P3:
     """Device image of a logical fp32 matrix [rows][cols] in the P3 format: ``data`` is a uint8 tensor [rows_cap, ldp]."""
-    __slots__ = ("data", "rows", "cols")
+    __slots__ = ("data", "rows", "cols", "row_map", "res_rows")
 
-    def __init__(self, data: torch.Tensor, rows: int, cols: int):
-        self.data, self.rows, self.cols = data, rows, cols
+    def __init__(self, data: torch.Tensor, rows: int, cols: int, row_map: Optional[torch.Tensor] = None, res_rows: int = 0):
+        """``row_map`` (int32, rows rounded up to 16, plus 1, entries; the entries past ``rows`` = res_rows): the matrix is the
+        rows row_map[0 .. rows) of the RESIDENT image ``data`` [res_rows] -- what ResidentPages hands the input layer instead of
+        a per-batch copy (gte_gemm_p3_nt_rows / gte_gemm_p3_tn_rows)."""
+        self.data, self.rows, self.cols, self.row_map, self.res_rows = data, rows, cols, row_map, res_rows
 
     @property
     def ldp(self) -> int:
@@ -556,7 +559,13 @@ class P3:
         return P3(torch.empty((max(rows_cap or rows, 1), ldp), dtype=torch.uint8, device=device), rows, cols)
 
     def view_rows(self, rows: int) -> "P3":
-        return P3(self.data, rows, self.cols)
+        return P3(self.data, rows, self.cols, self.row_map, self.res_rows)
+
+    def gathered(self) -> "P3":
+        """a contiguous copy of a row-mapped image (tests)"""
+        if self.row_map is None:
+            return self
+        return P3(self.data[self.row_map[:self.rows].long()].contiguous(), self.rows, self.cols)
 
 
 def p3_from_f32(src: torch.Tensor, transpose: bool = False, out: Optional[P3] = None, row0: int = 0) -> P3:
@@ -575,6 +584,7 @@ def p3_from_f32(src: torch.Tensor, transpose: bool = False, out: Optional[P3] = 
 
 def p3_to_f32(img: P3) -> torch.Tensor:
     lib = _lib.load()
+    img = img.gathered()
     out = torch.empty((img.rows, img.cols), dtype=torch.float32, device=img.data.device)
     check(lib.gte_p3_to_f32(ptr(img.data), img.ldp, img.rows, img.cols, ptr(out), max(img.cols, 1), current_stream()), "gte_p3_to_f32")
     return out
@@ -587,6 +597,14 @@ def gemm_p3_nt(a1: P3, b: P3, a2: Optional[P3] = None, bias: Optional[torch.Tens
     m, n = a1.rows, b.rows
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a1.data.device)
+    if a1.row_map is not None:
+        if a2 is not None:
+            raise ValueError("gemm_p3_nt: a row-mapped operand takes one K segment")
+        with _timed("gemm_nt", 2.0 * m * n * a1.cols):
+            check(lib.gte_gemm_p3_nt_rows(ptr(a1.data), a1.ldp, a1.cols, ptr(a1.row_map), a1.res_rows, ptr(b.data), b.ldp, ptr(bias),
+                                          bias_cols, ptr(out), _ld(out), m, n, int(relu), int(accumulate), current_stream()),
+                  "gte_gemm_p3_nt_rows")
+        return out
     with _timed("gemm_nt", 2.0 * m * n * (a1.cols + (a2.cols if a2 is not None else 0))):
         check(lib.gte_gemm_p3_nt(ptr(a1.data), a1.ldp, a1.cols, ptr(a2.data) if a2 is not None else None,
                                  a2.ldp if a2 is not None else 0, a2.cols if a2 is not None else 0, ptr(b.data), b.ldp, ptr(bias),
@@ -604,6 +622,14 @@ def gemm_p3_tn(a: P3, b: P3, a2: Optional[P3] = None, b2: Optional[P3] = None, t
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.data.device)
     ws = _workspace(lib.gte_gemm_p3_tn_workspace_bytes(m, n, nseg, k), a.data.device, "gemm_p3")
+    if b.row_map is not None:
+        if b2 is not None:
+            raise ValueError("gemm_p3_tn: a row-mapped b is read by both segments")
+        with _timed("gemm_tn", 2.0 * m * n * k):
+            check(lib.gte_gemm_p3_tn_rows(ptr(a.data), a.ldp, ptr(a2.data) if a2 is not None else None, a2.ldp if a2 is not None else 0,
+                                          ptr(b.data), b.ldp, ptr(b.row_map), b.res_rows, nseg, ptr(out), _ld(out), m, n, k, ptr(ws),
+                                          ws.numel(), current_stream()), "gte_gemm_p3_tn_rows")
+        return out
     with _timed("gemm_tn", 2.0 * m * n * k):
         check(lib.gte_gemm_p3_tn(ptr(a.data), a.ldp, ptr(a2.data) if a2 is not None else None, a2.ldp if a2 is not None else 0,
                                  ptr(b.data), b.ldp, ptr(b2.data) if b2 is not None else None, b2.ldp if b2 is not None else 0,

@@ -312,10 +312,28 @@ int gte_gemm_p3_nt(const void* a1, int64_t ldpa1, int64_t k1, const void* a2, in
 /* c[m, n] = a^T b over k rows (dW = dZ^T X; split over the rows, partial slabs in `workspace`, folded in a fixed order --
  * inside an open fold deferral by gte_fold_defer_flush).  a: P3 [k][m], b: P3 [k][n].  nseg > 0: two column segments of
  * nseg columns (n == 2 nseg): c[:, 0:nseg] = a^T b, c[:, nseg:] = a2^T b2 (a2 / b2 NULL: the operand of segment 0). */
+/* ... with A = the rows a_rows[0 .. m) of a RESIDENT image a_res [n_res_rows][k] (one K segment; the image < 4 GB): the input
+ * layer's forward transform straight from the resident features -- no per-batch copy of the rows (gte_batch_assemble_rows
+ * writes the map). */
+int gte_gemm_p3_nt_rows(const void* a_res, int64_t ldpa, int64_t k, const int32_t* a_rows, int64_t n_res_rows, const void* b,
+                        int64_t ldpb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
+                        int relu, int accumulate, void* stream);
 int64_t gte_gemm_p3_tn_workspace_bytes(int64_t m, int64_t n, int64_t nseg, int64_t k);
 int gte_gemm_p3_tn(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, const void* b, int64_t ldpb, const void* b2,
                    int64_t ldpb2, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, void* workspace,
                    int64_t workspace_bytes, void* stream);
+
+/* gte_gemm_p3_tn with b = the rows b_rows[0 .. k) of a RESIDENT image b_res (the input layer's dW).  b_rows holds k rounded up
+ * to 16, plus 1, entries; the entries past k = n_res_rows (a row past the image reads as zeros).  Image < 4 GB. */
+int gte_gemm_p3_tn_rows(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, const void* b_res, int64_t ldpb,
+                        const int32_t* b_rows, int64_t n_res_rows, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n,
+                        int64_t k, void* workspace, int64_t workspace_bytes, void* stream);
+/* gte_batch_assemble with a ROW MAP instead of (feat == NULL) or next to the copied feature rows: row_map[r] = resident row of
+ * batch row r (r < n_out), row_map[n_out .. n_out + row_map_pad) = n_res_rows. */
+int gte_batch_assemble_rows(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,
+                            const gte_batch_arrays* in_edges, const gte_batch_arrays* out_edges, const float* feat,
+                            int64_t ld_feat, int64_t n_cols, float* feat_out, const float* label, float* label_out,
+                            int64_t n_out, int32_t* row_map, int64_t row_map_pad, int64_t n_res_rows, void* stream);
 
 /* ---- one optimisation step from a prepared plan -------------------------------------------------------------------------
  * replaces the batch loop body of model_train.py:320-332 (logits = model(g); loss; zero_grad; backward; optimizer.step())
@@ -339,6 +357,7 @@ typedef struct gte_step_layer {
     void* wimg_bwd; int64_t ldp_wbwd;      /* PLANES, layer > 0: P3 [fin][2 fout] = [W_s^T | W_n^T]         */
     const float* x; int64_t ldx;           /* fp32 input rows (SMALLK; PLANES layer 0 when hp must be made) */
     void* hp; int64_t ldp_h;               /* PLANES: P3 image of the input [n][fin]                        */
+    const int32_t* h_rows; int64_t n_res_rows;   /* PLANES layer 0: hp is the RESIDENT image, read through this row map */
     int make_hp;                           /* PLANES: 1 = convert x (fp32) into hp first                    */
     float* ahn;                            /* SMALLK: aggregated input [n][fin]                             */
     float* t;                              /* PLANES: [n][2 fout]; SMALLK: z [n][fout]                      */

@@ -1,0 +1,241 @@
+"""The planes GEMMs (csrc/gemm_p3.hip) and the P3 operand format (csrc/p3.h): a fp32 matrix kept as three bf16 planes made ONCE by
+its producer, multiplied as six bf16 MFMA partial products with fp32 accumulation -- the arithmetic of the split mode
+(tests/test_gemm_split.py) without the per-stage splitting.
+
+Checked on an MI355X through the C ABI:
+  * P3 round trip is exact (h + m + l == x bit for bit), transposed too, ragged shapes;
+  * NT (forward transform / dX) is BIT-IDENTICAL to the split kernel on the fp32 operands, on every tile configuration the chooser
+    can pick and on the ones it never picks (GTE_P3_NT_CFG);
+  * TN (dW, split-K) against fp64 in units of u = 2^-24 sum_k |a_k b_k|, not above the split kernel's;
+  * small-integer operands come out exact; bias / relu / accumulate keep their meaning;
+  * the ROW-MAP forms (gte_gemm_p3_nt_rows / gte_gemm_p3_tn_rows: the operand is a subset of the rows of a resident image) are
+    bit-identical to the GEMM on a gathered copy of those rows;
+  * non-finite and denormal-range operands: see the two tests at the end for what the six-product arithmetic guarantees.
+"""
+import numpy as np
+import pytest
+import torch
+
+from gnn_tableextraction_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def split_mode():
+    prev = ops.set_gemm_mode("split_bf16")
+    try:
+        yield
+    finally:
+        ops.set_gemm_mode(prev)
+
+
+def _wide(r, c, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return torch.randn(r, c, device=DEV, generator=g) * torch.exp(3 * torch.randn(r, c, device=DEV, generator=g))
+
+
+def _units(c, ref64, unit):
+    return float(((c.double() - ref64).abs() / unit.clamp_min(1e-300)).max())
+
+
+@pytest.mark.parametrize("r,c", [(5, 3), (300, 831), (1000, 256), (77, 16), (64, 17), (1, 1)])
+def test_p3_round_trip_is_exact(r, c):
+    x = _wide(r, c)
+    img = ops.p3_from_f32(x)
+    assert img.ldp == _lib.load().gte_p3_row_bytes(c) == 96 * ((c + 15) // 16)
+    assert torch.equal(ops.p3_to_f32(img), x)
+    assert torch.equal(ops.p3_to_f32(ops.p3_from_f32(x, transpose=True)), x.t())
+
+
+@pytest.mark.parametrize("m,n,k", [(100, 128, 16), (128, 128, 32), (300, 512, 831), (2000, 256, 256), (24437, 512, 831),
+                                   (24437, 512, 256), (777, 200, 50), (1, 16, 7), (4100, 48, 1030)])
+def test_nt_is_bitwise_the_split_kernel(split_mode, m, n, k):
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)
+    a, b = torch.randn(m, k, device=DEV, generator=g), torch.randn(n, k, device=DEV, generator=g)
+    bias = torch.randn(n, device=DEV, generator=g)
+    ap, bp = ops.p3_from_f32(a), ops.p3_from_f32(b)
+    got = ops.gemm_p3_nt(ap, bp)
+    want = ops.gemm(a, b, trans_b=True)
+    if (m, n, k) in ((300, 512, 831), (1, 16, 7), (4100, 48, 1030)):
+        # few tiles and a long K: the split kernel cuts K into slabs here (another summation order); a one-row product takes its
+        # small-problem path: same accuracy, other bits
+        ref, unit = a.double() @ b.double().t(), 2.0 ** -24 * (a.double().abs() @ b.double().abs().t())
+        assert _units(got, ref, unit) < 6.0 and _units(want, ref, unit) < 6.0
+        want = got.clone()
+    assert torch.equal(got, want)
+    # epilogue: bias on the first bias_cols columns, relu, accumulate
+    half = n // 2
+    gb = ops.gemm_p3_nt(ap, bp, bias=bias, bias_cols=half, relu=True)
+    wb = (want + torch.cat([bias[:half], torch.zeros(n - half, device=DEV)])).clamp_min(0)
+    assert torch.equal(gb, wb)
+    acc = torch.full((m, n), 0.5, device=DEV)
+    ops.gemm_p3_nt(ap, bp, out=acc, accumulate=True)
+    assert torch.equal(acc, want + 0.5)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+def test_every_nt_tile_configuration_gives_the_same_bits(split_mode, monkeypatch, cfg):
+    """The chooser picks one tile shape per problem; each shape, forced, gives the bits of the split kernel (ragged M and N)."""
+    g = torch.Generator(device=DEV).manual_seed(cfg)
+    a, b = torch.randn(3001, 363, device=DEV, generator=g), torch.randn(500, 363, device=DEV, generator=g)
+    want = ops.gemm(a, b, trans_b=True)
+    monkeypatch.setenv("GTE_P3_NT_CFG", str(cfg))
+    assert torch.equal(ops.gemm_p3_nt(ops.p3_from_f32(a), ops.p3_from_f32(b)), want)
+
+
+@pytest.mark.parametrize("m,n,k1,k2", [(500, 256, 256, 256), (24437, 256, 256, 256), (333, 100, 40, 24)])
+def test_nt_two_k_segments(m, n, k1, k2):
+    """dX = dz W_s + q W_n: A = [a1 | a2], segment 1 padded to whole 16-feature blocks in b."""
+    g = torch.Generator(device=DEV).manual_seed(k1)
+    a1, a2 = torch.randn(m, k1, device=DEV, generator=g), torch.randn(m, k2, device=DEV, generator=g)
+    w = torch.randn(n, k1 + k2, device=DEV, generator=g)
+    kb1 = -(-k1 // 16) * 16
+    full = torch.zeros(n, kb1 + k2, device=DEV)
+    full[:, :k1], full[:, kb1:] = w[:, :k1], w[:, k1:]
+    c = ops.gemm_p3_nt(ops.p3_from_f32(a1), ops.p3_from_f32(full), a2=ops.p3_from_f32(a2))
+    cat = torch.cat([a1, a2], 1).double()
+    ref, unit = cat @ w.double().t(), 2.0 ** -24 * (cat.abs() @ w.double().abs().t())
+    assert _units(c, ref, unit) < 6.0
+
+
+@pytest.mark.parametrize("m,n,k,two", [(256, 256, 64, False), (256, 831, 1000, False), (256, 256, 24437, True),
+                                       (256, 831, 24437, True), (100, 50, 333, False), (218, 63, 5000, True), (128, 13, 17, True)])
+def test_tn_against_fp64(split_mode, m, n, k, two):
+    g = torch.Generator(device=DEV).manual_seed(k)
+    a, b, a2 = (torch.randn(k, c, device=DEV, generator=g) for c in (m, n, m))
+    if two:
+        c = ops.gemm_p3_tn(ops.p3_from_f32(a), ops.p3_from_f32(b), a2=ops.p3_from_f32(a2), two_segments=True)
+        ref = torch.cat([a.double().t() @ b.double(), a2.double().t() @ b.double()], 1)
+        unit = 2.0 ** -24 * torch.cat([a.double().abs().t() @ b.double().abs(), a2.double().abs().t() @ b.double().abs()], 1)
+    else:
+        c = ops.gemm_p3_tn(ops.p3_from_f32(a), ops.p3_from_f32(b))
+        ref, unit = a.double().t() @ b.double(), 2.0 ** -24 * (a.double().abs().t() @ b.double().abs())
+    e = _units(c, ref, unit)
+    e_split = _units(ops.gemm(a, b, trans_a=True), ref[:, :n], unit[:, :n])
+    assert e < 12.0 and e <= 1.25 * e_split + 2.5, (e, e_split)
+
+
+def test_small_integers_are_exact():
+    g = torch.Generator(device=DEV).manual_seed(1)
+    a = torch.randint(-8, 9, (1000, 100), device=DEV, generator=g).float()
+    b = torch.randint(-8, 9, (300, 100), device=DEV, generator=g).float()
+    assert torch.equal(ops.gemm_p3_nt(ops.p3_from_f32(a), ops.p3_from_f32(b)).double(), a.double() @ b.double().t())
+    a = torch.randint(-8, 9, (1003, 200), device=DEV, generator=g).float()
+    b = torch.randint(-8, 9, (1003, 300), device=DEV, generator=g).float()
+    assert torch.equal(ops.gemm_p3_tn(ops.p3_from_f32(a), ops.p3_from_f32(b)).double(), a.double().t() @ b.double())
+
+
+# ---- row maps: the operand is a subset of the rows of a RESIDENT image -----------------------------------------------------
+def _row_map(n_res, rows, seed):
+    """page-like runs of consecutive resident rows, in shuffled order; padded as ResidentPages pads it"""
+    rng = np.random.default_rng(seed)
+    out, left = [], rows
+    while left > 0:
+        run = int(min(left, rng.integers(1, 400)))
+        start = int(rng.integers(0, n_res - run + 1))
+        out.append(np.arange(start, start + run))
+        left -= run
+    ids = np.concatenate(out).astype(np.int32)
+    pad = np.full(33, n_res, dtype=np.int32)
+    return torch.from_numpy(np.concatenate([ids, pad])).to(DEV)
+
+
+@pytest.mark.parametrize("rows,k,n", [(24437, 831, 512), (3000, 831, 512), (100, 363, 256), (1, 48, 256), (6001, 831, 256)])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 5, 6])
+def test_nt_through_a_row_map_is_bitwise_the_gathered_gemm(monkeypatch, rows, k, n, cfg):
+    if cfg is not None:
+        if rows != 3000:
+            pytest.skip("forced tile shapes: one problem size")
+        monkeypatch.setenv("GTE_P3_NT_CFG", str(cfg))
+    n_res = 40000
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    res = ops.p3_from_f32(torch.randn(n_res, k, device=DEV, generator=g))
+    w = ops.p3_from_f32(torch.randn(n, k, device=DEV, generator=g))
+    bias = torch.randn(n, device=DEV, generator=g)
+    rm = _row_map(n_res, rows, rows)
+    mapped = ops.P3(res.data, rows, k, row_map=rm, res_rows=n_res)
+    want = ops.gemm_p3_nt(mapped.gathered(), w, bias=bias, bias_cols=n // 2)
+    got = ops.gemm_p3_nt(mapped, w, bias=bias, bias_cols=n // 2)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("rows,k,m", [(24437, 831, 256), (3000, 831, 256), (100, 363, 128), (17, 48, 256), (6001, 831, 128)])
+def test_tn_through_a_row_map_is_bitwise_the_gathered_gemm(rows, k, m):
+    """dW0 = [dz^T X | q^T X] with X = mapped rows of the resident image; the rows past the map's end read as zeros."""
+    n_res = 40000
+    g = torch.Generator(device=DEV).manual_seed(rows + 1)
+    res = ops.p3_from_f32(torch.randn(n_res, k, device=DEV, generator=g))
+    dz, q = (ops.p3_from_f32(torch.randn(rows, m, device=DEV, generator=g)) for _ in range(2))
+    rm = _row_map(n_res, rows, rows + 1)
+    mapped = ops.P3(res.data, rows, k, row_map=rm, res_rows=n_res)
+    want = ops.gemm_p3_tn(dz, mapped.gathered(), a2=q, two_segments=True)
+    got = ops.gemm_p3_tn(dz, mapped, a2=q, two_segments=True)
+    assert torch.equal(got, want)
+    # last resident row in the map, one segment
+    rm2 = rm.clone()
+    rm2[0] = n_res - 1
+    mapped2 = ops.P3(res.data, rows, k, row_map=rm2, res_rows=n_res)
+    assert torch.equal(ops.gemm_p3_tn(dz, mapped2), ops.gemm_p3_tn(dz, mapped2.gathered()))
+
+
+def test_row_map_entry_points_validate():
+    lib = _lib.load()
+    z = torch.zeros(64, 96, dtype=torch.uint8, device=DEV)
+    c = torch.zeros(16, 16, device=DEV)
+    P = _lib.ptr
+    assert lib.gte_gemm_p3_nt_rows(P(z), 96, 16, None, 64, P(z), 96, None, 0, P(c), 16, 16, 16, 0, 0, None) == -1
+    rm = torch.zeros(64, dtype=torch.int32, device=DEV)
+    too_big = (1 << 32) // 96 + 1
+    assert lib.gte_gemm_p3_nt_rows(P(z), 96, 16, P(rm), too_big, P(z), 96, None, 0, P(c), 16, 16, 16, 0, 0, None) == -4
+    assert b"4 GB" in lib.gte_last_error()
+
+
+# ---- operands outside the comfortable range -------------------------------------------------------------------------------
+def test_non_finite_operands_poison_exactly_the_outputs_fp32_poisons(split_mode):
+    """inf cannot be cut into pieces (inf - inf is NaN) and 0 x inf appears among the six products, so an output that fp32
+    arithmetic makes +-inf or NaN comes out NaN here -- never a finite number; every output whose operands are all finite is
+    untouched (bit-identical to the GEMM without the poisoned rows)."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    a, b = torch.randn(300, 100, device=DEV, generator=g), torch.randn(256, 100, device=DEV, generator=g)
+    clean = ops.gemm_p3_nt(ops.p3_from_f32(a), ops.p3_from_f32(b))
+    a2 = a.clone()
+    a2[7, 3], a2[100, 50], a2[200, 99] = float("inf"), float("-inf"), float("nan")
+    got = ops.gemm_p3_nt(ops.p3_from_f32(a2), ops.p3_from_f32(b))
+    f32 = a2 @ b.t()
+    assert torch.equal(torch.isfinite(got), torch.isfinite(f32))
+    assert torch.isnan(got[[7, 100, 200]]).all()
+    keep = torch.ones(300, dtype=torch.bool, device=DEV)
+    keep[[7, 100, 200]] = False
+    assert torch.equal(got[keep], clean[keep])
+    # the same through the weight-gradient GEMM: a poisoned k row poisons every output
+    d = torch.randn(300, 128, device=DEV, generator=g)
+    tn = ops.gemm_p3_tn(ops.p3_from_f32(d), ops.p3_from_f32(a2))
+    assert not torch.isfinite(tn[:, [3, 50, 99]]).any() and torch.isfinite(tn[:, :3]).all()
+
+
+@pytest.mark.parametrize("e", [-20, -60, -100, -110, -126, -140])
+def test_small_magnitudes(split_mode, e):
+    """Operands scaled by 2^e against fp64.  The pieces keep fp32's exponent range, so down to |x| ~ 2^-110 the result has full
+    accuracy (units of u = 2^-24 sum |a_k b_k|); below that the low pieces (2^-16 |x|) fall under bf16's normal range 2^-126
+    and are flushed: the error is bounded by K x 2^-126 x 2^-7 x max|b| ABSOLUTE, which the test states.  fp32 denormal inputs
+    (e = -140) are flushed to zero by the conversion: the product is 0."""
+    g = torch.Generator(device=DEV).manual_seed(-e)
+    k = 256
+    a = torch.randn(200, k, device=DEV, generator=g) * 2.0 ** max(e, -126)
+    if e < -126:
+        a = a * 2.0 ** (e + 126)
+    b = torch.randn(128, k, device=DEV, generator=g)
+    c = ops.gemm_p3_nt(ops.p3_from_f32(a), ops.p3_from_f32(b))
+    ref = a.double() @ b.double().t()
+    unit = 2.0 ** -24 * (a.double().abs() @ b.double().abs().t())
+    err = (c.double() - ref).abs()
+    if e >= -100:
+        assert float((err / unit).max()) < 6.0
+    else:
+        # absolute: every piece below 2^-126 may be dropped: |x| 2^-8 at worst for the middle piece of an operand just above
+        # the flush threshold, i.e. <= 2^-126 per term
+        bound = k * 2.0 ** -126 * float(b.abs().max()) + 6.0 * unit
+        assert bool((err <= bound).all())
+    assert torch.isfinite(c).all()

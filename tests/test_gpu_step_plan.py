@@ -42,7 +42,8 @@ def _run(monkeypatch, c_step, f0, hid, weighted, n_pages=12, steps=3, resident=F
             y = torch.from_numpy(label).to(dev)
         outs.append(tr.step(g, y).cpu().numpy().copy())
     used = any(k for full in tr._bufs.values() for k in full.get("_plans", {}))
-    return np.stack(outs), tr.flat_param.detach().cpu().numpy(), tr.flat_grad.detach().cpu().numpy(), tr.exp_avg_sq.detach().cpu().numpy(), used
+    return (np.stack(outs), tr.flat_param.detach().cpu().numpy(), tr.flat_grad.detach().cpu().numpy(),
+            tr.exp_avg_sq.detach().cpu().numpy(), used, res.p3_mode if resident else None)
 
 
 @pytest.mark.parametrize("f0,hid,weighted,resident", [(831, 256, False, False), (831, 256, True, True), (13, 256, False, False),
@@ -57,6 +58,19 @@ def test_one_call_step_is_bitwise_the_call_by_call_step(monkeypatch, f0, hid, we
     for x, y in zip(a[:4], b[:4]):
         np.testing.assert_array_equal(x, y)
     assert np.isfinite(a[0]).all()
+
+
+@pytest.mark.parametrize("c_step", [True, False])
+def test_row_map_batches_are_bitwise_the_copied_image_batches(monkeypatch, c_step):
+    """ResidentPages in image mode hands the input layer a ROW MAP into the resident image (GTE_P3_ROWS, default) instead of a
+    copy of the batch's image rows: same bits after three steps, through the one-call step and the call-by-call schedule."""
+    monkeypatch.setenv("GTE_P3_ROWS", "1")
+    a = _run(monkeypatch, c_step, 831, 256, True, resident=True)
+    monkeypatch.setenv("GTE_P3_ROWS", "0")
+    b = _run(monkeypatch, c_step, 831, 256, True, resident=True)
+    for x, y in zip(a[:4], b[:4]):
+        np.testing.assert_array_equal(x, y)
+    assert a[5] == "rows" and b[5] == "copy"
 
 
 def test_step_plan_rejects_bad_plans():
