@@ -589,6 +589,9 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
 // WM x WN waves of 64 x 64 (TM = TN = 2): block tile (64 WM) x (64 WN).  4 x 2 waves (256 x 128, one workgroup per CU) take in
 // 23 bytes per cycle and CU at the full matrix rate against 32 for 2 x 2 (128 x 128, two workgroups per CU) at the same slab
 // bytes per CU: the operand tile of the 256-wide side is shared by eight waves.
+#ifndef P3_TN_ABL
+#define P3_TN_ABL 0       // measurement builds (profiles/debug/build_variant.sh): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no fragment reads
+#endif
 template <int WM, int WN, int WGS, bool MAP = false>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN * WGS + 3) / 4)
 gemm_p3_tn_kernel(const P3Gemm p) {
@@ -714,31 +717,84 @@ gemm_p3_tn_kernel(const P3Gemm p) {
     // memory latency per stage on the critical path.  The ring's own counted wait + barrier is the ordering that is needed.
     typedef char __attribute__((address_space(3))) * lds_char;
     const unsigned lds_base = (unsigned)(__SIZE_TYPE__)(lds_char)lds;
-    auto read_frags = [&](F& f, int slot) {
-        const unsigned sbase = lds_base + (unsigned)slot * STAGE;
-        static_for<3>([&](auto PC) {
-            constexpr int pc = 2 - decltype(PC)::value;
-            static_for<TM + TN>([&](auto X) {
-                constexpr int x = decltype(X)::value;
-                constexpr bool isb = x >= TM;
-                constexpr int lo_off = pc * 32, hi_off = pc * 32 + 4 * (isb ? RSB : RSA);
-                const unsigned at = sbase + (unsigned)(isb ? b_rd[isb ? x - TM : 0] : a_rd[isb ? 0 : x]);
-                s16x4 lo, hi;
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(at), "n"(lo_off) : "memory");
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(at), "n"(hi_off) : "memory");
-                const bf16x8 v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                if constexpr (isb) f.b[pc][isb ? x - TM : 0] = v; else f.a[pc][isb ? 0 : x] = v;
-            });
+    static_assert(TM == 2 && TN == 2, "the waits below name four fragments per plane pair");
+    // fragments of planes (pa of A, pb of B): eight reads
+    auto read_pair = [&](F& f, unsigned sbase, auto PA_, auto PB_) {
+        static_for<TM + TN>([&](auto X) {
+            constexpr int x = decltype(X)::value;
+            constexpr bool isb = x >= TM;
+            constexpr int pc = isb ? decltype(PB_)::value : decltype(PA_)::value;
+            constexpr int lo_off = pc * 32, hi_off = pc * 32 + 4 * (isb ? RSB : RSA);
+            const unsigned at = sbase + (unsigned)(isb ? b_rd[isb ? x - TM : 0] : a_rd[isb ? 0 : x]);
+            s16x4 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(at), "n"(lo_off) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(at), "n"(hi_off) : "memory");
+            const bf16x8 v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            if constexpr (isb) f.b[pc][isb ? x - TM : 0] = v; else f.a[pc][isb ? 0 : x] = v;
         });
-        static_assert(TM == 2 && TN == 2, "the wait below names the twelve fragments");
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[2][0]), "+v"(f.a[2][1]),
-                       "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1]), "+v"(f.b[2][0]), "+v"(f.b[2][1])
-                     :
-                     : "memory");
+    };
+    // s_waitcnt lgkmcnt(N) that the fragments of planes (pa, pb) pass through: their consumers stay behind it
+    auto wait_pair = [&](F& f, auto N_, auto PA_, auto PB_) {
+        constexpr int pa = decltype(PA_)::value, pb = decltype(PB_)::value;
+        if constexpr (decltype(N_)::value == 8)
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f.a[pa][0]), "+v"(f.a[pa][1]), "+v"(f.b[pb][0]), "+v"(f.b[pb][1])::"memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[pa][0]), "+v"(f.a[pa][1]), "+v"(f.b[pb][0]), "+v"(f.b[pb][1])::"memory");
+    };
+    f32x16 acc[TM][TN];
+    auto mfma_pair = [&](const F& f, auto PA_, auto PB_) {
+        constexpr int pa = decltype(PA_)::value, pb = decltype(PB_)::value;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[pa][a], f.b[pb][b], acc[a][b], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I8 = std::integral_constant<int, 8>;
+    // One stage: the six piece products in the order of products<>() (hl, lh, mm, hm, mh, hh), the 24 fragment reads interleaved
+    // so that a product starts as soon as ITS planes have arrived (8 of 24 reads) instead of after all of them: within a wave
+    // the LDS latency of a stage hides behind its own first MFMAs (the other wave of the SIMD covers the rest).
+    // lgkmcnt is a 4-bit counter: at most 16 reads in flight.
+    auto stage_products = [&](int slot) {
+        const unsigned sbase = lds_base + (unsigned)slot * STAGE;
+        F f;
+#if P3_TN_ABL & 4
+        static_for<3>([&](auto PC) { f.a[PC.value][0] = f.a[PC.value][1] = f.b[PC.value][0] = f.b[PC.value][1] = bf16x8{}; });
+        asm volatile("" : "+v"(f.a[0][0]), "+v"(f.b[0][0]));
+#else
+        read_pair(f, sbase, I0{}, I2{});
+        read_pair(f, sbase, I2{}, I0{});
+        wait_pair(f, I8{}, I0{}, I2{});
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#if !(P3_TN_ABL & 2)
+        mfma_pair(f, I0{}, I2{});                              // h l
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#if !(P3_TN_ABL & 4)
+        read_pair(f, sbase, I1{}, I1{});
+        wait_pair(f, I8{}, I2{}, I0{});
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#if !(P3_TN_ABL & 2)
+        mfma_pair(f, I2{}, I0{});                              // l h
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#if !(P3_TN_ABL & 4)
+        wait_pair(f, I0{}, I1{}, I1{});
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#if !(P3_TN_ABL & 2)
+        mfma_pair(f, I1{}, I1{});                              // m m
+        mfma_pair(f, I0{}, I1{});                              // h m
+        mfma_pair(f, I1{}, I0{});                              // m h
+        mfma_pair(f, I0{}, I0{});                              // h h
+#else
+        asm volatile("" ::"v"(f.a[0][0]), "v"(f.a[1][1]), "v"(f.a[2][0]), "v"(f.b[0][0]), "v"(f.b[1][1]), "v"(f.b[2][1]));
+#endif
+        __builtin_amdgcn_sched_barrier(0);                     // (the MFMAs are queued BEFORE the wave parks at the ring's barrier)
     };
 
-    f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -758,12 +814,12 @@ gemm_p3_tn_kernel(const P3Gemm p) {
     wait_dma_barrier<(NBUF - 2) * NI>();
     int rd = 0;
     for (int st = st_begin; st < st_end; ++st) {
+#if !(P3_TN_ABL & 1)
         issue(next, lds + wr * STAGE);
+#endif
         ++next;
         wr = wr + 1 == NBUF ? 0 : wr + 1;
-        F f;
-        read_frags(f, rd);
-        products<TM, TN>(acc, f);
+        stage_products(rd);
         wait_dma_barrier<(NBUF - 2) * NI>();
         rd = rd + 1 == NBUF ? 0 : rd + 1;
     }
@@ -840,6 +896,8 @@ TnPlan tn_plan(int64_t M, int64_t N, int64_t Nseg, int64_t K) {
     const int64_t stages = gte::ceil_div(K > 0 ? K : 1, 16);
     // fill the resident slots exactly or stay below (a straggler round costs a whole unit time); >= 8 stages per split
     int64_t splits = slots / tiles;
+    static const int forced = getenv("GTE_P3_TN_SPLITS") ? atoi(getenv("GTE_P3_TN_SPLITS")) : 0;       // (measurement)
+    if (forced > 0) splits = forced;
     if (splits > stages / 8) splits = stages / 8;
     if (splits < 1) splits = 1;
     TnPlan pl;

@@ -794,15 +794,28 @@ class FusedGcnSageStep(TrainStep):
                 if i == 0 and self.before_last_gemm is not None:
                     self.before_last_gemm()
                 wsp = b["ws_p3"][i]
-                with timed("gemm_tn", 4.0 * n * fin * fout) as tm:
-                    for _ in tm.repeat():
-                        if hp.row_map is not None:
-                            check(lib.gte_gemm_p3_tn_rows(P(dzp.data), dzp.ldp, P(qp.data), qp.ldp, P(hp.data), hp.ldp, P(hp.row_map),
-                                                          hp.res_rows, fin, P(gW), 2 * fin, fout, 2 * fin, n, P(wsp), wsp.numel(), st),
-                                  "gte_gemm_p3_tn_rows")
-                        else:
-                            check(lib.gte_gemm_p3_tn(P(dzp.data), dzp.ldp, P(qp.data), qp.ldp, P(hp.data), hp.ldp, None, 0, fin, P(gW),
-                                                     2 * fin, fout, 2 * fin, n, P(wsp), wsp.numel(), st), "gte_gemm_p3_tn")
+
+                def dw_planes(stream):
+                    if hp.row_map is not None:
+                        check(lib.gte_gemm_p3_tn_rows(P(dzp.data), dzp.ldp, P(qp.data), qp.ldp, P(hp.data), hp.ldp, P(hp.row_map),
+                                                      hp.res_rows, fin, P(gW), 2 * fin, fout, 2 * fin, n, P(wsp), wsp.numel(), stream),
+                              "gte_gemm_p3_tn_rows")
+                    else:
+                        check(lib.gte_gemm_p3_tn(P(dzp.data), dzp.ldp, P(qp.data), qp.ldp, P(hp.data), hp.ldp, None, 0, fin, P(gW),
+                                                 2 * fin, fout, 2 * fin, n, P(wsp), wsp.numel(), stream), "gte_gemm_p3_tn")
+                if self.overlap_dw and i > 0 and ops._timers is None:
+                    # an upper layer's dW beside the chain below it (dX, LayerNorm backward, transpose aggregation: two of the
+                    # three HBM-bound): nothing needs it before the folds
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    with torch.cuda.stream(self._side):
+                        self._side.wait_event(ev)
+                        dw_planes(self._side.cuda_stream)
+                    side_used = True
+                else:
+                    with timed("gemm_tn", 4.0 * n * fin * fout) as tm:
+                        for _ in tm.repeat():
+                            dw_planes(st)
                 if i > 0:
                     wb = self._wimg[i][1]
                     with timed("gemm_nn", 4.0 * n * fin * fout) as tm:

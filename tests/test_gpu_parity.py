@@ -20,6 +20,19 @@ from tests.conftest import GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["split_bf16", "f32"])
+def both_gemm_modes(request):
+    """The model-level parity tests run in BOTH arithmetic modes of the transform GEMMs: the default (three exact bf16 pieces per
+    operand, six bf16 MFMA products -- planes GEMMs on P3 images where a layer takes them) and the fp32 MFMA mode."""
+    from gnn_tableextraction_amd import ops as _ops
+    prev = _ops.set_gemm_mode(request.param)
+    try:
+        yield request.param
+    finally:
+        _ops.set_gemm_mode(prev)
+
+
 DEV = "cuda:0"
 GCN_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
                    if not os.path.basename(p).startswith(("meansage", "aux_", "headline")))
@@ -570,6 +583,7 @@ def load_model(z):
     return m.to(DEV), g
 
 
+@pytest.mark.usefixtures("both_gemm_modes")
 @pytest.mark.parametrize("name", GCN_CASES)
 def test_gcnsage_forward_matches_reference_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
@@ -590,6 +604,7 @@ def test_gcnsage_forward_matches_reference_golden(name):
     np.testing.assert_array_equal(l2, logits)
 
 
+@pytest.mark.usefixtures("both_gemm_modes")
 @pytest.mark.parametrize("name", GCN_CASES)
 def test_gcnsage_train_step_matches_reference_golden(name):
     """loss.backward() through the HIP autograd nodes + torch.optim.Adam, exactly as model_train.py:320-332
@@ -620,6 +635,7 @@ def test_gcnsage_train_step_matches_reference_golden(name):
         np.testing.assert_allclose(q.grad.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.usefixtures("both_gemm_modes")
 def test_meansage_matches_reference_golden():
     z = np.load(os.path.join(GOLDEN_DIR, "meansage_120.npz"))
     n, f0, hid, ncls, nl, _ = (int(v) for v in z["meta"])
@@ -663,6 +679,7 @@ def test_meansage_backward_matches_the_oracles_autograd():
     np.testing.assert_allclose(xd.grad.cpu().numpy(), r, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(r).max())
 
 
+@pytest.mark.usefixtures("both_gemm_modes")
 def test_batched_pages_vs_oracle_and_per_page_equivalence():
     """100-page batch (BASELINE cfg2 shape, F0=13): forward vs the CPU oracle; and batching must not
     change a page's logits (block-diagonal: no edge crosses pages)."""
@@ -731,6 +748,7 @@ def test_cfg4_full_size_tiled_equals_plain_and_properties():
 
 
 # ---------------------------------------------------------------- hand-scheduled step engine
+@pytest.mark.usefixtures("both_gemm_modes")
 @pytest.mark.parametrize("name", ["page200_f13_l3_cw", "page300_f831_l3", "batch5_hetero", "single_node", "tiny_6n_10e"])
 def test_fused_step_matches_reference_golden_and_autograd_path(name):
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep, TrainStep
@@ -762,6 +780,7 @@ def test_fused_step_matches_reference_golden_and_autograd_path(name):
     poststep.check_against_fixture(z, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, after)
 
 
+@pytest.mark.usefixtures("both_gemm_modes")
 def test_fused_step_graph_replay_is_bitwise_the_eager_step():
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
     pages = S.make_pages(12, in_feats=63)
@@ -906,6 +925,7 @@ def _page_graphs(pages, device="cpu"):
     return gs
 
 
+@pytest.mark.usefixtures("both_gemm_modes")
 def test_resident_batch_is_bitwise_the_host_batch():
     pages = S.make_pages(25, in_feats=63)
     res = G.ResidentPages(_page_graphs(pages), DEV)
@@ -1017,6 +1037,7 @@ def test_adam_inside_the_fold_launch_is_bitwise_the_separate_launch():
 
 
 # ---------------------------------------------------------------- the headline model at full width, whole model
+@pytest.mark.usefixtures("both_gemm_modes")
 def test_headline_shape_case_matches_reference_golden():
     """GcnSAGE(831, 256, 9, 3) on a 2 000-node graph against the reference's own vectors (trimmed fixture):
     forward through the module path at 1e-5, then ONE fused step (transform-first / q-form / fused head): loss 1e-5,
@@ -1043,6 +1064,7 @@ def test_headline_shape_case_matches_reference_golden():
     poststep.check_headline(z, logits, hidden[:3], float(out3[0]), grads, params, after, state0, oracle_after=ref_after)
 
 
+@pytest.mark.usefixtures("both_gemm_modes")
 def test_cfg2_primary_full_size_step_matches_the_oracle():
     """BASELINE configs[1] at FULL size -- 100 pages (~24.5 k nodes), F0 = 831, hidden 256, 3 layers -- as ONE model: the fused
     step of the train loop against the CPU oracle's step (OracleTrainer, itself pinned to the reference's golden vectors):
