@@ -898,7 +898,8 @@ TnPlan tn_plan(int64_t M, int64_t N, int64_t Nseg, int64_t K) {
     int64_t splits = slots / tiles;
     static const int forced = getenv("GTE_P3_TN_SPLITS") ? atoi(getenv("GTE_P3_TN_SPLITS")) : 0;       // (measurement)
     if (forced > 0) splits = forced;
-    if (splits > stages / 8) splits = stages / 8;
+    static const int min_stages = getenv("GTE_P3_TN_MIN_STAGES") ? atoi(getenv("GTE_P3_TN_MIN_STAGES")) : 8;
+    if (splits > stages / min_stages) splits = stages / min_stages;
     if (splits < 1) splits = 1;
     TnPlan pl;
     pl.splits_bound = (int)splits;
