@@ -492,6 +492,23 @@ def gather_probe(args, gte, S, dev):
 
     ms_plain = timed(None)
     ms = timed(plan)
+    # (ii) of SURVEY 8(d) cfg4: the backward pass of the same aggregation = a SUM over the OUT-edge CSR with the weights
+    # w / in_degree(dst) (d(norm * A_w h) / dh), same kernel family, its own tile plan
+    dst_t, src_t = torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev)
+    w_bwd = torch.from_numpy(w).to(dev) * ops.inv_degree(indptr)[dst_t.long()]
+    r_indptr, r_indices, _, r_w = ops.coo_to_csr(src_t, dst_t, n, w_bwd)
+    r_plan = ops.build_tile_plan(r_indptr, r_indices, n)
+    bwd_evs = []
+    for i in range(13):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        ops.spmm_csr(r_indptr, r_indices, r_w, x, n, mean=False, out=out, tiles=r_plan, force_tiled=True)
+        e_.record()
+        if i >= 3:
+            bwd_evs.append((s_, e_))
+    torch.cuda.synchronize()
+    bwd_ms = float(np.mean([s_.elapsed_time(e_) for s_, e_ in bwd_evs]))
+    del r_plan, r_indptr, r_indices, r_w, w_bwd
     # yardstick: a plain device copy of the same feature matrix into the same output (reads X once, writes out once --
     # the compulsory traffic of the aggregation minus the edge list)
     for _ in range(3):
@@ -533,6 +550,7 @@ def gather_probe(args, gte, S, dev):
             "plain_kernel_GBs": alg_bytes / (ms_plain * 1e-3) / 1e9, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms_per_pass": ms, "algorithmic_bytes": alg_bytes,
             "nodes_per_s_per_pass": n / (ms * 1e-3),
+            "bwd_ms_per_pass": bwd_ms, "bwd_GBs": alg_bytes / (bwd_ms * 1e-3) / 1e9, "bwd_frac": alg_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "device_copy_same_matrix_ms": copy_ms, "device_copy_GBs": 2.0 * n * f * 4 / (copy_ms * 1e-3) / 1e9,
             "full_layer_512_fwd_bwd_ms": layer_ms,
             "full_layer_nodes_per_s": (n / (layer_ms * 1e-3)) if layer_ms else None,

@@ -79,6 +79,11 @@ SIGNATURES = {
     "gte_ln_relu_bwd_p3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                    c_void_p, c_int64, c_void_p]),
+    "gte_sage_smallk_bwd_supported": (c_int, [c_int64, c_int64]),
+    "gte_sage_smallk_bwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "gte_sage_smallk_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                    c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gte_gemm_p3_nt": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "gte_gemm_p3_nt_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
@@ -88,6 +93,7 @@ SIGNATURES = {
     "gte_gemm_p3_tn_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
     "gte_gemm_p3_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_adam_ticket_bytes": (c_int64, []),
     "gte_gcnsage_step": (c_int, [c_void_p, c_int, POINTER(c_int), c_void_p]),
     "gte_fold_defer_begin": (c_int, [c_void_p]),
     "gte_fold_defer_flush": (c_int, []),

@@ -78,6 +78,10 @@ struct Frags { bf16x8 a[3][TM], b[3][TN]; };
 template <int TM, int TN>
 __device__ __forceinline__ void products(f32x16 (&acc)[TM][TN], const Frags<TM, TN>& f) {
     // the six piece products of a fragment pair, smallest terms first (0 = h, 1 = m, 2 = l): hl, lh, mm, hm, mh, hh
+#ifndef P3_ORDER
+#define P3_ORDER 0        // measurement builds: 1 = A fragment held over consecutive MFMAs, 2 = B fragment held
+#endif
+#if P3_ORDER == 0
     constexpr int PA[6] = {0, 2, 1, 0, 1, 0};
     constexpr int PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -87,6 +91,27 @@ __device__ __forceinline__ void products(f32x16 (&acc)[TM][TN], const Frags<TM, 
 #pragma unroll
             for (int b = 0; b < TN; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[q]][a], f.b[PB[q]][b], acc[a][b], 0, 0, 0);
+#elif P3_ORDER == 1
+    constexpr int PA[6] = {2, 1, 1, 0, 0, 0};
+    constexpr int PB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[q]][a], f.b[PB[q]][b], acc[a][b], 0, 0, 0);
+#else
+    constexpr int PA[6] = {0, 1, 0, 2, 1, 0};
+    constexpr int PB[6] = {2, 1, 1, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[q]][a], f.b[PB[q]][b], acc[a][b], 0, 0, 0);
+#endif
 }
 
 // Store epilogue of a wave's TM x TN accumulator tiles through a buffer descriptor over the output: rows past M and columns

@@ -64,12 +64,23 @@ __device__ __forceinline__ void adam_update(const AdamCoef& c, float& pi, float 
 }
 // End of a launch that applied one optimiser step: the LAST workgroup to finish advances the step count and the bias
 // corrections for the next step (every workgroup has read `state` before it takes its ticket).  bc in double.
+// Tickets are SHARDED: a device-scope atomic on one address retires every ~12 ns, and the fold + Adam launch has 1 000 - 1 600
+// workgroups that finish together (r03: 13 - 20 us of a 25 - 32 us launch were that queue).  Workgroup b takes a ticket of
+// shard b % 32 (its own 128-byte line); the workgroup that completes a shard takes one of the <= 32 top-level tickets.
+// `ticket` = gte_adam_ticket_bytes() bytes, zero-initialised, returned to zero.
+constexpr int kTicketShards = 32, kTicketStride = 32;        // (words: 128 bytes between counters)
 __device__ __forceinline__ void adam_advance(float* __restrict__ state, long long* __restrict__ step_counter,
                                              unsigned* __restrict__ ticket) {
     __syncthreads();                                         // the whole block is done with `state`
     if (threadIdx.x == 0) {
+        const unsigned nsh = gridDim.x < (unsigned)kTicketShards ? gridDim.x : (unsigned)kTicketShards;
+        const unsigned sh = blockIdx.x % nsh;
+        const unsigned members = (gridDim.x - sh + nsh - 1) / nsh;
+        unsigned* mine = ticket + (1 + sh) * kTicketStride;
+        if (atomicAdd(mine, 1u) != members - 1) return;
+        *mine = 0;
         const unsigned t = atomicAdd(ticket, 1u);
-        if (t == gridDim.x - 1) {
+        if (t == nsh - 1) {
             *ticket = 0;
             const long long done = *step_counter + 1;
             *step_counter = done;

@@ -97,7 +97,7 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
     if (d.vec == 4) {
         // four consecutive elements per thread, 16-byte loads; per element the same partial order as the scalar path
         const long long e = ((long long)((int)blockIdx.x - d.first_block) * epb + el) * 4;
-        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0, s6 = s0, s7 = s0;
         auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
         // contiguous, 16-byte aligned destination with the optimiser tail: the four elements' parameter and moments move as
         // 16-byte accesses, requested BEFORE the partials are streamed (one memory round trip less on the critical path)
@@ -115,6 +115,16 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
             const float* p = d.src + e;
             const long long st = d.stride * d.slices;
             int k = sl;
+            // eight partials in flight per thread: the launch lasts as long as its longest chain of dependent memory round
+            // trips (r03: 512 LayerNorm block partials in 16 slices were 8 rounds of four loads, ~2 us each)
+            for (; k + 7 * d.slices < d.count; k += 8 * d.slices) {
+                const float* pk = p + k * d.stride;
+                const float4 v0 = *reinterpret_cast<const float4*>(pk), v1 = *reinterpret_cast<const float4*>(pk + st),
+                             v2 = *reinterpret_cast<const float4*>(pk + 2 * st), v3 = *reinterpret_cast<const float4*>(pk + 3 * st),
+                             v4 = *reinterpret_cast<const float4*>(pk + 4 * st), v5 = *reinterpret_cast<const float4*>(pk + 5 * st),
+                             v6 = *reinterpret_cast<const float4*>(pk + 6 * st), v7 = *reinterpret_cast<const float4*>(pk + 7 * st);
+                add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3); add(s4, v4); add(s5, v5); add(s6, v6); add(s7, v7);
+            }
             for (; k + 3 * d.slices < d.count; k += 4 * d.slices) {
                 const float* pk = p + k * d.stride;
                 add(s0, *reinterpret_cast<const float4*>(pk));
@@ -125,6 +135,7 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
             for (; k < d.count; k += d.slices) add(s0, *reinterpret_cast<const float4*>(p + k * d.stride));
         }
         float4 t;
+        add(s0, s4); add(s1, s5); add(s2, s6); add(s3, s7);
         t.x = (s0.x + s1.x) + (s2.x + s3.x); t.y = (s0.y + s1.y) + (s2.y + s3.y);
         t.z = (s0.z + s1.z) + (s2.z + s3.z); t.w = (s0.w + s1.w) + (s2.w + s3.w);
         reinterpret_cast<float4*>(part)[threadIdx.x] = t;
@@ -157,6 +168,14 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
         const float* p = d.src + e;
         const long long st = d.stride * d.slices;
         int k = sl;
+        float s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+        for (; k + 7 * d.slices < d.count; k += 8 * d.slices) {
+            const float* pk = p + k * d.stride;
+            const float v0 = pk[0], v1 = pk[st], v2 = pk[2 * st], v3 = pk[3 * st], v4 = pk[4 * st], v5 = pk[5 * st], v6 = pk[6 * st],
+                        v7 = pk[7 * st];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
+        }
+        s0 += s4; s1 += s5; s2 += s6; s3 += s7;
         for (; k + 3 * d.slices < d.count; k += 4 * d.slices) {
             const float* pk = p + k * d.stride;
             s0 += pk[0]; s1 += pk[st]; s2 += pk[2 * st]; s3 += pk[3 * st];

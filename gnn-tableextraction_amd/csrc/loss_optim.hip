@@ -208,6 +208,8 @@ extern "C" int gte_adam_step(float* param, const float* grad, float* exp_avg, fl
     return gte::check_launch("adam_step");
 }
 
+extern "C" int64_t gte_adam_ticket_bytes(void) { return (int64_t)(1 + gte::kTicketShards) * gte::kTicketStride * 4; }
+
 extern "C" int gte_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                                  int64_t* step_counter, unsigned* ticket, void* stream) {
     if (n <= 0) return n == 0 ? gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev: n == 0 (nothing would advance the step)")

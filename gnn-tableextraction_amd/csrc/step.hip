@@ -23,11 +23,13 @@ int forward(const gte_step_plan& p, void* st) {
         const gte_step_layer& L = p.layer[i];
         if (L.kind == GTE_LAYER_SMALLK) {
             GTE_TRY(gte_spmm_csr(p.indptr, p.indices, p.w_in, L.x, L.ldx, L.ahn, L.fin, n, L.fin, GTE_F32, GTE_REDUCE_MEAN, st));
+            // (the one-pass backward recomputes z from the 2 fin inputs per row: nothing to save)
+            float* zs = gte_sage_smallk_bwd_supported(2 * L.fin, L.fout) ? nullptr : L.t;
             if (L.yp)          // the next layer's input image straight from this kernel (y itself is not needed then)
                 GTE_TRY(gte_sage_linear_fwd_p3(L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.eps, L.relu,
-                                               L.t, L.fout, L.stats, L.y, L.fout, L.yp, L.ldp_y, n, L.fout, st));
+                                               zs, L.fout, L.stats, L.y, L.fout, L.yp, L.ldp_y, n, L.fout, st));
             else
-                GTE_TRY(gte_sage_linear_fwd(L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.eps, L.relu, L.t,
+                GTE_TRY(gte_sage_linear_fwd(L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.eps, L.relu, zs,
                                             L.fout, L.stats, L.y, L.fout, n, L.fout, st));
             continue;
         }
@@ -57,9 +59,10 @@ int backward_a(const gte_step_plan& p, void* st) {
     for (int i = p.n_hidden - 1; i >= 0; --i) {
         const gte_step_layer& L = p.layer[i];
         if (L.kind == GTE_LAYER_SMALLK) {
-            GTE_TRY(gte_ln_relu_bwd(L.dy, L.fout, L.t, L.fout, L.stats, L.gamma, L.beta, L.relu, L.dy, L.fout, L.ggamma, L.gbeta, L.gbias, n,
-                                    L.fout, L.ws_ln, L.ws_ln_bytes, st));
-            continue;                                  // (layer 0: its dW is phase 2)
+            if (!gte_sage_smallk_bwd_supported(2 * L.fin, L.fout))
+                GTE_TRY(gte_ln_relu_bwd(L.dy, L.fout, L.t, L.fout, L.stats, L.gamma, L.beta, L.relu, L.dy, L.fout, L.ggamma, L.gbeta, L.gbias, n,
+                                        L.fout, L.ws_ln, L.ws_ln_bytes, st));
+            continue;                                  // (layer 0: its dW -- or its whole one-pass backward -- is phase 2)
         }
         GTE_TRY(gte_ln_relu_bwd_p3(L.dy, L.fout, L.t, 2 * L.fout, L.stats, L.gamma, L.beta, L.relu, L.dy, L.fout, L.dzp, L.ldp_o, L.ggamma,
                                    L.gbeta, L.gbias, n, L.fout, L.ws_ln, L.ws_ln_bytes, st));
@@ -76,6 +79,9 @@ int backward_a(const gte_step_plan& p, void* st) {
 int backward_b(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes;
     const gte_step_layer& L = p.layer[0];
+    if (L.kind == GTE_LAYER_SMALLK && gte_sage_smallk_bwd_supported(2 * L.fin, L.fout))
+        return gte_sage_smallk_bwd(L.dy, L.fout, L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.stats,
+                                   L.relu, L.gW, 2 * L.fin, L.gbias, L.ggamma, L.gbeta, n, L.fout, L.ws_dw, L.ws_dw_bytes, st);
     if (L.kind == GTE_LAYER_SMALLK)
         return gte_sage_linear_dw(L.dy, L.fout, L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.gW, 2 * L.fin, L.fout, n, L.ws_dw, L.ws_dw_bytes, st);
     if (L.h_rows)

@@ -236,7 +236,8 @@ class FusedGcnSageStep(TrainStep):
                                   dtype=torch.uint8, device=dev)
         # one private workspace per layer for the dW GEMMs: they run on the side stream, several at once
         b["ws_dw"] = [torch.empty(int(max(lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], cap),
-                                          lib.gte_sage_qform_dw_workspace_bytes(dims[i + 1], dims[i], cap))),
+                                          lib.gte_sage_qform_dw_workspace_bytes(dims[i + 1], dims[i], cap),
+                                          lib.gte_sage_smallk_bwd_workspace_bytes(cap, 2 * dims[i], dims[i + 1]) if i == 0 else 0)),
                                   dtype=torch.uint8, device=dev) for i in range(len(layers))]
         return b
 
@@ -367,6 +368,14 @@ class FusedGcnSageStep(TrainStep):
                 _lib.check(self.lib.gte_p3_from_f32_batch(ctypes.addressof(arr), len(chunk), st), "gte_p3_from_f32_batch")
 
     # -- the whole step as one host call (gte_gcnsage_step) ---------------------------------------------
+    def _smallk_bwd(self, i: int, layer, fin: int) -> bool:
+        """Layer 0 with a short input (BBOX features) and LayerNorm: forward in one pass (gte_sage_linear_fwd_fuses_ln) and the
+        whole backward in one pass (gte_sage_smallk_bwd); z is then never saved."""
+        return (i == 0 and isinstance(layer.lynorm, nn.LayerNorm) and layer.linear.bias is not None and not self.fuse_ln_below
+                and not self._transform_first(layer, fin) and not self._planes_layer(i, layer, fin, 1 << 20)
+                and bool(self.lib.gte_sage_linear_fwd_fuses_ln(2 * fin, layer.out_feats))
+                and bool(self.lib.gte_sage_smallk_bwd_supported(2 * fin, layer.out_feats)))
+
     def _plan_kinds(self, f0: int, n: int):
         """Layer kinds of the one-call step (gte_gcnsage_step) or None when the configuration needs the call-by-call path."""
         layers = list(self.model.layers)
@@ -679,16 +688,17 @@ class FusedGcnSageStep(TrainStep):
             if ln and lib.gte_sage_linear_fwd_fuses_ln(2 * fin, fout):
                 # short K (BBOX features, 13 + 13 inputs): linear + LayerNorm + ReLU in one pass over the rows; when the next
                 # layer is a planes layer its input image is written by the same pass (and y itself is not needed)
+                zs = None if self._smallk_bwd(i, L, fin) else P(b["z"][i])   # (the one-pass backward recomputes z)
                 if i + 1 < len(layers) and b["pl"][i + 1] and fout % 16 == 0:
                     yp = b["hp"][i + 1]
                     check(lib.gte_sage_linear_fwd_p3(P(h), ld(h), fin, P(ahn), fin, fin, P(W), 2 * fin, P(bias), P(L.lynorm.weight),
-                                                     P(L.lynorm.bias), float(L.lynorm.eps), int(relu), P(b["z"][i]), fout,
+                                                     P(L.lynorm.bias), float(L.lynorm.eps), int(relu), zs, fout,
                                                      P(b["stats"][i]), None, fout, P(yp.data), yp.ldp, n, fout, st),
                           "gte_sage_linear_fwd_p3")
                     h, hp_in = y, yp
                     continue
                 check(lib.gte_sage_linear_fwd(P(h), ld(h), fin, P(ahn), fin, fin, P(W), 2 * fin, P(bias), P(L.lynorm.weight),
-                                              P(L.lynorm.bias), float(L.lynorm.eps), int(relu), P(b["z"][i]), fout,
+                                              P(L.lynorm.bias), float(L.lynorm.eps), int(relu), zs, fout,
                                               P(b["stats"][i]), P(y), fout, n, fout, st), "gte_sage_linear_fwd")
                 h = y
                 continue
@@ -823,6 +833,16 @@ class FusedGcnSageStep(TrainStep):
                             check(lib.gte_gemm_p3_nt(P(dzp.data), dzp.ldp, fout, P(qp.data), qp.ldp, fout, P(wb.data), wb.ldp, None, 0,
                                                      P(b["dy"][i - 1]), fin, n, fin, 0, 0, st), "gte_gemm_p3_nt dX")
                 continue
+            if self._smallk_bwd(i, L, fin):
+                # short-input layer 0: LayerNorm(+ReLU) backward and dW in ONE pass over dy (z recomputed, dz never stored)
+                if self.before_last_gemm is not None:
+                    self.before_last_gemm()
+                wdw = b["ws_dw"][i]
+                check(lib.gte_sage_smallk_bwd(P(dy), fout, P(hin), ld(hin), fin, P(b["ahn"][i]), fin, fin, P(W), 2 * fin,
+                                              P(L.linear.bias), P(L.lynorm.weight), P(L.lynorm.bias), P(b["stats"][i]), int(relu),
+                                              P(gW), 2 * fin, P(gb), P(gg), P(gbe), n, fout, P(wdw), wdw.numel(), st),
+                      "gte_sage_smallk_bwd")
+                continue
             tfirst, qform = self._transform_first(L, fin), self._qform(i, L, fin)
             zsrc = b["t"][i] if tfirst else (b["z"][i] if ln else b["y"][i])
             # dz in place of dy; column sums straight into the flat gradient (unless the layer above already did it)
@@ -938,7 +958,7 @@ class FusedGcnSageStep(TrainStep):
             self._hyper_host = self._adam_host_state(1)
             self._hyper = torch.tensor(self._hyper_host, dtype=torch.float32, device=dev)
             self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-            self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._ticket = torch.zeros(int(self.lib.gte_adam_ticket_bytes()) // 4, dtype=torch.int32, device=dev)
             self._step_dev_host = 0                   # what the device counter holds (completed optimiser steps)
 
     def _sync_adam_state(self) -> None:

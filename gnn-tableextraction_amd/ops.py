@@ -302,6 +302,24 @@ def ln_relu_bwd(dy, z, stats, gamma, beta, relu: bool, dgamma, dbeta, dbias) -> 
     return dz
 
 
+def sage_smallk_bwd(dy, a1, a2, weight, bias, gamma, beta, stats, relu: bool, dW, dbias=None, dgamma=None, dbeta=None):
+    """LayerNorm(+ReLU) backward and dW = dz^T [a1 | a2] of the short-input INPUT layer in one pass (gte_sage_smallk_bwd): z is
+    recomputed from the inputs, dz is never stored.  ``stats`` = the forward's [mean | rstd]."""
+    lib = _lib.load()
+    dy, a1, weight = _row_major(dy), _row_major(a1), _row_major(weight)
+    m, n_out = dy.shape
+    k1 = a1.shape[1]
+    k2 = 0
+    if a2 is not None:
+        a2 = _row_major(a2)
+        k2 = a2.shape[1]
+    ws = _workspace(lib.gte_sage_smallk_bwd_workspace_bytes(m, k1 + k2, n_out), dy.device, "smallk_bwd")
+    check(lib.gte_sage_smallk_bwd(ptr(dy), _ld(dy), ptr(a1), _ld(a1), k1, ptr(a2), 0 if a2 is None else _ld(a2), k2, ptr(weight),
+                                  _ld(weight), ptr(bias), ptr(gamma), ptr(beta), ptr(stats), int(relu), ptr(dW), _ld(dW), ptr(dbias),
+                                  ptr(dgamma), ptr(dbeta), m, n_out, ptr(ws), ws.numel(), current_stream()), "gte_sage_smallk_bwd")
+    return dW
+
+
 def weighted_ce(logits: torch.Tensor, labels: torch.Tensor, class_weight: Optional[torch.Tensor] = None,
                 want_grad: bool = True, grad_scale: float = 1.0):
     """Returns (out3 = [loss, sum_w, n_correct] on the device, dlogits or None)."""

@@ -292,6 +292,17 @@ int gte_sage_linear_fwd_p3(const float* a1, int64_t lda1, int64_t k1, const floa
                            int64_t ldw, const float* bias, const float* gamma, const float* beta, float eps, int relu,
                            float* z_save, int64_t ldz, float* stats, float* y /* nullable */, int64_t ldy, void* yp3,
                            int64_t ldyp3, int64_t M, int64_t n_out, void* stream);   /* one-pass form only (fuses_ln) */
+/* Backward of the short-input layer (the layer gte_sage_linear_fwd runs in one pass: k1 + k2 <= 28 here) when it is the INPUT
+ * layer (no dX): LayerNorm(+ReLU) backward and dW = dz^T [a1 | a2] in ONE pass over dy.  z is recomputed from the 26 inputs
+ * per row with the forward kernel's instruction sequence (bit-identical: the forward need not save z -- pass z_save = NULL
+ * there), dz never reaches memory.  Replaces gte_ln_relu_bwd + gte_sage_linear_dw (models.py:63-66 autograd).
+ * dgamma / dbeta / dbias nullable.  The partial sums join an open fold deferral. */
+int gte_sage_smallk_bwd_supported(int64_t k_total, int64_t n_out);
+int64_t gte_sage_smallk_bwd_workspace_bytes(int64_t n_nodes, int64_t k_total, int64_t n_out);
+int gte_sage_smallk_bwd(const float* dy, int64_t lddy, const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2,
+                        int64_t k2, const float* W, int64_t ldw, const float* bias, const float* gamma, const float* beta,
+                        const float* stats, int relu, float* dW, int64_t lddw, float* dbias, float* dgamma, float* dbeta,
+                        int64_t n_nodes, int64_t n_out, void* workspace, int64_t workspace_bytes, void* stream);
 int gte_spmm_csr_p3(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x, int64_t ldx,
                     void* outp3, int64_t ldp, int64_t n_rows, int64_t n_feat, int reduce, void* stream);
 int gte_spmm_csr_accumulate_ln_p3(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x,
@@ -541,8 +552,10 @@ int gte_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * in a HIP graph.  state (8 floats, read AND advanced by the call) = {lr, beta1, beta2, eps, weight_decay, grad_scale,
  * bc1 = 1 - beta1^t, sqrt(bc2) = sqrt(1 - beta2^t)} for t = *step_counter + 1; the last block to finish sets
  * *step_counter = t and the two bias corrections for t + 1 (double arithmetic, like the host-scalar version).
- * `ticket` is one zero-initialised uint32 of scratch that the call returns to zero.  The caller initialises state and
- * counter consistently (and may rewrite lr at any time between launches). */
+ * `ticket` is gte_adam_ticket_bytes() bytes of zero-initialised scratch that the call returns to zero (sharded completion
+ * counters: one counter for a thousand workgroups is a 12 - 20 us queue).  The caller initialises state and counter
+ * consistently (and may rewrite lr at any time between launches). */
+int64_t gte_adam_ticket_bytes(void);
 int gte_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                       int64_t* step_counter, unsigned* ticket, void* stream);
 

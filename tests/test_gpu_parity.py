@@ -538,6 +538,62 @@ def test_ln_relu_bwd_vs_torch_autograd(m, n, ln, relu):
         np.testing.assert_allclose(db.cpu().numpy(), bet.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("m,k1,k2,n_out,relu", [(24495, 13, 13, 256, True), (1000, 13, 13, 256, False), (333, 9, 9, 128, True),
+                                                (65, 14, 14, 200, True), (7, 5, 0, 8, True), (64, 1, 1, 4, True), (4099, 8, 8, 64, True)])
+def test_smallk_input_layer_backward_in_one_pass(m, k1, k2, n_out, relu):
+    """gte_sage_smallk_bwd (z recomputed from the 2 F0 inputs, dz never stored) against fp64 autograd of
+    relu(LayerNorm([x | ahn] W^T + b)) and against the two-kernel path it replaces (gte_ln_relu_bwd + gte_sage_linear_dw on the
+    z the forward saved)."""
+    from gnn_tableextraction_amd import _lib
+    lib, P = _lib.load(), _lib.ptr
+    assert lib.gte_sage_smallk_bwd_supported(k1 + k2, n_out) == 1
+    rng = np.random.default_rng(m + n_out)
+    a1 = rng.standard_normal((m, k1)).astype(np.float32)
+    a2 = rng.standard_normal((m, k2)).astype(np.float32) if k2 else None
+    w = (rng.standard_normal((n_out, k1 + k2)) / np.sqrt(k1 + k2)).astype(np.float32)
+    b = rng.standard_normal(n_out).astype(np.float32)
+    gam = (1 + 0.1 * rng.standard_normal(n_out)).astype(np.float32)
+    bet = (0.1 * rng.standard_normal(n_out)).astype(np.float32)
+    dy = rng.standard_normal((m, n_out)).astype(np.float32)
+    # forward on the device (one-pass kernel; z saved only for the two-kernel comparison)
+    d1, d2, dw_, db_, dg_, dbe_, ddy = dev(a1), (None if a2 is None else dev(a2)), dev(w), dev(b), dev(gam), dev(bet), dev(dy)
+    z = torch.empty(m, n_out, device=DEV)
+    yd = torch.empty(m, n_out, device=DEV)
+    stats = torch.empty(2 * m, device=DEV)
+    st = _lib.current_stream()
+    _lib.check(lib.gte_sage_linear_fwd(P(d1), k1, k1, P(d2), k2, k2, P(dw_), k1 + k2, P(db_), P(dg_), P(dbe_), 1e-5, int(relu),
+                                       P(z), n_out, P(stats), P(yd), n_out, m, n_out, st), "fwd")
+    # ... and without saving z: same y and stats
+    y2, stats2 = torch.empty_like(yd), torch.empty_like(stats)
+    _lib.check(lib.gte_sage_linear_fwd(P(d1), k1, k1, P(d2), k2, k2, P(dw_), k1 + k2, P(db_), P(dg_), P(dbe_), 1e-5, int(relu),
+                                       None, n_out, P(stats2), P(y2), n_out, m, n_out, st), "fwd")
+    assert torch.equal(y2, yd) and torch.equal(stats2, stats)
+    # fp64 autograd, the ReLU mask taken from the device's forward (of ~6 M outputs a few lie within rounding of 0: their mask
+    # is the forward's to decide, and each one moves a whole row of dW by O(1))
+    cat = torch.from_numpy(a1 if a2 is None else np.concatenate([a1, a2], 1)).double()
+    W64, b64 = torch.from_numpy(w).double().requires_grad_(True), torch.from_numpy(b).double().requires_grad_(True)
+    g64, be64 = torch.from_numpy(gam).double().requires_grad_(True), torch.from_numpy(bet).double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(torch.nn.functional.linear(cat, W64, b64), (n_out,), g64, be64, 1e-5)
+    if relu:
+        y = y * (yd > 0).double().cpu()
+    y.backward(torch.from_numpy(dy).double())
+    gW = torch.full((n_out, k1 + k2), 7.0, device=DEV)
+    gb, gg, gbe = (torch.full((n_out,), 7.0, device=DEV) for _ in range(3))
+    ops.sage_smallk_bwd(ddy, d1, d2, dw_, db_, dg_, dbe_, stats, relu, gW, gb, gg, gbe)
+    scale = lambda t: float(t.abs().max())
+    np.testing.assert_allclose(gW.cpu().numpy(), W64.grad.numpy(), rtol=1e-4, atol=1e-5 * scale(W64.grad) + 1e-6)
+    np.testing.assert_allclose(gb.cpu().numpy(), b64.grad.numpy(), rtol=1e-4, atol=1e-5 * scale(b64.grad) + 1e-6)
+    np.testing.assert_allclose(gg.cpu().numpy(), g64.grad.numpy(), rtol=1e-4, atol=1e-5 * scale(g64.grad) + 1e-6)
+    np.testing.assert_allclose(gbe.cpu().numpy(), be64.grad.numpy(), rtol=1e-4, atol=1e-5 * scale(be64.grad) + 1e-6)
+    # the two-kernel path on the saved z: same dz values (same arithmetic), sums in another order
+    dg2, db2, dbias2 = (torch.zeros(n_out, device=DEV) for _ in range(3))
+    dz = ops.ln_relu_bwd(ddy, z, stats, dg_, dbe_, relu, dg2, db2, dbias2)
+    gW2 = ops.sage_linear_dw(dz, d1, d2, torch.empty(n_out, k1 + k2, device=DEV))
+    np.testing.assert_allclose(gW.cpu().numpy(), gW2.cpu().numpy(), rtol=2e-5, atol=2e-6 * scale(gW2) + 1e-7)
+    np.testing.assert_allclose(gg.cpu().numpy(), dg2.cpu().numpy(), rtol=2e-5, atol=2e-6 * scale(dg2) + 1e-7)
+    np.testing.assert_allclose(gb.cpu().numpy(), dbias2.cpu().numpy(), rtol=2e-5, atol=2e-6 * scale(dbias2) + 1e-7)
+
+
 # ---------------------------------------------------------------- loss + optimiser
 @pytest.mark.parametrize("n,c,weighted,float_labels", [(1, 9, False, False), (1000, 9, True, False),
                                                        (7777, 9, False, True), (300, 13, True, True)])
