@@ -86,6 +86,11 @@ SIGNATURES = {
                                     c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gte_gemm_p3_nt": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "gte_gemm_p3_nt_ln_bwd_supported": (c_int, [c_int64]),
+    "gte_gemm_p3_nt_ln_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "gte_gemm_p3_nt_ln_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gte_gemm_p3_nt_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                     c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "gte_gemm_p3_tn_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
@@ -195,7 +200,7 @@ class StepPlan(ctypes.Structure):
                 ("wimg_descs", c_void_p), ("n_wimg_descs", c_int),
                 ("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n_param", c_int64),
                 ("hyper", c_void_p), ("step_counter", c_void_p), ("ticket", c_void_p),
-                ("tail_ws", c_void_p), ("tail_ws_bytes", c_int64)]
+                ("tail_ws", c_void_p), ("tail_ws_bytes", c_int64), ("fuse_ln_dx", c_int)]
 
 
 class BatchArrays(ctypes.Structure):

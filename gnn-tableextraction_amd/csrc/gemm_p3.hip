@@ -62,6 +62,11 @@ struct P3Gemm {
     // resident image and row m of the product is its row rowsA[m]; TN: B is the resident image and k row k is its row rowsB[k]
     // (entries past K name a row past the image).  res_bytes = size of the image (< 4 GB: 32-bit buffer offsets)
     const int* rowsA; const int* rowsB; long long res_bytes;
+    // LayerNorm(+ReLU) backward as the epilogue of an NT product whose tile holds whole rows (N <= 256): the product is
+    // dy = d(loss) / d(y of the layer below), never stored; the workgroup writes dz = LN'(z)(mask . dy) as fp32 and as a P3 image
+    // and leaves the column partials {sum g xhat, sum g, sum dz} in ln_part[tile][3][N]  (gte_gemm_p3_nt_ln_bwd)
+    const float* ln_z; long long ln_ldz; const float* ln_stats; const float* ln_gamma; const float* ln_beta; int ln_relu;
+    float* ln_dz; long long ln_lddz; char* ln_dzp3; long long ln_ldp3; float* ln_part;
 };
 
 
@@ -71,6 +76,8 @@ struct P3Gemm {
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t srd, char* dst, int voffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)dst, 16, voffset, 0, 0, 0);
 }
+
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 
 template <int TM, int TN>
 struct Frags { bf16x8 a[3][TM], b[3][TN]; };
@@ -498,7 +505,7 @@ gemm_p3_nt_ring16_kernel(const P3Gemm p) {
 // instructions, in order, in front of its MFMAs: 21 of 97 us on the layer-0 forward (profiles/r03/gemm_p3.md, ablation "no
 // DMA").  A loader wave's stream is: request stage t + 2, wait until stage t + 1 has landed (counted vmcnt), barrier; a compute
 // wave's: 3 (TM + TN) fragment reads, 6 TM TN MFMAs, barrier.  One barrier per stage for all waves.
-template <int WM, int WN, int TM, int TN, int NL>
+template <int WM, int WN, int TM, int TN, int NL, bool LNB = false>
 __global__ void __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL + 3) / 4)
 gemm_p3_nt_lw_kernel(const P3Gemm p) {
     constexpr int NW = WM * WN, NBUF = 3;
@@ -604,8 +611,97 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         rd = rd + 1 == NBUF ? 0 : rd + 1;
     }
-    store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
-                       p.accumulate, lane);
+    if constexpr (!LNB) {
+        store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
+                           p.accumulate, lane);
+    } else {
+        // ---- LayerNorm(+ReLU) backward of the tile's rows (the loader waves have left; the stage images are dead) ----
+        // Per slice of TM * 32 rows: the waves that own them put their accumulators into LDS row-major, then every wave takes
+        // rows of the slice in the layout of ln_relu_bwd_vec_kernel (lane l = columns 4 l .. 4 l + 3, two rows in flight) with
+        // ITS arithmetic: dz is bit for bit what the separate launch computes from the stored product.
+        static_assert(BN == 256 && TN == 2, "whole rows per workgroup");
+        constexpr int SR = TM * 32, LDT = 256;                        // slice rows; floats per LDS row
+        float* tile = reinterpret_cast<float*>(lds);
+        const int n = p.N, M = p.M;
+        const int j4 = 4 * lane;
+        const bool okc = j4 < n;
+        float gam[4], bet[4], s_dg[4], s_db[4], s_dbias[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gam[e] = okc ? p.ln_gamma[j4 + e] : 1.f;
+            bet[e] = okc ? p.ln_beta[j4 + e] : 0.f;
+            s_dg[e] = s_db[e] = s_dbias[e] = 0.f;
+        }
+        const float inv_n = 1.0f / (float)n;
+        const int col_l = lane & 31, hrow = (lane >> 5) * 4;
+        for (int sl = 0; sl < WM; ++sl) {
+            asm volatile("s_barrier" ::: "memory");                    // the previous slice's readers are done
+            if (wm == sl) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            tile[(a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * LDT + wn * 64 + b * 32 + col_l] = acc[a][b][r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int row_base = m0 + sl * SR;
+            for (int rl = wave; rl < SR; rl += 2 * NW) {
+                float gy[2][4], zz[2][4], mean[2], rstd[2];
+                bool rok[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int rloc = rl + u * NW, rg = row_base + rloc;
+                    rok[u] = rloc < SR && rg < M;
+                    const int rc = rok[u] ? rg : min(row_base, M - 1);
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bz = a;
+                    if (okc) {
+                        if (rok[u]) a = *reinterpret_cast<const float4*>(tile + rloc * LDT + j4);
+                        const f4u zt = *reinterpret_cast<const f4u*>(p.ln_z + (long long)rc * p.ln_ldz + j4);
+                        bz = make_float4(zt.x, zt.y, zt.z, zt.w);
+                    }
+                    gy[u][0] = a.x; gy[u][1] = a.y; gy[u][2] = a.z; gy[u][3] = a.w;
+                    zz[u][0] = bz.x; zz[u][1] = bz.y; zz[u][2] = bz.z; zz[u][3] = bz.w;
+                    mean[u] = p.ln_stats[rc]; rstd[u] = p.ln_stats[M + rc];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!rok[u]) continue;                              // wave-uniform
+                    const long long rg = row_base + rl + u * NW;
+                    float xh[4], g[4];
+                    float a = 0.f, b = 0.f;
+                    gte_ln_bwd_pre4(gy[u], zz[u], mean[u], rstd[u], gam, bet, okc, p.ln_relu, xh, g, a, b);
+                    const float c1 = gte_group_sum<64>(a) * inv_n, c2 = gte_group_sum<64>(b) * inv_n;
+                    float d[4];
+                    gte_ln_bwd_post4(g, xh, gam, rstd[u], c1, c2, okc, d, s_dg, s_db, s_dbias);
+                    if (okc) {
+                        f4u o; o.x = d[0]; o.y = d[1]; o.z = d[2]; o.w = d[3];
+                        *reinterpret_cast<f4u*>(p.ln_dz + rg * p.ln_lddz + j4) = o;
+                        if (p.ln_dzp3) p3::store4(p.ln_dzp3 + rg * p.ln_ldp3, j4, d[0], d[1], d[2], d[3]);
+                    }
+                }
+            }
+        }
+        // column partials of the workgroup: the eight waves through LDS, added in wave order
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float* red = reinterpret_cast<float*>(lds);                    // [NW][3][256]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(wave * 3 + 0) * 256 + j4 + e] = s_dg[e];
+            red[(wave * 3 + 1) * 256 + j4 + e] = s_db[e];
+            red[(wave * 3 + 2) * 256 + j4 + e] = s_dbias[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float* pp = p.ln_part + (long long)lb * 3 * n;
+        for (int i = tid; i < 3 * 256; i += NW * 64) {
+            const int q = i >> 8, j = i & 255;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[(w * 3 + q) * 256 + j];
+            if (j < n) pp[q * n + j] = v;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1054,6 +1150,19 @@ void launch_lw(const P3Gemm& p, hipStream_t s) {
     const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
     hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
+template <int WM, int WN, int TM, int TN, int NL>
+void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int NI = ((BM + BN) * 96 / 1024 + NL - 1) / NL, shm = 3 * NI * NL * 1024;
+    static_assert(shm >= TM * 32 * 256 * 4 && shm >= WM * WN * 3 * 256 * 4, "the epilogue's row slice lives in the stage images");
+    static bool configured = false;
+    if (!configured) {
+        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, true>), shm);
+        configured = true;
+    }
+    const dim3 grid((unsigned)gte::ceil_div(p.M, BM));
+    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, true>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
+}
 // Configurations (measured on the step's shapes, profiles/r03/gemm_p3.md): the kernel runs at the chip's power limit
 // (~1.3 PF bf16 whatever the tile), so what matters is ONE balanced round of tiles: the row tile is the smallest of
 // 128 / 160 / 192 / 224 / 256 that covers M with at most one tile per CU; N is cut in 256-column tiles.
@@ -1108,6 +1217,78 @@ int launch_nt(const P3Gemm& p, hipStream_t s) {
     return gte::check_launch("gemm_p3_nt");
 }
 }  // namespace
+
+// ---- the NT product with the LayerNorm(+ReLU) backward of the layer below as its epilogue ------------------------------
+namespace {
+int lnb_row_tile(int64_t m) { return gte::ceil_div(m, 128) <= gte::device_props().cus ? 128 : 192; }
+// out[j] = sum_k part[k * stride + j]   (only when no fold deferral is open)
+__global__ void __launch_bounds__(256)
+p3_colsum_fold_kernel(const float* __restrict__ part, long long stride, int count, int n, float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < count; ++k) s += part[k * stride + j];
+    out[j] = s;
+}
+}
+extern "C" int gte_gemm_p3_nt_ln_bwd_supported(int64_t n) { return (n >= 4 && n <= 256 && n % 4 == 0) ? 1 : 0; }
+extern "C" int64_t gte_gemm_p3_nt_ln_bwd_workspace_bytes(int64_t m, int64_t n) {
+    if (m <= 0 || n <= 0) return 256;
+    return gte::round_up(gte::ceil_div(m, lnb_row_tile(m)) * 3 * n * 4, 256);
+}
+// dy = [a1 | a2] b^T (m x n, n <= 256: a workgroup's tile holds whole rows) is NOT stored: the workgroup that computed a row
+// block runs the LayerNorm(+ReLU) backward of those rows on it -- dz = LN'(z)(mask . dy) as fp32 (feeds the transpose
+// aggregation) and as a P3 image (dzp3 nullable; feeds the layer's dW / dX GEMMs) -- and the column sums dgamma / dbeta / dbias
+// (each nullable) join the fold deferral.  Same arithmetic as gte_gemm_p3_nt + gte_ln_relu_bwd_p3: dz is bit-identical.
+extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, const void* a2, int64_t lda2, int64_t k2, const void* b,
+                                     int64_t ldb, const float* z, int64_t ldz, const float* stats, const float* gamma,
+                                     const float* beta, int relu, float* dz, int64_t lddz, void* dzp3, int64_t ldp3, float* dgamma,
+                                     float* dbeta, float* dbias, int64_t m, int64_t n, void* workspace, int64_t workspace_bytes,
+                                     void* stream) {
+    if (m < 0 || n <= 0 || k1 <= 0 || k2 < 0 || m > INT32_MAX || k1 > INT32_MAX || k2 > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: bad sizes");
+    if (!gte_gemm_p3_nt_ln_bwd_supported(n)) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_bwd: needs n <= 256, n %% 4 == 0");
+    if (m == 0) return GTE_OK;
+    if (!a1 || !b || !z || !stats || !gamma || !beta || !dz || !workspace || (k2 > 0 && !a2))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: null pointer");
+    const int64_t kb1 = p3::blocks(k1), kb2 = k2 > 0 ? p3::blocks(k2) : 0;
+    if (lda1 < p3::row_bytes(k1) || (k2 > 0 && lda2 < p3::row_bytes(k2)) || ldb < (kb1 + kb2) * 96 || ldz < n || lddz < n ||
+        (dzp3 && (ldp3 < p3::row_bytes(n) || ldp3 % 16 != 0)))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: leading dimension too small");
+    if (lda1 >= (1 << 23) || lda2 >= (1 << 23) || ldb >= (1 << 23) || (m + 256) * lda1 >= ((int64_t)1 << 31) ||
+        (k2 > 0 && (m + 256) * lda2 >= ((int64_t)1 << 31)))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_bwd: operand images must be < 2 GB with row strides < 8 MB");
+    const int64_t need = gte_gemm_p3_nt_ln_bwd_workspace_bytes(m, n);
+    if (workspace_bytes < need)
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "gemm_p3_nt_ln_bwd: needs %lld workspace bytes, got %lld", (long long)need,
+                         (long long)workspace_bytes);
+    P3Gemm p = {};
+    p.A1 = reinterpret_cast<const char*>(a1); p.lda1 = lda1; p.KB1 = (int)kb1;
+    p.A2 = k2 > 0 ? reinterpret_cast<const char*>(a2) : nullptr; p.lda2 = lda2; p.KB2 = (int)kb2;
+    p.B = reinterpret_cast<const char*>(b); p.ldb = ldb;
+    p.bsa1 = p.bsa2 = p.bsb = 96;
+    p.M = (int)m; p.N = (int)n; p.splits = 1;
+    p.ln_z = z; p.ln_ldz = ldz; p.ln_stats = stats; p.ln_gamma = gamma; p.ln_beta = beta; p.ln_relu = relu;
+    p.ln_dz = dz; p.ln_lddz = lddz; p.ln_dzp3 = reinterpret_cast<char*>(dzp3); p.ln_ldp3 = ldp3;
+    p.ln_part = reinterpret_cast<float*>(workspace);
+    hipStream_t s = gte::as_stream(stream);
+    const int bm = lnb_row_tile(m);
+    if (bm == 128) launch_lw_lnb<2, 4, 2, 2, 4>(p, s); else launch_lw_lnb<2, 4, 3, 2, 4>(p, s);
+    int rc = gte::check_launch("gemm_p3_nt_ln_bwd");
+    if (rc != GTE_OK) return rc;
+    const int nb = (int)gte::ceil_div(m, bm);
+    if (gte::defer_fold(p.ln_part, 3 * n, nb, 1, (int)n, dgamma, n)) {
+        gte::defer_fold(p.ln_part + n, 3 * n, nb, 1, (int)n, dbeta, n);
+        gte::defer_fold(p.ln_part + 2 * n, 3 * n, nb, 1, (int)n, dbias, n);
+        return GTE_OK;
+    }
+    float* outs[3] = {dgamma, dbeta, dbias};
+    for (int i = 0; i < 3; ++i)
+        if (outs[i])
+            hipLaunchKernelGGL(p3_colsum_fold_kernel, dim3((unsigned)gte::ceil_div(n, 256)), dim3(256), 0, s, p.ln_part + i * n,
+                               (long long)3 * n, nb, (int)n, outs[i]);
+    return gte::check_launch("gemm_p3_nt_ln_bwd fold");
+}
 
 extern "C" int64_t gte_gemm_p3_tn_workspace_bytes(int64_t m, int64_t n, int64_t nseg, int64_t k) {
     if (m <= 0 || n <= 0) return 256;

@@ -137,3 +137,38 @@ __device__ __forceinline__ float gte_quad_bcast(float v) {
     return __builtin_bit_cast(float, gte_quad_bcast<T>(__builtin_bit_cast(int, v)));
 }
 
+
+// ---- LayerNorm(+ReLU) backward of four columns of one row (device) ------------------------------------------------------------
+// Shared by ln_relu_bwd_vec_kernel (sage_linear.hip) and the LayerNorm-backward epilogue of the planes NT GEMM (gemm_p3.hip): the
+// same instruction sequence at both call sites (explicit fmaf, contraction off for everything else), so the fused launch is bit
+// for bit the two launches.  pre: xhat, masked gradient g and this lane's share of the two row sums; post (after the row sums
+// c1 = mean(dxhat), c2 = mean(dxhat xhat) are known): dz and the column partials.
+__device__ __forceinline__ void gte_ln_bwd_pre4(const float (&gy)[4], const float (&zz)[4], float mean, float rstd, const float (&gam)[4],
+                                                const float (&bet)[4], bool okc, int relu, float (&xh)[4], float (&g)[4], float& a,
+                                                float& b) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xh[e] = okc ? (zz[e] - mean) * rstd : 0.f;
+        float gv = gy[e];
+        if (relu && fmaf(xh[e], gam[e], bet[e]) <= 0.f) gv = 0.f;
+        g[e] = gv;
+        const float dxh = gv * gam[e];
+        a = a + dxh;
+        b = fmaf(dxh, xh[e], b);
+    }
+}
+__device__ __forceinline__ void gte_ln_bwd_post4(const float (&g)[4], const float (&xh)[4], const float (&gam)[4], float rstd, float c1,
+                                                 float c2, bool okc, float (&d)[4], float (&s_dg)[4], float (&s_db)[4],
+                                                 float (&s_dbias)[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t0 = g[e] * gam[e];
+        const float t1 = xh[e] * c2;
+        d[e] = rstd * ((t0 - c1) - t1);
+        s_dg[e] = fmaf(g[e], xh[e], s_dg[e]);
+        s_db[e] = s_db[e] + g[e];
+        s_dbias[e] = s_dbias[e] + (okc ? d[e] : 0.f);
+    }
+}

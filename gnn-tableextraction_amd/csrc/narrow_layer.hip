@@ -780,7 +780,8 @@ int narrow_blocks(int64_t n) {
 // partial behind (written here, read again by the fold): at 512 workgroups that was 14 MB of extra traffic on a 50 MB
 // kernel; measured per step 0.773 (512) / 0.766 (384) / 0.761 (256) / 0.769 ms (192).
 int narrow_mfma_blocks(int64_t n) {
-    const int cap = gte::device_props().cus < NB_MAX ? gte::device_props().cus : NB_MAX;
+    static const int forced = getenv("GTE_NARROW_BLOCKS") ? atoi(getenv("GTE_NARROW_BLOCKS")) : 0;      // (measurement)
+    const int cap = forced > 0 && forced <= NB_MAX ? forced : (gte::device_props().cus < NB_MAX ? gte::device_props().cus : NB_MAX);
     const int64_t b = gte::ceil_div(n, 32);
     return (int)(b < cap ? b : cap);
 }

@@ -1165,28 +1165,13 @@ ln_relu_bwd_vec_kernel(const float* __restrict__ dy, int64_t lddy, const float* 
                 float xh[NV][4], g[NV][4];
                 float a = 0.f, b = 0.f;
 #pragma unroll
-                for (int v = 0; v < NV; ++v)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        xh[v][e] = okv[v] ? (zz[u][v][e] - mean[u]) * rstd[u] : 0.f;
-                        float gv = gy[u][v][e];
-                        if (relu && ln_affine(xh[v][e], gam[v][e], bet[v][e]) <= 0.f) gv = 0.f;
-                        g[v][e] = gv;
-                        const float dxh = gv * gam[v][e];
-                        a += dxh;
-                        b = fmaf(dxh, xh[v][e], b);
-                    }
+                for (int v = 0; v < NV; ++v)                 // (gte_common.h: the arithmetic shared with the GEMM epilogue form)
+                    gte_ln_bwd_pre4(gy[u][v], zz[u][v], mean[u], rstd[u], gam[v], bet[v], okv[v], relu, xh[v], g[v], a, b);
                 const float c1 = wave_sum(a) * inv_n, c2 = wave_sum(b) * inv_n;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     float d[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        d[e] = rstd[u] * (g[v][e] * gam[v][e] - c1 - xh[v][e] * c2);
-                        s_dg[v][e] = fmaf(g[v][e], xh[v][e], s_dg[v][e]);
-                        s_db[v][e] += g[v][e];
-                        s_dbias[v][e] += okv[v] ? d[e] : 0.f;
-                    }
+                    gte_ln_bwd_post4(g[v], xh[v], gam[v], rstd[u], c1, c2, okv[v], d, s_dg[v], s_db[v], s_dbias[v]);
                     if (okv[v]) {
                         f4u o; o.x = d[0]; o.y = d[1]; o.z = d[2]; o.w = d[3];
                         *reinterpret_cast<f4u*>(dzr + 4 * (lane + 64 * v)) = o;

@@ -56,6 +56,7 @@ int backward_a(const gte_step_plan& p, void* st) {
     GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
     GTE_TRY(gte_sage_narrow_bwd_ce(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C, p.dh_out, p.out_fin,
                                    p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes, p.ce_part, p.grad_scale, p.out3, st));
+    bool ln_done = false;
     for (int i = p.n_hidden - 1; i >= 0; --i) {
         const gte_step_layer& L = p.layer[i];
         if (L.kind == GTE_LAYER_SMALLK) {
@@ -64,14 +65,24 @@ int backward_a(const gte_step_plan& p, void* st) {
                                         L.fout, L.ws_ln, L.ws_ln_bytes, st));
             continue;                                  // (layer 0: its dW -- or its whole one-pass backward -- is phase 2)
         }
-        GTE_TRY(gte_ln_relu_bwd_p3(L.dy, L.fout, L.t, 2 * L.fout, L.stats, L.gamma, L.beta, L.relu, L.dy, L.fout, L.dzp, L.ldp_o, L.ggamma,
-                                   L.gbeta, L.gbias, n, L.fout, L.ws_ln, L.ws_ln_bytes, st));
+        if (!ln_done)          // (else: the dX launch of the layer above ran this layer's LayerNorm backward as its epilogue)
+            GTE_TRY(gte_ln_relu_bwd_p3(L.dy, L.fout, L.t, 2 * L.fout, L.stats, L.gamma, L.beta, L.relu, L.dy, L.fout, L.dzp, L.ldp_o, L.ggamma,
+                                       L.gbeta, L.gbias, n, L.fout, L.ws_ln, L.ws_ln_bytes, st));
+        ln_done = false;
         GTE_TRY(gte_spmm_csr_p3(p.rindptr, p.rindices, p.w_out, L.dy, L.fout, L.qp, L.ldp_o, n, L.fout, GTE_REDUCE_SUM, st));
         if (i == 0) break;                             // layer 0's dW is the step's last GEMM: phase 2
         GTE_TRY(gte_gemm_p3_tn(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, nullptr, 0, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n, L.ws_dw,
                                L.ws_dw_bytes, st));
-        GTE_TRY(gte_gemm_p3_nt(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, nullptr, 0, p.layer[i - 1].dy, L.fin, n,
-                               L.fin, 0, 0, st));
+        const gte_step_layer& B = p.layer[i - 1];
+        if (p.fuse_ln_dx && B.kind == GTE_LAYER_PLANES && gte_gemm_p3_nt_ln_bwd_supported(L.fin)) {
+            GTE_TRY(gte_gemm_p3_nt_ln_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, B.t, 2 * B.fout, B.stats, B.gamma,
+                                          B.beta, B.relu, B.dy, B.fout, B.dzp, B.ldp_o, B.ggamma, B.gbeta, B.gbias, n, L.fin, B.ws_ln,
+                                          B.ws_ln_bytes, st));
+            ln_done = true;
+        } else {
+            GTE_TRY(gte_gemm_p3_nt(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, nullptr, 0, B.dy, L.fin, n, L.fin, 0, 0,
+                                   st));
+        }
     }
     return GTE_OK;
 }

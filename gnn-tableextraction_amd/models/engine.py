@@ -168,6 +168,9 @@ class FusedGcnSageStep(TrainStep):
         # 50 MB of traffic but serialises more work in one wave per SIMD: 41.6 us fused vs 22.4 + 16.6 us separate at
         # 24 k nodes -- off by default, kept (and tested) for a later retune
         self.fuse_ln_below = os.environ.get("GTE_FUSE_LN_BELOW", "0") == "1"
+        # dX of a planes layer with the LayerNorm(+ReLU) backward of the planes layer below as its epilogue (gte_gemm_p3_nt_ln_bwd)
+        self.fuse_ln_dx = os.environ.get("GTE_FUSE_LN_DX", "1") == "1"
+        self._ln_p3_done = None
         # LayerNorm(+ReLU) forward of the last hidden layer inside the output layer's forward kernel (gte_sage_narrow_fwd_ln):
         # one launch and one pass over [n, hidden] less
         self.fuse_ln_fwd = os.environ.get("GTE_FUSE_LN_FWD", "1") == "1"
@@ -229,6 +232,7 @@ class FusedGcnSageStep(TrainStep):
         # the backward defers its partial-sum folds to one launch (gte_fold_defer_*): every producer keeps its partials
         # in a workspace of its own until the flush
         b["ws_ln"] = [torch.empty(int(max(lib.gte_ln_relu_bwd_workspace_bytes(cap, dims[i + 1]),
+                                          lib.gte_gemm_p3_nt_ln_bwd_workspace_bytes(cap, dims[i + 1]),
                                           lib.gte_sage_narrow_bwd_ln_workspace_bytes(cap, min(dims[i + 1], 256)))),
                                   dtype=torch.uint8, device=dev) for i in range(len(layers))]
         b["ce_part"] = torch.empty(int(lib.gte_head_agg_ce_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
@@ -475,6 +479,7 @@ class FusedGcnSageStep(TrainStep):
                                                                         P(self.exp_avg_sq))
                 plan.n_param = self.flat_param.numel()
                 plan.hyper, plan.step_counter, plan.ticket = P(self._hyper), P(self._step_dev), P(self._ticket)
+            plan.fuse_ln_dx = int(self.fuse_ln_dx)
             if self._tail_ws is None:
                 self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=self.flat_param.device)
             if self.tail_split:
@@ -577,6 +582,7 @@ class FusedGcnSageStep(TrainStep):
             if forward:
                 self._forward_loss(g, labels, grad_scale, x, n, f0, b, layers, csr, w_in, t_in, aggregate, st)
                 self._ln_done = None
+                self._ln_p3_done = None
             # ---------------- backward of layers hi .. lo ----------------
             side_used = False
             check(lib.gte_fold_defer_begin(st), "gte_fold_defer_begin")
@@ -792,7 +798,9 @@ class FusedGcnSageStep(TrainStep):
                 # ---- planes layer: dz (fp32 for the transpose aggregation + image), q = A_w^T (norm dz) as an image,
                 # dW = [dz^T h | q^T h] and dh = dz W_s + q W_n on the planes GEMMs
                 t, dzp, qp, hp = b["t"][i], b["dzp"][i], b["qp"][i], b["hp_used"][i]
-                if self._ln_done != i:
+                if self._ln_p3_done == i:
+                    pass          # the dX launch of the layer above ran this layer's LayerNorm backward as its epilogue
+                elif self._ln_done != i:
                     check(lib.gte_ln_relu_bwd_p3(P(dy), fout, P(t), 2 * fout, P(b["stats"][i]), P(L.lynorm.weight),
                                                  P(L.lynorm.bias), int(relu), P(dy), fout, P(dzp.data), dzp.ldp, P(gg), P(gbe), P(gb),
                                                  n, fout, P(b["ws_ln"][i]), b["ws_ln"][i].numel(), st), "gte_ln_relu_bwd_p3")
@@ -828,10 +836,23 @@ class FusedGcnSageStep(TrainStep):
                             dw_planes(st)
                 if i > 0:
                     wb = self._wimg[i][1]
-                    with timed("gemm_nn", 4.0 * n * fin * fout) as tm:
-                        for _ in tm.repeat():
-                            check(lib.gte_gemm_p3_nt(P(dzp.data), dzp.ldp, fout, P(qp.data), qp.ldp, fout, P(wb.data), wb.ldp, None, 0,
-                                                     P(b["dy"][i - 1]), fin, n, fin, 0, 0, st), "gte_gemm_p3_nt dX")
+                    Lb = layers[i - 1]
+                    if (self.fuse_ln_dx and b["pl"][i - 1] and ops._timers is None and lib.gte_gemm_p3_nt_ln_bwd_supported(fin)):
+                        # dX with the LayerNorm(+ReLU) backward of the layer below as its epilogue: d(loss)/d(y) of that layer
+                        # is never stored, its dz comes out as fp32 + image
+                        gsl, dzb, wsl = self._gslice, b["dzp"][i - 1], b["ws_ln"][i - 1]
+                        check(lib.gte_gemm_p3_nt_ln_bwd(P(dzp.data), dzp.ldp, fout, P(qp.data), qp.ldp, fout, P(wb.data), wb.ldp,
+                                                        P(b["t"][i - 1]), 2 * fin, P(b["stats"][i - 1]), P(Lb.lynorm.weight),
+                                                        P(Lb.lynorm.bias), int(Lb.activation is not None), P(b["dy"][i - 1]), fin,
+                                                        P(dzb.data), dzb.ldp, P(gsl[id(Lb.lynorm.weight)]), P(gsl[id(Lb.lynorm.bias)]),
+                                                        P(gsl[id(Lb.linear.bias)]), n, fin, P(wsl), wsl.numel(), st),
+                              "gte_gemm_p3_nt_ln_bwd")
+                        self._ln_p3_done = i - 1
+                    else:
+                        with timed("gemm_nn", 4.0 * n * fin * fout) as tm:
+                            for _ in tm.repeat():
+                                check(lib.gte_gemm_p3_nt(P(dzp.data), dzp.ldp, fout, P(qp.data), qp.ldp, fout, P(wb.data), wb.ldp, None,
+                                                         0, P(b["dy"][i - 1]), fin, n, fin, 0, 0, st), "gte_gemm_p3_nt dX")
                 continue
             if self._smallk_bwd(i, L, fin):
                 # short-input layer 0: LayerNorm(+ReLU) backward and dW in ONE pass over dy (z recomputed, dz never stored)

@@ -329,6 +329,17 @@ int gte_gemm_p3_nt(const void* a1, int64_t ldpa1, int64_t k1, const void* a2, in
 int gte_gemm_p3_nt_rows(const void* a_res, int64_t ldpa, int64_t k, const int32_t* a_rows, int64_t n_res_rows, const void* b,
                         int64_t ldpb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
                         int relu, int accumulate, void* stream);
+/* gte_gemm_p3_nt (no bias / relu / accumulate) whose product dy [m][n], n <= 256, is NOT stored: the workgroup that computed a
+ * block of rows runs the LayerNorm(+ReLU) backward of those rows on it (models.py:64-66 autograd of the layer below): dz as fp32
+ * and as a P3 image (dzp3 nullable), column sums dgamma / dbeta / dbias (nullable) into the fold deferral.  z / stats / gamma /
+ * beta as gte_ln_relu_bwd.  Replaces gte_gemm_p3_nt + gte_ln_relu_bwd_p3 (one launch, 2 m n 4 bytes of traffic less); dz is
+ * bit-identical to theirs. */
+int gte_gemm_p3_nt_ln_bwd_supported(int64_t n);
+int64_t gte_gemm_p3_nt_ln_bwd_workspace_bytes(int64_t m, int64_t n);
+int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t ldpa1, int64_t k1, const void* a2, int64_t ldpa2, int64_t k2, const void* b,
+                          int64_t ldpb, const float* z, int64_t ldz, const float* stats, const float* gamma, const float* beta,
+                          int relu, float* dz, int64_t lddz, void* dzp3, int64_t ldp3, float* dgamma, float* dbeta, float* dbias,
+                          int64_t m, int64_t n, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t gte_gemm_p3_tn_workspace_bytes(int64_t m, int64_t n, int64_t nseg, int64_t k);
 int gte_gemm_p3_tn(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, const void* b, int64_t ldpb, const void* b2,
                    int64_t ldpb2, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, void* workspace,
@@ -396,6 +407,7 @@ typedef struct gte_step_plan {
     float* param; float* grad; float* exp_avg; float* exp_avg_sq; int64_t n_param;   /* fused Adam (NULL param: plain flush) */
     float* hyper; int64_t* step_counter; uint32_t* ticket;
     void* tail_ws; int64_t tail_ws_bytes;
+    int fuse_ln_dx;                        /* 1: dX of a PLANES layer above a PLANES layer runs gte_gemm_p3_nt_ln_bwd */
 } gte_step_plan;
 int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
 

@@ -192,6 +192,39 @@ def test_row_map_entry_points_validate():
     assert b"4 GB" in lib.gte_last_error()
 
 
+# ---- the backward GEMM with the LayerNorm backward of the layer below as its epilogue ---------------------------------------
+@pytest.mark.parametrize("m,n,k,relu", [(24437, 256, 256, True), (3000, 256, 256, False), (129, 128, 64, True), (1, 256, 256, True),
+                                        (40000, 256, 128, True), (500, 144, 256, True)])
+def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(m, n, k, relu):
+    """gte_gemm_p3_nt_ln_bwd: dy = [dz1 | q1] [W_s^T | W_n^T]^T is never stored; dz0 (fp32 and image) must be bit for bit what
+    gte_gemm_p3_nt + gte_ln_relu_bwd_p3 produce, the column sums agree to summation order."""
+    g = torch.Generator(device=DEV).manual_seed(m + n)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    a1, a2, w = rnd(m, k), rnd(m, k), rnd(n, 2 * k) / 16
+    z = rnd(m, 2 * n)[:, :n]                                 # a strided view: z lives in the left half of t = [t_self | t_neigh]
+    gam, bet = 1 + 0.1 * rnd(n), 0.1 * rnd(n)
+    mu = z.mean(1)
+    stats = torch.cat([mu, 1.0 / torch.sqrt(z.var(1, unbiased=False) + 1e-5)]).contiguous()
+    a1p, a2p, wp = ops.p3_from_f32(a1), ops.p3_from_f32(a2), ops.p3_from_f32(w)
+    # two launches
+    dy = ops.gemm_p3_nt(a1p, wp, a2=a2p)
+    lib, P = _lib.load(), _lib.ptr
+    dz_ref, dzp_ref = torch.empty(m, n, device=DEV), ops.P3.empty(m, n, DEV)
+    dg_ref, db_ref, dbias_ref = (torch.zeros(n, device=DEV) for _ in range(3))
+    ws = torch.empty(int(lib.gte_ln_relu_bwd_workspace_bytes(m, n)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.gte_ln_relu_bwd_p3(P(dy), n, P(z), z.stride(0), P(stats), P(gam), P(bet), int(relu), P(dz_ref), n, P(dzp_ref.data),
+                                      dzp_ref.ldp, P(dg_ref), P(db_ref), P(dbias_ref), m, n, P(ws), ws.numel(), _lib.current_stream()),
+               "gte_ln_relu_bwd_p3")
+    # one launch
+    dz, dzp = torch.full((m, n), 7.0, device=DEV), ops.P3.empty(m, n, DEV)
+    dg, db, dbias = (torch.full((n,), 7.0, device=DEV) for _ in range(3))
+    ops.gemm_p3_nt_ln_bwd(a1p, wp, a2p, z, stats, gam, bet, relu, dz, dzp, dg, db, dbias)
+    assert torch.equal(dz, dz_ref)
+    assert torch.equal(ops.p3_to_f32(dzp), dz_ref)
+    for got, want in ((dg, dg_ref), (db, db_ref), (dbias, dbias_ref)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-6)
+
+
 # ---- operands outside the comfortable range -------------------------------------------------------------------------------
 def test_non_finite_operands_poison_exactly_the_outputs_fp32_poisons(split_mode):
     """inf cannot be cut into pieces (inf - inf is NaN) and 0 x inf appears among the six products, so an output that fp32
