@@ -647,11 +647,13 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int row_base = m0 + sl * SR;
-            for (int rl = wave; rl < SR; rl += 2 * NW) {
-                float gy[2][4], zz[2][4], mean[2], rstd[2];
-                bool rok[2];
+            constexpr int RF = 4;                                       // rows in flight per wave (one workgroup per CU: the
+                                                                        // memory-level parallelism of this phase is all there is)
+            for (int rl = wave; rl < SR; rl += RF * NW) {
+                float gy[RF][4], zz[RF][4], mean[RF], rstd[RF];
+                bool rok[RF];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < RF; ++u) {
                     const int rloc = rl + u * NW, rg = row_base + rloc;
                     rok[u] = rloc < SR && rg < M;
                     const int rc = rok[u] ? rg : min(row_base, M - 1);
@@ -666,7 +668,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
                     mean[u] = p.ln_stats[rc]; rstd[u] = p.ln_stats[M + rc];
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < RF; ++u) {
                     if (!rok[u]) continue;                              // wave-uniform
                     const long long rg = row_base + rl + u * NW;
                     float xh[4], g[4];
