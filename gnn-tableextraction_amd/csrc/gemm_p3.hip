@@ -949,6 +949,9 @@ gemm_p3_tn_kernel(const P3Gemm p) {
     float* outp = p.splits > 1 ? p.slab + (long long)split * p.M * p.N : p.C;
     const long long ldo = p.splits > 1 ? p.N : p.ldc;
     const int cbase = nseg * seg_cols;
+#if P3_TN_ABL & 8
+    if (p.K == 12345)                                          // (measurement: no slab stores)
+#endif
     store_tile<TM, TN>(acc, outp, ldo, p.M, p.N, m0 + wm * TM * 32, cbase + n0 + wn * TN * 32, cbase + seg_cols, nullptr, 0,
                        p.splits > 1 ? 0 : p.relu, p.splits > 1 ? 0 : p.accumulate, lane);
 }

@@ -1304,8 +1304,10 @@ colsum_fold_kernel(const float* __restrict__ partial, int nblocks, int n, float*
 }
 
 int ln_bwd_blocks(int64_t M) {
+    static const int forced = getenv("GTE_LNB_BLOCKS") ? atoi(getenv("GTE_LNB_BLOCKS")) : 0;        // (measurement)
+    const int cap = forced > 0 ? forced : LNB_MAX_BLOCKS;
     const int64_t b = gte::ceil_div(M, 4);
-    return (int)(b < LNB_MAX_BLOCKS ? b : LNB_MAX_BLOCKS);
+    return (int)(b < cap ? b : cap);
 }
 
 // ---- short-K layer (BBOX features: 13 + 13 inputs): linear + bias + LayerNorm + ReLU in ONE pass ------------------------
