@@ -26,8 +26,11 @@ if len(sys.argv) > 4:
         b, n = fam(split, lambda k, pat=pat: pat in k)
         out[f"{tag}_split_bytes_per_launch"], out[f"{tag}_split_launches_sampled"] = b, n
     # round 3: the default step multiplies P3 images (planes GEMMs, csrc/gemm_p3.hip)
-    for tag, pat in (("gemm_nt", "gemm_p3_nt"), ("gemm_tn", "gemm_p3_tn")):
-        b, n = fam(split, lambda k, pat=pat: pat in k)
+    # (the NT kernel whose last template argument is `true` is dX with the LayerNorm-backward epilogue: its own family)
+    lnb = lambda k: "gemm_p3_nt_lw_kernel" in k and k.rstrip().split("(")[0].endswith("true>")
+    for tag, pred in (("gemm_nt", lambda k: "gemm_p3_nt" in k and not lnb(k)), ("gemm_tn", lambda k: "gemm_p3_tn" in k),
+                      ("gemm_nt_ln_bwd", lnb)):
+        b, n = fam(split, pred)
         out[f"{tag}_p3_bytes_per_launch"], out[f"{tag}_p3_launches_sampled"] = b, n
     for tag, pat in (("batch_assemble_p3", "batch_assemble"), ("ln_relu_bwd_p3", "ln_relu_bwd_vec_kernel"), ("fold_adam", "gte_fold_batch_kernel")):
         b, n = fam(split, lambda k, pat=pat: pat in k)
