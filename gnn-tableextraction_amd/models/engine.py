@@ -170,6 +170,9 @@ class FusedGcnSageStep(TrainStep):
         self.fuse_ln_below = os.environ.get("GTE_FUSE_LN_BELOW", "0") == "1"
         # dX of a planes layer with the LayerNorm(+ReLU) backward of the planes layer below as its epilogue (gte_gemm_p3_nt_ln_bwd)
         self.fuse_ln_dx = os.environ.get("GTE_FUSE_LN_DX", "1") == "1"
+        # the one-call step launched as an executable graph that is updated per batch (needs a non-default current stream)
+        self.use_step_graph = os.environ.get("GTE_STEP_GRAPH", "0") == "1"
+        self._step_exec = ctypes.c_void_p(None)
         self._ln_p3_done = None
         # LayerNorm(+ReLU) forward of the last hidden layer inside the output layer's forward kernel (gte_sage_narrow_fwd_ln):
         # one launch and one pass over [n, hidden] less
@@ -507,7 +510,12 @@ class FusedGcnSageStep(TrainStep):
         plan.labels, plan.labels_f32 = P(lab), int(lab.dtype == torch.float32)
         plan.grad_scale = float(grad_scale)
         addr = ctypes.addressof(plan)
-        if self.before_last_gemm is not None:
+        if self.use_step_graph and st:
+            # the whole step as one executable-graph launch (updated in place per batch); the next batch's assembly is queued first
+            if self.before_last_gemm is not None:
+                self.before_last_gemm()
+            _lib.check(lib.gte_gcnsage_step_graph(addr, ctypes.byref(fused), st, ctypes.byref(self._step_exec)), "gte_gcnsage_step_graph")
+        elif self.before_last_gemm is not None:
             _lib.check(lib.gte_gcnsage_step(addr, 1, ctypes.byref(fused), st), "gte_gcnsage_step")
             self.before_last_gemm()
             _lib.check(lib.gte_gcnsage_step(addr, 2, ctypes.byref(fused), st), "gte_gcnsage_step")

@@ -410,6 +410,12 @@ typedef struct gte_step_plan {
     int fuse_ln_dx;                        /* 1: dX of a PLANES layer above a PLANES layer runs gte_gemm_p3_nt_ln_bwd */
 } gte_step_plan;
 int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
+/* The whole step (phase 0) captured from `stream` -- not the legacy null stream -- and launched as ONE executable graph kept in
+ * *exec_slot (NULL at first; updated in place every step: same kernels, the batch's grid sizes and arguments; released with
+ * gte_step_graph_destroy).  Dependent kernels inside a graph launch follow each other without the per-dispatch overhead of
+ * eager launches. */
+int gte_gcnsage_step_graph(const gte_step_plan* plan, int* adam_fused, void* stream, void** exec_slot);
+int gte_step_graph_destroy(void* exec);
 
 /* ---- deferred folds -------------------------------------------------------------------------------------------
  * Several entry points end with a small "sum the per-block partials" kernel (gte_ln_relu_bwd: column sums;
