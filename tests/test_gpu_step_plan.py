@@ -19,6 +19,8 @@ def _run(monkeypatch, c_step, f0, hid, weighted, n_pages=12, steps=3, resident=F
     cw = torch.linspace(0.5, 2.0, 9, device=dev) if weighted else None
     tr = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4, class_weights=cw)
     assert tr.use_c_step == c_step
+    if not tr._planes_on():
+        pytest.skip("the one-call step drives the planes path (default GEMM mode, GTE_PLANES=1)")
     outs = []
     if resident:
         graphs = []
