@@ -23,6 +23,7 @@
 // order (no atomics: deterministic).
 #include "gte_common.h"
 #include "ce_fold.h"
+#include "p3.h"
 
 #include <stdlib.h>
 
@@ -415,9 +416,13 @@ narrow_fwd_mfma16_kernel(const float* __restrict__ h, int64_t ldh, const float* 
 // {sum g xhat, sum g, sum dz} per workgroup in lnpart[block][3][F] -- dh (25 MB at 24 k x 256) is never written or read.
 struct LnBackward {
     const float* z; int64_t ldz; const float* stats; const float* gamma; const float* beta; int relu; float* lnpart;
+    char* dzp3; int64_t ldp3;                   // LNB == 2: dz additionally as a P3 image (csrc/p3.h)
 };
 
-template <int NCT, bool LNB = false>
+// LNB: 0 plain; 1 LayerNorm backward in the accumulator layout (row sums across the four waves: the round-2 form, off by default);
+// 2 the dh tile goes through LDS and every wave takes whole rows of it in the layout and with the arithmetic of
+// ln_relu_bwd_vec_kernel (16-byte accesses, dz as fp32 + P3 image: bit for bit gte_sage_narrow_bwd + gte_ln_relu_bwd_p3).
+template <int NCT, int LNB = 0>
 __global__ void __launch_bounds__(256)
 narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* __restrict__ q, int64_t ldq,
                        const float* __restrict__ h, int64_t ldh, const float* __restrict__ W, int64_t ldw,
@@ -445,8 +450,19 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
     __shared__ float lnred[4][32][2];           // LNB: per wave, per row of the block: {sum dxhat, sum dxhat xhat}
     float gam0 = 1.f, gam1 = 1.f, bet0 = 0.f, bet1 = 0.f;
     float s_dg0 = 0.f, s_dg1 = 0.f, s_db0 = 0.f, s_db1 = 0.f, s_dz0 = 0.f, s_dz1 = 0.f;
-    if constexpr (LNB) {
+    if constexpr (LNB == 1) {
         if (colok) { gam0 = lnb.gamma[col]; gam1 = lnb.gamma[col + 1]; bet0 = lnb.beta[col]; bet1 = lnb.beta[col + 1]; }
+    }
+    // LNB == 2: lane l owns columns 4 l .. 4 l + 3 of the rows its wave takes
+    const int j4 = 4 * lane;
+    const bool okc = j4 < F;
+    float gam4[4] = {1.f, 1.f, 1.f, 1.f}, bet4[4] = {0.f, 0.f, 0.f, 0.f};
+    float c_dg[4] = {0.f, 0.f, 0.f, 0.f}, c_db[4] = {0.f, 0.f, 0.f, 0.f}, c_dz[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (LNB == 2) {
+        if (okc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gam4[e] = lnb.gamma[j4 + e]; bet4[e] = lnb.beta[j4 + e]; }
+        }
     }
 
     // Row-block pipeline: the h rows (for the dW product) and the dl / q values of the NEXT row block are requested before
@@ -492,9 +508,22 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
 #pragma unroll
         for (int t = 0; t < ND; ++t) dv[t] = dvn[t];
         if (rb + (int)gridDim.x < nblk) request(rb + gridDim.x);
-        f2n zv[LNB ? 16 : 1];                   // LNB: the z values under this lane's dh elements
-        float mu[LNB ? 16 : 1], rs[LNB ? 16 : 1];
-        if constexpr (LNB) {
+        f2n zv[LNB == 1 ? 16 : 1];              // LNB == 1: the z values under this lane's dh elements
+        float mu[LNB == 1 ? 16 : 1], rs[LNB == 1 ? 16 : 1];
+        // LNB == 2: the z rows (and statistics) of the eight rows this wave takes of the block: rows wave, wave + 4, ...
+        float zr[LNB == 2 ? 8 : 1][4], mu2[LNB == 2 ? 8 : 1], rs2[LNB == 2 ? 8 : 1];
+        if constexpr (LNB == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rr = min(row0 + wave + 4 * u, n - 1);
+                struct __attribute__((packed, aligned(4))) f4n { float x, y, z, w; };
+                f4n t{0.f, 0.f, 0.f, 0.f};
+                if (okc) t = *reinterpret_cast<const f4n*>(lnb.z + (int64_t)rr * lnb.ldz + j4);
+                zr[u][0] = t.x; zr[u][1] = t.y; zr[u][2] = t.z; zr[u][3] = t.w;
+                mu2[u] = lnb.stats[rr]; rs2[u] = lnb.stats[n + rr];
+            }
+        }
+        if constexpr (LNB == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 zv[r] = f2n{0.f, 0.f};
@@ -530,7 +559,49 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                 o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, o[0], 0, 0, 0);
                 o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, o[1], 0, 0, 0);
             }
-            if constexpr (LNB) {
+            if constexpr (LNB == 2) {
+                float* tile = D + 32 * DP;                                   // [32][F] floats, row-major
+                if (colok) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        float2 v; v.x = o[0][r]; v.y = o[1][r];
+                        *reinterpret_cast<float2*>(tile + rl * F + col) = v;
+                    }
+                }
+                __syncthreads();
+                const float inv_f = 1.0f / (float)F;
+#pragma unroll
+                for (int trip = 0; trip < 2; ++trip) {
+                    float gy[4][4];
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4) {
+                        const int rl = wave + 4 * (trip * 4 + u4);
+                        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (okc && row0 + rl < n) t = *reinterpret_cast<const float4*>(tile + rl * F + j4);
+                        gy[u4][0] = t.x; gy[u4][1] = t.y; gy[u4][2] = t.z; gy[u4][3] = t.w;
+                    }
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4) {
+                        const int u = trip * 4 + u4;
+                        const int64_t rr = row0 + wave + 4 * u;
+                        if (rr >= n) continue;                               // wave-uniform
+                        float xh[4], g[4];
+                        float a = 0.f, b = 0.f;
+                        gte_ln_bwd_pre4(gy[u4], zr[u], mu2[u], rs2[u], gam4, bet4, okc, lnb.relu, xh, g, a, b);
+                        const float c1 = gte_group_sum<64>(a) * inv_f, c2 = gte_group_sum<64>(b) * inv_f;
+                        float d[4];
+                        gte_ln_bwd_post4(g, xh, gam4, rs2[u], c1, c2, okc, d, c_dg, c_db, c_dz);
+                        if (okc) {
+                            struct __attribute__((packed, aligned(4))) f4n { float x, y, z, w; };
+                            f4n ov; ov.x = d[0]; ov.y = d[1]; ov.z = d[2]; ov.w = d[3];
+                            *reinterpret_cast<f4n*>(dh + rr * lddh + j4) = ov;
+                            if (lnb.dzp3) p3::store4(lnb.dzp3 + rr * lnb.ldp3, j4, d[0], d[1], d[2], d[3]);
+                        }
+                    }
+                }
+            } else
+            if constexpr (LNB == 1) {
                 // g = mask . dh, dxhat = g gamma; the row sums need all F columns: 32 lanes of this half-wave, then the
                 // four waves through LDS (fixed order)
                 float xh0[16], xh1[16], pa[16], pb[16];
@@ -616,7 +687,23 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
         }
     }
     if (wave == 0 && i < C && hh == 0) pp[2 * C * F + i] = gb;
-    if constexpr (LNB) {                        // the two half-waves hold different rows of the same columns
+    if constexpr (LNB == 2) {                   // column partials: the four waves through LDS, added in wave order
+        __syncthreads();
+        float* red = D + 32 * DP;                // [4][3][F]
+        if (okc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[(wave * 3 + 0) * F + j4 + e] = c_dg[e];
+                red[(wave * 3 + 1) * F + j4 + e] = c_db[e];
+                red[(wave * 3 + 2) * F + j4 + e] = c_dz[e];
+            }
+        }
+        __syncthreads();
+        float* lp = lnb.lnpart + (int64_t)blockIdx.x * 3 * F;
+        for (int t = threadIdx.x; t < 3 * F; t += 256)
+            lp[t] = ((red[t] + red[3 * F + t]) + red[6 * F + t]) + red[9 * F + t];
+    }
+    if constexpr (LNB == 1) {                   // the two half-waves hold different rows of the same columns
         s_dg0 += __shfl_xor(s_dg0, 32, 64); s_dg1 += __shfl_xor(s_dg1, 32, 64);
         s_db0 += __shfl_xor(s_db0, 32, 64); s_db1 += __shfl_xor(s_db1, 32, 64);
         s_dz0 += __shfl_xor(s_dz0, 32, 64); s_dz1 += __shfl_xor(s_dz1, 32, 64);
@@ -880,7 +967,7 @@ int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, 
                     const float* W, int64_t ldw, int64_t n_out, float* dh, int64_t lddh, float* dW, int64_t lddw, float* dbias,
                     int64_t n_nodes, void* workspace, int64_t workspace_bytes, const float* ce_partial, int64_t ce_blocks,
                     float grad_scale, float* out3, void* stream, const LnBackward* lnb = nullptr, float* dgamma = nullptr,
-                    float* dbeta = nullptr, float* dbias_below = nullptr) {
+                    float* dbeta = nullptr, float* dbias_below = nullptr, bool lnb_rows = false) {
     if (!gte_sage_narrow_supported(n_feat, n_out) || n_nodes < 0 || n_nodes > INT32_MAX)
         return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd: needs n_out <= 16 and n_feat <= 256");
     if (n_nodes == 0) return GTE_OK;
@@ -896,12 +983,16 @@ int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, 
         const int nbm = narrow_mfma_blocks(n_nodes);
 #define GTE_NBM(NCT)                                                                                                  \
     do {                                                                                                              \
-        if (lnb)                                                                                                      \
-            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, true>), dim3((unsigned)nbm), dim3(256),                   \
+        if (lnb && lnb_rows)                                                                                          \
+            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 2>), dim3((unsigned)nbm), dim3(256),                      \
+                               (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1) + 32 * F) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, \
+                               lddh, part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, *lnb);        \
+        else if (lnb)                                                                                                 \
+            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 1>), dim3((unsigned)nbm), dim3(256),                      \
                                (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1)) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, lddh, \
                                part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, *lnb);              \
         else                                                                                                          \
-            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, false>), dim3((unsigned)nbm), dim3(256),                  \
+            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 0>), dim3((unsigned)nbm), dim3(256),                      \
                                (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1)) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, lddh, \
                                part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, LnBackward{});      \
     } while (0)
@@ -1009,6 +1100,32 @@ extern "C" int gte_sage_narrow_bwd_ce(const float* dl_unscaled, int64_t lddl, co
 }
 
 
+// gte_sage_narrow_bwd_ln in the row form: the dh tile of a row block goes through LDS and whole rows get the LayerNorm(+ReLU)
+// backward with 16-byte accesses; dz_below as fp32 AND as a P3 image (dzp3 nullable).  Bit for bit
+// gte_sage_narrow_bwd[_ce] + gte_ln_relu_bwd_p3; one launch and the [N, F] round trip of dh less.  n_feat % 4 == 0.
+extern "C" int gte_sage_narrow_bwd_ln_p3(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
+                                         int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dz_below, int64_t lddz,
+                                         void* dzp3, int64_t ldp3, float* dW, int64_t lddw, float* dbias, int64_t n_nodes,
+                                         void* workspace, int64_t workspace_bytes, const void* ce_partial, float grad_scale,
+                                         float* out3, const float* z_below, int64_t ldz, const float* stats_below,
+                                         const float* gamma_below, const float* beta_below, int relu_below, float* dgamma_below,
+                                         float* dbeta_below, float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes,
+                                         void* stream) {
+    if (!gte_head_supported(n_feat, n_out)) return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd_ln_p3: see gte_head_supported");
+    if (!dz_below || !z_below || !stats_below || !gamma_below || !beta_below || !ln_workspace || (ce_partial && !out3))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln_p3: null pointer");
+    if (ldz < n_feat || lddz < n_feat || (dzp3 && (ldp3 < (int64_t)p3::row_bytes(n_feat) || ldp3 % 16 != 0 || n_feat % 16 != 0)))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln_p3: leading dimension too small (the image needs n_feat %% 16 == 0)");
+    if (ln_workspace_bytes < gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_feat))
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd_ln_p3: LayerNorm workspace too small");
+    const LnBackward lnb = {z_below, ldz, stats_below, gamma_below, beta_below, relu_below, reinterpret_cast<float*>(ln_workspace),
+                            reinterpret_cast<char*>(dzp3), ldp3};
+    return narrow_bwd_impl(dl, lddl, q, ldq, h, ldh, n_feat, W, ldw, n_out, dz_below, lddz, dW, lddw, dbias, n_nodes, workspace,
+                           workspace_bytes, reinterpret_cast<const float*>(ce_partial),
+                           gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream, &lnb, dgamma_below,
+                           dbeta_below, dbias_below, true);
+}
+
 extern "C" int64_t gte_sage_narrow_bwd_ln_workspace_bytes(int64_t n_nodes, int64_t n_feat) {
     return gte::round_up((int64_t)narrow_mfma_blocks(n_nodes > 0 ? n_nodes : 1) * 3 * n_feat * 4, 256);
 }
@@ -1026,7 +1143,8 @@ extern "C" int gte_sage_narrow_bwd_ln(const float* dl, int64_t lddl, const float
     if (ldz < n_feat || lddz < n_feat) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln: leading dimension too small");
     if (ln_workspace_bytes < gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_feat))
         return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd_ln: LayerNorm workspace too small");
-    const LnBackward lnb = {z_below, ldz, stats_below, gamma_below, beta_below, relu_below, reinterpret_cast<float*>(ln_workspace)};
+    const LnBackward lnb = {z_below, ldz, stats_below, gamma_below, beta_below, relu_below, reinterpret_cast<float*>(ln_workspace),
+                            nullptr, 0};
     return narrow_bwd_impl(dl, lddl, q, ldq, h, ldh, n_feat, W, ldw, n_out, dz_below, lddz, dW, lddw, dbias, n_nodes, workspace,
                            workspace_bytes, reinterpret_cast<const float*>(ce_partial),
                            gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream, &lnb, dgamma_below,

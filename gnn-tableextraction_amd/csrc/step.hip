@@ -54,9 +54,19 @@ int forward(const gte_step_plan& p, void* st) {
 int backward_a(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes, C = p.n_classes;
     GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
-    GTE_TRY(gte_sage_narrow_bwd_ce(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C, p.dh_out, p.out_fin,
-                                   p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes, p.ce_part, p.grad_scale, p.out3, st));
     bool ln_done = false;
+    const gte_step_layer& T = p.layer[p.n_hidden - 1];
+    if ((p.fuse_ln_dx & 2) && T.kind == GTE_LAYER_PLANES && T.fout % 16 == 0 && gte_head_supported(p.out_fin, C)) {
+        // ... with the LayerNorm(+ReLU) backward of the last hidden layer on the dh tile of every row block
+        GTE_TRY(gte_sage_narrow_bwd_ln_p3(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C, p.dh_out, p.out_fin,
+                                          T.dzp, T.ldp_o, p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes, p.ce_part,
+                                          p.grad_scale, p.out3, T.t, 2 * T.fout, T.stats, T.gamma, T.beta, T.relu, T.ggamma, T.gbeta, T.gbias,
+                                          T.ws_ln, T.ws_ln_bytes, st));
+        ln_done = true;
+    } else {
+        GTE_TRY(gte_sage_narrow_bwd_ce(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C, p.dh_out, p.out_fin,
+                                       p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes, p.ce_part, p.grad_scale, p.out3, st));
+    }
     for (int i = p.n_hidden - 1; i >= 0; --i) {
         const gte_step_layer& L = p.layer[i];
         if (L.kind == GTE_LAYER_SMALLK) {
@@ -74,7 +84,7 @@ int backward_a(const gte_step_plan& p, void* st) {
         GTE_TRY(gte_gemm_p3_tn(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, nullptr, 0, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n, L.ws_dw,
                                L.ws_dw_bytes, st));
         const gte_step_layer& B = p.layer[i - 1];
-        if (p.fuse_ln_dx && B.kind == GTE_LAYER_PLANES && gte_gemm_p3_nt_ln_bwd_supported(L.fin)) {
+        if ((p.fuse_ln_dx & 1) && B.kind == GTE_LAYER_PLANES && gte_gemm_p3_nt_ln_bwd_supported(L.fin)) {
             GTE_TRY(gte_gemm_p3_nt_ln_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, B.t, 2 * B.fout, B.stats, B.gamma,
                                           B.beta, B.relu, B.dy, B.fout, B.dzp, B.ldp_o, B.ggamma, B.gbeta, B.gbias, n, L.fin, B.ws_ln,
                                           B.ws_ln_bytes, st));

@@ -170,6 +170,8 @@ class FusedGcnSageStep(TrainStep):
         self.fuse_ln_below = os.environ.get("GTE_FUSE_LN_BELOW", "0") == "1"
         # dX of a planes layer with the LayerNorm(+ReLU) backward of the planes layer below as its epilogue (gte_gemm_p3_nt_ln_bwd)
         self.fuse_ln_dx = os.environ.get("GTE_FUSE_LN_DX", "1") == "1"
+        # ... and of the last hidden layer inside the output layer's backward (gte_sage_narrow_bwd_ln_p3)
+        self.fuse_ln_narrow = os.environ.get("GTE_FUSE_LN_NARROW", "1") == "1"
         # the one-call step launched as an executable graph that is updated per batch (needs a non-default current stream)
         self.use_step_graph = os.environ.get("GTE_STEP_GRAPH", "0") == "1"
         self._step_exec = ctypes.c_void_p(None)
@@ -300,6 +302,12 @@ class FusedGcnSageStep(TrainStep):
         Lb = layers[i - 1]
         return (isinstance(Lb.lynorm, nn.LayerNorm) and self._narrow(layers[i], fin)
                 and bool(self.lib.gte_head_supported(fin, layers[i].out_feats)))
+
+    def _ln_rows_below(self, i: int, layers, fin: int, b) -> bool:
+        """The output layer's backward runs the LayerNorm(+ReLU) backward of the PLANES layer below in the row form
+        (gte_sage_narrow_bwd_ln_p3: dz as fp32 + image)."""
+        return (self.fuse_ln_narrow and i > 0 and i == len(layers) - 1 and bool(b["pl"][i - 1]) and ops._timers is None
+                and self._narrow(layers[i], fin) and fin % 16 == 0 and bool(self.lib.gte_head_supported(fin, layers[i].out_feats)))
 
     def _fused_head(self, i: int, layer, fin: int) -> bool:
         """Output layer + weighted CE as gte_head_agg_ce / gte_sage_narrow_bwd_ce (the last, narrow layer only)."""
@@ -482,7 +490,7 @@ class FusedGcnSageStep(TrainStep):
                                                                         P(self.exp_avg_sq))
                 plan.n_param = self.flat_param.numel()
                 plan.hyper, plan.step_counter, plan.ticket = P(self._hyper), P(self._step_dev), P(self._ticket)
-            plan.fuse_ln_dx = int(self.fuse_ln_dx)
+            plan.fuse_ln_dx = int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0)
             if self._tail_ws is None:
                 self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=self.flat_param.device)
             if self.tail_split:
@@ -792,6 +800,19 @@ class FusedGcnSageStep(TrainStep):
                             P(gsl[id(Lb.linear.bias)]) if Lb.linear.bias is not None else None,
                             P(b["ws_ln"][i - 1]), b["ws_ln"][i - 1].numel(), st), "gte_sage_narrow_bwd_ln")
                         self._ln_done = i - 1
+                    elif self._ln_rows_below(i, layers, fin, b):
+                        # the LayerNorm(+ReLU) backward of the planes layer below on the dh tile of every row block (row form):
+                        # d(loss)/d(y) of that layer is never stored, its dz comes out as fp32 + image
+                        Lb, gsl, dzb, wsl = layers[i - 1], self._gslice, b["dzp"][i - 1], b["ws_ln"][i - 1]
+                        hs = self._head_scale
+                        check(lib.gte_sage_narrow_bwd_ln_p3(
+                            P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout, P(dh), fin, P(dzb.data), dzb.ldp,
+                            P(gW), 2 * fin, P(gb), n, P(b["ws_nar"]), b["ws_nar"].numel(), P(b["ce_part"]) if hs is not None else None,
+                            hs if hs is not None else 1.0, P(b["out3"]) if hs is not None else None, P(b["t"][i - 1]), 2 * fin,
+                            P(b["stats"][i - 1]), P(Lb.lynorm.weight), P(Lb.lynorm.bias), int(Lb.activation is not None),
+                            P(gsl[id(Lb.lynorm.weight)]), P(gsl[id(Lb.lynorm.bias)]), P(gsl[id(Lb.linear.bias)]), P(wsl), wsl.numel(),
+                            st), "gte_sage_narrow_bwd_ln_p3")
+                        self._ln_p3_done = i - 1
                     elif self._head_scale is not None and i == len(layers) - 1:
                         check(lib.gte_sage_narrow_bwd_ce(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,
                                                          P(dh), fin, P(gW), 2 * fin, P(gb), n, P(b["ws_nar"]),

@@ -407,7 +407,8 @@ typedef struct gte_step_plan {
     float* param; float* grad; float* exp_avg; float* exp_avg_sq; int64_t n_param;   /* fused Adam (NULL param: plain flush) */
     float* hyper; int64_t* step_counter; uint32_t* ticket;
     void* tail_ws; int64_t tail_ws_bytes;
-    int fuse_ln_dx;                        /* 1: dX of a PLANES layer above a PLANES layer runs gte_gemm_p3_nt_ln_bwd */
+    int fuse_ln_dx;                        /* bit 0: dX of a PLANES layer above a PLANES layer runs gte_gemm_p3_nt_ln_bwd;
+                                              bit 1: the output layer's backward runs gte_sage_narrow_bwd_ln_p3          */
 } gte_step_plan;
 int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
 /* The whole step (phase 0) captured from `stream` -- not the legacy null stream -- and launched as ONE executable graph kept in
@@ -506,6 +507,16 @@ int gte_sage_narrow_bwd_ce(const float* dl_unscaled, int64_t lddl, const float* 
  * ln_workspace >= gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_feat); its folds join an open deferral
  * (gte_fold_defer_begin) or run as one launch.  Same support rule as gte_head_supported. */
 int64_t gte_sage_narrow_bwd_ln_workspace_bytes(int64_t n_nodes, int64_t n_feat);
+/* The same fusion in the ROW form (round 3): the dh tile of every 32-row block goes through LDS and whole rows get the
+ * LayerNorm(+ReLU) backward with 16-byte accesses and the arithmetic of gte_ln_relu_bwd; dz_below as fp32 AND as a P3 image
+ * (dzp3 nullable; n_feat % 16 == 0).  Bit for bit gte_sage_narrow_bwd[_ce] + gte_ln_relu_bwd_p3. */
+int gte_sage_narrow_bwd_ln_p3(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
+                              int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dz_below, int64_t lddz,
+                              void* dzp3, int64_t ldp3, float* dW, int64_t lddw, float* dbias, int64_t n_nodes, void* workspace,
+                              int64_t workspace_bytes, const void* ce_partial, float grad_scale, float* out3,
+                              const float* z_below, int64_t ldz, const float* stats_below, const float* gamma_below,
+                              const float* beta_below, int relu_below, float* dgamma_below, float* dbeta_below,
+                              float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes, void* stream);
 int gte_sage_narrow_bwd_ln(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
                            int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dz_below, int64_t lddz,
                            float* dW, int64_t lddw, float* dbias, int64_t n_nodes, void* workspace, int64_t workspace_bytes,

@@ -410,6 +410,58 @@ def test_narrow_bwd_with_fused_layernorm_backward(n, f, c, relu):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=3e-6 * np.abs(ref).max() + 1e-12)
 
 
+@pytest.mark.parametrize("n,f,c,relu", [(1000, 256, 9, True), (333, 64, 4, False), (24495, 256, 9, True), (77, 128, 16, True), (1, 256, 9, True)])
+def test_narrow_bwd_with_layernorm_backward_in_row_form_is_bitwise_the_two_launches(n, f, c, relu):
+    """gte_sage_narrow_bwd_ln_p3 (the dh tile of a row block through LDS, whole rows in the layout and with the arithmetic of
+    gte_ln_relu_bwd): dz of the layer below as fp32 and as a P3 image bit for bit gte_sage_narrow_bwd + gte_ln_relu_bwd_p3; z is a
+    strided view (the left half of t = [t_self | t_neigh]); the column sums agree to summation order."""
+    lib = gte._lib.load()
+    P, cs, check = gte._lib.ptr, gte._lib.current_stream, gte._lib.check
+    rng = np.random.default_rng(n + f)
+    new = lambda *s: torch.empty(*s, device=DEV)
+    t = dev(rng.standard_normal((n, 2 * f)).astype(np.float32))
+    z = t[:, :f]
+    gam, bet = dev(1 + 0.1 * rng.standard_normal(f).astype(np.float32)), dev(0.1 * rng.standard_normal(f).astype(np.float32))
+    h, stats = new(n, f), new(2 * n)
+    check(lib.gte_ln_relu_fwd(P(z), 2 * f, P(gam), P(bet), 1e-5, int(relu), P(h), f, P(stats), n, f, cs()), "ln fwd")
+    W = dev((rng.standard_normal((c, 2 * f)) / np.sqrt(2 * f)).astype(np.float32))
+    dl, q = dev(rng.standard_normal((n, c)).astype(np.float32) / n), dev(rng.standard_normal((n, c)).astype(np.float32) / n)
+    wsn = torch.empty(int(lib.gte_sage_narrow_bwd_workspace_bytes(n, f, c)), dtype=torch.uint8, device=DEV)
+    # two launches
+    dh, dWa, dba = new(n, f), new(c, 2 * f), new(c)
+    check(lib.gte_sage_narrow_bwd(P(dl), c, P(q), c, P(h), f, f, P(W), 2 * f, c, P(dh), f, P(dWa), 2 * f, P(dba), n, P(wsn),
+                                  wsn.numel(), cs()), "bwd")
+    img = f % 16 == 0 and f >= 128
+    dga, dbea, dbia = new(f), new(f), new(f)
+    dzp_a = ops.P3.empty(n, f, DEV) if img else None
+    wl = torch.empty(int(lib.gte_ln_relu_bwd_workspace_bytes(n, f)), dtype=torch.uint8, device=DEV)
+    if img:
+        check(lib.gte_ln_relu_bwd_p3(P(dh), f, P(z), 2 * f, P(stats), P(gam), P(bet), int(relu), P(dh), f, P(dzp_a.data), dzp_a.ldp,
+                                     P(dga), P(dbea), P(dbia), n, f, P(wl), wl.numel(), cs()), "ln bwd p3")
+    else:
+        check(lib.gte_ln_relu_bwd(P(dh), f, P(z), 2 * f, P(stats), P(gam), P(bet), int(relu), P(dh), f, P(dga), P(dbea), P(dbia), n, f,
+                                  P(wl), wl.numel(), cs()), "ln bwd")
+    # one launch
+    dzb, dWb, dbb, dgb, dbeb, dbib = torch.full((n, f), 7.0, device=DEV), new(c, 2 * f), new(c), new(f), new(f), new(f)
+    dzp_b = ops.P3.empty(n, f, DEV) if f % 16 == 0 else None
+    wln = torch.empty(int(lib.gte_sage_narrow_bwd_ln_workspace_bytes(n, f)), dtype=torch.uint8, device=DEV)
+    check(lib.gte_sage_narrow_bwd_ln_p3(P(dl), c, P(q), c, P(h), f, f, P(W), 2 * f, c, P(dzb), f,
+                                        P(dzp_b.data) if dzp_b is not None else None, dzp_b.ldp if dzp_b is not None else 0,
+                                        P(dWb), 2 * f, P(dbb), n, P(wsn), wsn.numel(), None, 1.0, None, P(z), 2 * f, P(stats), P(gam),
+                                        P(bet), int(relu), P(dgb), P(dbeb), P(dbib), P(wln), wln.numel(), cs()), "bwd_ln_p3")
+    if img:
+        assert torch.equal(dzb, dh)
+    else:           # narrow rows: the separate launch runs another LayerNorm backward kernel (same maths, other instruction order)
+        np.testing.assert_allclose(dzb.cpu().numpy(), dh.cpu().numpy(), rtol=2e-5, atol=3e-6 * float(dh.abs().max()))
+    if dzp_b is not None:
+        assert torch.equal(ops.p3_to_f32(dzp_b), dzb)
+    if img:
+        assert torch.equal(dzp_b.data, dzp_a.data)
+    for got, want in ((dWb, dWa), (dbb, dba), (dgb, dga), (dbeb, dbea), (dbib, dbia)):
+        ref = want.cpu().numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=3e-6 * np.abs(ref).max() + 1e-12)
+
+
 @pytest.mark.parametrize("n,f,c,weighted,flt", [(1500, 256, 9, True, True), (777, 64, 4, False, False), (65, 8, 16, True, False),
                                                   (24495, 256, 9, False, True)])
 def test_fused_head_matches_the_separate_kernels(n, f, c, weighted, flt):
