@@ -417,6 +417,9 @@ narrow_fwd_mfma16_kernel(const float* __restrict__ h, int64_t ldh, const float* 
 struct LnBackward {
     const float* z; int64_t ldz; const float* stats; const float* gamma; const float* beta; int relu; float* lnpart;
     char* dzp3; int64_t ldp3;                   // LNB == 2: dz additionally as a P3 image (csrc/p3.h)
+    // q = A_w^T (norm dl) computed by the kernel itself from the out-edge CSR (q == NULL): the 9-wide transpose aggregation of the
+    // output layer's gradient costs a launch of its own otherwise (rows of dl are 48 bytes: the whole matrix lives in L2)
+    const int32_t* rindptr; const int32_t* rindices; const float* rw;
 };
 
 // LNB: 0 plain; 1 LayerNorm backward in the accumulator layout (row sums across the four waves: the round-2 form, off by default);
@@ -482,8 +485,30 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
             const int idx = threadIdx.x + 256 * t;
             const int r = idx / KD, kk = idx - r * KD, c = kk < NCT ? kk : kk - NCT;
             dvn[t] = 0.f;
-            if (idx < 32 * KD && r0 + r < n && c < C)
-                dvn[t] = kk < NCT ? dl[(int64_t)(r0 + r) * lddl + c] : q[(int64_t)(r0 + r) * ldq + c];
+            if (idx < 32 * KD && r0 + r < n && c < C) {
+                if (kk < NCT) dvn[t] = dl[(int64_t)(r0 + r) * lddl + c];
+                else if (q) dvn[t] = q[(int64_t)(r0 + r) * ldq + c];
+                else {
+                    // q[r0 + r, c] = sum over the row's out-edges of w_e dl[dst_e, c], in CSR order with sequential fmaf: the
+                    // summation order (and the bits) of gte_spmm_csr on the same CSR.  Four edges in flight.
+                    const int lo = lnb.rindptr[r0 + r], hi = lnb.rindptr[r0 + r + 1];
+                    float sacc = 0.f;
+                    for (int e = lo; e < hi; e += 4) {
+                        int u[4]; float w[4], v[4];
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) {
+                            const bool live = e + k2 < hi;
+                            u[k2] = live ? lnb.rindices[e + k2] : 0;
+                            w[k2] = live ? (lnb.rw ? lnb.rw[e + k2] : 1.0f) : 0.f;
+                        }
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) v[k2] = dl[(int64_t)u[k2] * lddl + c];
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) sacc = fmaf(w[k2], v[k2], sacc);
+                    }
+                    dvn[t] = sacc;
+                }
+            }
         }
     };
     if ((int)blockIdx.x < nblk) request(blockIdx.x);
@@ -971,8 +996,9 @@ int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, 
     if (!gte_sage_narrow_supported(n_feat, n_out) || n_nodes < 0 || n_nodes > INT32_MAX)
         return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd: needs n_out <= 16 and n_feat <= 256");
     if (n_nodes == 0) return GTE_OK;
-    if (!dl || !q || !h || !W || !dW || !workspace) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd: null pointer");
-    if (lddl < n_out || ldq < n_out || ldh < n_feat || ldw < 2 * n_feat || lddw < 2 * n_feat || (dh && lddh < n_feat))
+    if (!dl || (!q && !(lnb && lnb->rindptr)) || !h || !W || !dW || !workspace)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd: null pointer");
+    if (lddl < n_out || (q && ldq < n_out) || ldh < n_feat || ldw < 2 * n_feat || lddw < 2 * n_feat || (dh && lddh < n_feat))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd: leading dimension too small");
     if (workspace_bytes < gte_sage_narrow_bwd_workspace_bytes(n_nodes, n_feat, n_out))
         return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd: workspace too small");
@@ -1110,8 +1136,9 @@ extern "C" int gte_sage_narrow_bwd_ln_p3(const float* dl, int64_t lddl, const fl
                                          float* out3, const float* z_below, int64_t ldz, const float* stats_below,
                                          const float* gamma_below, const float* beta_below, int relu_below, float* dgamma_below,
                                          float* dbeta_below, float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes,
-                                         void* stream) {
+                                         const int32_t* rindptr, const int32_t* rindices, const float* rweight, void* stream) {
     if (!gte_head_supported(n_feat, n_out)) return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd_ln_p3: see gte_head_supported");
+    if (!q && !rindptr) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln_p3: q or the out-edge CSR");
     if (!dz_below || !z_below || !stats_below || !gamma_below || !beta_below || !ln_workspace || (ce_partial && !out3))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln_p3: null pointer");
     if (ldz < n_feat || lddz < n_feat || (dzp3 && (ldp3 < (int64_t)p3::row_bytes(n_feat) || ldp3 % 16 != 0 || n_feat % 16 != 0)))
@@ -1119,7 +1146,7 @@ extern "C" int gte_sage_narrow_bwd_ln_p3(const float* dl, int64_t lddl, const fl
     if (ln_workspace_bytes < gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_feat))
         return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd_ln_p3: LayerNorm workspace too small");
     const LnBackward lnb = {z_below, ldz, stats_below, gamma_below, beta_below, relu_below, reinterpret_cast<float*>(ln_workspace),
-                            reinterpret_cast<char*>(dzp3), ldp3};
+                            reinterpret_cast<char*>(dzp3), ldp3, q ? nullptr : rindptr, rindices, rweight};
     return narrow_bwd_impl(dl, lddl, q, ldq, h, ldh, n_feat, W, ldw, n_out, dz_below, lddz, dW, lddw, dbias, n_nodes, workspace,
                            workspace_bytes, reinterpret_cast<const float*>(ce_partial),
                            gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream, &lnb, dgamma_below,
@@ -1144,7 +1171,7 @@ extern "C" int gte_sage_narrow_bwd_ln(const float* dl, int64_t lddl, const float
     if (ln_workspace_bytes < gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_feat))
         return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd_ln: LayerNorm workspace too small");
     const LnBackward lnb = {z_below, ldz, stats_below, gamma_below, beta_below, relu_below, reinterpret_cast<float*>(ln_workspace),
-                            nullptr, 0};
+                            nullptr, 0, nullptr, nullptr, nullptr};
     return narrow_bwd_impl(dl, lddl, q, ldq, h, ldh, n_feat, W, ldw, n_out, dz_below, lddz, dW, lddw, dbias, n_nodes, workspace,
                            workspace_bytes, reinterpret_cast<const float*>(ce_partial),
                            gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream, &lnb, dgamma_below,

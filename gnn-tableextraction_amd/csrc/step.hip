@@ -53,17 +53,20 @@ int forward(const gte_step_plan& p, void* st) {
 // backward of the output layer and of hidden layers n_hidden - 1 .. 1, and of layer 0 up to its weight-gradient GEMM
 int backward_a(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes, C = p.n_classes;
-    GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
     bool ln_done = false;
     const gte_step_layer& T = p.layer[p.n_hidden - 1];
     if ((p.fuse_ln_dx & 2) && T.kind == GTE_LAYER_PLANES && T.fout % 16 == 0 && gte_head_supported(p.out_fin, C)) {
-        // ... with the LayerNorm(+ReLU) backward of the last hidden layer on the dh tile of every row block
-        GTE_TRY(gte_sage_narrow_bwd_ln_p3(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C, p.dh_out, p.out_fin,
-                                          T.dzp, T.ldp_o, p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes, p.ce_part,
-                                          p.grad_scale, p.out3, T.t, 2 * T.fout, T.stats, T.gamma, T.beta, T.relu, T.ggamma, T.gbeta, T.gbias,
-                                          T.ws_ln, T.ws_ln_bytes, st));
+        // the output layer's backward forms q = A_w^T (norm dl) itself (p.fuse_ln_dx & 4) and runs the LayerNorm(+ReLU) backward of
+        // the last hidden layer on the dh tile of every row block
+        const bool own_q = (p.fuse_ln_dx & 4) != 0;
+        if (!own_q) GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
+        GTE_TRY(gte_sage_narrow_bwd_ln_p3(p.dl, C, own_q ? nullptr : p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C,
+                                          p.dh_out, p.out_fin, T.dzp, T.ldp_o, p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes,
+                                          p.ce_part, p.grad_scale, p.out3, T.t, 2 * T.fout, T.stats, T.gamma, T.beta, T.relu, T.ggamma,
+                                          T.gbeta, T.gbias, T.ws_ln, T.ws_ln_bytes, p.rindptr, p.rindices, p.w_out, st));
         ln_done = true;
     } else {
+        GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
         GTE_TRY(gte_sage_narrow_bwd_ce(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C, p.dh_out, p.out_fin,
                                        p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes, p.ce_part, p.grad_scale, p.out3, st));
     }

@@ -172,6 +172,9 @@ class FusedGcnSageStep(TrainStep):
         self.fuse_ln_dx = os.environ.get("GTE_FUSE_LN_DX", "1") == "1"
         # ... and of the last hidden layer inside the output layer's backward (gte_sage_narrow_bwd_ln_p3)
         self.fuse_ln_narrow = os.environ.get("GTE_FUSE_LN_NARROW", "1") == "1"
+        # ... which can also form q = A_w^T (norm dl) itself instead of a 9-wide aggregation launch.  Off: the dependent chain
+        # indptr -> edges -> dl rows in front of every row block costs 18 us of kernel time for the 6 us launch it saves
+        self.fuse_q_narrow = os.environ.get("GTE_FUSE_Q_NARROW", "0") == "1"
         # the one-call step launched as an executable graph that is updated per batch (needs a non-default current stream)
         self.use_step_graph = os.environ.get("GTE_STEP_GRAPH", "0") == "1"
         self._step_exec = ctypes.c_void_p(None)
@@ -490,7 +493,7 @@ class FusedGcnSageStep(TrainStep):
                                                                         P(self.exp_avg_sq))
                 plan.n_param = self.flat_param.numel()
                 plan.hyper, plan.step_counter, plan.ticket = P(self._hyper), P(self._step_dev), P(self._ticket)
-            plan.fuse_ln_dx = int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0)
+            plan.fuse_ln_dx = int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (4 if self.fuse_q_narrow else 0)
             if self._tail_ws is None:
                 self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=self.flat_param.device)
             if self.tail_split:
@@ -778,7 +781,9 @@ class FusedGcnSageStep(TrainStep):
             gbe = self._gslice[id(L.lynorm.bias)] if ln else None
             if self._narrow(L, fin):
                 # q = A_w^T (norm * dlogits) on C columns; dW = [dl^T h | q^T h], dh = dl W_s + q W_n, dbias = colsum(dl)
-                aggregate(rcsr, w_out, None, dy, fout, b["q"], fout, fout, _lib.REDUCE_SUM, False)
+                own_q = self.fuse_q_narrow and self._ln_rows_below(i, layers, fin, b)        # the backward kernel forms q itself
+                if not own_q:
+                    aggregate(rcsr, w_out, None, dy, fout, b["q"], fout, fout, _lib.REDUCE_SUM, False)
                 dh = b["dy"][i - 1] if i > 0 else None
                 ln_below = self._ln_below_fused(i, layers, fin)
                 with timed("narrow_bwd", 3.0 * n * fin * 4):
@@ -806,12 +811,13 @@ class FusedGcnSageStep(TrainStep):
                         Lb, gsl, dzb, wsl = layers[i - 1], self._gslice, b["dzp"][i - 1], b["ws_ln"][i - 1]
                         hs = self._head_scale
                         check(lib.gte_sage_narrow_bwd_ln_p3(
-                            P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout, P(dh), fin, P(dzb.data), dzb.ldp,
+                            P(dy), fout, None if own_q else P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout, P(dh), fin,
+                            P(dzb.data), dzb.ldp,
                             P(gW), 2 * fin, P(gb), n, P(b["ws_nar"]), b["ws_nar"].numel(), P(b["ce_part"]) if hs is not None else None,
                             hs if hs is not None else 1.0, P(b["out3"]) if hs is not None else None, P(b["t"][i - 1]), 2 * fin,
                             P(b["stats"][i - 1]), P(Lb.lynorm.weight), P(Lb.lynorm.bias), int(Lb.activation is not None),
                             P(gsl[id(Lb.lynorm.weight)]), P(gsl[id(Lb.lynorm.bias)]), P(gsl[id(Lb.linear.bias)]), P(wsl), wsl.numel(),
-                            st), "gte_sage_narrow_bwd_ln_p3")
+                            P(rcsr.indptr), P(rcsr.indices), P(w_out), st), "gte_sage_narrow_bwd_ln_p3")
                         self._ln_p3_done = i - 1
                     elif self._head_scale is not None and i == len(layers) - 1:
                         check(lib.gte_sage_narrow_bwd_ce(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,

@@ -408,7 +408,8 @@ typedef struct gte_step_plan {
     float* hyper; int64_t* step_counter; uint32_t* ticket;
     void* tail_ws; int64_t tail_ws_bytes;
     int fuse_ln_dx;                        /* bit 0: dX of a PLANES layer above a PLANES layer runs gte_gemm_p3_nt_ln_bwd;
-                                              bit 1: the output layer's backward runs gte_sage_narrow_bwd_ln_p3          */
+                                              bit 1: the output layer's backward runs gte_sage_narrow_bwd_ln_p3;
+                                              bit 2: ... and forms q = A_w^T (norm dl) itself (no 9-wide aggregation launch) */
 } gte_step_plan;
 int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
 /* The whole step (phase 0) captured from `stream` -- not the legacy null stream -- and launched as ONE executable graph kept in
@@ -516,7 +517,10 @@ int gte_sage_narrow_bwd_ln_p3(const float* dl, int64_t lddl, const float* q, int
                               int64_t workspace_bytes, const void* ce_partial, float grad_scale, float* out3,
                               const float* z_below, int64_t ldz, const float* stats_below, const float* gamma_below,
                               const float* beta_below, int relu_below, float* dgamma_below, float* dbeta_below,
-                              float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes, void* stream);
+                              float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes, const int32_t* rindptr,
+                              const int32_t* rindices, const float* rweight, void* stream);
+/* (q may be NULL when the out-edge CSR rindptr / rindices / rweight -- weights x 1 / in_degree(dst) -- is given: the kernel then
+ * forms q = A_w^T (norm dl) itself, in the summation order of gte_spmm_csr: one 9-wide aggregation launch less.) */
 int gte_sage_narrow_bwd_ln(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
                            int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dz_below, int64_t lddz,
                            float* dW, int64_t lddw, float* dbias, int64_t n_nodes, void* workspace, int64_t workspace_bytes,
