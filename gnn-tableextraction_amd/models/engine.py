@@ -569,6 +569,9 @@ class FusedGcnSageStep(TrainStep):
             n, f0 = x.shape
         b = self._buffers(n, f0, self._private_key)
         b["xp"] = xp
+        # (kept with the buffer set, not with this call's row views: backward_rest() of the data-parallel overlap reads what the
+        # forward of forward_backward() left)
+        b["hp_used"] = b["_full"].setdefault("_hp_used", [None] * len(self.model.layers))
         layers = list(self.model.layers)
         ew = g.edata.get("feat")
         csr, rcsr = g.in_csr(), g.out_csr()
@@ -630,7 +633,7 @@ class FusedGcnSageStep(TrainStep):
         ws, wsn = P(b["ws"]), b["ws"].numel()
         # ---------------- forward ----------------
         h = x
-        b["hp_used"] = [None] * len(layers)
+        b["hp_used"][:] = [None] * len(layers)
         fused_head = False
         pending_ln = None            # (layer, z, y, stats) of a LayerNorm left to the output layer's forward kernel
         hp_in = None                 # P3 image of the current layer's input (set by the producer of h)

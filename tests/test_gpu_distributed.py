@@ -14,6 +14,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 F0, HID, NPAGES, BATCH, STEPS = 63, 96, 16, 4, 2
+SHAPES = {"narrow": (63, 96), "planes": (160, 128)}      # "planes": both hidden layers multiply P3 images (the default path of cfg2)
 
 
 def _free_port():
@@ -32,7 +33,8 @@ def _graph(gte, G, S, pages, ids, dev):
     return g, torch.from_numpy(label).to(dev)
 
 
-def _worker(rank, world, port, out_dir, overlap):
+def _worker(rank, world, port, out_dir, overlap, shape="narrow"):
+    F0, HID = SHAPES[shape]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       GTE_DP_OVERLAP=overlap)
     import torch.distributed as dist
@@ -66,14 +68,16 @@ def _worker(rank, world, port, out_dir, overlap):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("shape", ["narrow", "planes"])
 @pytest.mark.parametrize("overlap", ["0", "1"])       # one all-reduce behind one graph (default) / two around layer 0's backward
-def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, overlap):
+def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, overlap, shape):
+    F0, HID = SHAPES[shape]
     import gnn_tableextraction_amd as gte
     from gnn_tableextraction_amd import distributed as D, graph as G
     from gnn_tableextraction_amd.data import synthetic as S
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
     world = 2
-    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), overlap), nprocs=world, join=True,
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), overlap, shape), nprocs=world, join=True,
                        start_method="spawn")
     p0, p1 = np.load(tmp_path / "param_0.npy"), np.load(tmp_path / "param_1.npy")
     np.testing.assert_array_equal(p0, p1)                        # replicas stay bit-identical

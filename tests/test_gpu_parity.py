@@ -635,6 +635,8 @@ def test_smallk_input_layer_backward_in_one_pass(m, k1, k2, n_out, relu):
     z the forward saved)."""
     from gnn_tableextraction_amd import _lib
     lib, P = _lib.load(), _lib.ptr
+    if os.environ.get("GTE_SMALLK_BWD", "1")[0] == "0":
+        pytest.skip("the one-pass backward is switched off")
     assert lib.gte_sage_smallk_bwd_supported(k1 + k2, n_out) == 1
     rng = np.random.default_rng(m + n_out)
     a1 = rng.standard_normal((m, k1)).astype(np.float32)
