@@ -300,8 +300,8 @@ class FusedGcnSageStep(TrainStep):
 
     def _ln_below_fused(self, i: int, layers, fin: int) -> bool:
         """The output layer's backward also runs the LayerNorm(+ReLU) backward of layer i-1 (gte_sage_narrow_bwd_ln)."""
-        if not self.fuse_ln_below or not self.fused_head or i == 0 or i != len(layers) - 1:
-            return False
+        if not self.fuse_ln_below or not self.fused_head or i == 0 or i != len(layers) - 1 or self._planes_on():
+            return False          # (with P3 operands the row form gte_sage_narrow_bwd_ln_p3 does this, see _ln_rows_below)
         Lb = layers[i - 1]
         return (isinstance(Lb.lynorm, nn.LayerNorm) and self._narrow(layers[i], fin)
                 and bool(self.lib.gte_head_supported(fin, layers[i].out_feats)))
@@ -521,7 +521,7 @@ class FusedGcnSageStep(TrainStep):
         plan.labels, plan.labels_f32 = P(lab), int(lab.dtype == torch.float32)
         plan.grad_scale = float(grad_scale)
         addr = ctypes.addressof(plan)
-        if self.use_step_graph and st:
+        if self.use_step_graph and st and not torch.cuda.is_current_stream_capturing():
             # the whole step as one executable-graph launch (updated in place per batch); the next batch's assembly is queued first
             if self.before_last_gemm is not None:
                 self.before_last_gemm()
