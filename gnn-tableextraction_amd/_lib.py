@@ -95,6 +95,12 @@ SIGNATURES = {
     "gte_gemm_p3_nt_ln_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                       c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_gemm_p3_nt_smallk_bwd_supported": (c_int, [c_int64, c_int64]),
+    "gte_gemm_p3_nt_smallk_bwd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "gte_gemm_p3_nt_smallk_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                          c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                          c_void_p]),
     "gte_gemm_p3_nt_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                     c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "gte_gemm_p3_tn_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,

@@ -23,6 +23,7 @@
 //   four k rows a transposing read (ds_read_b64_tr_b16) touches fall on disjoint banks.
 #include "gte_common.h"
 #include "p3.h"
+#include "smallk_step.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -67,6 +68,10 @@ struct P3Gemm {
     // and leaves the column partials {sum g xhat, sum g, sum dz} in ln_part[tile][3][N]  (gte_gemm_p3_nt_ln_bwd)
     const float* ln_z; long long ln_ldz; const float* ln_stats; const float* ln_gamma; const float* ln_beta; int ln_relu;
     float* ln_dz; long long ln_lddz; char* ln_dzp3; long long ln_ldp3; float* ln_part;
+    // ... or the WHOLE backward of a short-input layer below (gte_gemm_p3_nt_smallk_bwd): z recomputed from its k1 + k2 <= 28 inputs,
+    // LayerNorm backward, dW = dz^T [x | ahn] accumulated per lane; outputs: sk_part_dw[tile][N][K], ln_part[tile][3][N]
+    const float* sk_x; long long sk_ldx; int sk_k1; const float* sk_ahn; long long sk_ldahn; int sk_k2;
+    const float* sk_W; long long sk_ldw; const float* sk_bias; float* sk_part_dw;
 };
 
 
@@ -189,7 +194,152 @@ constexpr int SG_VALU = 0x002, SG_SALU = 0x004, SG_MFMA = 0x008, SG_VMEM_R = 0x0
 // descriptor and move nothing), so the count is a compile-time constant.
 // What the tile size buys: a stage moves (BM + BN) * 96 bytes into LDS for BM * BN * 16 * 2 * 6 flop, i.e. at the full matrix
 // rate a CU has to take in 2048 (1 / BM + 1 / BN) bytes per cycle: 32 at 128 x 128, 18.7 at 192 x 256, 16 at 256 x 256.
-template <int WM, int WN, int TM, int TN, int NBUF, int WGS>
+// ---- epilogue of an NT tile that holds whole rows (BN = 256): the whole backward of a short-input layer below ------------------
+// (csrc/smallk_step.h; called by the ring kernel with every wave of the workgroup behind the ring's last barrier)
+template <int TM, int TN, int WM, int WN, int LDS_BYTES>
+__device__ __forceinline__ void smallk_bwd_epilogue(const f32x16 (&acc)[TM][TN], char* lds, const P3Gemm& p, int m0, unsigned lb, int wave,
+                                                    int wm, int wn, int lane, int tid) {
+    constexpr int NW = WM * WN, BM = WM * TM * 32, KMAX = 28, KC = KMAX / 4, XR = 32;     // XR: rows whose inputs are staged at a time
+    static_assert(WN * TN * 32 == 256 && TN == 2 && NW == 8, "whole rows per workgroup, eight waves");
+    // the WHOLE tile goes to LDS at once (every wave's accumulators are free before the 4 x 28 dW accumulators come alive:
+    // with half the tile at a time the other half's accumulators and the dW sums did not fit 256 registers)
+    static_assert((BM * 256 + KMAX * 256 + XR * KMAX) * 4 <= LDS_BYTES, "LDS");
+    // (the two stages requested past the end are empty windows, and an out-of-range LDS-DMA lane WRITES a zero: every wave's
+    // requests have landed before any wave re-uses the stage images)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    float* tile = reinterpret_cast<float*>(lds);                   // [BM][256]
+    float* Wt = tile + BM * 256;                                   // [Kp][256] (of [KMAX][256]), rows K .. Kp-1 zero
+    float* xs = Wt + KMAX * 256;                                   // [XR][Kp]
+    const int n = p.N, M = p.M, K = p.sk_k1 + p.sk_k2, Kp = (K + 3) & ~3, ns = 256;
+    const int j4 = 4 * lane;
+    const bool okc = j4 < n;
+    const int col_l = lane & 31, hrow = (lane >> 5) * 4;
+    {
+        float wv[KMAX];                                            // W^T: thread c < 256 walks row c of W
+        const float* wr = p.sk_W + (long long)min(tid, n - 1) * p.sk_ldw;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) wv[k] = k < K ? wr[k] : 0.f;
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tile[(wm * TM * 32 + a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * 256 + wn * 64 + b * 32 + col_l] = acc[a][b][r];
+        if (tid < 256) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (k < Kp) Wt[k * ns + tid] = tid < n ? wv[k] : 0.f;
+        }
+    }
+    float b4[4] = {0.f, 0.f, 0.f, 0.f}, g4[4] = {0.f, 0.f, 0.f, 0.f}, be4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (okc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b4[e] = p.sk_bias[j4 + e]; g4[e] = p.ln_gamma[j4 + e]; be4[e] = p.ln_beta[j4 + e]; }
+    }
+    float dw[4][KMAX], s_dg[4] = {0.f, 0.f, 0.f, 0.f}, s_db[4] = {0.f, 0.f, 0.f, 0.f}, s_dbias[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) dw[e][k] = 0.f;
+    const float inv_n = 1.0f / (float)n;
+    const float* wl = Wt + (okc ? j4 : 0);
+    for (int c0 = 0; c0 < BM; c0 += XR) {
+        const int row_base = m0 + c0;
+        if (row_base >= M) break;                                  // uniform
+        float xv[KMAX / 4];                                        // the chunk's inputs: 4 threads per row
+        const int rlx = tid >> 2, part = tid & 3;
+        if (rlx < XR) {
+            const int r = min(row_base + rlx, M - 1);
+            const float* r1 = p.sk_x + (long long)r * p.sk_ldx;
+            const float* r2 = p.sk_ahn ? p.sk_ahn + (long long)r * p.sk_ldahn : r1;
+#pragma unroll
+            for (int i = 0; i < KMAX / 4; ++i) {
+                const int k = part + 4 * i;
+                xv[i] = 0.f;
+                if (k < p.sk_k1) xv[i] = r1[k];
+                else if (k < K) xv[i] = r2[k - p.sk_k1];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // tile / W^T written; the previous chunk's readers are done
+        if (rlx < XR) {
+#pragma unroll
+            for (int i = 0; i < KMAX / 4; ++i) {
+                const int k = part + 4 * i;
+                if (k < Kp) xs[rlx * Kp + k] = xv[i];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int rl0 = 2 * wave; rl0 < XR; rl0 += 2 * NW) {         // two rows per step
+            float gy[2][4], mean[2], rstd[2];
+            bool rok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int rg = row_base + rl0 + u;
+                rok[u] = rg < M;
+                const int rc = min(rg, M - 1);
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (okc && rok[u]) t = *reinterpret_cast<const float4*>(tile + (c0 + rl0 + u) * 256 + j4);
+                gy[u][0] = t.x; gy[u][1] = t.y; gy[u][2] = t.z; gy[u][3] = t.w;
+                mean[u] = p.ln_stats[rc]; rstd[u] = p.ln_stats[M + rc];
+            }
+            if (!rok[0]) break;                                     // wave-uniform
+            gte_smallk_bwd_step<KMAX, 2>(gy, mean, rstd, rok, okc, xs + rl0 * Kp, Kp, wl, ns, b4, g4, be4, p.ln_relu, inv_n, dw, s_dg, s_db,
+                                         s_dbias);
+        }
+    }
+    // the eight waves' partial sums through LDS, a quarter of the k range per round (csrc/smallk_bwd.hip), into the tile's [N][K]
+    // result in LDS; global stores last, coalesced
+    float* red = reinterpret_cast<float*>(lds);                    // [NW][KC][256]
+    float* obuf = red + NW * KC * 256;                             // [N][K]
+    static_assert((NW * KC * 256 + 256 * KMAX) * 4 <= LDS_BYTES, "LDS");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c * KC < Kp) {                                          // uniform
+            if (okc) {
+#pragma unroll
+                for (int kk = 0; kk < KC; ++kk) {
+                    const int k = c * KC + kk;
+                    float4 v; v.x = dw[0][k]; v.y = dw[1][k]; v.z = dw[2][k]; v.w = dw[3][k];
+                    *reinterpret_cast<float4*>(red + (wave * KC + kk) * 256 + j4) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (tid < n) {
+#pragma unroll
+                for (int kk = 0; kk < KC; ++kk) {
+                    const int k = c * KC + kk;
+                    if (k < K) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) v += red[(w * KC + kk) * 256 + tid];
+                        obuf[tid * K + k] = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[(wave * 3 + 0) * 256 + j4 + e] = s_dg[e];
+        red[(wave * 3 + 1) * 256 + j4 + e] = s_db[e];
+        red[(wave * 3 + 2) * 256 + j4 + e] = s_dbias[e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    float* pp = p.ln_part + (long long)lb * 3 * n;
+    for (int i = tid; i < 3 * 256; i += NW * 64) {
+        const int q = i >> 8, j = i & 255;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[(w * 3 + q) * 256 + j];
+        if (j < n) pp[q * n + j] = v;
+    }
+    float* pd = p.sk_part_dw + (long long)lb * n * K;
+    for (int e = tid; e < n * K; e += NW * 64) pd[e] = obuf[e];
+}
+
+template <int WM, int WN, int TM, int TN, int NBUF, int WGS, int EPI = 0>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN * WGS + 3) / 4)
 gemm_p3_nt_ring_kernel(const P3Gemm p) {
     constexpr int NW = WM * WN;
@@ -347,8 +497,11 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
         st[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 #endif
-    store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
-                       p.accumulate, lane);
+    if constexpr (EPI == 2)
+        smallk_bwd_epilogue<TM, TN, WM, WN, 160 * 1024>(acc, lds, p, m0, lb, wave, wm, wn, lane, tid);     // (launched with 160 KB of LDS)
+    else
+        store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
+                           p.accumulate, lane);
 }
 
 // The same ring kernel on v_mfma_f32_16x16x32_bf16.  One MFMA covers K = 32: the two 16-deep halves are TWO PLANE PRODUCTS of
@@ -505,7 +658,9 @@ gemm_p3_nt_ring16_kernel(const P3Gemm p) {
 // instructions, in order, in front of its MFMAs: 21 of 97 us on the layer-0 forward (profiles/r03/gemm_p3.md, ablation "no
 // DMA").  A loader wave's stream is: request stage t + 2, wait until stage t + 1 has landed (counted vmcnt), barrier; a compute
 // wave's: 3 (TM + TN) fragment reads, 6 TM TN MFMAs, barrier.  One barrier per stage for all waves.
-template <int WM, int WN, int TM, int TN, int NL, bool LNB = false>
+// LNB: 0 plain store; 1 LayerNorm(+ReLU) backward of the tile's rows as the epilogue; 2 the whole backward of a short-input
+// layer below as the epilogue
+template <int WM, int WN, int TM, int TN, int NL, int LNB = 0>
 __global__ void __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL + 3) / 4)
 gemm_p3_nt_lw_kernel(const P3Gemm p) {
     constexpr int NW = WM * WN, NBUF = 3;
@@ -573,6 +728,9 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
             wr = wr + 1 == NBUF ? 0 : wr + 1;
             wait_dma_barrier<NI>();
         }
+        // an epilogue that re-uses the stage images must not start before the LAST requests have landed: the two stages
+        // requested past the end are empty windows, and an out-of-range LDS-DMA lane WRITES a zero
+        if constexpr (LNB != 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         return;
     }
     // ---------------- compute ----------------
@@ -611,11 +769,13 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         rd = rd + 1 == NBUF ? 0 : rd + 1;
     }
-    if constexpr (!LNB) {
+    if constexpr (LNB == 0) {
         store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
                            p.accumulate, lane);
     } else {
-        // ---- LayerNorm(+ReLU) backward of the tile's rows (the loader waves have left; the stage images are dead) ----
+        // ---- LayerNorm(+ReLU) backward of the tile's rows (the stage images are dead once the loader waves' last requests have
+        // landed: they wait for them and join this barrier before they leave) ----
+        asm volatile("s_barrier" ::: "memory");
         // Per slice of TM * 32 rows: the waves that own them put their accumulators into LDS row-major, then every wave takes
         // rows of the slice in the layout of ln_relu_bwd_vec_kernel (lane l = columns 4 l .. 4 l + 3, two rows in flight) with
         // ITS arithmetic: dz is bit for bit what the separate launch computes from the stored product.
@@ -1155,18 +1315,18 @@ void launch_lw(const P3Gemm& p, hipStream_t s) {
     const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
     hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
-template <int WM, int WN, int TM, int TN, int NL>
+template <int WM, int WN, int TM, int TN, int NL, int LNB = 1>
 void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NI = ((BM + BN) * 96 / 1024 + NL - 1) / NL, shm = 3 * NI * NL * 1024;
     static_assert(shm >= TM * 32 * 256 * 4 && shm >= WM * WN * 3 * 256 * 4, "the epilogue's row slice lives in the stage images");
     static bool configured = false;
     if (!configured) {
-        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, true>), shm);
+        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB>), shm);
         configured = true;
     }
     const dim3 grid((unsigned)gte::ceil_div(p.M, BM));
-    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, true>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
+    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
 // Configurations (measured on the step's shapes, profiles/r03/gemm_p3.md): the kernel runs at the chip's power limit
 // (~1.3 PF bf16 whatever the tile), so what matters is ONE balanced round of tiles: the row tile is the smallest of
@@ -1293,6 +1453,86 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
             hipLaunchKernelGGL(p3_colsum_fold_kernel, dim3((unsigned)gte::ceil_div(n, 256)), dim3(256), 0, s, p.ln_part + i * n,
                                (long long)3 * n, nb, (int)n, outs[i]);
     return gte::check_launch("gemm_p3_nt_ln_bwd fold");
+}
+
+// ---- ... with the WHOLE backward of a short-input layer below (gte_sage_smallk_bwd) as its epilogue --------------------------
+extern "C" int gte_gemm_p3_nt_smallk_bwd_supported(int64_t k_total, int64_t n) {
+    return (gte_gemm_p3_nt_ln_bwd_supported(n) && k_total >= 1 && k_total <= 28) ? 1 : 0;
+}
+extern "C" int64_t gte_gemm_p3_nt_smallk_bwd_workspace_bytes(int64_t m, int64_t k_total, int64_t n) {
+    if (m <= 0 || n <= 0 || k_total <= 0) return 256;
+    return gte::round_up(gte::ceil_div(m, 128) * n * (k_total + 3) * 4, 256);        // (always the 128-row tile)
+}
+// dy = [a1 | a2] b^T (m x n, n <= 256) is the gradient w.r.t. the output of a short-input INPUT layer y = relu?(LN([x | ahn] W^T +
+// bias)); it is not stored: the workgroup that computed a row block recomputes z from the k1 + k2 <= 28 inputs per row, runs the
+// LayerNorm(+ReLU) backward and accumulates dW = dz^T [x | ahn]; dW / dbias / dgamma / dbeta join the fold deferral.  Replaces
+// gte_gemm_p3_nt + gte_sage_smallk_bwd (one launch, the 2 m n 4 bytes of the dy round trip).
+extern "C" int gte_gemm_p3_nt_smallk_bwd(const void* a1, int64_t lda1, int64_t kg1, const void* a2, int64_t lda2, int64_t kg2,
+                                         const void* b, int64_t ldb, const float* x, int64_t ldx, int64_t k1, const float* ahn,
+                                         int64_t ldahn, int64_t k2, const float* W, int64_t ldw, const float* bias, const float* gamma,
+                                         const float* beta, const float* stats, int relu, float* dW, int64_t lddw, float* dbias,
+                                         float* dgamma, float* dbeta, int64_t m, int64_t n, void* workspace, int64_t workspace_bytes,
+                                         void* stream) {
+    if (m < 0 || n <= 0 || kg1 <= 0 || kg2 < 0 || k1 <= 0 || k2 < 0 || m > INT32_MAX || kg1 > INT32_MAX || kg2 > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_smallk_bwd: bad sizes");
+    const int64_t K = k1 + k2;
+    if (!gte_gemm_p3_nt_smallk_bwd_supported(K, n))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_smallk_bwd: needs n <= 256, n %% 4 == 0, k1 + k2 <= 28");
+    if (m == 0) return GTE_OK;
+    if (!a1 || !b || !x || (k2 > 0 && !ahn) || !W || !bias || !gamma || !beta || !stats || !dW || !workspace || (kg2 > 0 && !a2))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_smallk_bwd: null pointer");
+    const int64_t kb1 = p3::blocks(kg1), kb2 = kg2 > 0 ? p3::blocks(kg2) : 0;
+    if (lda1 < p3::row_bytes(kg1) || (kg2 > 0 && lda2 < p3::row_bytes(kg2)) || ldb < (kb1 + kb2) * 96 || ldx < k1 || (k2 > 0 && ldahn < k2) ||
+        ldw < K || lddw < K)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_smallk_bwd: leading dimension too small");
+    if (lda1 >= (1 << 23) || lda2 >= (1 << 23) || ldb >= (1 << 23) || (m + 256) * lda1 >= ((int64_t)1 << 31) ||
+        (kg2 > 0 && (m + 256) * lda2 >= ((int64_t)1 << 31)))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_smallk_bwd: operand images must be < 2 GB with row strides < 8 MB");
+    const int64_t need = gte_gemm_p3_nt_smallk_bwd_workspace_bytes(m, K, n);
+    if (workspace_bytes < need)
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "gemm_p3_nt_smallk_bwd: needs %lld workspace bytes, got %lld", (long long)need,
+                         (long long)workspace_bytes);
+    const int bm = 128;       // (the 192-row tile's stage images are 2.5 KB short of the row slice + W^T + inputs)
+    const int nb = (int)gte::ceil_div(m, bm);
+    P3Gemm p = {};
+    p.A1 = reinterpret_cast<const char*>(a1); p.lda1 = lda1; p.KB1 = (int)kb1;
+    p.A2 = kg2 > 0 ? reinterpret_cast<const char*>(a2) : nullptr; p.lda2 = lda2; p.KB2 = (int)kb2;
+    p.B = reinterpret_cast<const char*>(b); p.ldb = ldb;
+    p.bsa1 = p.bsa2 = p.bsb = 96;
+    p.M = (int)m; p.N = (int)n; p.splits = 1;
+    p.ln_stats = stats; p.ln_gamma = gamma; p.ln_beta = beta; p.ln_relu = relu;
+    p.sk_x = x; p.sk_ldx = ldx; p.sk_k1 = (int)k1; p.sk_ahn = k2 > 0 ? ahn : nullptr; p.sk_ldahn = ldahn; p.sk_k2 = (int)k2;
+    p.sk_W = W; p.sk_ldw = ldw; p.sk_bias = bias;
+    p.sk_part_dw = reinterpret_cast<float*>(workspace);
+    p.ln_part = p.sk_part_dw + (int64_t)nb * n * K;
+    hipStream_t s = gte::as_stream(stream);
+    {
+        constexpr int shm = 160 * 1024;                             // the 128 x 256 ring tile (3 x 40 KB) + room for the whole fp32 tile
+        static bool configured = false;
+        if (!configured) {
+            GTE_SET_LDS((gemm_p3_nt_ring_kernel<2, 4, 2, 2, 3, 1, 2>), shm);
+            configured = true;
+        }
+        hipLaunchKernelGGL((gemm_p3_nt_ring_kernel<2, 4, 2, 2, 3, 1, 2>), dim3((unsigned)nb), dim3(512), shm, s, p);
+    }
+    int rc = gte::check_launch("gemm_p3_nt_smallk_bwd");
+    if (rc != GTE_OK) return rc;
+    if (gte::defer_fold(p.sk_part_dw, n * K, nb, (int)n, (int)K, dW, lddw)) {
+        gte::defer_fold(p.ln_part, 3 * n, nb, 1, (int)n, dgamma, n);
+        gte::defer_fold(p.ln_part + n, 3 * n, nb, 1, (int)n, dbeta, n);
+        gte::defer_fold(p.ln_part + 2 * n, 3 * n, nb, 1, (int)n, dbias, n);
+        return GTE_OK;
+    }
+    // (no deferral open: fold here; dW is written packed, lddw == K)
+    if (lddw != K) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_smallk_bwd: outside a fold deferral dW must be packed (lddw == k1 + k2)");
+    hipLaunchKernelGGL(p3_colsum_fold_kernel, dim3((unsigned)gte::ceil_div(n * K, 256)), dim3(256), 0, s, p.sk_part_dw, (long long)n * K, nb,
+                       (int)(n * K), dW);
+    float* outs[3] = {dgamma, dbeta, dbias};
+    for (int i = 0; i < 3; ++i)
+        if (outs[i])
+            hipLaunchKernelGGL(p3_colsum_fold_kernel, dim3((unsigned)gte::ceil_div(n, 256)), dim3(256), 0, s, p.ln_part + i * n,
+                               (long long)3 * n, nb, (int)n, outs[i]);
+    return gte::check_launch("gemm_p3_nt_smallk_bwd fold");
 }
 
 extern "C" int64_t gte_gemm_p3_tn_workspace_bytes(int64_t m, int64_t n, int64_t nseg, int64_t k) {

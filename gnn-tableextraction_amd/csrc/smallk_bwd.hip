@@ -20,6 +20,7 @@ namespace {
 #ifndef SKB_ABL
 #define SKB_ABL 0         // measurement builds: 1 no z recomputation, 2 no dW accumulation, 4 no reduction epilogue, 8 no dy loads
 #endif
+#include "smallk_step.h"
 constexpr int SKB_KLIMIT = 28;            // k1 + k2 (rounded up to 4) the per-lane dW accumulators cover (4 x 28 registers)
 constexpr int SKB_ROWS = 2;               // rows per wave step (four in the forward kernel: the per-row FMA chains are the same)
 constexpr int SKB_BLOCK_ROWS = 64;        // rows per workgroup pass: 4 waves x 8 steps x 2 rows
@@ -112,81 +113,16 @@ sage_smallk_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* 
             // two waves per SIMD nothing else hides the memory latency
             float gyn[SKB_ROWS][4], meann[SKB_ROWS], rstdn[SKB_ROWS];
             load_rows(step + 1 < STEPS ? step + 1 : step, gyn, meann, rstdn);
-            // z = [x | ahn] W^T + b: the forward kernel's loop, instruction for instruction (sage_smallk_fwd_kernel)
-            float acc[SKB_ROWS][4];
+            bool rok[SKB_ROWS];
 #pragma unroll
-            for (int u = 0; u < SKB_ROWS; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[u][e] = b4[e];
-            const float* xq = xs + rl0 * Kp;
-#pragma unroll
-            for (int kc = 0; kc < SKB_KMAX; kc += 4) {
-                if (kc >= Kp || (SKB_ABL & 1)) break;                  // uniform
-                float4 w4[4], x4[SKB_ROWS];
-#pragma unroll
-                for (int u = 0; u < SKB_ROWS; ++u) x4[u] = *reinterpret_cast<const float4*>(xq + u * Kp + kc);    // broadcast
-#pragma unroll
-                for (int i = 0; i < 4; ++i) w4[i] = *reinterpret_cast<const float4*>(wl + (kc + i) * ns);
-#pragma unroll
-                for (int u = 0; u < SKB_ROWS; ++u) {
-                    const float xk[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[u][0] = fmaf(xk[i], w4[i].x, acc[u][0]); acc[u][1] = fmaf(xk[i], w4[i].y, acc[u][1]);
-                        acc[u][2] = fmaf(xk[i], w4[i].z, acc[u][2]); acc[u][3] = fmaf(xk[i], w4[i].w, acc[u][3]);
-                    }
-                }
-            }
-            // LayerNorm + ReLU backward of the four rows (the arithmetic of ln_relu_bwd_vec_kernel), dz kept in registers
-            float dz[SKB_ROWS][4];
-#pragma unroll
-            for (int u = 0; u < SKB_ROWS; ++u) {
-                const bool rok = row0 + u < M;                          // wave-uniform
-                float xh[4], g[4];
-                float a = 0.f, b = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    xh[e] = ok ? (acc[u][e] - mean[u]) * rstd[u] : 0.f;
-                    float gv = gy[u][e];
-                    if (relu && fmaf(xh[e], g4[e], be4[e]) <= 0.f) gv = 0.f;
-                    g[e] = gv;
-                    const float dxh = gv * g4[e];
-                    a += dxh;
-                    b = fmaf(dxh, xh[e], b);
-                }
-                const float c1 = wave_sum64(a) * inv_n, c2 = wave_sum64(b) * inv_n;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = rstd[u] * (g[e] * g4[e] - c1 - xh[e] * c2);
-                    const bool live = ok && rok;
-                    dz[u][e] = live ? d : 0.f;
-                    if (rok) {
-                        s_dg[e] = fmaf(g[e], xh[e], s_dg[e]);
-                        s_db[e] += g[e];
-                        s_dbias[e] += ok ? d : 0.f;
-                    }
-                }
-            }
+            for (int u = 0; u < SKB_ROWS; ++u) rok[u] = row0 + u < M;   // wave-uniform
+            gte_smallk_bwd_step<SKB_KMAX, SKB_ROWS>(gy, mean, rstd, rok, ok, xs + rl0 * Kp, Kp, wl, ns, b4, g4, be4, relu, inv_n, dw, s_dg,
+                                                    s_db, s_dbias);
 #pragma unroll
             for (int u = 0; u < SKB_ROWS; ++u) {
                 mean[u] = meann[u]; rstd[u] = rstdn[u];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gy[u][e] = gyn[u][e];
-            }
-            // dW[j + e][k] += dz[r][j + e] * xin[r][k]
-#pragma unroll
-            for (int kc = 0; kc < SKB_KMAX; kc += 4) {
-                if (kc < Kp && !(SKB_ABL & 2)) {                         // uniform
-#pragma unroll
-                    for (int u = 0; u < SKB_ROWS; ++u) {
-                        const float4 x4 = *reinterpret_cast<const float4*>(xq + u * Kp + kc);             // broadcast
-                        const float xk[4] = {x4.x, x4.y, x4.z, x4.w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) dw[e][kc + i] = fmaf(dz[u][e], xk[i], dw[e][kc + i]);
-                    }
-                }
             }
         }
     }

@@ -50,10 +50,19 @@ int forward(const gte_step_plan& p, void* st) {
     return GTE_OK;
 }
 
+// layer 0 is a short-input layer whose whole backward rides in the epilogue of layer 1's dX (gte_gemm_p3_nt_smallk_bwd)
+bool smallk_in_dx(const gte_step_plan& p) {
+    if (!(p.fuse_ln_dx & 8) || p.n_hidden < 2) return false;
+    const gte_step_layer& B = p.layer[0];
+    const gte_step_layer& L = p.layer[1];
+    return B.kind == GTE_LAYER_SMALLK && L.kind == GTE_LAYER_PLANES && gte_sage_smallk_bwd_supported(2 * B.fin, B.fout) &&
+           gte_gemm_p3_nt_smallk_bwd_supported(2 * B.fin, L.fin);
+}
+
 // backward of the output layer and of hidden layers n_hidden - 1 .. 1, and of layer 0 up to its weight-gradient GEMM
 int backward_a(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes, C = p.n_classes;
-    bool ln_done = false;
+    bool ln_done = false, smallk_done = false;
     const gte_step_layer& T = p.layer[p.n_hidden - 1];
     if ((p.fuse_ln_dx & 2) && T.kind == GTE_LAYER_PLANES && T.fout % 16 == 0 && gte_head_supported(p.out_fin, C)) {
         // the output layer's backward forms q = A_w^T (norm dl) itself (p.fuse_ln_dx & 4) and runs the LayerNorm(+ReLU) backward of
@@ -73,6 +82,7 @@ int backward_a(const gte_step_plan& p, void* st) {
     for (int i = p.n_hidden - 1; i >= 0; --i) {
         const gte_step_layer& L = p.layer[i];
         if (L.kind == GTE_LAYER_SMALLK) {
+            if (smallk_done) continue;
             if (!gte_sage_smallk_bwd_supported(2 * L.fin, L.fout))
                 GTE_TRY(gte_ln_relu_bwd(L.dy, L.fout, L.t, L.fout, L.stats, L.gamma, L.beta, L.relu, L.dy, L.fout, L.ggamma, L.gbeta, L.gbias, n,
                                         L.fout, L.ws_ln, L.ws_ln_bytes, st));
@@ -87,7 +97,13 @@ int backward_a(const gte_step_plan& p, void* st) {
         GTE_TRY(gte_gemm_p3_tn(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, nullptr, 0, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n, L.ws_dw,
                                L.ws_dw_bytes, st));
         const gte_step_layer& B = p.layer[i - 1];
-        if ((p.fuse_ln_dx & 1) && B.kind == GTE_LAYER_PLANES && gte_gemm_p3_nt_ln_bwd_supported(L.fin)) {
+        if (i == 1 && smallk_in_dx(p)) {
+            // ... with the WHOLE backward of the short-input layer 0 as its epilogue
+            GTE_TRY(gte_gemm_p3_nt_smallk_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, B.x, B.ldx, B.fin, B.ahn,
+                                              B.fin, B.fin, B.W, 2 * B.fin, B.bias, B.gamma, B.beta, B.stats, B.relu, B.gW, 2 * B.fin, B.gbias,
+                                              B.ggamma, B.gbeta, n, L.fin, B.ws_dw, B.ws_dw_bytes, st));
+            smallk_done = true;
+        } else if ((p.fuse_ln_dx & 1) && B.kind == GTE_LAYER_PLANES && gte_gemm_p3_nt_ln_bwd_supported(L.fin)) {
             GTE_TRY(gte_gemm_p3_nt_ln_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, B.t, 2 * B.fout, B.stats, B.gamma,
                                           B.beta, B.relu, B.dy, B.fout, B.dzp, B.ldp_o, B.ggamma, B.gbeta, B.gbias, n, L.fin, B.ws_ln,
                                           B.ws_ln_bytes, st));
@@ -103,6 +119,7 @@ int backward_a(const gte_step_plan& p, void* st) {
 int backward_b(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes;
     const gte_step_layer& L = p.layer[0];
+    if (smallk_in_dx(p)) return GTE_OK;                // (layer 0's backward ran as the epilogue of layer 1's dX, phase 1)
     if (L.kind == GTE_LAYER_SMALLK && gte_sage_smallk_bwd_supported(2 * L.fin, L.fout))
         return gte_sage_smallk_bwd(L.dy, L.fout, L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.stats,
                                    L.relu, L.gW, 2 * L.fin, L.gbias, L.ggamma, L.gbeta, n, L.fout, L.ws_dw, L.ws_dw_bytes, st);

@@ -172,6 +172,9 @@ class FusedGcnSageStep(TrainStep):
         self.fuse_ln_dx = os.environ.get("GTE_FUSE_LN_DX", "1") == "1"
         # ... and of the last hidden layer inside the output layer's backward (gte_sage_narrow_bwd_ln_p3)
         self.fuse_ln_narrow = os.environ.get("GTE_FUSE_LN_NARROW", "1") == "1"
+        # dX of layer 1 with the whole backward of a short-input layer 0 as its epilogue (gte_gemm_p3_nt_smallk_bwd)
+        self.fuse_smallk_dx = os.environ.get("GTE_FUSE_SMALLK_DX", "1") == "1"
+        self._smallk_done = False
         # ... which can also form q = A_w^T (norm dl) itself instead of a 9-wide aggregation launch.  Off: the dependent chain
         # indptr -> edges -> dl rows in front of every row block costs 18 us of kernel time for the 6 us launch it saves
         self.fuse_q_narrow = os.environ.get("GTE_FUSE_Q_NARROW", "0") == "1"
@@ -249,7 +252,8 @@ class FusedGcnSageStep(TrainStep):
         # one private workspace per layer for the dW GEMMs: they run on the side stream, several at once
         b["ws_dw"] = [torch.empty(int(max(lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], cap),
                                           lib.gte_sage_qform_dw_workspace_bytes(dims[i + 1], dims[i], cap),
-                                          lib.gte_sage_smallk_bwd_workspace_bytes(cap, 2 * dims[i], dims[i + 1]) if i == 0 else 0)),
+                                          lib.gte_sage_smallk_bwd_workspace_bytes(cap, 2 * dims[i], dims[i + 1]) if i == 0 else 0,
+                                          lib.gte_gemm_p3_nt_smallk_bwd_workspace_bytes(cap, 2 * dims[i], dims[i + 1]) if i == 0 else 0)),
                                   dtype=torch.uint8, device=dev) for i in range(len(layers))]
         return b
 
@@ -493,7 +497,8 @@ class FusedGcnSageStep(TrainStep):
                                                                         P(self.exp_avg_sq))
                 plan.n_param = self.flat_param.numel()
                 plan.hyper, plan.step_counter, plan.ticket = P(self._hyper), P(self._step_dev), P(self._ticket)
-            plan.fuse_ln_dx = int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (4 if self.fuse_q_narrow else 0)
+            plan.fuse_ln_dx = (int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (4 if self.fuse_q_narrow else 0)
+                               | (8 if self.fuse_smallk_dx else 0))
             if self._tail_ws is None:
                 self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=self.flat_param.device)
             if self.tail_split:
@@ -605,6 +610,7 @@ class FusedGcnSageStep(TrainStep):
                 self._forward_loss(g, labels, grad_scale, x, n, f0, b, layers, csr, w_in, t_in, aggregate, st)
                 self._ln_done = None
                 self._ln_p3_done = None
+                self._smallk_done = False
             # ---------------- backward of layers hi .. lo ----------------
             side_used = False
             check(lib.gte_fold_defer_begin(st), "gte_fold_defer_begin")
@@ -875,7 +881,20 @@ class FusedGcnSageStep(TrainStep):
                 if i > 0:
                     wb = self._wimg[i][1]
                     Lb = layers[i - 1]
-                    if (self.fuse_ln_dx and b["pl"][i - 1] and ops._timers is None and lib.gte_gemm_p3_nt_ln_bwd_supported(fin)):
+                    fin_b = Lb.linear.weight.shape[1] // 2
+                    if (self.fuse_smallk_dx and i == 1 and self._smallk_bwd(0, Lb, fin_b) and ops._timers is None
+                            and lib.gte_gemm_p3_nt_smallk_bwd_supported(2 * fin_b, fin)):
+                        # dX with the WHOLE backward of the short-input layer below as its epilogue: nothing of layer 0 is left
+                        gsl, wsd = self._gslice, b["ws_dw"][0]
+                        check(lib.gte_gemm_p3_nt_smallk_bwd(P(dzp.data), dzp.ldp, fout, P(qp.data), qp.ldp, fout, P(wb.data), wb.ldp,
+                                                            P(x), ld(x), fin_b, P(b["ahn"][0]), fin_b, fin_b, P(Lb.linear.weight),
+                                                            2 * fin_b, P(Lb.linear.bias), P(Lb.lynorm.weight), P(Lb.lynorm.bias),
+                                                            P(b["stats"][0]), int(Lb.activation is not None), P(gsl[id(Lb.linear.weight)]),
+                                                            2 * fin_b, P(gsl[id(Lb.linear.bias)]), P(gsl[id(Lb.lynorm.weight)]),
+                                                            P(gsl[id(Lb.lynorm.bias)]), n, fin, P(wsd), wsd.numel(), st),
+                              "gte_gemm_p3_nt_smallk_bwd")
+                        self._smallk_done = True
+                    elif (self.fuse_ln_dx and b["pl"][i - 1] and ops._timers is None and lib.gte_gemm_p3_nt_ln_bwd_supported(fin)):
                         # dX with the LayerNorm(+ReLU) backward of the layer below as its epilogue: d(loss)/d(y) of that layer
                         # is never stored, its dz comes out as fp32 + image
                         gsl, dzb, wsl = self._gslice, b["dzp"][i - 1], b["ws_ln"][i - 1]
@@ -891,6 +910,10 @@ class FusedGcnSageStep(TrainStep):
                             for _ in tm.repeat():
                                 check(lib.gte_gemm_p3_nt(P(dzp.data), dzp.ldp, fout, P(qp.data), qp.ldp, fout, P(wb.data), wb.ldp, None,
                                                          0, P(b["dy"][i - 1]), fin, n, fin, 0, 0, st), "gte_gemm_p3_nt dX")
+                continue
+            if self._smallk_bwd(i, L, fin) and self._smallk_done:
+                if self.before_last_gemm is not None:                  # (its backward ran as the epilogue of the layer above's dX)
+                    self.before_last_gemm()
                 continue
             if self._smallk_bwd(i, L, fin):
                 # short-input layer 0: LayerNorm(+ReLU) backward and dW in ONE pass over dy (z recomputed, dz never stored)

@@ -645,6 +645,27 @@ def gemm_p3_nt_ln_bwd(a1: P3, b: P3, a2: Optional[P3], z: torch.Tensor, stats: t
     return dz
 
 
+def gemm_p3_nt_smallk_bwd(a1: P3, b: P3, a2: Optional[P3], x, ahn, weight, bias, gamma, beta, stats, relu: bool, dW, dbias=None,
+                          dgamma=None, dbeta=None):
+    """The backward GEMM that produces d(loss)/d(y) of a short-input INPUT layer with that layer's whole backward as its epilogue
+    (gte_gemm_p3_nt_smallk_bwd): the product is not stored, dW = dz^T [x | ahn] and the LayerNorm parameter gradients come out."""
+    lib = _lib.load()
+    m, n = a1.rows, b.rows
+    x, weight = _row_major(x), _row_major(weight)
+    k1 = x.shape[1]
+    k2 = 0
+    if ahn is not None:
+        ahn = _row_major(ahn)
+        k2 = ahn.shape[1]
+    ws = _workspace(lib.gte_gemm_p3_nt_smallk_bwd_workspace_bytes(m, k1 + k2, n), a1.data.device, "gemm_p3_skb")
+    check(lib.gte_gemm_p3_nt_smallk_bwd(ptr(a1.data), a1.ldp, a1.cols, ptr(a2.data) if a2 is not None else None,
+                                        a2.ldp if a2 is not None else 0, a2.cols if a2 is not None else 0, ptr(b.data), b.ldp, ptr(x),
+                                        _ld(x), k1, ptr(ahn), 0 if ahn is None else _ld(ahn), k2, ptr(weight), _ld(weight), ptr(bias),
+                                        ptr(gamma), ptr(beta), ptr(stats), int(relu), ptr(dW), _ld(dW), ptr(dbias), ptr(dgamma),
+                                        ptr(dbeta), m, n, ptr(ws), ws.numel(), current_stream()), "gte_gemm_p3_nt_smallk_bwd")
+    return dW
+
+
 def gemm_p3_tn(a: P3, b: P3, a2: Optional[P3] = None, b2: Optional[P3] = None, two_segments: bool = False,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[m, n] = a^T b over the rows (two_segments: out = [a^T b | a2^T b2], a2 / b2 default to a / b): gte_gemm_p3_tn"""

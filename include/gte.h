@@ -340,6 +340,16 @@ int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t ldpa1, int64_t k1, const void*
                           int64_t ldpb, const float* z, int64_t ldz, const float* stats, const float* gamma, const float* beta,
                           int relu, float* dz, int64_t lddz, void* dzp3, int64_t ldp3, float* dgamma, float* dbeta, float* dbias,
                           int64_t m, int64_t n, void* workspace, int64_t workspace_bytes, void* stream);
+/* ... with the WHOLE backward of a short-input INPUT layer below (gte_sage_smallk_bwd: k1 + k2 <= 28) as the epilogue: dy is not
+ * stored, z is recomputed per row, dW / dbias / dgamma / dbeta of that layer come out through the fold deferral (outside a
+ * deferral dW must be packed, lddw == k1 + k2).  Replaces gte_gemm_p3_nt + gte_sage_smallk_bwd. */
+int gte_gemm_p3_nt_smallk_bwd_supported(int64_t k_total, int64_t n);
+int64_t gte_gemm_p3_nt_smallk_bwd_workspace_bytes(int64_t m, int64_t k_total, int64_t n);
+int gte_gemm_p3_nt_smallk_bwd(const void* a1, int64_t ldpa1, int64_t kg1, const void* a2, int64_t ldpa2, int64_t kg2, const void* b,
+                              int64_t ldpb, const float* x, int64_t ldx, int64_t k1, const float* ahn, int64_t ldahn, int64_t k2,
+                              const float* W, int64_t ldw, const float* bias, const float* gamma, const float* beta,
+                              const float* stats, int relu, float* dW, int64_t lddw, float* dbias, float* dgamma, float* dbeta,
+                              int64_t m, int64_t n, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t gte_gemm_p3_tn_workspace_bytes(int64_t m, int64_t n, int64_t nseg, int64_t k);
 int gte_gemm_p3_tn(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, const void* b, int64_t ldpb, const void* b2,
                    int64_t ldpb2, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n, int64_t k, void* workspace,
@@ -409,7 +419,8 @@ typedef struct gte_step_plan {
     void* tail_ws; int64_t tail_ws_bytes;
     int fuse_ln_dx;                        /* bit 0: dX of a PLANES layer above a PLANES layer runs gte_gemm_p3_nt_ln_bwd;
                                               bit 1: the output layer's backward runs gte_sage_narrow_bwd_ln_p3;
-                                              bit 2: ... and forms q = A_w^T (norm dl) itself (no 9-wide aggregation launch) */
+                                              bit 2: ... and forms q = A_w^T (norm dl) itself (no 9-wide aggregation launch);
+                                              bit 3: dX of layer 1 above a SMALLK layer 0 runs gte_gemm_p3_nt_smallk_bwd      */
 } gte_step_plan;
 int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
 /* The whole step (phase 0) captured from `stream` -- not the legacy null stream -- and launched as ONE executable graph kept in

@@ -225,6 +225,34 @@ def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(m, n, k
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-6)
 
 
+@pytest.mark.parametrize("m,n,k,kin", [(24437, 256, 256, 13), (3000, 256, 256, 13), (129, 128, 64, 9), (1, 256, 256, 13), (40000, 256, 128, 14)])
+def test_nt_with_the_short_input_layers_backward_as_epilogue(m, n, k, kin):
+    """gte_gemm_p3_nt_smallk_bwd against gte_gemm_p3_nt + gte_sage_smallk_bwd (same per-row arithmetic, csrc/smallk_step.h; the
+    partial sums are grouped by 128-row tiles instead of 64-row blocks: summation order only)."""
+    g = torch.Generator(device=DEV).manual_seed(m + n)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    a1, a2, w = rnd(m, k), rnd(m, k), rnd(n, 2 * k) / 16
+    x, ahn = rnd(m, kin), rnd(m, kin)
+    W0, b0 = rnd(n, 2 * kin) / 5, rnd(n)
+    gam, bet = 1 + 0.1 * rnd(n), 0.1 * rnd(n)
+    lib, P = _lib.load(), _lib.ptr
+    y, stats = torch.empty(m, n, device=DEV), torch.empty(2 * m, device=DEV)
+    _lib.check(lib.gte_sage_linear_fwd(P(x), kin, kin, P(ahn), kin, kin, P(W0), 2 * kin, P(b0), P(gam), P(bet), 1e-5, 1, None, n,
+                                       P(stats), P(y), n, m, n, _lib.current_stream()), "fwd")
+    a1p, a2p, wp = ops.p3_from_f32(a1), ops.p3_from_f32(a2), ops.p3_from_f32(w)
+    # two launches
+    dy = ops.gemm_p3_nt(a1p, wp, a2=a2p)
+    gW_ref = torch.empty(n, 2 * kin, device=DEV)
+    gb_ref, gg_ref, gbe_ref = (torch.empty(n, device=DEV) for _ in range(3))
+    ops.sage_smallk_bwd(dy, x, ahn, W0, b0, gam, bet, stats, True, gW_ref, gb_ref, gg_ref, gbe_ref)
+    # one launch
+    gW = torch.full((n, 2 * kin), 7.0, device=DEV)
+    gb, gg, gbe = (torch.full((n,), 7.0, device=DEV) for _ in range(3))
+    ops.gemm_p3_nt_smallk_bwd(a1p, wp, a2p, x, ahn, W0, b0, gam, bet, stats, True, gW, gb, gg, gbe)
+    for got, want in ((gW, gW_ref), (gb, gb_ref), (gg, gg_ref), (gbe, gbe_ref)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-6)
+
+
 # ---- operands outside the comfortable range -------------------------------------------------------------------------------
 def test_non_finite_operands_poison_exactly_the_outputs_fp32_poisons(split_mode):
     """inf cannot be cut into pieces (inf - inf is NaN) and 0 x inf appears among the six products, so an output that fp32
