@@ -228,13 +228,16 @@ def val_graph_probe(args, gte, S, model, dev, pages):
             "logits_finite": bool(torch.isfinite(logits).all())}
 
 
-def inference_probe(args, gte, model, dev, pages):
+def inference_probe(args, gte, model, dev, pages, trainer=None):
     """SURVEY 8(f) N2 / model_predict.py:130-154.  (i) the reference's shape: ONE forward per page (batch = 1), eager and as
     one HIP-graph launch per page (models.model_predict.PageForwardGraphs: size buckets, the page assembled into the bucket's
     buffers); (ii) batched: 100 pages per forward.  Pages are resident in HBM with their CSRs prepared (the reference rebuilds
-    them per forward inside DGL); host-synchronised wall time over all pages."""
+    them per forward inside DGL); host-synchronised wall time over all pages.  (iii) batched through the step engine:
+    model_predict.predict_resident -- one host call per forward (gte_gcnsage_forward), batches assembled one forward ahead on the
+    side stream, predictions written into one device vector."""
     from gnn_tableextraction_amd import graph as G
-    from gnn_tableextraction_amd.models.model_predict import PageForwardGraphs
+    from gnn_tableextraction_amd.models.model_predict import PageForwardGraphs, predict_resident
+    from gnn_tableextraction_amd.models.loop import BatchPipeline
     n_pages = min(len(pages), 400)
     res = G.ResidentPages(to_page_graphs(gte, pages[:n_pages]), dev)
     sizes = res.page_sizes()
@@ -261,6 +264,21 @@ def inference_probe(args, gte, model, dev, pages):
             el = time.perf_counter() - t0
             out[name] = {"ms_per_page": el * 1e3 / n_pages, "pages_per_s": n_pages / el, "nodes_per_s": float(sum(sizes)) / el}
         out["hip_graph_buckets"] = sorted(runner._b)
+        if trainer is not None and hasattr(trainer, "forward_logits"):
+            # LAST: it switches the resident pages to the engine's feature format (a P3 image in the split GEMM mode)
+            pipe = BatchPipeline(res)
+            engine_all = lambda: predict_resident(trainer, pipe, 100)
+            ref = torch.cat([model(res.batch(list(range(b0, min(b0 + 100, n_pages))))).argmax(dim=1) for b0 in range(0, n_pages, 100)])
+            got = engine_all()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                engine_all()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / reps
+            out["batched_100_engine"] = {"ms_per_page": el * 1e3 / n_pages, "pages_per_s": n_pages / el, "nodes_per_s": float(sum(sizes)) / el,
+                                         "predictions_equal_module_path": float((got == ref).float().mean())}
     model.train(was_training)
     return out
 
@@ -828,7 +846,7 @@ def main():
         line["order"] = ("gather / val_graph probes, long_run (>= 1 s of the same loop), THEN W warm-up + K timed steps = value, "
                          "then kernel timers, replay, the other GEMM mode, inference, secondary, cfg3, cpu_baseline")
         if extras and not args.no_inference:
-            line["inference"] = inference_probe(args, gte, model, dev, pages)
+            line["inference"] = inference_probe(args, gte, model, dev, pages, trainer)
         if pages13 is not None:
             line["secondary"] = secondary_probe(args, gte, S, dev, pages13)
         if extras and not args.no_cfg3:

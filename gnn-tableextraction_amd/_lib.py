@@ -112,6 +112,7 @@ SIGNATURES = {
     "gte_gcnsage_step": (c_int, [c_void_p, c_int, POINTER(c_int), c_void_p]),
     "gte_gcnsage_step_graph": (c_int, [c_void_p, POINTER(c_int), c_void_p, POINTER(c_void_p)]),
     "gte_step_graph_destroy": (c_int, [c_void_p]),
+    "gte_gcnsage_forward": (c_int, [c_void_p, c_void_p]),
     "gte_fold_defer_begin": (c_int, [c_void_p]),
     "gte_fold_defer_flush": (c_int, []),
     "gte_fold_defer_flush_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),

@@ -15,7 +15,8 @@ namespace {
         if (rc_ != GTE_OK) return rc_; \
     } while (0)
 
-int forward(const gte_step_plan& p, void* st) {
+// weight images + the hidden layers (the output layer's input is p.h_out afterwards)
+int forward_hidden(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes;
     if (p.n_wimg_descs > 0)
         GTE_TRY(gte_p3_from_f32_batch(reinterpret_cast<const gte_p3_desc*>(p.wimg_descs), p.n_wimg_descs, st));
@@ -43,6 +44,12 @@ int forward(const gte_step_plan& p, void* st) {
         GTE_TRY(gte_spmm_csr_accumulate_ln_p3(p.indptr, p.indices, p.w_in, L.t + L.fout, 2 * L.fout, L.t, 2 * L.fout, n, L.fout,
                                               GTE_REDUCE_MEAN, L.gamma, L.beta, L.eps, L.relu, L.y, L.fout, L.yp, L.ldp_y, L.stats, st));
     }
+    return GTE_OK;
+}
+
+int forward(const gte_step_plan& p, void* st) {
+    const int64_t n = p.n_nodes;
+    GTE_TRY(forward_hidden(p, st));
     const int64_t C = p.n_classes;
     GTE_TRY(gte_sage_narrow_fwd(p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, p.b_out, C, p.logits, C, p.tn, C, n, st));
     GTE_TRY(gte_head_agg_ce(p.indptr, p.indices, p.w_in, p.tn, C, p.logits, C, p.labels, p.labels_f32, p.class_weights, n, C,
@@ -143,12 +150,7 @@ int flush(const gte_step_plan& p, int* adam_fused) {
     return gte_fold_defer_flush();
 }
 
-}  // namespace
-
-extern "C" int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream) {
-    if (!plan) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: null plan");
-    const gte_step_plan& p = *plan;
-    if (phase < 0 || phase > 2) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: phase must be 0, 1 or 2");
+int check_plan(const gte_step_plan& p) {
     if (p.n_hidden < 1 || p.n_hidden > 7 || p.n_nodes < 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: bad plan");
     for (int i = 0; i < p.n_hidden; ++i) {
         const gte_step_layer& L = p.layer[i];
@@ -157,6 +159,16 @@ extern "C" int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_
         if (!L.gamma || !L.beta || !L.bias) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: hidden layers need bias and LayerNorm");
     }
     if (p.n_nodes == 0) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: empty batch");
+    return GTE_OK;
+}
+
+}  // namespace
+
+extern "C" int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream) {
+    if (!plan) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: null plan");
+    const gte_step_plan& p = *plan;
+    if (phase < 0 || phase > 2) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: phase must be 0, 1 or 2");
+    GTE_TRY(check_plan(p));
     if (phase != 2) {
         GTE_TRY(gte_gemm_set_tail_workspace(p.tail_ws, p.tail_ws ? p.tail_ws_bytes : 0));
         int rc = forward(p, stream);
@@ -171,6 +183,23 @@ extern "C" int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_
     int rc = backward_b(p, stream);
     if (rc != GTE_OK) { (void)gte_fold_defer_flush(); (void)gte_gemm_set_tail_workspace(nullptr, 0); return rc; }
     rc = flush(p, adam_fused);
+    (void)gte_gemm_set_tail_workspace(nullptr, 0);
+    return rc;
+}
+
+// The forward pass alone (model_predict.py:141-147 / the no_grad forward of model_train.py:349-353 of the reference): the
+// same plan, the same kernels and buffers as the step's forward -- logits [n, C] land in plan->logits.  Labels, gradients,
+// optimiser state and the backward workspaces of the plan are not touched.
+extern "C" int gte_gcnsage_forward(const gte_step_plan* plan, void* stream) {
+    if (!plan) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_forward: null plan");
+    const gte_step_plan& p = *plan;
+    GTE_TRY(check_plan(p));
+    GTE_TRY(gte_gemm_set_tail_workspace(p.tail_ws, p.tail_ws ? p.tail_ws_bytes : 0));
+    const int64_t n = p.n_nodes, C = p.n_classes;
+    int rc = forward_hidden(p, stream);
+    // logits = h W_s^T + b + mean-aggregate(h W_n^T): the class-count-wide aggregation the step runs inside its loss kernel
+    if (rc == GTE_OK) rc = gte_sage_narrow_fwd(p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, p.b_out, C, p.logits, C, p.tn, C, n, stream);
+    if (rc == GTE_OK) rc = gte_spmm_csr_accumulate(p.indptr, p.indices, p.w_in, p.tn, C, p.logits, C, n, C, GTE_F32, GTE_REDUCE_MEAN, stream);
     (void)gte_gemm_set_tail_workspace(nullptr, 0);
     return rc;
 }

@@ -423,11 +423,11 @@ class FusedGcnSageStep(TrainStep):
                 return None
         return kinds
 
-    def _c_step(self, g, labels, grad_scale, kinds, with_adam: bool):
-        """forward + loss + backward (+ Adam inside the fold launch) through gte_gcnsage_step: two host calls (the next batch's
-        assembly is queued between them) instead of ~19."""
+    def _bind_plan(self, g, kinds, with_adam: bool):
+        """The gte_step_plan of this layer plan (cached with the buffer set whose addresses it holds) with the per-batch fields --
+        graph, features, node count -- set for ``g``.  Returns (plan, fused flag, row views of the buffers, node count, tensors
+        the plan points at)."""
         lib, P = self.lib, _lib.ptr
-        st = _lib.current_stream()
         xp = getattr(g, "feat_p3", None)
         if xp is not None:
             x, n, f0 = None, xp.rows, xp.cols
@@ -522,6 +522,14 @@ class FusedGcnSageStep(TrainStep):
         plan.indptr, plan.indices, plan.w_in = P(csr.indptr), P(csr.indices), P(w_in)
         plan.rindptr, plan.rindices, plan.w_out = P(rcsr.indptr), P(rcsr.indices), P(w_out)
         plan.n_nodes = n
+        return plan, fused, b, n, (csr, rcsr, w_in, w_out)
+
+    def _c_step(self, g, labels, grad_scale, kinds, with_adam: bool):
+        """forward + loss + backward (+ Adam inside the fold launch) through gte_gcnsage_step: two host calls (the next batch's
+        assembly is queued between them) instead of ~19."""
+        lib, P = self.lib, _lib.ptr
+        st = _lib.current_stream()
+        plan, fused, b, n, (csr, rcsr, w_in, w_out) = self._bind_plan(g, kinds, with_adam)
         lab = labels if labels.dtype in (torch.float32, torch.int64) else labels.to(torch.int64)
         plan.labels, plan.labels_f32 = P(lab), int(lab.dtype == torch.float32)
         plan.grad_scale = float(grad_scale)
@@ -540,6 +548,21 @@ class FusedGcnSageStep(TrainStep):
         self._adam_fused = bool(fused.value)
         self._keep = (lab, csr, rcsr, w_in, w_out)                     # alive until the next step
         return b["out3"]
+
+    def forward_logits(self, g) -> torch.Tensor:
+        """``model(g)`` without autograd (model_predict.py:141-147, the validation forward of model_train.py:349-353): logits
+        [n, n_classes] through ONE host call (gte_gcnsage_forward) on the step's own buffers -- a view that the next step or
+        forward on this engine overwrites.  Configurations the one-call plan does not cover run the module path."""
+        xp = getattr(g, "feat_p3", None)
+        n, f0 = (xp.rows, xp.cols) if xp is not None else g.ndata['feat'].shape
+        kinds = self._plan_kinds(f0, n) if n > 0 else None
+        if kinds is None:
+            with torch.no_grad():
+                return self.model(g)
+        plan, _fused, b, n, keep = self._bind_plan(g, kinds, with_adam=False)
+        _lib.check(self.lib.gte_gcnsage_forward(ctypes.addressof(plan), _lib.current_stream()), "gte_gcnsage_forward")
+        self._keep = keep
+        return b["y"][-1]
 
     # -- the schedule ----------------------------------------------------------------------------------
     def forward_backward(self, g, labels: torch.Tensor, grad_scale: float = 1.0, upto_layer: int = 0) -> torch.Tensor:

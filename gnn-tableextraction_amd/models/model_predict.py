@@ -120,6 +120,41 @@ class PageForwardGraphs:
         return b["logits"][:n], b["pred"][:n]
 
 
+def predict_resident(engine, pipe, batch_pages: int, page_ids=None) -> torch.Tensor:
+    """Predictions (arg-max class per node, int64, pages concatenated in ``page_ids`` order -- default: all resident pages) with
+    ``batch_pages`` pages per forward.  The reference's loop (model_predict.py:141-151) is one forward per page from the host;
+    here a forward is ONE host call (``engine.forward_logits`` -> gte_gcnsage_forward) on a batch that the pipeline
+    (``loop.BatchPipeline``) assembled on its side stream while the forward before it ran, and nothing synchronises until the
+    caller reads the result."""
+    res = pipe.res
+    ids = np.arange(len(res.page_sizes()), dtype=np.int64) if page_ids is None else np.asarray(page_ids, dtype=np.int64)
+    steps = [ids[i:i + batch_pages] for i in range(0, ids.size, batch_pages)]
+    f0 = res.feat.shape[1]
+    want_p3 = bool(engine.wants_p3_features(f0))
+    if want_p3 != bool(res.p3_mode):                       # as loop.run_steps: layer 0 reads the resident feature image
+        torch.cuda.synchronize(pipe.device)
+        res.enable_p3() if want_p3 else res.disable_p3()
+        pipe._sets, pipe._free_ev = [], [None] * pipe.depth
+    pipe.load(steps)
+    total = sum(pipe.nodes(s) for s in range(len(steps)))
+    pred = torch.empty(total, dtype=torch.int64, device=pipe.device)
+    if not steps:
+        return pred
+    engine.reserve(pipe.max_batch_nodes(), f0)
+    pipe.start(0)
+    off = 0
+    for s in range(len(steps)):
+        if s + 1 < len(steps):
+            pipe.start(s + 1)
+        g = pipe.get(s)
+        logits = engine.forward_logits(g)
+        n = pipe.nodes(s)
+        torch.argmax(logits, dim=1, out=pred[off:off + n])
+        pipe.release(s)
+        off += n
+    return pred
+
+
 def test(data, config, weights_path=None, save_predictions=True):
     if not (config.TRAINING.gpu >= 0 and torch.cuda.is_available()):
         raise RuntimeError("model_predict runs on the MI355X HIP path only (no CPU fallback)")
@@ -138,17 +173,34 @@ def test(data, config, weights_path=None, save_predictions=True):
     bs = max(1, int(config.TRAINING.batch_size))
     all_pred, all_true = [], []
     mean_test_acc = 0.0
-    with torch.no_grad():
-        for b0 in range(0, len(data.graphs), bs):
-            pages = [g.to(device) for g in data.graphs[b0:b0 + bs]]
-            bg = G.batch(pages)
-            pred = model(bg).argmax(dim=1).cpu().numpy()
-            off = np.cumsum([0] + [g.num_nodes() for g in pages])
-            for i, g in enumerate(pages):
-                pp, tt = pred[off[i]:off[i + 1]], g.ndata['label'].long().cpu().numpy()
-                all_pred.append(pp)
-                all_true.append(tt)
-                mean_test_acc += float((pp == tt).sum()) / max(g.num_nodes(), 1)          # per-page accuracy (:150)
+    if not config.TRAINING.dropout and len(data.graphs) > 0:
+        # the shipped configuration: pages resident in HBM, batches assembled on the device one forward ahead, one host call per
+        # forward (predict_resident); one device -> host copy of all predictions at the end
+        from .engine import FusedGcnSageStep
+        from .loop import BatchPipeline
+        engine = FusedGcnSageStep(model)
+        pipe = BatchPipeline(G.ResidentPages(data.graphs, device))
+        flat_pred = predict_resident(engine, pipe, bs).cpu().numpy()
+        off = 0
+        for g in data.graphs:
+            n = g.num_nodes()
+            pp, tt = flat_pred[off:off + n], g.ndata['label'].long().cpu().numpy()
+            all_pred.append(pp)
+            all_true.append(tt)
+            mean_test_acc += float((pp == tt).sum()) / max(n, 1)                          # per-page accuracy (:150)
+            off += n
+    else:
+        with torch.no_grad():
+            for b0 in range(0, len(data.graphs), bs):
+                pages = [g.to(device) for g in data.graphs[b0:b0 + bs]]
+                bg = G.batch(pages)
+                pred = model(bg).argmax(dim=1).cpu().numpy()
+                off = np.cumsum([0] + [g.num_nodes() for g in pages])
+                for i, g in enumerate(pages):
+                    pp, tt = pred[off[i]:off[i + 1]], g.ndata['label'].long().cpu().numpy()
+                    all_pred.append(pp)
+                    all_true.append(tt)
+                    mean_test_acc += float((pp == tt).sum()) / max(g.num_nodes(), 1)      # per-page accuracy (:150)
     y_pred, y_true = np.concatenate(all_pred), np.concatenate(all_true)
     p, r, f1, conf = per_class_prf(y_true, y_pred, n_classes)
     acc_nodes = float((y_pred == y_true).mean()) if len(y_true) else 0.0

@@ -103,11 +103,12 @@ def load_adam_state_dict(step: TrainStep, model, sd: dict) -> None:
     step.lr = sd['param_groups'][0]['lr']
 
 
-def evaluate(model, graph, labels, class_weights=None):
-    """no_grad forward on one (batched) graph: (loss, accuracy, predictions) -- :349-353."""
+def evaluate(model, graph, labels, class_weights=None, engine=None):
+    """no_grad forward on one (batched) graph: (loss, accuracy, predictions) -- :349-353.  ``engine`` (a FusedGcnSageStep over
+    ``model``): the forward is one host call on the step's buffers (engine.forward_logits) instead of the module path."""
     model.eval()
     with torch.no_grad():
-        logits = model(graph)
+        logits = engine.forward_logits(graph) if hasattr(engine, "forward_logits") else model(graph)
         out3, _ = ops.weighted_ce(logits, labels, class_weights, want_grad=False)
         pred = logits.argmax(dim=1)
     o = out3.cpu().tolist()
@@ -224,7 +225,7 @@ def train(data, config, name_time=None):
 
             # ---- validation on the (sharded) batched val graph -------------------------------------------
             if val_graph is not None:
-                vl, va, pred = evaluate(model, val_graph, val_labels, class_weights)
+                vl, va, pred = evaluate(model, val_graph, val_labels, class_weights, engine=step)
                 n_val = val_labels.shape[0]
                 y_true, y_pred = val_labels.long().cpu().numpy(), pred.cpu().numpy()
             else:

@@ -430,6 +430,12 @@ int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void
 int gte_gcnsage_step_graph(const gte_step_plan* plan, int* adam_fused, void* stream, void** exec_slot);
 int gte_step_graph_destroy(void* exec);
 
+/* The forward pass alone from the same plan (replaces `logits = model(g)` under no_grad: src/models/model_predict.py:141-147 and
+ * the validation forward src/models/model_train.py:349-353): weight images, hidden layers, the output layer; logits [n, C] in
+ * plan->logits.  The same kernels in the same order as the forward half of gte_gcnsage_step (bit-identical activations);
+ * labels, gradients, optimiser fields and backward workspaces of the plan are ignored. */
+int gte_gcnsage_forward(const gte_step_plan* plan, void* stream);
+
 /* ---- deferred folds -------------------------------------------------------------------------------------------
  * Several entry points end with a small "sum the per-block partials" kernel (gte_ln_relu_bwd: column sums;
  * gte_sage_narrow_bwd: dW / dbias; split-K GEMMs behind gte_sage_linear_dw / gte_sage_qform_dw).  gte_gemm_f32 NEVER defers:

@@ -105,3 +105,61 @@ def test_step_plan_rejects_bad_plans():
     assert lib.gte_gcnsage_step(ctypes.addressof(plan), 3, ctypes.byref(fused), None) == -1      # phase
     assert lib.gte_gcnsage_step(ctypes.addressof(plan), 0, ctypes.byref(fused), None) == -4      # no LayerNorm / bias: unsupported
     assert b"LayerNorm" in lib.gte_last_error()
+
+
+@pytest.mark.parametrize("f0,hid,resident", [(831, 256, True), (831, 256, False), (13, 256, True), (363, 128, False)])
+def test_forward_only_call_matches_the_module_forward_and_the_steps_forward(monkeypatch, f0, hid, resident):
+    """gte_gcnsage_forward (engine.forward_logits): the logits of ``model(g)`` under no_grad (different summation order in the
+    planes GEMMs: 2e-5 relative to the logit scale), and BIT FOR BIT the logits the training step's forward computes from the
+    same weights; model_predict.predict_resident over all pages equals per-batch arg-max of those logits."""
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import graph as G, _lib
+    from gnn_tableextraction_amd.data import synthetic as S
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    from gnn_tableextraction_amd.models.loop import BatchPipeline
+    from gnn_tableextraction_amd.models.model_predict import predict_resident
+    dev = "cuda:0"
+    pages = S.make_pages(10, in_feats=f0)
+    torch.manual_seed(11)
+    model = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0).to(dev)
+    tr = FusedGcnSageStep(model, lr=0.0, weight_decay=0.0)          # lr 0: a step leaves the weights as they are
+    if not tr._planes_on():
+        pytest.skip("the one-call plan drives the planes path (default GEMM mode, GTE_PLANES=1)")
+    graphs = []
+    for p in pages:
+        g = gte.PageGraph(p.src, p.dst, p.num_nodes)
+        g.ndata["feat"], g.ndata["label"] = torch.from_numpy(p.feat), torch.from_numpy(p.label.astype(np.float32))
+        g.edata["feat"] = torch.from_numpy(p.weight)
+        graphs.append(g)
+    ids = [0, 3, 4, 7, 9]
+    whole = G.batch([graphs[i] for i in ids]).to(dev)
+    with torch.no_grad():
+        want = model(whole).clone()
+    if resident:
+        res = G.ResidentPages(graphs, dev)
+        if tr.wants_p3_features(f0):
+            res.enable_p3()
+        g = res.batch(ids)
+        y = g.ndata["label"]
+    else:
+        g, y = whole, whole.ndata["label"]
+    got = tr.forward_logits(g).clone()
+    if not any(k for full in tr._bufs.values() for k in full.get("_plans", {})):
+        pytest.skip("the engine's switches rule the one-call plan out for this configuration")
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * max(scale, 1.0)
+    tr.step(g, y)
+    n = want.shape[0]
+    step_logits = next(iter(tr._bufs.values()))["y"][-1][:n]
+    torch.testing.assert_close(step_logits, got, rtol=0, atol=0)
+    if resident:
+        pipe = BatchPipeline(res)
+        pred = predict_resident(tr, pipe, 4)
+        ref = []
+        for b0 in range(0, len(graphs), 4):
+            ref.append(tr.forward_logits(res.batch(list(range(b0, min(b0 + 4, len(graphs)))))).argmax(dim=1).clone())
+        assert torch.equal(pred, torch.cat(ref))
+        sub = predict_resident(tr, pipe, 3, page_ids=[5, 1, 2, 8])
+        assert sub.shape[0] == sum(graphs[i].num_nodes() for i in (5, 1, 2, 8))
+    lib = _lib.load()
+    assert lib.gte_gcnsage_forward(None, None) == -1
