@@ -1,5 +1,6 @@
 // libgte_hip.so: error reporting, version and device facts.
 #include "gte_common.h"
+#include "p3.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -51,12 +52,72 @@ constexpr int kMaxFolds = 24;
 struct FoldDesc {
     const float* src; long long stride; float* dst; long long ld;
     int count, rows, rowlen, first_block, slices, vec;
+    unsigned img_mask;                    // weight images (FoldImages) whose source overlaps this fold's destination
 };
 // Optional optimiser tail of the batch (gte_fold_defer_flush_adam): when `param` is set every folded element is a gradient
 // element of the flat buffer starting at `grad`, and the thread that writes it applies the Adam update of that element.
 struct FoldAdam { float* param; float* grad; float* exp_avg; float* exp_avg_sq; float* state; long long* step; unsigned* ticket; int vec_ok; };
-struct FoldBatch { FoldDesc d[kMaxFolds]; int n; FoldAdam adam; };
+// ... and, behind the update, the P3 images (csrc/p3.h) of parameter sub-matrices -- the operand images the planes GEMMs of the
+// NEXT step multiply (gte_fold_defer_flush_adam_images): the thread that updates a parameter element writes its three bf16
+// pieces into every image that holds it.  off = element offset of the sub-matrix in the flat parameter buffer; its rows x cols
+// elements sit at row stride ld; image(r, c) = transpose ? sub(c, r) : sub(r, c).
+constexpr int kMaxFoldImages = 8;
+struct FoldImage { long long off; unsigned span, ld, magic; int cols, transpose, pad; char* dst; long long ldp; };
+struct FoldImages { FoldImage im[kMaxFoldImages]; int n; };
+struct FoldBatch { FoldDesc d[kMaxFolds]; int n; FoldAdam adam; FoldImages img; };
 
+// (row, column) of element o of a sub-matrix with row stride ld: magic = floor(2^32 / ld) + 1 is exact for o < 2^32 / ld
+// (checked on the host); a 64-bit division per element cost the launch more than the conversion launch it replaces
+__device__ __forceinline__ void fold_rc(const FoldImage& im, unsigned o, int& r, int& c) {
+    unsigned q = __umulhi(o, im.magic);
+    unsigned rem = o - q * im.ld;
+    if (rem >= im.ld) { rem -= im.ld; ++q; }
+    r = (int)q; c = (int)rem;
+}
+__device__ __forceinline__ void fold_write_image1(const FoldImage& im, long long i, float v) {
+    const long long o = i - im.off;
+    if (o < 0 || o >= (long long)im.span) return;
+    int r, c;
+    fold_rc(im, (unsigned)o, r, c);
+    if (c >= im.cols) return;
+    const int ir = im.transpose ? c : r, ic = im.transpose ? r : c;
+    unsigned h, m, l;
+    p3::split2(v, 0.f, h, m, l);
+    unsigned short* q = reinterpret_cast<unsigned short*>(im.dst + (long long)ir * im.ldp + (ic >> 4) * p3::BLOCK_BYTES + (ic & 15) * 2);
+    q[0] = (unsigned short)h;
+    q[p3::PLANE_BYTES / 2] = (unsigned short)m;
+    q[p3::PLANE_BYTES] = (unsigned short)l;
+}
+// the images in `mask` only (FoldDesc::img_mask: the images whose source overlaps the fold's destination)
+__device__ __forceinline__ void fold_write_images(const FoldImages& fi, unsigned mask, long long i, float v) {
+    for (int k = 0; k < fi.n; ++k)
+        if (mask >> k & 1) fold_write_image1(fi.im[k], i, v);
+}
+// two consecutive parameter elements: where both fall into the same row of an untransposed image at an even column they
+// leave as ONE 4-byte store per plane; everything else goes element by element
+__device__ __forceinline__ void fold_write_images2(const FoldImages& fi, unsigned mask, long long i, float v0, float v1) {
+    for (int k = 0; k < fi.n; ++k) {
+        if (!(mask >> k & 1)) continue;
+        const FoldImage& im = fi.im[k];
+        const long long o = i - im.off;
+        if (o + 1 < 0 || o >= (long long)im.span) continue;
+        if (o >= 0 && !im.transpose) {
+            int r, c;
+            fold_rc(im, (unsigned)o, r, c);
+            if ((c & 1) == 0 && c + 1 < im.cols) {
+                unsigned h, m, l;
+                p3::split2(v0, v1, h, m, l);
+                unsigned* q = reinterpret_cast<unsigned*>(im.dst + (long long)r * im.ldp + (c >> 4) * p3::BLOCK_BYTES + (c & 15) * 2);
+                q[0] = h;
+                q[p3::PLANE_BYTES / 4] = m;
+                q[p3::PLANE_BYTES / 2] = l;
+                continue;
+            }
+        }
+        fold_write_image1(im, i, v0);
+        fold_write_image1(im, i + 1, v1);
+    }
+}
 struct FoldQueue {
     FoldBatch batch; bool open = false; hipStream_t stream = nullptr; int blocks = 0;
     bool spilled = false;                 // a full batch was flushed early: the queued folds no longer cover the whole deferral
@@ -89,6 +150,7 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
         if (ad.param) {
             const long long i = dst - ad.grad;
             gte::adam_update(co, ad.param[i], v, ad.exp_avg[i], ad.exp_avg_sq[i]);
+            if (d.img_mask) gte::fold_write_images(fb.img, d.img_mask, i, ad.param[i]);
         }
     };
     const int epb = 256 / d.slices;
@@ -150,6 +212,11 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
                 *reinterpret_cast<float4*>(ad.exp_avg + ai) = mv;
                 *reinterpret_cast<float4*>(ad.exp_avg_sq + ai) = qv;
                 *reinterpret_cast<float4*>(ad.param + ai) = pv;
+                if (d.img_mask) {
+                    // (pairs: one 8-byte store per plane for the four measured slower -- rows of odd length leave them 4-byte aligned)
+                    gte::fold_write_images2(fb.img, d.img_mask, ai, pv.x, pv.y);
+                    gte::fold_write_images2(fb.img, d.img_mask, ai + 2, pv.z, pv.w);
+                }
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -195,9 +262,27 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
 
 namespace gte {
 
-static int flush_folds(FoldQueue& q, const FoldAdam* adam = nullptr) {
+static int flush_folds(FoldQueue& q, const FoldAdam* adam = nullptr, const FoldImages* images = nullptr) {
     if (q.batch.n == 0) return GTE_OK;
     q.batch.adam = adam ? *adam : FoldAdam{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (images) q.batch.img = *images; else q.batch.img.n = 0;
+    static const int abl = getenv("GTE_WIMG_ABL") ? atoi(getenv("GTE_WIMG_ABL")) : 0;      // (measurement)
+    if (abl && images) {
+        FoldImages& fi = q.batch.img;
+        int m = 0;
+        for (int k = 0; k < fi.n; ++k)
+            if ((abl == 2 && !fi.im[k].transpose) || (abl == 3 && fi.im[k].transpose)) fi.im[m++] = fi.im[k];
+        fi.n = m;
+        images = &fi;
+    }
+    for (int i = 0; i < q.batch.n; ++i) {
+        FoldDesc& d = q.batch.d[i];
+        d.img_mask = 0;
+        if (!images || !adam) continue;
+        const long long lo = d.dst - adam->grad, hi = lo + (long long)(d.rows - 1) * d.ld + d.rowlen;
+        for (int k = 0; k < images->n; ++k)
+            if (images->im[k].off < hi && images->im[k].off + (long long)images->im[k].span > lo) d.img_mask |= 1u << k;
+    }
     hipLaunchKernelGGL(gte_fold_batch_kernel, dim3((unsigned)q.blocks), dim3(256), 0, q.stream, q.batch);
     q.batch.n = 0;
     q.blocks = 0;
@@ -299,8 +384,9 @@ static bool folds_cover(FoldQueue& q, const float* grad, int64_t n) {
 }
 }  // namespace gte
 
-extern "C" int gte_fold_defer_flush_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
-                                         int64_t* step_counter, unsigned* ticket, int* fused) {
+extern "C" int gte_fold_defer_flush_adam_images(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                                int64_t* step_counter, unsigned* ticket, const gte_p3_desc* images, int n_images,
+                                                int* fused) {
     gte::FoldQueue& q = gte::fold_queue();
     if (fused) *fused = 0;
     if (!q.open) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam: no deferral is open on this thread");
@@ -311,13 +397,40 @@ extern "C" int gte_fold_defer_flush_adam(float* param, float* grad, float* exp_a
         (void)gte::flush_folds(q);
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam: null pointer or n <= 0");
     }
+    gte::FoldImages fi;
+    fi.n = 0;
+    if (n_images < 0 || (n_images > 0 && !images)) {
+        (void)gte::flush_folds(q);
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam_images: bad image list");
+    }
+    bool images_ok = n_images > 0 && n_images <= gte::kMaxFoldImages;
+    for (int k = 0; images_ok && k < n_images; ++k) {
+        const gte_p3_desc& d = images[k];
+        const int64_t srows = d.transpose ? d.cols : d.rows, scols = d.transpose ? d.rows : d.cols;
+        if (!d.src || !d.dst || d.rows <= 0 || d.cols <= 0 || d.ld < scols || d.ld > INT32_MAX || d.ldp < p3::row_bytes(d.cols) ||
+            d.src < param || (d.src - param) + (srows - 1) * d.ld + scols > n) {
+            (void)gte::flush_folds(q);
+            return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam_images: image %d does not describe a sub-matrix of the parameters", k);
+        }
+        gte::FoldImage& im = fi.im[k];
+        const int64_t span = (srows - 1) * d.ld + scols;
+        if (span >= ((int64_t)1 << 32) / d.ld) { images_ok = false; break; }      // (the multiply-high row split would not be exact)
+        im.off = d.src - param; im.span = (unsigned)span; im.ld = (unsigned)d.ld; im.magic = (unsigned)((((uint64_t)1 << 32) / d.ld) + 1);
+        im.cols = (int)scols; im.transpose = d.transpose ? 1 : 0; im.pad = 0; im.dst = reinterpret_cast<char*>(d.dst); im.ldp = d.ldp;
+    }
+    if (images_ok) fi.n = n_images;
     if (spilled || q.batch.n == 0 || !gte::folds_cover(q, grad, n)) return gte::flush_folds(q);   // caller runs gte_adam_step_dev
     const int vec_ok = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                          reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
     const gte::FoldAdam ad = {param, grad, exp_avg, exp_avg_sq, state, reinterpret_cast<long long*>(step_counter), ticket, vec_ok};
-    const int rc = gte::flush_folds(q, &ad);
-    if (rc == GTE_OK) *fused = 1;
+    const int rc = gte::flush_folds(q, &ad, fi.n > 0 ? &fi : nullptr);
+    if (rc == GTE_OK) *fused = fi.n > 0 ? 3 : 1;
     return rc;
+}
+
+extern "C" int gte_fold_defer_flush_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                         int64_t* step_counter, unsigned* ticket, int* fused) {
+    return gte_fold_defer_flush_adam_images(param, grad, exp_avg, exp_avg_sq, n, state, step_counter, ticket, nullptr, 0, fused);
 }
 
 extern "C" int gte_version(void) { return GTE_VERSION; }

@@ -18,7 +18,7 @@ namespace {
 // weight images + the hidden layers (the output layer's input is p.h_out afterwards)
 int forward_hidden(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes;
-    if (p.n_wimg_descs > 0)
+    if (p.n_wimg_descs > 0 && !p.wimg_fresh)
         GTE_TRY(gte_p3_from_f32_batch(reinterpret_cast<const gte_p3_desc*>(p.wimg_descs), p.n_wimg_descs, st));
     for (int i = 0; i < p.n_hidden; ++i) {
         const gte_step_layer& L = p.layer[i];
@@ -143,7 +143,10 @@ int flush(const gte_step_plan& p, int* adam_fused) {
     if (adam_fused) *adam_fused = 0;
     if (p.param) {
         int fused = 0;
-        const int rc = gte_fold_defer_flush_adam(p.param, p.grad, p.exp_avg, p.exp_avg_sq, p.n_param, p.hyper, p.step_counter, p.ticket, &fused);
+        const bool img = p.wimg_in_fold && p.n_wimg_descs > 0;
+        const int rc = gte_fold_defer_flush_adam_images(p.param, p.grad, p.exp_avg, p.exp_avg_sq, p.n_param, p.hyper, p.step_counter, p.ticket,
+                                                        img ? reinterpret_cast<const gte_p3_desc*>(p.wimg_descs) : nullptr,
+                                                        img ? p.n_wimg_descs : 0, &fused);
         if (adam_fused) *adam_fused = fused;
         return rc;
     }

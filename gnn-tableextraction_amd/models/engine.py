@@ -191,6 +191,12 @@ class FusedGcnSageStep(TrainStep):
         # images (three bf16 planes, csrc/p3.h) by their producers and multiplied by the planes GEMMs (csrc/gemm_p3.hip)
         self.use_planes = os.environ.get("GTE_PLANES", "1") == "1"
         self._wimg = {}                               # layer index -> (forward image, backward image or None)
+        # one-call step: the fold + Adam launch also writes the weight images of the updated parameters
+        # (gte_fold_defer_flush_adam_images) and the next step's forward skips their conversion launch.  _wimg_sig = the version
+        # counters of the parameters the images were made from (None: stale).  In-place writes through torch (load_state_dict,
+        # p.copy_, flat_param.copy_) move the counters; raw writes through ``p.data`` do not: invalidate_weight_images() then.
+        self.wimg_in_fold = os.environ.get("GTE_WIMG_IN_FOLD", "1") == "1"
+        self._wimg_sig = None
         # the whole step through ONE C entry point (gte_gcnsage_step) when the configuration allows (GTE_C_STEP=0: call by call)
         self.use_c_step = os.environ.get("GTE_C_STEP", "1") == "1"
         # called (once per step, no arguments) right before the LAST big kernel of a step is launched -- layer 0's dW GEMM,
@@ -354,6 +360,14 @@ class FusedGcnSageStep(TrainStep):
         assembles batches of image rows (graph.ResidentPages.enable_p3)."""
         L = self.model.layers[0]
         return self._planes_layer(0, L, f0)
+
+    def _param_sig(self):
+        return (self.flat_param._version,) + tuple(p._version for p in self.model.parameters())
+
+    def invalidate_weight_images(self) -> None:
+        """The parameters were changed behind torch's version counters (a raw ``p.data`` write, a foreign kernel): the next
+        forward converts the weight images again."""
+        self._wimg_sig = None
 
     def _weight_images(self, dims, launch=True):
         """P3 images of the planes layers' weights: forward [W_s rows ; W_n rows] x fin, backward (dX) [fin rows] x [W_s^T | W_n^T].
@@ -533,6 +547,11 @@ class FusedGcnSageStep(TrainStep):
         lab = labels if labels.dtype in (torch.float32, torch.int64) else labels.to(torch.int64)
         plan.labels, plan.labels_f32 = P(lab), int(lab.dtype == torch.float32)
         plan.grad_scale = float(grad_scale)
+        capturing = torch.cuda.is_current_stream_capturing()
+        sig = self._param_sig()
+        plan.wimg_fresh = int(self.wimg_in_fold and not capturing and self._wimg_sig == sig)
+        plan.wimg_in_fold = int(self.wimg_in_fold and with_adam and not capturing)
+        self._wimg_sig = None
         addr = ctypes.addressof(plan)
         if self.use_step_graph and st and not torch.cuda.is_current_stream_capturing():
             # the whole step as one executable-graph launch (updated in place per batch); the next batch's assembly is queued first
@@ -545,7 +564,11 @@ class FusedGcnSageStep(TrainStep):
             _lib.check(lib.gte_gcnsage_step(addr, 2, ctypes.byref(fused), st), "gte_gcnsage_step")
         else:
             _lib.check(lib.gte_gcnsage_step(addr, 0, ctypes.byref(fused), st), "gte_gcnsage_step")
-        self._adam_fused = bool(fused.value)
+        self._adam_fused = bool(fused.value & 1)
+        # the images now hold: the updated parameters (written by the fold launch), or -- no optimiser step in this call -- the
+        # unchanged ones the forward converted; otherwise Adam follows as its own launch and they are stale
+        if not capturing and ((fused.value & 2) or not with_adam):
+            self._wimg_sig = sig
         self._keep = (lab, csr, rcsr, w_in, w_out)                     # alive until the next step
         return b["out3"]
 
@@ -560,7 +583,11 @@ class FusedGcnSageStep(TrainStep):
             with torch.no_grad():
                 return self.model(g)
         plan, _fused, b, n, keep = self._bind_plan(g, kinds, with_adam=False)
+        capturing = torch.cuda.is_current_stream_capturing()
+        sig = self._param_sig()
+        plan.wimg_fresh = int(self.wimg_in_fold and not capturing and self._wimg_sig == sig)
         _lib.check(self.lib.gte_gcnsage_forward(ctypes.addressof(plan), _lib.current_stream()), "gte_gcnsage_forward")
+        self._wimg_sig = None if capturing else sig
         self._keep = keep
         return b["y"][-1]
 
@@ -583,6 +610,7 @@ class FusedGcnSageStep(TrainStep):
 
     def _run(self, g, labels, grad_scale, hi, lo, forward):
         lib, P, check = self.lib, _lib.ptr, _lib.check
+        self._wimg_sig = None                         # (this schedule converts the weight images in front of every forward)
         st = _lib.current_stream()
         timed = ops._timed
         xp = getattr(g, "feat_p3", None)              # resident batches in image mode bring the features as a P3 image only
@@ -1083,6 +1111,7 @@ class FusedGcnSageStep(TrainStep):
 
     def _adam_dev_launch(self) -> None:
         P = _lib.ptr
+        self._wimg_sig = None
         _lib.check(self.lib.gte_adam_step_dev(P(self.flat_param), P(self.flat_grad), P(self.exp_avg), P(self.exp_avg_sq),
                                               self.flat_param.numel(), P(self._hyper), P(self._step_dev), P(self._ticket),
                                               _lib.current_stream()), "gte_adam_step_dev")
@@ -1152,6 +1181,7 @@ class FusedGcnSageStep(TrainStep):
             self._step_dev_host -= 1                  # capturing did not run it
 
         def replay():
+            self._wimg_sig = None                     # the graph updates the parameters; its own forward converts the images
             if in_graph_adam:
                 self.t += 1
                 self._sync_adam_state()               # no-op unless lr / t were changed from outside

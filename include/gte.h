@@ -421,7 +421,12 @@ typedef struct gte_step_plan {
                                               bit 1: the output layer's backward runs gte_sage_narrow_bwd_ln_p3;
                                               bit 2: ... and forms q = A_w^T (norm dl) itself (no 9-wide aggregation launch);
                                               bit 3: dX of layer 1 above a SMALLK layer 0 runs gte_gemm_p3_nt_smallk_bwd      */
+    int wimg_fresh;                        /* the weight images already hold the current parameters: the forward skips their
+                                              conversion launch (set by the caller after a step that returned *adam_fused & 2) */
+    int wimg_in_fold;                      /* the fold + Adam launch also writes the weight images of the UPDATED parameters
+                                              (gte_fold_defer_flush_adam_images); *adam_fused & 2 reports that it did        */
 } gte_step_plan;
+/* *adam_fused: bit 0 = the optimiser step ran inside the fold launch, bit 1 = ... and it wrote the weight images */
 int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
 /* The whole step (phase 0) captured from `stream` -- not the legacy null stream -- and launched as ONE executable graph kept in
  * *exec_slot (NULL at first; updated in place every step: same kernels, the batch's grid sizes and arguments; released with
@@ -453,6 +458,14 @@ int gte_fold_defer_flush(void);
  * caller launches gte_adam_step_dev itself.  grad still receives the folded gradient either way. */
 int gte_fold_defer_flush_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                               int64_t* step_counter, unsigned* ticket, int* fused);
+/* ... and, in the same launch, the P3 images of up to 8 sub-matrices of the UPDATED parameters (every `src` inside
+ * [param, param + n); the descriptors of gte_p3_from_f32_batch): the thread that updates a parameter element writes its three
+ * bf16 pieces into each image holding it -- bit for bit what gte_p3_from_f32_batch makes of the updated parameters, without
+ * the launch in front of the next step's first GEMM.  Padding columns of the images are not touched (zero them once).
+ * *fused = 3 when the step and the images were written, 1 when more than 8 images were asked for (step applied, images not),
+ * 0 as gte_fold_defer_flush_adam. */
+int gte_fold_defer_flush_adam_images(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                     int64_t* step_counter, unsigned* ticket, const gte_p3_desc* images, int n_images, int* fused);
 
 /* ---- transform-then-aggregate ("q-form") of a GcnSAGELayer --------------------------------------------------
  * replaces (reference src/components/graphs/models.py:53-72, `torch.cat((h, ah * norm), 1)` -> nn.Linear) where the

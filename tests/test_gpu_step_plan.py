@@ -163,3 +163,57 @@ def test_forward_only_call_matches_the_module_forward_and_the_steps_forward(monk
         assert sub.shape[0] == sum(graphs[i].num_nodes() for i in (5, 1, 2, 8))
     lib = _lib.load()
     assert lib.gte_gcnsage_forward(None, None) == -1
+
+
+@pytest.mark.parametrize("f0", [831, 13])
+def test_fold_launch_writes_the_weight_images_of_the_updated_parameters(monkeypatch, f0):
+    """gte_fold_defer_flush_adam_images: after a one-call step the weight images are, byte for byte, what the conversion launch
+    makes of the updated parameters (so the next forward skips it); a parameter changed through torch is noticed (version
+    counters) and the images are converted again; GTE_WIMG_IN_FOLD=0 gives the same bits."""
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import graph as G
+    from gnn_tableextraction_amd.data import synthetic as S
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    dev = "cuda:0"
+    pages = S.make_pages(8, in_feats=f0)
+    src, dst, w, feat, label, off = S.concat_pages(pages[:5])
+    g = G.PageGraph(src, dst, int(off[-1]), device=dev)
+    g.ndata["feat"], g.edata["feat"] = torch.from_numpy(feat).to(dev), torch.from_numpy(w).to(dev)
+    y = torch.from_numpy(label).to(dev)
+    finals = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GTE_WIMG_IN_FOLD", flag)
+        torch.manual_seed(3)
+        model = gte.GcnSAGE(f0, 256, 9, 3, torch.nn.functional.relu, 0).to(dev)
+        tr = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+        if not tr._planes_on():
+            pytest.skip("the one-call step drives the planes path (default GEMM mode, GTE_PLANES=1)")
+        for _ in range(3):
+            tr.step(g, y)
+        if not any(k for full in tr._bufs.values() for k in full.get("_plans", {})):
+            pytest.skip("the engine's switches rule the one-call step out for this configuration")
+        if not tr.fuse_adam:
+            pytest.skip("GTE_FUSE_ADAM=0: the optimiser step is its own launch")
+        if flag == "1":
+            assert tr.adam_fused_steps == 3 and tr._wimg_sig is not None          # the fold launch wrote them
+            have = {i: (fw.data.clone(), None if bw is None else bw.data.clone()) for i, (fw, bw) in tr._wimg.items()}
+            assert have
+            dims = [f0] + [l.out_feats for l in model.layers]
+            tr._weight_images(dims, launch=True)                                    # the conversion launch on the same parameters
+            for i, (fw, bw) in tr._wimg.items():
+                assert torch.equal(have[i][0], fw.data)
+                if bw is not None:
+                    assert torch.equal(have[i][1], bw.data)
+            # a change through torch is noticed: the forward-only call converts again and matches the module path
+            with torch.no_grad():
+                model.layers[1].linear.weight.mul_(0.5)
+                want = model(g).clone()
+            got = tr.forward_logits(g)
+            assert float((got - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1.0)
+            with torch.no_grad():
+                model.layers[1].linear.weight.mul_(2.0)                             # exact: back to the trained weights
+        else:
+            assert tr._wimg_sig is None
+        tr.step(g, y)
+        finals.append(tr.flat_param.detach().cpu().numpy().copy())
+    np.testing.assert_array_equal(finals[0], finals[1])
