@@ -116,8 +116,6 @@ SIGNATURES = {
     "gte_fold_defer_begin": (c_int, [c_void_p]),
     "gte_fold_defer_flush": (c_int, []),
     "gte_fold_defer_flush_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
-    "gte_fold_defer_flush_adam_partial": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int,
-                                                  c_void_p, POINTER(c_int)]),
     "gte_fold_defer_flush_adam_images": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_int, POINTER(c_int)]),
     "gte_sage_transform_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
@@ -218,7 +216,7 @@ class StepPlan(ctypes.Structure):
                 ("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n_param", c_int64),
                 ("hyper", c_void_p), ("step_counter", c_void_p), ("ticket", c_void_p),
                 ("tail_ws", c_void_p), ("tail_ws_bytes", c_int64), ("fuse_ln_dx", c_int),
-                ("wimg_fresh", c_int), ("wimg_in_fold", c_int), ("side_stream", c_void_p)]
+                ("wimg_fresh", c_int), ("wimg_in_fold", c_int)]
 
 
 class BatchArrays(ctypes.Structure):

@@ -121,13 +121,8 @@ __device__ __forceinline__ void fold_write_images2(const FoldImages& fi, unsigne
 struct FoldQueue {
     FoldBatch batch; bool open = false; hipStream_t stream = nullptr; int blocks = 0;
     bool spilled = false;                 // a full batch was flushed early: the queued folds no longer cover the whole deferral
-    // coverage caches (mode 0: the folds cover the gradient; 1: folds + pending regions do; 2: the folds cover exactly the
-    // pending regions of the partial flush): the descriptor signature each was computed for and its verdict
-    unsigned long long cover_key[3] = {0, 0, 0}; bool cover_ok[3] = {false, false, false};
-    // a partial flush (gte_fold_defer_flush_adam_partial) ran on `side`: the final flush joins it and folds the pending regions
-    bool partial = false; int partial_images = 0;
-    gte_fold_region pending[4]; int n_pending = 0;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // coverage cache of gte_fold_defer_flush_adam: the descriptor signature it was computed for and its verdict
+    unsigned long long cover_key = 0; bool cover_ok = false;
 };
 static FoldQueue& fold_queue() {
     static thread_local FoldQueue q;
@@ -231,7 +226,7 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
                 }
             }
         }
-        if (ad.param && ad.ticket) gte::adam_advance(ad.state, ad.step, ad.ticket);
+        if (ad.param) gte::adam_advance(ad.state, ad.step, ad.ticket);
         return;
     }
     const long long e = (long long)((int)blockIdx.x - d.first_block) * epb + el;
@@ -262,13 +257,12 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
         const long long r = e / d.rowlen;
         put(&d.dst[r * d.ld + (e - r * d.rowlen)], v);
     }
-    if (ad.param && ad.ticket) gte::adam_advance(ad.state, ad.step, ad.ticket);
+    if (ad.param) gte::adam_advance(ad.state, ad.step, ad.ticket);
 }
 
 namespace gte {
 
-static int flush_folds(FoldQueue& q, const FoldAdam* adam = nullptr, const FoldImages* images = nullptr, hipStream_t on = nullptr,
-                       bool use_on = false) {
+static int flush_folds(FoldQueue& q, const FoldAdam* adam = nullptr, const FoldImages* images = nullptr) {
     if (q.batch.n == 0) return GTE_OK;
     q.batch.adam = adam ? *adam : FoldAdam{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (images) q.batch.img = *images; else q.batch.img.n = 0;
@@ -289,7 +283,7 @@ static int flush_folds(FoldQueue& q, const FoldAdam* adam = nullptr, const FoldI
         for (int k = 0; k < images->n; ++k)
             if (images->im[k].off < hi && images->im[k].off + (long long)images->im[k].span > lo) d.img_mask |= 1u << k;
     }
-    hipLaunchKernelGGL(gte_fold_batch_kernel, dim3((unsigned)q.blocks), dim3(256), 0, use_on ? on : q.stream, q.batch);
+    hipLaunchKernelGGL(gte_fold_batch_kernel, dim3((unsigned)q.blocks), dim3(256), 0, q.stream, q.batch);
     q.batch.n = 0;
     q.blocks = 0;
     return check_launch("fold_batch");
@@ -338,7 +332,6 @@ extern "C" int gte_fold_defer_begin(void* stream) {
     gte::FoldQueue& q = gte::fold_queue();
     if (q.open) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_begin: a deferral is already open on this thread");
     q.open = true;
-    q.partial = false;
     q.stream = gte::as_stream(stream);
     q.batch.n = 0;
     q.blocks = 0;
@@ -350,12 +343,6 @@ extern "C" int gte_fold_defer_flush(void) {
     if (!q.open) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush: no deferral is open on this thread");
     q.open = false;
     q.spilled = false;
-    if (q.partial) {                                      // the early part already applied its share of an optimiser step
-        q.partial = false;
-        (void)hipStreamWaitEvent(q.stream, q.ev_join, 0);
-        (void)gte::flush_folds(q);
-        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush: a partial Adam flush is pending (close with gte_fold_defer_flush_adam)");
-    }
     return gte::flush_folds(q);
 }
 
@@ -363,30 +350,7 @@ namespace gte {
 // Do the queued folds write every element of [grad, grad + n) exactly once?  Rows of a fold are intervals
 // [off + r ld, off + r ld + rowlen); sorted and walked once.  The answer is cached on a signature of the descriptors (the
 // same step queues the same folds), so the steady state costs one pass over <= 24 descriptors.
-//   mode 0: the folds cover [0, n);  mode 1: the folds and the `pending` regions together do;  mode 2: the folds cover exactly
-//   the pending regions.
-static bool add_intervals(std::vector<std::pair<int64_t, int64_t>>& iv, const float* dst, int64_t ld, int64_t rows, int64_t rowlen,
-                          const float* grad, int64_t n) {
-    const int64_t off = dst - grad;
-    if (!dst || rows <= 0 || rowlen <= 0 || dst < grad || off + (rows - 1) * ld + rowlen > n) return false;
-    if (ld == rowlen) iv.emplace_back(off, off + rows * rowlen);
-    else for (int64_t r = 0; r < rows; ++r) iv.emplace_back(off + r * ld, off + r * ld + rowlen);
-    return true;
-}
-// sorted, adjacent intervals merged; false on an overlap
-static bool merge_intervals(std::vector<std::pair<int64_t, int64_t>>& iv) {
-    std::sort(iv.begin(), iv.end());
-    size_t m = 0;
-    for (size_t i = 0; i < iv.size(); ++i) {
-        if (m > 0 && iv[i].first < iv[m - 1].second) return false;
-        if (m > 0 && iv[i].first == iv[m - 1].second) iv[m - 1].second = iv[i].second;
-        else iv[m++] = iv[i];
-    }
-    iv.resize(m);
-    return true;
-}
-static bool folds_cover(FoldQueue& q, const float* grad, int64_t n, int mode = 0, const gte_fold_region* pending = nullptr,
-                        int n_pending = 0) {
+static bool folds_cover(FoldQueue& q, const float* grad, int64_t n) {
     unsigned long long key = 1469598103934665603ull;
     auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
     mix((unsigned long long)(uintptr_t)grad); mix((unsigned long long)n); mix((unsigned long long)q.batch.n);
@@ -395,94 +359,30 @@ static bool folds_cover(FoldQueue& q, const float* grad, int64_t n, int mode = 0
         mix((unsigned long long)(uintptr_t)d.dst); mix((unsigned long long)d.ld);
         mix(((unsigned long long)d.rows << 32) | (unsigned)d.rowlen);
     }
-    for (int i = 0; i < n_pending; ++i) {
-        mix((unsigned long long)(uintptr_t)pending[i].dst); mix((unsigned long long)pending[i].ld);
-        mix(((unsigned long long)pending[i].rows << 32) | (unsigned long long)pending[i].rowlen);
-    }
-    if (key == q.cover_key[mode]) return q.cover_ok[mode];
-    std::vector<std::pair<int64_t, int64_t>> iv, pv;
+    if (key == q.cover_key) return q.cover_ok;
+    std::vector<std::pair<int64_t, int64_t>> iv;
     bool ok = true;
     for (int i = 0; i < q.batch.n && ok; ++i) {
         const FoldDesc& d = q.batch.d[i];
-        ok = add_intervals(iv, d.dst, d.ld, d.rows, d.rowlen, grad, n);
+        const int64_t off = d.dst - grad;
+        if (d.dst < grad || off + (int64_t)(d.rows - 1) * d.ld + d.rowlen > n) { ok = false; break; }
+        if (d.ld == d.rowlen) iv.emplace_back(off, off + (int64_t)d.rows * d.rowlen);
+        else for (int r = 0; r < d.rows; ++r) iv.emplace_back(off + (int64_t)r * d.ld, off + (int64_t)r * d.ld + d.rowlen);
     }
-    for (int i = 0; i < n_pending && ok; ++i)
-        ok = add_intervals(mode == 1 ? iv : pv, pending[i].dst, pending[i].ld, pending[i].rows, pending[i].rowlen, grad, n);
-    ok = ok && merge_intervals(iv);                        // (an overlap: some element written twice)
-    if (ok && mode == 2) ok = merge_intervals(pv) && iv == pv;
-    else if (ok) ok = iv.size() == 1 && iv[0].first == 0 && iv[0].second == n;
-    q.cover_key[mode] = key;
-    q.cover_ok[mode] = ok;
+    if (ok) {
+        std::sort(iv.begin(), iv.end());
+        int64_t at = 0;
+        for (const auto& v : iv) {
+            if (v.first != at) { ok = false; break; }      // a gap (an element no fold writes) or an overlap
+            at = v.second;
+        }
+        ok = ok && at == n;
+    }
+    q.cover_key = key;
+    q.cover_ok = ok;
     return ok;
 }
-
-// the image table of gte_fold_defer_flush_adam_images from its descriptors: GTE_OK and fi.n = n_images, fi.n = 0 when the images
-// cannot ride in the fold launch (too many, a sub-matrix too large for the multiply-high row split), or an error
-static int fold_images(const float* param, int64_t n, const gte_p3_desc* images, int n_images, FoldImages& fi) {
-    fi.n = 0;
-    if (n_images < 0 || (n_images > 0 && !images)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam_images: bad image list");
-    if (n_images == 0 || n_images > kMaxFoldImages) return GTE_OK;
-    for (int k = 0; k < n_images; ++k) {
-        const gte_p3_desc& d = images[k];
-        const int64_t srows = d.transpose ? d.cols : d.rows, scols = d.transpose ? d.rows : d.cols;
-        if (!d.src || !d.dst || d.rows <= 0 || d.cols <= 0 || d.ld < scols || d.ld > INT32_MAX || d.ldp < p3::row_bytes(d.cols) ||
-            d.src < param || (d.src - param) + (srows - 1) * d.ld + scols > n)
-            return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam_images: image %d does not describe a sub-matrix of the parameters", k);
-        FoldImage& im = fi.im[k];
-        const int64_t span = (srows - 1) * d.ld + scols;
-        if (span >= ((int64_t)1 << 32) / d.ld) return GTE_OK;                   // (the multiply-high row split would not be exact)
-        im.off = d.src - param; im.span = (unsigned)span; im.ld = (unsigned)d.ld; im.magic = (unsigned)((((uint64_t)1 << 32) / d.ld) + 1);
-        im.cols = (int)scols; im.transpose = d.transpose ? 1 : 0; im.pad = 0; im.dst = reinterpret_cast<char*>(d.dst); im.ldp = d.ldp;
-    }
-    fi.n = n_images;
-    return GTE_OK;
-}
 }  // namespace gte
-
-// Part of the deferral EARLY, beside the kernels that are still to queue their folds: when the folds queued so far together with
-// the `pending` regions (<= 4: the gradients those later kernels will fold) cover the flat gradient exactly, the queued folds and
-// the Adam update of their elements (and their weight images) run NOW on `side_stream` -- ordered behind everything issued to
-// the deferral's stream so far -- and the deferral stays open for the rest: *launched = 1.  The optimiser state is not advanced;
-// the closing gte_fold_defer_flush_adam[_images] (same arguments) joins the side stream, checks that the folds queued since
-// cover exactly the pending regions, and finishes the step.  *launched = 0: nothing happened (not covering, spilled, ...).
-extern "C" int gte_fold_defer_flush_adam_partial(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
-                                                 const gte_p3_desc* images, int n_images, const gte_fold_region* pending, int n_pending,
-                                                 void* side_stream, int* launched) {
-    gte::FoldQueue& q = gte::fold_queue();
-    if (launched) *launched = 0;
-    if (!q.open) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam_partial: no deferral is open on this thread");
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !state || !launched || n <= 0 || !pending || n_pending < 1 || n_pending > 4)
-        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam_partial: null pointer, n <= 0 or not 1 .. 4 pending regions");
-    hipStream_t side = gte::as_stream(side_stream);
-    if (q.partial || q.spilled || q.batch.n == 0 || !side || side == q.stream) return GTE_OK;
-    if (!gte::folds_cover(q, grad, n, 1, pending, n_pending)) return GTE_OK;
-    gte::FoldImages fi;
-    const int irc = gte::fold_images(param, n, images, n_images, fi);
-    if (irc != GTE_OK) return irc;
-    if (!q.ev_fork) {
-        if (hipEventCreateWithFlags(&q.ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&q.ev_join, hipEventDisableTiming) != hipSuccess) {
-            q.ev_fork = q.ev_join = nullptr;
-            (void)hipGetLastError();
-            return GTE_OK;
-        }
-    }
-    if (hipEventRecord(q.ev_fork, q.stream) != hipSuccess || hipStreamWaitEvent(side, q.ev_fork, 0) != hipSuccess)
-        return gte::fail(GTE_ERR_LAUNCH, "fold_defer_flush_adam_partial: fork: %s", hipGetErrorString(hipGetLastError()));
-    const int vec_ok = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
-                         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
-    const gte::FoldAdam ad = {param, grad, exp_avg, exp_avg_sq, state, nullptr, nullptr, vec_ok};     // no ticket: no state advance
-    const int rc = gte::flush_folds(q, &ad, fi.n > 0 ? &fi : nullptr, side, true);
-    if (rc != GTE_OK) return rc;
-    if (hipEventRecord(q.ev_join, side) != hipSuccess)
-        return gte::fail(GTE_ERR_LAUNCH, "fold_defer_flush_adam_partial: join event: %s", hipGetErrorString(hipGetLastError()));
-    q.partial = true;
-    q.partial_images = fi.n;
-    q.n_pending = n_pending;
-    for (int i = 0; i < n_pending; ++i) q.pending[i] = pending[i];
-    *launched = 1;
-    return GTE_OK;
-}
 
 extern "C" int gte_fold_defer_flush_adam_images(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                                                 int64_t* step_counter, unsigned* ticket, const gte_p3_desc* images, int n_images,
@@ -491,30 +391,35 @@ extern "C" int gte_fold_defer_flush_adam_images(float* param, float* grad, float
     if (fused) *fused = 0;
     if (!q.open) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam: no deferral is open on this thread");
     q.open = false;
-    const bool spilled = q.spilled, partial = q.partial;
+    const bool spilled = q.spilled;
     q.spilled = false;
-    q.partial = false;
-    static const bool nojoin = getenv("GTE_FOLD_SPLIT_NOJOIN") != nullptr;      // (measurement only: WRONG results)
-    if (partial && !nojoin && hipStreamWaitEvent(q.stream, q.ev_join, 0) != hipSuccess) {            // join the early part first, whatever follows
-        (void)gte::flush_folds(q);
-        return gte::fail(GTE_ERR_LAUNCH, "fold_defer_flush_adam: join: %s", hipGetErrorString(hipGetLastError()));
-    }
     if (!param || !grad || !exp_avg || !exp_avg_sq || !state || !step_counter || !ticket || !fused || n <= 0) {
         (void)gte::flush_folds(q);
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam: null pointer or n <= 0");
     }
     gte::FoldImages fi;
-    const int irc = gte::fold_images(param, n, images, n_images, fi);
-    if (irc != GTE_OK) { (void)gte::flush_folds(q); return irc; }
-    if (partial) {
-        // the early part applied the step to its elements: the rest MUST be exactly the pending regions announced then
-        if (spilled || q.batch.n == 0 || !gte::folds_cover(q, grad, n, 2, q.pending, q.n_pending) || (fi.n > 0) != (q.partial_images > 0)) {
-            (void)gte::flush_folds(q);
-            return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam: the folds queued after the partial flush are not its pending regions");
-        }
-    } else if (spilled || q.batch.n == 0 || !gte::folds_cover(q, grad, n)) {
-        return gte::flush_folds(q);                       // caller runs gte_adam_step_dev
+    fi.n = 0;
+    if (n_images < 0 || (n_images > 0 && !images)) {
+        (void)gte::flush_folds(q);
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam_images: bad image list");
     }
+    bool images_ok = n_images > 0 && n_images <= gte::kMaxFoldImages;
+    for (int k = 0; images_ok && k < n_images; ++k) {
+        const gte_p3_desc& d = images[k];
+        const int64_t srows = d.transpose ? d.cols : d.rows, scols = d.transpose ? d.rows : d.cols;
+        if (!d.src || !d.dst || d.rows <= 0 || d.cols <= 0 || d.ld < scols || d.ld > INT32_MAX || d.ldp < p3::row_bytes(d.cols) ||
+            d.src < param || (d.src - param) + (srows - 1) * d.ld + scols > n) {
+            (void)gte::flush_folds(q);
+            return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam_images: image %d does not describe a sub-matrix of the parameters", k);
+        }
+        gte::FoldImage& im = fi.im[k];
+        const int64_t span = (srows - 1) * d.ld + scols;
+        if (span >= ((int64_t)1 << 32) / d.ld) { images_ok = false; break; }      // (the multiply-high row split would not be exact)
+        im.off = d.src - param; im.span = (unsigned)span; im.ld = (unsigned)d.ld; im.magic = (unsigned)((((uint64_t)1 << 32) / d.ld) + 1);
+        im.cols = (int)scols; im.transpose = d.transpose ? 1 : 0; im.pad = 0; im.dst = reinterpret_cast<char*>(d.dst); im.ldp = d.ldp;
+    }
+    if (images_ok) fi.n = n_images;
+    if (spilled || q.batch.n == 0 || !gte::folds_cover(q, grad, n)) return gte::flush_folds(q);   // caller runs gte_adam_step_dev
     const int vec_ok = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                          reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
     const gte::FoldAdam ad = {param, grad, exp_avg, exp_avg_sq, state, reinterpret_cast<long long*>(step_counter), ticket, vec_ok};

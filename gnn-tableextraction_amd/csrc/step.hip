@@ -66,27 +66,6 @@ bool smallk_in_dx(const gte_step_plan& p) {
            gte_gemm_p3_nt_smallk_bwd_supported(2 * B.fin, L.fin);
 }
 
-// Everything queued in the deferral so far -- the gradients of every layer but layer 0 -- is folded and stepped NOW on the plan's
-// side stream, beside the step's last GEMM; the closing flush then folds layer 0's gradient only
-// (gte_fold_defer_flush_adam_partial).  `with_images`: the early part may write its weight images (nothing that is still to run
-// reads them).
-int early_flush(const gte_step_plan& p, const gte_step_layer& L0, bool whole_layer, bool with_images) {
-    if (!p.param || !p.side_stream) return GTE_OK;
-    gte_fold_region pend[4];
-    int np = 0;
-    pend[np++] = gte_fold_region{L0.gW, 2 * L0.fin, L0.fout, 2 * L0.fin};
-    if (whole_layer) {
-        pend[np++] = gte_fold_region{L0.gbias, L0.fout, 1, L0.fout};
-        pend[np++] = gte_fold_region{L0.ggamma, L0.fout, 1, L0.fout};
-        pend[np++] = gte_fold_region{L0.gbeta, L0.fout, 1, L0.fout};
-    }
-    const bool img = with_images && p.wimg_in_fold && p.n_wimg_descs > 0;
-    int launched = 0;
-    return gte_fold_defer_flush_adam_partial(p.param, p.grad, p.exp_avg, p.exp_avg_sq, p.n_param, p.hyper,
-                                             img ? reinterpret_cast<const gte_p3_desc*>(p.wimg_descs) : nullptr, img ? p.n_wimg_descs : 0,
-                                             pend, np, p.side_stream, &launched);
-}
-
 // backward of the output layer and of hidden layers n_hidden - 1 .. 1, and of layer 0 up to its weight-gradient GEMM
 int backward_a(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes, C = p.n_classes;
@@ -126,9 +105,7 @@ int backward_a(const gte_step_plan& p, void* st) {
                                L.ws_dw_bytes, st));
         const gte_step_layer& B = p.layer[i - 1];
         if (i == 1 && smallk_in_dx(p)) {
-            // ... with the WHOLE backward of the short-input layer 0 as its epilogue: the step's last kernel.  The folds of the
-            // other layers run beside it (without weight images: this GEMM reads layer 1's)
-            GTE_TRY(early_flush(p, B, true, false));
+            // ... with the WHOLE backward of the short-input layer 0 as its epilogue
             GTE_TRY(gte_gemm_p3_nt_smallk_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, B.x, B.ldx, B.fin, B.ahn,
                                               B.fin, B.fin, B.W, 2 * B.fin, B.bias, B.gamma, B.beta, B.stats, B.relu, B.gW, 2 * B.fin, B.gbias,
                                               B.ggamma, B.gbeta, n, L.fin, B.ws_dw, B.ws_dw_bytes, st));
@@ -155,7 +132,6 @@ int backward_b(const gte_step_plan& p, void* st) {
                                    L.relu, L.gW, 2 * L.fin, L.gbias, L.ggamma, L.gbeta, n, L.fout, L.ws_dw, L.ws_dw_bytes, st);
     if (L.kind == GTE_LAYER_SMALLK)
         return gte_sage_linear_dw(L.dy, L.fout, L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.gW, 2 * L.fin, L.fout, n, L.ws_dw, L.ws_dw_bytes, st);
-    GTE_TRY(early_flush(p, L, false, true));           // the other layers' folds + Adam beside this GEMM (it reads no parameter)
     if (L.h_rows)
         return gte_gemm_p3_tn_rows(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, L.h_rows, L.n_res_rows, L.fin, L.gW, 2 * L.fin, L.fout,
                                    2 * L.fin, n, L.ws_dw, L.ws_dw_bytes, st);
@@ -167,7 +143,7 @@ int flush(const gte_step_plan& p, int* adam_fused) {
     if (adam_fused) *adam_fused = 0;
     if (p.param) {
         int fused = 0;
-        const bool img = p.wimg_in_fold && p.n_wimg_descs > 0 && !(p.side_stream && smallk_in_dx(p));
+        const bool img = p.wimg_in_fold && p.n_wimg_descs > 0;
         const int rc = gte_fold_defer_flush_adam_images(p.param, p.grad, p.exp_avg, p.exp_avg_sq, p.n_param, p.hyper, p.step_counter, p.ticket,
                                                         img ? reinterpret_cast<const gte_p3_desc*>(p.wimg_descs) : nullptr,
                                                         img ? p.n_wimg_descs : 0, &fused);

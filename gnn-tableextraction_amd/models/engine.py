@@ -196,9 +196,6 @@ class FusedGcnSageStep(TrainStep):
         # counters of the parameters the images were made from (None: stale).  In-place writes through torch (load_state_dict,
         # p.copy_, flat_param.copy_) move the counters; raw writes through ``p.data`` do not: invalidate_weight_images() then.
         self.wimg_in_fold = os.environ.get("GTE_WIMG_IN_FOLD", "1") == "1"
-        # one-call step: the gradient folds + Adam of every layer but layer 0 run on the side stream beside the step's last GEMM
-        # (layer 0's weight gradient), the closing launch folds and steps layer 0 only (gte_fold_defer_flush_adam_partial)
-        self.fold_split = os.environ.get("GTE_FOLD_SPLIT", "0") == "1"
         self._wimg_sig = None
         # the whole step through ONE C entry point (gte_gcnsage_step) when the configuration allows (GTE_C_STEP=0: call by call)
         self.use_c_step = os.environ.get("GTE_C_STEP", "1") == "1"
@@ -555,8 +552,6 @@ class FusedGcnSageStep(TrainStep):
         plan.wimg_fresh = int(self.wimg_in_fold and not capturing and self._wimg_sig == sig)
         plan.wimg_in_fold = int(self.wimg_in_fold and with_adam and not capturing)
         self._wimg_sig = None
-        # the folds + Adam of every layer but layer 0 on the side stream, beside the step's last GEMM
-        plan.side_stream = self._side.cuda_stream if (self.fold_split and with_adam and not capturing and not self.use_step_graph) else None
         addr = ctypes.addressof(plan)
         if self.use_step_graph and st and not torch.cuda.is_current_stream_capturing():
             # the whole step as one executable-graph launch (updated in place per batch); the next batch's assembly is queued first

@@ -425,8 +425,6 @@ typedef struct gte_step_plan {
                                               conversion launch (set by the caller after a step that returned *adam_fused & 2) */
     int wimg_in_fold;                      /* the fold + Adam launch also writes the weight images of the UPDATED parameters
                                               (gte_fold_defer_flush_adam_images); *adam_fused & 2 reports that it did        */
-    void* side_stream;                     /* not NULL (and fused Adam): the folds + Adam of everything but layer 0 run on this stream
-                                              beside the step's last GEMM (gte_fold_defer_flush_adam_partial)                */
 } gte_step_plan;
 /* *adam_fused: bit 0 = the optimiser step ran inside the fold launch, bit 1 = ... and it wrote the weight images */
 int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
@@ -468,20 +466,6 @@ int gte_fold_defer_flush_adam(float* param, float* grad, float* exp_avg, float* 
  * 0 as gte_fold_defer_flush_adam. */
 int gte_fold_defer_flush_adam_images(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                                      int64_t* step_counter, unsigned* ticket, const gte_p3_desc* images, int n_images, int* fused);
-/* Part of the deferral EARLY, beside the kernels that have yet to queue their folds (r03: the fold + Adam launch was 28 us at
- * the end of every step, behind a 107 us MFMA-bound weight-gradient GEMM that only the last fold depends on).  `pending` = the
- * 1 .. 4 gradient regions those later kernels will fold.  When the folds queued so far and the pending regions together cover the
- * flat gradient exactly, the queued folds, the Adam update of their elements and their weight images run on `side_stream`,
- * ordered behind everything issued to the deferral's stream so far; the deferral stays open: *launched = 1.  The optimiser state
- * (step count, bias corrections) is NOT advanced.  The closing gte_fold_defer_flush_adam[_images] -- same arguments -- joins the
- * side stream, requires the folds queued since to cover exactly the pending regions (GTE_ERR_INVALID_ARGUMENT otherwise) and
- * finishes the step.  *launched = 0: nothing was launched (no exact cover, an overflowed deferral, side_stream NULL or the
- * deferral's own stream) and the closing flush behaves as without this call.  The caller guarantees that nothing issued to the
- * deferral's stream between the two calls reads a parameter, gradient or weight image the early part writes. */
-typedef struct gte_fold_region { const float* dst; int64_t ld; int64_t rows, rowlen; } gte_fold_region;
-int gte_fold_defer_flush_adam_partial(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
-                                      const gte_p3_desc* images, int n_images, const gte_fold_region* pending, int n_pending,
-                                      void* side_stream, int* launched);
 
 /* ---- transform-then-aggregate ("q-form") of a GcnSAGELayer --------------------------------------------------
  * replaces (reference src/components/graphs/models.py:53-72, `torch.cat((h, ah * norm), 1)` -> nn.Linear) where the
