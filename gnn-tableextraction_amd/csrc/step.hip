@@ -105,11 +105,10 @@ int backward_a(const gte_step_plan& p, void* st) {
                                L.ws_dw_bytes, st));
         const gte_step_layer& B = p.layer[i - 1];
         if (i == 1 && smallk_in_dx(p)) {
-            // ... with the WHOLE backward of the short-input layer 0 as its epilogue
-            GTE_TRY(gte_gemm_p3_nt_smallk_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, B.x, B.ldx, B.fin, B.ahn,
-                                              B.fin, B.fin, B.W, 2 * B.fin, B.bias, B.gamma, B.beta, B.stats, B.relu, B.gW, 2 * B.fin, B.gbias,
-                                              B.ggamma, B.gbeta, n, L.fin, B.ws_dw, B.ws_dw_bytes, st));
+            // dX with the WHOLE backward of the short-input layer 0 as its epilogue is the step's last GEMM: phase 2 (the caller
+            // queues the next batch's assembly in front of it, as in front of a planes layer 0's dW)
             smallk_done = true;
+            break;
         } else if ((p.fuse_ln_dx & 1) && B.kind == GTE_LAYER_PLANES && gte_gemm_p3_nt_ln_bwd_supported(L.fin)) {
             GTE_TRY(gte_gemm_p3_nt_ln_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, B.t, 2 * B.fout, B.stats, B.gamma,
                                           B.beta, B.relu, B.dy, B.fout, B.dzp, B.ldp_o, B.ggamma, B.gbeta, B.gbias, n, L.fin, B.ws_ln,
@@ -126,7 +125,12 @@ int backward_a(const gte_step_plan& p, void* st) {
 int backward_b(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes;
     const gte_step_layer& L = p.layer[0];
-    if (smallk_in_dx(p)) return GTE_OK;                // (layer 0's backward ran as the epilogue of layer 1's dX, phase 1)
+    if (smallk_in_dx(p)) {                             // layer 1's dX with layer 0's whole backward as its epilogue
+        const gte_step_layer& U = p.layer[1];
+        return gte_gemm_p3_nt_smallk_bwd(U.dzp, U.ldp_o, U.fout, U.qp, U.ldp_o, U.fout, U.wimg_bwd, U.ldp_wbwd, L.x, L.ldx, L.fin, L.ahn,
+                                         L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.stats, L.relu, L.gW, 2 * L.fin, L.gbias,
+                                         L.ggamma, L.gbeta, n, U.fin, L.ws_dw, L.ws_dw_bytes, st);
+    }
     if (L.kind == GTE_LAYER_SMALLK && gte_sage_smallk_bwd_supported(2 * L.fin, L.fout))
         return gte_sage_smallk_bwd(L.dy, L.fout, L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.W, 2 * L.fin, L.bias, L.gamma, L.beta, L.stats,
                                    L.relu, L.gW, 2 * L.fin, L.gbias, L.ggamma, L.gbeta, n, L.fout, L.ws_dw, L.ws_dw_bytes, st);
