@@ -580,6 +580,10 @@ class FusedGcnSageStep(TrainStep):
         n, f0 = (xp.rows, xp.cols) if xp is not None else g.ndata['feat'].shape
         kinds = self._plan_kinds(f0, n) if n > 0 else None
         if kinds is None:
+            if xp is not None and 'feat' not in g.ndata:
+                # a resident batch in image mode carries its features as a P3 image only: the module path reads fp32 rows (the
+                # image holds exactly the fp32 values)
+                g.ndata['feat'] = ops.p3_to_f32(xp)
             with torch.no_grad():
                 return self.model(g)
         plan, _fused, b, n, keep = self._bind_plan(g, kinds, with_adam=False)
