@@ -218,3 +218,35 @@ def test_fold_launch_writes_the_weight_images_of_the_updated_parameters(monkeypa
         tr.step(g, y)
         finals.append(tr.flat_param.detach().cpu().numpy().copy())
     np.testing.assert_array_equal(finals[0], finals[1])
+
+
+def test_fold_flush_with_images_rejects_bad_image_lists():
+    """gte_fold_defer_flush_adam_images: an image that is not a sub-matrix of the parameter buffer, or a negative count, is an error
+    (the deferral is closed either way); without an open deferral the call fails; more than 8 images are not an error (the step
+    is applied, the images are left to the conversion launch: *fused = 1 at most)."""
+    import ctypes
+    from gnn_tableextraction_amd import _lib, ops
+    lib, P = _lib.load(), _lib.ptr
+    dev = "cuda:0"
+    n = 4096
+    param, grad, m, v = (torch.zeros(n, device=dev) for _ in range(4))
+    hyper = torch.tensor([0.01, 0.9, 0.999, 1e-8, 0.0, 1.0, 0.1, 0.0316], device=dev)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    ticket = torch.zeros(int(lib.gte_adam_ticket_bytes()) // 4, dtype=torch.int32, device=dev)
+    other = torch.zeros(64, 64, device=dev)
+    img = ops.P3.empty(64, 64, dev)
+    fused = ctypes.c_int(7)
+    args = (P(param), P(grad), P(m), P(v), n, P(hyper), P(step), P(ticket))
+    assert lib.gte_fold_defer_flush_adam_images(*args, None, 0, ctypes.byref(fused)) == -1          # no deferral open
+    bad = (_lib.P3Desc * 1)(_lib.P3Desc(other.data_ptr(), 64, 64, 64, 0, img.data.data_ptr(), img.ldp))   # not inside `param`
+    assert lib.gte_fold_defer_begin(_lib.current_stream()) == 0
+    assert lib.gte_fold_defer_flush_adam_images(*args, ctypes.addressof(bad), 1, ctypes.byref(fused)) == -1
+    assert b"sub-matrix" in lib.gte_last_error() and fused.value == 0
+    assert lib.gte_fold_defer_begin(_lib.current_stream()) == 0                                     # (the failed call closed it)
+    assert lib.gte_fold_defer_flush_adam_images(*args, None, -1, ctypes.byref(fused)) == -1
+    good = _lib.P3Desc(param.data_ptr(), 64, 64, 64, 0, img.data.data_ptr(), img.ldp)
+    many = (_lib.P3Desc * 9)(*([good] * 9))
+    assert lib.gte_fold_defer_begin(_lib.current_stream()) == 0
+    assert lib.gte_fold_defer_flush_adam_images(*args, ctypes.addressof(many), 9, ctypes.byref(fused)) == 0
+    assert fused.value == 0                                                                          # nothing queued: no step either
+    torch.cuda.synchronize()
