@@ -20,16 +20,23 @@ for p in pages:
 res = G.ResidentPages(graphs, dev)
 torch.manual_seed(0)
 model = gte.GcnSAGE(831, 256, 9, 3, torch.nn.functional.relu, 0).to(dev)
-tr = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+DIST = os.environ.get("LOOP_DIST") == "1"        # the data-parallel step through a one-rank RCCL process group
+if DIST:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+tr = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4, distributed=DIST)
 pipe = L.BatchPipeline(res)
 rng = np.random.default_rng(0)
 def plan(nsteps):
     return [rng.choice(NP, 100, replace=False) for _ in range(nsteps)]
+EPOCH = int(os.environ.get("LOOP_EPOCH", "240"))   # steps per run_steps call (bench.py: epochs of 12 steps)
 L.run_steps(tr, pipe, plan(24))
 torch.cuda.synchronize()
 stamps = []
 t0 = time.perf_counter()
-L.run_steps(tr, pipe, plan(240), on_step=lambda s, g, o: stamps.append(time.perf_counter()))
+for _ in range(240 // EPOCH):
+    L.run_steps(tr, pipe, plan(EPOCH), on_step=lambda s, g, o: stamps.append(time.perf_counter()))
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
