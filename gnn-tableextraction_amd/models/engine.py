@@ -572,13 +572,21 @@ class FusedGcnSageStep(TrainStep):
         self._keep = (lab, csr, rcsr, w_in, w_out)                     # alive until the next step
         return b["out3"]
 
+    FORWARD_IMAGE_MAX_ELEMS = 1 << 21     # forward_logits: largest fp32 feature matrix that is converted to an image per call
+
     def forward_logits(self, g) -> torch.Tensor:
         """``model(g)`` without autograd (model_predict.py:141-147, the validation forward of model_train.py:349-353): logits
         [n, n_classes] through ONE host call (gte_gcnsage_forward) on the step's own buffers -- a view that the next step or
-        forward on this engine overwrites.  Configurations the one-call plan does not cover run the module path."""
+        forward on this engine overwrites.  Configurations the one-call plan does not cover -- and large graphs that bring fp32
+        features to a planes input layer (a validation graph: the plan would write their image first) -- run the module path."""
         xp = getattr(g, "feat_p3", None)
         n, f0 = (xp.rows, xp.cols) if xp is not None else g.ndata['feat'].shape
         kinds = self._plan_kinds(f0, n) if n > 0 else None
+        if kinds is not None and xp is None and kinds[0] == 0 and n * f0 > self.FORWARD_IMAGE_MAX_ELEMS:
+            # fp32 features under a planes input layer: the one-call plan would first write their P3 image (65 us at 21.5 k x 831)
+            # -- more than the call saves on a graph of this size; the module path multiplies the fp32 rows directly
+            # (profiles/debug/val_forward_time.py: 0.241 against 0.275 ms at 21.5 k nodes, 1.24 against 1.43 ms at 124 k)
+            kinds = None
         if kinds is None:
             if xp is not None and 'feat' not in g.ndata:
                 # a resident batch in image mode carries its features as a P3 image only: the module path reads fp32 rows (the
