@@ -150,6 +150,10 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_ln_relu_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p,
                                 c_int64, c_int64, c_void_p]),
+    "gte_ln_relu_fwd_p3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p, c_int64,
+                                   c_void_p, c_int64, c_int64, c_void_p]),
+    "gte_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "gte_colsum": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_ln_relu_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "gte_ln_relu_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
@@ -197,7 +201,8 @@ class StepLayer(ctypes.Structure):
                 ("make_hp", c_int),
                 ("ahn", c_void_p), ("t", c_void_p), ("stats", c_void_p), ("y", c_void_p), ("yp", c_void_p), ("ldp_y", c_int64),
                 ("dy", c_void_p), ("dzp", c_void_p), ("qp", c_void_p), ("ldp_o", c_int64),
-                ("ws_ln", c_void_p), ("ws_ln_bytes", c_int64), ("ws_dw", c_void_p), ("ws_dw_bytes", c_int64)]
+                ("ws_ln", c_void_p), ("ws_ln_bytes", c_int64), ("ws_dw", c_void_p), ("ws_dw_bytes", c_int64),
+                ("ldf", c_int64), ("ahnp", c_void_p), ("ldp_ahn", c_int64)]
 
 
 class StepPlan(ctypes.Structure):
@@ -216,7 +221,11 @@ class StepPlan(ctypes.Structure):
                 ("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n_param", c_int64),
                 ("hyper", c_void_p), ("step_counter", c_void_p), ("ticket", c_void_p),
                 ("tail_ws", c_void_p), ("tail_ws_bytes", c_int64), ("fuse_ln_dx", c_int),
-                ("wimg_fresh", c_int), ("wimg_in_fold", c_int)]
+                ("wimg_fresh", c_int), ("wimg_in_fold", c_int),
+                ("out_gemm", c_int), ("ld_lg", c_int64), ("hp_out", c_void_p), ("ldp_hout", c_int64),
+                ("wimg_out_fwd", c_void_p), ("ldp_wout_fwd", c_int64), ("wimg_out_bwd", c_void_p), ("ldp_wout_bwd", c_int64),
+                ("dlqp", c_void_p), ("ldp_dlq", c_int64), ("ws_out", c_void_p), ("ws_out_bytes", c_int64),
+                ("ws_ce", c_void_p), ("ws_ce_bytes", c_int64), ("ws_cs", c_void_p), ("ws_cs_bytes", c_int64)]
 
 
 class BatchArrays(ctypes.Structure):

@@ -61,7 +61,7 @@ struct FoldAdam { float* param; float* grad; float* exp_avg; float* exp_avg_sq; 
 // NEXT step multiply (gte_fold_defer_flush_adam_images): the thread that updates a parameter element writes its three bf16
 // pieces into every image that holds it.  off = element offset of the sub-matrix in the flat parameter buffer; its rows x cols
 // elements sit at row stride ld; image(r, c) = transpose ? sub(c, r) : sub(r, c).
-constexpr int kMaxFoldImages = 8;
+constexpr int kMaxFoldImages = 12;
 struct FoldImage { long long off; unsigned span, ld, magic; int cols, transpose, pad; char* dst; long long ldp; };
 struct FoldImages { FoldImage im[kMaxFoldImages]; int n; };
 struct FoldBatch { FoldDesc d[kMaxFolds]; int n; FoldAdam adam; FoldImages img; };
@@ -414,7 +414,8 @@ extern "C" int gte_fold_defer_flush_adam_images(float* param, float* grad, float
         }
         gte::FoldImage& im = fi.im[k];
         const int64_t span = (srows - 1) * d.ld + scols;
-        if (span >= ((int64_t)1 << 32) / d.ld) { images_ok = false; break; }      // (the multiply-high row split would not be exact)
+        // (the multiply-high row split would not be exact; ld == 1: the magic constant 2^32 + 1 does not fit 32 bits)
+        if (d.ld < 2 || span >= ((int64_t)1 << 32) / d.ld) { images_ok = false; break; }
         im.off = d.src - param; im.span = (unsigned)span; im.ld = (unsigned)d.ld; im.magic = (unsigned)((((uint64_t)1 << 32) / d.ld) + 1);
         im.cols = (int)scols; im.transpose = d.transpose ? 1 : 0; im.pad = 0; im.dst = reinterpret_cast<char*>(d.dst); im.ldp = d.ldp;
     }

@@ -194,6 +194,51 @@ extern "C" int gte_weighted_ce(const float* logits, int64_t ld, const void* labe
     return gte::check_launch("weighted_ce");
 }
 
+// ---- column sums of a narrow matrix: out[c] = sum_r x[r][c], c < n <= 64 (the bias gradient of the output layer when its
+// backward runs on the planes GEMMs: dbias = colsum(dlogits), models.py:101-103 through autograd) ----------------------------
+// Block partials in a fixed order, folded by the step's deferred fold launch (or one tiny launch): deterministic, no atomics.
+namespace {
+constexpr int kColsumBlocks = 256;
+__global__ void __launch_bounds__(256)
+colsum_partial_kernel(const float* __restrict__ x, long long ldx, int M, int n, float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s = 0.f;
+    if (lane < n)
+        for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) s += x[(long long)r * ldx + lane];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && lane < n) partial[(long long)blockIdx.x * n + lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+__global__ void __launch_bounds__(64)
+colsum_fold_small_kernel(const float* __restrict__ partial, int nb, int n, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(long long)b * n + c];
+    out[c] = s;
+}
+int colsum_blocks(int64_t M) { return (int)(gte::ceil_div(M, 4) < kColsumBlocks ? gte::ceil_div(M, 4) : kColsumBlocks); }
+}  // namespace
+
+extern "C" int64_t gte_colsum_workspace_bytes(int64_t n_rows, int64_t n_cols) {
+    return gte::round_up((int64_t)colsum_blocks(n_rows > 0 ? n_rows : 1) * (n_cols > 0 ? n_cols : 1) * 4, 256);
+}
+
+extern "C" int gte_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_t n_cols, float* out, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    if (n_rows <= 0 || n_cols <= 0 || n_cols > 64 || n_rows > INT32_MAX) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "colsum: needs 1 <= n_cols <= 64, n_rows >= 1");
+    if (!x || !out || !workspace || ldx < n_cols) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "colsum: null pointer or ld < n_cols");
+    if (workspace_bytes < gte_colsum_workspace_bytes(n_rows, n_cols)) return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "colsum: workspace too small");
+    hipStream_t s = gte::as_stream(stream);
+    const int nb = colsum_blocks(n_rows);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, (long long)ldx, (int)n_rows, (int)n_cols, part);
+    if (!gte::defer_fold(part, n_cols, nb, 1, (int)n_cols, out, n_cols))
+        hipLaunchKernelGGL(colsum_fold_small_kernel, dim3(1), dim3(64), 0, s, part, nb, (int)n_cols, out);
+    return gte::check_launch("colsum");
+}
+
 extern "C" int gte_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                              float grad_scale, void* stream) {

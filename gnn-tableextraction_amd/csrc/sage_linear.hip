@@ -1216,6 +1216,195 @@ ln_relu_bwd_vec_kernel(const float* __restrict__ dy, int64_t lddy, const float* 
     }
 }
 
+// ---- any width up to 1024 (the reference's own run shapes: hidden 1000, or int(calculate_hidden) = 96 ... 218) ----------------
+// Rows PADDED to a multiple of 4 floats (ld >= n rounded up to 4): lane l owns columns 4 (l + 64 v) .. + 3, v < NV; per-element
+// masks instead of the per-chunk mask of the vec kernels; columns n .. up to the next multiple of 4 of the fp32 outputs and up to
+// the next multiple of 16 of the P3 images are written as zeros.  Same two-pass statistics / the same backward arithmetic.
+template <int NV, int RF>
+__global__ void __launch_bounds__(256)
+ln_relu_fwd_gen_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ gamma, const float* __restrict__ beta,
+                       float eps, int relu, float* __restrict__ y, int64_t ldy, char* __restrict__ yp3, int64_t ldyp3,
+                       float* __restrict__ stats, int M, int n) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RF;
+    if (row0 >= M) return;
+    const int n16 = (n + 15) & ~15;
+    float g[NV][4], b[NV][4];
+    bool okv[NV], imv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int j = 4 * (lane + 64 * v);
+        okv[v] = j < n;
+        imv[v] = j < n16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[v][e] = j + e < n ? gamma[j + e] : 0.f; b[v][e] = j + e < n ? beta[j + e] : 0.f; }
+    }
+    float c[RF][NV][4];
+    bool rok[RF];
+#pragma unroll
+    for (int u = 0; u < RF; ++u) {
+        rok[u] = row0 + u < M;
+        const int r = rok[u] ? row0 + u : row0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int j = 4 * (lane + 64 * v);
+            f4u t{0.f, 0.f, 0.f, 0.f};
+            if (okv[v]) t = *reinterpret_cast<const f4u*>(z + (int64_t)r * ldz + j);
+            c[u][v][0] = t.x; c[u][v][1] = j + 1 < n ? t.y : 0.f; c[u][v][2] = j + 2 < n ? t.z : 0.f; c[u][v][3] = j + 3 < n ? t.w : 0.f;
+        }
+    }
+    const float inv_n = 1.0f / (float)n;
+#pragma unroll
+    for (int u = 0; u < RF; ++u) {
+        if (!rok[u]) continue;                             // wave-uniform
+        const int r = row0 + u;
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += c[u][v][e];
+        const float mean = wave_sum(s) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = 4 * (lane + 64 * v) + e < n ? c[u][v][e] - mean : 0.f; q = fmaf(d, d, q); }
+        const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+        if (stats && lane == 0) { stats[r] = mean; stats[M + r] = rstd; }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!imv[v]) continue;
+            const int j = 4 * (lane + 64 * v);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = ln_affine((c[u][v][e] - mean) * rstd, g[v][e], b[v][e]);
+                if (relu) o[e] = fmaxf(o[e], 0.f);
+                if (j + e >= n) o[e] = 0.f;
+            }
+            if (y && okv[v]) {
+                f4u t; t.x = o[0]; t.y = o[1]; t.z = o[2]; t.w = o[3];
+                *reinterpret_cast<f4u*>(y + (int64_t)r * ldy + j) = t;
+            }
+            if (yp3) p3::store4(yp3 + (int64_t)r * ldyp3, j, o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+template <int NV, int RF>
+__global__ void __launch_bounds__(256)
+ln_relu_bwd_gen_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ z, int64_t ldz,
+                       const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                       int relu, float* __restrict__ dz, int64_t lddz, float* __restrict__ partial, int M, int n,
+                       char* __restrict__ dzp3, int64_t ldp3) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [4 waves][3][NV*256]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n16 = (n + 15) & ~15;
+    float gam[NV][4], bet[NV][4], s_dg[NV][4], s_db[NV][4], s_dbias[NV][4];
+    bool okv[NV], imv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int j = 4 * (lane + 64 * v);
+        okv[v] = j < n;
+        imv[v] = j < n16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gam[v][e] = j + e < n ? gamma[j + e] : 1.f;
+            bet[v][e] = j + e < n ? beta[j + e] : 0.f;
+            s_dg[v][e] = s_db[v][e] = s_dbias[v][e] = 0.f;
+        }
+    }
+    const float inv_n = 1.0f / (float)n;
+    const int stride = gridDim.x * 4;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += RF * stride) {
+        float gy[RF][NV][4], zz[RF][NV][4];
+        float mean[RF], rstd[RF];
+        bool rok[RF];
+#pragma unroll
+        for (int u = 0; u < RF; ++u) {
+            const int r = row + u * stride;
+            rok[u] = r < M;
+            const int rc = rok[u] ? r : row;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int j = 4 * (lane + 64 * v);
+                f4u a{0.f, 0.f, 0.f, 0.f}, b{0.f, 0.f, 0.f, 0.f};
+                if (okv[v]) {
+                    a = *reinterpret_cast<const f4u*>(dy + (int64_t)rc * lddy + j);
+                    b = *reinterpret_cast<const f4u*>(z + (int64_t)rc * ldz + j);
+                }
+                gy[u][v][0] = a.x; gy[u][v][1] = a.y; gy[u][v][2] = a.z; gy[u][v][3] = a.w;
+                zz[u][v][0] = b.x; zz[u][v][1] = b.y; zz[u][v][2] = b.z; zz[u][v][3] = b.w;
+            }
+            mean[u] = stats[rc]; rstd[u] = stats[M + rc];
+        }
+#pragma unroll
+        for (int u = 0; u < RF; ++u) {
+            if (!rok[u]) continue;                       // wave-uniform
+            const int64_t r = row + u * stride;
+            float xh[NV][4], g[NV][4];
+            float a = 0.f, b = 0.f;
+            {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = 4 * (lane + 64 * v) + e < n;
+                        xh[v][e] = ok ? (zz[u][v][e] - mean[u]) * rstd[u] : 0.f;
+                        float gv = ok ? gy[u][v][e] : 0.f;
+                        if (relu && fmaf(xh[v][e], gam[v][e], bet[v][e]) <= 0.f) gv = 0.f;
+                        g[v][e] = gv;
+                        const float dxh = gv * gam[v][e];
+                        a = a + dxh;
+                        b = fmaf(dxh, xh[v][e], b);
+                    }
+            }
+            const float c1 = wave_sum(a) * inv_n, c2 = wave_sum(b) * inv_n;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (!imv[v]) continue;
+                const int j = 4 * (lane + 64 * v);
+                float d[4];
+                {
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t0 = g[v][e] * gam[v][e];
+                        const float t1 = xh[v][e] * c2;
+                        d[e] = j + e < n ? rstd[u] * ((t0 - c1) - t1) : 0.f;
+                        s_dg[v][e] = fmaf(g[v][e], xh[v][e], s_dg[v][e]);
+                        s_db[v][e] = s_db[v][e] + g[v][e];
+                        s_dbias[v][e] = s_dbias[v][e] + d[e];
+                    }
+                }
+                if (okv[v]) {
+                    f4u o; o.x = d[0]; o.y = d[1]; o.z = d[2]; o.w = d[3];
+                    *reinterpret_cast<f4u*>(dz + r * lddz + j) = o;
+                }
+                if (dzp3) p3::store4(dzp3 + r * ldp3, j, d[0], d[1], d[2], d[3]);
+            }
+        }
+    }
+    constexpr int W = NV * 256;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * (lane + 64 * v) + e;
+            red[(wave * 3 + 0) * W + j] = s_dg[v][e];
+            red[(wave * 3 + 1) * W + j] = s_db[v][e];
+            red[(wave * 3 + 2) * W + j] = s_dbias[v][e];
+        }
+    __syncthreads();
+    float* pp = partial + (int64_t)blockIdx.x * 3 * n;
+    for (int i = threadIdx.x; i < 3 * W; i += 256) {
+        const int q = i / W, j = i - q * W;
+        if (j < n) pp[q * n + j] = red[(0 * 3 + q) * W + j] + red[(1 * 3 + q) * W + j] + red[(2 * 3 + q) * W + j] +
+                                   red[(3 * 3 + q) * W + j];
+    }
+}
+
 // Rows wider than 1024: same maths, the row is re-read from L1/L2 instead of cached in registers, and
 // the column partials are produced 64 columns at a time.  dz must not alias dy here.
 __global__ void __launch_bounds__(256)
@@ -1727,6 +1916,29 @@ extern "C" int gte_ln_relu_fwd(const float* z, int64_t ldz, const float* gamma, 
     return gte::check_launch("ln_relu_fwd");
 }
 
+// ... any width up to 1024 on PADDED rows (ldz, ldy >= n_out rounded up to 4), y as fp32 (nullable) and / or as a P3 image
+// (nullable): the LayerNorm(+ReLU) of an aggregate-first planes layer, whose output feeds the next layer's planes GEMM
+extern "C" int gte_ln_relu_fwd_p3(const float* z, int64_t ldz, const float* gamma, const float* beta, float eps, int relu,
+                                  float* y, int64_t ldy, void* yp3, int64_t ldyp3, float* stats, int64_t M, int64_t n_out,
+                                  void* stream) {
+    if (M < 0 || n_out <= 0 || M > INT32_MAX || n_out > 1024)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_fwd_p3: bad sizes (n_out <= 1024)");
+    if (M == 0) return GTE_OK;
+    if (!z || !gamma || !beta || (!y && !yp3)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_fwd_p3: null pointer");
+    const int64_t n4 = gte::round_up(n_out, 4);
+    if (ldz < n4 || (y && ldy < n4) || (yp3 && (ldyp3 < p3::row_bytes(n_out) || ldyp3 % 16 != 0)))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_fwd_p3: rows must be padded to a multiple of 4 floats; ldp >= 96 ceil(n_out / 16)");
+    hipStream_t s = gte::as_stream(stream);
+    char* yp = reinterpret_cast<char*>(yp3);
+    const int64_t n16 = gte::round_up(n_out, 16);
+#define GTE_LNF(NV, RF)                                                                                                      \
+    hipLaunchKernelGGL((ln_relu_fwd_gen_kernel<NV, RF>), dim3((unsigned)gte::ceil_div(M, 4 * RF)), dim3(256), 0, s, z, ldz, gamma, beta, \
+                       eps, relu, y, ldy, yp, ldyp3, stats, (int)M, (int)n_out)
+    if (n16 <= 256) GTE_LNF(1, 2); else if (n16 <= 512) GTE_LNF(2, 2); else if (n16 <= 768) GTE_LNF(3, 1); else GTE_LNF(4, 1);
+#undef GTE_LNF
+    return gte::check_launch("ln_relu_fwd_p3");
+}
+
 extern "C" int64_t gte_ln_relu_bwd_workspace_bytes(int64_t M, int64_t n_out) {
     return gte::round_up((int64_t)ln_bwd_blocks(M > 0 ? M : 1) * 3 * (n_out > 0 ? n_out : 1) * 4, 256);
 }
@@ -1757,8 +1969,21 @@ static int ln_relu_bwd_impl(const float* dy, int64_t lddy, const float* z, int64
 #define GTE_LNV(NV)                                                                                                 \
     hipLaunchKernelGGL((ln_relu_bwd_vec_kernel<NV>), grid, block, (size_t)(4 * 3 * NV * 256) * sizeof(float), s, dy, lddy, \
                        zz, ldzz, stats, gamma, beta, relu, dz, lddz, part, (int)M, (int)n_out, dzp3, ldp3)
-    if (dzp3 && !(n_out % 16 == 0 && n_out >= 128 && n_out <= 512 && ldp3 >= p3::row_bytes(n_out) && ldp3 % 16 == 0))
-        return gte::fail(GTE_ERR_UNSUPPORTED, "ln_relu_bwd: the P3 image needs 128 <= n_out <= 512, n_out %% 16 == 0");
+    if (dzp3 && (ldp3 < p3::row_bytes(n_out) || ldp3 % 16 != 0))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "ln_relu_bwd: the P3 image needs ldp >= 96 ceil(n_out / 16)");
+    if (dzp3 && !(n_out % 16 == 0 && n_out >= 128 && n_out <= 512)) {
+        // any other width up to 1024 with the image: padded rows (ld >= n_out rounded up to 4), LayerNorm layers only
+        const int64_t n4 = gte::round_up(n_out, 4);
+        if (!gamma || n_out > 1024 || lddy < n4 || ldzz < n4 || lddz < n4)
+            return gte::fail(GTE_ERR_UNSUPPORTED, "ln_relu_bwd: the P3 image at this width needs LayerNorm, n_out <= 1024 and rows padded "
+                                                  "to a multiple of 4 floats");
+#define GTE_LNG(NV, RF)                                                                                                  \
+    hipLaunchKernelGGL((ln_relu_bwd_gen_kernel<NV, RF>), grid, block, (size_t)(4 * 3 * NV * 256) * sizeof(float), s, dy, lddy, \
+                       zz, ldzz, stats, gamma, beta, relu, dz, lddz, part, (int)M, (int)n_out, dzp3, ldp3)
+        const int64_t n16 = gte::round_up(n_out, 16);
+        if (n16 <= 256) GTE_LNG(1, 2); else if (n16 <= 512) GTE_LNG(2, 2); else if (n16 <= 768) GTE_LNG(3, 1); else GTE_LNG(4, 1);
+#undef GTE_LNG
+    } else
     if (n_out % 4 == 0 && n_out >= 128 && n_out <= 512) {              // 16-byte accesses
         if (n_out <= 256) GTE_LNV(1); else GTE_LNV(2);
     } else

@@ -85,6 +85,8 @@ struct LnEpilogue {
     const float* gamma; const float* beta; float eps; int relu;
     float* y; int64_t ldy; float* stats;                 // stats[row] = mean, stats[n_rows + row] = rstd
     char* yp3; int64_t ldyp3;                            // optional P3 image of y (csrc/p3.h) for the next layer's planes GEMM
+    int n_true;                                          // LayerNorm width: the kernel processes n_feat >= n_true columns (the rows are
+                                                         // padded to a multiple of 4 / 16 floats), columns >= n_true are written as zeros
 };
 
 template <int G>
@@ -191,6 +193,15 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                 }
             }
 
+            // P3 output of a width that is not a multiple of 4: the (< 4) tail elements sit one per lane on the first lanes of the
+            // group; lane 0 collects them into the row's last quarter block (lanes >= rem hold tail = 0)
+            float tq[3] = {0.f, 0.f, 0.f};
+            if constexpr (std::is_same<T, F32>::value && !ACCUM && !LNE) {
+                if (outp3 && cb == 0) {
+                    const float ts = tail * scale;
+                    tq[0] = __shfl(ts, 0, G); tq[1] = __shfl(ts, 1, G); tq[2] = __shfl(ts, 2, G);
+                }
+            }
             if (row_ok) {
                 elem* orow = out + (int64_t)r * ldo;
 #pragma unroll
@@ -202,6 +213,10 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                             T::load(orow + (int64_t)c * EPC, o);
 #pragma unroll
                             for (int q = 0; q < EPC; ++q) o[q] += acc[j][q] * scale;
+                            if constexpr (LNE) {             // columns past the LayerNorm width are padding: zero
+#pragma unroll
+                                for (int q = 0; q < EPC; ++q) if (c * EPC + q >= ln.n_true) o[q] = 0.f;
+                            }
                         } else {
 #pragma unroll
                             for (int q = 0; q < EPC; ++q) o[q] = acc[j][q] * scale;
@@ -222,32 +237,56 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                         for (int q = 0; q < EPC; ++q) acc[j][q] = 0.f;
                     }
                 }
-                if constexpr (LNE) {                         // CPL == 1, rem == 0, nchunk <= G: acc[0] is this lane's z chunk
-                    const bool have = li < nchunk;
+                if constexpr (LNE) {                         // rem == 0, nchunk <= G * CPL: acc[j] are this lane's z chunks (padding = 0)
+                    const int nt = ln.n_true;
                     float sm = 0.f;
 #pragma unroll
-                    for (int q = 0; q < EPC; ++q) sm += acc[0][q];
-                    const float mean = group_sum<G>(sm) / (float)n_feat;
+                    for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                        for (int q = 0; q < EPC; ++q) sm += acc[j][q];
+                    const float mean = group_sum<G>(sm) / (float)nt;
                     float sq = 0.f;
 #pragma unroll
-                    for (int q = 0; q < EPC; ++q) { const float d = have ? acc[0][q] - mean : 0.f; sq = fmaf(d, d, sq); }
-                    const float rstd = rsqrtf(group_sum<G>(sq) / (float)n_feat + ln.eps);
-                    if (have) {
-                        float yv[EPC];
+                    for (int j = 0; j < CPL; ++j)
 #pragma unroll
                         for (int q = 0; q < EPC; ++q) {
-                            const int col = li * EPC + q;
-                            float v = fmaf((acc[0][q] - mean) * rstd, ln.gamma[col], ln.beta[col]);
-                            yv[q] = ln.relu ? fmaxf(v, 0.f) : v;
+                            const float d = ((li + j * G) * EPC + q < nt) ? acc[j][q] - mean : 0.f;
+                            sq = fmaf(d, d, sq);
                         }
-                        if (ln.y) F32::store(ln.y + (int64_t)r * ln.ldy + (int64_t)li * EPC, yv);
-                        if constexpr (EPC == 4) {
-                            if (ln.yp3) p3::store4(ln.yp3 + (int64_t)r * ln.ldyp3, li * 4, yv[0], yv[1], yv[2], yv[3]);
+                    const float rstd = rsqrtf(group_sum<G>(sq) / (float)nt + ln.eps);
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const int c = li + j * G;
+                        if (c < nchunk) {
+                            float yv[EPC];
+#pragma unroll
+                            for (int q = 0; q < EPC; ++q) {
+                                const int col = c * EPC + q;
+                                const bool ok = col < nt;
+                                float v = fmaf((acc[j][q] - mean) * rstd, ok ? ln.gamma[col] : 0.f, ok ? ln.beta[col] : 0.f);
+                                v = ln.relu ? fmaxf(v, 0.f) : v;
+                                yv[q] = ok ? v : 0.f;
+                            }
+                            if (ln.y) F32::store(ln.y + (int64_t)r * ln.ldy + (int64_t)c * EPC, yv);
+                            if constexpr (EPC == 4) {
+                                if (ln.yp3) p3::store4(ln.yp3 + (int64_t)r * ln.ldyp3, c * 4, yv[0], yv[1], yv[2], yv[3]);
+                            }
                         }
                     }
                     if (li == 0 && ln.stats) { ln.stats[r] = mean; ln.stats[n_rows + r] = rstd; }
                 }
-                if (do_tail) {
+                if constexpr (std::is_same<T, F32>::value && !ACCUM && !LNE) {
+                    // P3 output: the quarter blocks past the last full chunk up to the image's 16-column block boundary -- the
+                    // tail elements (lane 0) and zeros
+                    if (outp3 && cb == 0 && li < 4) {
+                        const int qi = nchunk + li;
+                        if (qi * 4 < (int)p3::blocks(n_feat) * p3::BLOCK) {
+                            const bool t = li == 0 && rem > 0;
+                            p3::store4(outp3 + (int64_t)r * ldp3, qi * 4, t ? tq[0] : 0.f, t ? tq[1] : 0.f, t ? tq[2] : 0.f, 0.f);
+                        }
+                    }
+                }
+                if (do_tail && !(std::is_same<T, F32>::value && !ACCUM && !LNE && outp3)) {
                     float o = tail * scale;
                     if constexpr (ACCUM) o += T::to_f32(orow[tail_off]);
                     orow[tail_off] = T::from_f32(o);
@@ -296,14 +335,14 @@ int dispatch(const int32_t* indptr, const int32_t* indices, const float* ew, con
 #undef GTE_L
 }
 
-template <int G>
+template <int G, int CPL = 1>
 int launch_ln(const int32_t* indptr, const int32_t* indices, const float* ew, const float* x, int64_t ldx, float* out,
               int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, const LnEpilogue& ln, hipStream_t s) {
     constexpr int RPW = gte::kWave / G;
     int passes = 4;
     while (passes > 1 && gte::ceil_div(n_rows, (int64_t)4 * RPW * passes) < (int64_t)16 * gte::device_props().cus) passes /= 2;
     const int rows_per_block = 4 * RPW * passes;
-    hipLaunchKernelGGL((spmm_csr_kernel<F32, G, 1, true, true>), dim3((unsigned)gte::ceil_div(n_rows, rows_per_block)), dim3(256), 0,
+    hipLaunchKernelGGL((spmm_csr_kernel<F32, G, CPL, true, true>), dim3((unsigned)gte::ceil_div(n_rows, rows_per_block)), dim3(256), 0,
                        s, indptr, indices, ew, x, ldx, out, ldo, (int)n_rows, (int)n_feat, reduce, rows_per_block, ln);
     return gte::check_launch("spmm_csr_accumulate_ln");
 }
@@ -345,12 +384,11 @@ extern "C" int gte_spmm_csr_accumulate(const int32_t* indptr, const int32_t* ind
 }
 
 // out (P3 image, csrc/p3.h) = scale_v * sum w x[u]: the aggregation whose result only feeds planes GEMMs (q = A_w^T (norm dz), the
-// aggregated input of an aggregate-first layer).  n_feat % 4 == 0; columns up to the next multiple of 16 must be zero in the
-// image already or are written as zero here when n_feat % 16 != 0 is not supported: n_feat % 16 == 0 required.
+// aggregated input of an aggregate-first layer).  Any n_feat: the image columns from n_feat up to the next multiple of 16 are
+// written as zeros.
 extern "C" int gte_spmm_csr_p3(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x, int64_t ldx,
                                void* outp3, int64_t ldp, int64_t n_rows, int64_t n_feat, int reduce, void* stream) {
     if (n_rows < 0 || n_feat <= 0 || n_rows > INT32_MAX || n_feat > INT32_MAX) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_p3: bad sizes");
-    if (n_feat % 16 != 0) return gte::fail(GTE_ERR_UNSUPPORTED, "spmm_csr_p3: n_feat must be a multiple of 16");
     if (n_rows == 0) return GTE_OK;
     if (!indptr || !x || !outp3) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_p3: null pointer");
     if (ldx < n_feat || ldp < p3::row_bytes(n_feat) || ldp % 16 != 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_p3: leading dimension too small");
@@ -360,8 +398,11 @@ extern "C" int gte_spmm_csr_p3(const int32_t* indptr, const int32_t* indices, co
                                 gte::as_stream(stream), reinterpret_cast<char*>(outp3), ldp);
 }
 
+// Widths the fused aggregation + LayerNorm kernel covers: any n_feat up to 1024 (a row lives in the registers of one lane group).
+// n_feat % 4 != 0 (or, with a P3 image of y, n_feat % 16 != 0) needs PADDED rows: x, z and y allocated to the next multiple of
+// 4 (16) floats per row (ld >= that); the padding of x is read (zeros), the padding of z / y / the image is written as zeros.
 extern "C" int gte_spmm_csr_accumulate_ln_supported(int64_t n_feat) {
-    return (n_feat >= 4 && n_feat % 4 == 0 && n_feat <= 256) ? 1 : 0;
+    return (n_feat >= 1 && n_feat <= 1024) ? 1 : 0;
 }
 
 static int accumulate_ln_impl(const int32_t* indptr, const int32_t* indices, const float* eweight,
@@ -370,24 +411,29 @@ static int accumulate_ln_impl(const int32_t* indptr, const int32_t* indices, con
                               int relu, float* y, int64_t ldy, float* stats, void* yp3, int64_t ldyp3, void* stream) {
     if (n_rows < 0 || n_rows > INT32_MAX) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: bad n_rows");
     if (!gte_spmm_csr_accumulate_ln_supported(n_feat))
-        return gte::fail(GTE_ERR_UNSUPPORTED, "spmm_csr_accumulate_ln: needs n_feat %% 4 == 0 and n_feat <= 256");
+        return gte::fail(GTE_ERR_UNSUPPORTED, "spmm_csr_accumulate_ln: needs 1 <= n_feat <= 1024");
     if (n_rows == 0) return GTE_OK;
     if (!indptr || !x || !z || !gamma || !beta || (!y && !yp3)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: null pointer");
-    if (ldx < n_feat || ldz < n_feat || (y && ldy < n_feat)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: ld < n_feat");
-    if (yp3 && (n_feat % 16 != 0 || ldyp3 < p3::row_bytes(n_feat) || ldyp3 % 16 != 0))
-        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: the P3 image needs n_feat %% 16 == 0 and ldp >= 96 n_feat / 16");
+    // columns processed: the rows' padded width (a multiple of 4; of 16 when the image is written)
+    const int64_t np = yp3 ? gte::round_up(n_feat, 16) : gte::round_up(n_feat, 4);
+    if (ldx < np || ldz < np || (y && ldy < np))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: ld < n_feat rounded up to %d (padded rows)", yp3 ? 16 : 4);
+    if (yp3 && (ldyp3 < p3::row_bytes(n_feat) || ldyp3 % 16 != 0))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: the P3 image needs ldp >= 96 ceil(n_feat / 16)");
     if (reduce != GTE_REDUCE_SUM && reduce != GTE_REDUCE_MEAN)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_accumulate_ln: reduce must be 0 (sum) or 1 (mean)");
-    const LnEpilogue ln = {gamma, beta, eps, relu, y, ldy, stats, reinterpret_cast<char*>(yp3), ldyp3};
+    const LnEpilogue ln = {gamma, beta, eps, relu, y, ldy, stats, reinterpret_cast<char*>(yp3), ldyp3, (int)n_feat};
     hipStream_t s = gte::as_stream(stream);
-    const int64_t nchunk = n_feat / 4;
-#define GTE_LN(G) return launch_ln<G>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, n_feat, reduce, ln, s)
+    const int64_t nchunk = np / 4;
+#define GTE_LN(G) return launch_ln<G>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, np, reduce, ln, s)
     if (nchunk <= 4) GTE_LN(4);
     if (nchunk <= 8) GTE_LN(8);
     if (nchunk <= 16) GTE_LN(16);
     if (nchunk <= 32) GTE_LN(32);
-    GTE_LN(64);
+    if (nchunk <= 64) GTE_LN(64);
 #undef GTE_LN
+    if (nchunk <= 128) return launch_ln<64, 2>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, np, reduce, ln, s);
+    return launch_ln<64, 4>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, np, reduce, ln, s);
 }
 
 extern "C" int gte_spmm_csr_accumulate_ln(const int32_t* indptr, const int32_t* indices, const float* eweight,

@@ -15,13 +15,21 @@ namespace {
         if (rc_ != GTE_OK) return rc_; \
     } while (0)
 
-// weight images + the hidden layers (the output layer's input is p.h_out afterwards)
+// leading dimension (floats) of a layer's fp32 row buffers: fout rounded up to 16 (0 in the plan = fout itself)
+inline int64_t ldf(const gte_step_layer& L) { return L.ldf > 0 ? L.ldf : L.fout; }
+inline int64_t ld_lg(const gte_step_plan& p) { return p.ld_lg > 0 ? p.ld_lg : p.n_classes; }
+
+// weight images + the hidden layers (the output layer's input is p.h_out / p.hp_out afterwards)
 int forward_hidden(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes;
-    if (p.n_wimg_descs > 0 && !p.wimg_fresh)
-        GTE_TRY(gte_p3_from_f32_batch(reinterpret_cast<const gte_p3_desc*>(p.wimg_descs), p.n_wimg_descs, st));
+    if (p.n_wimg_descs > 0 && !p.wimg_fresh) {
+        const gte_p3_desc* d = reinterpret_cast<const gte_p3_desc*>(p.wimg_descs);
+        for (int k = 0; k < p.n_wimg_descs; k += 16)
+            GTE_TRY(gte_p3_from_f32_batch(d + k, p.n_wimg_descs - k < 16 ? p.n_wimg_descs - k : 16, st));
+    }
     for (int i = 0; i < p.n_hidden; ++i) {
         const gte_step_layer& L = p.layer[i];
+        const int64_t ld = ldf(L);
         if (L.kind == GTE_LAYER_SMALLK) {
             GTE_TRY(gte_spmm_csr(p.indptr, p.indices, p.w_in, L.x, L.ldx, L.ahn, L.fin, n, L.fin, GTE_F32, GTE_REDUCE_MEAN, st));
             // (the one-pass backward recomputes z from the 2 fin inputs per row: nothing to save)
@@ -34,26 +42,51 @@ int forward_hidden(const gte_step_plan& p, void* st) {
                                             L.fout, L.stats, L.y, L.fout, n, L.fout, st));
             continue;
         }
+        if (L.kind == GTE_LAYER_AGGFIRST) {
+            // z = [x | mean-aggregate(x)] W^T + b on the planes GEMM (two K segments), then LayerNorm + ReLU: the input layer of a
+            // model whose hidden width exceeds its input width (aggregating fin columns is the cheaper order, models.py:53-72)
+            GTE_TRY(gte_p3_from_f32(L.x, L.ldx, n, L.fin, 0, L.hp, L.ldp_h, st));
+            GTE_TRY(gte_spmm_csr_p3(p.indptr, p.indices, p.w_in, L.x, L.ldx, L.ahnp, L.ldp_ahn, n, L.fin, GTE_REDUCE_MEAN, st));
+            GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, L.ahnp, L.ldp_ahn, L.fin, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, ld, n, L.fout,
+                                   0, 0, st));
+            GTE_TRY(gte_ln_relu_fwd_p3(L.t, ld, L.gamma, L.beta, L.eps, L.relu, L.y, ld, L.yp, L.ldp_y, L.stats, n, L.fout, st));
+            continue;
+        }
         if (L.make_hp) GTE_TRY(gte_p3_from_f32(L.x, L.ldx, n, L.fin, 0, L.hp, L.ldp_h, st));
+        // t = [t_self | t_neigh], each half ld columns wide (the weight image holds zero rows behind the fout rows of a half)
         if (L.h_rows)
-            GTE_TRY(gte_gemm_p3_nt_rows(L.hp, L.ldp_h, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * L.fout,
-                                        n, 2 * L.fout, 0, 0, st));
+            GTE_TRY(gte_gemm_p3_nt_rows(L.hp, L.ldp_h, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * ld,
+                                        n, 2 * ld, 0, 0, st));
         else
-            GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, nullptr, 0, 0, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * L.fout, n,
-                                   2 * L.fout, 0, 0, st));
-        GTE_TRY(gte_spmm_csr_accumulate_ln_p3(p.indptr, p.indices, p.w_in, L.t + L.fout, 2 * L.fout, L.t, 2 * L.fout, n, L.fout,
-                                              GTE_REDUCE_MEAN, L.gamma, L.beta, L.eps, L.relu, L.y, L.fout, L.yp, L.ldp_y, L.stats, st));
+            GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, nullptr, 0, 0, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * ld, n,
+                                   2 * ld, 0, 0, st));
+        GTE_TRY(gte_spmm_csr_accumulate_ln_p3(p.indptr, p.indices, p.w_in, L.t + ld, 2 * ld, L.t, 2 * ld, n, L.fout,
+                                              GTE_REDUCE_MEAN, L.gamma, L.beta, L.eps, L.relu, L.y, ld, L.yp, L.ldp_y, L.stats, st));
     }
     return GTE_OK;
+}
+
+// the output layer's two products: logits' = h W_s^T + b, t_neigh = h W_n^T
+int forward_out_products(const gte_step_plan& p, void* st) {
+    const int64_t n = p.n_nodes, C = p.n_classes, lg = ld_lg(p);
+    if (p.out_gemm)            // hidden widths the narrow kernels do not cover: one planes GEMM with N = 32 (rows 0.. = W_s, 16.. = W_n)
+        return gte_gemm_p3_nt(p.hp_out, p.ldp_hout, p.out_fin, nullptr, 0, 0, p.wimg_out_fwd, p.ldp_wout_fwd, p.b_out, C, p.logits, lg, n,
+                              32, 0, 0, st);
+    return gte_sage_narrow_fwd(p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, p.b_out, C, p.logits, lg, p.tn, lg, n, st);
 }
 
 int forward(const gte_step_plan& p, void* st) {
     const int64_t n = p.n_nodes;
     GTE_TRY(forward_hidden(p, st));
-    const int64_t C = p.n_classes;
-    GTE_TRY(gte_sage_narrow_fwd(p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, p.b_out, C, p.logits, C, p.tn, C, n, st));
-    GTE_TRY(gte_head_agg_ce(p.indptr, p.indices, p.w_in, p.tn, C, p.logits, C, p.labels, p.labels_f32, p.class_weights, n, C,
-                            GTE_REDUCE_MEAN, p.dl, C, p.ce_part, p.ce_part_bytes, st));
+    const int64_t C = p.n_classes, lg = ld_lg(p);
+    GTE_TRY(forward_out_products(p, st));
+    if (p.out_gemm) {
+        GTE_TRY(gte_spmm_csr_accumulate(p.indptr, p.indices, p.w_in, p.tn, lg, p.logits, lg, n, C, GTE_F32, GTE_REDUCE_MEAN, st));
+        return gte_weighted_ce(p.logits, lg, p.labels, p.labels_f32, p.class_weights, n, (int)C, p.grad_scale, p.dl, lg, p.out3, p.ws_ce,
+                               p.ws_ce_bytes, st);
+    }
+    GTE_TRY(gte_head_agg_ce(p.indptr, p.indices, p.w_in, p.tn, lg, p.logits, lg, p.labels, p.labels_f32, p.class_weights, n, C,
+                            GTE_REDUCE_MEAN, p.dl, lg, p.ce_part, p.ce_part_bytes, st));
     return GTE_OK;
 }
 
@@ -63,31 +96,46 @@ bool smallk_in_dx(const gte_step_plan& p) {
     const gte_step_layer& B = p.layer[0];
     const gte_step_layer& L = p.layer[1];
     return B.kind == GTE_LAYER_SMALLK && L.kind == GTE_LAYER_PLANES && gte_sage_smallk_bwd_supported(2 * B.fin, B.fout) &&
-           gte_gemm_p3_nt_smallk_bwd_supported(2 * B.fin, L.fin);
+           gte_gemm_p3_nt_smallk_bwd_supported(2 * B.fin, L.fin) && ldf(B) == B.fout;
 }
+
+// z of a hidden layer (the operand of its LayerNorm backward) and its leading dimension
+inline const float* z_of(const gte_step_layer& L) { return L.t; }
+inline int64_t ldz_of(const gte_step_layer& L) { return L.kind == GTE_LAYER_PLANES ? 2 * ldf(L) : ldf(L); }
 
 // backward of the output layer and of hidden layers n_hidden - 1 .. 1, and of layer 0 up to its weight-gradient GEMM
 int backward_a(const gte_step_plan& p, void* st) {
-    const int64_t n = p.n_nodes, C = p.n_classes;
+    const int64_t n = p.n_nodes, C = p.n_classes, lg = ld_lg(p);
     bool ln_done = false, smallk_done = false;
     const gte_step_layer& T = p.layer[p.n_hidden - 1];
-    if ((p.fuse_ln_dx & 2) && T.kind == GTE_LAYER_PLANES && T.fout % 16 == 0 && gte_head_supported(p.out_fin, C)) {
+    if (p.out_gemm) {
+        // q = A_w^T (norm dl); dl and q as ONE image [n][32] (dl in block 0, q in block 1); dW_out = [dl^T h | q^T h] (two column
+        // segments of one TN launch, M = n_classes), dbias = colsum(dl), dh = [dl | q] [W_s^T | W_n^T] (K = 32)
+        GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, lg, p.q_out, lg, n, C, GTE_F32, GTE_REDUCE_SUM, st));
+        GTE_TRY(gte_p3_from_f32(p.dl, lg, n, 32, 0, p.dlqp, p.ldp_dlq, st));
+        GTE_TRY(gte_colsum(p.dl, lg, n, C, p.gb_out, p.ws_cs, p.ws_cs_bytes, st));
+        GTE_TRY(gte_gemm_p3_tn(p.dlqp, p.ldp_dlq, static_cast<const char*>(p.dlqp) + 96, p.ldp_dlq, p.hp_out, p.ldp_hout, nullptr, 0,
+                               p.out_fin, p.gW_out, 2 * p.out_fin, C, 2 * p.out_fin, n, p.ws_out, p.ws_out_bytes, st));
+        GTE_TRY(gte_gemm_p3_nt(p.dlqp, p.ldp_dlq, 32, nullptr, 0, 0, p.wimg_out_bwd, p.ldp_wout_bwd, nullptr, 0, p.dh_out, p.ld_h_out, n,
+                               p.out_fin, 0, 0, st));
+    } else if ((p.fuse_ln_dx & 2) && T.kind == GTE_LAYER_PLANES && T.fout % 16 == 0 && gte_head_supported(p.out_fin, C)) {
         // the output layer's backward forms q = A_w^T (norm dl) itself (p.fuse_ln_dx & 4) and runs the LayerNorm(+ReLU) backward of
         // the last hidden layer on the dh tile of every row block
         const bool own_q = (p.fuse_ln_dx & 4) != 0;
         if (!own_q) GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
         GTE_TRY(gte_sage_narrow_bwd_ln_p3(p.dl, C, own_q ? nullptr : p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C,
-                                          p.dh_out, p.out_fin, T.dzp, T.ldp_o, p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes,
-                                          p.ce_part, p.grad_scale, p.out3, T.t, 2 * T.fout, T.stats, T.gamma, T.beta, T.relu, T.ggamma,
+                                          p.dh_out, p.ld_h_out, T.dzp, T.ldp_o, p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes,
+                                          p.ce_part, p.grad_scale, p.out3, T.t, 2 * ldf(T), T.stats, T.gamma, T.beta, T.relu, T.ggamma,
                                           T.gbeta, T.gbias, T.ws_ln, T.ws_ln_bytes, p.rindptr, p.rindices, p.w_out, st));
         ln_done = true;
     } else {
         GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
-        GTE_TRY(gte_sage_narrow_bwd_ce(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C, p.dh_out, p.out_fin,
+        GTE_TRY(gte_sage_narrow_bwd_ce(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C, p.dh_out, p.ld_h_out,
                                        p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes, p.ce_part, p.grad_scale, p.out3, st));
     }
     for (int i = p.n_hidden - 1; i >= 0; --i) {
         const gte_step_layer& L = p.layer[i];
+        const int64_t ld = ldf(L);
         if (L.kind == GTE_LAYER_SMALLK) {
             if (smallk_done) continue;
             if (!gte_sage_smallk_bwd_supported(2 * L.fin, L.fout))
@@ -96,10 +144,11 @@ int backward_a(const gte_step_plan& p, void* st) {
             continue;                                  // (layer 0: its dW -- or its whole one-pass backward -- is phase 2)
         }
         if (!ln_done)          // (else: the dX launch of the layer above ran this layer's LayerNorm backward as its epilogue)
-            GTE_TRY(gte_ln_relu_bwd_p3(L.dy, L.fout, L.t, 2 * L.fout, L.stats, L.gamma, L.beta, L.relu, L.dy, L.fout, L.dzp, L.ldp_o, L.ggamma,
+            GTE_TRY(gte_ln_relu_bwd_p3(L.dy, ld, z_of(L), ldz_of(L), L.stats, L.gamma, L.beta, L.relu, L.dy, ld, L.dzp, L.ldp_o, L.ggamma,
                                        L.gbeta, L.gbias, n, L.fout, L.ws_ln, L.ws_ln_bytes, st));
         ln_done = false;
-        GTE_TRY(gte_spmm_csr_p3(p.rindptr, p.rindices, p.w_out, L.dy, L.fout, L.qp, L.ldp_o, n, L.fout, GTE_REDUCE_SUM, st));
+        if (L.kind == GTE_LAYER_AGGFIRST) break;       // (layer 0: dW = dz^T [x | ahn] is the step's last GEMM: phase 2)
+        GTE_TRY(gte_spmm_csr_p3(p.rindptr, p.rindices, p.w_out, L.dy, ld, L.qp, L.ldp_o, n, L.fout, GTE_REDUCE_SUM, st));
         if (i == 0) break;                             // layer 0's dW is the step's last GEMM: phase 2
         GTE_TRY(gte_gemm_p3_tn(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, nullptr, 0, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n, L.ws_dw,
                                L.ws_dw_bytes, st));
@@ -109,14 +158,14 @@ int backward_a(const gte_step_plan& p, void* st) {
             // queues the next batch's assembly in front of it, as in front of a planes layer 0's dW)
             smallk_done = true;
             break;
-        } else if ((p.fuse_ln_dx & 1) && B.kind == GTE_LAYER_PLANES && gte_gemm_p3_nt_ln_bwd_supported(L.fin)) {
-            GTE_TRY(gte_gemm_p3_nt_ln_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, B.t, 2 * B.fout, B.stats, B.gamma,
-                                          B.beta, B.relu, B.dy, B.fout, B.dzp, B.ldp_o, B.ggamma, B.gbeta, B.gbias, n, L.fin, B.ws_ln,
+        } else if ((p.fuse_ln_dx & 1) && B.kind != GTE_LAYER_SMALLK && L.fin % 16 == 0 && gte_gemm_p3_nt_ln_bwd_supported(L.fin)) {
+            GTE_TRY(gte_gemm_p3_nt_ln_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, z_of(B), ldz_of(B), B.stats,
+                                          B.gamma, B.beta, B.relu, B.dy, ldf(B), B.dzp, B.ldp_o, B.ggamma, B.gbeta, B.gbias, n, L.fin, B.ws_ln,
                                           B.ws_ln_bytes, st));
             ln_done = true;
         } else {
-            GTE_TRY(gte_gemm_p3_nt(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, nullptr, 0, B.dy, L.fin, n, L.fin, 0, 0,
-                                   st));
+            GTE_TRY(gte_gemm_p3_nt(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, nullptr, 0, B.dy, ldf(B), n, L.fin, 0,
+                                   0, st));
         }
     }
     return GTE_OK;
@@ -136,6 +185,9 @@ int backward_b(const gte_step_plan& p, void* st) {
                                    L.relu, L.gW, 2 * L.fin, L.gbias, L.ggamma, L.gbeta, n, L.fout, L.ws_dw, L.ws_dw_bytes, st);
     if (L.kind == GTE_LAYER_SMALLK)
         return gte_sage_linear_dw(L.dy, L.fout, L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.gW, 2 * L.fin, L.fout, n, L.ws_dw, L.ws_dw_bytes, st);
+    if (L.kind == GTE_LAYER_AGGFIRST)                  // dW = [dz^T x | dz^T ahn]
+        return gte_gemm_p3_tn(L.dzp, L.ldp_o, nullptr, 0, L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n,
+                              L.ws_dw, L.ws_dw_bytes, st);
     if (L.h_rows)
         return gte_gemm_p3_tn_rows(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, L.h_rows, L.n_res_rows, L.fin, L.gW, 2 * L.fin, L.fout,
                                    2 * L.fin, n, L.ws_dw, L.ws_dw_bytes, st);
@@ -161,10 +213,17 @@ int check_plan(const gte_step_plan& p) {
     if (p.n_hidden < 1 || p.n_hidden > 7 || p.n_nodes < 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: bad plan");
     for (int i = 0; i < p.n_hidden; ++i) {
         const gte_step_layer& L = p.layer[i];
-        if (L.kind != GTE_LAYER_PLANES && L.kind != GTE_LAYER_SMALLK) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: layer kind");
-        if (L.kind == GTE_LAYER_SMALLK && i != 0) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: a short-input layer must be layer 0");
+        if (L.kind != GTE_LAYER_PLANES && L.kind != GTE_LAYER_SMALLK && L.kind != GTE_LAYER_AGGFIRST)
+            return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: layer kind");
+        if (L.kind != GTE_LAYER_PLANES && i != 0)
+            return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: a short-input / aggregate-first layer must be layer 0");
         if (!L.gamma || !L.beta || !L.bias) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: hidden layers need bias and LayerNorm");
+        if (L.ldf != 0 && (L.ldf < L.fout || L.ldf % 4 != 0)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: ldf < fout or not a multiple of 4");
+        if (L.kind == GTE_LAYER_SMALLK && ldf(L) != L.fout) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: a short-input layer takes unpadded rows");
     }
+    if (p.out_gemm && (p.n_classes > 16 || ld_lg(p) != 32 || !p.hp_out || !p.wimg_out_fwd || !p.wimg_out_bwd || !p.dlqp || p.tn != p.logits + 16 ||
+                       p.q_out != p.dl + 16))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: the GEMM output layer needs n_classes <= 16, [n][32] logits / dl buffers and its images");
     if (p.n_nodes == 0) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: empty batch");
     return GTE_OK;
 }
@@ -205,8 +264,9 @@ extern "C" int gte_gcnsage_forward(const gte_step_plan* plan, void* stream) {
     const int64_t n = p.n_nodes, C = p.n_classes;
     int rc = forward_hidden(p, stream);
     // logits = h W_s^T + b + mean-aggregate(h W_n^T): the class-count-wide aggregation the step runs inside its loss kernel
-    if (rc == GTE_OK) rc = gte_sage_narrow_fwd(p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, p.b_out, C, p.logits, C, p.tn, C, n, stream);
-    if (rc == GTE_OK) rc = gte_spmm_csr_accumulate(p.indptr, p.indices, p.w_in, p.tn, C, p.logits, C, n, C, GTE_F32, GTE_REDUCE_MEAN, stream);
+    if (rc == GTE_OK) rc = forward_out_products(p, stream);
+    if (rc == GTE_OK)
+        rc = gte_spmm_csr_accumulate(p.indptr, p.indices, p.w_in, p.tn, ld_lg(p), p.logits, ld_lg(p), n, C, GTE_F32, GTE_REDUCE_MEAN, stream);
     (void)gte_gemm_set_tail_workspace(nullptr, 0);
     return rc;
 }

@@ -106,6 +106,10 @@ from ..components.graphs.models import GcnSAGE, _is_relu               # noqa: E
 import torch.nn as nn                                                  # noqa: E402
 
 
+def _c16(x: int) -> int:
+    return -(-int(x) // 16) * 16
+
+
 class FusedGcnSageStep(TrainStep):
     """The same optimisation step as :class:`TrainStep` for a :class:`GcnSAGE` model, scheduled by hand:
 
@@ -190,6 +194,9 @@ class FusedGcnSageStep(TrainStep):
         # planes path (GTE_PLANES=0 disables): in the split-bf16 GEMM mode the operands of the transform GEMMs are written as P3
         # images (three bf16 planes, csrc/p3.h) by their producers and multiplied by the planes GEMMs (csrc/gemm_p3.hip)
         self.use_planes = os.environ.get("GTE_PLANES", "1") == "1"
+        # ... for EVERY hidden width up to 1024 and any input width through the one-call plan (padded rows, masked LayerNorm
+        # kernels, aggregate-first input layer, output layer on the planes GEMMs); GTE_PLANES_GENERAL=0: the tuned range only
+        self.general_planes = os.environ.get("GTE_PLANES_GENERAL", "1") == "1"
         self._wimg = {}                               # layer index -> (forward image, backward image or None)
         # one-call step: the fold + Adam launch also writes the weight images of the updated parameters
         # (gte_fold_defer_flush_adam_images) and the next step's forward skips their conversion launch.  _wimg_sig = the version
@@ -256,12 +263,86 @@ class FusedGcnSageStep(TrainStep):
         b["ws_nar"] = torch.empty(int(lib.gte_sage_narrow_bwd_workspace_bytes(cap, min(dims[-2], 256), min(dims[-1], 16))),
                                   dtype=torch.uint8, device=dev)
         # one private workspace per layer for the dW GEMMs: they run on the side stream, several at once
-        b["ws_dw"] = [torch.empty(int(max(lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], cap),
-                                          lib.gte_sage_qform_dw_workspace_bytes(dims[i + 1], dims[i], cap),
-                                          lib.gte_sage_smallk_bwd_workspace_bytes(cap, 2 * dims[i], dims[i + 1]) if i == 0 else 0,
-                                          lib.gte_gemm_p3_nt_smallk_bwd_workspace_bytes(cap, 2 * dims[i], dims[i + 1]) if i == 0 else 0)),
-                                  dtype=torch.uint8, device=dev) for i in range(len(layers))]
+        b["ws_dw"] = [torch.empty(int(self._ws_dw_bytes(i, dims, cap)), dtype=torch.uint8, device=dev) for i in range(len(layers))]
         return b
+
+    def _ws_dw_bytes(self, i: int, dims, cap: int) -> int:
+        """Workspace of layer i's weight-gradient launch: split-K slabs of the dW GEMM; for the input layer additionally the
+        partials of the one-pass short-input backward -- only where that path exists (k1 + k2 <= 28: at F0 = 831 the size
+        functions, which do not check support, would ask for 764 + 382 MB per buffer set)."""
+        lib = self.lib
+        need = [lib.gte_sage_linear_dw_workspace_bytes(dims[i + 1], dims[i], dims[i], cap),
+                lib.gte_sage_qform_dw_workspace_bytes(dims[i + 1], dims[i], cap)]
+        if i == 0 and lib.gte_sage_smallk_bwd_supported(2 * dims[0], dims[1]):
+            need.append(lib.gte_sage_smallk_bwd_workspace_bytes(cap, 2 * dims[0], dims[1]))
+        if i == 0 and len(dims) > 2 and lib.gte_gemm_p3_nt_smallk_bwd_supported(2 * dims[0], dims[1]):
+            need.append(lib.gte_gemm_p3_nt_smallk_bwd_workspace_bytes(cap, 2 * dims[0], dims[1]))
+        return max(need)
+
+    # -- buffers of the one-call plan on general widths (padded rows) ----------------------------------
+    def _alloc_gen(self, cap: int, f0: int, kinds, out_gemm: bool):
+        """Buffer set of a one-call plan whose layers are not all in the tuned range (128 <= hidden <= 256, hidden % 16 == 0):
+        the fp32 row buffers of a hidden layer are PADDED to ld = hidden rounded up to 16 floats (include/gte.h, gte_step_layer.ldf),
+        zero-initialised once (the kernels keep the padding zero); images are padded to 16-column blocks by construction."""
+        dev, lib = self.flat_param.device, self.lib
+        layers = list(self.model.layers)
+        dims = [f0] + [l.out_feats for l in layers]
+        nh = len(layers) - 1
+        ld = [_c16(d) for d in dims[1:nh + 1]]
+        z32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        u8 = lambda nbytes: torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+
+        def img(rows, cols):
+            t = ops.P3.empty(rows, cols, dev)
+            t.data.zero_()
+            return t
+        b = {"cap": cap, "gen": True, "kinds": tuple(kinds), "out_gemm": bool(out_gemm), "ld": ld, "pl": [k == 0 for k in kinds]}
+        b["t"] = [z32(cap, 2 * ld[i]) if kinds[i] == 0 else z32(cap, ld[i]) for i in range(nh)]       # [t_self | t_neigh], or z
+        b["y"] = [z32(cap, ld[i]) for i in range(nh)]
+        b["dy"] = [z32(cap, ld[i]) for i in range(nh)]
+        b["stats"] = [z32(2 * cap) for _ in range(nh)]
+        b["ahn"] = [z32(cap, dims[0]) if kinds[i] == 1 else None for i in range(nh)]
+        b["ahnp"] = [img(cap, dims[0]) if kinds[i] == 2 else None for i in range(nh)]
+        b["hp"] = [img(cap, dims[i]) if kinds[i] != 1 else None for i in range(nh)]
+        b["dzp"] = [img(cap, dims[i + 1]) if kinds[i] != 1 else None for i in range(nh)]
+        b["qp"] = [img(cap, dims[i + 1]) if kinds[i] == 0 else None for i in range(nh)]
+        b["ws_dw"] = [u8(lib.gte_gemm_p3_tn_workspace_bytes(dims[i + 1], 2 * dims[i], dims[i], cap) if kinds[i] != 1
+                         else self._ws_dw_bytes(i, dims, cap)) for i in range(nh)]
+        b["ws_ln"] = [u8(max(lib.gte_ln_relu_bwd_workspace_bytes(cap, dims[i + 1]),
+                             lib.gte_gemm_p3_nt_ln_bwd_workspace_bytes(cap, dims[i + 1]) if dims[i + 1] <= 256 else 0,
+                             lib.gte_sage_narrow_bwd_ln_workspace_bytes(cap, min(dims[i + 1], 256)))) for i in range(nh)]
+        C = dims[-1]
+        b["out3"] = z32(3)
+        if out_gemm:
+            b["hp_out"] = img(cap, dims[-2])                       # image of the last hidden layer's output
+            b["t_out"], b["dlq"] = z32(cap, 32), z32(cap, 32)      # [logits .. | t_neigh ..], [dl .. | q ..]
+            b["dlqp"] = img(cap + 8, 32)
+            b["ws_out"] = u8(lib.gte_gemm_p3_tn_workspace_bytes(C, 2 * dims[-2], dims[-2], cap))
+            b["ws_ce"] = u8(lib.gte_weighted_ce_workspace_bytes(cap))
+            b["ws_cs"] = u8(lib.gte_colsum_workspace_bytes(cap, C))
+        else:
+            b["logits"], b["tn"], b["q"], b["dl"] = z32(cap, C), z32(cap, C), z32(cap, C), z32(cap, C)
+            b["ce_part"] = u8(lib.gte_head_agg_ce_workspace_bytes(cap))
+            b["ws_nar"] = u8(lib.gte_sage_narrow_bwd_workspace_bytes(cap, min(dims[-2], 256), min(C, 16)))
+        return b
+
+    def _buffers_gen(self, n: int, f0: int, kinds, out_gemm: bool):
+        """The (capacity-sized, shared or captured-batch-private) buffer set of a general plan; see _buffers."""
+        key = ("gen", f0, tuple(kinds), bool(out_gemm))
+        if self._private_key is not None:
+            store, k2 = self._graph_bufs, (self._private_key, key)
+            full = store.get(k2)
+            if full is None:
+                full = store[k2] = self._alloc_gen(n, f0, kinds, out_gemm)
+            if full["cap"] < n:
+                raise RuntimeError(f"captured batch buffers hold {full['cap']} nodes; asked for {n} (a captured batch must not change)")
+            return full
+        full = self._bufs.get(key)
+        if full is None or full["cap"] < n:
+            cap = max(-(-int(n * 1.125) // 4096) * 4096, getattr(self, "_reserved", {}).get(f0, 0))
+            self._bufs.pop(key, None)
+            full = self._bufs[key] = self._alloc_gen(cap, f0, kinds, out_gemm)
+        return full
 
     def _buffers(self, n: int, f0: int, private=None):
         """Row views [0:n] of buffers allocated for a CAPACITY, not for n: in the real loop every batch has a
@@ -298,11 +379,18 @@ class FusedGcnSageStep(TrainStep):
         """Size the shared per-batch buffers for batches of up to ``n_nodes`` nodes now (the train loop knows the largest batch
         its page table can produce): no reallocation -- a device synchronisation plus ~12 KB per node of new buffers -- later,
         in the middle of an epoch."""
+        cap = -(-int(n_nodes) // 4096) * 4096
+        if not hasattr(self, "_reserved"):
+            self._reserved = {}
+        self._reserved[f0] = max(self._reserved.get(f0, 0), cap)
+        kinds = self._plan_kinds(f0, 0)
+        if kinds is not None and self._plan_mode(kinds, f0)[0]:
+            return                      # a general plan allocates its own (padded) set at this capacity on first use
         key = (f0, self._planes_on())
         full = self._bufs.get(key)
         if n_nodes > 0 and (full is None or full["cap"] < n_nodes):
             self._bufs = {k: v for k, v in self._bufs.items() if k[0] != f0}    # drop the old set first: both need not be alive
-            self._bufs[key] = self._alloc(-(-int(n_nodes) // 4096) * 4096, f0)
+            self._bufs[key] = self._alloc(cap, f0)
 
     def _narrow(self, layer, fin: int) -> bool:
         return (not isinstance(layer.lynorm, nn.LayerNorm) and layer.activation is None and layer.linear.bias is not None
@@ -359,7 +447,7 @@ class FusedGcnSageStep(TrainStep):
         """True when layer 0 takes its input as a P3 image: the train loop then keeps the resident features as images and
         assembles batches of image rows (graph.ResidentPages.enable_p3)."""
         L = self.model.layers[0]
-        return self._planes_layer(0, L, f0)
+        return self._layer_kind(0, L, f0) == 0
 
     def _param_sig(self):
         return (self.flat_param._version,) + tuple(p._version for p in self.model.parameters())
@@ -412,6 +500,27 @@ class FusedGcnSageStep(TrainStep):
                 and bool(self.lib.gte_sage_linear_fwd_fuses_ln(2 * fin, layer.out_feats))
                 and bool(self.lib.gte_sage_smallk_bwd_supported(2 * fin, layer.out_feats)))
 
+    def _layer_kind(self, i: int, L, fin: int, n: int = 0):
+        """How hidden layer i runs on the one-call plan (gte_step_layer.kind): 0 planes layer in transform-first order, 1 the
+        one-pass short-input layer (BBOX features), 2 aggregate-first planes input layer (fin < fout); None: not on the plan.
+        Every shape the reference's runs produce is covered (run_multiple_train.sh:8-113: hidden 1000, or
+        int(calculate_hidden) = 96 ... 218, with F0 = 13 ... 831): hidden widths up to 1024, any input width."""
+        fout = L.out_feats
+        if not (self._planes_on() and isinstance(L.lynorm, nn.LayerNorm) and L.linear.bias is not None
+                and (L.activation is None or _is_relu(L.activation))):
+            return None
+        if self._planes_layer(i, L, fin, n):
+            return 0                                             # the tuned range: 128 <= fout <= 256, fout % 16 == 0
+        if (i == 0 and not self._transform_first(L, fin) and fout % 16 == 0
+                and bool(self.lib.gte_sage_linear_fwd_fuses_ln(2 * fin, fout)) and not ops.use_tiled(n, fin, None)):
+            return 1
+        if not self.general_planes or fout > 1024:
+            return None
+        # transform-first while the layer does not widen by more than a quarter (the aggregation then moves fout columns: 1000
+        # against 831 costs less than a per-batch fp32 copy of the input rows, and layer 0 reads the RESIDENT image through the row
+        # map); aggregate-first for a widening input layer (13 / 63 / 313 / 363 -> 1000: aggregate fin columns)
+        return 0 if (i > 0 or 4 * fout <= 5 * fin) else 2
+
     def _plan_kinds(self, f0: int, n: int):
         """Layer kinds of the one-call step (gte_gcnsage_step) or None when the configuration needs the call-by-call path."""
         layers = list(self.model.layers)
@@ -420,22 +529,203 @@ class FusedGcnSageStep(TrainStep):
             return None
         dims = [f0] + [l.out_feats for l in layers]
         last = len(layers) - 1
-        if not (self._narrow(layers[last], dims[last]) and self._fused_head(last, layers[last], dims[last])):
+        Lo = layers[last]
+        if (isinstance(Lo.lynorm, nn.LayerNorm) or Lo.activation is not None or Lo.linear.bias is None or Lo.use_pp
+                or not 1 <= Lo.out_feats <= 16 or not self.fused_head):
+            return None
+        if not self.general_planes and not (self._narrow(Lo, dims[last]) and self._fused_head(last, Lo, dims[last])):
             return None
         kinds = []
         for i, L in enumerate(layers[:-1]):
-            fin = dims[i]
-            if self._planes_layer(i, L, fin, n):
-                kinds.append(0)
-            elif (i == 0 and isinstance(L.lynorm, nn.LayerNorm) and L.linear.bias is not None and not self._transform_first(L, fin)
-                  and bool(self.lib.gte_sage_linear_fwd_fuses_ln(2 * fin, L.out_feats))
-                  and not ops.use_tiled(n, fin, None)):
-                kinds.append(1)
-            else:
+            k = self._layer_kind(i, L, dims[i], n)
+            if k is None:
                 return None
-            if L.activation is not None and not _is_relu(L.activation):
-                return None
+            kinds.append(k)
         return kinds
+
+    def _plan_mode(self, kinds, f0: int):
+        """(general, out_gemm) of a plan: ``general`` = it runs on the padded buffer set (_alloc_gen) -- some hidden layer lies
+        outside the tuned range or the output layer runs on the planes GEMMs; ``out_gemm`` = the latter (hidden width beyond the
+        narrow kernels: > 256 or not a multiple of 8)."""
+        layers = list(self.model.layers)
+        dims = [f0] + [l.out_feats for l in layers]
+        last = len(layers) - 1
+        out_gemm = not (self._narrow(layers[last], dims[last]) and self._fused_head(last, layers[last], dims[last]))
+        gen = out_gemm or any(k == 2 or (k == 0 and not self._planes_layer(i, layers[i], dims[i])) for i, k in enumerate(kinds))
+        return gen, out_gemm
+
+    def _weight_images_gen(self, dims, kinds, out_gemm: bool):
+        """Weight images of a general plan (kept per (kinds, out_gemm)) and their conversion descriptors.  A planes layer's forward
+        image holds [W_s rows ; zero rows up to ld ; W_n rows ; zero rows] (ld = fout rounded up to 16: the two halves of t start on
+        16-column boundaries), its backward image [fin] x [W_s^T | W_n^T] with the second segment at column block ld / 16; an
+        aggregate-first layer's image is [fout] x [W_s | W_n] with the second K segment at block ceil(fin / 16); the output
+        layer's images are [32] x [H] (rows 0.. = W_s, 16.. = W_n) and [H] x [32].  Allocated zeroed: the padding is never written."""
+        key = ("gen", tuple(dims), tuple(kinds), bool(out_gemm))
+        hit = self._wimg.get(key)
+        if hit is not None:
+            return hit
+        dev = self.flat_param.device
+        layers = list(self.model.layers)
+
+        def img(rows, cols):
+            t = ops.P3.empty(rows, cols, dev)
+            t.data.zero_()
+            return t
+        imgs, descs = {}, []
+        for i, k in enumerate(kinds):
+            L = layers[i]
+            fin, fout = dims[i], L.out_feats
+            W = L.linear.weight
+            wp, ldw = W.data_ptr(), W.stride(0)
+            if k == 0:
+                ld = _c16(fout)
+                fwd = img(2 * ld, fin)
+                descs.append(_lib.P3Desc(wp, ldw, fout, fin, 0, fwd.data.data_ptr(), fwd.ldp))
+                descs.append(_lib.P3Desc(wp + 4 * fin, ldw, fout, fin, 0, fwd.data.data_ptr() + ld * fwd.ldp, fwd.ldp))
+                bwd = None
+                if i > 0:
+                    bwd = img(fin, 2 * ld)
+                    descs.append(_lib.P3Desc(wp, ldw, fin, fout, 1, bwd.data.data_ptr(), bwd.ldp))
+                    descs.append(_lib.P3Desc(wp + 4 * fin, ldw, fin, fout, 1, bwd.data.data_ptr() + (ld // 16) * 96, bwd.ldp))
+                imgs[i] = (fwd, bwd)
+            elif k == 2:
+                kp = _c16(fin)
+                fwd = img(fout, 2 * kp)
+                descs.append(_lib.P3Desc(wp, ldw, fout, fin, 0, fwd.data.data_ptr(), fwd.ldp))
+                descs.append(_lib.P3Desc(wp + 4 * fin, ldw, fout, fin, 0, fwd.data.data_ptr() + (kp // 16) * 96, fwd.ldp))
+                imgs[i] = (fwd, None)
+        if out_gemm:
+            Lo = layers[-1]
+            H, C = dims[-2], Lo.out_feats
+            W = Lo.linear.weight
+            wp, ldw = W.data_ptr(), W.stride(0)
+            fwd, bwd = img(32, H), img(H, 32)
+            descs.append(_lib.P3Desc(wp, ldw, C, H, 0, fwd.data.data_ptr(), fwd.ldp))
+            descs.append(_lib.P3Desc(wp + 4 * H, ldw, C, H, 0, fwd.data.data_ptr() + 16 * fwd.ldp, fwd.ldp))
+            descs.append(_lib.P3Desc(wp, ldw, H, C, 1, bwd.data.data_ptr(), bwd.ldp))
+            descs.append(_lib.P3Desc(wp + 4 * H, ldw, H, C, 1, bwd.data.data_ptr() + 96, bwd.ldp))
+            imgs["out"] = (fwd, bwd)
+        if len(descs) > 32:
+            raise _lib.GteError("gte_gcnsage_step: more than 32 weight images")
+        arr = (_lib.P3Desc * max(len(descs), 1))(*descs)
+        hit = self._wimg[key] = (imgs, arr, len(descs))
+        return hit
+
+    def _bind_plan_gen(self, g, kinds, with_adam: bool, out_gemm: bool):
+        """_bind_plan for a general plan (padded buffer set, _alloc_gen)."""
+        lib, P = self.lib, _lib.ptr
+        xp = getattr(g, "feat_p3", None)
+        if xp is not None:
+            x, n, f0 = None, xp.rows, xp.cols
+        else:
+            x = ops._row_major(g.ndata['feat'])
+            _lib.require_device(x, "FusedGcnSageStep")
+            n, f0 = x.shape
+        b = self._buffers_gen(n, f0, kinds, out_gemm)
+        layers = list(self.model.layers)
+        dims = [f0] + [l.out_feats for l in layers]
+        nh = len(layers) - 1
+        ew = g.edata.get("feat")
+        csr, rcsr = g.in_csr(), g.out_csr()
+        w_in, w_out = g.in_weights(ew), g.out_weights(ew, True)
+        plans = b.setdefault("_plans", {})
+        cached = plans.get(("gen", with_adam))
+        if cached is None:
+            imgs, arr, n_desc = self._weight_images_gen(dims, kinds, out_gemm)
+            plan = _lib.StepPlan()
+            plan.n_hidden = nh
+            gs = self._gslice
+            for i, L in enumerate(layers[:-1]):
+                sl = plan.layer[i]
+                fin, fout = dims[i], L.out_feats
+                sl.kind, sl.fin, sl.fout, sl.ldf = kinds[i], fin, fout, b["ld"][i]
+                sl.W, sl.bias, sl.gamma, sl.beta = P(L.linear.weight), P(L.linear.bias), P(L.lynorm.weight), P(L.lynorm.bias)
+                sl.eps, sl.relu = float(L.lynorm.eps), int(L.activation is not None)
+                sl.gW, sl.gbias = P(gs[id(L.linear.weight)]), P(gs[id(L.linear.bias)])
+                sl.ggamma, sl.gbeta = P(gs[id(L.lynorm.weight)]), P(gs[id(L.lynorm.bias)])
+                last_hidden = i == nh - 1
+                nxt_img = (not last_hidden and kinds[i + 1] == 0) or (last_hidden and out_gemm)
+                # the layer's output: as an image for a planes consumer, as fp32 rows for the narrow output kernels
+                if nxt_img:
+                    yp = b["hp_out"] if last_hidden else b["hp"][i + 1]
+                    sl.yp, sl.ldp_y = P(yp.data), yp.ldp
+                sl.y = P(b["y"][i]) if (last_hidden and not out_gemm) or not nxt_img else None
+                sl.t, sl.stats, sl.dy = P(b["t"][i]), P(b["stats"][i]), P(b["dy"][i])
+                sl.ws_ln, sl.ws_ln_bytes = P(b["ws_ln"][i]), b["ws_ln"][i].numel()
+                sl.ws_dw, sl.ws_dw_bytes = P(b["ws_dw"][i]), b["ws_dw"][i].numel()
+                if kinds[i] == 1:
+                    sl.ahn = P(b["ahn"][i])
+                    continue
+                wf, wb = imgs[i]
+                sl.wimg_fwd, sl.ldp_wfwd = P(wf.data), wf.ldp
+                if wb is not None:
+                    sl.wimg_bwd, sl.ldp_wbwd = P(wb.data), wb.ldp
+                sl.hp, sl.ldp_h = P(b["hp"][i].data), b["hp"][i].ldp
+                sl.dzp, sl.ldp_o = P(b["dzp"][i].data), b["dzp"][i].ldp
+                if kinds[i] == 0:
+                    sl.qp = P(b["qp"][i].data)
+                else:
+                    sl.ahnp, sl.ldp_ahn = P(b["ahnp"][i].data), b["ahnp"][i].ldp
+            Lo = layers[-1]
+            C = Lo.out_feats
+            plan.out_fin, plan.n_classes = dims[-2], C
+            plan.W_out, plan.b_out = P(Lo.linear.weight), P(Lo.linear.bias)
+            plan.gW_out, plan.gb_out = P(gs[id(Lo.linear.weight)]), P(gs[id(Lo.linear.bias)])
+            plan.ld_h_out = b["ld"][-1]
+            plan.dh_out = P(b["dy"][-1])
+            if out_gemm:
+                wf, wb = imgs["out"]
+                plan.out_gemm, plan.ld_lg = 1, 32
+                plan.hp_out, plan.ldp_hout = P(b["hp_out"].data), b["hp_out"].ldp
+                plan.wimg_out_fwd, plan.ldp_wout_fwd = P(wf.data), wf.ldp
+                plan.wimg_out_bwd, plan.ldp_wout_bwd = P(wb.data), wb.ldp
+                plan.logits, plan.tn = P(b["t_out"]), P(b["t_out"]) + 64
+                plan.dl, plan.q_out = P(b["dlq"]), P(b["dlq"]) + 64
+                plan.dlqp, plan.ldp_dlq = P(b["dlqp"].data), b["dlqp"].ldp
+                plan.ws_out, plan.ws_out_bytes = P(b["ws_out"]), b["ws_out"].numel()
+                plan.ws_ce, plan.ws_ce_bytes = P(b["ws_ce"]), b["ws_ce"].numel()
+                plan.ws_cs, plan.ws_cs_bytes = P(b["ws_cs"]), b["ws_cs"].numel()
+            else:
+                plan.h_out = P(b["y"][-1])
+                plan.logits, plan.tn, plan.q_out, plan.dl = P(b["logits"]), P(b["tn"]), P(b["q"]), P(b["dl"])
+                plan.ce_part, plan.ce_part_bytes = P(b["ce_part"]), b["ce_part"].numel()
+                plan.ws_nar, plan.ws_nar_bytes = P(b["ws_nar"]), b["ws_nar"].numel()
+            plan.out3 = P(b["out3"])
+            plan.wimg_descs, plan.n_wimg_descs = ctypes.addressof(arr), n_desc
+            if with_adam:
+                plan.param, plan.grad, plan.exp_avg, plan.exp_avg_sq = (P(self.flat_param), P(self.flat_grad), P(self.exp_avg),
+                                                                        P(self.exp_avg_sq))
+                plan.n_param = self.flat_param.numel()
+                plan.hyper, plan.step_counter, plan.ticket = P(self._hyper), P(self._step_dev), P(self._ticket)
+            if self._tail_ws is None:
+                self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=self.flat_param.device)
+            if self.tail_split:
+                plan.tail_ws, plan.tail_ws_bytes = P(self._tail_ws), self._tail_ws.numel()
+            cached = plans[("gen", with_adam)] = (plan, arr, ctypes.c_int(0))
+        plan, _arr, fused = cached
+        # per call: switches and class weights (public attributes), the graph, the features
+        plan.class_weights = P(self.class_weights)
+        plan.fuse_ln_dx = (int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (8 if self.fuse_smallk_dx else 0))
+        L0 = plan.layer[0]
+        if kinds[0] == 0:
+            if xp is not None:
+                L0.hp, L0.ldp_h, L0.make_hp, L0.x = P(xp.data), xp.ldp, 0, None
+                L0.h_rows, L0.n_res_rows = (P(xp.row_map), xp.res_rows) if xp.row_map is not None else (None, 0)
+            else:
+                L0.hp, L0.ldp_h, L0.make_hp = P(b["hp"][0].data), b["hp"][0].ldp, 1
+                L0.h_rows, L0.n_res_rows = None, 0
+                L0.x, L0.ldx = P(x), ops._ld(x)
+        else:
+            if x is None:
+                raise _lib.GteError("the batch holds its features as a P3 image, but layer 0 reads fp32 rows")
+            L0.x, L0.ldx = P(x), ops._ld(x)
+        plan.indptr, plan.indices, plan.w_in = P(csr.indptr), P(csr.indices), P(w_in)
+        plan.rindptr, plan.rindices, plan.w_out = P(rcsr.indptr), P(rcsr.indices), P(w_out)
+        plan.n_nodes = n
+        C = layers[-1].out_feats
+        view = {"out3": b["out3"], "_full": b, "_wkey": ("gen", tuple(dims), tuple(kinds), bool(out_gemm)),
+                "logits": b["t_out"][:n, :C] if out_gemm else b["logits"][:n]}
+        return plan, fused, view, n, (csr, rcsr, w_in, w_out, self.class_weights)
 
     def _bind_plan(self, g, kinds, with_adam: bool):
         """The gte_step_plan of this layer plan (cached with the buffer set whose addresses it holds) with the per-batch fields --
@@ -449,6 +739,9 @@ class FusedGcnSageStep(TrainStep):
             x = ops._row_major(g.ndata['feat'])
             _lib.require_device(x, "FusedGcnSageStep")
             n, f0 = x.shape
+        gen, out_gemm = self._plan_mode(kinds, f0)
+        if gen:
+            return self._bind_plan_gen(g, kinds, with_adam, out_gemm)
         b = self._buffers(n, f0, self._private_key)
         layers = list(self.model.layers)
         dims = [f0] + [l.out_feats for l in layers]
@@ -503,7 +796,6 @@ class FusedGcnSageStep(TrainStep):
             plan.dl, plan.dh_out = P(b["dy"][-1]), P(b["dy"][-2])
             plan.ce_part, plan.ce_part_bytes = P(b["ce_part"]), b["ce_part"].numel()
             plan.ws_nar, plan.ws_nar_bytes = P(b["ws_nar"]), b["ws_nar"].numel()
-            plan.class_weights = P(self.class_weights)
             plan.out3 = P(b["out3"])
             plan.wimg_descs, plan.n_wimg_descs = ctypes.addressof(arr), len(descs)
             if with_adam:
@@ -511,15 +803,18 @@ class FusedGcnSageStep(TrainStep):
                                                                         P(self.exp_avg_sq))
                 plan.n_param = self.flat_param.numel()
                 plan.hyper, plan.step_counter, plan.ticket = P(self._hyper), P(self._step_dev), P(self._ticket)
-            plan.fuse_ln_dx = (int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (4 if self.fuse_q_narrow else 0)
-                               | (8 if self.fuse_smallk_dx else 0))
             if self._tail_ws is None:
                 self._tail_ws = torch.empty(int(lib.gte_gemm_tail_workspace_bytes()), dtype=torch.uint8, device=self.flat_param.device)
             if self.tail_split:
                 plan.tail_ws, plan.tail_ws_bytes = P(self._tail_ws), self._tail_ws.numel()
             cached = plans[key] = (plan, arr, ctypes.c_int(0))
         plan, _arr, fused = cached
-        # per batch: the graph, the features, the labels
+        # per call: the public switches and the class weights (re-read like the call-by-call path does) ...
+        plan.class_weights = P(self.class_weights)
+        plan.fuse_ln_dx = (int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (4 if self.fuse_q_narrow else 0)
+                           | (8 if self.fuse_smallk_dx else 0))
+        # ... and per batch: the graph, the features, the labels
+        b["logits"], b["_wkey"] = b["y"][-1], "tuned"
         L0 = plan.layer[0]
         if kinds[0] == 0:
             if xp is not None:
@@ -536,19 +831,20 @@ class FusedGcnSageStep(TrainStep):
         plan.indptr, plan.indices, plan.w_in = P(csr.indptr), P(csr.indices), P(w_in)
         plan.rindptr, plan.rindices, plan.w_out = P(rcsr.indptr), P(rcsr.indices), P(w_out)
         plan.n_nodes = n
-        return plan, fused, b, n, (csr, rcsr, w_in, w_out)
+        return plan, fused, b, n, (csr, rcsr, w_in, w_out, self.class_weights)
 
     def _c_step(self, g, labels, grad_scale, kinds, with_adam: bool):
         """forward + loss + backward (+ Adam inside the fold launch) through gte_gcnsage_step: two host calls (the next batch's
         assembly is queued between them) instead of ~19."""
         lib, P = self.lib, _lib.ptr
         st = _lib.current_stream()
-        plan, fused, b, n, (csr, rcsr, w_in, w_out) = self._bind_plan(g, kinds, with_adam)
+        plan, fused, b, n, keep = self._bind_plan(g, kinds, with_adam)
         lab = labels if labels.dtype in (torch.float32, torch.int64) else labels.to(torch.int64)
         plan.labels, plan.labels_f32 = P(lab), int(lab.dtype == torch.float32)
         plan.grad_scale = float(grad_scale)
         capturing = torch.cuda.is_current_stream_capturing()
         sig = self._param_sig()
+        sig = (sig, b["_wkey"])                   # (which image set: a plan of another layout keeps its own images)
         plan.wimg_fresh = int(self.wimg_in_fold and not capturing and self._wimg_sig == sig)
         plan.wimg_in_fold = int(self.wimg_in_fold and with_adam and not capturing)
         self._wimg_sig = None
@@ -560,8 +856,17 @@ class FusedGcnSageStep(TrainStep):
             _lib.check(lib.gte_gcnsage_step_graph(addr, ctypes.byref(fused), st, ctypes.byref(self._step_exec)), "gte_gcnsage_step_graph")
         elif self.before_last_gemm is not None:
             _lib.check(lib.gte_gcnsage_step(addr, 1, ctypes.byref(fused), st), "gte_gcnsage_step")
-            self.before_last_gemm()
-            _lib.check(lib.gte_gcnsage_step(addr, 2, ctypes.byref(fused), st), "gte_gcnsage_step")
+            # phase 1 returned with this thread's fold deferral OPEN and the tail workspace registered: whatever the callback (the
+            # next batch's assembly) or phase 2 raises, both are closed again -- a step that died here must not poison the next
+            # one ("a deferral is already open") or let later standalone calls queue folds nobody flushes
+            try:
+                self.before_last_gemm()
+                _lib.check(lib.gte_gcnsage_step(addr, 2, ctypes.byref(fused), st), "gte_gcnsage_step")
+            except BaseException:
+                lib.gte_fold_defer_flush()                      # (an error if phase 2 already closed it: ignored)
+                lib.gte_gemm_set_tail_workspace(None, 0)
+                self._wimg_sig = None
+                raise
         else:
             _lib.check(lib.gte_gcnsage_step(addr, 0, ctypes.byref(fused), st), "gte_gcnsage_step")
         self._adam_fused = bool(fused.value & 1)
@@ -569,7 +874,7 @@ class FusedGcnSageStep(TrainStep):
         # unchanged ones the forward converted; otherwise Adam follows as its own launch and they are stale
         if not capturing and ((fused.value & 2) or not with_adam):
             self._wimg_sig = sig
-        self._keep = (lab, csr, rcsr, w_in, w_out)                     # alive until the next step
+        self._keep = (lab,) + tuple(keep)                              # alive until the next step
         return b["out3"]
 
     FORWARD_IMAGE_MAX_ELEMS = 1 << 21     # forward_logits: largest fp32 feature matrix that is converted to an image per call
@@ -596,12 +901,12 @@ class FusedGcnSageStep(TrainStep):
                 return self.model(g)
         plan, _fused, b, n, keep = self._bind_plan(g, kinds, with_adam=False)
         capturing = torch.cuda.is_current_stream_capturing()
-        sig = self._param_sig()
+        sig = (self._param_sig(), b["_wkey"])
         plan.wimg_fresh = int(self.wimg_in_fold and not capturing and self._wimg_sig == sig)
         _lib.check(self.lib.gte_gcnsage_forward(ctypes.addressof(plan), _lib.current_stream()), "gte_gcnsage_forward")
         self._wimg_sig = None if capturing else sig
         self._keep = keep
-        return b["y"][-1]
+        return b["logits"]
 
     # -- the schedule ----------------------------------------------------------------------------------
     def forward_backward(self, g, labels: torch.Tensor, grad_scale: float = 1.0, upto_layer: int = 0) -> torch.Tensor:
@@ -768,7 +1073,8 @@ class FusedGcnSageStep(TrainStep):
                     for _ in tm.repeat():
                         check(lib.gte_sage_transform_fwd(P(h), ld(h), fin, P(W), 2 * fin, P(bias), fout, P(t), 2 * fout, n,
                                                          st), "gte_sage_transform_fwd")
-                if lib.gte_spmm_csr_accumulate_ln_supported(fout) and not (t_in is not None and ops.use_tiled(n, fout, csr.indices.numel(), fused_ln=True)):
+                if (fout % 4 == 0 and lib.gte_spmm_csr_accumulate_ln_supported(fout)
+                        and not (t_in is not None and ops.use_tiled(n, fout, csr.indices.numel(), fused_ln=True))):
                     # z = t_self + mean-aggregate(t_neigh) and y = relu(LayerNorm(z)) in one pass over the rows
                     with timed("spmm_csr", 3.0 * n * fout * 4 + 8.0 * csr.indices.numel() + 4.0 * (n + 1)):
                         check(lib.gte_spmm_csr_accumulate_ln(P(csr.indptr), P(csr.indices), P(w_in), P(t) + 4 * fout, 2 * fout,

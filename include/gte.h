@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GTE_VERSION 100 /* major*10000 + minor*100 + patch */
+#define GTE_VERSION 400 /* major*10000 + minor*100 + patch */
 
 enum gte_status {
     GTE_OK = 0,
@@ -227,8 +227,11 @@ int gte_sage_linear_dw(const float* dz, int64_t lddz, const float* x1, int64_t l
 /* gte_spmm_csr_accumulate with a LayerNorm(+ReLU) epilogue, for a layer in transform-then-aggregate order
  * (models.py:53-54 then :64-66): z[v,:] += scale_v * sum_e w[e] x[src,:] (z written back: the LayerNorm backward
  * needs it), then y[v,:] = relu?(gamma * (z - mean) / sqrt(var + eps) + beta) and stats[v] = mean,
- * stats[n_rows + v] = rstd (nullable) -- same statistics as gte_ln_relu_fwd.  f32 only, n_feat % 4 == 0, n_feat <= 256
- * (a row must fit one lane group; gte_spmm_csr_accumulate_ln_supported says so). */
+ * stats[n_rows + v] = rstd (nullable) -- same statistics as gte_ln_relu_fwd.  f32 only, n_feat <= 1024 (a row lives in
+ * the registers of one lane group; gte_spmm_csr_accumulate_ln_supported says so).  The kernel works on 16-byte chunks:
+ * when n_feat % 4 != 0 (% 16 != 0 with a P3 image of y) the rows of x, z and y must be PADDED -- allocated to the next
+ * multiple of 4 (16) floats, ld >= that; the padding of x is read and must hold zeros, the padding of z / y / the image is
+ * written as zeros; mean and variance run over the n_feat true columns (models.py:64). */
 int gte_spmm_csr_accumulate_ln_supported(int64_t n_feat);
 int gte_spmm_csr_accumulate_ln(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x,
                                int64_t ldx, float* z, int64_t ldz, int64_t n_rows, int64_t n_feat, int reduce,
@@ -284,10 +287,12 @@ typedef struct gte_p3_desc {
     void* dst; int64_t ldp;            /* image (first byte of its row 0 / column block 0), row stride in bytes */
 } gte_p3_desc;
 int gte_p3_from_f32_batch(const gte_p3_desc* descs, int n, void* stream);
-/* Producers that write their result as a P3 image: the aggregation (q = A_w^T (norm dz), aggregated inputs; n_feat % 16 == 0),
- * the fused aggregation + LayerNorm(+ReLU) (y as image and / or fp32: either may be NULL) and the LayerNorm backward (dz as
- * fp32 AND image: fp32 feeds the transpose aggregation, the image the dX / dW GEMMs).  Same arithmetic as their fp32
- * forms (gte_spmm_csr, gte_spmm_csr_accumulate_ln, gte_ln_relu_bwd); the image holds exactly the fp32 values. */
+/* Producers that write their result as a P3 image: the aggregation (q = A_w^T (norm dz), aggregated inputs; any n_feat, the
+ * image's columns up to the next multiple of 16 are written as zeros), the fused aggregation + LayerNorm(+ReLU) (y as image
+ * and / or fp32: either may be NULL) and the LayerNorm backward (dz as fp32 AND image: fp32 feeds the transpose aggregation,
+ * the image the dX / dW GEMMs; widths other than 128 <= n_out <= 512 with n_out % 16 == 0 run a masked kernel on PADDED
+ * rows: LayerNorm required, n_out <= 1024, lddy / ldz / lddz >= n_out rounded up to 4).  Same arithmetic as their fp32 forms
+ * (gte_spmm_csr, gte_spmm_csr_accumulate_ln, gte_ln_relu_bwd); the image holds exactly the fp32 values. */
 int gte_sage_linear_fwd_p3(const float* a1, int64_t lda1, int64_t k1, const float* a2, int64_t lda2, int64_t k2, const float* W,
                            int64_t ldw, const float* bias, const float* gamma, const float* beta, float eps, int relu,
                            float* z_save, int64_t ldz, float* stats, float* y /* nullable */, int64_t ldy, void* yp3,
@@ -375,11 +380,19 @@ int gte_batch_assemble_rows(const int32_t* pages, int64_t n_batch, const int32_t
  * BBOX-only configurations, F0 = 13, were host-bound at ~0.25 ms of ctypes calls per 0.37 ms step).
  * The plan only borrows device pointers; nothing is allocated or synchronised.  Layer kinds:
  *   GTE_LAYER_PLANES  t = h [W_s ; W_n]^T on the planes GEMM, z = t_self + b + mean-aggregate(t_neigh), LayerNorm, ReLU;
- *                     input / dz / q as P3 images (needs fin >= fout, fout % 16 == 0, 128 <= fout <= 256)
+ *                     input / dz / q as P3 images.  Any fout <= 1024 (the reference's runs: --h_layer_dim=1000 or
+ *                     int(calculate_hidden) = 96 ... 218, run_multiple_train.sh:8-113): the fp32 row buffers of the layer are
+ *                     PADDED to ldf = fout rounded up to 16 floats per row (t: two halves of ldf), the weight image holds zero
+ *                     rows behind the fout rows of each half, LayerNorm statistics run over the true width
  *   GTE_LAYER_SMALLK  input layer with k = 2 fin <= 64 (BBOX features): aggregate-first, linear + LayerNorm + ReLU in one pass
- * followed by the output layer (gte_sage_narrow_*, gte_head_agg_ce).  phase: 0 the whole step; 1 everything up to the last
- * weight-gradient GEMM, 2 the rest (the train loop queues the NEXT batch's assembly on its side stream in between). */
-enum gte_layer_kind { GTE_LAYER_PLANES = 0, GTE_LAYER_SMALLK = 1 };
+ *   GTE_LAYER_AGGFIRST input layer that widens (fin < fout, e.g. 13 / 63 / 363 -> 1000): x and mean-aggregate(x) as P3 images,
+ *                     z = [x | ahn] W^T + b on the planes GEMM (two K segments), LayerNorm + ReLU (gte_ln_relu_fwd_p3);
+ *                     dW = [dz^T x | dz^T ahn] on the TN planes GEMM
+ * followed by the output layer: the narrow kernels (gte_sage_narrow_*, gte_head_agg_ce; out_fin <= 256, out_fin % 8 == 0) or,
+ * out_gemm = 1, the planes GEMMs (N = 32 forward; dW_out with M = n_classes; dh with K = 32).  phase: 0 the whole step; 1
+ * everything up to the last weight-gradient GEMM, 2 the rest (the train loop queues the NEXT batch's assembly on its side
+ * stream in between). */
+enum gte_layer_kind { GTE_LAYER_PLANES = 0, GTE_LAYER_SMALLK = 1, GTE_LAYER_AGGFIRST = 2 };
 typedef struct gte_step_layer {
     int kind;
     int64_t fin, fout;
@@ -400,6 +413,8 @@ typedef struct gte_step_layer {
     void* dzp; void* qp; int64_t ldp_o;    /* PLANES: images [n][fout]                                      */
     void* ws_ln; int64_t ws_ln_bytes;      /* gte_ln_relu_bwd workspace                                     */
     void* ws_dw; int64_t ws_dw_bytes;      /* split-K workspace of the layer's dW                           */
+    int64_t ldf;                           /* floats per row of y / dy / z (t: 2 ldf): fout rounded up to 16; 0 = fout */
+    void* ahnp; int64_t ldp_ahn;           /* AGGFIRST: P3 image of the aggregated input [n][fin]           */
 } gte_step_layer;
 typedef struct gte_step_plan {
     int n_hidden;                          /* hidden layers (1 .. 7), followed by the output layer          */
@@ -425,6 +440,16 @@ typedef struct gte_step_plan {
                                               conversion launch (set by the caller after a step that returned *adam_fused & 2) */
     int wimg_in_fold;                      /* the fold + Adam launch also writes the weight images of the UPDATED parameters
                                               (gte_fold_defer_flush_adam_images); *adam_fused & 2 reports that it did        */
+    /* output layer on the planes GEMMs (out_gemm = 1): logits / tn are columns 0.. / 16.. of ONE [n][32] fp32 buffer (logits =
+     * its base, tn = logits + 16), dl / q_out likewise of a second one whose other columns stay zero; ld_lg = 32 */
+    int out_gemm; int64_t ld_lg;           /* ld_lg: floats per row of logits / tn / dl / q_out (0 = n_classes)             */
+    void* hp_out; int64_t ldp_hout;        /* P3 image of the output layer's input [n][out_fin] (yp of the last hidden layer) */
+    void* wimg_out_fwd; int64_t ldp_wout_fwd;   /* P3 [32][out_fin]: rows 0.. = W_s rows, rows 16.. = W_n rows              */
+    void* wimg_out_bwd; int64_t ldp_wout_bwd;   /* P3 [out_fin][32]: columns 0.. = W_s^T, 16.. = W_n^T                      */
+    void* dlqp; int64_t ldp_dlq;           /* P3 image [n + 1][32] of the dl / q buffer                                     */
+    void* ws_out; int64_t ws_out_bytes;    /* split-K workspace of dW_out: gte_gemm_p3_tn_workspace_bytes(C, 2 out_fin, out_fin, n) */
+    void* ws_ce; int64_t ws_ce_bytes;      /* gte_weighted_ce workspace                                                     */
+    void* ws_cs; int64_t ws_cs_bytes;      /* gte_colsum workspace                                                          */
 } gte_step_plan;
 /* *adam_fused: bit 0 = the optimiser step ran inside the fold launch, bit 1 = ... and it wrote the weight images */
 int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
@@ -458,11 +483,11 @@ int gte_fold_defer_flush(void);
  * caller launches gte_adam_step_dev itself.  grad still receives the folded gradient either way. */
 int gte_fold_defer_flush_adam(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                               int64_t* step_counter, unsigned* ticket, int* fused);
-/* ... and, in the same launch, the P3 images of up to 8 sub-matrices of the UPDATED parameters (every `src` inside
+/* ... and, in the same launch, the P3 images of up to 12 sub-matrices of the UPDATED parameters (every `src` inside
  * [param, param + n); the descriptors of gte_p3_from_f32_batch): the thread that updates a parameter element writes its three
  * bf16 pieces into each image holding it -- bit for bit what gte_p3_from_f32_batch makes of the updated parameters, without
  * the launch in front of the next step's first GEMM.  Padding columns of the images are not touched (zero them once).
- * *fused = 3 when the step and the images were written, 1 when more than 8 images were asked for (step applied, images not),
+ * *fused = 3 when the step and the images were written, 1 when more than 12 images were asked for (or one with a single source column) (step applied, images not),
  * 0 as gte_fold_defer_flush_adam. */
 int gte_fold_defer_flush_adam_images(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                                      int64_t* step_counter, unsigned* ticket, const gte_p3_desc* images, int n_images, int* fused);
@@ -565,6 +590,12 @@ int gte_sage_narrow_bwd_ln(const float* dl, int64_t lddl, const float* q, int64_
 int gte_ln_relu_fwd(const float* z, int64_t ldz, const float* gamma, const float* beta, float eps, int relu,
                     float* y, int64_t ldy, float* stats, int64_t M, int64_t n_out, void* stream);
 
+/* ... on PADDED rows of any width up to 1024 (ldz, ldy >= n_out rounded up to 4 floats), y as fp32 (nullable) and / or as a
+ * P3 image (nullable; its columns up to the next multiple of 16 are written as zeros): the LayerNorm(+ReLU) of an
+ * aggregate-first planes layer (GTE_LAYER_AGGFIRST).  Same two-pass statistics over the n_out true columns. */
+int gte_ln_relu_fwd_p3(const float* z, int64_t ldz, const float* gamma, const float* beta, float eps, int relu, float* y,
+                       int64_t ldy, void* yp3, int64_t ldyp3, float* stats, int64_t M, int64_t n_out, void* stream);
+
 /* Backward of LayerNorm+ReLU (+ bias grad):  given dy, the saved z and stats, writes
  *   dz[M,n_out], and WRITES the column sums dgamma, dbeta, dbias (f32[n_out], nullable; no zero-init needed).
  * With gamma == NULL it is the backward of (relu?)(z) only.  dz may alias dy unless gamma != NULL and
@@ -603,6 +634,13 @@ int gte_weighted_ce(const float* logits, int64_t ld, const void* labels, int lab
                     const float* class_weight, int64_t n_nodes, int n_classes, float grad_scale,
                     float* dlogits, int64_t lddl, float* out3,
                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* out[c] = sum_r x[r][c], c < n_cols <= 64: the bias gradient of the output layer (colsum of dlogits; autograd of the
+ * nn.Linear bias, models.py:101-103) when its backward runs on the planes GEMMs.  Block partials in a fixed order; the fold
+ * joins an open fold deferral.  workspace: gte_colsum_workspace_bytes(n_rows, n_cols). */
+int64_t gte_colsum_workspace_bytes(int64_t n_rows, int64_t n_cols);
+int gte_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_t n_cols, float* out, void* workspace,
+               int64_t workspace_bytes, void* stream);
 
 /* gte_adam_step: replaces torch.optim.Adam(lr, weight_decay).step() (model_train.py:168,332) on one
  * flat fp32 buffer: g' = grad_scale*g + weight_decay*p (L2-coupled, NOT AdamW);

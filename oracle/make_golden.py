@@ -202,6 +202,36 @@ def headline_inputs(seed=11, n=2000, f0=831):
     return s, d, ww, x, y
 
 
+def shape_inputs(seed, n, f0, bbox_like=False):
+    """Inputs of a trimmed run-shape case (run_shape_case), regenerated from the seed by the tests.  ``bbox_like``: the first
+    nine features carry raw-pixel magnitudes like the geometry features of nlp/bbox.py:49-54 (un-normalised, up to 5e5)."""
+    rng = np.random.default_rng(seed)
+    s, d, ww = knn_like_graph(rng, n, 5)
+    if bbox_like:
+        x = np.concatenate([rng.uniform(0, 2000, (n, 6)), rng.uniform(0, 5e5, (n, 3)), rng.uniform(0, 1, (n, f0 - 9))], 1).astype(np.float32)
+    else:
+        x = rng.standard_normal((n, f0)).astype(np.float32)
+    y = rng.integers(0, 9, n).astype(np.int64)
+    return s, d, ww, x, y
+
+
+# The reference's OWN run shapes (run_multiple_train.sh:8-113 with model_train.py:81-91,157 and components/features/utils.py:90-101):
+# --h_layer_dim=1000, or --mode_params=scaled --params_no=100000 -> int(calculate_hidden) = 218 / 206 / 157 / 149 / 100 / 96 for
+# F0 = 13 / 63 / 313 / 363 / 781 / 831.  (name, seed, nodes, F0, hidden, bbox-like inputs)
+SHAPE_CASES = [("shape_f13_h218", 21, 640, 13, 218, True), ("shape_f363_h149", 22, 512, 363, 149, False),
+               ("shape_f363_h139", 23, 384, 363, 139, False), ("shape_f63_h1000", 24, 400, 63, 1000, False),
+               ("shape_f831_h96", 25, 512, 831, 96, False), ("shape_f831_h1000", 26, 320, 831, 1000, False),
+               ("shape_f13_h1000", 27, 320, 13, 1000, True), ("shape_f781_h100", 28, 384, 781, 100, False)]
+
+
+def run_shape_case(ref, name, seed, n, f0, hid, bbox_like=False):
+    """One of the reference's run shapes, GcnSAGE(f0, hid, 9, 3), in the TRIMMED format of the headline case (inputs and initial
+    weights are regenerated from the seed; the fixture holds the graph, logits, loss, post-step logits, small gradients whole,
+    8 192 sampled entries + sum + max of every large tensor, every 16th row of the hidden activations)."""
+    s, d, ww, x, y = shape_inputs(seed, n, f0, bbox_like)
+    _run_trimmed(ref, name, seed, n, f0, hid, s, d, ww, x, y, extra_meta=[int(bbox_like)])
+
+
 def run_headline_case(ref, name="headline_n2000_f831_h256"):
     """(N, E, F0, H, L) = (2 000, ~16 000, 831, 256, 3) -- the headline model on a 2 000-node graph.  Stored
     TRIMMED (the full case is ~17 MB): graph, logits, loss, post-step logits, every small gradient, 8 192 sampled entries + sum
@@ -210,6 +240,10 @@ def run_headline_case(ref, name="headline_n2000_f831_h256"):
     reference's RNG stream bit for bit; the fixture carries sums to check that)."""
     seed, n, f0, hid = 11, 2000, 831, 256
     s, d, ww, x, y = headline_inputs(seed, n, f0)
+    _run_trimmed(ref, name, seed, n, f0, hid, s, d, ww, x, y)
+
+
+def _run_trimmed(ref, name, seed, n, f0, hid, s, d, ww, x, y, extra_meta=()):
     torch.manual_seed(seed)
     model = ref.GcnSAGE(f0, hid, 9, 3, F.relu, 0)
     g = StubGraph(s, d, n)
@@ -229,7 +263,8 @@ def run_headline_case(ref, name="headline_n2000_f831_h256"):
     state1 = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
     with torch.no_grad():
         logits1 = model(g).numpy()
-    out = dict(src=s.astype(np.int32), dst=d.astype(np.int32), w=ww, meta=np.array([n, f0, hid, 9, 3, seed], dtype=np.int64),
+    out = dict(src=s.astype(np.int32), dst=d.astype(np.int32), w=ww,
+               meta=np.array([n, f0, hid, 9, 3, seed] + list(extra_meta), dtype=np.int64),
                logits=logits.detach().numpy(), loss=np.float32(loss.item()), logits_after_step=logits1,
                x_sum=np.float64(x.astype(np.float64).sum()), y_sum=np.int64(y.sum()))
     srng = np.random.default_rng(99)
@@ -258,6 +293,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "headline":      # only the trimmed headline-shape case
         run_headline_case(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "shapes":        # only the reference's run shapes (trimmed)
+        for c in SHAPE_CASES:
+            run_shape_case(ref, *c)
+        return
+    for c in SHAPE_CASES:
+        run_shape_case(ref, *c)
     run_headline_case(ref)
     rng = np.random.default_rng(42)
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/gte.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
-    assert lib.gte_version() == 100
+    assert lib.gte_version() == 400
     assert lib.gte_coo_to_csr_workspace_bytes(1000, 8000) > 2 * 8000 * 4
     assert lib.gte_weighted_ce_workspace_bytes(1000) >= 4 * 3 * 4
 

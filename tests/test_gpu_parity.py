@@ -35,7 +35,8 @@ def both_gemm_modes(request):
 
 DEV = "cuda:0"
 GCN_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                   if not os.path.basename(p).startswith(("meansage", "aux_", "headline")))
+                   if not os.path.basename(p).startswith(("meansage", "aux_", "headline", "shape_")))
+SHAPE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "shape_*.npz")))
 
 
 def dev(a, dtype=None):

@@ -1,0 +1,303 @@
+"""The reference's OWN run shapes on the planes path (run_multiple_train.sh:8-113 of the reference: --h_layer_dim=1000, or
+--mode_params=scaled --params_no=100000 -> int(calculate_hidden) = 218 / 206 / 157 / 149 / 100 / 96, with F0 = 13 ... 831).
+
+* the general-width row kernels (padded rows, LayerNorm over the true width) against torch / the CPU oracle;
+* the one-call plan (gte_gcnsage_step / gte_gcnsage_forward: transform-first planes layers of any width <= 1024, the
+  aggregate-first input layer, the output layer on the planes GEMMs) against the reference-generated ``shape_*`` fixtures:
+  logits 1e-5, loss 1e-5, gradients 1e-4, post-step parameters / logits per tests/poststep.py;
+* the exact path ``bench.py`` times (ResidentPages.enable_p3 + BatchPipeline + run_steps, one 100-page step at F0 = 831,
+  hidden 256) and ``forward_logits`` against the oracle directly.
+"""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gnn_tableextraction_amd as gte
+from gnn_tableextraction_amd import _lib, graph as G, ops
+from gnn_tableextraction_amd.data import synthetic as S
+from oracle import gcnsage_cpu as oc
+from tests import poststep
+from tests.conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SHAPE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "shape_*.npz")))
+WIDTHS = [5, 13, 96, 100, 139, 149, 157, 206, 218, 256, 300, 520, 1000, 1024]
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(a)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def c16(x):
+    return -(-x // 16) * 16
+
+
+def _graph(rng, n, deg=6):
+    e = n * deg
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    dst[: n // 50 + 1] = 0                                            # a hub row; some rows stay empty
+    w = rng.uniform(0, 1, e).astype(np.float32)
+    return oc.OracleGraph(src, dst, n, w)
+
+
+def _padded(a, ld):
+    """device copy of ``a`` [n, f] in a zero buffer with ``ld`` floats per row (a view of the first f columns is returned too)"""
+    buf = torch.zeros((a.shape[0], ld), dtype=torch.float32, device=DEV)
+    buf[:, :a.shape[1]] = dev(a)
+    return buf
+
+
+@pytest.mark.parametrize("f", WIDTHS)
+@pytest.mark.parametrize("relu", [True, False])
+def test_aggregate_layernorm_kernel_on_any_width(f, relu):
+    """gte_spmm_csr_accumulate_ln_p3 on padded rows: z = t_self + mean-aggregate(t_neigh) (the oracle's CSR SpMM, same order),
+    LayerNorm over the f TRUE columns, ReLU; y as fp32 and as a P3 image; padding written as zeros."""
+    lib, P = _lib.load(), _lib.ptr
+    rng = np.random.default_rng(f)
+    n = 777
+    g = _graph(rng, n)
+    ld = c16(f)
+    t_self = rng.standard_normal((n, f)).astype(np.float32)
+    t_neigh = rng.standard_normal((n, f)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, f).astype(np.float32), rng.standard_normal(f).astype(np.float32)
+    t = torch.zeros((n, 2 * ld), dtype=torch.float32, device=DEV)
+    t[:, :f], t[:, ld:ld + f] = dev(t_self), dev(t_neigh)
+    y = torch.full((n, ld), 7.0, dtype=torch.float32, device=DEV)
+    yp = ops.P3.empty(n, f, DEV)
+    yp.data.fill_(0x55)
+    stats = torch.zeros(2 * n, dtype=torch.float32, device=DEV)
+    indptr, indices, w = dev(g.indptr), dev(g.indices), dev(g.weight)
+    _lib.check(lib.gte_spmm_csr_accumulate_ln_p3(P(indptr), P(indices), P(w), P(t) + 4 * ld, 2 * ld, P(t), 2 * ld, n, f, 1, P(dev(gamma)),
+                                                 P(dev(beta)), 1e-5, int(relu), P(y), ld, P(yp.data), yp.ldp, P(stats),
+                                                 _lib.current_stream()), "accumulate_ln_p3")
+    agg = oc.spmm_csr_numpy(g.indptr, g.indices, g.weight, t_neigh) * g.norm
+    z = t_self + agg
+    np.testing.assert_allclose(t[:, :f].cpu().numpy(), z, rtol=1e-6, atol=1e-6)
+    zt = torch.from_numpy(z).double()
+    want = torch.nn.functional.layer_norm(zt, (f,), torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5)
+    want = (want.relu() if relu else want).numpy()
+    got = y.cpu().numpy()
+    np.testing.assert_allclose(got[:, :f], want, rtol=1e-5, atol=1e-5)
+    assert (got[:, f:] == 0).all()                                    # (with the image: the whole 16-column block is written)
+    img = ops.p3_to_f32(ops.P3(yp.data, n, ld)).cpu().numpy()         # the whole padded image row
+    np.testing.assert_array_equal(img[:, :f], got[:, :f])
+    assert (img[:, f:] == 0).all()
+    np.testing.assert_allclose(stats[:n].cpu().numpy(), z.mean(1), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(stats[n:].cpu().numpy(), 1.0 / np.sqrt(z.astype(np.float64).var(1) + 1e-5), rtol=2e-5)
+
+
+@pytest.mark.parametrize("f", WIDTHS)
+@pytest.mark.parametrize("relu", [True, False])
+def test_layernorm_forward_and_backward_kernels_on_any_width(f, relu):
+    """gte_ln_relu_fwd_p3 and gte_ln_relu_bwd_p3 on padded rows against torch autograd in fp64."""
+    lib, P = _lib.load(), _lib.ptr
+    rng = np.random.default_rng(100 + f)
+    m, ld = 531, c16(f)
+    z = rng.standard_normal((m, f)).astype(np.float32) * 2 + 0.3
+    dy = rng.standard_normal((m, f)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, f).astype(np.float32), rng.standard_normal(f).astype(np.float32) * 0.3
+    zt = torch.from_numpy(z).double().requires_grad_(True)
+    gt, bt = torch.from_numpy(gamma).double().requires_grad_(True), torch.from_numpy(beta).double().requires_grad_(True)
+    yt = torch.nn.functional.layer_norm(zt, (f,), gt, bt, 1e-5)
+    yt = yt.relu() if relu else yt
+    yt.backward(torch.from_numpy(dy).double())
+    zb = _padded(z, ld)
+    zb[:, f:] = 3.0                                                   # garbage in the padding of z must not matter
+    y = torch.zeros((m, ld), dtype=torch.float32, device=DEV)
+    yp = ops.P3.empty(m, f, DEV)
+    yp.data.fill_(0x55)
+    stats = torch.zeros(2 * m, dtype=torch.float32, device=DEV)
+    dg, db = dev(gamma), dev(beta)
+    _lib.check(lib.gte_ln_relu_fwd_p3(P(zb), ld, P(dg), P(db), 1e-5, int(relu), P(y), ld, P(yp.data), yp.ldp, P(stats), m, f,
+                                      _lib.current_stream()), "ln_relu_fwd_p3")
+    np.testing.assert_allclose(y[:, :f].cpu().numpy(), yt.detach().numpy(), rtol=1e-5, atol=1e-5)
+    img = ops.p3_to_f32(ops.P3(yp.data, m, ld)).cpu().numpy()
+    np.testing.assert_array_equal(img[:, :f], y[:, :f].cpu().numpy())
+    assert (img[:, f:] == 0).all()
+    # backward: dz in place of dy, as fp32 + image; column sums
+    dyb = _padded(dy, ld)
+    dyb[:, f:] = -2.0
+    dzp = ops.P3.empty(m, f, DEV)
+    dzp.data.fill_(0x55)
+    dgam, dbet, dbias = (torch.zeros(f, dtype=torch.float32, device=DEV) for _ in range(3))
+    ws = torch.empty(int(lib.gte_ln_relu_bwd_workspace_bytes(m, f)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.gte_ln_relu_bwd_p3(P(dyb), ld, P(zb), ld, P(stats), P(dg), P(db), int(relu), P(dyb), ld, P(dzp.data), dzp.ldp,
+                                      P(dgam), P(dbet), P(dbias), m, f, P(ws), ws.numel(), _lib.current_stream()), "ln_relu_bwd_p3")
+    want_dz = zt.grad.numpy()
+    scale = np.abs(want_dz).max()
+    np.testing.assert_allclose(dyb[:, :f].cpu().numpy(), want_dz, rtol=1e-4, atol=1e-5 * scale)
+    img = ops.p3_to_f32(ops.P3(dzp.data, m, ld)).cpu().numpy()
+    np.testing.assert_array_equal(img[:, :f], dyb[:, :f].cpu().numpy())
+    assert (img[:, f:] == 0).all()
+    np.testing.assert_allclose(dgam.cpu().numpy(), gt.grad.numpy(), rtol=1e-4, atol=1e-4 * np.abs(gt.grad.numpy()).max())
+    np.testing.assert_allclose(dbet.cpu().numpy(), bt.grad.numpy(), rtol=1e-4, atol=1e-4 * np.abs(bt.grad.numpy()).max())
+    np.testing.assert_allclose(dbias.cpu().numpy(), want_dz.sum(0), rtol=1e-4, atol=1e-4 * np.abs(want_dz).sum(0).max())
+
+
+@pytest.mark.parametrize("f", [1, 3, 9, 13, 16, 63, 100, 218, 313, 363, 1000, 1100])
+@pytest.mark.parametrize("mean", [False, True])
+def test_aggregation_into_an_image_is_bitwise_the_fp32_aggregation(f, mean):
+    """gte_spmm_csr_p3 for any width: the image holds exactly the values gte_spmm_csr writes, zeros up to the 16-column block."""
+    lib, P = _lib.load(), _lib.ptr
+    rng = np.random.default_rng(200 + f)
+    n = 1234
+    g = _graph(rng, n)
+    x = dev(rng.standard_normal((n, f)).astype(np.float32))
+    indptr, indices, w = dev(g.indptr), dev(g.indices), dev(g.weight)
+    out = torch.empty((n, f), dtype=torch.float32, device=DEV)
+    _lib.check(lib.gte_spmm_csr(P(indptr), P(indices), P(w), P(x), f, P(out), f, n, f, 0, int(mean), _lib.current_stream()), "spmm")
+    img = ops.P3.empty(n, f, DEV)
+    img.data.fill_(0x55)
+    _lib.check(lib.gte_spmm_csr_p3(P(indptr), P(indices), P(w), P(x), f, P(img.data), img.ldp, n, f, int(mean), _lib.current_stream()),
+               "spmm_p3")
+    got = ops.p3_to_f32(ops.P3(img.data, n, c16(f)))
+    assert torch.equal(got[:, :f], out) and bool((got[:, f:] == 0).all())
+
+
+def test_colsum_is_deterministic_and_exact_on_integers():
+    lib, P = _lib.load(), _lib.ptr
+    rng = np.random.default_rng(5)
+    for m, c, ld in ((1, 9, 32), (1000, 9, 32), (24437, 16, 16), (70000, 1, 5)):
+        x = torch.zeros((m, ld), dtype=torch.float32, device=DEV)
+        vals = rng.integers(-8, 9, (m, c)).astype(np.float32)
+        x[:, :c] = dev(vals)
+        out = torch.full((c,), 99.0, dtype=torch.float32, device=DEV)
+        ws = torch.empty(int(lib.gte_colsum_workspace_bytes(m, c)), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.gte_colsum(P(x), ld, m, c, P(out), P(ws), ws.numel(), _lib.current_stream()), "colsum")
+        np.testing.assert_array_equal(out.cpu().numpy(), vals.sum(0))
+    assert lib.gte_colsum(None, 4, 10, 4, None, None, 0, None) == -1
+
+
+# ---------------------------------------------------------------- whole model on the reference's run shapes
+@pytest.fixture(params=["split_bf16", "f32"])
+def both_gemm_modes(request):
+    prev = ops.set_gemm_mode(request.param)
+    try:
+        yield request.param
+    finally:
+        ops.set_gemm_mode(prev)
+
+
+def _case_graph(src, dst, w, x):
+    g = G.PageGraph(src, dst, len(x), device=DEV)
+    g.ndata["feat"], g.edata["feat"] = dev(x), dev(w)
+    return g
+
+
+@pytest.mark.parametrize("name", SHAPE_CASES)
+def test_run_shape_step_matches_reference_golden(name, both_gemm_modes):
+    """One optimisation step of the step engine (in the default GEMM mode: the one-call plan on the planes kernels -- asserted)
+    on a shape the reference's runs use, against the fixture generated from the reference's models.py."""
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    z, src, dst, w, x, y, state0, model = poststep.trimmed_case(GOLDEN_DIR, name)
+    n, f0, hid = (int(v) for v in z["meta"][:3])
+    model = model.to(DEV)
+    g = _case_graph(src, dst, w, x)
+    fused = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+    on_plan = fused._planes_on()
+    if on_plan:
+        kinds = fused._plan_kinds(f0, n)
+        assert kinds is not None, "every run shape of the reference is on the one-call plan"
+        gen, out_gemm = fused._plan_mode(kinds, f0)
+        assert kinds[1:] == [0] * (len(kinds) - 1) and kinds[0] == (0 if 4 * hid <= 5 * f0 else 2)
+        assert out_gemm == (hid > 256 or hid % 8 != 0)
+    logits = fused.forward_logits(g).cpu().numpy()                  # gte_gcnsage_forward on the plan (module path in fp32 mode)
+    np.testing.assert_allclose(logits, z["logits"], rtol=1e-5, atol=1e-5)
+    out3 = fused.step(g, dev(y).float())
+    if on_plan:
+        assert any(k[0] == "gen" for k in fused._bufs), "the step ran on the general plan's buffer set"
+    grads = {k: fused._gslice[id(p)].cpu().numpy() for k, p in model.named_parameters()}
+    params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    after = fused.forward_logits(g).cpu().numpy()
+    og = oc.OracleGraph(src, dst, len(x), w)
+    ref_after = oc.gcnsage_forward({k: torch.from_numpy(v) for k, v in params.items()}, og, torch.from_numpy(x)).numpy()
+    poststep.check_headline(z, logits, [], float(out3[0]), grads, params, after, state0, oracle_after=ref_after)
+    assert int(out3[2]) == int((z["logits"].argmax(1) == y).sum())
+
+
+@pytest.mark.parametrize("name", ["shape_f13_h218", "shape_f363_h149", "shape_f63_h1000"])
+def test_run_shape_module_forward_matches_reference_golden(name, both_gemm_modes):
+    """``model(g)`` (autograd path) on the same shapes: logits and hidden activations at the north_star tolerance."""
+    z, src, dst, w, x, y, state0, model = poststep.trimmed_case(GOLDEN_DIR, name)
+    model = model.to(DEV)
+    g = _case_graph(src, dst, w, x)
+    hidden = []
+    hooks = [l.register_forward_hook(lambda m, i, o: hidden.append(o.detach().cpu().numpy())) for l in model.layers]
+    with torch.no_grad():
+        logits = model(g).cpu().numpy()
+    for h in hooks:
+        h.remove()
+    np.testing.assert_allclose(logits, z["logits"], rtol=1e-5, atol=1e-5)
+    for i, h in enumerate(hidden[:2]):
+        np.testing.assert_allclose(h[::16], z[f"hidden_rows16.{i}"], rtol=1e-5, atol=2e-5)
+
+
+def _resident(pages, tr, f0):
+    graphs = []
+    for p in pages:
+        g = gte.PageGraph(p.src, p.dst, p.num_nodes)
+        g.ndata["feat"], g.ndata["label"] = torch.from_numpy(p.feat), torch.from_numpy(p.label.astype(np.float32))
+        g.edata["feat"] = torch.from_numpy(p.weight)
+        graphs.append(g)
+    return G.ResidentPages(graphs, DEV)
+
+
+@pytest.mark.parametrize("f0,hid,n_pages", [(831, 256, 100), (831, 96, 40), (63, 1000, 16), (13, 218, 40), (831, 1000, 12)])
+def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages):
+    """The path ``bench.py`` and ``train()`` run -- ResidentPages (features as a P3 image + row map where layer 0 takes one),
+    BatchPipeline, run_steps, the one-call step with Adam in the fold launch -- for ONE step on n_pages pages against the CPU
+    oracle's step on the same pages: logits 1e-5 (forward_logits on the assembled batch), loss 1e-5, every gradient 1e-4,
+    parameters / post-step logits per tests/poststep.py.  (831, 256, 100 pages) is the headline configuration at full size."""
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    from gnn_tableextraction_amd.models.loop import BatchPipeline, run_steps
+    pages = S.make_pages(n_pages + 7, in_feats=f0)
+    ids = np.arange(3, 3 + n_pages)
+    src, dst, w, feat, label, off = S.concat_pages([pages[i] for i in ids])
+    n = int(off[-1])
+    torch.manual_seed(42)
+    model = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0)
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    og = oc.OracleGraph(src, dst, n, w)
+    xt, yt = torch.from_numpy(feat), torch.from_numpy(label)
+    want_logits = oc.gcnsage_forward(state0, og, xt).numpy()
+    tr_o = oc.OracleTrainer(state0, lr=0.01, weight_decay=5e-4)
+    want_loss, _ = tr_o.step(og, xt, yt)
+    want_grads = {k: v.numpy() for k, v in tr_o.grads().items()}
+    want_state = {k: v.detach().numpy() for k, v in tr_o.state.items()}
+
+    model = model.to(DEV)
+    fused = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+    assert fused._plan_kinds(f0, n) is not None
+    res = _resident(pages, fused, f0)
+    pipe = BatchPipeline(res)
+    seen = {}
+
+    def on_step(s, g, out3):
+        seen["n"] = g.num_nodes()
+    # forward only, on the batch the pipeline assembles (row-map batch in image mode)
+    if fused.wants_p3_features(f0):
+        res.enable_p3()
+        assert res.p3_mode == "rows"
+    logits = fused.forward_logits(res.batch(ids)).cpu().numpy()
+    np.testing.assert_allclose(logits, want_logits, rtol=1e-5, atol=1e-5)
+    out3 = run_steps(fused, pipe, [ids], on_step=on_step)
+    torch.cuda.synchronize()
+    assert seen["n"] == n and fused.adam_fused_steps == 1
+    assert abs(float(out3[0]) - want_loss) < 1e-5
+    for k, p in model.named_parameters():
+        got, ref = fused._gslice[id(p)].cpu().numpy(), want_grads[k]
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(ref).max())
+    params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    g_eff = {k: np.abs(want_grads.get(k, np.zeros_like(v)) + 5e-4 * state0[k].numpy()) for k, v in want_state.items()}
+    hyb = poststep.hybrid_state(want_state, params, g_eff)
+    after = fused.forward_logits(res.batch(ids)).cpu().numpy()
+    ref_after = oc.gcnsage_forward(hyb, og, xt).numpy()
+    assert np.abs(after - ref_after).max() < 1e-4

@@ -13,7 +13,8 @@ from tests import poststep
 from tests.conftest import GOLDEN_DIR
 
 GCN_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                   if not os.path.basename(p).startswith(("meansage", "aux_", "headline")))
+                   if not os.path.basename(p).startswith(("meansage", "aux_", "headline", "shape_")))
+SHAPE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "shape_*.npz")))
 
 
 def load_case(name):
@@ -121,3 +122,23 @@ def test_headline_shape_case_matches_reference():
         after = oc.gcnsage_forward({k: v.detach() for k, v in tr.state.items()}, g, torch.from_numpy(x)).numpy()
     poststep.check_headline(z, logits.numpy(), [h.numpy() for h in hidden], loss, {k: v.numpy() for k, v in tr.grads().items()},
                             {k: v.detach().numpy() for k, v in tr.state.items()}, after, state0)
+
+
+@pytest.mark.parametrize("name", SHAPE_CASES)
+def test_reference_run_shapes_match_reference(name):
+    """The reference's OWN run shapes (run_multiple_train.sh:8-113: --h_layer_dim=1000, or int(calculate_hidden) for 100 000
+    parameters): hidden 1000 / 218 / 149 / 139 / 100 / 96 with F0 = 13 ... 831, trimmed fixtures generated from the reference's
+    models.py; the oracle's forward, loss, gradients and post-step state against them."""
+    z, src, dst, w, x, y, state0, _ = poststep.trimmed_case(GOLDEN_DIR, name)
+    g = oc.OracleGraph(src, dst, len(x), w)
+    logits, hidden = oc.gcnsage_forward(state0, g, torch.from_numpy(x), return_hidden=True)
+    tr = oc.OracleTrainer(state0, lr=0.01, weight_decay=5e-4)
+    loss, _ = tr.step(g, torch.from_numpy(x), torch.from_numpy(y))
+    with torch.no_grad():
+        after = oc.gcnsage_forward({k: v.detach() for k, v in tr.state.items()}, g, torch.from_numpy(x)).numpy()
+    poststep.check_headline(z, logits.numpy(), [h.numpy() for h in hidden], loss, {k: v.numpy() for k, v in tr.grads().items()},
+                            {k: v.detach().numpy() for k, v in tr.state.items()}, after, state0)
+
+
+def test_shape_cases_cover_the_reference_grid():
+    assert {"shape_f13_h218", "shape_f363_h149", "shape_f63_h1000", "shape_f831_h96", "shape_f831_h1000"} <= set(SHAPE_CASES)
