@@ -504,7 +504,8 @@ def _sage_layer_transform_first(graph, h, weight, bias, gamma, beta, edge_weight
     csr = graph.in_csr()
     w = graph.in_weights(edge_weight)
     y = torch.empty((n, fout), dtype=torch.float32, device=h.device)
-    if lib.gte_spmm_csr_accumulate_ln_supported(fout) and not use_tiled(n, fout, csr.indices.numel(), fused_ln=True):
+    # (unpadded rows here: the fused kernel's 16-byte chunks need fout % 4 == 0)
+    if fout % 4 == 0 and lib.gte_spmm_csr_accumulate_ln_supported(fout) and not use_tiled(n, fout, csr.indices.numel(), fused_ln=True):
         check(lib.gte_spmm_csr_accumulate_ln(ptr(csr.indptr), ptr(csr.indices), ptr(w), ptr(t) + 4 * fout, 2 * fout, ptr(t),
                                              2 * fout, n, fout, _lib.REDUCE_MEAN, ptr(gamma), ptr(beta), float(eps), int(relu),
                                              ptr(y), fout, None, current_stream()), "gte_spmm_csr_accumulate_ln")

@@ -104,7 +104,7 @@ def test_spmm_accumulate_ln_epilogue_matches_the_two_kernels(f, relu):
     y / stats to 1e-6: the row sums are taken in a different order)."""
     lib = gte._lib.load()
     P, cs, check = gte._lib.ptr, gte._lib.current_stream, gte._lib.check
-    assert lib.gte_spmm_csr_accumulate_ln_supported(f) and not lib.gte_spmm_csr_accumulate_ln_supported(258)
+    assert lib.gte_spmm_csr_accumulate_ln_supported(f) and lib.gte_spmm_csr_accumulate_ln_supported(258) and not lib.gte_spmm_csr_accumulate_ln_supported(1028)
     rng = np.random.default_rng(f)
     n, e = 1003, 7000
     g = oc.OracleGraph(rng.integers(0, n, e), rng.integers(0, n, e), n, rng.random(e).astype(np.float32))
