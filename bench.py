@@ -484,12 +484,37 @@ def shapes_probe(args, gte, dev, page_sets, loop):
                  "mfma_bound_nodes_per_s": peak * 1e12 / flops_node,
                  "frac_of_mfma_bound": nodes / el / (peak * 1e12 / flops_node)}
         if kinds is not None and trainer._planes_on():
-            ms0, fl0 = forward_gemm_rate(ops, n_step, f0, hid, dev, aggregate_first=kinds[0] == 2) if kinds[0] != 1 else (0.0, 0.0)
-            ms1, fl1 = forward_gemm_rate(ops, n_step, hid, hid, dev)
-            entry["forward_gemms"] = {"layer0_ms": ms0, "layer1_ms": ms1, "tflops_fp32_eq": (fl0 + fl1) / ((ms0 + ms1) * 1e-3) / 1e12,
-                                      "frac_of_peak": (fl0 + fl1) / ((ms0 + ms1) * 1e-3) / 1e12 / peak, "peak_tflops": peak,
-                                      "layer0_tflops": fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else None,
-                                      "layer1_tflops": fl1 / (ms1 * 1e-3) / 1e12}
+            # the forward transform GEMMs of the two hidden layers INSIDE the loop: HIP events recorded by the one-call step on its
+            # launch stream around those launches (gte_step_plan.fwd_events), eight more steps of the same loop, one at a time
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            trainer.fwd_events = evs
+            more, e = epoch_steps(sizes, args.pages, 42, e, 8)
+            ms, fl = [0.0, 0.0], [0.0, 0.0]
+            for plan_ in more:
+                for ids in plan_:
+                    loop.run_steps(trainer, pipe, [ids])
+                    torch.cuda.synchronize()
+                    nn = pipe.nodes(0)
+                    for li in range(2):
+                        if kinds[li] == 1:
+                            continue
+                        ms[li] += evs[2 * li].elapsed_time(evs[2 * li + 1])
+                        fl[li] += 2.0 * nn * (f0 if li == 0 else hid) * 2 * hid
+            trainer.fwd_events = None
+            tot_ms, tot_fl = ms[0] + ms[1], fl[0] + fl[1]
+            entry["forward_gemms"] = {"how": "HIP events on the launch stream around the two hidden layers' forward GEMM launches, 8 steps "
+                                             "of the same loop (an event pair costs ~5 us of the interval it brackets)",
+                                      "layer0_ms": ms[0] / 8, "layer1_ms": ms[1] / 8, "tflops_fp32_eq": tot_fl / (tot_ms * 1e-3) / 1e12,
+                                      "frac_of_peak": tot_fl / (tot_ms * 1e-3) / 1e12 / peak, "peak_tflops": peak,
+                                      "layer0_tflops": fl[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else None,
+                                      "layer1_tflops": fl[1] / (ms[1] * 1e-3) / 1e12}
+            iso0 = forward_gemm_rate(ops, n_step, f0, hid, dev, aggregate_first=kinds[0] == 2) if kinds[0] != 1 else (0.0, 0.0)
+            iso1 = forward_gemm_rate(ops, n_step, hid, hid, dev)
+            entry["forward_gemms"]["isolated_random_operands"] = {
+                "layer0_ms": iso0[0], "layer1_ms": iso1[0],
+                "tflops_fp32_eq": (iso0[1] + iso1[1]) / ((iso0[0] + iso1[0]) * 1e-3) / 1e12,
+                "note": "dense N(0,1) operands, 10 launches per event pair: the matrix pipe runs at the power limit, and the loop's "
+                        "post-ReLU activations (half zeros) toggle fewer bits"}
         if (f0, hid) == (831, 1000):
             # the same loop with the fp32 MFMA kernels
             prev = ops.set_gemm_mode("f32")

@@ -225,7 +225,8 @@ class StepPlan(ctypes.Structure):
                 ("out_gemm", c_int), ("ld_lg", c_int64), ("hp_out", c_void_p), ("ldp_hout", c_int64),
                 ("wimg_out_fwd", c_void_p), ("ldp_wout_fwd", c_int64), ("wimg_out_bwd", c_void_p), ("ldp_wout_bwd", c_int64),
                 ("dlqp", c_void_p), ("ldp_dlq", c_int64), ("ws_out", c_void_p), ("ws_out_bytes", c_int64),
-                ("ws_ce", c_void_p), ("ws_ce_bytes", c_int64), ("ws_cs", c_void_p), ("ws_cs_bytes", c_int64)]
+                ("ws_ce", c_void_p), ("ws_ce_bytes", c_int64), ("ws_cs", c_void_p), ("ws_cs_bytes", c_int64),
+                ("fwd_events", c_void_p)]
 
 
 class BatchArrays(ctypes.Structure):

@@ -1385,7 +1385,10 @@ int launch_nt(const P3Gemm& p, hipStream_t s) {
 
 // ---- the NT product with the LayerNorm(+ReLU) backward of the layer below as its epilogue ------------------------------
 namespace {
-int lnb_row_tile(int64_t m) { return gte::ceil_div(m, 128) <= gte::device_props().cus ? 128 : 192; }
+// Row tile of the fused dX + LayerNorm-backward launch: 128.  (A 192-row instantiation served m > 128 x #CUs until round 3: its
+// epilogue's row slice + 96 accumulator registers did not fit the 170-register budget of three waves per SIMD -- 140 bytes of
+// scratch per lane.  Batches beyond one round of 128-row tiles run several rounds of the same kernel.)
+int lnb_row_tile(int64_t) { return 128; }
 // out[j] = sum_k part[k * stride + j]   (only when no fold deferral is open)
 __global__ void __launch_bounds__(256)
 p3_colsum_fold_kernel(const float* __restrict__ part, long long stride, int count, int n, float* __restrict__ out) {
@@ -1438,7 +1441,7 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
     p.ln_part = reinterpret_cast<float*>(workspace);
     hipStream_t s = gte::as_stream(stream);
     const int bm = lnb_row_tile(m);
-    if (bm == 128) launch_lw_lnb<2, 4, 2, 2, 4>(p, s); else launch_lw_lnb<2, 4, 3, 2, 4>(p, s);
+    launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
     int rc = gte::check_launch("gemm_p3_nt_ln_bwd");
     if (rc != GTE_OK) return rc;
     const int nb = (int)gte::ceil_div(m, bm);

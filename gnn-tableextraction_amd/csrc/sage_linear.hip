@@ -598,18 +598,23 @@ gemm_tn_skinny_kernel(const float* __restrict__ A, int64_t lda, const float* __r
         const int r = i / SK_MAX, c = i % SK_MAX;
         sA[r][c] = (r < nk && c < M) ? A[(int64_t)(k0 + r) * lda + c] : 0.f;
     }
-    float b[SK_ROWS];
     const int nn = min(n, N - 1);
-#pragma unroll
-    for (int r = 0; r < SK_ROWS; ++r) b[r] = B[(int64_t)(k0 + min(r, nk - 1)) * ldb + nn];
     __syncthreads();
     float acc[SK_MAX];
 #pragma unroll
     for (int i = 0; i < SK_MAX; ++i) acc[i] = 0.f;
+    // Eight k rows per trip of a loop that is NOT unrolled: fully unrolled (32 rows), the compiler hoisted all 512 broadcast
+    // reads of sA in front of the FMAs -- 256 VGPRs + 256 AGPRs and 148 bytes of scratch per lane.  Eight B loads in flight per
+    // thread, the other waves of the CU cover the rest.
+#pragma unroll 1
+    for (int r0 = 0; r0 < SK_ROWS; r0 += 8) {
+        float b[8];
 #pragma unroll
-    for (int r = 0; r < SK_ROWS; ++r) {
+        for (int r = 0; r < 8; ++r) b[r] = B[(int64_t)(k0 + min(r0 + r, nk - 1)) * ldb + nn];
 #pragma unroll
-        for (int i = 0; i < SK_MAX; ++i) acc[i] = fmaf(sA[r][i], b[r], acc[i]);   // rows >= nk hold zeros in sA
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < SK_MAX; ++i) acc[i] = fmaf(sA[r0 + r][i], b[r], acc[i]);   // rows >= nk hold zeros in sA
     }
     if (n < N) {
         float* out = slab + (int64_t)blockIdx.y * M * N;

@@ -27,6 +27,9 @@ int forward_hidden(const gte_step_plan& p, void* st) {
         for (int k = 0; k < p.n_wimg_descs; k += 16)
             GTE_TRY(gte_p3_from_f32_batch(d + k, p.n_wimg_descs - k < 16 ? p.n_wimg_descs - k : 16, st));
     }
+    auto mark = [&](int k) {        // (measurement: an event in front of / behind a layer's forward GEMM)
+        if (p.fwd_events && p.fwd_events[k]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p.fwd_events[k]), gte::as_stream(st));
+    };
     for (int i = 0; i < p.n_hidden; ++i) {
         const gte_step_layer& L = p.layer[i];
         const int64_t ld = ldf(L);
@@ -47,19 +50,23 @@ int forward_hidden(const gte_step_plan& p, void* st) {
             // model whose hidden width exceeds its input width (aggregating fin columns is the cheaper order, models.py:53-72)
             GTE_TRY(gte_p3_from_f32(L.x, L.ldx, n, L.fin, 0, L.hp, L.ldp_h, st));
             GTE_TRY(gte_spmm_csr_p3(p.indptr, p.indices, p.w_in, L.x, L.ldx, L.ahnp, L.ldp_ahn, n, L.fin, GTE_REDUCE_MEAN, st));
+            mark(2 * i);
             GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, L.ahnp, L.ldp_ahn, L.fin, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, ld, n, L.fout,
                                    0, 0, st));
+            mark(2 * i + 1);
             GTE_TRY(gte_ln_relu_fwd_p3(L.t, ld, L.gamma, L.beta, L.eps, L.relu, L.y, ld, L.yp, L.ldp_y, L.stats, n, L.fout, st));
             continue;
         }
         if (L.make_hp) GTE_TRY(gte_p3_from_f32(L.x, L.ldx, n, L.fin, 0, L.hp, L.ldp_h, st));
         // t = [t_self | t_neigh], each half ld columns wide (the weight image holds zero rows behind the fout rows of a half)
+        mark(2 * i);
         if (L.h_rows)
             GTE_TRY(gte_gemm_p3_nt_rows(L.hp, L.ldp_h, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * ld,
                                         n, 2 * ld, 0, 0, st));
         else
             GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, nullptr, 0, 0, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * ld, n,
                                    2 * ld, 0, 0, st));
+        mark(2 * i + 1);
         GTE_TRY(gte_spmm_csr_accumulate_ln_p3(p.indptr, p.indices, p.w_in, L.t + ld, 2 * ld, L.t, 2 * ld, n, L.fout,
                                               GTE_REDUCE_MEAN, L.gamma, L.beta, L.eps, L.relu, L.y, ld, L.yp, L.ldp_y, L.stats, st));
     }

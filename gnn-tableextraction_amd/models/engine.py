@@ -211,6 +211,10 @@ class FusedGcnSageStep(TrainStep):
         # it then runs on the side stream under that GEMM, and the batch is still in the Infinity Cache when the next
         # step's first GEMM reads it.
         self.before_last_gemm = None
+        # measurement hook of the one-call step (bench.py): a list of 2 x n_hidden torch.cuda.Event(enable_timing=True), recorded
+        # around the forward transform GEMM of every hidden layer of the NEXT steps (None: off)
+        self.fwd_events = None
+        self._fwd_ev_arr = None
 
     # -- buffers -------------------------------------------------------------------------------------
     def _alloc(self, cap: int, f0: int):
@@ -842,6 +846,14 @@ class FusedGcnSageStep(TrainStep):
         lab = labels if labels.dtype in (torch.float32, torch.int64) else labels.to(torch.int64)
         plan.labels, plan.labels_f32 = P(lab), int(lab.dtype == torch.float32)
         plan.grad_scale = float(grad_scale)
+        if self.fwd_events:
+            for e in self.fwd_events:
+                if not e.cuda_event:                  # (created lazily by the first record)
+                    e.record()
+            self._fwd_ev_arr = (ctypes.c_void_p * len(self.fwd_events))(*[e.cuda_event for e in self.fwd_events])
+            plan.fwd_events = ctypes.addressof(self._fwd_ev_arr)
+        else:
+            plan.fwd_events = None
         capturing = torch.cuda.is_current_stream_capturing()
         sig = self._param_sig()
         sig = (sig, b["_wkey"])                   # (which image set: a plan of another layout keeps its own images)

@@ -450,6 +450,9 @@ typedef struct gte_step_plan {
     void* ws_out; int64_t ws_out_bytes;    /* split-K workspace of dW_out: gte_gemm_p3_tn_workspace_bytes(C, 2 out_fin, out_fin, n) */
     void* ws_ce; int64_t ws_ce_bytes;      /* gte_weighted_ce workspace                                                     */
     void* ws_cs; int64_t ws_cs_bytes;      /* gte_colsum workspace                                                          */
+    /* measurement (NULL: off): hipEvent_t handles, recorded on `stream` in front of ([2 i]) and behind ([2 i + 1]) the forward
+     * transform GEMM of hidden layer i -- the roofline figure of a shape is timed inside the loop it belongs to */
+    void* const* fwd_events;
 } gte_step_plan;
 /* *adam_fused: bit 0 = the optimiser step ran inside the fold launch, bit 1 = ... and it wrote the weight images */
 int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
