@@ -89,7 +89,7 @@ SIGNATURES = {
     "gte_sage_narrow_bwd_ln_p3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                           c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                           c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
-                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_gemm_p3_nt_ln_bwd_supported": (c_int, [c_int64]),
     "gte_gemm_p3_nt_ln_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "gte_gemm_p3_nt_ln_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
@@ -110,8 +110,6 @@ SIGNATURES = {
                                c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gte_adam_ticket_bytes": (c_int64, []),
     "gte_gcnsage_step": (c_int, [c_void_p, c_int, POINTER(c_int), c_void_p]),
-    "gte_gcnsage_step_graph": (c_int, [c_void_p, POINTER(c_int), c_void_p, POINTER(c_void_p)]),
-    "gte_step_graph_destroy": (c_int, [c_void_p]),
     "gte_gcnsage_forward": (c_int, [c_void_p, c_void_p]),
     "gte_fold_defer_begin": (c_int, [c_void_p]),
     "gte_fold_defer_flush": (c_int, []),
@@ -144,10 +142,6 @@ SIGNATURES = {
                                        c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                        c_void_p, c_float, c_void_p, c_void_p]),
     "gte_sage_narrow_bwd_ln_workspace_bytes": (c_int64, [c_int64, c_int64]),
-    "gte_sage_narrow_bwd_ln": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
-                                       c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
-                                       c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
-                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_ln_relu_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p,
                                 c_int64, c_int64, c_void_p]),
     "gte_ln_relu_fwd_p3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p, c_int64,

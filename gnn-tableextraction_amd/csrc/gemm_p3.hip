@@ -504,154 +504,8 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
                            p.accumulate, lane);
 }
 
-// The same ring kernel on v_mfma_f32_16x16x32_bf16.  One MFMA covers K = 32: the two 16-deep halves are TWO PLANE PRODUCTS of
-// the same 16-feature block -- lanes 0-31 supply plane pair (a_x, b_y), lanes 32-63 pair (a_u, b_v), the matrix unit adds both:
-//     (a_h | a_l) x (b_l | b_h) = hl + lh,   (a_m | a_h) x (b_m | b_m) = mm + hm,   (a_m | a_h) x (b_h | b_h) = mh + hh
-// -- the six products in three instructions of half the cycles each (same matrix-pipe time), smallest terms first.  Why: on
-// gfx950 a 16x16x32 stream holds a higher clock under the power limit than a 32x32x16 stream of the same flops
-// (MI355X_MICROARCH.md, DVFS note 7); measured here in profiles/r03/gemm_p3.md.  A fragment is one ds_read_b128 with a per-lane
-// plane: lane l reads (row l & 15, k half (l >> 4) & 1, plane by l >> 5); rows of 96 bytes make the four 16-lane service
-// groups of that read conflict-free without a swizzle.  The sum order differs from the 32x32 kernels: not bitwise equal to
-// them, same error against fp64.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int WM, int WN, int TM, int TN, int NBUF, int WGS>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN * WGS + 3) / 4)
-gemm_p3_nt_ring16_kernel(const P3Gemm p) {
-    constexpr int NW = WM * WN;
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, RM = 2 * TM, RN = 2 * TN;
-    constexpr int A_INST = BM * 96 / 1024, B_INST = BN * 96 / 1024, N_INST = A_INST + B_INST;
-    constexpr int A_BYTES = BM * 96;
-    constexpr int NI = (N_INST + NW - 1) / NW;
-    constexpr int STAGE = NI * NW * 1024;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const unsigned lb = gte_xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = (int)(lb / (unsigned)tiles_n), tn = (int)(lb % (unsigned)tiles_n);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int rowsA = min(BM, p.M - m0), rowsB = min(BN, p.N - n0);
-
-    const int lda1 = (int)p.lda1, lda2 = (int)(p.A2 ? p.lda2 : p.lda1), ldb = (int)p.ldb;
-    const char* baseA1 = p.rowsA ? p.A1 : p.A1 + (long long)m0 * p.lda1;
-    const char* baseA2 = p.A2 ? p.A2 + (long long)m0 * p.lda2 : baseA1;
-    const int recA1 = p.rowsA ? (int)(unsigned)p.res_bytes : rowsA * (int)p.lda1;     // window of segment 1
-    const char* baseB = p.B + (long long)n0 * p.ldb;
-    const long long bsa1 = p.bsa1, bsa2 = p.A2 ? p.bsa2 : p.bsa1, bsb = p.bsb;
-
-    constexpr int OOB = 0x7f000000;
-    int vo1[NI], vo2[NI], isb[NI];
-    static_for<NI>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        const int ii = i * NW + wave;
-        const bool b = ii >= A_INST;
-        const int s = (b ? ii - A_INST : ii) * 64 + lane, row = s / 6, part = s - row * 6;      // image in memory order: no swizzle
-        isb[i] = b ? 1 : 0;
-        vo1[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda1) + part * 16;
-        vo2[i] = ii >= N_INST ? OOB : row * (b ? ldb : lda2) + part * 16;
-    });
-    const int KB1 = p.KB1, T = p.KB1 + p.KB2;
-    auto issue = [&](int t, char* buf) {
-        const bool seg = t >= KB1;
-        const int live = t < T ? 1 : 0;
-        const char* pa = seg ? baseA2 + (long long)(t - KB1) * bsa2 : baseA1 + (long long)t * bsa1;
-        const __amdgpu_buffer_rsrc_t sa =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? rowsA * lda2 : recA1) * live, SRD_FLAGS);
-        const __amdgpu_buffer_rsrc_t sb =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
-        static_for<NI>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            dma16(isb[i] ? sb : sa, buf + (i * NW + wave) * 1024, seg ? vo2[i] : vo1[i]);
-        });
-    };
-
-    // per-lane fragment addresses: row l & 15 of a 16-row tile, k half (l >> 4) & 1, plane by the lane's half-wave
-    const int r16 = lane & 15, kh = (lane >> 4) & 1, ps = lane >> 5;
-    const int a_row = (wm * TM * 32 + r16) * 96 + kh * 16, b_row = A_BYTES + (wn * TN * 32 + r16) * 96 + kh * 16;
-    const int a_t0 = a_row + (ps ? 2 : 0) * 32;            // (a_h | a_l)
-    const int a_t1 = a_row + (ps ? 0 : 1) * 32;            // (a_m | a_h)
-    const int b_t0 = b_row + (ps ? 0 : 2) * 32;            // (b_l | b_h)
-    const int b_t1 = b_row + 1 * 32;                       // (b_m | b_m)
-    const int b_t2 = b_row + 0 * 32;                       // (b_h | b_h)
-
-    f32x4v acc[RM][RN];
-#pragma unroll
-    for (int a = 0; a < RM; ++a)
-#pragma unroll
-        for (int b = 0; b < RN; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
-
-    int next = 0, wr = 0;
-#pragma unroll
-    for (int d = 0; d < NBUF - 1; ++d) {
-        issue(next, lds + wr * STAGE);
-        ++next;
-        wr = wr + 1 == NBUF ? 0 : wr + 1;
-    }
-    wait_dma_barrier<(NBUF - 2) * NI>();
-    int rd = 0;
-    for (int t = 0; t < T; ++t) {
-        issue(next, lds + wr * STAGE);
-        ++next;
-        wr = wr + 1 == NBUF ? 0 : wr + 1;
-        const char* buf = lds + rd * STAGE;
-        bf16x8 fa0[RM], fa1[RM], fb0[RN], fb1[RN], fb2[RN];
-        static_for<RM>([&](auto A) { constexpr int a = decltype(A)::value; fa0[a] = *reinterpret_cast<const bf16x8*>(buf + a_t0 + a * 16 * 96); });
-        static_for<RN>([&](auto B) { constexpr int b = decltype(B)::value; fb0[b] = *reinterpret_cast<const bf16x8*>(buf + b_t0 + b * 16 * 96); });
-        static_for<RM>([&](auto A) { constexpr int a = decltype(A)::value; fa1[a] = *reinterpret_cast<const bf16x8*>(buf + a_t1 + a * 16 * 96); });
-        static_for<RN>([&](auto B) { constexpr int b = decltype(B)::value; fb1[b] = *reinterpret_cast<const bf16x8*>(buf + b_t1 + b * 16 * 96); });
-        static_for<RN>([&](auto B) { constexpr int b = decltype(B)::value; fb2[b] = *reinterpret_cast<const bf16x8*>(buf + b_t2 + b * 16 * 96); });
-#pragma unroll
-        for (int a = 0; a < RM; ++a)
-#pragma unroll
-            for (int b = 0; b < RN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[a], fb0[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int a = 0; a < RM; ++a)
-#pragma unroll
-            for (int b = 0; b < RN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[a], fb1[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int a = 0; a < RM; ++a)
-#pragma unroll
-            for (int b = 0; b < RN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[a], fb2[b], acc[a][b], 0, 0, 0);
-        wait_dma_barrier<(NBUF - 2) * NI>();
-        rd = rd + 1 == NBUF ? 0 : rd + 1;
-    }
-    // epilogue: C/D of the 16 x 16 form: col = lane & 15, row = 4 (lane >> 4) + register
-    {
-        const int col_l = lane & 15, rquad = (lane >> 4) * 4;
-        const long long ldo = p.ldc;
-        const __amdgpu_buffer_rsrc_t c_srd =
-            __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((long long)(p.M - 1) * ldo + p.N) * 4), SRD_FLAGS);
-        const int ld4 = (int)ldo * 4;
-        const bool post = p.accumulate || p.relu;
-#pragma unroll
-        for (int b = 0; b < RN; ++b) {
-            const int col = n0 + wn * TN * 32 + b * 16 + col_l;
-            const bool cok = col < p.N;
-            const int coff = cok ? col * 4 : (int)0x80000000;
-            const float bv = (p.bias && cok && (p.bias_cols <= 0 || col < p.bias_cols)) ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int a = 0; a < RM; ++a) {
-                const int roff0 = (m0 + wm * TM * 32 + a * 16 + rquad) * ld4 + coff;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int off = roff0 + r * ld4;
-                    float v = acc[a][b][r] + bv;
-                    if (post) {
-                        if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_srd, off, 0, 0));
-                        if (p.relu) v = fmaxf(v, 0.f);
-                    }
-                    asm volatile("" : "+v"(v));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_srd, off, 0, 0);
-                }
-            }
-        }
-    }
-}
+// (A variant of the ring kernel on v_mfma_f32_16x16x32_bf16 -- two plane products per instruction -- was measured in round 3 and
+// removed in round 4: same matrix-pipe time, no clock advantage at these tile shapes; profiles/r03/gemm_p3.md section 5.)
 
 // NT with LOADER WAVES: WM x WN compute waves (fragment reads + MFMAs only) and NL loader waves that issue every LDS-DMA
 // instruction of the workgroup.  In the ring kernel above each wave spends ~NI x 60-100 issue cycles per stage on its DMA
@@ -1166,18 +1020,12 @@ p3_to_f32_kernel(const char* __restrict__ src, long long ldp, int rows, int cols
     dst[(long long)r * ld + c] = p3::load1(src + (long long)r * ldp, c);
 }
 
-// TN tile: 128 x 128 (4 waves, two workgroups per CU).  The 256 x 128 tile (8 waves, one per CU; GTE_P3_TN_BIG=1) needs a
-// quarter less operand traffic per flop but measured slower on both dW shapes of the step (126 vs 115 us, 59 vs 55 us).
-int tn_big(int64_t M) {
-    static const int forced = getenv("GTE_P3_TN_BIG") ? atoi(getenv("GTE_P3_TN_BIG")) : 0;
-    return forced == 1 && M > 128 ? 1 : 0;
-}
-
+// TN tile: 128 x 128 (4 waves, two workgroups per CU).  (The 256 x 128 tile -- 8 waves, one workgroup per CU, a quarter less
+// operand traffic per flop -- measured slower on both dW shapes of the step, 126 vs 115 us and 59 vs 55 us, and was removed.)
 struct TnPlan { int splits, stages_per_split, splits_bound; };
 TnPlan tn_plan(int64_t M, int64_t N, int64_t Nseg, int64_t K) {
     const int cus = gte::device_props().cus;
-    const int big = tn_big(M);
-    const int64_t bm = big ? 256 : 128, slots = big ? cus : 2 * cus;
+    const int64_t bm = 128, slots = 2 * cus;
     const int64_t tiles = gte::ceil_div(M, bm) * (Nseg > 0 ? 2 * gte::ceil_div(Nseg, 128) : gte::ceil_div(N, 128));
     const int64_t stages = gte::ceil_div(K > 0 ? K : 1, 16);
     // fill the resident slots exactly or stay below (a straggler round costs a whole unit time); >= 8 stages per split
@@ -1334,21 +1182,9 @@ void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
 struct NtCfg { int id, bm, bn, wgs; };
 constexpr NtCfg kNtCfg[] = {{0, 64, 128, 3}, {1, 128, 128, 2}, {2, 128, 256, 1}, {3, 160, 256, 1}, {4, 192, 256, 1}, {5, 224, 256, 1},
                             {6, 256, 256, 1}};
-template <int WM, int WN, int TM, int TN, int NBUF, int WGS>
-void launch_ring16(const P3Gemm& p, hipStream_t s) {
-    constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int NI = ((BM + BN) * 96 / 1024 + NW - 1) / NW, shm = NBUF * NI * NW * 1024;
-    static bool configured = false;
-    if (!configured) {
-        GTE_SET_LDS((gemm_p3_nt_ring16_kernel<WM, WN, TM, TN, NBUF, WGS>), shm);
-        configured = true;
-    }
-    const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
-    hipLaunchKernelGGL((gemm_p3_nt_ring16_kernel<WM, WN, TM, TN, NBUF, WGS>), grid, dim3(NW * 64), shm, s, p);
-}
 int nt_choose(const P3Gemm& p) {
     static const int forced = getenv("GTE_P3_NT_CFG") ? atoi(getenv("GTE_P3_NT_CFG")) : -1;
-    if (forced >= 0 && forced <= 12) return forced;
+    if (forced >= 0 && forced <= 7) return forced;
     const int cus = gte::device_props().cus;
     double best = 1e30;
     int bi = 0;
@@ -1365,11 +1201,7 @@ int nt_choose(const P3Gemm& p) {
 }
 int launch_nt(const P3Gemm& p, hipStream_t s) {
     int cfg = nt_choose(p);
-    if (p.rowsA && cfg >= 10) cfg = 4;            // (the 16 x 16 x 32 measurement variants do not take a row map)
     switch (cfg) {
-        case 10: launch_ring16<2, 4, 3, 2, 3, 1>(p, s); break;  // measurement: 192 x 256 on the 16 x 16 x 32 MFMA
-        case 11: launch_ring16<2, 4, 2, 2, 3, 1>(p, s); break;  // 128 x 256
-        case 12: launch_ring16<2, 2, 2, 2, 3, 2>(p, s); break;  // 128 x 128
         case 7: launch_ring<2, 4, 3, 2, 3, 1>(p, s); break;     // measurement: 192 x 256 ring (no loader waves)
         case 0: launch_ring<2, 2, 1, 2, 2, 3>(p, s); break;    //  64 x 128, three workgroups per CU
         case 1: launch_ring<2, 2, 2, 2, 3, 2>(p, s); break;    // 128 x 128, two
@@ -1589,7 +1421,7 @@ static int gemm_p3_tn_impl(const void* a, int64_t lda, const void* a2, int64_t l
     p.Nseg = (int)nseg; p.M = (int)m; p.N = (int)n; p.K = (int)k; p.C = c; p.ldc = ldc;
     p.splits = pl.splits; p.stages_per_split = pl.stages_per_split;
     if (b_rows) {
-        if (b2 || tn_big(m)) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_tn_rows: one B image, 128 x 128 tiles");
+        if (b2) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_tn_rows: one B image");
         if (n_res_rows <= 0 || (n_res_rows + 1) * ldb >= ((int64_t)1 << 32) - 4096)
             return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_tn_rows: the resident image must be smaller than 4 GB (32-bit buffer offsets)");
         p.rowsB = b_rows; p.res_bytes = n_res_rows * ldb;
@@ -1601,19 +1433,16 @@ static int gemm_p3_tn_impl(const void* a, int64_t lda, const void* a2, int64_t l
                              (long long)workspace_bytes);
         p.slab = reinterpret_cast<float*>(workspace);
     }
-    const int big = tn_big(m);
-    const int64_t tiles = gte::ceil_div(m, big ? 256 : 128) * (nseg > 0 ? 2 * gte::ceil_div(nseg, 128) : gte::ceil_div(n, 128));
-    constexpr int shm_big = 3 * 5 * 8 * 1024, shm_small = 3 * 6 * 4 * 1024;
+    const int64_t tiles = gte::ceil_div(m, 128) * (nseg > 0 ? 2 * gte::ceil_div(nseg, 128) : gte::ceil_div(n, 128));
+    constexpr int shm_small = 3 * 6 * 4 * 1024;
     static bool configured = false;
     if (!configured) {
-        GTE_SET_LDS((gemm_p3_tn_kernel<4, 2, 1>), shm_big);
         GTE_SET_LDS((gemm_p3_tn_kernel<2, 2, 2>), shm_small);
         GTE_SET_LDS((gemm_p3_tn_kernel<2, 2, 2, true>), shm_small);
         configured = true;
     }
     const dim3 grid((unsigned)(tiles * pl.splits));
-    if (big) hipLaunchKernelGGL((gemm_p3_tn_kernel<4, 2, 1>), grid, dim3(512), shm_big, s, p);
-    else if (p.rowsB) hipLaunchKernelGGL((gemm_p3_tn_kernel<2, 2, 2, true>), grid, dim3(256), shm_small, s, p);
+    if (p.rowsB) hipLaunchKernelGGL((gemm_p3_tn_kernel<2, 2, 2, true>), grid, dim3(256), shm_small, s, p);
     else hipLaunchKernelGGL((gemm_p3_tn_kernel<2, 2, 2>), grid, dim3(256), shm_small, s, p);
     int rc = gte::check_launch("gemm_p3_tn");
     if (rc != GTE_OK || pl.splits <= 1) return rc;

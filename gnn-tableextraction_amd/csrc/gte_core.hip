@@ -266,15 +266,6 @@ static int flush_folds(FoldQueue& q, const FoldAdam* adam = nullptr, const FoldI
     if (q.batch.n == 0) return GTE_OK;
     q.batch.adam = adam ? *adam : FoldAdam{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (images) q.batch.img = *images; else q.batch.img.n = 0;
-    static const int abl = getenv("GTE_WIMG_ABL") ? atoi(getenv("GTE_WIMG_ABL")) : 0;      // (measurement)
-    if (abl && images) {
-        FoldImages& fi = q.batch.img;
-        int m = 0;
-        for (int k = 0; k < fi.n; ++k)
-            if ((abl == 2 && !fi.im[k].transpose) || (abl == 3 && fi.im[k].transpose)) fi.im[m++] = fi.im[k];
-        fi.n = m;
-        images = &fi;
-    }
     for (int i = 0; i < q.batch.n; ++i) {
         FoldDesc& d = q.batch.d[i];
         d.img_mask = 0;
@@ -425,8 +416,7 @@ extern "C" int gte_fold_defer_flush_adam_images(float* param, float* grad, float
                          reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
     const gte::FoldAdam ad = {param, grad, exp_avg, exp_avg_sq, state, reinterpret_cast<long long*>(step_counter), ticket, vec_ok};
     const int rc = gte::flush_folds(q, &ad, fi.n > 0 ? &fi : nullptr);
-    static const bool abl = getenv("GTE_WIMG_ABL") && atoi(getenv("GTE_WIMG_ABL")) != 0;      // (measurement: images incomplete, not claimed)
-    if (rc == GTE_OK) *fused = (fi.n > 0 && !abl) ? 3 : 1;
+    if (rc == GTE_OK) *fused = fi.n > 0 ? 3 : 1;
     return rc;
 }
 

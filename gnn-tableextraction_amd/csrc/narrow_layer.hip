@@ -416,15 +416,14 @@ narrow_fwd_mfma16_kernel(const float* __restrict__ h, int64_t ldh, const float* 
 // {sum g xhat, sum g, sum dz} per workgroup in lnpart[block][3][F] -- dh (25 MB at 24 k x 256) is never written or read.
 struct LnBackward {
     const float* z; int64_t ldz; const float* stats; const float* gamma; const float* beta; int relu; float* lnpart;
-    char* dzp3; int64_t ldp3;                   // LNB == 2: dz additionally as a P3 image (csrc/p3.h)
-    // q = A_w^T (norm dl) computed by the kernel itself from the out-edge CSR (q == NULL): the 9-wide transpose aggregation of the
-    // output layer's gradient costs a launch of its own otherwise (rows of dl are 48 bytes: the whole matrix lives in L2)
-    const int32_t* rindptr; const int32_t* rindices; const float* rw;
+    char* dzp3; int64_t ldp3;                   // dz additionally as a P3 image (csrc/p3.h)
 };
 
-// LNB: 0 plain; 1 LayerNorm backward in the accumulator layout (row sums across the four waves: the round-2 form, off by default);
-// 2 the dh tile goes through LDS and every wave takes whole rows of it in the layout and with the arithmetic of
+// LNB: 0 plain; 2 the dh tile goes through LDS and every wave takes whole rows of it in the layout and with the arithmetic of
 // ln_relu_bwd_vec_kernel (16-byte accesses, dz as fp32 + P3 image: bit for bit gte_sage_narrow_bwd + gte_ln_relu_bwd_p3).
+// (Round 2's form 1 -- the LayerNorm backward in the accumulator layout, row sums across the four waves -- measured slower than
+// two launches, 41.6 against 39 us at 24 k x 256, and is gone; so is form 2's option of gathering q = A_w^T (norm dl) from the
+// out-edge CSR inside the kernel: 18 us of dependent loads for the 6 us launch it saved.  profiles/r03/gemm_p3.md keeps the numbers.)
 template <int NCT, int LNB = 0>
 __global__ void __launch_bounds__(256)
 narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* __restrict__ q, int64_t ldq,
@@ -450,12 +449,6 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
         for (int r = 0; r < 16; ++r) gw[j][r] = 0.f;
     float gb = 0.f;                             // wave 0, lane c (< C): dbias[c]
     struct __attribute__((packed, aligned(4))) f2n { float x, y; };
-    __shared__ float lnred[4][32][2];           // LNB: per wave, per row of the block: {sum dxhat, sum dxhat xhat}
-    float gam0 = 1.f, gam1 = 1.f, bet0 = 0.f, bet1 = 0.f;
-    float s_dg0 = 0.f, s_dg1 = 0.f, s_db0 = 0.f, s_db1 = 0.f, s_dz0 = 0.f, s_dz1 = 0.f;
-    if constexpr (LNB == 1) {
-        if (colok) { gam0 = lnb.gamma[col]; gam1 = lnb.gamma[col + 1]; bet0 = lnb.beta[col]; bet1 = lnb.beta[col + 1]; }
-    }
     // LNB == 2: lane l owns columns 4 l .. 4 l + 3 of the rows its wave takes
     const int j4 = 4 * lane;
     const bool okc = j4 < F;
@@ -487,27 +480,7 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
             dvn[t] = 0.f;
             if (idx < 32 * KD && r0 + r < n && c < C) {
                 if (kk < NCT) dvn[t] = dl[(int64_t)(r0 + r) * lddl + c];
-                else if (q) dvn[t] = q[(int64_t)(r0 + r) * ldq + c];
-                else {
-                    // q[r0 + r, c] = sum over the row's out-edges of w_e dl[dst_e, c], in CSR order with sequential fmaf: the
-                    // summation order (and the bits) of gte_spmm_csr on the same CSR.  Four edges in flight.
-                    const int lo = lnb.rindptr[r0 + r], hi = lnb.rindptr[r0 + r + 1];
-                    float sacc = 0.f;
-                    for (int e = lo; e < hi; e += 4) {
-                        int u[4]; float w[4], v[4];
-#pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2) {
-                            const bool live = e + k2 < hi;
-                            u[k2] = live ? lnb.rindices[e + k2] : 0;
-                            w[k2] = live ? (lnb.rw ? lnb.rw[e + k2] : 1.0f) : 0.f;
-                        }
-#pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2) v[k2] = dl[(int64_t)u[k2] * lddl + c];
-#pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2) sacc = fmaf(w[k2], v[k2], sacc);
-                    }
-                    dvn[t] = sacc;
-                }
+                else dvn[t] = q[(int64_t)(r0 + r) * ldq + c];
             }
         }
     };
@@ -533,8 +506,6 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
 #pragma unroll
         for (int t = 0; t < ND; ++t) dv[t] = dvn[t];
         if (rb + (int)gridDim.x < nblk) request(rb + gridDim.x);
-        f2n zv[LNB == 1 ? 16 : 1];              // LNB == 1: the z values under this lane's dh elements
-        float mu[LNB == 1 ? 16 : 1], rs[LNB == 1 ? 16 : 1];
         // LNB == 2: the z rows (and statistics) of the eight rows this wave takes of the block: rows wave, wave + 4, ...
         float zr[LNB == 2 ? 8 : 1][4], mu2[LNB == 2 ? 8 : 1], rs2[LNB == 2 ? 8 : 1];
         if constexpr (LNB == 2) {
@@ -546,16 +517,6 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                 if (okc) t = *reinterpret_cast<const f4n*>(lnb.z + (int64_t)rr * lnb.ldz + j4);
                 zr[u][0] = t.x; zr[u][1] = t.y; zr[u][2] = t.z; zr[u][3] = t.w;
                 mu2[u] = lnb.stats[rr]; rs2[u] = lnb.stats[n + rr];
-            }
-        }
-        if constexpr (LNB == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                zv[r] = f2n{0.f, 0.f};
-                const int rr = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * hh, n - 1);
-                if (colok) zv[r] = *reinterpret_cast<const f2n*>(lnb.z + (int64_t)rr * lnb.ldz + col);
-                mu[r] = lnb.stats[rr];
-                rs[r] = lnb.stats[n + rr];
             }
         }
         __syncthreads();                        // the previous block's D reads are done (and W image staged)
@@ -626,58 +587,6 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                     }
                 }
             } else
-            if constexpr (LNB == 1) {
-                // g = mask . dh, dxhat = g gamma; the row sums need all F columns: 32 lanes of this half-wave, then the
-                // four waves through LDS (fixed order)
-                float xh0[16], xh1[16], pa[16], pb[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const bool ok = colok && rr < n;
-                    xh0[r] = ok ? (zv[r].x - mu[r]) * rs[r] : 0.f;
-                    xh1[r] = ok ? (zv[r].y - mu[r]) * rs[r] : 0.f;
-                    float g0 = ok ? o[0][r] : 0.f, g1 = ok ? o[1][r] : 0.f;
-                    if (lnb.relu) {
-                        if (fmaf(xh0[r], gam0, bet0) <= 0.f) g0 = 0.f;
-                        if (fmaf(xh1[r], gam1, bet1) <= 0.f) g1 = 0.f;
-                    }
-                    o[0][r] = g0; o[1][r] = g1;
-                    const float d0 = g0 * gam0, d1 = g1 * gam1;
-                    pa[r] = d0 + d1;
-                    pb[r] = fmaf(d0, xh0[r], d1 * xh1[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    pa[r] = gte_group_sum<32>(pa[r]);
-                    pb[r] = gte_group_sum<32>(pb[r]);
-                }
-                if (i == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        lnred[wave][rl][0] = pa[r];
-                        lnred[wave][rl][1] = pb[r];
-                    }
-                }
-                __syncthreads();
-                const float inv_f = 1.0f / (float)F;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const int rr = row0 + rl;
-                    const float c1 = (((lnred[0][rl][0] + lnred[1][rl][0]) + lnred[2][rl][0]) + lnred[3][rl][0]) * inv_f;
-                    const float c2 = (((lnred[0][rl][1] + lnred[1][rl][1]) + lnred[2][rl][1]) + lnred[3][rl][1]) * inv_f;
-                    const float d0 = rs[r] * (o[0][r] * gam0 - c1 - xh0[r] * c2);
-                    const float d1 = rs[r] * (o[1][r] * gam1 - c1 - xh1[r] * c2);
-                    s_dg0 = fmaf(o[0][r], xh0[r], s_dg0); s_dg1 = fmaf(o[1][r], xh1[r], s_dg1);
-                    s_db0 += o[0][r]; s_db1 += o[1][r];
-                    if (colok && rr < n) {
-                        s_dz0 += d0; s_dz1 += d1;
-                        f2n v; v.x = d0; v.y = d1;
-                        *reinterpret_cast<f2n*>(dh + (int64_t)rr * lddh + col) = v;
-                    }
-                }
-            } else
             if (colok) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -727,17 +636,6 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
         float* lp = lnb.lnpart + (int64_t)blockIdx.x * 3 * F;
         for (int t = threadIdx.x; t < 3 * F; t += 256)
             lp[t] = ((red[t] + red[3 * F + t]) + red[6 * F + t]) + red[9 * F + t];
-    }
-    if constexpr (LNB == 1) {                   // the two half-waves hold different rows of the same columns
-        s_dg0 += __shfl_xor(s_dg0, 32, 64); s_dg1 += __shfl_xor(s_dg1, 32, 64);
-        s_db0 += __shfl_xor(s_db0, 32, 64); s_db1 += __shfl_xor(s_db1, 32, 64);
-        s_dz0 += __shfl_xor(s_dz0, 32, 64); s_dz1 += __shfl_xor(s_dz1, 32, 64);
-        if (colok && hh == 0) {
-            float* lp = lnb.lnpart + (int64_t)blockIdx.x * 3 * F + col;
-            lp[0] = s_dg0; lp[1] = s_dg1;
-            lp[F] = s_db0; lp[F + 1] = s_db1;
-            lp[2 * F] = s_dz0; lp[2 * F + 1] = s_dz1;
-        }
     }
 }
 
@@ -992,13 +890,13 @@ int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, 
                     const float* W, int64_t ldw, int64_t n_out, float* dh, int64_t lddh, float* dW, int64_t lddw, float* dbias,
                     int64_t n_nodes, void* workspace, int64_t workspace_bytes, const float* ce_partial, int64_t ce_blocks,
                     float grad_scale, float* out3, void* stream, const LnBackward* lnb = nullptr, float* dgamma = nullptr,
-                    float* dbeta = nullptr, float* dbias_below = nullptr, bool lnb_rows = false) {
+                    float* dbeta = nullptr, float* dbias_below = nullptr) {
     if (!gte_sage_narrow_supported(n_feat, n_out) || n_nodes < 0 || n_nodes > INT32_MAX)
         return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd: needs n_out <= 16 and n_feat <= 256");
     if (n_nodes == 0) return GTE_OK;
-    if (!dl || (!q && !(lnb && lnb->rindptr)) || !h || !W || !dW || !workspace)
+    if (!dl || !q || !h || !W || !dW || !workspace)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd: null pointer");
-    if (lddl < n_out || (q && ldq < n_out) || ldh < n_feat || ldw < 2 * n_feat || lddw < 2 * n_feat || (dh && lddh < n_feat))
+    if (lddl < n_out || ldq < n_out || ldh < n_feat || ldw < 2 * n_feat || lddw < 2 * n_feat || (dh && lddh < n_feat))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd: leading dimension too small");
     if (workspace_bytes < gte_sage_narrow_bwd_workspace_bytes(n_nodes, n_feat, n_out))
         return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd: workspace too small");
@@ -1009,14 +907,10 @@ int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, 
         const int nbm = narrow_mfma_blocks(n_nodes);
 #define GTE_NBM(NCT)                                                                                                  \
     do {                                                                                                              \
-        if (lnb && lnb_rows)                                                                                          \
+        if (lnb)                                                                                                      \
             hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 2>), dim3((unsigned)nbm), dim3(256),                      \
                                (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1) + 32 * F) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, \
                                lddh, part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, *lnb);        \
-        else if (lnb)                                                                                                 \
-            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 1>), dim3((unsigned)nbm), dim3(256),                      \
-                               (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1)) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, lddh, \
-                               part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, *lnb);              \
         else                                                                                                          \
             hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 0>), dim3((unsigned)nbm), dim3(256),                      \
                                (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1)) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, lddh, \
@@ -1136,9 +1030,8 @@ extern "C" int gte_sage_narrow_bwd_ln_p3(const float* dl, int64_t lddl, const fl
                                          float* out3, const float* z_below, int64_t ldz, const float* stats_below,
                                          const float* gamma_below, const float* beta_below, int relu_below, float* dgamma_below,
                                          float* dbeta_below, float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes,
-                                         const int32_t* rindptr, const int32_t* rindices, const float* rweight, void* stream) {
+                                         void* stream) {
     if (!gte_head_supported(n_feat, n_out)) return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd_ln_p3: see gte_head_supported");
-    if (!q && !rindptr) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln_p3: q or the out-edge CSR");
     if (!dz_below || !z_below || !stats_below || !gamma_below || !beta_below || !ln_workspace || (ce_partial && !out3))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln_p3: null pointer");
     if (ldz < n_feat || lddz < n_feat || (dzp3 && (ldp3 < (int64_t)p3::row_bytes(n_feat) || ldp3 % 16 != 0 || n_feat % 16 != 0)))
@@ -1146,34 +1039,13 @@ extern "C" int gte_sage_narrow_bwd_ln_p3(const float* dl, int64_t lddl, const fl
     if (ln_workspace_bytes < gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_feat))
         return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd_ln_p3: LayerNorm workspace too small");
     const LnBackward lnb = {z_below, ldz, stats_below, gamma_below, beta_below, relu_below, reinterpret_cast<float*>(ln_workspace),
-                            reinterpret_cast<char*>(dzp3), ldp3, q ? nullptr : rindptr, rindices, rweight};
-    return narrow_bwd_impl(dl, lddl, q, ldq, h, ldh, n_feat, W, ldw, n_out, dz_below, lddz, dW, lddw, dbias, n_nodes, workspace,
-                           workspace_bytes, reinterpret_cast<const float*>(ce_partial),
-                           gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream, &lnb, dgamma_below,
-                           dbeta_below, dbias_below, true);
-}
-
-extern "C" int64_t gte_sage_narrow_bwd_ln_workspace_bytes(int64_t n_nodes, int64_t n_feat) {
-    return gte::round_up((int64_t)narrow_mfma_blocks(n_nodes > 0 ? n_nodes : 1) * 3 * n_feat * 4, 256);
-}
-
-extern "C" int gte_sage_narrow_bwd_ln(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
-                                      int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dz_below, int64_t lddz,
-                                      float* dW, int64_t lddw, float* dbias, int64_t n_nodes, void* workspace,
-                                      int64_t workspace_bytes, const void* ce_partial, float grad_scale, float* out3,
-                                      const float* z_below, int64_t ldz, const float* stats_below, const float* gamma_below,
-                                      const float* beta_below, int relu_below, float* dgamma_below, float* dbeta_below,
-                                      float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes, void* stream) {
-    if (!gte_head_supported(n_feat, n_out)) return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd_ln: see gte_head_supported");
-    if (!dz_below || !z_below || !stats_below || !gamma_below || !beta_below || !ln_workspace || (ce_partial && !out3))
-        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln: null pointer");
-    if (ldz < n_feat || lddz < n_feat) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln: leading dimension too small");
-    if (ln_workspace_bytes < gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_feat))
-        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd_ln: LayerNorm workspace too small");
-    const LnBackward lnb = {z_below, ldz, stats_below, gamma_below, beta_below, relu_below, reinterpret_cast<float*>(ln_workspace),
-                            nullptr, 0, nullptr, nullptr, nullptr};
+                            reinterpret_cast<char*>(dzp3), ldp3};
     return narrow_bwd_impl(dl, lddl, q, ldq, h, ldh, n_feat, W, ldw, n_out, dz_below, lddz, dW, lddw, dbias, n_nodes, workspace,
                            workspace_bytes, reinterpret_cast<const float*>(ce_partial),
                            gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream, &lnb, dgamma_below,
                            dbeta_below, dbias_below);
+}
+
+extern "C" int64_t gte_sage_narrow_bwd_ln_workspace_bytes(int64_t n_nodes, int64_t n_feat) {
+    return gte::round_up((int64_t)narrow_mfma_blocks(n_nodes > 0 ? n_nodes : 1) * 3 * n_feat * 4, 256);
 }

@@ -126,14 +126,12 @@ int backward_a(const gte_step_plan& p, void* st) {
         GTE_TRY(gte_gemm_p3_nt(p.dlqp, p.ldp_dlq, 32, nullptr, 0, 0, p.wimg_out_bwd, p.ldp_wout_bwd, nullptr, 0, p.dh_out, p.ld_h_out, n,
                                p.out_fin, 0, 0, st));
     } else if ((p.fuse_ln_dx & 2) && T.kind == GTE_LAYER_PLANES && T.fout % 16 == 0 && gte_head_supported(p.out_fin, C)) {
-        // the output layer's backward forms q = A_w^T (norm dl) itself (p.fuse_ln_dx & 4) and runs the LayerNorm(+ReLU) backward of
-        // the last hidden layer on the dh tile of every row block
-        const bool own_q = (p.fuse_ln_dx & 4) != 0;
-        if (!own_q) GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
-        GTE_TRY(gte_sage_narrow_bwd_ln_p3(p.dl, C, own_q ? nullptr : p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C,
+        // the output layer's backward runs the LayerNorm(+ReLU) backward of the last hidden layer on the dh tile of every row block
+        GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
+        GTE_TRY(gte_sage_narrow_bwd_ln_p3(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, C,
                                           p.dh_out, p.ld_h_out, T.dzp, T.ldp_o, p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar, p.ws_nar_bytes,
                                           p.ce_part, p.grad_scale, p.out3, T.t, 2 * ldf(T), T.stats, T.gamma, T.beta, T.relu, T.ggamma,
-                                          T.gbeta, T.gbias, T.ws_ln, T.ws_ln_bytes, p.rindptr, p.rindices, p.w_out, st));
+                                          T.gbeta, T.gbias, T.ws_ln, T.ws_ln_bytes, st));
         ln_done = true;
     } else {
         GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
@@ -276,51 +274,4 @@ extern "C" int gte_gcnsage_forward(const gte_step_plan* plan, void* stream) {
         rc = gte_spmm_csr_accumulate(p.indptr, p.indices, p.w_in, p.tn, ld_lg(p), p.logits, ld_lg(p), n, C, GTE_F32, GTE_REDUCE_MEAN, stream);
     (void)gte_gemm_set_tail_workspace(nullptr, 0);
     return rc;
-}
-
-// The same step as ONE executable graph launch: the step is captured from `stream` (not the legacy null stream), an executable
-// graph kept in *exec_slot is UPDATED with the captured topology (same kernels every step; grid sizes and arguments follow the
-// batch) and launched.  Inside a graph launch dependent kernels follow each other without the per-dispatch fences of eager
-// launches (r03: the replay of fixed batches ran 5 - 6 % faster than the eager loop).  *exec_slot starts as NULL and is released
-// with gte_step_graph_destroy.  Host work (plan validation, fold queue, Adam coverage) runs at capture time as in the eager call.
-extern "C" int gte_gcnsage_step_graph(const gte_step_plan* plan, int* adam_fused, void* stream, void** exec_slot) {
-    if (!exec_slot) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step_graph: null exec slot");
-    hipStream_t s = gte::as_stream(stream);
-    if (!s) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step_graph: the legacy null stream cannot be captured");
-    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) return gte::fail(GTE_ERR_LAUNCH, "gcnsage_step_graph: hipStreamBeginCapture: %s", hipGetErrorString(e));
-    const int rc = gte_gcnsage_step(plan, 0, adam_fused, stream);
-    hipGraph_t g = nullptr;
-    e = hipStreamEndCapture(s, &g);
-    if (rc != GTE_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-    if (e != hipSuccess || !g) return gte::fail(GTE_ERR_LAUNCH, "gcnsage_step_graph: hipStreamEndCapture: %s", hipGetErrorString(e));
-    hipGraphExec_t ex = reinterpret_cast<hipGraphExec_t>(*exec_slot);
-    if (ex) {
-        hipGraphNode_t bad = nullptr;
-        hipGraphExecUpdateResult res;
-        e = hipGraphExecUpdate(ex, g, &bad, &res);
-        if (e != hipSuccess) {                             // topology changed (another layer plan): start over
-            (void)hipGetLastError();
-            (void)hipGraphExecDestroy(ex);
-            ex = nullptr;
-        }
-    }
-    if (!ex) {
-        e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-        if (e != hipSuccess) {
-            (void)hipGraphDestroy(g);
-            *exec_slot = nullptr;
-            return gte::fail(GTE_ERR_LAUNCH, "gcnsage_step_graph: hipGraphInstantiate: %s", hipGetErrorString(e));
-        }
-    }
-    *exec_slot = ex;
-    (void)hipGraphDestroy(g);
-    e = hipGraphLaunch(ex, s);
-    if (e != hipSuccess) return gte::fail(GTE_ERR_LAUNCH, "gcnsage_step_graph: hipGraphLaunch: %s", hipGetErrorString(e));
-    return GTE_OK;
-}
-
-extern "C" int gte_step_graph_destroy(void* exec) {
-    if (exec) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(exec));
-    return GTE_OK;
 }

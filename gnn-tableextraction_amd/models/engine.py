@@ -155,10 +155,6 @@ class FusedGcnSageStep(TrainStep):
         self._private_key = None
         self._graphs = {}
         self._graph_owner = {}
-        self._side = torch.cuda.Stream(device=self.flat_param.device)
-        # dW GEMMs on a side stream (GTE_OVERLAP_DW=1).  Off by default since the pipelined GEMM: with the matrix pipe at
-        # 110-120 TF the HBM-bound kernels it would overlap with slow it down more than they hide (0.887 vs 0.862 ms/step)
-        self.overlap_dw = os.environ.get("GTE_OVERLAP_DW", "0") == "1"
         # transform-then-aggregate where a layer narrows + q-form backward (see _transform_first / _qform); "0" keeps
         # the reference's aggregate-then-transform order everywhere (same math, different summation order)
         self.transform_first = os.environ.get("GTE_TRANSFORM_FIRST", "1") == "1"
@@ -168,10 +164,6 @@ class FusedGcnSageStep(TrainStep):
         self._fuse_adam_req, self._adam_fused = False, False
         self.adam_fused_steps = 0                     # steps whose optimiser update ran inside the fold launch
         self.fused_head = os.environ.get("GTE_FUSED_HEAD", "1") == "1"
-        # gte_sage_narrow_bwd_ln (LayerNorm backward of the layer below inside the output layer's backward kernel) saves
-        # 50 MB of traffic but serialises more work in one wave per SIMD: 41.6 us fused vs 22.4 + 16.6 us separate at
-        # 24 k nodes -- off by default, kept (and tested) for a later retune
-        self.fuse_ln_below = os.environ.get("GTE_FUSE_LN_BELOW", "0") == "1"
         # dX of a planes layer with the LayerNorm(+ReLU) backward of the planes layer below as its epilogue (gte_gemm_p3_nt_ln_bwd)
         self.fuse_ln_dx = os.environ.get("GTE_FUSE_LN_DX", "1") == "1"
         # ... and of the last hidden layer inside the output layer's backward (gte_sage_narrow_bwd_ln_p3)
@@ -179,12 +171,6 @@ class FusedGcnSageStep(TrainStep):
         # dX of layer 1 with the whole backward of a short-input layer 0 as its epilogue (gte_gemm_p3_nt_smallk_bwd)
         self.fuse_smallk_dx = os.environ.get("GTE_FUSE_SMALLK_DX", "1") == "1"
         self._smallk_done = False
-        # ... which can also form q = A_w^T (norm dl) itself instead of a 9-wide aggregation launch.  Off: the dependent chain
-        # indptr -> edges -> dl rows in front of every row block costs 18 us of kernel time for the 6 us launch it saves
-        self.fuse_q_narrow = os.environ.get("GTE_FUSE_Q_NARROW", "0") == "1"
-        # the one-call step launched as an executable graph that is updated per batch (needs a non-default current stream)
-        self.use_step_graph = os.environ.get("GTE_STEP_GRAPH", "0") == "1"
-        self._step_exec = ctypes.c_void_p(None)
         self._ln_p3_done = None
         # LayerNorm(+ReLU) forward of the last hidden layer inside the output layer's forward kernel (gte_sage_narrow_fwd_ln):
         # one launch and one pass over [n, hidden] less
@@ -400,18 +386,10 @@ class FusedGcnSageStep(TrainStep):
         return (not isinstance(layer.lynorm, nn.LayerNorm) and layer.activation is None and layer.linear.bias is not None
                 and bool(self.lib.gte_sage_narrow_supported(fin, layer.out_feats)))
 
-    def _ln_below_fused(self, i: int, layers, fin: int) -> bool:
-        """The output layer's backward also runs the LayerNorm(+ReLU) backward of layer i-1 (gte_sage_narrow_bwd_ln)."""
-        if not self.fuse_ln_below or not self.fused_head or i == 0 or i != len(layers) - 1 or self._planes_on():
-            return False          # (with P3 operands the row form gte_sage_narrow_bwd_ln_p3 does this, see _ln_rows_below)
-        Lb = layers[i - 1]
-        return (isinstance(Lb.lynorm, nn.LayerNorm) and self._narrow(layers[i], fin)
-                and bool(self.lib.gte_head_supported(fin, layers[i].out_feats)))
-
     def _ln_rows_below(self, i: int, layers, fin: int, b) -> bool:
         """The output layer's backward runs the LayerNorm(+ReLU) backward of the PLANES layer below in the row form
         (gte_sage_narrow_bwd_ln_p3: dz as fp32 + image)."""
-        return (self.fuse_ln_narrow and i > 0 and i == len(layers) - 1 and bool(b["pl"][i - 1]) and ops._timers is None
+        return (self.fuse_ln_narrow and i > 0 and i == len(layers) - 1 and bool(b["pl"][i - 1])
                 and self._narrow(layers[i], fin) and fin % 16 == 0 and bool(self.lib.gte_head_supported(fin, layers[i].out_feats)))
 
     def _fused_head(self, i: int, layer, fin: int) -> bool:
@@ -499,7 +477,7 @@ class FusedGcnSageStep(TrainStep):
     def _smallk_bwd(self, i: int, layer, fin: int) -> bool:
         """Layer 0 with a short input (BBOX features) and LayerNorm: forward in one pass (gte_sage_linear_fwd_fuses_ln) and the
         whole backward in one pass (gte_sage_smallk_bwd); z is then never saved."""
-        return (i == 0 and isinstance(layer.lynorm, nn.LayerNorm) and layer.linear.bias is not None and not self.fuse_ln_below
+        return (i == 0 and isinstance(layer.lynorm, nn.LayerNorm) and layer.linear.bias is not None
                 and not self._transform_first(layer, fin) and not self._planes_layer(i, layer, fin, 1 << 20)
                 and bool(self.lib.gte_sage_linear_fwd_fuses_ln(2 * fin, layer.out_feats))
                 and bool(self.lib.gte_sage_smallk_bwd_supported(2 * fin, layer.out_feats)))
@@ -528,8 +506,7 @@ class FusedGcnSageStep(TrainStep):
     def _plan_kinds(self, f0: int, n: int):
         """Layer kinds of the one-call step (gte_gcnsage_step) or None when the configuration needs the call-by-call path."""
         layers = list(self.model.layers)
-        if (not self.use_c_step or not self._planes_on() or len(layers) < 2 or len(layers) > 8 or self.overlap_dw or self.fuse_ln_below
-                or ops._timers is not None):
+        if (not self.use_c_step or not self._planes_on() or len(layers) < 2 or len(layers) > 8 or ops._timers is not None):
             return None
         dims = [f0] + [l.out_feats for l in layers]
         last = len(layers) - 1
@@ -815,7 +792,7 @@ class FusedGcnSageStep(TrainStep):
         plan, _arr, fused = cached
         # per call: the public switches and the class weights (re-read like the call-by-call path does) ...
         plan.class_weights = P(self.class_weights)
-        plan.fuse_ln_dx = (int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (4 if self.fuse_q_narrow else 0)
+        plan.fuse_ln_dx = (int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0)
                            | (8 if self.fuse_smallk_dx else 0))
         # ... and per batch: the graph, the features, the labels
         b["logits"], b["_wkey"] = b["y"][-1], "tuned"
@@ -861,12 +838,7 @@ class FusedGcnSageStep(TrainStep):
         plan.wimg_in_fold = int(self.wimg_in_fold and with_adam and not capturing)
         self._wimg_sig = None
         addr = ctypes.addressof(plan)
-        if self.use_step_graph and st and not torch.cuda.is_current_stream_capturing():
-            # the whole step as one executable-graph launch (updated in place per batch); the next batch's assembly is queued first
-            if self.before_last_gemm is not None:
-                self.before_last_gemm()
-            _lib.check(lib.gte_gcnsage_step_graph(addr, ctypes.byref(fused), st, ctypes.byref(self._step_exec)), "gte_gcnsage_step_graph")
-        elif self.before_last_gemm is not None:
+        if self.before_last_gemm is not None:
             _lib.check(lib.gte_gcnsage_step(addr, 1, ctypes.byref(fused), st), "gte_gcnsage_step")
             # phase 1 returned with this thread's fold deferral OPEN and the tail workspace registered: whatever the callback (the
             # next batch's assembly) or phase 2 raises, both are closed again -- a step that died here must not poison the next
@@ -988,17 +960,13 @@ class FusedGcnSageStep(TrainStep):
         try:
             if forward:
                 self._forward_loss(g, labels, grad_scale, x, n, f0, b, layers, csr, w_in, t_in, aggregate, st)
-                self._ln_done = None
                 self._ln_p3_done = None
                 self._smallk_done = False
             # ---------------- backward of layers hi .. lo ----------------
-            side_used = False
             check(lib.gte_fold_defer_begin(st), "gte_fold_defer_begin")
             try:
-                side_used = self._backward(g, b, layers, x, n, aggregate, rcsr, w_out, t_out, st, hi, lo)
+                self._backward(g, b, layers, x, n, aggregate, rcsr, w_out, t_out, st, hi, lo)
             finally:
-                if side_used:
-                    torch.cuda.current_stream().wait_stream(self._side)  # join: the folds / Adam / all-reduce need every dW
                 if self._fuse_adam_req and lo == 0:
                     # the folds produce every gradient element: the optimiser step rides in the same launch (falls back to a
                     # plain flush, fused = 0, when some gradient was written directly)
@@ -1152,11 +1120,10 @@ class FusedGcnSageStep(TrainStep):
                                       P(self.class_weights), n, logits.shape[1], float(grad_scale), P(dl), dl.shape[1],
                                       P(b["out3"]), ws, wsn, st), "gte_weighted_ce")
 
-    def _backward(self, g, b, layers, x, n, aggregate, rcsr, w_out, t_out, st, hi, lo) -> bool:
+    def _backward(self, g, b, layers, x, n, aggregate, rcsr, w_out, t_out, st, hi, lo) -> None:
         lib, P, check = self.lib, _lib.ptr, _lib.check
         timed, ld = ops._timed, ops._ld
         ws, wsn = P(b["ws"]), b["ws"].numel()
-        side_used = False
         for i in range(hi, lo - 1, -1):
             L = layers[i]
             hin = x if i == 0 else b["y"][i - 1]
@@ -1171,43 +1138,22 @@ class FusedGcnSageStep(TrainStep):
             gbe = self._gslice[id(L.lynorm.bias)] if ln else None
             if self._narrow(L, fin):
                 # q = A_w^T (norm * dlogits) on C columns; dW = [dl^T h | q^T h], dh = dl W_s + q W_n, dbias = colsum(dl)
-                own_q = self.fuse_q_narrow and self._ln_rows_below(i, layers, fin, b)        # the backward kernel forms q itself
-                if not own_q:
-                    aggregate(rcsr, w_out, None, dy, fout, b["q"], fout, fout, _lib.REDUCE_SUM, False)
+                aggregate(rcsr, w_out, None, dy, fout, b["q"], fout, fout, _lib.REDUCE_SUM, False)
                 dh = b["dy"][i - 1] if i > 0 else None
-                ln_below = self._ln_below_fused(i, layers, fin)
                 with timed("narrow_bwd", 3.0 * n * fin * 4):
-                    if ln_below:
-                        # ... and the LayerNorm(+ReLU) backward of layer i-1 in the same kernel: dz_{i-1} lands where dh
-                        # would have gone; that layer's own iteration below skips its gte_ln_relu_bwd
-                        Lb = layers[i - 1]
-                        tfb = self._transform_first(Lb, Lb.linear.weight.shape[1] // 2)
-                        zb = b["t"][i - 1] if tfb else b["z"][i - 1]
-                        gsl = self._gslice
-                        check(lib.gte_sage_narrow_bwd_ln(
-                            P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout, P(dh), fin, P(gW), 2 * fin,
-                            P(gb), n, P(b["ws_nar"]), b["ws_nar"].numel(),
-                            P(b["ce_part"]) if self._head_scale is not None else None,
-                            self._head_scale if self._head_scale is not None else 1.0,
-                            P(b["out3"]) if self._head_scale is not None else None,
-                            P(zb), 2 * fin if tfb else fin, P(b["stats"][i - 1]), P(Lb.lynorm.weight), P(Lb.lynorm.bias),
-                            int(Lb.activation is not None), P(gsl[id(Lb.lynorm.weight)]), P(gsl[id(Lb.lynorm.bias)]),
-                            P(gsl[id(Lb.linear.bias)]) if Lb.linear.bias is not None else None,
-                            P(b["ws_ln"][i - 1]), b["ws_ln"][i - 1].numel(), st), "gte_sage_narrow_bwd_ln")
-                        self._ln_done = i - 1
-                    elif self._ln_rows_below(i, layers, fin, b):
+                    if self._ln_rows_below(i, layers, fin, b):
                         # the LayerNorm(+ReLU) backward of the planes layer below on the dh tile of every row block (row form):
                         # d(loss)/d(y) of that layer is never stored, its dz comes out as fp32 + image
                         Lb, gsl, dzb, wsl = layers[i - 1], self._gslice, b["dzp"][i - 1], b["ws_ln"][i - 1]
                         hs = self._head_scale
                         check(lib.gte_sage_narrow_bwd_ln_p3(
-                            P(dy), fout, None if own_q else P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout, P(dh), fin,
+                            P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout, P(dh), fin,
                             P(dzb.data), dzb.ldp,
                             P(gW), 2 * fin, P(gb), n, P(b["ws_nar"]), b["ws_nar"].numel(), P(b["ce_part"]) if hs is not None else None,
                             hs if hs is not None else 1.0, P(b["out3"]) if hs is not None else None, P(b["t"][i - 1]), 2 * fin,
                             P(b["stats"][i - 1]), P(Lb.lynorm.weight), P(Lb.lynorm.bias), int(Lb.activation is not None),
                             P(gsl[id(Lb.lynorm.weight)]), P(gsl[id(Lb.lynorm.bias)]), P(gsl[id(Lb.linear.bias)]), P(wsl), wsl.numel(),
-                            P(rcsr.indptr), P(rcsr.indices), P(w_out), st), "gte_sage_narrow_bwd_ln_p3")
+                            st), "gte_sage_narrow_bwd_ln_p3")
                         self._ln_p3_done = i - 1
                     elif self._head_scale is not None and i == len(layers) - 1:
                         check(lib.gte_sage_narrow_bwd_ce(P(dy), fout, P(b["q"]), fout, P(hin), ld(hin), fin, P(W), 2 * fin, fout,
@@ -1223,14 +1169,10 @@ class FusedGcnSageStep(TrainStep):
                 # ---- planes layer: dz (fp32 for the transpose aggregation + image), q = A_w^T (norm dz) as an image,
                 # dW = [dz^T h | q^T h] and dh = dz W_s + q W_n on the planes GEMMs
                 t, dzp, qp, hp = b["t"][i], b["dzp"][i], b["qp"][i], b["hp_used"][i]
-                if self._ln_p3_done == i:
-                    pass          # the dX launch of the layer above ran this layer's LayerNorm backward as its epilogue
-                elif self._ln_done != i:
+                if self._ln_p3_done != i:         # (else: the launch above ran this layer's LayerNorm backward as its epilogue)
                     check(lib.gte_ln_relu_bwd_p3(P(dy), fout, P(t), 2 * fout, P(b["stats"][i]), P(L.lynorm.weight),
                                                  P(L.lynorm.bias), int(relu), P(dy), fout, P(dzp.data), dzp.ldp, P(gg), P(gbe), P(gb),
                                                  n, fout, P(b["ws_ln"][i]), b["ws_ln"][i].numel(), st), "gte_ln_relu_bwd_p3")
-                else:
-                    check(lib.gte_p3_from_f32(P(dy), fout, n, fout, 0, P(dzp.data), dzp.ldp, st), "gte_p3_from_f32")
                 with timed("spmm_csr", 2.0 * n * fout * 4 + 8.0 * rcsr.indices.numel() + 4.0 * (n + 1)):
                     check(lib.gte_spmm_csr_p3(P(rcsr.indptr), P(rcsr.indices), P(w_out), P(dy), fout, P(qp.data), qp.ldp, n, fout,
                                               _lib.REDUCE_SUM, st), "gte_spmm_csr_p3")
@@ -1246,24 +1188,14 @@ class FusedGcnSageStep(TrainStep):
                     else:
                         check(lib.gte_gemm_p3_tn(P(dzp.data), dzp.ldp, P(qp.data), qp.ldp, P(hp.data), hp.ldp, None, 0, fin, P(gW),
                                                  2 * fin, fout, 2 * fin, n, P(wsp), wsp.numel(), stream), "gte_gemm_p3_tn")
-                if self.overlap_dw and i > 0 and ops._timers is None:
-                    # an upper layer's dW beside the chain below it (dX, LayerNorm backward, transpose aggregation: two of the
-                    # three HBM-bound): nothing needs it before the folds
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    with torch.cuda.stream(self._side):
-                        self._side.wait_event(ev)
-                        dw_planes(self._side.cuda_stream)
-                    side_used = True
-                else:
-                    with timed("gemm_tn", 4.0 * n * fin * fout) as tm:
-                        for _ in tm.repeat():
-                            dw_planes(st)
+                with timed("gemm_tn", 4.0 * n * fin * fout) as tm:
+                    for _ in tm.repeat():
+                        dw_planes(st)
                 if i > 0:
                     wb = self._wimg[i][1]
                     Lb = layers[i - 1]
                     fin_b = Lb.linear.weight.shape[1] // 2
-                    if (self.fuse_smallk_dx and i == 1 and self._smallk_bwd(0, Lb, fin_b) and ops._timers is None
+                    if (self.fuse_smallk_dx and i == 1 and self._smallk_bwd(0, Lb, fin_b)
                             and lib.gte_gemm_p3_nt_smallk_bwd_supported(2 * fin_b, fin)):
                         # dX with the WHOLE backward of the short-input layer below as its epilogue: nothing of layer 0 is left
                         gsl, wsd = self._gslice, b["ws_dw"][0]
@@ -1275,7 +1207,7 @@ class FusedGcnSageStep(TrainStep):
                                                             P(gsl[id(Lb.lynorm.bias)]), n, fin, P(wsd), wsd.numel(), st),
                               "gte_gemm_p3_nt_smallk_bwd")
                         self._smallk_done = True
-                    elif (self.fuse_ln_dx and b["pl"][i - 1] and ops._timers is None and lib.gte_gemm_p3_nt_ln_bwd_supported(fin)):
+                    elif self.fuse_ln_dx and b["pl"][i - 1] and lib.gte_gemm_p3_nt_ln_bwd_supported(fin):
                         # dX with the LayerNorm(+ReLU) backward of the layer below as its epilogue: d(loss)/d(y) of that layer
                         # is never stored, its dz comes out as fp32 + image
                         gsl, dzb, wsl = self._gslice, b["dzp"][i - 1], b["ws_ln"][i - 1]
@@ -1308,12 +1240,11 @@ class FusedGcnSageStep(TrainStep):
                 continue
             tfirst, qform = self._transform_first(L, fin), self._qform(i, L, fin)
             zsrc = b["t"][i] if tfirst else (b["z"][i] if ln else b["y"][i])
-            # dz in place of dy; column sums straight into the flat gradient (unless the layer above already did it)
-            if self._ln_done != i:
-                check(lib.gte_ln_relu_bwd(P(dy), fout, P(zsrc), 2 * fout if tfirst else fout, P(b["stats"][i]) if ln else None,
-                                          P(L.lynorm.weight) if ln else None, P(L.lynorm.bias) if ln else None, int(relu),
-                                          P(dy), fout, P(gg), P(gbe), P(gb), n, fout, P(b["ws_ln"][i]), b["ws_ln"][i].numel(),
-                                          st), "gte_ln_relu_bwd")
+            # dz in place of dy; column sums straight into the flat gradient
+            check(lib.gte_ln_relu_bwd(P(dy), fout, P(zsrc), 2 * fout if tfirst else fout, P(b["stats"][i]) if ln else None,
+                                      P(L.lynorm.weight) if ln else None, P(L.lynorm.bias) if ln else None, int(relu),
+                                      P(dy), fout, P(gg), P(gbe), P(gb), n, fout, P(b["ws_ln"][i]), b["ws_ln"][i].numel(),
+                                      st), "gte_ln_relu_bwd")
             dz, ahn = dy, b["ahn"][i]
             if qform:
                 # q = A_w^T (norm * dz) into the dead right half of t (transform-first) or the dead ahn buffer
@@ -1333,17 +1264,9 @@ class FusedGcnSageStep(TrainStep):
                 else:
                     check(lib.gte_sage_linear_dw(P(dz), fout, P(hin), ld(hin), fin, P(ahn), fin, fin, P(gW), 2 * fin, fout,
                                                  n, P(wdw), wdw.numel(), stream), "gte_sage_linear_dw")
-            if self.overlap_dw and ops._timers is None:
-                ev = torch.cuda.Event()
-                ev.record()
-                with torch.cuda.stream(self._side):
-                    self._side.wait_event(ev)
-                    dw_launch(self._side.cuda_stream)
-                side_used = True
-            else:
-                with timed("gemm_tn", 4.0 * n * fin * fout) as tm:
-                    for _ in tm.repeat():
-                        dw_launch(st)
+            with timed("gemm_tn", 4.0 * n * fin * fout) as tm:
+                for _ in tm.repeat():
+                    dw_launch(st)
             if i > 0 and qform:
                 with timed("gemm_nn", 4.0 * n * fin * fout) as tm:
                     for _ in tm.repeat():
@@ -1357,7 +1280,6 @@ class FusedGcnSageStep(TrainStep):
                     check(lib.gte_gemm_f32(0, 0, n, fin, fout, P(dz), fout, P(W) + 4 * fin, 2 * fin, P(dahn), fin, 0, ws,
                                            wsn, st), "gte_gemm_f32 dh_neigh")
                 aggregate(rcsr, w_out, t_out, dahn, fin, dh, fin, fin, _lib.REDUCE_SUM, True)
-        return side_used
 
     def step(self, g, labels: torch.Tensor, n_global: Optional[int] = None,
              loss_scale: Optional[float] = None) -> torch.Tensor:

@@ -185,17 +185,7 @@ def run_steps(step, pipe: BatchPipeline, page_steps: Sequence[np.ndarray], n_glo
             pending[0] = None
     if hooked:
         step.before_last_gemm = late_start
-    # graph-launched steps (GTE_STEP_GRAPH=1) are captured from the stream they run on: not the legacy default stream
-    graph_stream = None
-    if getattr(step, "use_step_graph", False):
-        graph_stream = getattr(pipe, "_graph_stream", None)
-        if graph_stream is None:
-            graph_stream = pipe._graph_stream = torch.cuda.Stream(device=pipe.device)
-        graph_stream.wait_stream(torch.cuda.current_stream(pipe.device))
-    import contextlib
-    ctx = torch.cuda.stream(graph_stream) if graph_stream is not None else contextlib.nullcontext()
     try:
-      with ctx:
         for s in range(n_steps):
             if s + 1 < n_steps:
                 if hooked:
@@ -212,6 +202,4 @@ def run_steps(step, pipe: BatchPipeline, page_steps: Sequence[np.ndarray], n_glo
     finally:
         if hooked:
             step.before_last_gemm = None
-        if graph_stream is not None:
-            torch.cuda.current_stream(pipe.device).wait_stream(graph_stream)
     return out3

@@ -434,7 +434,6 @@ typedef struct gte_step_plan {
     void* tail_ws; int64_t tail_ws_bytes;
     int fuse_ln_dx;                        /* bit 0: dX of a PLANES layer above a PLANES layer runs gte_gemm_p3_nt_ln_bwd;
                                               bit 1: the output layer's backward runs gte_sage_narrow_bwd_ln_p3;
-                                              bit 2: ... and forms q = A_w^T (norm dl) itself (no 9-wide aggregation launch);
                                               bit 3: dX of layer 1 above a SMALLK layer 0 runs gte_gemm_p3_nt_smallk_bwd      */
     int wimg_fresh;                        /* the weight images already hold the current parameters: the forward skips their
                                               conversion launch (set by the caller after a step that returned *adam_fused & 2) */
@@ -456,13 +455,6 @@ typedef struct gte_step_plan {
 } gte_step_plan;
 /* *adam_fused: bit 0 = the optimiser step ran inside the fold launch, bit 1 = ... and it wrote the weight images */
 int gte_gcnsage_step(const gte_step_plan* plan, int phase, int* adam_fused, void* stream);
-/* The whole step (phase 0) captured from `stream` -- not the legacy null stream -- and launched as ONE executable graph kept in
- * *exec_slot (NULL at first; updated in place every step: same kernels, the batch's grid sizes and arguments; released with
- * gte_step_graph_destroy).  Dependent kernels inside a graph launch follow each other without the per-dispatch overhead of
- * eager launches. */
-int gte_gcnsage_step_graph(const gte_step_plan* plan, int* adam_fused, void* stream, void** exec_slot);
-int gte_step_graph_destroy(void* exec);
-
 /* The forward pass alone from the same plan (replaces `logits = model(g)` under no_grad: src/models/model_predict.py:141-147 and
  * the validation forward src/models/model_train.py:349-353): weight images, hidden layers, the output layer; logits [n, C] in
  * plan->logits.  The same kernels in the same order as the forward half of gte_gcnsage_step (bit-identical activations);
@@ -566,26 +558,17 @@ int gte_sage_narrow_bwd_ce(const float* dl_unscaled, int64_t lddl, const float* 
  * ln_workspace >= gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_feat); its folds join an open deferral
  * (gte_fold_defer_begin) or run as one launch.  Same support rule as gte_head_supported. */
 int64_t gte_sage_narrow_bwd_ln_workspace_bytes(int64_t n_nodes, int64_t n_feat);
-/* The same fusion in the ROW form (round 3): the dh tile of every 32-row block goes through LDS and whole rows get the
- * LayerNorm(+ReLU) backward with 16-byte accesses and the arithmetic of gte_ln_relu_bwd; dz_below as fp32 AND as a P3 image
- * (dzp3 nullable; n_feat % 16 == 0).  Bit for bit gte_sage_narrow_bwd[_ce] + gte_ln_relu_bwd_p3. */
+/* Row form: the dh tile of every 32-row block goes through LDS and whole rows get the LayerNorm(+ReLU) backward with 16-byte
+ * accesses and the arithmetic of gte_ln_relu_bwd; dz_below as fp32 AND as a P3 image (dzp3 nullable; n_feat % 16 == 0).  Bit for
+ * bit gte_sage_narrow_bwd[_ce] + gte_ln_relu_bwd_p3.  (Round 2's accumulator-layout form gte_sage_narrow_bwd_ln and round 3's
+ * option of forming q inside the kernel measured slower than what they replaced and were removed in round 4.) */
 int gte_sage_narrow_bwd_ln_p3(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
                               int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dz_below, int64_t lddz,
                               void* dzp3, int64_t ldp3, float* dW, int64_t lddw, float* dbias, int64_t n_nodes, void* workspace,
                               int64_t workspace_bytes, const void* ce_partial, float grad_scale, float* out3,
                               const float* z_below, int64_t ldz, const float* stats_below, const float* gamma_below,
                               const float* beta_below, int relu_below, float* dgamma_below, float* dbeta_below,
-                              float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes, const int32_t* rindptr,
-                              const int32_t* rindices, const float* rweight, void* stream);
-/* (q may be NULL when the out-edge CSR rindptr / rindices / rweight -- weights x 1 / in_degree(dst) -- is given: the kernel then
- * forms q = A_w^T (norm dl) itself, in the summation order of gte_spmm_csr: one 9-wide aggregation launch less.) */
-int gte_sage_narrow_bwd_ln(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
-                           int64_t n_feat, const float* W, int64_t ldw, int64_t n_out, float* dz_below, int64_t lddz,
-                           float* dW, int64_t lddw, float* dbias, int64_t n_nodes, void* workspace, int64_t workspace_bytes,
-                           const void* ce_partial, float grad_scale, float* out3, const float* z_below, int64_t ldz,
-                           const float* stats_below, const float* gamma_below, const float* beta_below, int relu_below,
-                           float* dgamma_below, float* dbeta_below, float* dbias_below, void* ln_workspace,
-                           int64_t ln_workspace_bytes, void* stream);
+                              float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes, void* stream);
 
 /* LayerNorm + ReLU alone (row-wise over n_out):  y = relu?(gamma * (z - mean) * rstd + beta).
  * replaces models.py:64-66 when the caller ran the linear part separately.  In place (y == z) is

@@ -376,41 +376,6 @@ def test_narrow_fwd_with_fused_layernorm_forward(n, f, c, relu):
     np.testing.assert_allclose(ts.cpu().numpy(), ts2.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("n,f,c,relu", [(1000, 256, 9, True), (333, 64, 4, False), (24495, 256, 9, True), (77, 128, 16, True)])
-def test_narrow_bwd_with_fused_layernorm_backward(n, f, c, relu):
-    """gte_sage_narrow_bwd_ln == gte_sage_narrow_bwd followed by gte_ln_relu_bwd of the layer below (dz, dgamma, dbeta,
-    dbias of that layer; dW / dbias of the output layer unchanged)."""
-    lib = gte._lib.load()
-    P, cs, check = gte._lib.ptr, gte._lib.current_stream, gte._lib.check
-    rng = np.random.default_rng(n + f)
-    new = lambda *s: torch.empty(*s, device=DEV)
-    z = dev(rng.standard_normal((n, f)).astype(np.float32))
-    gam, bet = dev(1 + 0.1 * rng.standard_normal(f).astype(np.float32)), dev(0.1 * rng.standard_normal(f).astype(np.float32))
-    h, stats = new(n, f), new(2 * n)
-    check(lib.gte_ln_relu_fwd(P(z), f, P(gam), P(bet), 1e-5, int(relu), P(h), f, P(stats), n, f, cs()), "ln fwd")
-    W = dev((rng.standard_normal((c, 2 * f)) / np.sqrt(2 * f)).astype(np.float32))
-    dl, q = dev(rng.standard_normal((n, c)).astype(np.float32) / n), dev(rng.standard_normal((n, c)).astype(np.float32) / n)
-    wsn = torch.empty(int(lib.gte_sage_narrow_bwd_workspace_bytes(n, f, c)), dtype=torch.uint8, device=DEV)
-    # separate
-    dh, dWa, dba = new(n, f), new(c, 2 * f), new(c)
-    check(lib.gte_sage_narrow_bwd(P(dl), c, P(q), c, P(h), f, f, P(W), 2 * f, c, P(dh), f, P(dWa), 2 * f, P(dba), n, P(wsn),
-                                  wsn.numel(), cs()), "bwd")
-    dga, dbea, dbia = new(f), new(f), new(f)
-    wl = torch.empty(int(lib.gte_ln_relu_bwd_workspace_bytes(n, f)), dtype=torch.uint8, device=DEV)
-    check(lib.gte_ln_relu_bwd(P(dh), f, P(z), f, P(stats), P(gam), P(bet), int(relu), P(dh), f, P(dga), P(dbea), P(dbia), n, f,
-                              P(wl), wl.numel(), cs()), "ln bwd")
-    # fused
-    dzb, dWb, dbb, dgb, dbeb, dbib = new(n, f), new(c, 2 * f), new(c), new(f), new(f), new(f)
-    wln = torch.empty(int(lib.gte_sage_narrow_bwd_ln_workspace_bytes(n, f)), dtype=torch.uint8, device=DEV)
-    check(lib.gte_sage_narrow_bwd_ln(P(dl), c, P(q), c, P(h), f, f, P(W), 2 * f, c, P(dzb), f, P(dWb), 2 * f, P(dbb), n, P(wsn),
-                                     wsn.numel(), None, 1.0, None, P(z), f, P(stats), P(gam), P(bet), int(relu), P(dgb), P(dbeb),
-                                     P(dbib), P(wln), wln.numel(), cs()), "bwd_ln")
-    # (dW / dbias: same partial sums, folded by a different kernel -> last-bit differences only)
-    for got, want in ((dWb, dWa), (dbb, dba), (dzb, dh), (dgb, dga), (dbeb, dbea), (dbib, dbia)):
-        ref = want.cpu().numpy()
-        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=3e-6 * np.abs(ref).max() + 1e-12)
-
-
 @pytest.mark.parametrize("n,f,c,relu", [(1000, 256, 9, True), (333, 64, 4, False), (24495, 256, 9, True), (77, 128, 16, True), (1, 256, 9, True)])
 def test_narrow_bwd_with_layernorm_backward_in_row_form_is_bitwise_the_two_launches(n, f, c, relu):
     """gte_sage_narrow_bwd_ln_p3 (the dh tile of a row block through LDS, whole rows in the layout and with the arithmetic of
@@ -449,7 +414,7 @@ def test_narrow_bwd_with_layernorm_backward_in_row_form_is_bitwise_the_two_launc
     check(lib.gte_sage_narrow_bwd_ln_p3(P(dl), c, P(q), c, P(h), f, f, P(W), 2 * f, c, P(dzb), f,
                                         P(dzp_b.data) if dzp_b is not None else None, dzp_b.ldp if dzp_b is not None else 0,
                                         P(dWb), 2 * f, P(dbb), n, P(wsn), wsn.numel(), None, 1.0, None, P(z), 2 * f, P(stats), P(gam),
-                                        P(bet), int(relu), P(dgb), P(dbeb), P(dbib), P(wln), wln.numel(), None, None, None, cs()),
+                                        P(bet), int(relu), P(dgb), P(dbeb), P(dbib), P(wln), wln.numel(), cs()),
           "bwd_ln_p3")
     if img:
         assert torch.equal(dzb, dh)
@@ -462,42 +427,6 @@ def test_narrow_bwd_with_layernorm_backward_in_row_form_is_bitwise_the_two_launc
     for got, want in ((dWb, dWa), (dbb, dba), (dgb, dga), (dbeb, dbea), (dbib, dbia)):
         ref = want.cpu().numpy()
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=3e-6 * np.abs(ref).max() + 1e-12)
-
-
-@pytest.mark.parametrize("n,f,c", [(3000, 256, 9), (24495, 256, 12), (500, 128, 16), (40, 256, 1)])
-def test_narrow_bwd_forms_q_from_the_out_edge_csr_bitwise(n, f, c):
-    """gte_sage_narrow_bwd_ln_p3 with q = NULL and the out-edge CSR: the kernel's own q = A_w^T (norm dl) has the summation order of
-    gte_spmm_csr, so every output is bit for bit the call that is handed the aggregated q."""
-    lib = gte._lib.load()
-    P, cs, check = gte._lib.ptr, gte._lib.current_stream, gte._lib.check
-    rng = np.random.default_rng(n + c)
-    new = lambda *s: torch.empty(*s, device=DEV)
-    src, dst = rng.integers(0, n, 6 * n), rng.integers(0, n, 6 * n)        # duplicates, self loops, rows without out-edges
-    src[src == n // 2] = 0
-    w = rng.random(6 * n).astype(np.float32)
-    g = G.PageGraph(src, dst, n, device=DEV)
-    rcsr = g.out_csr()
-    w_out = g.out_weights(dev(w), True)
-    t = dev(rng.standard_normal((n, 2 * f)).astype(np.float32))
-    z = t[:, :f]
-    gam, bet = dev(1 + 0.1 * rng.standard_normal(f).astype(np.float32)), dev(0.1 * rng.standard_normal(f).astype(np.float32))
-    h, stats = new(n, f), new(2 * n)
-    check(lib.gte_ln_relu_fwd(P(z), 2 * f, P(gam), P(bet), 1e-5, 1, P(h), f, P(stats), n, f, cs()), "ln fwd")
-    W = dev((rng.standard_normal((c, 2 * f)) / np.sqrt(2 * f)).astype(np.float32))
-    dl = dev(rng.standard_normal((n, c)).astype(np.float32) / n)
-    q = ops.spmm_csr(rcsr.indptr, rcsr.indices, w_out, dl, n, mean=False)
-    wsn = torch.empty(int(lib.gte_sage_narrow_bwd_workspace_bytes(n, f, c)), dtype=torch.uint8, device=DEV)
-    wln = torch.empty(int(lib.gte_sage_narrow_bwd_ln_workspace_bytes(n, f)), dtype=torch.uint8, device=DEV)
-    outs = []
-    for own in (False, True):
-        dz, dzp, dW, db, dg, dbe, dbi = new(n, f), ops.P3.empty(n, f, DEV), new(c, 2 * f), new(c), new(f), new(f), new(f)
-        check(lib.gte_sage_narrow_bwd_ln_p3(P(dl), c, None if own else P(q), c, P(h), f, f, P(W), 2 * f, c, P(dz), f, P(dzp.data), dzp.ldp,
-                                            P(dW), 2 * f, P(db), n, P(wsn), wsn.numel(), None, 1.0, None, P(z), 2 * f, P(stats), P(gam),
-                                            P(bet), 1, P(dg), P(dbe), P(dbi), P(wln), wln.numel(), P(rcsr.indptr), P(rcsr.indices),
-                                            P(w_out), cs()), "bwd_ln_p3")
-        outs.append((dz, dzp.data.clone(), dW, db, dg, dbe, dbi))
-    for a, b_ in zip(*outs):
-        assert torch.equal(a, b_)
 
 
 @pytest.mark.parametrize("n,f,c,weighted,flt", [(1500, 256, 9, True, True), (777, 64, 4, False, False), (65, 8, 16, True, False),

@@ -77,22 +77,6 @@ def test_row_map_batches_are_bitwise_the_copied_image_batches(monkeypatch, c_ste
     assert a[5] == "rows" and b[5] == "copy"
 
 
-def test_graph_launched_step_is_bitwise_the_eager_step(monkeypatch):
-    """GTE_STEP_GRAPH=1: every step is captured and launched as one executable graph that is updated in place per batch (batches
-    of different sizes): same bits as the eager one-call step.  Needs a non-default current stream."""
-    side = torch.cuda.Stream()
-    outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("GTE_STEP_GRAPH", flag)
-        with torch.cuda.stream(side):
-            outs.append(_run(monkeypatch, True, 831, 256, True, resident=True, steps=4))
-        side.synchronize()
-    for x, y in zip(outs[0][:4], outs[1][:4]):
-        np.testing.assert_array_equal(x, y)
-    lib = __import__("gnn_tableextraction_amd")._lib.load()
-    assert lib.gte_gcnsage_step_graph(None, None, None, None) == -1        # null exec slot
-
-
 def test_step_plan_rejects_bad_plans():
     import ctypes
     from gnn_tableextraction_amd import _lib
