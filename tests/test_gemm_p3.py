@@ -194,7 +194,8 @@ def test_row_map_entry_points_validate():
 
 # ---- the backward GEMM with the LayerNorm backward of the layer below as its epilogue ---------------------------------------
 @pytest.mark.parametrize("m,n,k,relu", [(24437, 256, 256, True), (3000, 256, 256, False), (129, 128, 64, True), (1, 256, 256, True),
-                                        (40000, 256, 128, True), (500, 144, 256, True)])
+                                        (40000, 256, 128, True), (500, 144, 256, True), (40000, 256, 256, True), (80000, 256, 256, True),
+                                        (80149, 96, 96, False)])
 def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(m, n, k, relu):
     """gte_gemm_p3_nt_ln_bwd: dy = [dz1 | q1] [W_s^T | W_n^T]^T is never stored; dz0 (fp32 and image) must be bit for bit what
     gte_gemm_p3_nt + gte_ln_relu_bwd_p3 produce, the column sums agree to summation order."""
