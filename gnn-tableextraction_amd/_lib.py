@@ -22,6 +22,9 @@ SIGNATURES = {
                              c_int64, c_int64, c_int, c_int, c_void_p]),
     "gte_spmm_csr_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                         c_int64, c_int64, c_int, c_int, c_void_p]),
+    "gte_spmm_csr_edge_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "gte_spmm_csr_edge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int,
+                                  c_void_p, c_int64, c_void_p]),
     "gte_spmm_tile_rows": (c_int, []),
     "gte_spmm_csr_tiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),

@@ -181,7 +181,7 @@ __device__ __forceinline__ void wait_dma_barrier() {
 #define P3_SCHED 1        // 0: the compiler's own order inside a stage
 #endif
 #define GTE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-constexpr int SG_VALU = 0x002, SG_SALU = 0x004, SG_MFMA = 0x008, SG_VMEM_R = 0x020, SG_DS_R = 0x100, SG_DS_W = 0x200;
+constexpr int SG_MFMA = 0x008, SG_VMEM_R = 0x020, SG_DS_R = 0x100;      // (sched_group_barrier masks: 0x002 VALU, 0x004 SALU, 0x200 DS write)
 #ifndef P3_ABL
 #define P3_ABL 0          // measurement builds only (profiles/micro/gemm_p3_abl.hip): 1 no DMA, 2 no barrier, 4 fragments read once,
 #endif                    // 8 no MFMA, 16 clock stamps into p.slab; results are wrong by construction when a bit is set

@@ -371,6 +371,188 @@ int spmm_entry(bool accumulate, const int32_t* indptr, const int32_t* indices, c
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// Edge-parallel aggregation with a wavefront-level segmented reduction (skewed graphs: hub rows)
+// ---------------------------------------------------------------------------------------------------------------
+// The row kernels above give a destination row to ONE lane group, which walks the row's edges four at a time: a 3 000-edge hub
+// is 750 dependent rounds on one wave while the rest of the chip idles.  Here the unit of work is a SEGMENT of 64 consecutive
+// edges of the CSR order, one wave per segment whatever rows it cuts: the wave reads its 64 (source, weight) pairs coalesced,
+// one per lane, and reduces them SEGMENTED BY DESTINATION ROW -- lanes across the feature row (16-byte chunks), edges
+// broadcast from their lanes, four source rows in flight, a row's sum closed when its last edge (or the segment's) is reached.
+// Rows that lie inside one segment are written directly; a row cut by a segment boundary leaves partial sums -- TAIL (the row
+// starts in the segment and runs on) or HEAD (it started earlier) -- in a carry buffer, and a second pass adds a row's TAIL and
+// HEADs in segment order.  Fixed segmentation, fixed order: bit-reproducible run to run; rows inside a segment are summed in CSR
+// order exactly as the row kernels do.  Rows without edges are zero-filled by the segment holding the last edge before them.
+constexpr int EP_SEG = 64;
+
+template <int CPL>
+__global__ void __launch_bounds__(256)
+spmm_edge_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ ew,
+                 const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo, int n_rows, int n_edges, int n_feat,
+                 int reduce, float* __restrict__ carry, int32_t* __restrict__ carry_row, int64_t ldc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int seg = blockIdx.x * 4 + wave;
+    const int e0 = seg * EP_SEG;
+    if (e0 >= n_edges) return;
+    const int e1 = min(e0 + EP_SEG, n_edges);
+    const int my_e = e0 + lane;
+    int my_u = 0;
+    float my_w = 0.f;
+    if (my_e < e1) { my_u = indices[my_e]; my_w = ew ? ew[my_e] : 1.0f; }
+    // the row of the segment's first edge: the last r with indptr[r] <= e0 (uniform binary search)
+    int lo = 0, hi = n_rows - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (indptr[mid] <= e0) lo = mid; else hi = mid - 1;
+    }
+    int r = lo;
+    int32_t* crow = carry_row + 2 * (int64_t)seg;              // {row of the HEAD partial, row of the TAIL partial} or -1
+    if (lane == 0) { crow[0] = -1; crow[1] = -1; }
+    float* chead = carry + (int64_t)seg * 2 * ldc;
+    float* ctail = chead + ldc;
+    const int nchunk = (n_feat + 3) / 4;
+    auto zero_rows = [&](int ra, int rb) {                     // rows [ra, rb) have no edges
+        for (int rr = ra; rr < rb; ++rr)
+            for (int c = lane; c < nchunk; c += 64) {
+                float* o = out + (int64_t)rr * ldo + 4 * c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (4 * c + q < n_feat) o[q] = 0.f;
+            }
+    };
+    if (seg == 0 && r > 0) zero_rows(0, r);                    // (leading empty rows)
+    int e = e0;
+    while (e < e1) {
+        const int row_lo = indptr[r], row_hi = indptr[r + 1];
+        const int se = min(row_hi, e1);
+        const bool starts = row_lo >= e0, ends = row_hi <= e1;
+        const float scale = (reduce == GTE_REDUCE_MEAN) ? 1.0f / (float)(row_hi - row_lo) : 1.0f;
+        for (int cb = 0; cb < nchunk; cb += 64 * CPL) {
+            float acc[CPL][4];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][q] = 0.f;
+            for (int t = e; t < se; t += kEdgeUnroll) {
+                int u[kEdgeUnroll];
+                float w[kEdgeUnroll];
+#pragma unroll
+                for (int k = 0; k < kEdgeUnroll; ++k) {
+                    const int tt = min(t + k, se - 1) - e0;      // past the end: the last valid source (cache hit), weight 0
+                    u[k] = __shfl(my_u, tt, 64);
+                    w[k] = (t + k < se) ? __shfl(my_w, tt, 64) : 0.f;
+                }
+                float v[kEdgeUnroll][CPL][4];
+#pragma unroll
+                for (int k = 0; k < kEdgeUnroll; ++k) {
+                    const float* xr = x + (int64_t)u[k] * ldx;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const int c = cb + lane + 64 * j;
+                        if (4 * c + 3 < n_feat) {
+                            const f4u tq = *reinterpret_cast<const f4u*>(xr + 4 * c);
+                            v[k][j][0] = tq.x; v[k][j][1] = tq.y; v[k][j][2] = tq.z; v[k][j][3] = tq.w;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[k][j][q] = 4 * c + q < n_feat ? xr[4 * c + q] : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kEdgeUnroll; ++k)
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[j][q] = fmaf(w[k], v[k][j][q], acc[j][q]);
+            }
+            // the row's sum over this segment: final (scaled, to out) or a partial (unscaled, to the carry buffer)
+            float* dst = (starts && ends) ? out + (int64_t)r * ldo : (starts ? ctail : chead);
+            const float sc = (starts && ends) ? scale : 1.0f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const int c = cb + lane + 64 * j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (4 * c + q < n_feat) dst[4 * c + q] = acc[j][q] * sc;
+            }
+        }
+        if (lane == 0 && !(starts && ends)) crow[starts ? 1 : 0] = r;
+        e = se;
+        if (ends) {                                            // on to the next row that has edges; empty rows in between are zero
+            int rn = r + 1;
+            while (rn < n_rows && indptr[rn + 1] == row_hi) ++rn;
+            if (rn > r + 1) zero_rows(r + 1, rn);
+            r = rn;
+        }
+    }
+}
+
+// second pass: the rows cut by segment boundaries.  One wave per segment that holds a TAIL: the row's TAIL and the HEADs of the
+// following segments (their number follows from the row's end), added in segment order.
+__global__ void __launch_bounds__(256)
+spmm_edge_carry_kernel(const int32_t* __restrict__ indptr, const float* __restrict__ carry, const int32_t* __restrict__ carry_row,
+                       int64_t ldc, float* __restrict__ out, int64_t ldo, int n_seg, int n_feat, int reduce) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int seg = blockIdx.x * 4 + wave;
+    if (seg >= n_seg) return;
+    const int r = carry_row[2 * (int64_t)seg + 1];
+    if (r < 0) return;
+    const int row_lo = indptr[r], row_hi = indptr[r + 1];
+    const int last = (row_hi - 1) / EP_SEG;                    // the segment of the row's last edge
+    const float scale = (reduce == GTE_REDUCE_MEAN) ? 1.0f / (float)(row_hi - row_lo) : 1.0f;
+    for (int c = lane; 4 * c < n_feat; c += 64) {
+        float s[4];
+        const float* t = carry + ((int64_t)seg * 2 + 1) * ldc + 4 * c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = 4 * c + q < n_feat ? t[q] : 0.f;
+        for (int g = seg + 1; g <= last; ++g) {
+            const float* h = carry + (int64_t)g * 2 * ldc + 4 * c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] += 4 * c + q < n_feat ? h[q] : 0.f;
+        }
+        float* o = out + (int64_t)r * ldo + 4 * c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (4 * c + q < n_feat) o[q] = s[q] * scale;
+    }
+}
+
+extern "C" int64_t gte_spmm_csr_edge_workspace_bytes(int64_t n_edges, int64_t n_feat) {
+    const int64_t n_seg = gte::ceil_div(n_edges > 0 ? n_edges : 1, EP_SEG), ldc = gte::round_up(n_feat > 0 ? n_feat : 1, 4);
+    return gte::round_up(n_seg * 2 * ldc * 4 + n_seg * 2 * 4, 256);
+}
+
+// out[v, :] = scale_v * sum_e w[e] x[indices[e], :] with the work split by EDGES (64-edge segments, one wave each) instead of by
+// rows: the aggregation for graphs with hub rows (max in-degree > 64).  fp32; results equal gte_spmm_csr's up to the summation
+// order of rows that span segments.  workspace: gte_spmm_csr_edge_workspace_bytes(n_edges, n_feat).
+extern "C" int gte_spmm_csr_edge(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x, int64_t ldx,
+                                 float* out, int64_t ldo, int64_t n_rows, int64_t n_edges, int64_t n_feat, int reduce, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+    if (n_rows < 0 || n_edges < 0 || n_feat < 0 || n_rows > INT32_MAX || n_edges > INT32_MAX - EP_SEG || n_feat > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_edge: bad sizes");
+    if (n_rows == 0 || n_feat == 0) return GTE_OK;
+    if (!indptr || !x || !out || (n_edges > 0 && (!indices || !workspace))) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_edge: null pointer");
+    if (ldx < n_feat || ldo < n_feat) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_edge: ld < n_feat");
+    if (reduce != GTE_REDUCE_SUM && reduce != GTE_REDUCE_MEAN) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_edge: reduce must be 0 or 1");
+    hipStream_t s = gte::as_stream(stream);
+    if (n_edges == 0) {                                        // no edges: every row is zero
+        for (int64_t r = 0; r < n_rows; ++r)
+            if (hipMemsetAsync(out + r * ldo, 0, (size_t)n_feat * 4, s) != hipSuccess) return gte::fail(GTE_ERR_LAUNCH, "spmm_csr_edge: memset failed");
+        return GTE_OK;
+    }
+    if (workspace_bytes < gte_spmm_csr_edge_workspace_bytes(n_edges, n_feat))
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "spmm_csr_edge: workspace too small");
+    const int64_t n_seg = gte::ceil_div(n_edges, EP_SEG), ldc = gte::round_up(n_feat, 4);
+    float* carry = reinterpret_cast<float*>(workspace);
+    int32_t* crow = reinterpret_cast<int32_t*>(carry + n_seg * 2 * ldc);
+    const dim3 grid((unsigned)gte::ceil_div(n_seg, 4)), block(256);
+    const int64_t nchunk = gte::ceil_div(n_feat, 4);
+#define GTE_EP(CPL)                                                                                                          \
+    hipLaunchKernelGGL((spmm_edge_kernel<CPL>), grid, block, 0, s, indptr, indices, eweight, x, ldx, out, ldo, (int)n_rows, \
+                       (int)n_edges, (int)n_feat, reduce, carry, crow, ldc)
+    if (nchunk <= 64) GTE_EP(1); else if (nchunk <= 128) GTE_EP(2); else GTE_EP(4);
+#undef GTE_EP
+    hipLaunchKernelGGL(spmm_edge_carry_kernel, grid, block, 0, s, indptr, carry, crow, ldc, out, ldo, (int)n_seg, (int)n_feat, reduce);
+    return gte::check_launch("spmm_csr_edge");
+}
+
 extern "C" int gte_spmm_csr(const int32_t* indptr, const int32_t* indices, const float* eweight, const void* x,
                             int64_t ldx, void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int dtype,
                             int reduce, void* stream) {

@@ -33,10 +33,11 @@ class _FrameDict(dict):
 
 
 class CSR:
-    __slots__ = ("indptr", "indices", "perm")
+    __slots__ = ("indptr", "indices", "perm", "max_deg")
 
     def __init__(self, indptr, indices, perm):
         self.indptr, self.indices, self.perm = indptr, indices, perm
+        self.max_deg = None           # largest row, read from the device on first use (_max_degree)
 
 
 def _build_csr(key: torch.Tensor, other: torch.Tensor, n: int) -> CSR:
@@ -54,6 +55,13 @@ def _build_csr(key: torch.Tensor, other: torch.Tensor, n: int) -> CSR:
     indptr = torch.zeros(n + 1, dtype=torch.int64, device=key.device)
     indptr[1:] = torch.cumsum(counts, 0)
     return CSR(indptr.to(torch.int32), other[perm].to(torch.int32).contiguous(), perm.to(torch.int32))
+
+
+def _max_degree(csr) -> int:
+    if getattr(csr, "max_deg", None) is None:
+        ip = csr.indptr
+        csr.max_deg = int((ip[1:] - ip[:-1]).max()) if ip.numel() > 1 else 0
+    return csr.max_deg
 
 
 class PageGraph:
@@ -114,6 +122,14 @@ class PageGraph:
     def out_degrees(self) -> torch.Tensor:
         ip = self.out_csr().indptr
         return (ip[1:] - ip[:-1]).to(torch.int64)
+
+    def max_in_degree(self) -> int:
+        """Largest in-degree (cached with the CSR, which local_var() copies share: one device->host read per graph): hub rows
+        send the aggregation to the edge-parallel kernel (ops.spmm_csr)."""
+        return _max_degree(self.in_csr())
+
+    def max_out_degree(self) -> int:
+        return _max_degree(self.out_csr())
 
     def local_var(self) -> "PageGraph":
         """Shallow copy: new ndata/edata dicts over the same tensors and the same cached CSRs
@@ -383,6 +399,7 @@ class ResidentPages:
         self.node_off = self.node_off_host.to(torch.int32).to(self.device)
         page_of_node = torch.repeat_interleave(torch.arange(len(graphs), device=self.device),
                                                torch.tensor(sizes, device=self.device))
+        self.max_deg = {"in": _max_degree(whole.in_csr()), "out": _max_degree(whole.out_csr())}     # (bounds for every batch)
         self._sets = {}
         for name, csr, wt in (("in", whole.in_csr(), whole.in_weights(w)),
                               ("out", whole.out_csr(), whole.out_weights(w, True))):
@@ -476,6 +493,7 @@ class ResidentPages:
             descs.append(_lib.BatchArrays(P(s["edge_off"]), P(s["indptr_loc"]), P(s["indices_loc"]), P(s["weight"]) or None,
                                           P(b_eoff), P(indptr), P(indices), P(wout) or None))
             csrs.append(CSR(indptr, indices, None))
+            csrs[-1].max_deg = self.max_deg[name]        # (no device read per batch)
             weights.append(wout)
         f = self.feat.shape[1]
         p3 = bufs.get("feat_p3") is not None

@@ -521,8 +521,23 @@ class FusedGcnSageStep(TrainStep):
             k = self._layer_kind(i, L, dims[i], n)
             if k is None:
                 return None
+            # (the planes GEMMs address their output through 32-bit buffer offsets: [n][2 ld] fp32 must stay below 2 GB)
+            if k != 1 and (n + 256) * 2 * _c16(L.out_feats) * 4 >= (1 << 31):
+                return None
             kinds.append(k)
         return kinds
+
+    def attach_feature_image(self, g) -> bool:
+        """Give a graph that is evaluated again and again (the validation graph of train(): the same graph every epoch,
+        model_train.py:246,349-353 of the reference) the P3 image of its features, made ONCE: forward_logits then runs the one-call
+        plan on the planes kernels instead of the module path.  False when layer 0 does not take an image."""
+        if getattr(g, "feat_p3", None) is not None:
+            return True
+        x = g.ndata.get('feat')
+        if x is None or not x.is_cuda or not self.wants_p3_features(x.shape[1]):
+            return False
+        g.feat_p3 = ops.p3_from_f32(ops._row_major(x.to(torch.float32)))
+        return True
 
     def _plan_mode(self, kinds, f0: int):
         """(general, out_gemm) of a plan: ``general`` = it runs on the padded buffer set (_alloc_gen) -- some hidden layer lies

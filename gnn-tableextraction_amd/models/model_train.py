@@ -199,6 +199,10 @@ def train(data, config, name_time=None):
     val_shard = val_graphs[rank::world] if distributed else val_graphs
     val_graph = G.batch([g.to(device) for g in val_shard]) if val_shard else None
     val_labels = None if val_graph is None else val_graph.ndata['label']
+    if val_graph is not None and hasattr(step, "attach_feature_image"):
+        # the validation graph is the same graph every epoch (reference model_train.py:246): its feature image is made once and
+        # the per-epoch forward runs on the planes kernels (engine.forward_logits)
+        step.attach_feature_image(val_graph)
     label_ids = [v for v in range(n_classes)]
 
     say("\n### START TRAINING ###\n")

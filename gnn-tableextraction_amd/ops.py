@@ -182,14 +182,42 @@ def use_tiled(n_rows: int, n_feat: int, nnz: Optional[int] = None, fused_ln: boo
     return nbytes >= TILED_MIN_BYTES and (nnz is None or nnz >= TILED_MIN_DEGREE * n_rows)
 
 
+EDGE_PARALLEL_MIN_DEGREE = 64      # graphs whose largest row exceeds this take the edge-parallel kernel (gte_spmm_csr_edge)
+
+
+def spmm_csr_edge(indptr, indices, weight, x: torch.Tensor, n_rows: int, mean: bool = False,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The same contraction with the work split by EDGES (one wave per 64-edge segment of the CSR order, reduced segmented by
+    destination row, two-pass carry for rows cut by a segment boundary): gte_spmm_csr_edge, for graphs with hub rows."""
+    require_device(x, "spmm_csr_edge")
+    lib = _lib.load()
+    x = _row_major(x)
+    if x.dtype != torch.float32:
+        raise TypeError("spmm_csr_edge: fp32 features only")
+    f, e = x.shape[1], int(indices.numel())
+    if out is None:
+        out = torch.empty((n_rows, f), dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.gte_spmm_csr_edge_workspace_bytes(e, f), x.device, "spmm_edge")
+    nnz_bytes = 8.0 * e if weight is not None else 4.0 * e
+    with _timed("spmm_edge", 2.0 * n_rows * f * 4 + nnz_bytes + 4.0 * (n_rows + 1)):
+        check(lib.gte_spmm_csr_edge(ptr(indptr), ptr(indices), ptr(weight), ptr(x), _ld(x), ptr(out), _ld(out), n_rows, e, f,
+                                    _lib.REDUCE_MEAN if mean else _lib.REDUCE_SUM, ptr(ws), ws.numel(), current_stream()),
+              "gte_spmm_csr_edge")
+    return out
+
+
 def spmm_csr(indptr, indices, weight, x: torch.Tensor, n_rows: int, mean: bool = False,
              out: Optional[torch.Tensor] = None, accumulate: bool = False,
-             tiles: Optional[TilePlan] = None, force_tiled: bool = False) -> torch.Tensor:
+             tiles: Optional[TilePlan] = None, force_tiled: bool = False, max_degree: Optional[int] = None) -> torch.Tensor:
     """out[v] = scale_v * sum_e w[e] * x[indices[e]] over row v of the CSR (fp32 or bf16 features).
-    With a ``TilePlan`` (and fp32 rows of >= 32 features) the LDS-staged kernel runs instead."""
+    With a ``TilePlan`` (and fp32 rows of >= 32 features) the LDS-staged kernel runs instead; with ``max_degree`` (the graph's
+    largest row) above EDGE_PARALLEL_MIN_DEGREE the edge-parallel kernel (hub rows would serialise a lane group)."""
     require_device(x, "spmm_csr")
     lib = _lib.load()
     x = _row_major(x)
+    if (max_degree is not None and max_degree > EDGE_PARALLEL_MIN_DEGREE and x.dtype == torch.float32 and not accumulate
+            and not force_tiled):
+        return spmm_csr_edge(indptr, indices, weight, x, n_rows, mean=mean, out=out)
     if tiles is not None and x.dtype == torch.float32 and (force_tiled or use_tiled(n_rows, x.shape[1], indices.numel())):
         f = x.shape[1]
         if out is None:
@@ -363,7 +391,7 @@ class _Aggregate(torch.autograd.Function):
         csr = graph.in_csr()
         ctx.graph, ctx.w, ctx.mean = graph, w, mean
         return spmm_csr(csr.indptr, csr.indices, graph.in_weights(w), h, graph.num_nodes(), mean=mean,
-                        tiles=graph.in_tiles())
+                        tiles=graph.in_tiles(), max_degree=graph.max_in_degree())
 
     @staticmethod
     def backward(ctx, dout):
@@ -371,7 +399,7 @@ class _Aggregate(torch.autograd.Function):
         rcsr = g.out_csr()
         # d h[u] = sum_{e: u->v} w_e * norm_v * dout[v]   (norm folded into the out-edge weights)
         dh = spmm_csr(rcsr.indptr, rcsr.indices, g.out_weights(ctx.w, ctx.mean), dout.contiguous(), g.num_nodes(),
-                      tiles=g.out_tiles())
+                      tiles=g.out_tiles(), max_degree=g.max_out_degree())
         return dh, None, None, None
 
 

@@ -62,6 +62,17 @@ int gte_spmm_csr(const int32_t* indptr, const int32_t* indices, const float* ewe
                  const void* x, int64_t ldx, void* out, int64_t ldo,
                  int64_t n_rows, int64_t n_feat, int dtype, int reduce, void* stream);
 
+/* The same contraction with the work split by EDGES instead of by rows -- the edge-parallel, wavefront-level segmented
+ * reduction BASELINE.json's north_star names for the call site models.py:53-54: one wave per segment of 64 consecutive edges
+ * of the CSR order, reduced segmented by destination row (lanes across the features, four source rows in flight); rows cut
+ * by a segment boundary leave partial sums in `workspace` and a second pass adds them in segment order (deterministic).  For
+ * graphs with hub rows (max in-degree > 64): a 3 000-edge row is 47 waves instead of one lane group walking 750 rounds.  fp32;
+ * equal to gte_spmm_csr up to the summation order of rows that span segments. */
+int64_t gte_spmm_csr_edge_workspace_bytes(int64_t n_edges, int64_t n_feat);
+int gte_spmm_csr_edge(const int32_t* indptr, const int32_t* indices, const float* eweight, const float* x, int64_t ldx,
+                      float* out, int64_t ldo, int64_t n_rows, int64_t n_edges, int64_t n_feat, int reduce, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+
 /* Same contraction, but ACCUMULATING into out (out += ...): lets the backward add the
  * transpose-aggregated gradient onto the self-path gradient without a temporary. */
 int gte_spmm_csr_accumulate(const int32_t* indptr, const int32_t* indices, const float* eweight,
