@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--no-cfg3", action="store_true", help="skip the GAT bf16 probe (BASELINE configs[2])")
     ap.add_argument("--no-shapes", action="store_true", help="skip the reference's own run shapes (hidden 1000 / scaled hidden)")
     ap.add_argument("--no-size-sweep", action="store_true", help="skip the pages-per-step sweep of the headline configuration")
+    ap.add_argument("--no-residency", action="store_true", help="skip the host-resident (windowed) training-set probe")
     ap.add_argument("--gemm-mode", choices=["f32", "split_bf16"], default=None,
                     help="arithmetic of the transform GEMMs for the headline loop (default: GTE_GEMM_MODE or f32)")
     ap.add_argument("--no-split-probe", action="store_true",
@@ -577,6 +578,75 @@ def size_sweep_probe(args, trainer, pipe, sizes, loop, first_epoch):
     return out
 
 
+def residency_probe(args, gte, dev, pages, loop):
+    """A training set that does NOT fit its HBM budget (models/residency.py): the pages in pinned host memory, two window slots on
+    the device, the next window uploaded on a copy stream while the current one trains, `passes` passes per window visit.  Same
+    model, same step stream on the all-resident set for the reference rate."""
+    from gnn_tableextraction_amd import graph as G
+    from gnn_tableextraction_amd.models import residency as R
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    graphs = to_page_graphs(gte, pages)
+    passes, n_steps = 4, 160
+
+    def fresh():
+        torch.manual_seed(42)
+        m = gte.GcnSAGE(args.in_feats, args.hidden, 9, args.layers, torch.nn.functional.relu, 0).to(dev)
+        return FusedGcnSageStep(m, lr=0.01, weight_decay=5e-4)
+    tr = fresh()
+    want_p3 = tr.wants_p3_features(args.in_feats)
+    t0 = time.perf_counter()
+    host = R.HostPages(graphs, dev)
+    build_s = time.perf_counter() - t0
+    per_node = R.WindowedPages.bytes_per_node(host.page_nodes, host.page_edges, args.in_feats, want_p3)
+    set_bytes = float(host.page_nodes.sum()) * per_node
+    budget = set_bytes / 2.5                                     # two slots of ~1/6 of the set each (+ the staging rows)
+    wp = R.WindowedPages(host, budget, want_p3)
+    stream = R.WindowStream(wp.ranges, args.pages, passes, 42)
+    wp.prefetch(stream.peek_window())
+    pipe = loop.BatchPipeline(wp.acquire(stream.peek_window()))
+    pipe._bound_pages = (host.page_nodes, np.diff(host.sets["in"]["edge_off"]), np.diff(host.sets["out"]["edge_off"]))
+    R.run_windowed(tr, pipe, wp, stream, 24)                     # warm-up
+    torch.cuda.synchronize()
+    up0 = wp.uploaded_bytes
+    nodes = [0]
+    t0 = time.perf_counter()
+    R.run_windowed(tr, pipe, wp, stream, n_steps, on_step=lambda s, g, o: nodes.__setitem__(0, nodes[0] + g.num_nodes()))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"workload": f"{len(pages)} pages ({set_bytes / 1e9:.2f} GB in resident form) under a budget of {budget / 1e9:.2f} GB: "
+                       f"{len(wp.ranges)} windows, {passes} passes per window visit, {args.pages} pages per step",
+           "windowed": {"value": nodes[0] / el, "unit": "nodes/s", "ms_per_step": el / n_steps * 1e3, "steps": n_steps,
+                        "device_bytes": wp.device_bytes, "upload_GB_per_s": (wp.uploaded_bytes - up0) / el / 1e9},
+           "host_build_s": build_s}
+    del tr, pipe
+    # the same stream on the all-resident set
+    tr2 = fresh()
+    res = G.ResidentPages(graphs, dev)
+    if want_p3:
+        res.enable_p3()
+    pipe2 = loop.BatchPipeline(res)
+    stream2 = R.WindowStream(wp.ranges, args.pages, passes, 42)
+
+    def run_resident(k):
+        n = 0
+        for w, steps in stream2.take(k):
+            p0 = wp.ranges[w][0]
+            loop.run_steps(tr2, pipe2, [ids + p0 for ids in steps])
+            n += sum(pipe2.nodes(i) for i in range(len(steps)))
+        return n
+    run_resident(24)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n2 = run_resident(n_steps)
+    torch.cuda.synchronize()
+    el2 = time.perf_counter() - t0
+    out["all_resident"] = {"value": n2 / el2, "unit": "nodes/s", "ms_per_step": el2 / n_steps * 1e3}
+    out["windowed_over_all_resident"] = out["windowed"]["value"] / out["all_resident"]["value"]
+    out["note"] = ("a step consumes its batch's feature rows at ~147 GB/s, PCIe delivers ~50: a window must be trained on for >= 3 "
+                   "passes per upload to hide it (models/residency.py)")
+    return out
+
+
 def cfg3_probe(args, gte, dev):
     """BASELINE configs[2]: "PubTables-1M table-structure graphs, 4-head GAT bf16" -- no reference counterpart (the
     reference has no GAT and builds no table graphs), PARITY UNPINNED (oracle = oracle/gat_cpu.py, the build's own restatement).
@@ -1041,6 +1111,8 @@ def main():
             if pages13 is not None:
                 sets[13] = pages13[:300]
             line["shapes"] = shapes_probe(args, gte, dev, sets, loop)
+        if extras and not args.no_residency and split_mode:
+            line["residency"] = residency_probe(args, gte, dev, pages, loop)
         if extras and not args.no_cfg3:
             line["cfg3"] = cfg3_probe(args, gte, dev)
         if world == 1 and not args.no_cpu_baseline:

@@ -417,6 +417,24 @@ class ResidentPages:
                                     indices_loc=indices_loc, indptr_loc=indptr_loc,
                                     weight=None if wt is None else wt.contiguous())
 
+    @classmethod
+    def from_arrays(cls, device, node_off_host: torch.Tensor, feat: torch.Tensor, label: Optional[torch.Tensor], sets: dict,
+                    weighted: bool, max_deg: dict, feat_p3=None, p3_mode=False) -> "ResidentPages":
+        """A resident set over arrays that already live on the device in this class's layout (models/residency.py: a WINDOW of a
+        host-resident dataset, uploaded slice by slice).  ``sets[name]`` = {edge_off (int32, device), edge_off_host (int64, cpu),
+        indptr_loc, indices_loc, weight | None}; ``feat`` may be an empty [0, F] placeholder when ``feat_p3`` carries the rows."""
+        self = cls.__new__(cls)
+        self.device = torch.device(device)
+        self.node_off_host = node_off_host
+        self.n_pages, self.n_nodes = int(node_off_host.numel() - 1), int(node_off_host[-1])
+        self.feat, self.feat_p3, self.p3_mode = feat, feat_p3, p3_mode
+        self.label = label
+        self.weighted = weighted
+        self.node_off = node_off_host.to(torch.int32).to(self.device)
+        self.max_deg = dict(max_deg)
+        self._sets = sets
+        return self
+
     def enable_p3(self) -> None:
         """Keep the features as a P3 image (three bf16 planes per value, csrc/p3.h: the operand format of the planes GEMMs)
         and assemble batches of image rows from now on: a batch then carries ``feat_p3`` instead of ``ndata['feat']``.

@@ -48,6 +48,20 @@ class BatchPipeline:
             eo = resident._sets[name]["edge_off_host"].numpy().astype(np.int64)
             self._page_ent.append(eo[1:] - eo[:-1])
 
+    def rebind(self, resident: G.ResidentPages) -> None:
+        """Another resident set of the same layout (the next WINDOW of a host-resident dataset, models/residency.py): the batch
+        buffer sets stay, the page table behind the metadata changes.  The caller orders the streams (every step on the old
+        set has been queued; its buffers are protected by the per-set events as before)."""
+        self.res = resident
+        self._ready = {}
+        self._info = None
+        self._page_nodes = (resident.node_off_host[1:] - resident.node_off_host[:-1]).numpy().astype(np.int64)
+        self._page_ent = []
+        for name in ("in", "out"):
+            eo = resident._sets[name]["edge_off_host"].numpy().astype(np.int64)
+            self._page_ent.append(eo[1:] - eo[:-1])
+        self._bound_nb = getattr(self, "_bound_nb", None) if getattr(self, "_bound_pages", None) else None
+
     # ---- per epoch -------------------------------------------------------------------------------
     def load(self, steps: Sequence[np.ndarray]) -> None:
         """Metadata of every step of an epoch (``steps[s]`` = page ids of step s): one upload."""
@@ -97,7 +111,9 @@ class BatchPipeline:
         nb_max = max(r[0].size for r in rows)
         if nb_max != getattr(self, "_bound_nb", None):
             top = lambda a: int(np.sort(a)[-nb_max:].sum())
-            self._bound = [top(self._page_nodes), top(self._page_ent[0]), top(self._page_ent[1])]
+            # (a windowed dataset bounds the batch by the pages of the WHOLE dataset: no reallocation when the window changes)
+            src = getattr(self, "_bound_pages", None) or (self._page_nodes, self._page_ent[0], self._page_ent[1])
+            self._bound = [top(src[0]), top(src[1]), top(src[2])]
             self._bound_nb = nb_max
         self._ensure_capacity([max(c, b) for c, b in zip(cap, self._bound)])
 

@@ -187,15 +187,51 @@ def train(data, config, name_time=None):
         say(f"=> loaded checkpoint '{ckpt_path}' (epoch {start_epoch})")
 
     train_graphs, val_graphs, _ = data.split(len(data))
-    # all training pages concatenated ONCE in HBM (features, labels, both CSRs, CSR-ordered weights); a batch is
-    # four kernel launches of index arithmetic instead of dgl.batch(...).to(device) per step (:297)
-    resident = G.ResidentPages(train_graphs, device)
-    pipe = BatchPipeline(resident)          # a step's batch is assembled on a side stream while the step before it runs
-    sizes = resident.page_sizes()
     # class-weighted data parallelism: every rank knows every page's labels, hence every step's weight sums (no exchange)
     page_wsum = None
     if distributed and cw is not None:
         page_wsum = [float(np.asarray(cw, dtype=np.float64)[g.ndata['label'].long().numpy()].sum()) for g in train_graphs]
+    # GTE_RESIDENT_BUDGET_GB: HBM the training pages may take per rank.  A set that fits is kept whole in HBM (below); a larger one
+    # stays in pinned host memory and a window of it is resident (models/residency.py).
+    budget_gb = float(os.environ.get("GTE_RESIDENT_BUDGET_GB", "0") or 0)
+    windowed = False
+    if budget_gb > 0:
+        from . import residency as R
+        all_nodes = np.array([g.num_nodes() for g in train_graphs], dtype=np.int64)
+        all_edges = np.array([g.num_edges() for g in train_graphs], dtype=np.int64)
+        want_p3 = bool(getattr(step, "wants_p3_features", lambda f: False)(in_feats))
+        set_bytes = float(all_nodes.sum()) * R.WindowedPages.bytes_per_node(all_nodes, all_edges, in_feats, want_p3)
+        windowed = set_bytes / max(world, 1) > budget_gb * 1e9
+    if windowed:
+        seed0 = config.PREPROCESS.get('seed', 42)
+        owner = R.page_owner(len(train_graphs), world, seed0)
+        passes = int(os.environ.get("GTE_WINDOW_PASSES", "4"))
+        mine = np.nonzero(owner == rank)[0]
+        host = R.HostPages([train_graphs[i] for i in mine], device)
+        wp = R.WindowedPages(host, budget_gb * 1e9, want_p3)
+        # every rank's stream (pure host logic): the node counts / weight sums of a step follow without communication
+        streams, rank_pages = [], []
+        for r in range(world):
+            ids = np.nonzero(owner == r)[0]
+            rank_pages.append(ids)
+            rng_ = R.WindowedPages.layout(all_nodes[ids], all_edges[ids], in_feats, budget_gb * 1e9, want_p3)
+            streams.append(R.WindowStream(rng_, batch_size, passes, seed0, rank=r))
+        assert streams[rank].ranges == wp.ranges
+        wp.prefetch(streams[rank].peek_window())
+        pipe = BatchPipeline(wp.acquire(streams[rank].peek_window()))
+        pipe._bound_pages = (host.page_nodes, np.diff(host.sets["in"]["edge_off"]), np.diff(host.sets["out"]["edge_off"]))
+        steps_per_epoch = min(len(ids) for ids in rank_pages) // batch_size
+        if steps_per_epoch == 0:
+            raise ValueError(f"{len(train_graphs)} training pages do not fill one global batch of {batch_size} pages x {world} rank(s)")
+        say(f"DATA: {set_bytes / 1e9:.3f} GB resident form > {budget_gb} GB budget per rank: host-resident, {len(wp.ranges)} windows per rank, "
+            f"{passes} passes per window visit, {wp.device_bytes / 1e9:.2f} GB on the device")
+        resident = sizes = None
+    else:
+        # all training pages concatenated ONCE in HBM (features, labels, both CSRs, CSR-ordered weights); a batch is
+        # four kernel launches of index arithmetic instead of dgl.batch(...).to(device) per step (:297)
+        resident = G.ResidentPages(train_graphs, device)
+        pipe = BatchPipeline(resident)          # a step's batch is assembled on a side stream while the step before it runs
+        sizes = resident.page_sizes()
     val_shard = val_graphs[rank::world] if distributed else val_graphs
     val_graph = G.batch([g.to(device) for g in val_shard]) if val_shard else None
     val_labels = None if val_graph is None else val_graph.ndata['label']
@@ -215,17 +251,45 @@ def train(data, config, name_time=None):
     gc.freeze()
     try:
         for epoch in range(start_epoch, config.TRAINING.n_epochs):
-            plan = D.plan_epoch(sizes, batch_size, world, seed=config.PREPROCESS.get('seed', 42), epoch=epoch)
-            counts = D.step_node_counts(plan, sizes)
-            scales = None
-            if page_wsum is not None:
-                wsums = D.step_weight_sums(plan, page_wsum)
-                scales = wsums[:, rank] / np.maximum(wsums.sum(axis=1), 1e-30)
-            # the same loop bench.py times: models/loop.py
-            out3 = run_steps(step, pipe, [ranks[rank] for ranks in plan], n_global=counts.sum(axis=1), loss_scale=scales)
-            if out3 is not None:
-                o = out3.cpu().tolist()
-                train_loss, train_acc = o[0], o[2] / max(int(counts[-1][rank]), 1)
+            if windowed:
+                # an epoch = the next len(train) // batch_size steps of every rank's stream (residency.WindowStream); the other
+                # ranks' streams are advanced on the host for the global node counts / weight sums of those steps
+                counts = np.zeros((steps_per_epoch, world), dtype=np.int64)
+                wsums = np.zeros((steps_per_epoch, world), dtype=np.float64) if page_wsum is not None else None
+                for r in range(world):
+                    if r == rank and not distributed:
+                        continue
+                    st = streams[r] if r != rank else None
+                    if st is None:          # this rank's own stream is consumed by run_windowed below: count on a copy
+                        import copy
+                        st = copy.deepcopy(streams[r])
+                    k = 0
+                    for w, chunk in st.take(steps_per_epoch):
+                        p0 = st.ranges[w][0]
+                        for ids in chunk:
+                            gl = rank_pages[r][p0 + ids]
+                            counts[k, r] = all_nodes[gl].sum()
+                            if wsums is not None:
+                                wsums[k, r] = float(np.asarray(page_wsum)[gl].sum())
+                            k += 1
+                scales = None if wsums is None else wsums[:, rank] / np.maximum(wsums.sum(axis=1), 1e-30)
+                out3, last_n = R.run_windowed(step, pipe, wp, streams[rank], steps_per_epoch,
+                                              n_global=counts.sum(axis=1) if distributed else None, loss_scale=scales)
+                if out3 is not None:
+                    o = out3.cpu().tolist()
+                    train_loss, train_acc = o[0], o[2] / max(int(last_n), 1)
+            else:
+                plan = D.plan_epoch(sizes, batch_size, world, seed=config.PREPROCESS.get('seed', 42), epoch=epoch)
+                counts = D.step_node_counts(plan, sizes)
+                scales = None
+                if page_wsum is not None:
+                    wsums = D.step_weight_sums(plan, page_wsum)
+                    scales = wsums[:, rank] / np.maximum(wsums.sum(axis=1), 1e-30)
+                # the same loop bench.py times: models/loop.py
+                out3 = run_steps(step, pipe, [ranks[rank] for ranks in plan], n_global=counts.sum(axis=1), loss_scale=scales)
+                if out3 is not None:
+                    o = out3.cpu().tolist()
+                    train_loss, train_acc = o[0], o[2] / max(int(counts[-1][rank]), 1)
 
             # ---- validation on the (sharded) batched val graph -------------------------------------------
             if val_graph is not None:
@@ -280,8 +344,11 @@ def train(data, config, name_time=None):
         gc.unfreeze()          # a library entry point must not leave the caller's objects in the permanent generation
 
     say("\n### TRAINING ENDED ###\n")
-    global LAST_RUN
-    LAST_RUN = {"model": model, "step": step, "rank": rank, "world": world}     # inspection handle (tests: replicas identical)
+    if os.environ.get("GTE_KEEP_LAST_RUN", "0") == "1":
+        # inspection handle for tests (replicas identical); opt-in: it pins the model and the engine's GB-scale device buffers
+        global LAST_RUN
+        LAST_RUN = {"model": model, "step": step, "rank": rank, "world": world,
+                    "windows": (len(wp.ranges), wp.uploaded_bytes, wp.device_bytes, host.n_pages) if windowed else None}
     if rank == 0:
         os.makedirs(res_dir, exist_ok=True)
         path = os.path.join(res_dir, f'{logs}.json')

@@ -126,8 +126,11 @@ def test_bench_self_spawned_two_ranks_share_the_gpu():
 # ---------------------------------------------------------------------------------------------------------------------
 # train() end to end with two ranks (the box has one GPU: both ranks on cuda:0, gloo): the eval confusion-matrix all-reduce
 # and the early-stop broadcast of model_train.py:230-249 run every epoch
-def _train_worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+def _train_worker(rank, world, port, out_dir, budget_gb=None):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      GTE_KEEP_LAST_RUN="1")
+    if budget_gb is not None:
+        os.environ.update(GTE_RESIDENT_BUDGET_GB=str(budget_gb), GTE_WINDOW_PASSES="2")
     import torch.distributed as dist
     from gnn_tableextraction_amd.components.graphs.loader import PrebuiltPages
     from gnn_tableextraction_amd.models import model_train
@@ -147,6 +150,8 @@ def _train_worker(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, f"train_m_{rank}.npy"), run["step"].exp_avg.detach().cpu().numpy())
     np.save(os.path.join(out_dir, f"train_metrics_{rank}.npy"),
             np.array([metrics.val.loss, metrics.val.acc, metrics.train.loss] + list(metrics.f1_vect)))
+    if run["windows"] is not None:
+        np.save(os.path.join(out_dir, f"train_windows_{rank}.npy"), np.array(run["windows"], dtype=np.float64))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -167,3 +172,22 @@ def test_train_end_to_end_with_two_ranks_keeps_the_replicas_identical(tmp_path):
     assert np.isfinite(m0).all() and m0[0] < np.log(9.0)
     assert os.path.isdir(tmp_path / "rank0" / "checkpoints") and os.path.isdir(tmp_path / "rank0" / "weights")
     assert not os.path.exists(tmp_path / "rank1" / "checkpoints") and not os.path.exists(tmp_path / "rank1" / "results")
+
+
+def test_windowed_residency_with_two_ranks(tmp_path):
+    """GTE_RESIDENT_BUDGET_GB below the training set's size: every rank keeps only ITS pages (about half of them) in pinned host
+    memory and a window of those in HBM (models/residency.py); the step streams of both ranks are computed on every rank
+    (global node counts without communication); replicas stay bit-identical."""
+    world = 2
+    # 38 training pages x ~230 nodes x 13 features x 4 B ~ 0.45 MB: a 0.0006 GB budget per rank forces several windows
+    mp.start_processes(_train_worker, args=(world, _free_port(), str(tmp_path), 0.0006), nprocs=world, join=True, start_method="spawn")
+    p0, p1 = (np.load(os.path.join(tmp_path, f"train_param_{r}.npy")) for r in range(world))
+    np.testing.assert_array_equal(p0, p1)
+    w0, w1 = (np.load(os.path.join(tmp_path, f"train_windows_{r}.npy")) for r in range(world))
+    assert w0[0] >= 2 and w1[0] >= 2                          # several windows per rank
+    assert abs(w0[3] - w1[3]) <= 1 and w0[3] + w1[3] == 38    # each rank holds about half of the 38 training pages
+    assert w0[1] > 0 and w0[2] <= 0.0006e9 * 1.6              # something was uploaded; the device slots respect the budget (+ CSR slack)
+    m0, m1 = (np.load(os.path.join(tmp_path, f"train_metrics_{r}.npy")) for r in range(world))
+    np.testing.assert_array_equal(m0[:2], m1[:2])             # all-reduced validation loss / accuracy (the train loss is rank-local)
+    np.testing.assert_array_equal(m0[3:], m1[3:])
+    assert np.isfinite(m0).all()

@@ -398,3 +398,56 @@ def test_edge_parallel_aggregation_beats_the_row_kernel_on_hub_rows():
     t_edge = t(lambda: ops.spmm_csr_edge(indptr, indices, w, x, n))
     print(f"hub graph: row kernel {t_row * 1e3:.1f} us, edge-parallel {t_edge * 1e3:.1f} us")
     assert t_edge * 3 <= t_row
+
+
+# ---------------------------------------------------------------- host-resident training sets (models/residency.py)
+@pytest.mark.parametrize("f0,hid", [(831, 256), (13, 256), (63, 200)])
+def test_windowed_run_is_bitwise_the_all_resident_run_on_the_same_step_stream(f0, hid):
+    """A training set kept in pinned host memory with a two-slot window in HBM (uploads on a copy stream while the previous
+    window trains, image conversion on the device, row-map batches) against the SAME step stream run on the all-resident set:
+    losses and parameters bit for bit after three sweeps' worth of steps."""
+    from gnn_tableextraction_amd.models import residency as R
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    from gnn_tableextraction_amd.models.loop import BatchPipeline, run_steps
+    pages = S.make_pages(48, in_feats=f0)
+    graphs = []
+    for p in pages:
+        g = gte.PageGraph(p.src, p.dst, p.num_nodes)
+        g.ndata["feat"], g.ndata["label"] = torch.from_numpy(p.feat), torch.from_numpy(p.label.astype(np.float32))
+        g.edata["feat"] = torch.from_numpy(p.weight)
+        graphs.append(g)
+    B, n_steps = 5, 40
+
+    def fresh():
+        torch.manual_seed(9)
+        m = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0).to(DEV)
+        return FusedGcnSageStep(m, lr=0.01, weight_decay=5e-4)
+    # windowed
+    tr = fresh()
+    want_p3 = tr.wants_p3_features(f0)
+    host = R.HostPages(graphs, DEV, chunk_bytes=1 << 20)                # (several construction chunks)
+    total = host.feature_bytes() * (1.5 if want_p3 else 1.0)
+    wp = R.WindowedPages(host, budget_bytes=total * 0.9, want_p3=want_p3)     # two slots of < half the set: >= 3 windows
+    assert len(wp.ranges) >= 3
+    stream = R.WindowStream(wp.ranges, B, passes=2, seed=5)
+    wp.prefetch(stream.peek_window())
+    pipe = BatchPipeline(wp.acquire(stream.peek_window()))
+    losses_w = []
+    R.run_windowed(tr, pipe, wp, stream, n_steps, on_step=lambda s, g, o: losses_w.append(o[:1].clone()))
+    torch.cuda.synchronize()
+    assert wp.uploaded_bytes > host.feature_bytes()                         # windows were revisited: more than one sweep
+    # all-resident, the same stream in global page ids
+    tr2 = fresh()
+    res = G.ResidentPages(graphs, DEV)
+    if want_p3:
+        res.enable_p3()
+    pipe2 = BatchPipeline(res)
+    stream2 = R.WindowStream(wp.ranges, B, passes=2, seed=5)
+    losses_r = []
+    for w, steps in stream2.take(n_steps):
+        p0 = wp.ranges[w][0]
+        run_steps(tr2, pipe2, [ids + p0 for ids in steps], on_step=lambda s, g, o: losses_r.append(o[:1].clone()))
+    torch.cuda.synchronize()
+    assert len(losses_w) == len(losses_r) == n_steps
+    assert torch.equal(torch.cat(losses_w), torch.cat(losses_r))
+    assert torch.equal(tr.flat_param, tr2.flat_param) and torch.equal(tr.exp_avg_sq, tr2.exp_avg_sq)
