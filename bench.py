@@ -586,7 +586,7 @@ def residency_probe(args, gte, dev, pages, loop):
     from gnn_tableextraction_amd.models import residency as R
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
     graphs = to_page_graphs(gte, pages)
-    passes, n_steps = 4, 160
+    n_steps = 240
 
     def fresh():
         torch.manual_seed(42)
@@ -601,31 +601,49 @@ def residency_probe(args, gte, dev, pages, loop):
     set_bytes = float(host.page_nodes.sum()) * per_node
     budget = set_bytes / 2.5                                     # two slots of ~1/6 of the set each (+ the staging rows)
     wp = R.WindowedPages(host, budget, want_p3)
-    stream = R.WindowStream(wp.ranges, args.pages, passes, 42)
-    wp.prefetch(stream.peek_window())
-    pipe = loop.BatchPipeline(wp.acquire(stream.peek_window()))
-    pipe._bound_pages = (host.page_nodes, np.diff(host.sets["in"]["edge_off"]), np.diff(host.sets["out"]["edge_off"]))
-    R.run_windowed(tr, pipe, wp, stream, 24)                     # warm-up
+    # raw pinned-host -> device rate of this box (one window's feature rows)
+    p0, p1 = wp.ranges[0]
+    n0, n1 = int(host.node_off[p0]), int(host.node_off[p1])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst = torch.empty((n1 - n0, args.in_feats), dtype=torch.float32, device=dev)
+    dst.copy_(host.feat[n0:n1], non_blocking=True)
+    e0.record()
+    dst.copy_(host.feat[n0:n1], non_blocking=True)
+    e1.record()
     torch.cuda.synchronize()
-    up0 = wp.uploaded_bytes
-    nodes = [0]
-    t0 = time.perf_counter()
-    R.run_windowed(tr, pipe, wp, stream, n_steps, on_step=lambda s, g, o: nodes.__setitem__(0, nodes[0] + g.num_nodes()))
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    h2d = (n1 - n0) * args.in_feats * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del dst
     out = {"workload": f"{len(pages)} pages ({set_bytes / 1e9:.2f} GB in resident form) under a budget of {budget / 1e9:.2f} GB: "
-                       f"{len(wp.ranges)} windows, {passes} passes per window visit, {args.pages} pages per step",
-           "windowed": {"value": nodes[0] / el, "unit": "nodes/s", "ms_per_step": el / n_steps * 1e3, "steps": n_steps,
-                        "device_bytes": wp.device_bytes, "upload_GB_per_s": (wp.uploaded_bytes - up0) / el / 1e9},
-           "host_build_s": build_s}
-    del tr, pipe
-    # the same stream on the all-resident set
+                       f"{len(wp.ranges)} windows, {args.pages} pages per step",
+           "host_build_s": build_s, "pinned_h2d_GB_per_s": h2d, "device_bytes": wp.device_bytes, "windowed": {}}
+    for passes in (4, 8):
+        tr = fresh()
+        stream = R.WindowStream(wp.ranges, args.pages, passes, 42)
+        wp.prefetch(stream.peek_window())
+        pipe = loop.BatchPipeline(wp.acquire(stream.peek_window()))
+        pipe._bound_pages = (host.page_nodes, np.diff(host.sets["in"]["edge_off"]), np.diff(host.sets["out"]["edge_off"]))
+        R.run_windowed(tr, pipe, wp, stream, 24)                     # warm-up
+        torch.cuda.synchronize()
+        up0 = wp.uploaded_bytes
+        nodes = [0]
+        t0 = time.perf_counter()
+        ht = {}
+        R.run_windowed(tr, pipe, wp, stream, n_steps, on_step=lambda s, g, o: nodes.__setitem__(0, nodes[0] + g.num_nodes()), host_times=ht)
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out["windowed"][f"passes_{passes}"] = {"value": nodes[0] / el, "unit": "nodes/s", "ms_per_step": el / n_steps * 1e3, "steps": n_steps,
+                                               "upload_GB_per_s": (wp.uploaded_bytes - up0) / el / 1e9,
+                                               "host_ms": {"queueing_total": t_host * 1e3, "prefetch_sync": getattr(wp, "sync_s", 0.0) * 1e3,
+                                                           **{k: (v * 1e3 if k != "chunks" else v) for k, v in ht.items()}}}
+        del tr, pipe
+    # the same kind of stream on the all-resident set
     tr2 = fresh()
     res = G.ResidentPages(graphs, dev)
     if want_p3:
         res.enable_p3()
     pipe2 = loop.BatchPipeline(res)
-    stream2 = R.WindowStream(wp.ranges, args.pages, passes, 42)
+    stream2 = R.WindowStream(wp.ranges, args.pages, 4, 42)
 
     def run_resident(k):
         n = 0
@@ -641,9 +659,10 @@ def residency_probe(args, gte, dev, pages, loop):
     torch.cuda.synchronize()
     el2 = time.perf_counter() - t0
     out["all_resident"] = {"value": n2 / el2, "unit": "nodes/s", "ms_per_step": el2 / n_steps * 1e3}
-    out["windowed_over_all_resident"] = out["windowed"]["value"] / out["all_resident"]["value"]
-    out["note"] = ("a step consumes its batch's feature rows at ~147 GB/s, PCIe delivers ~50: a window must be trained on for >= 3 "
-                   "passes per upload to hide it (models/residency.py)")
+    for k, v in out["windowed"].items():
+        v["over_all_resident"] = v["value"] / out["all_resident"]["value"]
+    out["note"] = ("a step consumes its batch's feature rows at ~147 GB/s; the host link delivers pinned_h2d_GB_per_s: a window has to "
+                   "be trained on for several passes per upload (GTE_WINDOW_PASSES) before the upload hides behind it")
     return out
 
 
@@ -853,6 +872,11 @@ def main():
     pages13 = None
     if extras and not args.no_secondary and args.in_feats != 13:
         pages13 = make_pages_parallel(min(args.resident_pages, 600), 13, 0, workers)
+    pages_res = None
+    if extras and not args.no_residency:
+        # the host-resident probe: a set big enough that a window holds several steps' pages (image < 4 GB: the all-resident
+        # reference keeps reading it through the row map)
+        pages_res = make_pages_parallel(1800, args.in_feats, 20_000_000, workers)
     pages363 = None
     if extras and not args.no_shapes and args.in_feats == 831:
         pages363 = make_pages_parallel(300, 363, 0, workers)
@@ -1112,7 +1136,8 @@ def main():
                 sets[13] = pages13[:300]
             line["shapes"] = shapes_probe(args, gte, dev, sets, loop)
         if extras and not args.no_residency and split_mode:
-            line["residency"] = residency_probe(args, gte, dev, pages, loop)
+            line["residency"] = residency_probe(args, gte, dev, pages + (pages_res or []), loop)
+            pages_res = None
         if extras and not args.no_cfg3:
             line["cfg3"] = cfg3_probe(args, gte, dev)
         if world == 1 and not args.no_cpu_baseline:

@@ -419,7 +419,7 @@ class ResidentPages:
 
     @classmethod
     def from_arrays(cls, device, node_off_host: torch.Tensor, feat: torch.Tensor, label: Optional[torch.Tensor], sets: dict,
-                    weighted: bool, max_deg: dict, feat_p3=None, p3_mode=False) -> "ResidentPages":
+                    weighted: bool, max_deg: dict, feat_p3=None, p3_mode=False, node_off_dev=None) -> "ResidentPages":
         """A resident set over arrays that already live on the device in this class's layout (models/residency.py: a WINDOW of a
         host-resident dataset, uploaded slice by slice).  ``sets[name]`` = {edge_off (int32, device), edge_off_host (int64, cpu),
         indptr_loc, indices_loc, weight | None}; ``feat`` may be an empty [0, F] placeholder when ``feat_p3`` carries the rows."""
@@ -430,7 +430,9 @@ class ResidentPages:
         self.feat, self.feat_p3, self.p3_mode = feat, feat_p3, p3_mode
         self.label = label
         self.weighted = weighted
-        self.node_off = node_off_host.to(torch.int32).to(self.device)
+        # (node_off_dev: already uploaded by the caller -- a pageable host->device copy here would block the host until the
+        # stream it is queued on has drained)
+        self.node_off = node_off_dev if node_off_dev is not None else node_off_host.to(torch.int32).to(self.device)
         self.max_deg = dict(max_deg)
         self._sets = sets
         return self

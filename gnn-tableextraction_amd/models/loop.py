@@ -82,13 +82,22 @@ class BatchPipeline:
             np.cumsum(self._page_ent[1][ids], out=b_out[1:])
             rows.append((ids, b_node, b_in, b_out))
         total = sum(4 * r[0].size + 3 for r in rows)
-        if self._pinned is None or self._pinned.numel() < total:
+        # two pinned staging areas, used alternately: the upload of the PREVIOUS load() may still be queued behind that load's
+        # batch assemblies (which wait for the steps that free their buffers) -- waiting for it here would stall the host once per
+        # load, i.e. once per window chunk of a host-resident dataset (models/residency.py); the one before that is long done
+        if getattr(self, "_pin2", None) is None:
+            self._pin2, self._pin_ev, self._pin_k = [None, None], [None, None], 0
+        self._pin_k ^= 1
+        k = self._pin_k
+        if self._pin_ev[k] is not None:
+            self._pin_ev[k].synchronize()
+        if self._pin2[k] is None or self._pin2[k].numel() < total:
+            self._pin2[k] = torch.empty(max(total, 4096), dtype=torch.int32).pin_memory()
+        self._pinned = self._pin2[k]
+        if self._meta_dev is None or self._meta_dev.numel() < total:
             if self._meta_ev is not None:
-                self._meta_ev.synchronize()                      # the previous upload still reads the old staging buffer
-            self._pinned = torch.empty(max(total, 4096), dtype=torch.int32).pin_memory()
-            self._meta_dev = torch.empty(self._pinned.numel(), dtype=torch.int32, device=self.device)
-        elif self._meta_ev is not None:
-            self._meta_ev.synchronize()
+                self._meta_ev.synchronize()                      # (a larger device table: the old one may still be read)
+            self._meta_dev = torch.empty(max(self._pinned.numel(), total), dtype=torch.int32, device=self.device)
         stage = self._pinned.numpy()
         off = 0
         cap = [0, 0, 0]
@@ -106,6 +115,7 @@ class BatchPipeline:
             self._meta_dev[:total].copy_(self._pinned[:total], non_blocking=True)
             self._meta_ev = torch.cuda.Event()
             self._meta_ev.record(self.side)
+            self._pin_ev[self._pin_k] = self._meta_ev
         # Capacity for ANY batch of this many pages (the nb largest pages of the dataset), not just this epoch's largest: a
         # later epoch with a bigger batch would otherwise reallocate (synchronise + allocate ~1 ms) in the middle of the loop.
         nb_max = max(r[0].size for r in rows)

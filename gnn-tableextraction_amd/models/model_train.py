@@ -205,7 +205,7 @@ def train(data, config, name_time=None):
     if windowed:
         seed0 = config.PREPROCESS.get('seed', 42)
         owner = R.page_owner(len(train_graphs), world, seed0)
-        passes = int(os.environ.get("GTE_WINDOW_PASSES", "4"))
+        passes = int(os.environ.get("GTE_WINDOW_PASSES", "8"))
         mine = np.nonzero(owner == rank)[0]
         host = R.HostPages([train_graphs[i] for i in mine], device)
         wp = R.WindowedPages(host, budget_gb * 1e9, want_p3)

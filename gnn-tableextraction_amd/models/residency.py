@@ -216,13 +216,22 @@ class WindowedPages:
             sl = {"feat": torch.empty((nmax, self.ldp), dtype=torch.uint8, device=dev) if want_p3
                   else torch.empty((nmax, F), dtype=torch.float32, device=dev),
                   "label": torch.empty((nmax, 1), dtype=torch.float32, device=dev) if host.has_label else None,
-                  "window": None, "ready": None, "free": None, "res": None}
+                  "window": None, "ready": None, "free": None, "res": None,
+                  # page tables of the window (node / in-edge / out-edge offsets): pinned staging + device copy, so that their
+                  # upload is asynchronous like the big slices (a pageable copy blocks the host until the copy stream has
+                  # drained -- i.e. until the steps of the slot's previous window are through: a bubble per window)
+                  "meta_host": torch.empty(3 * (pmax + 1), dtype=torch.int32).pin_memory(),
+                  "meta_dev": torch.empty(3 * (pmax + 1), dtype=torch.int32, device=dev), "meta_ev": None}
             for name in ("in", "out"):
                 sl[name] = dict(indptr_loc=torch.empty(nmax + pmax, dtype=torch.int32, device=dev),
                                 indices_loc=torch.empty(emax, dtype=torch.int32, device=dev),
                                 weight=torch.empty(emax, dtype=torch.float32, device=dev) if host.sets[name]["weight"] is not None else None)
             self.slots.append(sl)
+        # (HIP deals its streams round-robin onto a few hardware queues -- GPU_MAX_HW_QUEUES, 4 by default --, and a copy stream
+        # that shares the queue of a busy stream runs its uploads IN ORDER with that stream's work: the package raises the queue
+        # count before HIP starts, see gnn_tableextraction_amd.py)
         self.copy = torch.cuda.Stream(device=dev)
+        self._no_feat = torch.empty((0, F), dtype=torch.float32, device=dev)
         self.device_bytes = sum(t.numel() * t.element_size() for sl in self.slots for t in
                                 [sl["feat"], sl["label"]] + [v for n in ("in", "out") for v in sl[n].values()] if t is not None)
         self.device_bytes += self.stage.numel() * 4 if self.stage is not None else 0
@@ -243,9 +252,23 @@ class WindowedPages:
         p0, p1 = self.ranges[w]
         n0, n1 = int(h.node_off[p0]), int(h.node_off[p1])
         n = n1 - n0
+        np_ = p1 - p0
+        import time as _t
+        _t0 = _t.perf_counter()
+        if sl["meta_ev"] is not None:
+            sl["meta_ev"].synchronize()                       # (the previous upload from this pinned staging area has left the host)
+        self.sync_s = getattr(self, "sync_s", 0.0) + _t.perf_counter() - _t0
+        mh = sl["meta_host"].numpy()
+        mh[:np_ + 1] = h.node_off[p0:p1 + 1] - n0
+        for k, name in enumerate(("in", "out")):
+            eo_ = h.sets[name]["edge_off"]
+            mh[(k + 1) * (np_ + 1):(k + 2) * (np_ + 1)] = eo_[p0:p1 + 1] - eo_[p0]
         with torch.cuda.stream(self.copy):
             if sl["free"] is not None:
                 self.copy.wait_event(sl["free"])              # the last step that read this slot's old window has run
+            sl["meta_dev"][:3 * (np_ + 1)].copy_(sl["meta_host"][:3 * (np_ + 1)], non_blocking=True)
+            sl["meta_ev"] = torch.cuda.Event()
+            sl["meta_ev"].record(self.copy)
             sets = {}
             for name in ("in", "out"):
                 hs, ds = h.sets[name], sl[name]
@@ -257,7 +280,8 @@ class WindowedPages:
                     ds["weight"][:b1 - b0].copy_(hs["weight"][b0:b1], non_blocking=True)
                     wt = ds["weight"][:b1 - b0]
                 eo = torch.from_numpy(hs["edge_off"][p0:p1 + 1] - b0)
-                sets[name] = dict(edge_off=eo.to(torch.int32).to(self.device, non_blocking=True), edge_off_host=eo,
+                kk = 1 if name == "in" else 2
+                sets[name] = dict(edge_off=sl["meta_dev"][kk * (np_ + 1):(kk + 1) * (np_ + 1)], edge_off_host=eo,
                                   indices_loc=ds["indices_loc"][:max(b1 - b0, 1)], indptr_loc=ds["indptr_loc"][:n + (p1 - p0)], weight=wt)
             label = None
             if sl["label"] is not None:
@@ -268,12 +292,14 @@ class WindowedPages:
                 self.stage[:n].copy_(h.feat[n0:n1], non_blocking=True)
                 img = ops.P3(sl["feat"], n, h.n_feat)
                 ops.p3_from_f32(self.stage[:n], out=img)
-                feat = torch.empty((0, h.n_feat), dtype=torch.float32, device=self.device)
+                feat = self._no_feat
                 res = G.ResidentPages.from_arrays(self.device, node_off, feat, label, sets, h.weighted, h.max_deg,
-                                                  feat_p3=ops.P3(sl["feat"][:n], n, h.n_feat), p3_mode="rows")
+                                                  feat_p3=ops.P3(sl["feat"][:n], n, h.n_feat), p3_mode="rows",
+                                                  node_off_dev=sl["meta_dev"][:np_ + 1])
             else:
                 sl["feat"][:n].copy_(h.feat[n0:n1], non_blocking=True)
-                res = G.ResidentPages.from_arrays(self.device, node_off, sl["feat"][:n], label, sets, h.weighted, h.max_deg)
+                res = G.ResidentPages.from_arrays(self.device, node_off, sl["feat"][:n], label, sets, h.weighted, h.max_deg,
+                                                  node_off_dev=sl["meta_dev"][:np_ + 1])
             ev = torch.cuda.Event()
             ev.record(self.copy)
         sl["window"], sl["ready"], sl["res"] = w, ev, res
@@ -299,17 +325,29 @@ class WindowedPages:
             sl["in_use"] = False
 
 
-def run_windowed(step, pipe, wp: WindowedPages, stream: WindowStream, n_steps: int, n_global=None, loss_scale=None, on_step=None):
+def run_windowed(step, pipe, wp: WindowedPages, stream: WindowStream, n_steps: int, n_global=None, loss_scale=None, on_step=None,
+                 host_times: Optional[dict] = None):
     """``n_steps`` steps of ``stream`` (an epoch's worth): per chunk of steps on one window -- acquire it, start the upload of
     the next window of the stream, run the same loop as the all-resident path (models/loop.run_steps).  Returns (last out3,
     nodes of the last step)."""
     from .loop import run_steps
     out3, done, last_nodes = None, 0, 0
+    import time
+    tick = time.perf_counter
+    t_ = tick()
     chunks = stream.take(n_steps)
+    if host_times is not None:
+        host_times["plan"] = host_times.get("plan", 0.0) + tick() - t_
     for i, (w, steps) in enumerate(chunks):
+        t_ = tick()
         res = wp.acquire(w)
+        t_a = tick()
         if pipe.res is not res:
             pipe.rebind(res)
+        t_b = tick()
+        if host_times is not None:
+            host_times["acquire"] = host_times.get("acquire", 0.0) + t_a - t_
+            host_times["rebind"] = host_times.get("rebind", 0.0) + t_b - t_a
         # the window the stream needs after this one: the next chunk's, or -- at the end of this call -- where the stream stands
         if i + 1 < len(chunks):
             nxt = chunks[i + 1][0]
@@ -317,10 +355,16 @@ def run_windowed(step, pipe, wp: WindowedPages, stream: WindowStream, n_steps: i
             nxt = stream.peek_window() if stream.peek_window() != w else stream.next_window()
         if nxt != w:
             wp.prefetch(nxt)
+        if host_times is not None:
+            host_times["window"] = host_times.get("window", 0.0) + tick() - t_
+            host_times["chunks"] = host_times.get("chunks", 0) + 1
+        t_ = tick()
         k = len(steps)
         out3 = run_steps(step, pipe, steps, n_global=None if n_global is None else n_global[done:done + k],
                          loss_scale=None if loss_scale is None else loss_scale[done:done + k], on_step=on_step)
         last_nodes = pipe.nodes(k - 1)
         wp.release(w)
+        if host_times is not None:
+            host_times["steps"] = host_times.get("steps", 0.0) + tick() - t_
         done += k
     return out3, last_nodes
