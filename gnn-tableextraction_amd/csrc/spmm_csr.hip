@@ -100,6 +100,9 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                 int rows_per_block, const LnEpilogue ln = LnEpilogue{}, char* __restrict__ outp3 = nullptr, int64_t ldp3 = 0) {
     using elem = typename T::elem;
     constexpr int EPC = T::EPC;
+    // source rows in flight per lane group: four; two where a lane owns four chunks AND carries the LayerNorm epilogue (rows up to
+    // 1024 wide: 179 VGPRs -> two waves per SIMD with four in flight)
+    constexpr int EU = (LNE && CPL >= 4) ? 2 : kEdgeUnroll;
     constexpr int RPW = gte::kWave / G;                 // rows per wave per pass
     const int lane = threadIdx.x & (gte::kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -148,10 +151,10 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                     my_w = ew ? ew[my_e] : 1.0f;
                 }
                 const int cnt = min(G, hi - eb);
-                for (int t = 0; t < cnt; t += kEdgeUnroll) {
-                    int u[kEdgeUnroll];
-                    float w[kEdgeUnroll];
-                    if constexpr (G == 4 && kEdgeUnroll == 4) {
+                for (int t = 0; t < cnt; t += EU) {
+                    int u[EU];
+                    float w[EU];
+                    if constexpr (G == 4 && EU == 4) {
                         // one quad per row: DPP quad broadcasts (lanes past the row end hold source 0 / weight 0)
                         u[0] = gte_quad_bcast<0>(my_u); u[1] = gte_quad_bcast<1>(my_u);
                         u[2] = gte_quad_bcast<2>(my_u); u[3] = gte_quad_bcast<3>(my_u);
@@ -159,17 +162,17 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                         w[2] = gte_quad_bcast<2>(my_w); w[3] = gte_quad_bcast<3>(my_w);
                     } else {
 #pragma unroll
-                    for (int k = 0; k < kEdgeUnroll; ++k) {
+                    for (int k = 0; k < EU; ++k) {
                         // past the end of the row: re-use the last valid source (cache hit) with w = 0
                         const int tt = min(t + k, cnt - 1);
                         u[k] = __shfl(my_u, tt, G);
                         w[k] = (t + k < cnt) ? __shfl(my_w, tt, G) : 0.f;
                     }
                     }
-                    float v[kEdgeUnroll][CPL][EPC];
-                    float tv[kEdgeUnroll];
+                    float v[EU][CPL][EPC];
+                    float tv[EU];
 #pragma unroll
-                    for (int k = 0; k < kEdgeUnroll; ++k) {
+                    for (int k = 0; k < EU; ++k) {
                         const elem* xr = x + (int64_t)u[k] * ldx;
 #pragma unroll
                         for (int j = 0; j < CPL; ++j) {
@@ -179,7 +182,7 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                         tv[k] = do_tail ? T::to_f32(xr[tail_off]) : 0.f;
                     }
 #pragma unroll
-                    for (int k = 0; k < kEdgeUnroll; ++k) {
+                    for (int k = 0; k < EU; ++k) {
 #pragma unroll
                         for (int j = 0; j < CPL; ++j) {
                             const int c = cb + li + j * G;
