@@ -634,7 +634,7 @@ def residency_probe(args, gte, dev, pages, loop):
         el = time.perf_counter() - t0
         out["windowed"][f"passes_{passes}"] = {"value": nodes[0] / el, "unit": "nodes/s", "ms_per_step": el / n_steps * 1e3, "steps": n_steps,
                                                "upload_GB_per_s": (wp.uploaded_bytes - up0) / el / 1e9,
-                                               "host_ms": {"queueing_total": t_host * 1e3, "prefetch_sync": getattr(wp, "sync_s", 0.0) * 1e3,
+                                               "host_ms": {"queueing_total": t_host * 1e3, 
                                                            **{k: (v * 1e3 if k != "chunks" else v) for k, v in ht.items()}}}
         del tr, pipe
     # the same kind of stream on the all-resident set
