@@ -163,9 +163,6 @@ class BatchPipeline:
         ev = torch.cuda.Event()
         ev.record(self.side)
         self._ready[s] = (g, ev)
-        hook = getattr(self, "after_start", None)
-        if hook is not None:
-            hook()                  # (a host-resident dataset pieces its next window's upload out behind the assemblies)
 
     def get(self, s: int) -> G.ResidentBatch:
         """The batch of step s; the CURRENT stream waits (on the device) for its assembly."""

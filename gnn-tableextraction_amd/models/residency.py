@@ -9,13 +9,9 @@ above it (``GTE_RESIDENT_BUDGET_GB``):
   world size), concatenated once in pinned host memory in the array layout of graph.ResidentPages (features, labels, per-page
   local CSRs of both directions, CSR-ordered weights): a contiguous page range is a handful of contiguous slices.
 * **WindowedPages** -- two device slots of budget / 2 each; a window = a contiguous page range that fits a slot.  While the
-  steps of window k run, window k + 1 is uploaded PIECE BY PIECE on the batch pipeline's side stream, one piece behind every
-  step's batch assembly (contiguous pinned slices -> cudaMemcpyAsync, no host gather), converted to the P3 image there when
-  layer 0 takes one, and handed over through events.  No stream of its own: HIP deals a process's streams round-robin onto a
-  few hardware queues, and a dedicated copy stream that happened to share the queue of a busy stream ran its uploads in order
-  with that stream's work -- 21 instead of 38 GB/s, or 0.54 instead of 0.90 of the all-resident rate, depending on how many
-  streams the process had created before (measured inside bench.py against a fresh process).  Windows stay below 4 GB of
-  image, so the input layer keeps reading the resident image through the row map.
+  steps of window k run, window k + 1 is uploaded on a copy stream (contiguous pinned slices -> cudaMemcpyAsync at PCIe rate,
+  no host gather), converted to the P3 image there when layer 0 takes one, and handed over through events.  Windows stay below
+  4 GB of image, so the input layer keeps reading the resident image through the row map.
 * **WindowStream** -- the order of steps.  A step of the headline configuration consumes 81 MB of features in 0.55 ms = 147 GB/s,
   more than twice what PCIe Gen5 x16 delivers: a loop that uploads every page once per epoch CANNOT run at the all-resident
   rate.  So a window is visited for ``passes`` shuffled passes before the next one is taken (every page is still seen once per
@@ -231,19 +227,17 @@ class WindowedPages:
                                 indices_loc=torch.empty(emax, dtype=torch.int32, device=dev),
                                 weight=torch.empty(emax, dtype=torch.float32, device=dev) if host.sets[name]["weight"] is not None else None)
             self.slots.append(sl)
-        self.copy = torch.cuda.Stream(device=dev)             # replaced by the batch pipeline's side stream (use_stream)
-        self._pending, self._pending_bytes, self._pending_w = [], 0, None
+        # A stream of its own.  Measured alternatives (profiles/r04/residency.md): the upload pieced out on the batch pipeline's
+        # side stream behind every assembly (0.52 / 0.68 of the all-resident rate at 4 / 8 passes: a piece in front of an assembly
+        # that waits for the step before it stalls the next piece), a high-priority stream (0.42 / 0.48), more HIP hardware
+        # queues (GPU_MAX_HW_QUEUES 8 ... 32: 0.53 / 0.98).  What the uploads get while the step's kernels run is 21 ... 38 GB/s of
+        # the link's 57 (host memory and PCIe are shared with the other GPUs' jobs of the node: it differs run to run).
+        self.copy = torch.cuda.Stream(device=dev)
         self._no_feat = torch.empty((0, F), dtype=torch.float32, device=dev)
         self.device_bytes = sum(t.numel() * t.element_size() for sl in self.slots for t in
                                 [sl["feat"], sl["label"]] + [v for n in ("in", "out") for v in sl[n].values()] if t is not None)
         self.device_bytes += self.stage.numel() * 4 if self.stage is not None else 0
         self.uploaded_bytes = 0
-
-    def use_stream(self, stream) -> None:
-        """Issue the uploads on ``stream`` (the batch pipeline's side stream: see the module docstring)."""
-        if self._pending:
-            self.pump(None)
-        self.copy = stream
 
     def _slot_of(self, w):
         for sl in self.slots:
@@ -251,20 +245,16 @@ class WindowedPages:
                 return sl
         return None
 
-    PIECE_ROWS = 4096                  # feature rows per upload piece (13.6 MB at F0 = 831: ~0.25 ms of host link)
-
     def prefetch(self, w: int) -> None:
-        """Plan the upload of window w into the slot that does not hold the window in use (no-op if it is resident or already
-        planned).  Nothing is copied yet: ``pump`` issues the pieces."""
+        """Start the upload of window w into the slot that does not hold the window in use (no-op if it is resident)."""
         if self._slot_of(w) is not None:
             return
-        if self._pending:
-            self.pump(None)                                   # (one upload at a time: finish the previous plan first)
         sl = next(s for s in self.slots if s.get("in_use") is not True)
         h = self.host
         p0, p1 = self.ranges[w]
         n0, n1 = int(h.node_off[p0]), int(h.node_off[p1])
-        n, np_ = n1 - n0, p1 - p0
+        n = n1 - n0
+        np_ = p1 - p0
         if sl["meta_ev"] is not None:
             sl["meta_ev"].synchronize()                       # (the previous upload from this pinned staging area has left the host)
         mh = sl["meta_host"].numpy()
@@ -272,75 +262,53 @@ class WindowedPages:
         for k, name in enumerate(("in", "out")):
             eo_ = h.sets[name]["edge_off"]
             mh[(k + 1) * (np_ + 1):(k + 2) * (np_ + 1)] = eo_[p0:p1 + 1] - eo_[p0]
-        ops_ = []                                             # (bytes, callable) in issue order
-
-        def first():
+        with torch.cuda.stream(self.copy):
             if sl["free"] is not None:
                 self.copy.wait_event(sl["free"])              # the last step that read this slot's old window has run
             sl["meta_dev"][:3 * (np_ + 1)].copy_(sl["meta_host"][:3 * (np_ + 1)], non_blocking=True)
             sl["meta_ev"] = torch.cuda.Event()
             sl["meta_ev"].record(self.copy)
-        ops_.append((0, first))
-        sets = {}
-        for name in ("in", "out"):
-            hs, ds = h.sets[name], sl[name]
-            b0, b1 = int(hs["edge_off"][p0]), int(hs["edge_off"][p1])
-            ops_.append((4 * (b1 - b0), lambda ds=ds, hs=hs, b0=b0, b1=b1: ds["indices_loc"][:b1 - b0].copy_(hs["indices_loc"][b0:b1], non_blocking=True)))
-            ops_.append((4 * (n + np_), lambda ds=ds, hs=hs: ds["indptr_loc"][:n + np_].copy_(hs["indptr_loc"][n0 + p0:n1 + p1], non_blocking=True)))
-            wt = None
-            if ds["weight"] is not None:
-                ops_.append((4 * (b1 - b0), lambda ds=ds, hs=hs, b0=b0, b1=b1: ds["weight"][:b1 - b0].copy_(hs["weight"][b0:b1], non_blocking=True)))
-                wt = ds["weight"][:b1 - b0]
-            eo = torch.from_numpy(hs["edge_off"][p0:p1 + 1] - b0)
-            kk = 1 if name == "in" else 2
-            sets[name] = dict(edge_off=sl["meta_dev"][kk * (np_ + 1):(kk + 1) * (np_ + 1)], edge_off_host=eo,
-                              indices_loc=ds["indices_loc"][:max(b1 - b0, 1)], indptr_loc=ds["indptr_loc"][:n + np_], weight=wt)
-        label = None
-        if sl["label"] is not None:
-            ops_.append((4 * n, lambda: sl["label"][:n].copy_(h.label[n0:n1], non_blocking=True)))
-            label = sl["label"][:n]
-        node_off = torch.from_numpy(h.node_off[p0:p1 + 1] - n0)
-        F = h.n_feat
-        dst = self.stage if self.want_p3 else sl["feat"]
-        for r0 in range(0, n, self.PIECE_ROWS):
-            r1 = min(r0 + self.PIECE_ROWS, n)
-            ops_.append((4 * F * (r1 - r0), lambda r0=r0, r1=r1: dst[r0:r1].copy_(h.feat[n0 + r0:n0 + r1], non_blocking=True)))
-        if self.want_p3:
-            img = ops.P3(sl["feat"], n, F)
-            ops_.append((0, lambda: ops.p3_from_f32(self.stage[:n], out=img)))
-            res = G.ResidentPages.from_arrays(self.device, node_off, self._no_feat, label, sets, h.weighted, h.max_deg,
-                                              feat_p3=ops.P3(sl["feat"][:n], n, F), p3_mode="rows", node_off_dev=sl["meta_dev"][:np_ + 1])
-        else:
-            res = G.ResidentPages.from_arrays(self.device, node_off, sl["feat"][:n], label, sets, h.weighted, h.max_deg,
-                                              node_off_dev=sl["meta_dev"][:np_ + 1])
-        ev = torch.cuda.Event()
-        ops_.append((0, lambda: ev.record(self.copy)))
+            sets = {}
+            for name in ("in", "out"):
+                hs, ds = h.sets[name], sl[name]
+                b0, b1 = int(hs["edge_off"][p0]), int(hs["edge_off"][p1])
+                ds["indices_loc"][:b1 - b0].copy_(hs["indices_loc"][b0:b1], non_blocking=True)
+                ds["indptr_loc"][:n + (p1 - p0)].copy_(hs["indptr_loc"][n0 + p0:n1 + p1], non_blocking=True)
+                wt = None
+                if ds["weight"] is not None:
+                    ds["weight"][:b1 - b0].copy_(hs["weight"][b0:b1], non_blocking=True)
+                    wt = ds["weight"][:b1 - b0]
+                eo = torch.from_numpy(hs["edge_off"][p0:p1 + 1] - b0)
+                kk = 1 if name == "in" else 2
+                sets[name] = dict(edge_off=sl["meta_dev"][kk * (np_ + 1):(kk + 1) * (np_ + 1)], edge_off_host=eo,
+                                  indices_loc=ds["indices_loc"][:max(b1 - b0, 1)], indptr_loc=ds["indptr_loc"][:n + (p1 - p0)], weight=wt)
+            label = None
+            if sl["label"] is not None:
+                sl["label"][:n].copy_(h.label[n0:n1], non_blocking=True)
+                label = sl["label"][:n]
+            node_off = torch.from_numpy(h.node_off[p0:p1 + 1] - n0)
+            if self.want_p3:
+                self.stage[:n].copy_(h.feat[n0:n1], non_blocking=True)
+                img = ops.P3(sl["feat"], n, h.n_feat)
+                ops.p3_from_f32(self.stage[:n], out=img)
+                feat = self._no_feat
+                res = G.ResidentPages.from_arrays(self.device, node_off, feat, label, sets, h.weighted, h.max_deg,
+                                                  feat_p3=ops.P3(sl["feat"][:n], n, h.n_feat), p3_mode="rows",
+                                                  node_off_dev=sl["meta_dev"][:np_ + 1])
+            else:
+                sl["feat"][:n].copy_(h.feat[n0:n1], non_blocking=True)
+                res = G.ResidentPages.from_arrays(self.device, node_off, sl["feat"][:n], label, sets, h.weighted, h.max_deg,
+                                                  node_off_dev=sl["meta_dev"][:np_ + 1])
+            ev = torch.cuda.Event()
+            ev.record(self.copy)
         sl["window"], sl["ready"], sl["res"] = w, ev, res
-        self._pending, self._pending_w = ops_, w
-        self._pending_bytes = sum(b for b, _ in ops_)
-        self.uploaded_bytes += n * F * 4
-
-    def pump(self, steps_left: Optional[int]) -> None:
-        """Issue the next pieces of the planned upload on the copy stream: about 1 / steps_left of what is left (None: all of
-        it).  Called behind every step's batch assembly, so a piece never sits in front of an assembly the next step waits for."""
-        if not self._pending:
-            return
-        quota = self._pending_bytes if not steps_left or steps_left <= 1 else -(-self._pending_bytes // steps_left)
-        with torch.cuda.stream(self.copy):
-            issued = 0
-            while self._pending and (issued < quota or self._pending[0][0] == 0):
-                b, fn = self._pending.pop(0)
-                fn()
-                issued += b
-            self._pending_bytes -= issued
+        self.uploaded_bytes += n * h.n_feat * 4
 
     def acquire(self, w: int) -> G.ResidentPages:
         """Window w as a resident set; the CURRENT stream waits (on the device) for its upload."""
         if self._slot_of(w) is None:
             self.prefetch(w)
         sl = self._slot_of(w)
-        if self._pending and self._pending_w == w:
-            self.pump(None)                                   # (its upload is still being pieced out: issue the rest now)
         for s in self.slots:
             s["in_use"] = s is sl
         torch.cuda.current_stream(self.device).wait_event(sl["ready"])
@@ -386,23 +354,13 @@ def run_windowed(step, pipe, wp: WindowedPages, stream: WindowStream, n_steps: i
             nxt = stream.peek_window() if stream.peek_window() != w else stream.next_window()
         if nxt != w:
             wp.prefetch(nxt)
-        # the planned upload goes out in pieces on the pipeline's side stream, one piece behind every step's batch assembly
-        k = len(steps)
-        left = [k]
-
-        def piece():
-            wp.pump(max(left[0] - 1, 1))
-            left[0] -= 1
-        wp.use_stream(pipe.side)
-        pipe.after_start = piece
         if host_times is not None:
             host_times["window"] = host_times.get("window", 0.0) + tick() - t_
             host_times["chunks"] = host_times.get("chunks", 0) + 1
         t_ = tick()
+        k = len(steps)
         out3 = run_steps(step, pipe, steps, n_global=None if n_global is None else n_global[done:done + k],
                          loss_scale=None if loss_scale is None else loss_scale[done:done + k], on_step=on_step)
-        pipe.after_start = None
-        wp.pump(None)
         last_nodes = pipe.nodes(k - 1)
         wp.release(w)
         if host_times is not None:
