@@ -92,7 +92,10 @@ struct LnEpilogue {
 template <int G>
 __device__ __forceinline__ float group_sum(float v) { return gte_group_sum<G>(v); }
 
-template <typename T, int G, int CPL, bool ACCUM, bool LNE = false>
+// MASK, LNE kernels: the LayerNorm width ln.n_true is smaller than the n_feat columns processed (padded rows): per-element masks.
+// Without it the epilogue is the round-3 code, instruction for instruction (24.5 us at 24 k x 256; the masks cost 6 us there).
+// MASK, P3-output kernels: n_feat is not a multiple of 16 (tail elements collected by lane 0, zero quarter blocks).
+template <typename T, int G, int CPL, bool ACCUM, bool LNE = false, bool MASK = false>
 __global__ void __launch_bounds__(256)
 spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                 const float* __restrict__ ew, const typename T::elem* __restrict__ x, int64_t ldx,
@@ -199,8 +202,8 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
             // P3 output of a width that is not a multiple of 4: the (< 4) tail elements sit one per lane on the first lanes of the
             // group; lane 0 collects them into the row's last quarter block (lanes >= rem hold tail = 0)
             float tq[3] = {0.f, 0.f, 0.f};
-            if constexpr (std::is_same<T, F32>::value && !ACCUM && !LNE) {
-                if (outp3 && cb == 0) {
+            if constexpr (std::is_same<T, F32>::value && !ACCUM && !LNE && MASK) {
+                if (outp3 && cb == 0 && rem > 0) {                 // (uniform: widths that are a multiple of 4 skip the shuffles)
                     const float ts = tail * scale;
                     tq[0] = __shfl(ts, 0, G); tq[1] = __shfl(ts, 1, G); tq[2] = __shfl(ts, 2, G);
                 }
@@ -216,7 +219,7 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                             T::load(orow + (int64_t)c * EPC, o);
 #pragma unroll
                             for (int q = 0; q < EPC; ++q) o[q] += acc[j][q] * scale;
-                            if constexpr (LNE) {             // columns past the LayerNorm width are padding: zero
+                            if constexpr (LNE && MASK) {     // columns past the LayerNorm width are padding: zero
 #pragma unroll
                                 for (int q = 0; q < EPC; ++q) if (c * EPC + q >= ln.n_true) o[q] = 0.f;
                             }
@@ -253,7 +256,8 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                     for (int j = 0; j < CPL; ++j)
 #pragma unroll
                         for (int q = 0; q < EPC; ++q) {
-                            const float d = ((li + j * G) * EPC + q < nt) ? acc[j][q] - mean : 0.f;
+                            const bool in = MASK ? ((li + j * G) * EPC + q < nt) : (li + j * G < nchunk);
+                            const float d = in ? acc[j][q] - mean : 0.f;
                             sq = fmaf(d, d, sq);
                         }
                     const float rstd = rsqrtf(group_sum<G>(sq) / (float)nt + ln.eps);
@@ -265,10 +269,15 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
 #pragma unroll
                             for (int q = 0; q < EPC; ++q) {
                                 const int col = c * EPC + q;
-                                const bool ok = col < nt;
-                                float v = fmaf((acc[j][q] - mean) * rstd, ok ? ln.gamma[col] : 0.f, ok ? ln.beta[col] : 0.f);
-                                v = ln.relu ? fmaxf(v, 0.f) : v;
-                                yv[q] = ok ? v : 0.f;
+                                if constexpr (MASK) {
+                                    const bool ok = col < nt;
+                                    float v = fmaf((acc[j][q] - mean) * rstd, ok ? ln.gamma[col] : 0.f, ok ? ln.beta[col] : 0.f);
+                                    v = ln.relu ? fmaxf(v, 0.f) : v;
+                                    yv[q] = ok ? v : 0.f;
+                                } else {
+                                    const float v = fmaf((acc[j][q] - mean) * rstd, ln.gamma[col], ln.beta[col]);
+                                    yv[q] = ln.relu ? fmaxf(v, 0.f) : v;
+                                }
                             }
                             if (ln.y) F32::store(ln.y + (int64_t)r * ln.ldy + (int64_t)c * EPC, yv);
                             if constexpr (EPC == 4) {
@@ -278,10 +287,10 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                     }
                     if (li == 0 && ln.stats) { ln.stats[r] = mean; ln.stats[n_rows + r] = rstd; }
                 }
-                if constexpr (std::is_same<T, F32>::value && !ACCUM && !LNE) {
+                if constexpr (std::is_same<T, F32>::value && !ACCUM && !LNE && MASK) {
                     // P3 output: the quarter blocks past the last full chunk up to the image's 16-column block boundary -- the
                     // tail elements (lane 0) and zeros
-                    if (outp3 && cb == 0 && li < 4) {
+                    if (outp3 && cb == 0 && li < 4 && (n_feat & 15) != 0) {
                         const int qi = nchunk + li;
                         if (qi * 4 < (int)p3::blocks(n_feat) * p3::BLOCK) {
                             const bool t = li == 0 && rem > 0;
@@ -289,7 +298,7 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                         }
                     }
                 }
-                if (do_tail && !(std::is_same<T, F32>::value && !ACCUM && !LNE && outp3)) {
+                if (do_tail && !(std::is_same<T, F32>::value && !ACCUM && !LNE && MASK && outp3)) {
                     float o = tail * scale;
                     if constexpr (ACCUM) o += T::to_f32(orow[tail_off]);
                     orow[tail_off] = T::from_f32(o);
@@ -299,7 +308,7 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
     }
 }
 
-template <typename T, int G, int CPL, bool ACCUM>
+template <typename T, int G, int CPL, bool ACCUM, bool MASK = false>
 int launch_g(const int32_t* indptr, const int32_t* indices, const float* ew, const void* x, int64_t ldx,
              void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, hipStream_t s, char* outp3 = nullptr,
              int64_t ldp3 = 0) {
@@ -314,7 +323,7 @@ int launch_g(const int32_t* indptr, const int32_t* indices, const float* ew, con
     const int rows_per_block = 4 * RPW * passes;
     const int64_t nblocks = gte::ceil_div(n_rows, rows_per_block);
     dim3 grid((unsigned)nblocks), block(256);
-    hipLaunchKernelGGL((spmm_csr_kernel<T, G, CPL, ACCUM>), grid, block, 0, s, indptr, indices, ew,
+    hipLaunchKernelGGL((spmm_csr_kernel<T, G, CPL, ACCUM, false, MASK>), grid, block, 0, s, indptr, indices, ew,
                        (const elem*)x, ldx, (elem*)out, ldo, (int)n_rows, (int)n_feat, reduce, rows_per_block, LnEpilogue{}, outp3,
                        ldp3);
     return gte::check_launch("spmm_csr");
@@ -325,7 +334,15 @@ int dispatch(const int32_t* indptr, const int32_t* indices, const float* ew, con
              void* out, int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, hipStream_t s, char* outp3 = nullptr,
              int64_t ldp3 = 0) {
     const int64_t nchunk = n_feat / T::EPC;
-#define GTE_L(G, CPL) return launch_g<T, G, CPL, ACCUM>(indptr, indices, ew, x, ldx, out, ldo, n_rows, n_feat, reduce, s, outp3, ldp3)
+    // (an image output of a width that is not a multiple of 16 runs the instantiation with the tail / zero-block code)
+    const bool tail_img = std::is_same<T, F32>::value && !ACCUM && outp3 && (n_feat % 16) != 0;
+#define GTE_L(G, CPL)                                                                                                        \
+    do {                                                                                                                     \
+        if constexpr (std::is_same<T, F32>::value && !ACCUM) {                                                               \
+            if (tail_img) return launch_g<T, G, CPL, ACCUM, true>(indptr, indices, ew, x, ldx, out, ldo, n_rows, n_feat, reduce, s, outp3, ldp3); \
+        }                                                                                                                    \
+        return launch_g<T, G, CPL, ACCUM>(indptr, indices, ew, x, ldx, out, ldo, n_rows, n_feat, reduce, s, outp3, ldp3);   \
+    } while (0)
     if (nchunk <= 8 && T::EPC <= 8) {
         if (nchunk <= 4 && T::EPC == 4) GTE_L(4, 1);
         GTE_L(8, 1);
@@ -338,14 +355,14 @@ int dispatch(const int32_t* indptr, const int32_t* indices, const float* ew, con
 #undef GTE_L
 }
 
-template <int G, int CPL = 1>
+template <int G, int CPL = 1, bool MASK = false>
 int launch_ln(const int32_t* indptr, const int32_t* indices, const float* ew, const float* x, int64_t ldx, float* out,
               int64_t ldo, int64_t n_rows, int64_t n_feat, int reduce, const LnEpilogue& ln, hipStream_t s) {
     constexpr int RPW = gte::kWave / G;
     int passes = 4;
     while (passes > 1 && gte::ceil_div(n_rows, (int64_t)4 * RPW * passes) < (int64_t)16 * gte::device_props().cus) passes /= 2;
     const int rows_per_block = 4 * RPW * passes;
-    hipLaunchKernelGGL((spmm_csr_kernel<F32, G, CPL, true, true>), dim3((unsigned)gte::ceil_div(n_rows, rows_per_block)), dim3(256), 0,
+    hipLaunchKernelGGL((spmm_csr_kernel<F32, G, CPL, true, true, MASK>), dim3((unsigned)gte::ceil_div(n_rows, rows_per_block)), dim3(256), 0,
                        s, indptr, indices, ew, x, ldx, out, ldo, (int)n_rows, (int)n_feat, reduce, rows_per_block, ln);
     return gte::check_launch("spmm_csr_accumulate_ln");
 }
@@ -610,15 +627,18 @@ static int accumulate_ln_impl(const int32_t* indptr, const int32_t* indices, con
     const LnEpilogue ln = {gamma, beta, eps, relu, y, ldy, stats, reinterpret_cast<char*>(yp3), ldyp3, (int)n_feat};
     hipStream_t s = gte::as_stream(stream);
     const int64_t nchunk = np / 4;
-#define GTE_LN(G) return launch_ln<G>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, np, reduce, ln, s)
-    if (nchunk <= 4) GTE_LN(4);
-    if (nchunk <= 8) GTE_LN(8);
-    if (nchunk <= 16) GTE_LN(16);
-    if (nchunk <= 32) GTE_LN(32);
-    if (nchunk <= 64) GTE_LN(64);
+    const bool mask = np != n_feat;
+#define GTE_LN(G, CPL)                                                                                                       \
+    return mask ? launch_ln<G, CPL, true>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, np, reduce, ln, s)            \
+                : launch_ln<G, CPL, false>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, np, reduce, ln, s)
+    if (nchunk <= 4) GTE_LN(4, 1);
+    if (nchunk <= 8) GTE_LN(8, 1);
+    if (nchunk <= 16) GTE_LN(16, 1);
+    if (nchunk <= 32) GTE_LN(32, 1);
+    if (nchunk <= 64) GTE_LN(64, 1);
+    if (nchunk <= 128) GTE_LN(64, 2);
+    GTE_LN(64, 4);
 #undef GTE_LN
-    if (nchunk <= 128) return launch_ln<64, 2>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, np, reduce, ln, s);
-    return launch_ln<64, 4>(indptr, indices, eweight, x, ldx, z, ldz, n_rows, np, reduce, ln, s);
 }
 
 extern "C" int gte_spmm_csr_accumulate_ln(const int32_t* indptr, const int32_t* indices, const float* eweight,

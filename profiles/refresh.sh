@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --no-inference --val-graph 0"
+STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --no-inference --no-shapes --no-size-sweep --no-residency --val-graph 0"
 timeout 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python3 $R/bench.py --long-run-seconds 0.2 --no-cpu-baseline > $O/bench_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_step -o t -- python3 $R/bench.py --long-run-seconds 0.2 $STEP_ONLY > $O/bench_trace_step.log 2>&1
@@ -27,6 +27,14 @@ timeout 300 python3 profiles/debug/gemm_split_check.py > $O/gemm_split_check.txt
 python3 profiles/rocpd_summary.py $(ls $O/trace/*.db | head -1) $O/final_kernel_stats.csv > /dev/null
 python3 profiles/rocpd_summary.py $(ls $O/trace_step/*.db | head -1) $O/step_kernel_stats.csv > /dev/null
 bash profiles/pmc_refresh.sh $TAG > /dev/null       # FETCH_SIZE / WRITE_SIZE passes over profiles/pmc_step.py and the cfg4 probe
+# round 4: the reference's run shapes, the validation-graph forward, planes GEMMs beyond one round of tiles, the host-resident set
+bash profiles/shapes_refresh.sh $TAG > /dev/null
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_val -o t -- python3 $R/profiles/val_forward.py > $O/val_forward.log 2>&1)
+python3 profiles/rocpd_summary.py $(ls $O/trace_val/*.db | head -1) $O/val_forward_kernel_stats.csv > /dev/null; rm -rf $O/trace_val
+timeout 300 python3 profiles/gemm_p3_big_m.py 2> /dev/null > $O/gemm_p3_big_m.txt
+for c in 2 4 5; do GTE_P3_NT_CFG=$c timeout 300 python3 profiles/gemm_p3_big_m.py 2> /dev/null >> $O/gemm_p3_big_m.txt; done
+timeout 300 python3 profiles/debug/residency_probe_alone.py 2> /dev/null > $O/residency_alone.txt
+timeout 300 python3 profiles/residency_trace.py 3000 4 2.5 2> /dev/null | grep -v "^chunk" | head -12 > $O/residency_trace.txt
 [ -x profiles/micro/stream_bw ] && timeout 60 ./profiles/micro/stream_bw 2048 > $O/stream_bw.txt
 [ -x profiles/micro/copy_variants ] && timeout 60 ./profiles/micro/copy_variants 2048 > $O/copy_variants.txt
 rm -rf $O/trace $O/trace_step $O/trace_f32 $O/trace_13
