@@ -1411,6 +1411,8 @@ class FusedGcnSageStep(TrainStep):
         for k in keys:
             self._graphs.pop(k, None)
             self._graph_bufs.pop(k, None)
+            for kk in [q for q in self._graph_bufs if isinstance(q, tuple) and q[0] == k]:     # (general plans: (batch, layout) keys)
+                self._graph_bufs.pop(kk, None)
             self._graph_owner.pop(k, None)
 
     def _capture(self, g, labels, scale, key):

@@ -1,4 +1,4 @@
-"""Host time per step() call against the device time per step (eager one-call step vs graph-launched step, GTE_STEP_GRAPH)."""
+"""Host time per step() call against the device time per step (the one-call step)."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
@@ -33,4 +33,4 @@ with torch.cuda.stream(s):
         host += time.perf_counter() - h0
     torch.cuda.synchronize()
     tot = time.perf_counter() - t0
-print(f"GTE_STEP_GRAPH={os.environ.get('GTE_STEP_GRAPH', '0')}: host {host / 120 * 1e6:.0f} us per step() call, {tot / 120 * 1e6:.0f} us per step with the device")
+print(f"host {host / 120 * 1e6:.0f} us per step() call, {tot / 120 * 1e6:.0f} us per step with the device")
