@@ -33,6 +33,12 @@ namespace {
 constexpr int TILE_R = 32;        // destination rows per tile  (must match the host-side plan)
 constexpr int UMAX = 128;         // distinct source rows staged per tile
 constexpr int EMAX = 448;         // edges of a tile kept in LDS (32 rows x up to 14 in-edges): 8-byte {weight, local index} entries
+#ifndef GTE_TILED_EMAX_FULL
+#define GTE_TILED_EMAX_FULL 512
+#endif
+constexpr int EMAX_FULL = GTE_TILED_EMAX_FULL;   // the same in spmm_tiled_full_kernel (7 workgroups per CU by registers, so the
+                                  // half KB is free there).  cfg4's out-edge CSR has 13 tiles of 449 ... 460 edges: on the direct-gather path
+                                  // they were the tail of the launch -- 966 -> 880 us (0.54 -> 0.60 of HBM peak) with 512
 #ifndef GTE_TILED_FC
 #define GTE_TILED_FC 32
 #endif
@@ -206,7 +212,7 @@ spmm_tiled_full_kernel(const int32_t* __restrict__ indptr, const int32_t* __rest
                        int n_rows, int n_feat, int reduce) {
     __shared__ __attribute__((aligned(16))) float s_rows[UMAX * FC];
     struct Edge { float w; int off; };                         // off = local index * FC (float offset of the staged row)
-    __shared__ __attribute__((aligned(8))) Edge s_e[EMAX];
+    __shared__ __attribute__((aligned(8))) Edge s_e[EMAX_FULL];
     __shared__ int s_usrc[UMAX];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -221,11 +227,32 @@ spmm_tiled_full_kernel(const int32_t* __restrict__ indptr, const int32_t* __rest
     // The tile's sources are addressed as {uniform base = row of the smallest source (tile_src is sorted), 32-bit byte
     // offset}: no 64-bit address arithmetic in the chunk loop.  A tile whose sources span 4 GB or more is gathered directly.
     const int src_lo = nu > 0 ? tile_src[u0] : 0, src_hi = nu > 0 ? tile_src[u0 + nu - 1] : 0;
-    const bool staged = (nu <= UMAX) && (ne <= EMAX) &&
+    const bool staged = (nu <= UMAX) && (ne <= EMAX_FULL) &&
                         ((int64_t)(src_hi - src_lo + 1) * ldx * 4 < ((int64_t)1 << 32));   // block-uniform
 
     static_assert(TILE_R == 4 * GPW, "one destination row per lane group");
-    const int r = row0 + wave * GPW + g;
+    // Rows of the tile are handed to the lane groups in order of decreasing degree: the groups of a wave run their edge loops
+    // in lockstep, so a wave lasts as long as its longest row -- rows of similar degree share a wave (cfg4 backward, the
+    // out-edge CSR with degrees 0 ... 24: 872 -> 857 us; tiles of equal degrees, the forward graph, skip the ranking).  Every
+    // wave ranks the 32 rows for itself in registers (lane t < 32 holds row t's degree; no LDS, no barrier); a row is still
+    // summed by one group in CSR order: same bits as before.
+    int r = row0 + wave * GPW + g;
+#ifndef GTE_TILED_NO_SORT
+    {
+        const int t = lane & 31;
+        const int d = row0 + t < row_end ? indptr[row0 + t + 1] - indptr[row0 + t] : -1;
+        if (!__all(d == __builtin_amdgcn_readfirstlane(d))) {
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < TILE_R; ++j) {
+                const int dj = __builtin_amdgcn_readlane(d, j);
+                rank += (dj > d || (dj == d && j < t)) ? 1 : 0;
+            }
+            const int by_rank = __builtin_amdgcn_ds_permute(rank << 2, t);        // lane q < 32 <- the row of rank q
+            r = row0 + __builtin_amdgcn_ds_bpermute((wave * GPW + g) << 2, by_rank);
+        }
+    }
+#endif
     const bool r_ok = r < row_end;
     int lo = 0, hi = 0;
     if (r_ok) { lo = indptr[r]; hi = indptr[r + 1]; }
