@@ -1123,7 +1123,7 @@ def main():
             line["gemm_modes"] = gemm_mode_probe(ops, run, alt, global_counts(alt), dev)
         line.update(pre)
         line["order"] = ("gather / val_graph probes, long_run (>= 1 s of the same loop), THEN W warm-up + K timed steps = value, "
-                         "then kernel timers, replay, the other GEMM mode, inference, secondary, size_sweep, shapes, cfg3, cpu_baseline")
+                         "then kernel timers, replay, the other GEMM mode, inference, secondary, size_sweep, shapes, residency, cfg3, cpu_baseline")
         if extras and not args.no_inference:
             line["inference"] = inference_probe(args, gte, model, dev, pages, trainer)
         if pages13 is not None:

@@ -19,8 +19,10 @@ namespace {
 inline int64_t ldf(const gte_step_layer& L) { return L.ldf > 0 ? L.ldf : L.fout; }
 inline int64_t ld_lg(const gte_step_plan& p) { return p.ld_lg > 0 ? p.ld_lg : p.n_classes; }
 
-// weight images + the hidden layers (the output layer's input is p.h_out / p.hp_out afterwards)
-int forward_hidden(const gte_step_plan& p, void* st) {
+// weight images + the hidden layers (the output layer's input is p.h_out / p.hp_out afterwards).  fwd_only: nothing is kept for a
+// backward -- a planes layer whose output is consumed as an image (by the next planes layer, or by the output layer's GEMM) does
+// not write its fp32 rows (a sixth of the aggregation + LayerNorm kernel's bytes)
+int forward_hidden(const gte_step_plan& p, void* st, bool fwd_only = false) {
     const int64_t n = p.n_nodes;
     if (p.n_wimg_descs > 0 && !p.wimg_fresh) {
         const gte_p3_desc* d = reinterpret_cast<const gte_p3_desc*>(p.wimg_descs);
@@ -67,8 +69,9 @@ int forward_hidden(const gte_step_plan& p, void* st) {
             GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, nullptr, 0, 0, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * ld, n,
                                    2 * ld, 0, 0, st));
         mark(2 * i + 1);
+        float* const y = (fwd_only && L.yp && (i + 1 < p.n_hidden ? (p.layer[i + 1].kind == GTE_LAYER_PLANES && !p.layer[i + 1].make_hp) : p.out_gemm != 0)) ? nullptr : L.y;
         GTE_TRY(gte_spmm_csr_accumulate_ln_p3(p.indptr, p.indices, p.w_in, L.t + ld, 2 * ld, L.t, 2 * ld, n, L.fout,
-                                              GTE_REDUCE_MEAN, L.gamma, L.beta, L.eps, L.relu, L.y, ld, L.yp, L.ldp_y, L.stats, st));
+                                              GTE_REDUCE_MEAN, L.gamma, L.beta, L.eps, L.relu, y, ld, L.yp, L.ldp_y, L.stats, st));
     }
     return GTE_OK;
 }
@@ -267,7 +270,7 @@ extern "C" int gte_gcnsage_forward(const gte_step_plan* plan, void* stream) {
     GTE_TRY(check_plan(p));
     GTE_TRY(gte_gemm_set_tail_workspace(p.tail_ws, p.tail_ws ? p.tail_ws_bytes : 0));
     const int64_t n = p.n_nodes, C = p.n_classes;
-    int rc = forward_hidden(p, stream);
+    int rc = forward_hidden(p, stream, true);
     // logits = h W_s^T + b + mean-aggregate(h W_n^T): the class-count-wide aggregation the step runs inside its loss kernel
     if (rc == GTE_OK) rc = forward_out_products(p, stream);
     if (rc == GTE_OK)
