@@ -553,8 +553,8 @@ extern "C" int gte_spmm_csr_edge(const int32_t* indptr, const int32_t* indices, 
     if (reduce != GTE_REDUCE_SUM && reduce != GTE_REDUCE_MEAN) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "spmm_csr_edge: reduce must be 0 or 1");
     hipStream_t s = gte::as_stream(stream);
     if (n_edges == 0) {                                        // no edges: every row is zero
-        for (int64_t r = 0; r < n_rows; ++r)
-            if (hipMemsetAsync(out + r * ldo, 0, (size_t)n_feat * 4, s) != hipSuccess) return gte::fail(GTE_ERR_LAUNCH, "spmm_csr_edge: memset failed");
+        if (hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)n_feat * 4, (size_t)n_rows, s) != hipSuccess)
+            return gte::fail(GTE_ERR_LAUNCH, "spmm_csr_edge: memset failed");
         return GTE_OK;
     }
     if (workspace_bytes < gte_spmm_csr_edge_workspace_bytes(n_edges, n_feat))
