@@ -63,6 +63,7 @@ struct P3Gemm {
     // resident image and row m of the product is its row rowsA[m]; TN: B is the resident image and k row k is its row rowsB[k]
     // (entries past K name a row past the image).  res_bytes = size of the image (< 4 GB: 32-bit buffer offsets)
     const int* rowsA; const int* rowsB; long long res_bytes;
+    int rows64;                                          // the row map is followed through 64-bit addresses (image >= 4 GB)
     // LayerNorm(+ReLU) backward as the epilogue of an NT product whose tile holds whole rows (N <= 256): the product is
     // dy = d(loss) / d(y of the layer below), never stored; the workgroup writes dz = LN'(z)(mask . dy) as fp32 and as a P3 image
     // and leaves the column partials {sum g xhat, sum g, sum dz} in ln_part[tile][3][N]  (gte_gemm_p3_nt_ln_bwd)
@@ -80,6 +81,13 @@ struct P3Gemm {
 // HOST pass of hipcc 7.2 failed to instantiate the kernel -- silently: no diagnostic, an undefined symbol at load time.
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t srd, char* dst, int voffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)dst, 16, voffset, 0, 0, 0);
+}
+
+// the same from a 64-bit per-lane address (global_load_lds_dwordx4): the row-mapped operand of a resident image of 4 GB or more,
+// whose rows a 32-bit buffer offset does not reach.  No range check: every lane names valid memory.
+typedef const void __attribute__((address_space(1))) * global_cptr_t;
+__device__ __forceinline__ void gdma16(const char* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((global_cptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
 }
 
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
@@ -514,7 +522,8 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
 // wave's: 3 (TM + TN) fragment reads, 6 TM TN MFMAs, barrier.  One barrier per stage for all waves.
 // LNB: 0 plain store; 1 LayerNorm(+ReLU) backward of the tile's rows as the epilogue; 2 the whole backward of a short-input
 // layer below as the epilogue
-template <int WM, int WN, int TM, int TN, int NL, int LNB = 0>
+// BIG: the row-mapped A operand (p.rowsA) is read through 64-bit per-lane addresses -- a resident image of 4 GB or more
+template <int WM, int WN, int TM, int TN, int NL, int LNB = 0, bool BIG = false>
 __global__ void __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL + 3) / 4)
 gemm_p3_nt_lw_kernel(const P3Gemm p) {
     constexpr int NW = WM * WN, NBUF = 3;
@@ -560,9 +569,31 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
             }
         });
         const int KB1 = p.KB1;
+        // BIG: the lane's piece of its image row as a pointer.  Rows past the tile's valid rows read the tile's first row (their
+        // products are never stored), stages past the end of K re-read the last block (never multiplied): no lane leaves the image.
+        const char* ap[NI];
+        if constexpr (BIG)
+            static_for<NI>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                const int ii = i * NL + lw;
+                const int s = ii * 64 + lane, row = s / 6, part = s - row * 6, sp = part ^ ((row >> 3) & 1);
+                const int rr = (ii < A_INST) ? p.rowsA[m0 + (row < rowsA ? row : 0)] : 0;
+                ap[i] = p.A1 + (long long)rr * p.lda1 + sp * 16;
+            });
         auto issue = [&](int t, char* buf) {
             const bool seg = t >= KB1;
             const int live = t < T ? 1 : 0;
+            if constexpr (BIG) {
+                const __amdgpu_buffer_rsrc_t sbb =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
+                const long long ta = (long long)(t < T ? t : T - 1) * bsa1;
+                static_for<NI>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    if (i * NL + lw < A_INST) gdma16(ap[i] + ta, buf + (i * NL + lw) * 1024);      // (wave-uniform choice)
+                    else dma16(sbb, buf + (i * NL + lw) * 1024, vo1[i]);
+                });
+                return;
+            }
             const char* pa = seg ? baseA2 + (long long)(t - KB1) * bsa2 : baseA1 + (long long)t * bsa1;
             const __amdgpu_buffer_rsrc_t sa =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? rowsA * lda2 : recA1) * live, SRD_FLAGS);
@@ -729,9 +760,12 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
 #ifndef P3_TN_ABL
 #define P3_TN_ABL 0       // measurement builds (profiles/debug/build_variant.sh): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no fragment reads
 #endif
-template <int WM, int WN, int WGS, bool MAP = false>
+// BIG (with MAP): the resident image is 4 GB or more -- its rows are read through 64-bit per-lane addresses, without a range
+// check: the map's entries past K name row n_res_rows, which must EXIST and be zero
+template <int WM, int WN, int WGS, bool MAP = false, bool BIG = false>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN * WGS + 3) / 4)
 gemm_p3_tn_kernel(const P3Gemm p) {
+    static_assert(!BIG || MAP, "64-bit rows: the row-mapped kernel");
     static_assert(!MAP || (WM == 2 && WN == 2), "row map: the 128 x 128 tile");
     constexpr int NW = WM * WN, TM = 2, TN = 2;
     constexpr int BM = WM * 64, BN = WN * 64, NBA = BM / 16, NBB = BN / 16;        // 16-feature blocks per k row
@@ -812,6 +846,26 @@ gemm_p3_tn_kernel(const P3Gemm p) {
                 // just issued and everything older --, volatile loads become system-scope flat loads with vmcnt(0) each, and
                 // scalar loads stall the issue by their latency (all three measured / read off the ISA, profiles/r03/gemm_p3.md).
                 asm volatile("s_waitcnt vmcnt(6)" : "+v"(rid[0]), "+v"(rid[1]), "+v"(rid[2])::"memory");
+                if constexpr (BIG) {
+                    const char* g0 = Bm + cob + (long long)rid[0] * ldb + vc[3];
+                    const char* g1 = Bm + cob + (long long)rid[1] * ldb + vc[4];
+                    const char* g2 = Bm + cob + (long long)rid[2] * ldb + vc[5];
+                    const int kn_ = st + 1 < st_end ? k0 + 16 : 0;
+                    const int* r0 = rmap + kn_ + kb[3];
+                    const int* r1 = rmap + kn_ + kb[4];
+                    const int* r2 = rmap + kn_ + kb[5];
+                    asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
+                                 : "=&v"(rid[0]), "=&v"(rid[1]), "=&v"(rid[2])
+                                 : "v"(r0), "v"(r1), "v"(r2), "v"(g0), "v"(g1), "v"(g2)       // (the old ids are consumed first)
+                                 : "memory");
+                    dma16(sa, buf + (0 * NW + wave) * 1024, vo[0]);
+                    dma16(sa, buf + (1 * NW + wave) * 1024, vo[1]);
+                    dma16(sa, buf + (2 * NW + wave) * 1024, vo[2]);
+                    gdma16(g0, buf + (3 * NW + wave) * 1024);
+                    gdma16(g1, buf + (4 * NW + wave) * 1024);
+                    gdma16(g2, buf + (5 * NW + wave) * 1024);
+                    return;
+                }
                 const int o0 = (int)((unsigned)rid[0] * (unsigned)ldb + (unsigned)vc[3]);
                 const int o1 = (int)((unsigned)rid[1] * (unsigned)ldb + (unsigned)vc[4]);
                 const int o2 = (int)((unsigned)rid[2] * (unsigned)ldb + (unsigned)vc[5]);
@@ -1094,6 +1148,19 @@ extern "C" int gte_p3_to_f32(const void* src, int64_t ldp, int64_t rows, int64_t
     return gte::check_launch("p3_to_f32");
 }
 
+// Row maps: 32-bit buffer offsets reach images below 4 GB; larger ones are read through 64-bit per-lane addresses
+// (gte_gemm_p3_set_rows64(1) forces that path for any size: tests, A/B timing)
+static int g_rows64_mode = 0;
+static inline int rows64_needed(long long res_bytes) {
+    static const int env = getenv("GTE_P3_ROWS64") ? atoi(getenv("GTE_P3_ROWS64")) : 0;          // (A/B timing of the train loop)
+    return (g_rows64_mode == 1 || env == 1 || res_bytes >= ((long long)1 << 32) - 4096) ? 1 : 0;
+}
+extern "C" int gte_gemm_p3_set_rows64(int mode) {
+    if (mode != 0 && mode != 1) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_set_rows64: mode must be 0 (by size) or 1 (always)");
+    g_rows64_mode = mode;
+    return GTE_OK;
+}
+
 // C[m, n] (+)= [a1 | a2] b^T (+ bias): a1 = P3 [m][k1], a2 = P3 [m][k2] (nullable, k2 = 0), b = P3 [n][ceil16(k1) + k2]
 // (the K blocks of the second segment follow the ceil(k1 / 16) blocks of the first in every row of b)
 static int gemm_p3_nt_impl(const void* a1, int64_t lda1, int64_t k1, const void* a2, int64_t lda2, int64_t k2, const void* b,
@@ -1116,9 +1183,9 @@ static int gemm_p3_nt_impl(const void* a1, int64_t lda1, int64_t k1, const void*
     p.M = (int)m; p.N = (int)n; p.relu = relu; p.accumulate = accumulate; p.splits = 1;
     if (a_rows) {
         if (k2 > 0) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_rows: one K segment only");
-        if (n_res_rows <= 0 || n_res_rows * lda1 >= ((int64_t)1 << 32) - 4096)
-            return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_rows: the resident image must be smaller than 4 GB (32-bit buffer offsets)");
+        if (n_res_rows <= 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_rows: empty resident image");
         p.rowsA = a_rows; p.res_bytes = n_res_rows * lda1;
+        p.rows64 = rows64_needed(p.res_bytes);
     }
     return launch_nt(p, gte::as_stream(stream));
 }
@@ -1130,7 +1197,8 @@ extern "C" int gte_gemm_p3_nt(const void* a1, int64_t lda1, int64_t k1, const vo
 }
 
 // c[m, n] (+)= A b^T with A = the rows a_rows[0 .. m) of a RESIDENT P3 image a_res [n_res_rows][k]: the input layer's forward
-// transform straight from the resident features (no per-batch copy of the rows).  One K segment; the image < 4 GB.
+// transform straight from the resident features (no per-batch copy of the rows).  One K segment.  Images of 4 GB or more are
+// read through 64-bit per-lane addresses (the loader-wave kernels, 128 / 192 x 256 tiles).
 extern "C" int gte_gemm_p3_nt_rows(const void* a_res, int64_t ldpa, int64_t k, const int32_t* a_rows, int64_t n_res_rows, const void* b,
                                    int64_t ldpb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
                                    int relu, int accumulate, void* stream) {
@@ -1151,17 +1219,17 @@ void launch_ring(const P3Gemm& p, hipStream_t s) {
     const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
     hipLaunchKernelGGL((gemm_p3_nt_ring_kernel<WM, WN, TM, TN, NBUF, WGS>), grid, dim3(NW * 64), shm, s, p);
 }
-template <int WM, int WN, int TM, int TN, int NL>
+template <int WM, int WN, int TM, int TN, int NL, bool BIG = false>
 void launch_lw(const P3Gemm& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NI = ((BM + BN) * 96 / 1024 + NL - 1) / NL, shm = 3 * NI * NL * 1024;
     static bool configured = false;
     if (!configured) {
-        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL>), shm);
+        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, 0, BIG>), shm);
         configured = true;
     }
     const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
-    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
+    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, 0, BIG>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
 template <int WM, int WN, int TM, int TN, int NL, int LNB = 1>
 void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
@@ -1200,6 +1268,14 @@ int nt_choose(const P3Gemm& p) {
     return bi;
 }
 int launch_nt(const P3Gemm& p, hipStream_t s) {
+    if (p.rowsA && p.rows64) {
+        // a row map into an image of 4 GB or more: the two loader-wave tiles, whichever makes the shorter schedule
+        const int cus = gte::device_props().cus;
+        const int64_t r128 = gte::ceil_div(gte::ceil_div(p.M, 128) * gte::ceil_div(p.N, 256), cus) * 128;
+        const int64_t r192 = gte::ceil_div(gte::ceil_div(p.M, 192) * gte::ceil_div(p.N, 256), cus) * 192;
+        if (r192 < r128) launch_lw<2, 4, 3, 2, 4, true>(p, s); else launch_lw<2, 4, 2, 2, 4, true>(p, s);
+        return gte::check_launch("gemm_p3_nt_rows");
+    }
     int cfg = nt_choose(p);
     switch (cfg) {
         case 7: launch_ring<2, 4, 3, 2, 3, 1>(p, s); break;     // measurement: 192 x 256 ring (no loader waves)
@@ -1422,9 +1498,9 @@ static int gemm_p3_tn_impl(const void* a, int64_t lda, const void* a2, int64_t l
     p.splits = pl.splits; p.stages_per_split = pl.stages_per_split;
     if (b_rows) {
         if (b2) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_tn_rows: one B image");
-        if (n_res_rows <= 0 || (n_res_rows + 1) * ldb >= ((int64_t)1 << 32) - 4096)
-            return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_tn_rows: the resident image must be smaller than 4 GB (32-bit buffer offsets)");
+        if (n_res_rows <= 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_tn_rows: empty resident image");
         p.rowsB = b_rows; p.res_bytes = n_res_rows * ldb;
+        p.rows64 = rows64_needed((n_res_rows + 1) * ldb);
     }
     if (pl.splits > 1) {
         const int64_t need = (int64_t)pl.splits * m * n * 4;
@@ -1439,10 +1515,12 @@ static int gemm_p3_tn_impl(const void* a, int64_t lda, const void* a2, int64_t l
     if (!configured) {
         GTE_SET_LDS((gemm_p3_tn_kernel<2, 2, 2>), shm_small);
         GTE_SET_LDS((gemm_p3_tn_kernel<2, 2, 2, true>), shm_small);
+        GTE_SET_LDS((gemm_p3_tn_kernel<2, 2, 2, true, true>), shm_small);
         configured = true;
     }
     const dim3 grid((unsigned)(tiles * pl.splits));
-    if (p.rowsB) hipLaunchKernelGGL((gemm_p3_tn_kernel<2, 2, 2, true>), grid, dim3(256), shm_small, s, p);
+    if (p.rowsB && p.rows64) hipLaunchKernelGGL((gemm_p3_tn_kernel<2, 2, 2, true, true>), grid, dim3(256), shm_small, s, p);
+    else if (p.rowsB) hipLaunchKernelGGL((gemm_p3_tn_kernel<2, 2, 2, true>), grid, dim3(256), shm_small, s, p);
     else hipLaunchKernelGGL((gemm_p3_tn_kernel<2, 2, 2>), grid, dim3(256), shm_small, s, p);
     int rc = gte::check_launch("gemm_p3_tn");
     if (rc != GTE_OK || pl.splits <= 1) return rc;
@@ -1461,7 +1539,8 @@ extern "C" int gte_gemm_p3_tn(const void* a, int64_t lda, const void* a2, int64_
 
 // ... with b = the rows b_rows[0 .. k) of a RESIDENT P3 image b_res [n_res_rows][.] (the input layer's dW straight from the
 // resident features).  b_rows must hold k rounded up to 16, plus 1, entries; the entries past k = n_res_rows (a row past the
-// image: zeros).  Both column segments read the same image; the image < 4 GB.
+// image: zeros).  Both column segments read the same image.  An image of 4 GB or more is read through 64-bit addresses without a
+// range check: row n_res_rows must then exist in the allocation and hold zeros.
 extern "C" int gte_gemm_p3_tn_rows(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, const void* b_res, int64_t ldpb,
                                    const int32_t* b_rows, int64_t n_res_rows, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n,
                                    int64_t k, void* workspace, int64_t workspace_bytes, void* stream) {

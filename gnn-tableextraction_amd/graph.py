@@ -443,11 +443,17 @@ class ResidentPages:
         Called by the train loop when layer 0 of the step engine takes its input as an image."""
         if self.feat_p3 is None:
             from . import ops
-            self.feat_p3 = ops.p3_from_f32(self.feat)
+            # one row more than the set has nodes, zero: the row maps' padding entries name it (an image of 4 GB or more is
+            # read without a range check, gte_gemm_p3_tn_rows)
+            img = ops.P3.empty(self.n_nodes, int(self.feat.shape[1]), self.device, rows_cap=self.n_nodes + 1)
+            img.data[self.n_nodes:].zero_()
+            self.feat_p3 = ops.p3_from_f32(self.feat, out=img)
         # "rows": a batch names its rows of the RESIDENT image through a row map (no copy of the image rows at all; the input
-        # layer's two GEMMs read the image through the map); "copy": the batch holds a copy of its image rows.  The map needs
-        # 32-bit byte offsets into the image.
-        rows_ok = self.feat_p3.data.numel() + self.feat_p3.ldp < (1 << 32) - 4096
+        # layer's two GEMMs read the image through the map -- 32-bit buffer offsets below 4 GB of image, 64-bit addresses above);
+        # "copy": the batch holds a copy of its image rows.  An image handed in from outside (from_arrays) may lack the zero row
+        # behind its last node that the 64-bit path needs: it takes the map below 4 GB only.
+        rows_ok = (self.feat_p3.data.shape[0] > self.n_nodes or
+                   self.feat_p3.data.numel() + self.feat_p3.ldp < (1 << 32) - 4096)
         want = os.environ.get("GTE_P3_ROWS", "1").lower() not in ("0", "off", "false")
         self.p3_mode = "rows" if (rows_ok and want) else "copy"
 

@@ -339,9 +339,9 @@ int gte_gemm_p3_nt(const void* a1, int64_t ldpa1, int64_t k1, const void* a2, in
 /* c[m, n] = a^T b over k rows (dW = dZ^T X; split over the rows, partial slabs in `workspace`, folded in a fixed order --
  * inside an open fold deferral by gte_fold_defer_flush).  a: P3 [k][m], b: P3 [k][n].  nseg > 0: two column segments of
  * nseg columns (n == 2 nseg): c[:, 0:nseg] = a^T b, c[:, nseg:] = a2^T b2 (a2 / b2 NULL: the operand of segment 0). */
-/* ... with A = the rows a_rows[0 .. m) of a RESIDENT image a_res [n_res_rows][k] (one K segment; the image < 4 GB): the input
- * layer's forward transform straight from the resident features -- no per-batch copy of the rows (gte_batch_assemble_rows
- * writes the map). */
+/* ... with A = the rows a_rows[0 .. m) of a RESIDENT image a_res [n_res_rows][k] (one K segment): the input layer's forward
+ * transform straight from the resident features -- no per-batch copy of the rows (gte_batch_assemble_rows writes the map).
+ * Images below 4 GB are read through 32-bit buffer offsets, larger ones through 64-bit per-lane addresses (same results). */
 int gte_gemm_p3_nt_rows(const void* a_res, int64_t ldpa, int64_t k, const int32_t* a_rows, int64_t n_res_rows, const void* b,
                         int64_t ldpb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
                         int relu, int accumulate, void* stream);
@@ -372,10 +372,14 @@ int gte_gemm_p3_tn(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, c
                    int64_t workspace_bytes, void* stream);
 
 /* gte_gemm_p3_tn with b = the rows b_rows[0 .. k) of a RESIDENT image b_res (the input layer's dW).  b_rows holds k rounded up
- * to 16, plus 1, entries; the entries past k = n_res_rows (a row past the image reads as zeros).  Image < 4 GB. */
+ * to 16, plus 1, entries; the entries past k = n_res_rows (a row past the image reads as zeros).  An image of 4 GB or more is
+ * read through 64-bit addresses WITHOUT a range check: its allocation must then hold row n_res_rows, filled with zeros. */
 int gte_gemm_p3_tn_rows(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, const void* b_res, int64_t ldpb,
                         const int32_t* b_rows, int64_t n_res_rows, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n,
                         int64_t k, void* workspace, int64_t workspace_bytes, void* stream);
+/* Row maps: 0 = 64-bit addresses for resident images of 4 GB or more only (default), 1 = always (tests, A/B timing; the
+ * zero-row requirement of gte_gemm_p3_tn_rows then holds for every image). */
+int gte_gemm_p3_set_rows64(int mode);
 /* gte_batch_assemble with a ROW MAP instead of (feat == NULL) or next to the copied feature rows: row_map[r] = resident row of
  * batch row r (r < n_out), row_map[n_out .. n_out + row_map_pad) = n_res_rows. */
 int gte_batch_assemble_rows(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,

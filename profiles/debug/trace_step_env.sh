@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$1; shift
 mkdir -p $O
-STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --no-inference --val-graph 0"
+STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --no-inference --val-graph 0 --no-shapes --no-size-sweep --no-residency"
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   tag=$(echo $v | tr '= ' '__')

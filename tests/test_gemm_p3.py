@@ -142,16 +142,33 @@ def _row_map(n_res, rows, seed):
     return torch.from_numpy(np.concatenate([ids, pad])).to(DEV)
 
 
+def _resident_image(x):
+    """P3 image of x with one more row, zero, behind it (what ResidentPages.enable_p3 allocates: the 64-bit row-map path reads
+    the map's padding entries without a range check)"""
+    img = ops.P3.empty(x.shape[0], x.shape[1], x.device, rows_cap=x.shape[0] + 1)
+    img.data[x.shape[0]:].zero_()
+    return ops.p3_from_f32(x, out=img)
+
+
+@pytest.fixture(params=[False, True], ids=["offsets32", "addresses64"])
+def rows64(request):
+    """row maps through 32-bit buffer offsets (images below 4 GB) and, forced, through the 64-bit addresses of larger images"""
+    lib = _lib.load()
+    assert lib.gte_gemm_p3_set_rows64(1 if request.param else 0) == 0
+    yield request.param
+    assert lib.gte_gemm_p3_set_rows64(0) == 0
+
+
 @pytest.mark.parametrize("rows,k,n", [(24437, 831, 512), (3000, 831, 512), (100, 363, 256), (1, 48, 256), (6001, 831, 256)])
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 5, 6])
-def test_nt_through_a_row_map_is_bitwise_the_gathered_gemm(monkeypatch, rows, k, n, cfg):
+def test_nt_through_a_row_map_is_bitwise_the_gathered_gemm(monkeypatch, rows64, rows, k, n, cfg):
     if cfg is not None:
-        if rows != 3000:
-            pytest.skip("forced tile shapes: one problem size")
+        if rows != 3000 or rows64:
+            pytest.skip("forced tile shapes: one problem size, 32-bit offsets (the 64-bit path has its own two tiles)")
         monkeypatch.setenv("GTE_P3_NT_CFG", str(cfg))
     n_res = 40000
     g = torch.Generator(device=DEV).manual_seed(rows)
-    res = ops.p3_from_f32(torch.randn(n_res, k, device=DEV, generator=g))
+    res = _resident_image(torch.randn(n_res, k, device=DEV, generator=g))
     w = ops.p3_from_f32(torch.randn(n, k, device=DEV, generator=g))
     bias = torch.randn(n, device=DEV, generator=g)
     rm = _row_map(n_res, rows, rows)
@@ -162,11 +179,11 @@ def test_nt_through_a_row_map_is_bitwise_the_gathered_gemm(monkeypatch, rows, k,
 
 
 @pytest.mark.parametrize("rows,k,m", [(24437, 831, 256), (3000, 831, 256), (100, 363, 128), (17, 48, 256), (6001, 831, 128)])
-def test_tn_through_a_row_map_is_bitwise_the_gathered_gemm(rows, k, m):
+def test_tn_through_a_row_map_is_bitwise_the_gathered_gemm(rows64, rows, k, m):
     """dW0 = [dz^T X | q^T X] with X = mapped rows of the resident image; the rows past the map's end read as zeros."""
     n_res = 40000
     g = torch.Generator(device=DEV).manual_seed(rows + 1)
-    res = ops.p3_from_f32(torch.randn(n_res, k, device=DEV, generator=g))
+    res = _resident_image(torch.randn(n_res, k, device=DEV, generator=g))
     dz, q = (ops.p3_from_f32(torch.randn(rows, m, device=DEV, generator=g)) for _ in range(2))
     rm = _row_map(n_res, rows, rows + 1)
     mapped = ops.P3(res.data, rows, k, row_map=rm, res_rows=n_res)
@@ -187,9 +204,37 @@ def test_row_map_entry_points_validate():
     P = _lib.ptr
     assert lib.gte_gemm_p3_nt_rows(P(z), 96, 16, None, 64, P(z), 96, None, 0, P(c), 16, 16, 16, 0, 0, None) == -1
     rm = torch.zeros(64, dtype=torch.int32, device=DEV)
-    too_big = (1 << 32) // 96 + 1
-    assert lib.gte_gemm_p3_nt_rows(P(z), 96, 16, P(rm), too_big, P(z), 96, None, 0, P(c), 16, 16, 16, 0, 0, None) == -4
-    assert b"4 GB" in lib.gte_last_error()
+    assert lib.gte_gemm_p3_nt_rows(P(z), 96, 16, P(rm), 0, P(z), 96, None, 0, P(c), 16, 16, 16, 0, 0, None) == -1
+    assert b"empty resident image" in lib.gte_last_error()
+    assert lib.gte_gemm_p3_set_rows64(2) == -1
+
+
+def test_row_maps_into_a_resident_image_above_4_gb():
+    """900 000 resident rows x 831 features = 4.5 GB of image: 32-bit buffer offsets do not reach its rows, the GEMMs follow the
+    map through 64-bit per-lane addresses (global_load_lds).  Forward (NT) and weight-gradient (TN) products against the same
+    GEMMs on a gathered copy of the rows, bit for bit; the map takes rows from the whole image, its last row included."""
+    n_res, k, rows = 900_000, 831, 24437
+    ldp = _lib.load().gte_p3_row_bytes(k)
+    assert n_res * ldp > (1 << 32)
+    img = ops.P3.empty(n_res, k, DEV, rows_cap=n_res + 1)
+    img.data[n_res:].zero_()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for r0 in range(0, n_res, 100_000):                            # (converted chunk by chunk: 330 MB of fp32 at a time)
+        chunk = torch.randn(100_000, k, device=DEV, generator=g)
+        ops.p3_from_f32(chunk, out=img, row0=r0)
+        del chunk
+    rm = _row_map(n_res, rows, 77)
+    rm[0], rm[1] = n_res - 1, 0                                    # first and last row of the image
+    assert int(rm[:rows].max()) * ldp > (1 << 32)
+    mapped = ops.P3(img.data, rows, k, row_map=rm, res_rows=n_res)
+    gathered = mapped.gathered()
+    w = ops.p3_from_f32(torch.randn(512, k, device=DEV, generator=g))
+    bias = torch.randn(512, device=DEV, generator=g)
+    assert torch.equal(ops.gemm_p3_nt(mapped, w, bias=bias, bias_cols=256), ops.gemm_p3_nt(gathered, w, bias=bias, bias_cols=256))
+    small = ops.P3(img.data, 3000, k, row_map=torch.cat([rm[:3000], rm[-33:]]), res_rows=n_res)      # the 128-row tile
+    assert torch.equal(ops.gemm_p3_nt(small, w), ops.gemm_p3_nt(small.gathered(), w))
+    dz, q = (ops.p3_from_f32(torch.randn(rows, 256, device=DEV, generator=g)) for _ in range(2))
+    assert torch.equal(ops.gemm_p3_tn(dz, mapped, a2=q, two_segments=True), ops.gemm_p3_tn(dz, gathered, a2=q, two_segments=True))
 
 
 # ---- the backward GEMM with the LayerNorm backward of the layer below as its epilogue ---------------------------------------
