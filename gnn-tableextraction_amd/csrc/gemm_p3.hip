@@ -520,7 +520,8 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
 // instructions, in order, in front of its MFMAs: 21 of 97 us on the layer-0 forward (profiles/r03/gemm_p3.md, ablation "no
 // DMA").  A loader wave's stream is: request stage t + 2, wait until stage t + 1 has landed (counted vmcnt), barrier; a compute
 // wave's: 3 (TM + TN) fragment reads, 6 TM TN MFMAs, barrier.  One barrier per stage for all waves.
-// LNB: 0 plain store; 1 LayerNorm(+ReLU) backward of the tile's rows as the epilogue; 2 the whole backward of a short-input
+// LNB: 0 plain store; 1 LayerNorm(+ReLU) backward of the tile's rows as the epilogue (3: the same for a LayerNorm width that is
+// not a multiple of 16 -- per-element validity, zeros up to the next multiple of 16 in the image); 2 the whole backward of a short-input
 // layer below as the epilogue
 // BIG: the row-mapped A operand (p.rowsA) is read through 64-bit per-lane addresses -- a resident image of 4 GB or more
 template <int WM, int WN, int TM, int TN, int NL, int LNB = 0, bool BIG = false>
@@ -667,14 +668,20 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         static_assert(BN == 256 && TN == 2, "whole rows per workgroup");
         constexpr int SR = TM * 32, LDT = 256;                        // slice rows; floats per LDS row
         float* tile = reinterpret_cast<float*>(lds);
+        constexpr bool MSK = LNB == 3;
         const int n = p.N, M = p.M;
         const int j4 = 4 * lane;
-        const bool okc = j4 < n;
+        // MSK: n is any width; the lane takes part while it has a valid column (the rows of z / dz are padded to a multiple of 4
+        // floats), and writes image columns up to the next multiple of 16
+        const bool okc = MSK ? j4 < ((n + 3) & ~3) : j4 < n;
+        const bool imc = MSK ? j4 < ((n + 15) & ~15) : okc;
+        bool oke[4];
         float gam[4], bet[4], s_dg[4], s_db[4], s_dbias[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            gam[e] = okc ? p.ln_gamma[j4 + e] : 1.f;
-            bet[e] = okc ? p.ln_beta[j4 + e] : 0.f;
+            oke[e] = MSK ? j4 + e < n : okc;
+            gam[e] = oke[e] ? p.ln_gamma[j4 + e] : 1.f;
+            bet[e] = oke[e] ? p.ln_beta[j4 + e] : 0.f;
             s_dg[e] = s_db[e] = s_dbias[e] = 0.f;
         }
         const float inv_n = 1.0f / (float)n;
@@ -718,15 +725,17 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
                     const long long rg = row_base + rl + u * NW;
                     float xh[4], g[4];
                     float a = 0.f, b = 0.f;
-                    gte_ln_bwd_pre4(gy[u], zz[u], mean[u], rstd[u], gam, bet, okc, p.ln_relu, xh, g, a, b);
+                    if constexpr (MSK) gte_ln_bwd_pre4m(gy[u], zz[u], mean[u], rstd[u], gam, bet, oke, p.ln_relu, xh, g, a, b);
+                    else gte_ln_bwd_pre4(gy[u], zz[u], mean[u], rstd[u], gam, bet, okc, p.ln_relu, xh, g, a, b);
                     const float c1 = gte_group_sum<64>(a) * inv_n, c2 = gte_group_sum<64>(b) * inv_n;
                     float d[4];
-                    gte_ln_bwd_post4(g, xh, gam, rstd[u], c1, c2, okc, d, s_dg, s_db, s_dbias);
+                    if constexpr (MSK) gte_ln_bwd_post4m(g, xh, gam, rstd[u], c1, c2, oke, d, s_dg, s_db, s_dbias);
+                    else gte_ln_bwd_post4(g, xh, gam, rstd[u], c1, c2, okc, d, s_dg, s_db, s_dbias);
                     if (okc) {
                         f4u o; o.x = d[0]; o.y = d[1]; o.z = d[2]; o.w = d[3];
                         *reinterpret_cast<f4u*>(p.ln_dz + rg * p.ln_lddz + j4) = o;
-                        if (p.ln_dzp3) p3::store4(p.ln_dzp3 + rg * p.ln_ldp3, j4, d[0], d[1], d[2], d[3]);
                     }
+                    if (imc && p.ln_dzp3) p3::store4(p.ln_dzp3 + rg * p.ln_ldp3, j4, d[0], d[1], d[2], d[3]);
                 }
             }
         }
@@ -1307,7 +1316,8 @@ p3_colsum_fold_kernel(const float* __restrict__ part, long long stride, int coun
     out[j] = s;
 }
 }
-extern "C" int gte_gemm_p3_nt_ln_bwd_supported(int64_t n) { return (n >= 4 && n <= 256 && n % 4 == 0) ? 1 : 0; }
+// any width up to 256 (a workgroup's tile holds whole rows); n % 4 != 0 needs rows of z / dz padded to a multiple of 4 floats
+extern "C" int gte_gemm_p3_nt_ln_bwd_supported(int64_t n) { return (n >= 1 && n <= 256) ? 1 : 0; }
 extern "C" int64_t gte_gemm_p3_nt_ln_bwd_workspace_bytes(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 256;
     return gte::round_up(gte::ceil_div(m, lnb_row_tile(m)) * 3 * n * 4, 256);
@@ -1323,12 +1333,13 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
                                      void* stream) {
     if (m < 0 || n <= 0 || k1 <= 0 || k2 < 0 || m > INT32_MAX || k1 > INT32_MAX || k2 > INT32_MAX)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: bad sizes");
-    if (!gte_gemm_p3_nt_ln_bwd_supported(n)) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_bwd: needs n <= 256, n %% 4 == 0");
+    if (!gte_gemm_p3_nt_ln_bwd_supported(n)) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_bwd: needs n <= 256");
     if (m == 0) return GTE_OK;
     if (!a1 || !b || !z || !stats || !gamma || !beta || !dz || !workspace || (k2 > 0 && !a2))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: null pointer");
     const int64_t kb1 = p3::blocks(k1), kb2 = k2 > 0 ? p3::blocks(k2) : 0;
-    if (lda1 < p3::row_bytes(k1) || (k2 > 0 && lda2 < p3::row_bytes(k2)) || ldb < (kb1 + kb2) * 96 || ldz < n || lddz < n ||
+    const int64_t n4 = gte::round_up(n, 4);
+    if (lda1 < p3::row_bytes(k1) || (k2 > 0 && lda2 < p3::row_bytes(k2)) || ldb < (kb1 + kb2) * 96 || ldz < n4 || lddz < n4 ||
         (dzp3 && (ldp3 < p3::row_bytes(n) || ldp3 % 16 != 0)))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: leading dimension too small");
     if (lda1 >= (1 << 23) || lda2 >= (1 << 23) || ldb >= (1 << 23) || (m + 256) * lda1 >= ((int64_t)1 << 31) ||
@@ -1349,7 +1360,8 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
     p.ln_part = reinterpret_cast<float*>(workspace);
     hipStream_t s = gte::as_stream(stream);
     const int bm = lnb_row_tile(m);
-    launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
+    if (n % 16 == 0) launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
+    else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);           // per-element validity, zero image columns up to the next multiple of 16
     int rc = gte::check_launch("gemm_p3_nt_ln_bwd");
     if (rc != GTE_OK) return rc;
     const int nb = (int)gte::ceil_div(m, bm);
@@ -1368,7 +1380,7 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
 
 // ---- ... with the WHOLE backward of a short-input layer below (gte_sage_smallk_bwd) as its epilogue --------------------------
 extern "C" int gte_gemm_p3_nt_smallk_bwd_supported(int64_t k_total, int64_t n) {
-    return (gte_gemm_p3_nt_ln_bwd_supported(n) && k_total >= 1 && k_total <= 28) ? 1 : 0;
+    return (n >= 4 && n <= 256 && n % 4 == 0 && k_total >= 1 && k_total <= 28) ? 1 : 0;
 }
 extern "C" int64_t gte_gemm_p3_nt_smallk_bwd_workspace_bytes(int64_t m, int64_t k_total, int64_t n) {
     if (m <= 0 || n <= 0 || k_total <= 0) return 256;

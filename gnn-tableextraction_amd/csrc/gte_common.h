@@ -172,3 +172,33 @@ __device__ __forceinline__ void gte_ln_bwd_post4(const float (&g)[4], const floa
         s_dbias[e] = s_dbias[e] + (okc ? d[e] : 0.f);
     }
 }
+// ... for a LayerNorm width that is not a multiple of 4 (16): per-element validity; the arithmetic of ln_relu_bwd_gen_kernel
+__device__ __forceinline__ void gte_ln_bwd_pre4m(const float (&gy)[4], const float (&zz)[4], float mean, float rstd, const float (&gam)[4],
+                                                 const float (&bet)[4], const bool (&ok)[4], int relu, float (&xh)[4], float (&g)[4],
+                                                 float& a, float& b) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xh[e] = ok[e] ? (zz[e] - mean) * rstd : 0.f;
+        float gv = ok[e] ? gy[e] : 0.f;
+        if (relu && fmaf(xh[e], gam[e], bet[e]) <= 0.f) gv = 0.f;
+        g[e] = gv;
+        const float dxh = gv * gam[e];
+        a = a + dxh;
+        b = fmaf(dxh, xh[e], b);
+    }
+}
+__device__ __forceinline__ void gte_ln_bwd_post4m(const float (&g)[4], const float (&xh)[4], const float (&gam)[4], float rstd, float c1,
+                                                  float c2, const bool (&ok)[4], float (&d)[4], float (&s_dg)[4], float (&s_db)[4],
+                                                  float (&s_dbias)[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t0 = g[e] * gam[e];
+        const float t1 = xh[e] * c2;
+        d[e] = ok[e] ? rstd * ((t0 - c1) - t1) : 0.f;
+        s_dg[e] = fmaf(g[e], xh[e], s_dg[e]);
+        s_db[e] = s_db[e] + g[e];
+        s_dbias[e] = s_dbias[e] + d[e];
+    }
+}

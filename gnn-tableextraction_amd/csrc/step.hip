@@ -166,7 +166,8 @@ int backward_a(const gte_step_plan& p, void* st) {
             // queues the next batch's assembly in front of it, as in front of a planes layer 0's dW)
             smallk_done = true;
             break;
-        } else if ((p.fuse_ln_dx & 1) && B.kind != GTE_LAYER_SMALLK && L.fin % 16 == 0 && gte_gemm_p3_nt_ln_bwd_supported(L.fin)) {
+        } else if ((p.fuse_ln_dx & 1) && B.kind != GTE_LAYER_SMALLK && gte_gemm_p3_nt_ln_bwd_supported(L.fin) &&
+                   (L.fin % 16 == 0 || ldf(B) >= ((L.fin + 3) & ~(int64_t)3))) {      // (unaligned widths: padded rows)
             GTE_TRY(gte_gemm_p3_nt_ln_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, z_of(B), ldz_of(B), B.stats,
                                           B.gamma, B.beta, B.relu, B.dy, ldf(B), B.dzp, B.ldp_o, B.ggamma, B.gbeta, B.gbias, n, L.fin, B.ws_ln,
                                           B.ws_ln_bytes, st));

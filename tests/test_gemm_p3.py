@@ -271,6 +271,47 @@ def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(m, n, k
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-6)
 
 
+@pytest.mark.parametrize("m,n,relu", [(24437, 218, True), (3000, 149, True), (5001, 206, False), (24437, 100, True), (777, 157, True),
+                                      (260, 5, True), (2, 250, True)])
+def test_nt_with_layernorm_backward_epilogue_at_widths_that_are_not_multiples_of_16(m, n, relu):
+    """The hidden widths the reference's runs use (218, 206, 157, 149, 100): rows of z / dz padded to 16 floats, the LayerNorm over
+    the true width.  dz -- fp32 with its padding, and the image up to the next multiple of 16 columns -- bit for bit what
+    gte_gemm_p3_nt + gte_ln_relu_bwd_p3 (the general-width kernel) produce; k = n as in the step (dX of the layer above)."""
+    ld = -(-n // 16) * 16
+    g = torch.Generator(device=DEV).manual_seed(m + n)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    a1, a2, w = rnd(m, n), rnd(m, n), rnd(n, 2 * ld) / 16
+    w[:, n:ld] = 0                                             # [W_s^T | W_n^T] with the K blocks of each half padded to 16
+    w[:, ld + n:] = 0
+    t = torch.zeros(m, 2 * ld, device=DEV)
+    t[:, :n] = rnd(m, n)
+    z = t[:, :n]                                               # the left half of t = [t_self | t_neigh], padding zero
+    gam, bet = 1 + 0.1 * rnd(n), 0.1 * rnd(n)
+    mu = z.mean(1)
+    stats = torch.cat([mu, 1.0 / torch.sqrt(z.var(1, unbiased=False) + 1e-5)]).contiguous()
+    a1p, a2p = ops.p3_from_f32(a1), ops.p3_from_f32(a2)
+    wp = ops.p3_from_f32(w)                                    # K = 2 ld: block ld / 16 starts the second segment
+    lib, P = _lib.load(), _lib.ptr
+    dyb = torch.zeros(m, ld, device=DEV)
+    ops.gemm_p3_nt(a1p, wp, a2=a2p, out=dyb[:, :n])
+    dz_ref, dzp_ref = torch.zeros(m, ld, device=DEV), ops.P3.empty(m, n, DEV)
+    dzp_ref.data.zero_()
+    dg_ref, db_ref, dbias_ref = (torch.zeros(n, device=DEV) for _ in range(3))
+    ws = torch.empty(int(lib.gte_ln_relu_bwd_workspace_bytes(m, n)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.gte_ln_relu_bwd_p3(P(dyb), ld, P(t), 2 * ld, P(stats), P(gam), P(bet), int(relu), P(dz_ref), ld, P(dzp_ref.data),
+                                      dzp_ref.ldp, P(dg_ref), P(db_ref), P(dbias_ref), m, n, P(ws), ws.numel(), _lib.current_stream()),
+               "gte_ln_relu_bwd_p3")
+    dzb, dzp = torch.zeros(m, ld, device=DEV), ops.P3.empty(m, n, DEV)
+    dzp.data.fill_(0x55)                                       # the fused launch must write every column block of the image itself
+    dg, db, dbias = (torch.full((n,), 7.0, device=DEV) for _ in range(3))
+    ops.gemm_p3_nt_ln_bwd(a1p, wp, a2p, z, stats, gam, bet, relu, dzb[:, :n], dzp, dg, db, dbias)
+    assert torch.equal(dzb, dz_ref)
+    assert torch.equal(dzp.data, dzp_ref.data)
+    assert float(dzb[:, n:].abs().sum()) == 0.0
+    for got, want in ((dg, dg_ref), (db, db_ref), (dbias, dbias_ref)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-6)
+
+
 @pytest.mark.parametrize("m,n,k,kin", [(24437, 256, 256, 13), (3000, 256, 256, 13), (129, 128, 64, 9), (1, 256, 256, 13), (40000, 256, 128, 14)])
 def test_nt_with_the_short_input_layers_backward_as_epilogue(m, n, k, kin):
     """gte_gemm_p3_nt_smallk_bwd against gte_gemm_p3_nt + gte_sage_smallk_bwd (same per-row arithmetic, csrc/smallk_step.h; the
