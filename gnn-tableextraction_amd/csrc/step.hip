@@ -126,8 +126,17 @@ int backward_a(const gte_step_plan& p, void* st) {
         GTE_TRY(gte_colsum(p.dl, lg, n, C, p.gb_out, p.ws_cs, p.ws_cs_bytes, st));
         GTE_TRY(gte_gemm_p3_tn(p.dlqp, p.ldp_dlq, static_cast<const char*>(p.dlqp) + 96, p.ldp_dlq, p.hp_out, p.ldp_hout, nullptr, 0,
                                p.out_fin, p.gW_out, 2 * p.out_fin, C, 2 * p.out_fin, n, p.ws_out, p.ws_out_bytes, st));
-        GTE_TRY(gte_gemm_p3_nt(p.dlqp, p.ldp_dlq, 32, nullptr, 0, 0, p.wimg_out_bwd, p.ldp_wout_bwd, nullptr, 0, p.dh_out, p.ld_h_out, n,
-                               p.out_fin, 0, 0, st));
+        if ((p.fuse_ln_dx & 1) && T.kind != GTE_LAYER_SMALLK && gte_gemm_p3_nt_ln_bwd_supported(p.out_fin) && T.dy == p.dh_out &&
+            (p.out_fin % 16 == 0 || ldf(T) >= ((p.out_fin + 3) & ~(int64_t)3))) {
+            // ... with the LayerNorm(+ReLU) backward of the last hidden layer as its epilogue (hidden widths up to 256)
+            GTE_TRY(gte_gemm_p3_nt_ln_bwd(p.dlqp, p.ldp_dlq, 32, nullptr, 0, 0, p.wimg_out_bwd, p.ldp_wout_bwd, z_of(T), ldz_of(T), T.stats,
+                                          T.gamma, T.beta, T.relu, T.dy, ldf(T), T.dzp, T.ldp_o, T.ggamma, T.gbeta, T.gbias, n, p.out_fin,
+                                          T.ws_ln, T.ws_ln_bytes, st));
+            ln_done = true;
+        } else {
+            GTE_TRY(gte_gemm_p3_nt(p.dlqp, p.ldp_dlq, 32, nullptr, 0, 0, p.wimg_out_bwd, p.ldp_wout_bwd, nullptr, 0, p.dh_out, p.ld_h_out, n,
+                                   p.out_fin, 0, 0, st));
+        }
     } else if ((p.fuse_ln_dx & 2) && T.kind == GTE_LAYER_PLANES && T.fout % 16 == 0 && gte_head_supported(p.out_fin, C)) {
         // the output layer's backward runs the LayerNorm(+ReLU) backward of the last hidden layer on the dh tile of every row block
         GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
