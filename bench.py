@@ -19,7 +19,7 @@ RCCL all-reduce of the flat gradient per step.  One JSON line is printed by rank
 Extra objects in the JSON line:
   roofline      dominant kernel (the forward transform GEMMs: planes GEMM on the bf16 matrix pipe by default), live HIP-event
                 timing of the same steps
-  long_run      the same loop for >= 1 s of device time, run BEFORE the W warm-up + K timed steps (the driver's 20-step
+  long_run      the same loop for >= 1 s of device time (after a few warm-up steps of its own), run BEFORE the W warm-up + K timed steps (the driver's 20-step
                 region is ~15 ms; measured right after an idle GPU woke up it reads ~7 % low: the chip has not reached its
                 sustained clocks -- a training run is at them)
   replay        secondary: HIP-graph replay of pre-captured resident batches (round 1's headline mode)
@@ -953,12 +953,18 @@ def main():
         ev.record()
         step_events.append((ev, g.num_nodes()))
 
+    epoch_diag = [] if os.environ.get("GTE_BENCH_LONG_DIAG") else None        # debug: (host time, device event) per run_steps call
+
     def run(epochs, counts):
         nodes, out3 = 0, None
         for plan, cnt in zip(epochs, counts):
             out3 = loop.run_steps(trainer, pipe, plan, n_global=cnt if distributed else None,
                                   on_step=_mark if step_events is not None else None)
             nodes += sum(pipe.nodes(i) for i in range(len(plan)))
+            if epoch_diag is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                epoch_diag.append((time.perf_counter(), ev, len(plan)))
         return nodes, out3
 
     def barrier():
@@ -999,6 +1005,12 @@ def main():
             nl = torch.tensor([n_long], dtype=torch.int64, device=dev)
             dist.all_reduce(nl, op=dist.ReduceOp.MAX)
             n_long = int(nl.item())
+        # (its own few warm-up steps: this is the first training activity of the process -- buffer sets, the plan, the first launch
+        # of every kernel; measured 0.28 s, which read as 37 M instead of 44 M nodes/s over a 1.4 s run)
+        pre_ep, ep = epoch_steps(sizes, args.pages, seed, ep, max(args.warmup, 4))
+        run(pre_ep, global_counts(pre_ep))
+        if epoch_diag is not None:
+            epoch_diag.clear()
         long_ep, ep = epoch_steps(sizes, args.pages, seed, ep, n_long)
         long_cnt = global_counts(long_ep)
         barrier()
@@ -1014,6 +1026,15 @@ def main():
             el_long, nodes_long = float(mx[0]), float(st[1])
         long_run = {"steps": n_long, "seconds": el_long, "ms_per_step": el_long / n_long * 1e3,
                     "value": nodes_long / el_long, "unit": "nodes/s"}
+        if epoch_diag:
+            hs = np.diff(np.array([h for h, _, _ in epoch_diag])) * 1e3
+            ds = np.array([epoch_diag[i][1].elapsed_time(epoch_diag[i + 1][1]) for i in range(len(epoch_diag) - 1)])
+            k = epoch_diag[0][2]
+            print(f"long run, per run_steps call of {k} steps: device ms median {np.median(ds):.2f} p90 {np.percentile(ds, 90):.2f} max "
+                  f"{ds.max():.2f} (calls above 1.3 x median: {int((ds > 1.3 * np.median(ds)).sum())} of {len(ds)}); host ms median "
+                  f"{np.median(hs):.2f} p90 {np.percentile(hs, 90):.2f} max {hs.max():.2f}; device ms by tenth of the run: "
+                  + " ".join(f"{c.mean():.2f}" for c in np.array_split(ds, 10)), file=sys.stderr)
+            epoch_diag.clear()
 
     run(warm, warm_cnt)
     barrier()
@@ -1122,7 +1143,7 @@ def main():
         if extras and not args.no_split_probe:
             line["gemm_modes"] = gemm_mode_probe(ops, run, alt, global_counts(alt), dev)
         line.update(pre)
-        line["order"] = ("gather / val_graph probes, long_run (>= 1 s of the same loop), THEN W warm-up + K timed steps = value, "
+        line["order"] = ("gather / val_graph probes, long_run (its own warm-up steps, then >= 1 s of the same loop), THEN W warm-up + K timed steps = value, "
                          "then kernel timers, replay, the other GEMM mode, inference, secondary, size_sweep, shapes, residency, cfg3, cpu_baseline")
         if extras and not args.no_inference:
             line["inference"] = inference_probe(args, gte, model, dev, pages, trainer)
