@@ -14,7 +14,7 @@ out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pa
                  "profiles/pmc_probe.py spmm (cfg4); bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of "
                  "the kernel family (FETCH_SIZE x2: gfx950 counts the 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md HBM "
                  "section); the counters sit on the L2's memory side, so Infinity-Cache hits are included.  Scripts: profiles/refresh.sh, "
-                 "pmc_traffic_summary.py, make_pmc_traffic.py", "round": 3}
+                 "pmc_traffic_summary.py, make_pmc_traffic.py", "round": 4}
 for tag, pred in (("gemm_nt", lambda k: "gemm_f32_mfma_kernel<true, true" in k), ("gemm_tn", lambda k: "gemm_f32_mfma_kernel<false, false" in k),
                   ("gemm_nn", lambda k: "gemm_f32_mfma_kernel<true, false" in k), ("batch_assemble", lambda k: "batch_assemble" in k),
                   ("spmm_csr", lambda k: k.startswith("spmm_csr_kernel"))):
@@ -26,8 +26,10 @@ if len(sys.argv) > 4:
         b, n = fam(split, lambda k, pat=pat: pat in k)
         out[f"{tag}_split_bytes_per_launch"], out[f"{tag}_split_launches_sampled"] = b, n
     # round 3: the default step multiplies P3 images (planes GEMMs, csrc/gemm_p3.hip)
-    # (the NT kernel whose last template argument is `true` is dX with the LayerNorm-backward epilogue: its own family)
-    lnb = lambda k: "gemm_p3_nt_lw_kernel" in k and k.rstrip().split("(")[0].endswith("true>")
+    # (dX with the LayerNorm-backward epilogue is its own family)
+    import re
+    # (the loader-wave NT kernel whose sixth template argument -- the epilogue -- is 1 or 3: LayerNorm backward)
+    lnb = lambda k: re.search(r"gemm_p3_nt_lw_kernel<\d+[,;] \d+[,;] \d+[,;] \d+[,;] \d+[,;] [13][,;>]", k) is not None
     for tag, pred in (("gemm_nt", lambda k: "gemm_p3_nt" in k and not lnb(k)), ("gemm_tn", lambda k: "gemm_p3_tn" in k),
                       ("gemm_nt_ln_bwd", lnb)):
         b, n = fam(split, pred)
