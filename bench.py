@@ -775,7 +775,7 @@ def gather_probe(args, gte, S, dev):
     plan = ops.build_tile_plan(indptr, indices, n)          # graph structure, built once per graph
 
     def timed(tiles):
-        for _ in range(3):
+        for _ in range(12):            # (enough launches for the sustained clocks: the probe is the process's first GPU work)
             ops.spmm_csr(indptr, indices, wout, x, n, mean=True, out=out, tiles=tiles, force_tiled=tiles is not None)
         torch.cuda.synchronize()
         reps = 10
@@ -795,13 +795,15 @@ def gather_probe(args, gte, S, dev):
     w_bwd = torch.from_numpy(w).to(dev) * ops.inv_degree(indptr)[dst_t.long()]
     r_indptr, r_indices, _, r_w = ops.coo_to_csr(src_t, dst_t, n, w_bwd)
     r_plan = ops.build_tile_plan(r_indptr, r_indices, n)
+    # (building the reverse CSR and its tile plan left the GPU idle for a few hundred ms: the first launches after that run at
+    # lower clocks -- 1040 us against 850 us once warm, profiles/debug/gather_timing_methods.py; 20 warm-up launches ~ 18 ms)
     bwd_evs = []
-    for i in range(13):
+    for i in range(30):
         s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s_.record()
         ops.spmm_csr(r_indptr, r_indices, r_w, x, n, mean=False, out=out, tiles=r_plan, force_tiled=True)
         e_.record()
-        if i >= 3:
+        if i >= 20:
             bwd_evs.append((s_, e_))
     torch.cuda.synchronize()
     bwd_ms = float(np.mean([s_.elapsed_time(e_) for s_, e_ in bwd_evs]))
