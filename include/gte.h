@@ -349,7 +349,9 @@ int gte_gemm_p3_nt_rows(const void* a_res, int64_t ldpa, int64_t k, const int32_
  * block of rows runs the LayerNorm(+ReLU) backward of those rows on it (models.py:64-66 autograd of the layer below): dz as fp32
  * and as a P3 image (dzp3 nullable), column sums dgamma / dbeta / dbias (nullable) into the fold deferral.  z / stats / gamma /
  * beta as gte_ln_relu_bwd.  Replaces gte_gemm_p3_nt + gte_ln_relu_bwd_p3 (one launch, 2 m n 4 bytes of traffic less); dz is
- * bit-identical to theirs. */
+ * bit-identical to theirs.  Any n in 1 .. 256; n % 4 != 0 needs the rows of z and dz padded to a multiple of 4 floats (ldz,
+ * lddz >= that, padding of dz written as zeros), and whenever n % 16 != 0 the image's columns up to the next multiple of 16 are
+ * written as zeros. */
 int gte_gemm_p3_nt_ln_bwd_supported(int64_t n);
 int64_t gte_gemm_p3_nt_ln_bwd_workspace_bytes(int64_t m, int64_t n);
 int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t ldpa1, int64_t k1, const void* a2, int64_t ldpa2, int64_t k2, const void* b,
