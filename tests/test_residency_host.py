@@ -1,0 +1,106 @@
+"""Host logic of the windowed residency (models/residency.py): page ownership, window layout, the step stream.  Pure index
+arithmetic -- every rank computes every rank's stream without communication, so it has to be deterministic and exact."""
+import numpy as np
+import pytest
+
+from gnn_tableextraction_amd.models import residency as R
+
+
+def test_page_owner_deals_pages_evenly_and_reproducibly():
+    for n, w in ((1000, 8), (7, 2), (5, 8), (64, 1)):
+        o = R.page_owner(n, w, seed=3)
+        assert o.shape == (n,) and o.min() >= 0 and o.max() < w
+        counts = np.bincount(o, minlength=w)
+        assert counts.max() - counts.min() <= 1                     # round-robin over a shuffle
+        np.testing.assert_array_equal(o, R.page_owner(n, w, seed=3))
+    assert not np.array_equal(R.page_owner(1000, 8, seed=3), R.page_owner(1000, 8, seed=4))
+
+
+def test_window_ranges_partition_the_pages_within_the_slot():
+    rng = np.random.default_rng(0)
+    nodes = rng.integers(20, 2000, 500)
+    per_node = 5000.0
+    slot = 40 * 2000 * per_node
+    rs = R.window_ranges(nodes, per_node, slot)
+    assert rs[0][0] == 0 and rs[-1][1] == len(nodes)
+    for (a0, a1), (b0, b1) in zip(rs, rs[1:]):
+        assert a1 == b0 and a0 < a1
+    cap = int(slot // per_node)
+    for p0, p1 in rs:
+        assert nodes[p0:p1].sum() <= cap
+    for (p0, p1) in rs[:-1]:                                         # greedy: the next page would not have fitted
+        assert nodes[p0:p1].sum() + nodes[p1] > cap
+    bounded = R.window_ranges(nodes, per_node, slot, max_nodes=10_000)   # the row-map bound is the tighter one
+    assert all(nodes[p0:p1].sum() <= 10_000 for p0, p1 in bounded) and len(bounded) > len(rs)
+    with pytest.raises(ValueError):
+        R.window_ranges(np.array([50, 5000, 50]), per_node, 1000 * per_node)
+
+
+def test_layout_is_the_same_arithmetic_for_every_caller():
+    rng = np.random.default_rng(1)
+    nodes, edges = rng.integers(20, 2000, 300), rng.integers(100, 12000, 300)
+    a = R.WindowedPages.layout(nodes, edges, 831, 2e9, True)
+    b = R.WindowedPages.layout(nodes.copy(), edges.copy(), 831, 2e9, True)
+    assert a == b and a[0][0] == 0 and a[-1][1] == 300
+    per = R.WindowedPages.bytes_per_node(nodes, edges, 831, True)
+    assert per > 96 * 52                                              # the image row alone
+    assert R.WindowedPages.bytes_per_node(nodes, edges, 831, False) < per      # fp32 rows are smaller than the image
+    assert len(R.WindowedPages.layout(nodes, edges, 831, 1e9, True)) > len(a)   # half the budget: more windows
+
+
+def _stream(ranges, B=10, passes=3, seed=7, rank=0):
+    return R.WindowStream(ranges, B, passes, seed, rank)
+
+
+def test_window_stream_steps_are_batches_of_distinct_pages_of_one_window():
+    ranges = [(0, 95), (95, 140), (140, 260)]
+    s = _stream(ranges)
+    chunks = s.take(200)
+    assert sum(len(steps) for _, steps in chunks) == 200
+    for w, steps in chunks:
+        p0, p1 = ranges[w]
+        for ids in steps:
+            assert ids.shape == (10,) and len(np.unique(ids)) == 10 and ids.min() >= 0 and ids.max() < p1 - p0
+            assert np.all(np.diff(ids) > 0)                           # sorted: the resident rows of a batch ascend
+    # consecutive chunks name different windows (a chunk is one visit, or the part of it this call covers)
+    assert all(a[0] != b[0] for a, b in zip(chunks, chunks[1:]))
+
+
+def test_window_stream_visits_every_page_passes_times_per_visit():
+    ranges = [(0, 95), (95, 140), (140, 260)]
+    s = _stream(ranges, B=10, passes=3)
+    per_visit = {0: 9 * 3, 1: 4 * 3, 2: 12 * 3}                      # (pages // B) steps per pass, three passes
+    seen = {}
+    for w, steps in s.take(sum(per_visit.values())):                 # exactly one sweep over the three windows
+        assert len(steps) == per_visit[w]
+        cnt = np.bincount(np.concatenate(steps), minlength=ranges[w][1] - ranges[w][0])
+        assert cnt.max() <= 3 and cnt.sum() == 10 * per_visit[w]      # a page at most once per pass; the pass's tail is dropped
+        seen[w] = True
+    assert set(seen) == {0, 1, 2}
+
+
+def test_window_stream_is_deterministic_and_independent_of_how_it_is_consumed():
+    ranges = [(0, 95), (95, 140), (140, 260), (260, 265)]            # (the last window holds fewer pages than a batch: skipped)
+    flat = lambda chunks: [(w, tuple(ids)) for w, steps in chunks for ids in steps]
+    a = flat(_stream(ranges).take(150))
+    s2 = _stream(ranges)
+    b = flat(s2.take(37)) + flat(s2.take(1)) + flat(s2.take(112))
+    assert a == b
+    assert all(w != 3 for w, _ in a)
+    assert a != flat(_stream(ranges, rank=1).take(150))               # another rank draws another order
+    assert a != flat(_stream(ranges, seed=8).take(150))
+
+
+def test_window_stream_names_the_window_to_upload_next():
+    ranges = [(0, 50), (50, 100), (100, 150)]
+    s = _stream(ranges, B=10, passes=2)
+    for _ in range(12):
+        cur, nxt = s.peek_window(), s.next_window()
+        chunk = s.take(10)                                           # one visit: 5 steps per pass, two passes
+        assert len(chunk) == 1 and chunk[0][0] == cur
+        assert s.peek_window() == nxt                                 # what was announced is what comes
+
+
+def test_window_stream_refuses_a_batch_no_window_can_hold():
+    with pytest.raises(ValueError):
+        R.WindowStream([(0, 5), (5, 9)], 10, 2, 0)
