@@ -95,6 +95,9 @@ __device__ __forceinline__ float group_sum(float v) { return gte_group_sum<G>(v)
 // MASK, LNE kernels: the LayerNorm width ln.n_true is smaller than the n_feat columns processed (padded rows): per-element masks.
 // Without it the epilogue is the round-3 code, instruction for instruction (24.5 us at 24 k x 256; the masks cost 6 us there).
 // MASK, P3-output kernels: n_feat is not a multiple of 16 (tail elements collected by lane 0, zero quarter blocks).
+#ifndef GTE_SPMM_NO_PREFETCH
+#define GTE_SPMM_NO_PREFETCH 0     // measurement build: 1 = the self term loaded behind the edge loop (round 3's order)
+#endif
 template <typename T, int G, int CPL, bool ACCUM, bool LNE = false, bool MASK = false>
 __global__ void __launch_bounds__(256)
 spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
@@ -144,6 +147,19 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
             float tail = 0.f;
             const bool do_tail = (cb == 0) && (li < rem);
             const int64_t tail_off = (int64_t)nchunk * EPC + li;
+            // ACCUM: the row's own chunks of `out` (the self term of a transform-first layer) are requested HERE, in front of the
+            // edge loop -- they depend on nothing, and behind the loop they were one more memory round trip on the row's chain
+            float opre[ACCUM ? CPL : 1][EPC];
+            if constexpr (ACCUM && !GTE_SPMM_NO_PREFETCH) {
+                if (row_ok) {
+                    const elem* orow_c = out + (int64_t)r * ldo;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const int c = cb + li + j * G;
+                        if (c < nchunk) T::load(orow_c + (int64_t)c * EPC, opre[j]);
+                    }
+                }
+            }
 
             for (int eb = lo; eb < hi; eb += G) {
                 const int my_e = eb + li;
@@ -216,7 +232,11 @@ spmm_csr_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ 
                     if (c < nchunk) {
                         float o[EPC];
                         if constexpr (ACCUM) {
-                            T::load(orow + (int64_t)c * EPC, o);
+                            if constexpr (GTE_SPMM_NO_PREFETCH) T::load(orow + (int64_t)c * EPC, o);
+                            else {
+#pragma unroll
+                                for (int q = 0; q < EPC; ++q) o[q] = opre[j][q];
+                            }
 #pragma unroll
                             for (int q = 0; q < EPC; ++q) o[q] += acc[j][q] * scale;
                             if constexpr (LNE && MASK) {     // columns past the LayerNorm width are padding: zero
