@@ -221,7 +221,8 @@ def shape_inputs(seed, n, f0, bbox_like=False):
 SHAPE_CASES = [("shape_f13_h218", 21, 640, 13, 218, True), ("shape_f363_h149", 22, 512, 363, 149, False),
                ("shape_f363_h139", 23, 384, 363, 139, False), ("shape_f63_h1000", 24, 400, 63, 1000, False),
                ("shape_f831_h96", 25, 512, 831, 96, False), ("shape_f831_h1000", 26, 320, 831, 1000, False),
-               ("shape_f13_h1000", 27, 320, 13, 1000, True), ("shape_f781_h100", 28, 384, 781, 100, False)]
+               ("shape_f13_h1000", 27, 320, 13, 1000, True), ("shape_f781_h100", 28, 384, 781, 100, False),
+               ("shape_f63_h206", 29, 448, 63, 206, False), ("shape_f313_h157", 30, 448, 313, 157, False)]
 
 
 def run_shape_case(ref, name, seed, n, f0, hid, bbox_like=False):
@@ -293,9 +294,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "headline":      # only the trimmed headline-shape case
         run_headline_case(ref)
         return
-    if len(sys.argv) > 1 and sys.argv[1] == "shapes":        # only the reference's run shapes (trimmed)
+    if len(sys.argv) > 1 and sys.argv[1] == "shapes":        # only the reference's run shapes (trimmed); names: only those
         for c in SHAPE_CASES:
-            run_shape_case(ref, *c)
+            if len(sys.argv) == 2 or c[0] in sys.argv[2:]:
+                run_shape_case(ref, *c)
         return
     for c in SHAPE_CASES:
         run_shape_case(ref, *c)

@@ -142,3 +142,5 @@ def test_reference_run_shapes_match_reference(name):
 
 def test_shape_cases_cover_the_reference_grid():
     assert {"shape_f13_h218", "shape_f363_h149", "shape_f63_h1000", "shape_f831_h96", "shape_f831_h1000"} <= set(SHAPE_CASES)
+    # every scaled width of run_multiple_train.sh (int(calculate_hidden) for F0 = 13 / 63 / 313 / 363 / 781 / 831)
+    assert {"shape_f13_h218", "shape_f63_h206", "shape_f313_h157", "shape_f363_h149", "shape_f781_h100", "shape_f831_h96"} <= set(SHAPE_CASES)
