@@ -419,7 +419,8 @@ def secondary_probe(args, gte, S, dev, pages13):
 # The reference's OWN run shapes (run_multiple_train.sh:8-113 of the reference with model_train.py:81-91,157 and
 # components/features/utils.py:90-101): --h_layer_dim=1000, or --mode_params=scaled --params_no=100000 -> int(calculate_hidden).
 # (363, 139) is the pair the round-3 review named; the grid's own pair for F0 = 363 is (363, 149).
-RUN_SHAPES = [(831, 1000), (13, 1000), (13, 218), (363, 149), (363, 139), (831, 96)]
+RUN_SHAPES = [(831, 1000), (13, 1000), (13, 218), (363, 149), (363, 139), (831, 96), (781, 100), (313, 157), (63, 206)]
+SLICED_FROM = {781: 831, 313: 363, 63: 363}      # page sets of these input widths = the leading columns of a generated set
 
 
 def _c16(x):
@@ -471,6 +472,9 @@ def shapes_probe(args, gte, dev, page_sets, loop):
     cache = {}
     for f0, hid in RUN_SHAPES:
         pages = page_sets.get(f0)
+        if pages is None and page_sets.get(SLICED_FROM.get(f0)) is not None:
+            import dataclasses
+            pages = [dataclasses.replace(p, feat=np.ascontiguousarray(p.feat[:, :f0])) for p in page_sets[SLICED_FROM[f0]]]
         if pages is None:
             continue
         key = f0

@@ -5,7 +5,7 @@
 # train loop alone).  Every command is bounded by `timeout`.
 set -u
 TAG=${1:-x}
-SHAPES=${2:-"831:1000 13:1000 13:218 363:149 363:139 831:96"}
+SHAPES=${2:-"831:1000 13:1000 13:218 363:149 363:139 831:96 781:100 313:157 63:206"}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
