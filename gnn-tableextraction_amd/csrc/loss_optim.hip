@@ -9,6 +9,7 @@
 // is deterministic: per-block partial sums in a fixed order, one reducing block, no atomics.
 #include "gte_common.h"
 #include "ce_fold.h"
+#include "p3.h"
 
 #include <stdint.h>
 
@@ -237,6 +238,85 @@ extern "C" int gte_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_t n
     if (!gte::defer_fold(part, n_cols, nb, 1, (int)n_cols, out, n_cols))
         hipLaunchKernelGGL(colsum_fold_small_kernel, dim3(1), dim3(64), 0, s, part, nb, (int)n_cols, out);
     return gte::check_launch("colsum");
+}
+
+// ---- the second half of the fused head on the GEMM output path ---------------------------------------------------------------
+// gte_head_agg_ce leaves dl WITHOUT the 1 / sum(w) of the weighted cross-entropy (and q = A_w^T (norm dl) inherits that).  One
+// launch: every block folds the CE partials for itself (fixed order: the same alpha everywhere), block 0 publishes out3; a thread
+// per node writes alpha [dl | q] as ONE P3 image [n][32] (the operand of the dW / dh GEMMs of the output layer) and the block adds
+// up alpha dl by columns (the bias gradient; block partials folded in order).  Replaces the loss-gradient launch, the image
+// conversion and the column-sum launch of the unfused path.
+namespace {
+constexpr int DLQ_ROWS = 256;
+__global__ void __launch_bounds__(DLQ_ROWS)
+head_dlq_finish_kernel(const float* __restrict__ dlq, long long ld, int n, int C, const float* __restrict__ ce_partial, long long ce_blocks,
+                       float grad_scale, float* __restrict__ out3, char* __restrict__ dlqp, long long ldp, float* __restrict__ bias_part) {
+    __shared__ double ce_red[3][kCeBlock];
+    static_assert(kCeBlock == DLQ_ROWS, "one fold per block");
+    ce_fold(ce_partial, ce_blocks, ce_red);
+    const float wsum = (float)ce_red[1][0];
+    const float alpha = wsum > 0.f ? grad_scale / wsum : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && out3) ce_write_out3(ce_red, out3);
+    const int row = blockIdx.x * DLQ_ROWS + threadIdx.x;
+    float v[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = 0.f;
+    if (row < n) {
+        const float4* src = reinterpret_cast<const float4*>(dlq + (long long)row * ld);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 t = src[k];
+            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v[c] = (c & 15) < C ? v[c] * alpha : 0.f;      // (columns C .. 15 of a half are not data)
+        char* img = dlqp + (long long)row * ldp;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p3::store4(img, 4 * k, v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    }
+    // column sums of alpha dl over the block's rows: waves by shuffles, the four waves in order
+    __shared__ float cs[4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float s_ = gte_group_sum<64>(v[c]);
+        if (lane == 0) cs[wave][c] = s_;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) bias_part[(long long)blockIdx.x * 16 + threadIdx.x] = (cs[0][threadIdx.x] + cs[1][threadIdx.x]) + (cs[2][threadIdx.x] + cs[3][threadIdx.x]);
+}
+__global__ void __launch_bounds__(64)
+head_bias_fold_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out) {
+    if ((int)threadIdx.x >= C) return;
+    float s_ = 0.f;
+    for (int k = 0; k < nb; ++k) s_ += part[(long long)k * 16 + threadIdx.x];
+    out[threadIdx.x] = s_;
+}
+}  // namespace
+
+extern "C" int64_t gte_head_dlq_finish_workspace_bytes(int64_t n_nodes) {
+    return gte::round_up(gte::ceil_div(n_nodes > 0 ? n_nodes : 1, DLQ_ROWS) * 16 * 4, 256);
+}
+
+extern "C" int gte_head_dlq_finish(const float* dlq, int64_t lddlq, int64_t n_nodes, int64_t n_classes, const void* ce_partial,
+                                   float grad_scale, float* out3, void* dlqp3, int64_t ldp, float* gbias, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    if (n_nodes <= 0 || n_nodes > INT32_MAX || n_classes < 1 || n_classes > 16)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "head_dlq_finish: needs 1 <= n_classes <= 16 and n_nodes >= 1");
+    if (!dlq || !ce_partial || !out3 || !dlqp3 || !gbias || !workspace) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "head_dlq_finish: null pointer");
+    if (lddlq < 32 || lddlq % 4 != 0 || (reinterpret_cast<uintptr_t>(dlq) & 15) != 0 || ldp < 192 || ldp % 16 != 0)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "head_dlq_finish: dlq is [n][>= 32] floats, 16-byte aligned rows; the image two blocks wide");
+    if (workspace_bytes < gte_head_dlq_finish_workspace_bytes(n_nodes))
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "head_dlq_finish: workspace too small");
+    hipStream_t s = gte::as_stream(stream);
+    const int nb = (int)gte::ceil_div(n_nodes, DLQ_ROWS);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(head_dlq_finish_kernel, dim3((unsigned)nb), dim3(DLQ_ROWS), 0, s, dlq, (long long)lddlq, (int)n_nodes, (int)n_classes,
+                       reinterpret_cast<const float*>(ce_partial), (long long)gte::ceil_div(n_nodes, 64), grad_scale, out3,
+                       reinterpret_cast<char*>(dlqp3), (long long)ldp, part);
+    if (!gte::defer_fold(part, 16, nb, 1, (int)n_classes, gbias, n_classes))
+        hipLaunchKernelGGL(head_bias_fold_kernel, dim3(1), dim3(64), 0, s, part, nb, (int)n_classes, gbias);
+    return gte::check_launch("head_dlq_finish");
 }
 
 extern "C" int gte_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

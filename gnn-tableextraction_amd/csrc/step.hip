@@ -19,6 +19,14 @@ namespace {
 inline int64_t ldf(const gte_step_layer& L) { return L.ldf > 0 ? L.ldf : L.fout; }
 inline int64_t ld_lg(const gte_step_plan& p) { return p.ld_lg > 0 ? p.ld_lg : p.n_classes; }
 
+// the GEMM output layer with the fused head: aggregation + loss in one launch (dl without 1 / sum w), the scaling, the [dl | q]
+// image, the bias gradient and out3 in another (gte_head_agg_ce + gte_head_dlq_finish)
+bool head_gemm_fused(const gte_step_plan& p) {
+    return p.out_gemm && (p.fuse_ln_dx & 4) && p.n_classes <= 16 && ld_lg(p) >= 32 && p.n_nodes > 0 &&
+           p.ws_ce_bytes >= gte_head_agg_ce_workspace_bytes(p.n_nodes) && p.ws_cs_bytes >= gte_head_dlq_finish_workspace_bytes(p.n_nodes);
+}
+
+
 // weight images + the hidden layers (the output layer's input is p.h_out / p.hp_out afterwards).  fwd_only: nothing is kept for a
 // backward -- a planes layer whose output is consumed as an image (by the next planes layer, or by the output layer's GEMM) does
 // not write its fp32 rows (a sixth of the aggregation + LayerNorm kernel's bytes)
@@ -91,6 +99,9 @@ int forward(const gte_step_plan& p, void* st) {
     const int64_t C = p.n_classes, lg = ld_lg(p);
     GTE_TRY(forward_out_products(p, st));
     if (p.out_gemm) {
+        if (head_gemm_fused(p))
+            return gte_head_agg_ce(p.indptr, p.indices, p.w_in, p.tn, lg, p.logits, lg, p.labels, p.labels_f32, p.class_weights, n, C,
+                                   GTE_REDUCE_MEAN, p.dl, lg, p.ws_ce, p.ws_ce_bytes, st);
         GTE_TRY(gte_spmm_csr_accumulate(p.indptr, p.indices, p.w_in, p.tn, lg, p.logits, lg, n, C, GTE_F32, GTE_REDUCE_MEAN, st));
         return gte_weighted_ce(p.logits, lg, p.labels, p.labels_f32, p.class_weights, n, (int)C, p.grad_scale, p.dl, lg, p.out3, p.ws_ce,
                                p.ws_ce_bytes, st);
@@ -122,8 +133,12 @@ int backward_a(const gte_step_plan& p, void* st) {
         // q = A_w^T (norm dl); dl and q as ONE image [n][32] (dl in block 0, q in block 1); dW_out = [dl^T h | q^T h] (two column
         // segments of one TN launch, M = n_classes), dbias = colsum(dl), dh = [dl | q] [W_s^T | W_n^T] (K = 32)
         GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, lg, p.q_out, lg, n, C, GTE_F32, GTE_REDUCE_SUM, st));
-        GTE_TRY(gte_p3_from_f32(p.dl, lg, n, 32, 0, p.dlqp, p.ldp_dlq, st));
-        GTE_TRY(gte_colsum(p.dl, lg, n, C, p.gb_out, p.ws_cs, p.ws_cs_bytes, st));
+        if (head_gemm_fused(p)) {
+            GTE_TRY(gte_head_dlq_finish(p.dl, lg, n, C, p.ws_ce, p.grad_scale, p.out3, p.dlqp, p.ldp_dlq, p.gb_out, p.ws_cs, p.ws_cs_bytes, st));
+        } else {
+            GTE_TRY(gte_p3_from_f32(p.dl, lg, n, 32, 0, p.dlqp, p.ldp_dlq, st));
+            GTE_TRY(gte_colsum(p.dl, lg, n, C, p.gb_out, p.ws_cs, p.ws_cs_bytes, st));
+        }
         GTE_TRY(gte_gemm_p3_tn(p.dlqp, p.ldp_dlq, static_cast<const char*>(p.dlqp) + 96, p.ldp_dlq, p.hp_out, p.ldp_hout, nullptr, 0,
                                p.out_fin, p.gW_out, 2 * p.out_fin, C, 2 * p.out_fin, n, p.ws_out, p.ws_out_bytes, st));
         if ((p.fuse_ln_dx & 1) && T.kind != GTE_LAYER_SMALLK && gte_gemm_p3_nt_ln_bwd_supported(p.out_fin) && T.dy == p.dh_out &&

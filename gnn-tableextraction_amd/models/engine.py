@@ -164,6 +164,7 @@ class FusedGcnSageStep(TrainStep):
         self._fuse_adam_req, self._adam_fused = False, False
         self.adam_fused_steps = 0                     # steps whose optimiser update ran inside the fold launch
         self.fused_head = os.environ.get("GTE_FUSED_HEAD", "1") == "1"
+        self.fuse_head_gemm = os.environ.get("GTE_FUSE_HEAD_GEMM", "1") == "1"     # (general plans: the fused head on the GEMM output path)
         # dX of a planes layer with the LayerNorm(+ReLU) backward of the planes layer below as its epilogue (gte_gemm_p3_nt_ln_bwd)
         self.fuse_ln_dx = os.environ.get("GTE_FUSE_LN_DX", "1") == "1"
         # ... and of the last hidden layer inside the output layer's backward (gte_sage_narrow_bwd_ln_p3)
@@ -308,8 +309,8 @@ class FusedGcnSageStep(TrainStep):
             b["t_out"], b["dlq"] = z32(cap, 32), z32(cap, 32)      # [logits .. | t_neigh ..], [dl .. | q ..]
             b["dlqp"] = img(cap + 8, 32)
             b["ws_out"] = u8(lib.gte_gemm_p3_tn_workspace_bytes(C, 2 * dims[-2], dims[-2], cap))
-            b["ws_ce"] = u8(lib.gte_weighted_ce_workspace_bytes(cap))
-            b["ws_cs"] = u8(lib.gte_colsum_workspace_bytes(cap, C))
+            b["ws_ce"] = u8(max(lib.gte_weighted_ce_workspace_bytes(cap), lib.gte_head_agg_ce_workspace_bytes(cap)))
+            b["ws_cs"] = u8(max(lib.gte_colsum_workspace_bytes(cap, C), lib.gte_head_dlq_finish_workspace_bytes(cap)))
         else:
             b["logits"], b["tn"], b["q"], b["dl"] = z32(cap, C), z32(cap, C), z32(cap, C), z32(cap, C)
             b["ce_part"] = u8(lib.gte_head_agg_ce_workspace_bytes(cap))
@@ -701,7 +702,8 @@ class FusedGcnSageStep(TrainStep):
         plan, _arr, fused = cached
         # per call: switches and class weights (public attributes), the graph, the features
         plan.class_weights = P(self.class_weights)
-        plan.fuse_ln_dx = (int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (8 if self.fuse_smallk_dx else 0))
+        plan.fuse_ln_dx = (int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (8 if self.fuse_smallk_dx else 0)
+                           | (4 if self.fuse_head_gemm else 0))
         L0 = plan.layer[0]
         if kinds[0] == 0:
             if xp is not None:

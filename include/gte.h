@@ -379,6 +379,16 @@ int gte_gemm_p3_tn(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, c
 int gte_gemm_p3_tn_rows(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, const void* b_res, int64_t ldpb,
                         const int32_t* b_rows, int64_t n_res_rows, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n,
                         int64_t k, void* workspace, int64_t workspace_bytes, void* stream);
+/* Second half of the fused head (gte_head_agg_ce) when the output layer's products run on the planes GEMMs: dlq [n][>= 32] holds
+ * dl in columns 0 .. C-1 and q = A_w^T (norm dl) in columns 16 .. 16 + C-1, both WITHOUT the 1 / sum(w) of the weighted
+ * cross-entropy (model_train.py:171,327).  One launch folds the CE partials of gte_head_agg_ce (ce_partial), publishes out3 =
+ * {loss, sum w, #correct}, writes alpha [dl | q], alpha = grad_scale / sum w, as ONE P3 image [n][32] (the operand of the layer's
+ * dW / dh GEMMs) and gbias [C] = column sums of alpha dl (block partials in `workspace`, folded in order -- inside an open fold
+ * deferral by gte_fold_defer_flush). */
+int64_t gte_head_dlq_finish_workspace_bytes(int64_t n_nodes);
+int gte_head_dlq_finish(const float* dlq, int64_t lddlq, int64_t n_nodes, int64_t n_classes, const void* ce_partial,
+                        float grad_scale, float* out3, void* dlqp3, int64_t ldp, float* gbias, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 /* Row maps: 0 = 64-bit addresses for resident images of 4 GB or more only (default), 1 = always (tests, A/B timing; the
  * zero-row requirement of gte_gemm_p3_tn_rows then holds for every image). */
 int gte_gemm_p3_set_rows64(int mode);
@@ -451,6 +461,7 @@ typedef struct gte_step_plan {
     void* tail_ws; int64_t tail_ws_bytes;
     int fuse_ln_dx;                        /* bit 0: dX of a PLANES layer above a PLANES layer runs gte_gemm_p3_nt_ln_bwd;
                                               bit 1: the output layer's backward runs gte_sage_narrow_bwd_ln_p3;
+                                              bit 2: the GEMM output layer (out_gemm) runs gte_head_agg_ce + gte_head_dlq_finish;
                                               bit 3: dX of layer 1 above a SMALLK layer 0 runs gte_gemm_p3_nt_smallk_bwd      */
     int wimg_fresh;                        /* the weight images already hold the current parameters: the forward skips their
                                               conversion launch (set by the caller after a step that returned *adam_fused & 2) */

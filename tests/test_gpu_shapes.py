@@ -322,6 +322,43 @@ def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages):
     assert np.abs(after - ref_after).max() < 1e-4
 
 
+@pytest.mark.parametrize("n,C", [(24437, 9), (300, 16), (1, 3), (257, 9)])
+def test_head_dlq_finish_scales_images_and_sums(n, C):
+    """gte_head_dlq_finish: out3 from the CE partials, alpha [dl | q] as one image [n][32], gbias = colsum(alpha dl) -- against the
+    same quantities computed with torch from the unscaled inputs; inside and outside a fold deferral."""
+    lib, P, st = _lib.load(), _lib.ptr, _lib.current_stream()
+    g = torch.Generator(device=DEV).manual_seed(n + C)
+    dlq = torch.full((n, 32), 3e30, device=DEV)                       # columns C .. 15 / 16 + C .. 31 hold no data
+    dlq[:, :C] = torch.randn(n, C, device=DEV, generator=g)
+    dlq[:, 16:16 + C] = torch.randn(n, C, device=DEV, generator=g)
+    nb = -(-n // 64)
+    part = torch.rand(nb, 3, device=DEV, generator=g) + 0.5           # {sum w nll, sum w, #correct} per 64-node block
+    wsum = float(part[:, 1].double().sum())
+    grad_scale = 0.37
+    alpha = grad_scale / wsum
+    want = torch.zeros(n, 32, device=DEV)
+    want[:, :C] = dlq[:, :C] * np.float32(alpha)
+    want[:, 16:16 + C] = dlq[:, 16:16 + C] * np.float32(alpha)
+    ws = torch.empty(int(lib.gte_head_dlq_finish_workspace_bytes(n)), dtype=torch.uint8, device=DEV)
+    for deferred in (False, True):
+        img = ops.P3.empty(n, 32, DEV)
+        img.data.fill_(0x55)
+        out3, gb = torch.full((3,), 7.0, device=DEV), torch.full((C,), 7.0, device=DEV)
+        if deferred:
+            _lib.check(lib.gte_fold_defer_begin(st), "begin")
+        _lib.check(lib.gte_head_dlq_finish(P(dlq), 32, n, C, P(part), grad_scale, P(out3), P(img.data), img.ldp, P(gb), P(ws), ws.numel(), st),
+                   "gte_head_dlq_finish")
+        if deferred:
+            _lib.check(lib.gte_fold_defer_flush(), "flush")
+        got = ops.p3_to_f32(img)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=3e-7, atol=0)     # (alpha in fp32 on both sides)
+        np.testing.assert_allclose(out3.cpu().numpy(), [float(part[:, 0].double().sum()) / wsum, wsum, float(part[:, 2].double().sum())],
+                                   rtol=1e-6)
+        np.testing.assert_allclose(gb.double().cpu().numpy(), want[:, :C].double().sum(0).cpu().numpy(), rtol=1e-5,
+                                   atol=1e-6 * float(want[:, :C].abs().sum(0).max()) + 1e-12)
+    assert lib.gte_head_dlq_finish(P(dlq), 32, n, 17, P(part), grad_scale, P(out3), P(img.data), img.ldp, P(gb), P(ws), ws.numel(), st) == -1
+
+
 # ---------------------------------------------------------------- edge-parallel aggregation (hub rows)
 def _hub_graph(rng, n, hubs, hub_deg, base_deg=5):
     src = [rng.integers(0, n, n * base_deg)]
