@@ -110,8 +110,8 @@ SIGNATURES = {
                                     c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gte_gemm_p3_set_rows64": (c_int, [c_int]),
     "gte_head_dlq_finish_workspace_bytes": (c_int64, [c_int64]),
-    "gte_head_dlq_finish": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p,
-                                    c_void_p, c_int64, c_void_p]),
+    "gte_head_dlq_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_float, c_void_p,
+                                    c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_gemm_p3_tn_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
     "gte_gemm_p3_tn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),

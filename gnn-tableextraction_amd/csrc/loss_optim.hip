@@ -244,13 +244,15 @@ extern "C" int gte_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_t n
 // gte_head_agg_ce leaves dl WITHOUT the 1 / sum(w) of the weighted cross-entropy (and q = A_w^T (norm dl) inherits that).  One
 // launch: every block folds the CE partials for itself (fixed order: the same alpha everywhere), block 0 publishes out3; a thread
 // per node writes alpha [dl | q] as ONE P3 image [n][32] (the operand of the dW / dh GEMMs of the output layer) and the block adds
-// up alpha dl by columns (the bias gradient; block partials folded in order).  Replaces the loss-gradient launch, the image
-// conversion and the column-sum launch of the unfused path.
+// up alpha dl by columns (the bias gradient; block partials folded in order).  With the out-edge CSR (rindptr != NULL) the thread
+// also forms its node's q = A_w^T (norm dl) itself from the dl rows of its out-neighbours (the q columns of dlq are not read).
+// Replaces the loss-gradient launch, the 9-wide transpose aggregation, the image conversion and the column-sum launch.
 namespace {
 constexpr int DLQ_ROWS = 256;
 __global__ void __launch_bounds__(DLQ_ROWS)
 head_dlq_finish_kernel(const float* __restrict__ dlq, long long ld, int n, int C, const float* __restrict__ ce_partial, long long ce_blocks,
-                       float grad_scale, float* __restrict__ out3, char* __restrict__ dlqp, long long ldp, float* __restrict__ bias_part) {
+                       float grad_scale, float* __restrict__ out3, char* __restrict__ dlqp, long long ldp, float* __restrict__ bias_part,
+                       const int32_t* __restrict__ rindptr, const int32_t* __restrict__ rindices, const float* __restrict__ w_out) {
     __shared__ double ce_red[3][kCeBlock];
     static_assert(kCeBlock == DLQ_ROWS, "one fold per block");
     ce_fold(ce_partial, ce_blocks, ce_red);
@@ -267,6 +269,25 @@ head_dlq_finish_kernel(const float* __restrict__ dlq, long long ld, int n, int C
         for (int k = 0; k < 8; ++k) {
             const float4 t = src[k];
             v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+        }
+        if (rindptr) {
+            // q = A_w^T (norm dl) of this node, here instead of by a 9-wide aggregation launch: the row's out-edges in CSR order,
+            // fmaf(w, dl[u], acc) -- the arithmetic of spmm_csr_kernel
+#pragma unroll
+            for (int c = 16; c < 32; ++c) v[c] = 0.f;
+            const int e1 = rindptr[row + 1];
+            for (int e = rindptr[row]; e < e1; ++e) {
+                const float w = w_out ? w_out[e] : 1.f;
+                const float4* ur = reinterpret_cast<const float4*>(dlq + (long long)rindices[e] * ld);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (4 * k < C) {                                   // uniform
+                        const float4 t = ur[k];
+                        v[16 + 4 * k] = fmaf(w, t.x, v[16 + 4 * k]); v[17 + 4 * k] = fmaf(w, t.y, v[17 + 4 * k]);
+                        v[18 + 4 * k] = fmaf(w, t.z, v[18 + 4 * k]); v[19 + 4 * k] = fmaf(w, t.w, v[19 + 4 * k]);
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int c = 0; c < 32; ++c) v[c] = (c & 15) < C ? v[c] * alpha : 0.f;      // (columns C .. 15 of a half are not data)
@@ -298,9 +319,9 @@ extern "C" int64_t gte_head_dlq_finish_workspace_bytes(int64_t n_nodes) {
     return gte::round_up(gte::ceil_div(n_nodes > 0 ? n_nodes : 1, DLQ_ROWS) * 16 * 4, 256);
 }
 
-extern "C" int gte_head_dlq_finish(const float* dlq, int64_t lddlq, int64_t n_nodes, int64_t n_classes, const void* ce_partial,
-                                   float grad_scale, float* out3, void* dlqp3, int64_t ldp, float* gbias, void* workspace,
-                                   int64_t workspace_bytes, void* stream) {
+extern "C" int gte_head_dlq_finish(const int32_t* rindptr, const int32_t* rindices, const float* w_out, const float* dlq, int64_t lddlq,
+                                   int64_t n_nodes, int64_t n_classes, const void* ce_partial, float grad_scale, float* out3, void* dlqp3,
+                                   int64_t ldp, float* gbias, void* workspace, int64_t workspace_bytes, void* stream) {
     if (n_nodes <= 0 || n_nodes > INT32_MAX || n_classes < 1 || n_classes > 16)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "head_dlq_finish: needs 1 <= n_classes <= 16 and n_nodes >= 1");
     if (!dlq || !ce_partial || !out3 || !dlqp3 || !gbias || !workspace) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "head_dlq_finish: null pointer");
@@ -313,7 +334,7 @@ extern "C" int gte_head_dlq_finish(const float* dlq, int64_t lddlq, int64_t n_no
     float* part = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(head_dlq_finish_kernel, dim3((unsigned)nb), dim3(DLQ_ROWS), 0, s, dlq, (long long)lddlq, (int)n_nodes, (int)n_classes,
                        reinterpret_cast<const float*>(ce_partial), (long long)gte::ceil_div(n_nodes, 64), grad_scale, out3,
-                       reinterpret_cast<char*>(dlqp3), (long long)ldp, part);
+                       reinterpret_cast<char*>(dlqp3), (long long)ldp, part, rindptr, rindices, w_out);
     if (!gte::defer_fold(part, 16, nb, 1, (int)n_classes, gbias, n_classes))
         hipLaunchKernelGGL(head_bias_fold_kernel, dim3(1), dim3(64), 0, s, part, nb, (int)n_classes, gbias);
     return gte::check_launch("head_dlq_finish");

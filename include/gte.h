@@ -380,15 +380,16 @@ int gte_gemm_p3_tn_rows(const void* a, int64_t ldpa, const void* a2, int64_t ldp
                         const int32_t* b_rows, int64_t n_res_rows, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n,
                         int64_t k, void* workspace, int64_t workspace_bytes, void* stream);
 /* Second half of the fused head (gte_head_agg_ce) when the output layer's products run on the planes GEMMs: dlq [n][>= 32] holds
- * dl in columns 0 .. C-1 and q = A_w^T (norm dl) in columns 16 .. 16 + C-1, both WITHOUT the 1 / sum(w) of the weighted
- * cross-entropy (model_train.py:171,327).  One launch folds the CE partials of gte_head_agg_ce (ce_partial), publishes out3 =
- * {loss, sum w, #correct}, writes alpha [dl | q], alpha = grad_scale / sum w, as ONE P3 image [n][32] (the operand of the layer's
- * dW / dh GEMMs) and gbias [C] = column sums of alpha dl (block partials in `workspace`, folded in order -- inside an open fold
- * deferral by gte_fold_defer_flush). */
+ * dl in columns 0 .. C-1 WITHOUT the 1 / sum(w) of the weighted cross-entropy (model_train.py:171,327) and -- when rindptr is
+ * NULL -- q = A_w^T (norm dl) in columns 16 .. 16 + C-1; with the out-edge CSR (rindptr / rindices / w_out = w / in_degree(dst))
+ * the launch forms q itself (autograd of models.py:53-54 for the class-count-wide aggregation).  It folds the CE partials of
+ * gte_head_agg_ce (ce_partial), publishes out3 = {loss, sum w, #correct}, writes alpha [dl | q], alpha = grad_scale / sum w, as
+ * ONE P3 image [n][32] (the operand of the layer's dW / dh GEMMs) and gbias [C] = column sums of alpha dl (block partials in
+ * `workspace`, folded in order -- inside an open fold deferral by gte_fold_defer_flush). */
 int64_t gte_head_dlq_finish_workspace_bytes(int64_t n_nodes);
-int gte_head_dlq_finish(const float* dlq, int64_t lddlq, int64_t n_nodes, int64_t n_classes, const void* ce_partial,
-                        float grad_scale, float* out3, void* dlqp3, int64_t ldp, float* gbias, void* workspace,
-                        int64_t workspace_bytes, void* stream);
+int gte_head_dlq_finish(const int32_t* rindptr, const int32_t* rindices, const float* w_out, const float* dlq, int64_t lddlq,
+                        int64_t n_nodes, int64_t n_classes, const void* ce_partial, float grad_scale, float* out3, void* dlqp3,
+                        int64_t ldp, float* gbias, void* workspace, int64_t workspace_bytes, void* stream);
 /* Row maps: 0 = 64-bit addresses for resident images of 4 GB or more only (default), 1 = always (tests, A/B timing; the
  * zero-row requirement of gte_gemm_p3_tn_rows then holds for every image). */
 int gte_gemm_p3_set_rows64(int mode);

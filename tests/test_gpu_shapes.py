@@ -346,8 +346,8 @@ def test_head_dlq_finish_scales_images_and_sums(n, C):
         out3, gb = torch.full((3,), 7.0, device=DEV), torch.full((C,), 7.0, device=DEV)
         if deferred:
             _lib.check(lib.gte_fold_defer_begin(st), "begin")
-        _lib.check(lib.gte_head_dlq_finish(P(dlq), 32, n, C, P(part), grad_scale, P(out3), P(img.data), img.ldp, P(gb), P(ws), ws.numel(), st),
-                   "gte_head_dlq_finish")
+        _lib.check(lib.gte_head_dlq_finish(None, None, None, P(dlq), 32, n, C, P(part), grad_scale, P(out3), P(img.data), img.ldp, P(gb),
+                                           P(ws), ws.numel(), st), "gte_head_dlq_finish")
         if deferred:
             _lib.check(lib.gte_fold_defer_flush(), "flush")
         got = ops.p3_to_f32(img)
@@ -356,7 +356,20 @@ def test_head_dlq_finish_scales_images_and_sums(n, C):
                                    rtol=1e-6)
         np.testing.assert_allclose(gb.double().cpu().numpy(), want[:, :C].double().sum(0).cpu().numpy(), rtol=1e-5,
                                    atol=1e-6 * float(want[:, :C].abs().sum(0).max()) + 1e-12)
-    assert lib.gte_head_dlq_finish(P(dlq), 32, n, 17, P(part), grad_scale, P(out3), P(img.data), img.ldp, P(gb), P(ws), ws.numel(), st) == -1
+    assert lib.gte_head_dlq_finish(None, None, None, P(dlq), 32, n, 17, P(part), grad_scale, P(out3), P(img.data), img.ldp, P(gb), P(ws),
+                                   ws.numel(), st) == -1
+    # with the out-edge CSR the launch forms q = A_w^T dl itself: bit for bit the aggregation kernel's q, then scaled
+    rng = np.random.default_rng(n)
+    e = 6 * n
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    rip, rix, _, rw = ops.coo_to_csr(dev(src, torch.int32), dev(dst, torch.int32), n, dev(rng.random(e).astype(np.float32)))
+    q = ops.spmm_csr(rip, rix, rw, dlq[:, :C].contiguous(), n, mean=False)
+    img2 = ops.P3.empty(n, 32, DEV)
+    _lib.check(lib.gte_head_dlq_finish(P(rip), P(rix), P(rw), P(dlq), 32, n, C, P(part), grad_scale, P(out3), P(img2.data), img2.ldp, P(gb),
+                                       P(ws), ws.numel(), st), "gte_head_dlq_finish")
+    got2 = ops.p3_to_f32(img2)
+    assert torch.equal(got2[:, :C], got[:, :C])
+    assert torch.equal(got2[:, 16:16 + C], q * np.float32(alpha)) or torch.allclose(got2[:, 16:16 + C], q * np.float32(alpha), rtol=3e-7, atol=0)
 
 
 # ---------------------------------------------------------------- edge-parallel aggregation (hub rows)
@@ -433,13 +446,17 @@ def test_edge_parallel_aggregation_beats_the_row_kernel_on_hub_rows():
     def t(fn):
         for _ in range(3):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / 10
+        best = None
+        for _ in range(4):                                           # (the best of four: a shared box stalls now and then)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            best = ms if best is None else min(best, ms)
+        return best
     t_row = t(lambda: ops.spmm_csr(indptr, indices, w, x, n))
     t_edge = t(lambda: ops.spmm_csr_edge(indptr, indices, w, x, n))
     print(f"hub graph: row kernel {t_row * 1e3:.1f} us, edge-parallel {t_edge * 1e3:.1f} us")
