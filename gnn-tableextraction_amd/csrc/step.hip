@@ -132,12 +132,13 @@ int backward_a(const gte_step_plan& p, void* st) {
     if (p.out_gemm) {
         // q = A_w^T (norm dl); dl and q as ONE image [n][32] (dl in block 0, q in block 1); dW_out = [dl^T h | q^T h] (two column
         // segments of one TN launch, M = n_classes), dbias = colsum(dl), dh = [dl | q] [W_s^T | W_n^T] (K = 32)
+        GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, lg, p.q_out, lg, n, C, GTE_F32, GTE_REDUCE_SUM, st));
         if (head_gemm_fused(p)) {
-            // (q = A_w^T (norm dl) is formed by the same launch, from the out-edge CSR)
-            GTE_TRY(gte_head_dlq_finish(p.rindptr, p.rindices, p.w_out, p.dl, lg, n, C, p.ws_ce, p.grad_scale, p.out3, p.dlqp, p.ldp_dlq,
+            // (q from the aggregation launch above: gte_head_dlq_finish can form it itself from the out-edge CSR, one launch less,
+            // but a thread per node walking its out-edges one after the other measured 14.7 us against 6 + 6 for the two launches)
+            GTE_TRY(gte_head_dlq_finish(nullptr, nullptr, nullptr, p.dl, lg, n, C, p.ws_ce, p.grad_scale, p.out3, p.dlqp, p.ldp_dlq,
                                         p.gb_out, p.ws_cs, p.ws_cs_bytes, st));
         } else {
-            GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, lg, p.q_out, lg, n, C, GTE_F32, GTE_REDUCE_SUM, st));
             GTE_TRY(gte_p3_from_f32(p.dl, lg, n, 32, 0, p.dlqp, p.ldp_dlq, st));
             GTE_TRY(gte_colsum(p.dl, lg, n, C, p.gb_out, p.ws_cs, p.ws_cs_bytes, st));
         }
