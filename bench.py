@@ -628,7 +628,7 @@ def residency_probe(args, gte, dev, pages, loop):
     out = {"workload": f"{len(pages)} pages ({set_bytes / 1e9:.2f} GB in resident form) under a budget of {budget / 1e9:.2f} GB: "
                        f"{len(wp.ranges)} windows, {args.pages} pages per step",
            "host_build_s": build_s, "pinned_h2d_GB_per_s": h2d, "device_bytes": wp.device_bytes, "windowed": {}}
-    for passes in (4, 8):
+    for passes in (4, 8, 16):
         tr = fresh()
         stream = R.WindowStream(wp.ranges, args.pages, passes, 42)
         wp.prefetch(stream.peek_window())
