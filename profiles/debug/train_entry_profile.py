@@ -16,5 +16,5 @@ with tempfile.TemporaryDirectory() as out:
     model_train.train(data, cfg)
     pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
-print("\n".join(l[:150] for l in s.getvalue().splitlines()[:75]))
+pstats.Stats(pr, stream=s).sort_stats(sys.argv[2] if len(sys.argv) > 2 else "cumulative").print_stats(60)
+print("\n".join(l[:150] for l in s.getvalue().splitlines()[:90]))
