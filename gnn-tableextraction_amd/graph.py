@@ -335,49 +335,50 @@ def unbatch_sizes(g: PageGraph) -> List[int]:
     return list(g.batch_num_nodes_)
 
 
-def upload_rows(parts: Sequence[torch.Tensor], device, out: Optional[torch.Tensor] = None, chunk_bytes: int = 64 << 20) -> torch.Tensor:
+def upload_rows(parts: Sequence[torch.Tensor], device, out: Optional[torch.Tensor] = None, chunk_bytes: int = 64 << 20,
+                threads: int = 8) -> torch.Tensor:
     """Concatenation of host matrices [n_i, F] as ONE fp32 matrix -- on ``device``, or into ``out`` (e.g. a pinned host matrix) --
-    without a host-side torch.cat: the parts are copied into two pinned staging buffers in turn, each uploaded asynchronously while
-    the other is filled."""
+    without a host-side torch.cat: the parts are copied into two pinned staging buffers in turn (a few host threads: a row copy
+    releases the interpreter lock), each uploaded asynchronously while the other is filled."""
+    from concurrent.futures import ThreadPoolExecutor
     n = int(sum(int(p.shape[0]) for p in parts))
     f = int(parts[0].shape[1]) if parts else 0
     if out is None:
         out = torch.empty((n, f), dtype=torch.float32, device=device)
     if n == 0 or f == 0:
         return out
-    if not out.is_cuda:                                           # host destination: plain row copies
-        r0 = 0
-        for p in parts:
-            out[r0:r0 + p.shape[0]].copy_(p)
-            r0 += int(p.shape[0])
-        return out
-    rows = max(1, chunk_bytes // (4 * f))
-    stage = [torch.empty((rows, f), dtype=torch.float32).pin_memory() for _ in range(2)]
-    done = [None, None]
-    k, fill, r0 = 0, 0, 0
-
-    def flush():
-        nonlocal k, fill, r0
-        if fill:
-            out[r0:r0 + fill].copy_(stage[k][:fill], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            done[k] = ev
-            r0 += fill
-            k ^= 1
-            fill = 0
-            if done[k] is not None:
-                done[k].synchronize()                             # (the buffer about to be refilled has left the host)
-    for p in parts:
+    # jobs: (part index, first row of the part, rows, destination row) cut at the staging-buffer boundaries
+    rows = max(1, chunk_bytes // (4 * f)) if out.is_cuda else n
+    chunks, cur, fill, r0 = [], [], 0, 0
+    for i, p in enumerate(parts):
         a, m = 0, int(p.shape[0])
         while a < m:
             take = min(m - a, rows - fill)
-            stage[k][fill:fill + take].copy_(p[a:a + take])
+            cur.append((i, a, take, fill))
             fill += take
             a += take
             if fill == rows:
-                flush()
-    flush()
+                chunks.append((r0, fill, cur))
+                r0, cur, fill = r0 + fill, [], 0
+    if fill:
+        chunks.append((r0, fill, cur))
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        if not out.is_cuda:                                       # host destination: row copies straight into it
+            for r0, _, jobs in chunks:
+                list(pool.map(lambda j: out[r0 + j[3]:r0 + j[3] + j[2]].copy_(parts[j[0]][j[1]:j[1] + j[2]]), jobs))
+            return out
+        stage = [torch.empty((rows, f), dtype=torch.float32).pin_memory() for _ in range(min(2, len(chunks)))]
+        done = [None, None]
+        for c, (r0, cnt, jobs) in enumerate(chunks):
+            k = c & 1
+            if done[k] is not None:
+                done[k].synchronize()                             # (the buffer about to be refilled has left the host)
+            buf = stage[k]
+            list(pool.map(lambda j: buf[j[3]:j[3] + j[2]].copy_(parts[j[0]][j[1]:j[1] + j[2]]), jobs))
+            out[r0:r0 + cnt].copy_(buf[:cnt], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            done[k] = ev
     torch.cuda.current_stream(out.device).synchronize()
     return out
 
