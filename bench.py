@@ -671,10 +671,15 @@ def residency_probe(args, gte, dev, pages, loop):
         return n
     run_resident(24)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n2 = run_resident(n_steps)
-    torch.cuda.synchronize()
-    el2 = time.perf_counter() - t0
+    best2 = None
+    for _ in range(2):                                           # (the better of two runs, like the windowed settings)
+        t0 = time.perf_counter()
+        n2 = run_resident(n_steps)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        if best2 is None or n2 / el2 > best2[0] / best2[1]:
+            best2 = (n2, el2)
+    n2, el2 = best2
     out["all_resident"] = {"value": n2 / el2, "unit": "nodes/s", "ms_per_step": el2 / n_steps * 1e3}
     for k, v in out["windowed"].items():
         v["over_all_resident"] = v["value"] / out["all_resident"]["value"]
