@@ -200,6 +200,7 @@ def cpu_baseline(args, host_batch, state):
                       f"{len(src)} edges, F0={args.in_feats}); aggregation = "
                       f"{'OpenMP CSR SpMM' if oc.omp_available() else 'torch.sparse_csr'}, "
                       f"dense ops = torch CPU ({torch.get_num_threads()} threads)",
+            "sample_short": f"{len(times)} train steps (median) on one {int(off[-1])}-node batch of the workload, {time.time() - t_all:.0f} s",
             "ms_per_step": med * 1e3}
 
 
@@ -427,6 +428,17 @@ def _c16(x):
     return -(-int(x) // 16) * 16
 
 
+def step_bounds(dims, deg, peak_tf, world=1):
+    """Whole-step bounds of SURVEY 8(d): per node, layer l (F_l -> F_{l+1}, mean in-degree d), training mode, no recomputation.
+    Returns (flops per node, bytes per node, MFMA-bound nodes/s, HBM-bound nodes/s)."""
+    n_l = len(dims) - 1
+    flops_node = sum(2.0 * 2 * dims[l] * dims[l + 1] * (3 if l > 0 else 2) for l in range(n_l))
+    bytes_node = sum(4.0 * (2 * dims[l] + dims[l + 1]) + 8 * deg + 4 +                            # forward
+                     4.0 * (dims[l + 1] + 2 * dims[l] + (dims[l] if l > 0 else 0)) + 8 * deg + 4  # backward
+                     for l in range(n_l))
+    return flops_node, bytes_node, peak_tf * 1e12 / flops_node * world, HBM_PEAK_GBS * 1e9 / bytes_node * world
+
+
 def forward_gemm_rate(ops, n, fin, fout, dev, aggregate_first=False, reps=10):
     """The forward transform of one hidden layer as the step launches it -- t = h [W_s ; W_n]^T (transform-first: N = 2 fout, K = fin)
     or z = [x | ahn] W^T (aggregate-first: N = fout, K = 2 fin) -- on P3 operands of the step's shapes, `reps` launches inside one
@@ -501,15 +513,18 @@ def shapes_probe(args, gte, dev, page_sets, loop):
         kinds = trainer._plan_kinds(f0, n_step)
         gen, out_gemm = trainer._plan_mode(kinds, f0) if kinds is not None else (None, None)
         dims = [f0] + [hid] * (args.layers - 1) + [9]
-        flops_node = sum(2.0 * 2 * dims[l] * dims[l + 1] * (3 if l > 0 else 2) for l in range(args.layers))
+        deg = float(sum(len(p.src) for p in pages)) / max(float(sum(p.num_nodes for p in pages)), 1.0)
+        flops_node, bytes_node, mfma_b, hbm_b = step_bounds(dims, deg, peak)
         entry = {"value": nodes / el, "unit": "nodes/s", "ms_per_step": el / steps * 1e3, "nodes_per_step": n_step,
                  "final_loss": float(out3[0]),
                  "plan": None if kinds is None else {"layer_kinds": kinds, "kinds": "0 planes transform-first, 1 one-pass short input, "
                                                      "2 planes aggregate-first", "padded_rows": bool(gen),
                                                      "output_layer": "planes GEMMs" if out_gemm else "narrow kernels"},
                  "step_tflops_fp32_eq": nodes / el * flops_node / 1e12,
-                 "mfma_bound_nodes_per_s": peak * 1e12 / flops_node,
-                 "frac_of_mfma_bound": nodes / el / (peak * 1e12 / flops_node)}
+                 "mfma_bound_nodes_per_s": mfma_b, "hbm_bound_nodes_per_s": hbm_b, "bytes_per_node": bytes_node,
+                 "bound": "mfma" if mfma_b < hbm_b else "hbm",            # the BINDING bound of SURVEY 8(d): min of the two
+                 "frac_of_bound": nodes / el / min(mfma_b, hbm_b),
+                 "frac_of_mfma_bound": nodes / el / mfma_b}
         if kinds is not None and trainer._planes_on():
             # the forward transform GEMMs of the two hidden layers INSIDE the loop: HIP events recorded by the one-call step on its
             # launch stream around those launches (gte_step_plan.fwd_events), eight more steps of the same loop, one at a time
@@ -587,6 +602,8 @@ def size_sweep_probe(args, trainer, pipe, sizes, loop, first_epoch):
     for p in out["points"]:
         p["frac_of_best"] = p["value"] / best
     out["min_frac_of_best"] = min(p["frac_of_best"] for p in out["points"])
+    hl = [p["frac_of_best"] for p in out["points"] if p["pages_per_step"] == args.pages]
+    out["headline_frac_of_best"] = hl[0] if hl else None          # the reference's batch size (parsers/graphs.py:74)
     return out
 
 
@@ -628,7 +645,7 @@ def residency_probe(args, gte, dev, pages, loop):
     out = {"workload": f"{len(pages)} pages ({set_bytes / 1e9:.2f} GB in resident form) under a budget of {budget / 1e9:.2f} GB: "
                        f"{len(wp.ranges)} windows, {args.pages} pages per step",
            "host_build_s": build_s, "pinned_h2d_GB_per_s": h2d, "device_bytes": wp.device_bytes, "windowed": {}}
-    for passes in (4, 8, 16):
+    for passes in (1, 4, 8, 16):
         tr = fresh()
         stream = R.WindowStream(wp.ranges, args.pages, passes, 42)
         wp.prefetch(stream.peek_window())
@@ -870,6 +887,94 @@ def gather_probe(args, gte, S, dev):
             "traffic": pmc_traffic()[0].get("gather_cfg4_tiled_bytes_per_launch") if n == 1_000_000 else None,
             "traffic_source": pmc_traffic()[1]}
 
+RECORD_MAX_CHARS = 3000      # the driver keeps ~8 000 characters of stdout; round 4's 22 kB line was cut and could not be parsed
+
+
+def _r(x, digits=4):
+    """floats to `digits` significant digits (the record is a summary: the full precision is in bench_extras.json)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def compact_record(full):
+    """The ONE stdout line: the driver's keys, `roofline`, `step_roofline`, `cpu_baseline`, and one-number summaries of the
+    secondary measurements.  No prose beyond `config.workload`; everything else lives in bench_extras.json."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    rec = {k: full[k] for k in keep}
+    cfg = full["config"]
+    rec["config"] = {"workload": (f"cfg2: {cfg['pages_per_gpu_per_step']} synthetic PubLayNet-style page graphs per GPU per step "
+                                  f"(~{cfg['nodes_per_step_per_gpu']} nodes), GcnSAGE {cfg['layers']} layers F0={cfg['in_feats']} "
+                                  f"hidden={cfg['hidden']} classes=9 fp32, CE + Adam; train loop, a different device-built batch "
+                                  f"every step"),
+                     "pages_per_gpu_per_step": cfg["pages_per_gpu_per_step"], "nodes_per_step_per_gpu": cfg["nodes_per_step_per_gpu"],
+                     "resident_pages_per_gpu": cfg["resident_pages_per_gpu"], "parallelism": cfg["parallelism"]}
+    ro = full["roofline"]
+    rec["roofline"] = {"bound": ro["bound"], "achieved": ro["achieved"], "peak": ro["peak"], "unit": ro["unit"], "frac": ro["frac"],
+                       "traffic": ro["traffic"], "kernel": ro["kernel_short"], "avg_launch_ms": ro["avg_launch_ms"],
+                       "launches": ro["launches"], "algorithmic_flops_per_launch": ro["algorithmic_flops_per_launch"]}
+    sr = full["step_roofline"]
+    rec["step_roofline"] = {k: sr[k] for k in ("bound", "frac", "flops_per_node", "bytes_per_node", "mfma_bound_nodes_per_s",
+                                                "hbm_bound_nodes_per_s")}
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        rec["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                               "sample": cb["sample_short"], "ms_per_step": cb["ms_per_step"]}
+        rec["gpu_over_cpu"] = full["gpu_over_cpu"]
+    if "long_run" in full:
+        rec["long_run"] = {k: full["long_run"][k] for k in ("steps", "seconds", "value")}
+    if "gather" in full:
+        g = full["gather"]
+        rec["gather"] = {"frac": g["frac"], "bwd_frac": g["bwd_frac"], "GBs": g["achieved"], "traffic": g["traffic"],
+                         "algorithmic_bytes": g["algorithmic_bytes"]}
+    if "shapes" in full:
+        rec["shapes"] = {k: [v["value"], v["frac_of_bound"]] for k, v in full["shapes"].items() if isinstance(v, dict) and "value" in v}
+        rec["shapes_fmt"] = "f<F0>_h<H>: [nodes/s, frac of min(HBM, MFMA) step bound]"
+    if "size_sweep" in full:
+        rec["size_sweep"] = {"min_frac_of_best": full["size_sweep"]["min_frac_of_best"],
+                             "headline_frac_of_best": full["size_sweep"].get("headline_frac_of_best")}
+    if "residency" in full:
+        w = full["residency"]["windowed"]
+        rec["residency"] = {"over_all_resident": {k: v["over_all_resident"] for k, v in w.items()}}
+    for k in ("replay", "secondary", "val_graph"):
+        if k in full and isinstance(full[k], dict) and "value" in full[k]:
+            rec[k] = full[k]["value"]
+    if "gemm_modes" in full:
+        rec["f32_mfma_mode"] = full["gemm_modes"]["other_mode"]["value"]
+    if "dist_1rank" in full:
+        rec["dist_1rank"] = full["dist_1rank"]
+    rec["extras"] = "bench_extras.json"
+    rec = {k: (_r(v, 7) if k in keep else _r(v)) for k, v in rec.items()}
+    s = json.dumps(rec, separators=(",", ":"))
+    # never let the record outgrow the driver's window: drop the secondary summaries first
+    for k in ("shapes_fmt", "val_graph", "secondary", "replay", "f32_mfma_mode", "residency", "size_sweep", "shapes", "gather", "long_run"):
+        if len(s) <= RECORD_MAX_CHARS:
+            break
+        rec.pop(k, None)
+        s = json.dumps(rec, separators=(",", ":"))
+    return s
+
+
+def emit(full):
+    """Full measurements -> bench_extras.json (next to this file; also under gpurun_out/ when that exists) and stderr; the compact
+    record -> the LAST stdout line."""
+    blob = json.dumps(full, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_extras.json"), "w") as f:
+                    f.write(blob)
+            except OSError as e:                                   # a read-only tree must not cost the record
+                print(f"bench.py: could not write bench_extras.json in {d}: {e}", file=sys.stderr)
+    print(json.dumps(full), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(compact_record(full), flush=True)
+
 
 def main():
     args = parse()
@@ -1101,6 +1206,8 @@ def main():
                                ("gemm_split_kernel<NT> (layer transforms, forward; fp32 operands as 3 exact bf16 pieces, 6 bf16 "
                                 "MFMA products, fp32 accumulate; peak = bf16 dense / 6)")) if split_mode
                               else "gemm_f32_mfma_kernel<NT> (layer transforms, forward)",
+                    "kernel_short": (("gemm_p3_nt_lw/ring fwd (bf16x3 planes, peak=bf16/6)" if trainer._planes_on() else "gemm_split<NT> fwd (peak=bf16/6)")
+                                     if split_mode else "gemm_f32_mfma<NT> fwd"),
                     "achieved": tf, "peak": gemm_peak, "unit": "TFLOP/s", "frac": tf / gemm_peak,
                     "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
                     "algorithmic_flops_per_launch": flops / max(n_launch, 1),
@@ -1127,6 +1234,7 @@ def main():
                                    f"CE + Adam(lr 0.01, wd 5e-4); the train loop of models/loop.py: a different batch "
                                    f"every step, assembled on the device from {args.resident_pages} resident pages per GPU "
                                    f"(shuffled epochs), eager launches",
+                       "layers": args.layers, "in_feats": args.in_feats, "hidden": args.hidden,
                        "pages_per_gpu_per_step": args.pages, "global_pages_per_step": args.pages * world,
                        "resident_pages_per_gpu": args.resident_pages, "nodes_per_step_per_gpu": mean_nodes,
                        "parallelism": f"dp{world}"},
@@ -1137,12 +1245,7 @@ def main():
         # whole-step bounds of SURVEY 8(d): per node, layer l (F_l -> F_{l+1}, mean in-degree d), training mode, no recomputation
         dims = [args.in_feats] + [args.hidden] * (args.layers - 1) + [9]
         deg = float(sum(len(p.src) for p in pages)) / max(float(sum(p.num_nodes for p in pages)), 1.0)
-        flops_node = sum(2.0 * 2 * dims[l] * dims[l + 1] * (3 if l > 0 else 2) for l in range(args.layers))
-        bytes_node = sum(4.0 * (2 * dims[l] + dims[l + 1]) + 8 * deg + 4 +                       # forward
-                         4.0 * (dims[l + 1] + 2 * dims[l] + (dims[l] if l > 0 else 0)) + 8 * deg + 4  # backward
-                         for l in range(args.layers))
-        mfma_bound = gemm_peak * 1e12 / flops_node * world
-        hbm_bound = HBM_PEAK_GBS * 1e9 / bytes_node * world
+        flops_node, bytes_node, mfma_bound, hbm_bound = step_bounds(dims, deg, gemm_peak, world)
         line["step_roofline"] = {"flops_per_node": flops_node, "bytes_per_node": bytes_node, "mean_in_degree": deg,
                                  "mfma_bound_nodes_per_s": mfma_bound, "hbm_bound_nodes_per_s": hbm_bound,
                                  "bound": "mfma" if mfma_bound < hbm_bound else "hbm",
@@ -1190,7 +1293,7 @@ def main():
             cb = cpu_baseline(args, S.concat_pages([pages[int(i)] for i in ids]), state0)
             line["cpu_baseline"] = cb
             line["gpu_over_cpu"] = line["value"] / cb["value"]
-        print(json.dumps(line), flush=True)
+        emit(line)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

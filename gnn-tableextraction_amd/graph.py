@@ -377,7 +377,7 @@ def upload_rows(parts: Sequence[torch.Tensor], device, out: Optional[torch.Tenso
             list(pool.map(lambda j: buf[j[3]:j[3] + j[2]].copy_(parts[j[0]][j[1]:j[1] + j[2]]), jobs))
             out[r0:r0 + cnt].copy_(buf[:cnt], non_blocking=True)
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(torch.cuda.current_stream(out.device))      # (the stream the copy runs on: out's device, not the current one)
             done[k] = ev
     torch.cuda.current_stream(out.device).synchronize()
     return out

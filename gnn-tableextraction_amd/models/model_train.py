@@ -193,38 +193,73 @@ def train(data, config, name_time=None):
         page_wsum = [float(np.asarray(cw, dtype=np.float64)[g.ndata['label'].long().numpy()].sum()) for g in train_graphs]
     # GTE_RESIDENT_BUDGET_GB: HBM the training pages may take per rank.  A set that fits is kept whole in HBM (below); a larger one
     # stays in pinned host memory and a window of it is resident (models/residency.py).
+    # Unset: derived from the free HBM of this rank's device when the set does not fit (residency.default_budget_bytes).
+    from . import residency as R
+    all_nodes = np.array([g.num_nodes() for g in train_graphs], dtype=np.int64)
+    all_edges = np.array([g.num_edges() for g in train_graphs], dtype=np.int64)
+    want_p3 = bool(getattr(step, "wants_p3_features", lambda f: False)(in_feats))
+    set_bytes = float(all_nodes.sum()) * R.WindowedPages.bytes_per_node(all_nodes, all_edges, in_feats, want_p3)
     budget_gb = float(os.environ.get("GTE_RESIDENT_BUDGET_GB", "0") or 0)
-    windowed = False
-    if budget_gb > 0:
-        from . import residency as R
-        all_nodes = np.array([g.num_nodes() for g in train_graphs], dtype=np.int64)
-        all_edges = np.array([g.num_edges() for g in train_graphs], dtype=np.int64)
-        want_p3 = bool(getattr(step, "wants_p3_features", lambda f: False)(in_feats))
-        set_bytes = float(all_nodes.sum()) * R.WindowedPages.bytes_per_node(all_nodes, all_edges, in_feats, want_p3)
-        windowed = set_bytes / max(world, 1) > budget_gb * 1e9
+    if budget_gb <= 0 and torch.device(device).type == 'cuda':
+        free_b, total_b = torch.cuda.mem_get_info(device)
+        derived = R.default_budget_bytes(set_bytes, float(free_b), float(total_b))
+        if distributed:
+            # one decision for all ranks (their free memory differs by a few MB): the smallest budget, "none" only if none needs one
+            import torch.distributed as dist
+            t_ = torch.tensor([derived if derived is not None else float('inf')], dtype=torch.float64, device=device)
+            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+            derived = None if not np.isfinite(float(t_.item())) else float(t_.item())
+        if derived is not None:
+            budget_gb = derived / 1e9
+            say(f"DATA: {set_bytes / 1e9:.1f} GB of training pages against {free_b / 1e9:.1f} GB of free HBM: budget {budget_gb:.1f} GB "
+                f"(set GTE_RESIDENT_BUDGET_GB to choose)")
+    # Three tiers under a budget: (i) the set fits it -> all resident on every rank (the plan deals every step's pages to the
+    # ranks by node count: distributed.plan_epoch); (ii) a rank's share -- the pages it OWNS, set / world -- fits -> the rank holds
+    # its own pages for good and plans over them; (iii) otherwise the own pages stay in pinned host memory, a window is resident.
+    tier = "all"
+    if budget_gb > 0 and set_bytes > budget_gb * 1e9:
+        tier = "windowed" if set_bytes / max(world, 1) > budget_gb * 1e9 else "owned"
+    windowed = tier != "all"           # (both per-rank tiers run the stream loop below)
     if windowed:
         seed0 = config.PREPROCESS.get('seed', 42)
         owner = R.page_owner(len(train_graphs), world, seed0)
-        passes = int(os.environ.get("GTE_WINDOW_PASSES", "8"))
         mine = np.nonzero(owner == rank)[0]
-        host = R.HostPages([train_graphs[i] for i in mine], device)
-        wp = R.WindowedPages(host, budget_gb * 1e9, want_p3)
+        if tier == "windowed":
+            passes = int(os.environ.get("GTE_WINDOW_PASSES", "8"))
+            host = R.HostPages([train_graphs[i] for i in mine], device)
+            wp = R.WindowedPages(host, budget_gb * 1e9, want_p3)
+        else:
+            passes = 1                 # one window = every page the rank owns: a pass is a shuffled epoch over them
+            wp = R.OwnedResident([train_graphs[i] for i in mine], device)
         # every rank's stream (pure host logic): the node counts / weight sums of a step follow without communication
         streams, rank_pages = [], []
         for r in range(world):
             ids = np.nonzero(owner == r)[0]
             rank_pages.append(ids)
-            rng_ = R.WindowedPages.layout(all_nodes[ids], all_edges[ids], in_feats, budget_gb * 1e9, want_p3)
+            rng_ = (R.WindowedPages.layout(all_nodes[ids], all_edges[ids], in_feats, budget_gb * 1e9, want_p3) if tier == "windowed"
+                    else [(0, len(ids))])
             streams.append(R.WindowStream(rng_, batch_size, passes, seed0, rank=r))
         assert streams[rank].ranges == wp.ranges
-        wp.prefetch(streams[rank].peek_window())
-        pipe = BatchPipeline(wp.acquire(streams[rank].peek_window()))
-        pipe._bound_pages = (host.page_nodes, np.diff(host.sets["in"]["edge_off"]), np.diff(host.sets["out"]["edge_off"]))
         steps_per_epoch = min(len(ids) for ids in rank_pages) // batch_size
         if steps_per_epoch == 0:
             raise ValueError(f"{len(train_graphs)} training pages do not fill one global batch of {batch_size} pages x {world} rank(s)")
-        say(f"DATA: {set_bytes / 1e9:.3f} GB resident form > {budget_gb} GB budget per rank: host-resident, {len(wp.ranges)} windows per rank, "
-            f"{passes} passes per window visit, {wp.device_bytes / 1e9:.2f} GB on the device")
+        lost = sum(len(st.never_visited()) for st in streams)
+        if lost:
+            say(f"DATA: {lost} training pages lie in windows smaller than one batch of {batch_size} pages and are never visited")
+        if start_epoch:
+            # a resumed run continues every rank's stream where the interrupted run stood (its position is a function of the steps
+            # taken, as plan_epoch's plan is a function of the epoch)
+            for st in streams:
+                st.skip(start_epoch * steps_per_epoch)
+        wp.prefetch(streams[rank].peek_window())
+        pipe = BatchPipeline(wp.acquire(streams[rank].peek_window()))
+        if tier == "windowed":
+            pipe._bound_pages = (host.page_nodes, np.diff(host.sets["in"]["edge_off"]), np.diff(host.sets["out"]["edge_off"]))
+            say(f"DATA: {set_bytes / 1e9:.3f} GB resident form, {set_bytes / max(world, 1) / 1e9:.3f} GB per rank > {budget_gb:.3f} GB budget: "
+                f"host-resident, {len(wp.ranges)} windows per rank, {passes} passes per window visit, {wp.device_bytes / 1e9:.2f} GB on the device")
+        else:
+            say(f"DATA: {set_bytes / 1e9:.3f} GB resident form > {budget_gb:.3f} GB budget, {set_bytes / max(world, 1) / 1e9:.3f} GB per rank fits: "
+                f"every rank holds the {len(mine)} pages it owns")
         resident = sizes = None
     else:
         # all training pages concatenated ONCE in HBM (features, labels, both CSRs, CSR-ordered weights); a batch is
@@ -348,7 +383,8 @@ def train(data, config, name_time=None):
         # inspection handle for tests (replicas identical); opt-in: it pins the model and the engine's GB-scale device buffers
         global LAST_RUN
         LAST_RUN = {"model": model, "step": step, "rank": rank, "world": world,
-                    "windows": (len(wp.ranges), wp.uploaded_bytes, wp.device_bytes, host.n_pages) if windowed else None}
+                    "tier": tier,
+                    "windows": (len(wp.ranges), wp.uploaded_bytes, wp.device_bytes, len(mine)) if windowed else None}
     if rank == 0:
         os.makedirs(res_dir, exist_ok=True)
         path = os.path.join(res_dir, f'{logs}.json')

@@ -45,16 +45,31 @@ def window_ranges(page_nodes: np.ndarray, bytes_per_node: float, slot_bytes: flo
     cap = int(slot_bytes // bytes_per_node)
     if max_nodes is not None:
         cap = min(cap, int(max_nodes))
-    out, p0, acc = [], 0, 0
-    for p, n in enumerate(page_nodes):
-        if n > cap:
-            raise ValueError(f"page {p} with {n} nodes does not fit a window of {cap} nodes: raise GTE_RESIDENT_BUDGET_GB")
-        if acc + n > cap:
-            out.append((p0, p))
-            p0, acc = p, 0
-        acc += int(n)
-    out.append((p0, len(page_nodes)))
-    return out
+    big = int(np.max(page_nodes)) if len(page_nodes) else 0
+    if big > cap:
+        raise ValueError(f"a page with {big} nodes does not fit a window of {cap} nodes: raise GTE_RESIDENT_BUDGET_GB")
+
+    def greedy(c):
+        out, p0, acc = [], 0, 0
+        for p, n in enumerate(page_nodes):
+            if acc + n > c:
+                out.append((p0, p))
+                p0, acc = p, 0
+            acc += int(n)
+        out.append((p0, len(page_nodes)))
+        return out
+    out = greedy(cap)
+    # the same NUMBER of windows, balanced: the smallest capacity that still needs no more windows.  (Filling every window to the
+    # brim leaves a last range of whatever remains -- possibly fewer pages than one batch, which the stream would then never
+    # train on.)
+    lo, hi = max(big, int(np.sum(page_nodes)) // max(len(out), 1)), cap
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if len(greedy(mid)) <= len(out):
+            hi = mid
+        else:
+            lo = mid + 1
+    return greedy(hi)
 
 
 class WindowStream:
@@ -69,6 +84,32 @@ class WindowStream:
         self.sweep, self.pos, self.pas, self.off = 0, 0, 0, 0          # sweep, position in its window order, pass, step in pass
         self._order = self._window_order(0)
         self._perm = None
+
+    def never_visited(self) -> List[int]:
+        """pages (local ids) of windows that hold fewer than one batch: the stream skips such a window, so they are never trained
+        on (balanced window_ranges make this a corner case -- a rank with fewer pages than two batches; callers report it)"""
+        return [p for p0, p1 in self.ranges if p1 - p0 < self.B for p in range(p0, p1)]
+
+    def skip(self, n_steps: int) -> None:
+        """Advance by n_steps without producing them: a resumed run (checkpoint at epoch e) continues the stream where the
+        interrupted run stood -- the position is a function of the number of steps taken, like distributed.plan_epoch's plan
+        is a function of the epoch."""
+        while n_steps > 0:
+            w = int(self._order[self.pos])
+            p0, p1 = self.ranges[w]
+            per_pass = (p1 - p0) // self.B
+            if per_pass == 0:
+                self._advance_window()
+                continue
+            left_in_visit = (self.passes - self.pas) * per_pass - self.off
+            if n_steps >= left_in_visit:                          # whole rest of this window visit
+                n_steps -= left_in_visit
+                self.off, self.pas, self._perm = 0, 0, None
+                self._advance_window()
+            else:
+                done = self.pas * per_pass + self.off + n_steps
+                self.pas, self.off, self._perm = done // per_pass, done % per_pass, None
+                n_steps = 0
 
     def _window_order(self, sweep):
         return np.random.default_rng([self.seed, 31, self.rank, sweep]).permutation(len(self.ranges))
@@ -235,6 +276,7 @@ class WindowedPages:
         # queues (GPU_MAX_HW_QUEUES 8 ... 32: 0.53 / 0.98).  What the uploads get while the step's kernels run is 21 ... 38 GB/s of
         # the link's 57 (host memory and PCIe are shared with the other GPUs' jobs of the node: it differs run to run).
         self.copy = torch.cuda.Stream(device=dev)
+        self.delay_cycles = 0                                 # test hook: spin this many GPU cycles in front of every upload
         self._no_feat = torch.empty((0, F), dtype=torch.float32, device=dev)
         self.device_bytes = sum(t.numel() * t.element_size() for sl in self.slots for t in
                                 [sl["feat"], sl["label"]] + [v for n in ("in", "out") for v in sl[n].values()] if t is not None)
@@ -267,6 +309,8 @@ class WindowedPages:
         with torch.cuda.stream(self.copy):
             if sl["free"] is not None:
                 self.copy.wait_event(sl["free"])              # the last step that read this slot's old window has run
+            if self.delay_cycles:
+                torch.cuda._sleep(int(self.delay_cycles))     # (tests: an upload that is late -- every reader must wait for it)
             sl["meta_dev"][:3 * (np_ + 1)].copy_(sl["meta_host"][:3 * (np_ + 1)], non_blocking=True)
             sl["meta_ev"] = torch.cuda.Event()
             sl["meta_ev"].record(self.copy)
@@ -306,14 +350,19 @@ class WindowedPages:
         sl["window"], sl["ready"], sl["res"] = w, ev, res
         self.uploaded_bytes += n * h.n_feat * 4
 
-    def acquire(self, w: int) -> G.ResidentPages:
-        """Window w as a resident set; the CURRENT stream waits (on the device) for its upload."""
+    def acquire(self, w: int, also: Sequence[torch.cuda.Stream] = ()) -> G.ResidentPages:
+        """Window w as a resident set; the CURRENT stream -- and every stream in ``also`` -- waits (on the device) for its upload.
+        Every stream that READS the window must be ordered behind the upload: the batch pipeline assembles on a side stream that
+        otherwise waits only for its own buffer events, and would gather page tables, CSRs, labels and (fp32 mode) feature rows
+        of a window that is still arriving."""
         if self._slot_of(w) is None:
             self.prefetch(w)
         sl = self._slot_of(w)
         for s in self.slots:
             s["in_use"] = s is sl
         torch.cuda.current_stream(self.device).wait_event(sl["ready"])
+        for st in also:
+            st.wait_event(sl["ready"])
         return sl["res"]
 
     def release(self, w: int) -> None:
@@ -341,7 +390,7 @@ def run_windowed(step, pipe, wp: WindowedPages, stream: WindowStream, n_steps: i
         host_times["plan"] = host_times.get("plan", 0.0) + tick() - t_
     for i, (w, steps) in enumerate(chunks):
         t_ = tick()
-        res = wp.acquire(w)
+        res = wp.acquire(w, also=(pipe.side,))       # the assembly stream reads the window too (page tables, CSRs, labels, rows)
         t_a = tick()
         if pipe.res is not res:
             pipe.rebind(res)
@@ -369,3 +418,35 @@ def run_windowed(step, pipe, wp: WindowedPages, stream: WindowStream, n_steps: i
             host_times["steps"] = host_times.get("steps", 0.0) + tick() - t_
         done += k
     return out3, last_nodes
+
+
+class OwnedResident:
+    """The interface of WindowedPages for a rank whose OWN pages fit its budget: one window = all of them, resident for good.
+    (Data-parallel runs under a budget: a rank holds the pages it owns -- set / world bytes --, not the whole set.)"""
+
+    def __init__(self, graphs: Sequence[G.PageGraph], device):
+        self.device = torch.device(device)
+        self.res = G.ResidentPages(graphs, self.device)
+        self.ranges = [(0, len(graphs))]
+        self.uploaded_bytes = 0
+        nodes = np.array([g.num_nodes() for g in graphs], dtype=np.int64)
+        edges = np.array([g.num_edges() for g in graphs], dtype=np.int64)
+        self.device_bytes = int(nodes.sum() * WindowedPages.bytes_per_node(nodes, edges, int(graphs[0].ndata['feat'].shape[1]), False))
+
+    def prefetch(self, w: int) -> None:
+        pass
+
+    def acquire(self, w: int, also: Sequence[torch.cuda.Stream] = ()) -> G.ResidentPages:
+        return self.res
+
+    def release(self, w: int) -> None:
+        pass
+
+
+def default_budget_bytes(set_bytes: float, free_bytes: float, total_bytes: float) -> Optional[float]:
+    """The HBM budget of the training pages when GTE_RESIDENT_BUDGET_GB is not set: None (keep the whole set resident) while the
+    set fits in 70 % of what is free now -- the rest is for the validation graph, the step's per-batch buffers (a few GB at
+    hidden 1000) and the allocator's slack --, otherwise half of the free memory (two window slots + staging rows)."""
+    if set_bytes <= 0.7 * free_bytes:
+        return None
+    return 0.5 * free_bytes

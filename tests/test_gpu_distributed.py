@@ -129,6 +129,7 @@ def test_bench_self_spawned_two_ranks_share_the_gpu():
 def _train_worker(rank, world, port, out_dir, budget_gb=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       GTE_KEEP_LAST_RUN="1")
+    os.environ.pop("GTE_RESIDENT_BUDGET_GB", None)
     if budget_gb is not None:
         os.environ.update(GTE_RESIDENT_BUDGET_GB=str(budget_gb), GTE_WINDOW_PASSES="2")
     import torch.distributed as dist
@@ -152,6 +153,7 @@ def _train_worker(rank, world, port, out_dir, budget_gb=None):
             np.array([metrics.val.loss, metrics.val.acc, metrics.train.loss] + list(metrics.f1_vect)))
     if run["windows"] is not None:
         np.save(os.path.join(out_dir, f"train_windows_{rank}.npy"), np.array(run["windows"], dtype=np.float64))
+    open(os.path.join(out_dir, f"train_tier_{rank}.txt"), "w").write(run["tier"])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -191,3 +193,21 @@ def test_windowed_residency_with_two_ranks(tmp_path):
     np.testing.assert_array_equal(m0[:2], m1[:2])             # all-reduced validation loss / accuracy (the train loss is rank-local)
     np.testing.assert_array_equal(m0[3:], m1[3:])
     assert np.isfinite(m0).all()
+
+
+def test_a_budget_the_ranks_share_fits_makes_every_rank_hold_only_its_own_pages(tmp_path):
+    """GTE_RESIDENT_BUDGET_GB between set / world and set: round 4 compared the per-rank SHARE with the budget and then let every
+    rank hold the WHOLE set.  Now a rank holds the pages it owns (residency.OwnedResident: one window, resident for good) and plans
+    over them; replicas stay bit-identical and the validation metrics are the all-reduced ones."""
+    world = 2
+    # 38 training pages ~ 8 700 nodes x ~175 B in resident form ~ 1.5 MB: 1 MB holds a rank's half, not the set
+    mp.start_processes(_train_worker, args=(world, _free_port(), str(tmp_path), 0.001), nprocs=world, join=True, start_method="spawn")
+    assert [open(os.path.join(tmp_path, f"train_tier_{r}.txt")).read() for r in range(world)] == ["owned", "owned"]
+    p0, p1 = (np.load(os.path.join(tmp_path, f"train_param_{r}.npy")) for r in range(world))
+    np.testing.assert_array_equal(p0, p1)
+    w0, w1 = (np.load(os.path.join(tmp_path, f"train_windows_{r}.npy")) for r in range(world))
+    assert w0[0] == 1 and w1[0] == 1 and w0[3] + w1[3] == 38 and abs(w0[3] - w1[3]) <= 1
+    assert w0[2] <= 0.001e9                                   # the bytes a rank holds respect the budget
+    m0, m1 = (np.load(os.path.join(tmp_path, f"train_metrics_{r}.npy")) for r in range(world))
+    np.testing.assert_array_equal(m0[:2], m1[:2])
+    assert np.isfinite(m0).all() and m0[0] < np.log(9.0)

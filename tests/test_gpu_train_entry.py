@@ -222,7 +222,22 @@ def test_bench_line_keeps_the_driver_contract():
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
-    d = json.loads(lines[0])
+    # the record is the LAST stdout line and fits the driver's stdout window with room to spare (round 4's 22 kB line was cut
+    # in the middle and could not be parsed); no prose objects in it
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) <= 3000, len(lines[0])
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "step_roofline", "cpu_baseline", "gpu_over_cpu", "long_run", "gather", "extras"):
+        assert k in rec, k
+    assert set(rec["gather"]) >= {"frac", "bwd_frac", "traffic"} and 0 < rec["gather"]["frac"] < 1
+    assert all(len(v) <= 120 for v in rec.values() if isinstance(v, str))
+    ro, cb = rec["roofline"], rec["cpu_baseline"]
+    assert ro["bound"] in ("hbm", "mfma") and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and "traffic" in ro
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert abs(rec["value"] - rec["config"]["nodes_per_step_per_gpu"] / (rec["ms_per_step"] * 1e-3)) < 0.05 * rec["value"]
+    # everything else: bench_extras.json next to bench.py (the full measurements, the same keys as before)
+    d = json.load(open(os.path.join(root, rec["extras"])))
+    assert abs(d["value"] - rec["value"]) <= 1e-6 * d["value"] and d["steps"] == 4
     assert d["metric"].startswith("nodes/sec") and d["unit"] == "nodes/s" and d["higher_is_better"] is True
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"].startswith("f32") and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
