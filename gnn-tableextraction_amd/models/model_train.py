@@ -223,7 +223,12 @@ def train(data, config, name_time=None):
     if windowed:
         seed0 = config.PREPROCESS.get('seed', 42)
         owner = R.page_owner(len(train_graphs), world, seed0)
-        mine = np.nonzero(owner == rank)[0]
+        # every rank's pages in a seeded random order (windows are contiguous ranges of it: unbiased samples of the set)
+        rank_pages = []
+        for r in range(world):
+            ids = np.nonzero(owner == r)[0]
+            rank_pages.append(ids[R.window_page_order(len(ids), seed0, r)])
+        mine = rank_pages[rank]
         if tier == "windowed":
             passes = int(os.environ.get("GTE_WINDOW_PASSES", "8"))
             host = R.HostPages([train_graphs[i] for i in mine], device)
@@ -232,10 +237,9 @@ def train(data, config, name_time=None):
             passes = 1                 # one window = every page the rank owns: a pass is a shuffled epoch over them
             wp = R.OwnedResident([train_graphs[i] for i in mine], device)
         # every rank's stream (pure host logic): the node counts / weight sums of a step follow without communication
-        streams, rank_pages = [], []
+        streams = []
         for r in range(world):
-            ids = np.nonzero(owner == r)[0]
-            rank_pages.append(ids)
+            ids = rank_pages[r]
             rng_ = (R.WindowedPages.layout(all_nodes[ids], all_edges[ids], in_feats, budget_gb * 1e9, want_p3) if tier == "windowed"
                     else [(0, len(ids))])
             streams.append(R.WindowStream(rng_, batch_size, passes, seed0, rank=r))

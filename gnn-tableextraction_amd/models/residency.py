@@ -40,6 +40,14 @@ def page_owner(n_pages: int, world: int, seed: int = 42) -> np.ndarray:
     return owner
 
 
+def window_page_order(n_pages: int, seed: int = 42, rank: int = 0) -> np.ndarray:
+    """The order in which a rank lays its pages out in host memory: a seeded permutation.  Windows are CONTIGUOUS ranges of that
+    layout; in dataset order (papers, or -- the adversarial case -- pages sorted by size) a window is a biased sample of the set and a
+    loop that trains on one window at a time ends biased towards the windows it saw last: measured 0.79 against 0.34 validation
+    loss after 1 500 steps on size-sorted windows (tests/test_gpu_residency.py).  Shuffled once, every window is an unbiased sample."""
+    return np.random.default_rng([seed, 1213, rank]).permutation(n_pages)
+
+
 def window_ranges(page_nodes: np.ndarray, bytes_per_node: float, slot_bytes: float, max_nodes: Optional[int] = None) -> List[Tuple[int, int]]:
     """Contiguous page ranges [p0, p1) whose nodes fit a device slot (and ``max_nodes``: the 4 GB bound of the row map)."""
     cap = int(slot_bytes // bytes_per_node)

@@ -38,7 +38,8 @@ def test_windowed_order_reaches_the_validation_loss_of_the_reference_order():
     """3 000 training pages (F0 = 13, hidden 64), 20 pages per step, 1 500 steps = 10 epochs' worth, three orders:
     (a) all-resident, every epoch a fresh shuffle of all pages (distributed.plan_epoch = model_train.py:279-283);
     (b) windowed, 1 pass per window visit (every page once per sweep of the windows: the closest a windowed loop gets to (a));
-    (c) windowed, 8 passes per visit (the default of train() under a budget).
+    (c) windowed, 8 passes per visit (the default of train() under a budget);
+    (d) as (c) with the pages laid out sorted by size instead of train()'s seeded random order -- reported only.
     Same initial weights, same optimiser, same 300 held-out validation pages in one graph.  Asserted: the windowed orders end
     within 10 % of (a)'s validation loss (relative) and all three learn (loss far below ln 9).  The measured losses are written to
     gpurun_out/residency_semantics.json for DESIGN.md."""
@@ -74,9 +75,13 @@ def test_windowed_order_reaches_the_validation_loss_of_the_reference_order():
         epoch += 1
     out["all_resident"] = evaluate(m, val, val_y, engine=tr)[:2]
     del pipe, res
-    # (b), (c) windows of ~1/8 of the set
-    host = R.HostPages(train, DEV)
-    for passes in (1, 8):
+    # (b), (c) windows of ~1/8 of the set, the pages laid out in the seeded random order train() uses (window_page_order);
+    # (d) the same with the pages left sorted by size: windows that are biased samples of the set (reported, not asserted --
+    # the reason train() shuffles the layout)
+    order = R.window_page_order(len(train), 42, 0)
+    shuffled = [train[i] for i in order]
+    for tag, pages_, passes in (("windowed_passes_1", shuffled, 1), ("windowed_passes_8", shuffled, 8), ("sorted_windows_passes_8", train, 8)):
+        host = R.HostPages(pages_, DEV)
         m, tr = fresh()
         want_p3 = tr.wants_p3_features(f0)
         per_node = R.WindowedPages.bytes_per_node(host.page_nodes, host.page_edges, f0, want_p3)
@@ -88,8 +93,8 @@ def test_windowed_order_reaches_the_validation_loss_of_the_reference_order():
         pipe._bound_pages = (host.page_nodes, np.diff(host.sets["in"]["edge_off"]), np.diff(host.sets["out"]["edge_off"]))
         R.run_windowed(tr, pipe, wp, stream, n_steps)
         torch.cuda.synchronize()
-        out[f"windowed_passes_{passes}"] = evaluate(m, val, val_y, engine=tr)[:2] + (len(wp.ranges),)
-        del pipe, wp
+        out[tag] = evaluate(m, val, val_y, engine=tr)[:2] + (len(wp.ranges),)
+        del pipe, wp, host
     ref = out["all_resident"][0]
     report = {"workload": f"{len(train)} training pages sorted by size (F0 = {f0}, hidden {hid}), {B} pages per step, {n_steps} steps; "
                           f"300 held-out pages", "val_loss": {k: v[0] for k, v in out.items()}, "val_acc": {k: v[1] for k, v in out.items()},
@@ -98,6 +103,6 @@ def test_windowed_order_reaches_the_validation_loss_of_the_reference_order():
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
         json.dump(report, open(os.path.join(d, "residency_semantics.json"), "w"), indent=1)
-    assert all(v[0] < 0.6 * np.log(9.0) for v in out.values()), report
+    assert all(v[0] < 0.6 * np.log(9.0) for k, v in out.items() if not k.startswith("sorted")), report
     for k in ("windowed_passes_1", "windowed_passes_8"):
         assert abs(out[k][0] - ref) <= 0.10 * ref + 0.01, report
