@@ -67,6 +67,17 @@ int forward_hidden(const gte_step_plan& p, void* st, bool fwd_only = false) {
             GTE_TRY(gte_ln_relu_fwd_p3(L.t, ld, L.gamma, L.beta, L.eps, L.relu, L.y, ld, L.yp, L.ldp_y, L.stats, n, L.fout, st));
             continue;
         }
+        if (L.kind == GTE_LAYER_CACHED) {
+            // z = [x | ahn] W^T + b with x AND its mean aggregate read from their RESIDENT images through the batch's row map (the
+            // aggregate of the input is page-local and constant: cached when the pages were loaded), then LayerNorm + ReLU
+            mark(2 * i);
+            GTE_TRY(gte_gemm_p3_nt_rows2(L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd, L.ldp_wfwd, L.bias,
+                                         L.fout, L.t, ld, n, L.fout, 0, 0, st));
+            mark(2 * i + 1);
+            float* const y3 = (fwd_only && L.yp) ? nullptr : L.y;
+            GTE_TRY(gte_ln_relu_fwd_p3(L.t, ld, L.gamma, L.beta, L.eps, L.relu, y3, ld, L.yp, L.ldp_y, L.stats, n, L.fout, st));
+            continue;
+        }
         if (L.make_hp) GTE_TRY(gte_p3_from_f32(L.x, L.ldx, n, L.fin, 0, L.hp, L.ldp_h, st));
         // t = [t_self | t_neigh], each half ld columns wide (the weight image holds zero rows behind the fout rows of a half)
         mark(2 * i);
@@ -182,7 +193,7 @@ int backward_a(const gte_step_plan& p, void* st) {
             GTE_TRY(gte_ln_relu_bwd_p3(L.dy, ld, z_of(L), ldz_of(L), L.stats, L.gamma, L.beta, L.relu, L.dy, ld, L.dzp, L.ldp_o, L.ggamma,
                                        L.gbeta, L.gbias, n, L.fout, L.ws_ln, L.ws_ln_bytes, st));
         ln_done = false;
-        if (L.kind == GTE_LAYER_AGGFIRST) break;       // (layer 0: dW = dz^T [x | ahn] is the step's last GEMM: phase 2)
+        if (L.kind == GTE_LAYER_AGGFIRST || L.kind == GTE_LAYER_CACHED) break;       // (layer 0: dW = dz^T [x | ahn] is the step's last GEMM: phase 2)
         GTE_TRY(gte_spmm_csr_p3(p.rindptr, p.rindices, p.w_out, L.dy, ld, L.qp, L.ldp_o, n, L.fout, GTE_REDUCE_SUM, st));
         if (i == 0) break;                             // layer 0's dW is the step's last GEMM: phase 2
         GTE_TRY(gte_gemm_p3_tn(L.dzp, L.ldp_o, L.qp, L.ldp_o, L.hp, L.ldp_h, nullptr, 0, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n, L.ws_dw,
@@ -221,6 +232,9 @@ int backward_b(const gte_step_plan& p, void* st) {
                                    L.relu, L.gW, 2 * L.fin, L.gbias, L.ggamma, L.gbeta, n, L.fout, L.ws_dw, L.ws_dw_bytes, st);
     if (L.kind == GTE_LAYER_SMALLK)
         return gte_sage_linear_dw(L.dy, L.fout, L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.gW, 2 * L.fin, L.fout, n, L.ws_dw, L.ws_dw_bytes, st);
+    if (L.kind == GTE_LAYER_CACHED)                    // dW = [dz^T x | dz^T ahn], both operands resident behind the row map
+        return gte_gemm_p3_tn_rows2(L.dzp, L.ldp_o, L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.h_rows, L.n_res_rows, L.fin, L.gW, 2 * L.fin,
+                                    L.fout, 2 * L.fin, n, L.ws_dw, L.ws_dw_bytes, st);
     if (L.kind == GTE_LAYER_AGGFIRST)                  // dW = [dz^T x | dz^T ahn]
         return gte_gemm_p3_tn(L.dzp, L.ldp_o, nullptr, 0, L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n,
                               L.ws_dw, L.ws_dw_bytes, st);
@@ -249,8 +263,10 @@ int check_plan(const gte_step_plan& p) {
     if (p.n_hidden < 1 || p.n_hidden > 7 || p.n_nodes < 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: bad plan");
     for (int i = 0; i < p.n_hidden; ++i) {
         const gte_step_layer& L = p.layer[i];
-        if (L.kind != GTE_LAYER_PLANES && L.kind != GTE_LAYER_SMALLK && L.kind != GTE_LAYER_AGGFIRST)
+        if (L.kind != GTE_LAYER_PLANES && L.kind != GTE_LAYER_SMALLK && L.kind != GTE_LAYER_AGGFIRST && L.kind != GTE_LAYER_CACHED)
             return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: layer kind");
+        if (L.kind == GTE_LAYER_CACHED && (!L.hp || !L.ahnp || !L.h_rows || L.n_res_rows <= 0))
+            return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: a cached-aggregate layer needs both resident images and the row map");
         if (L.kind != GTE_LAYER_PLANES && i != 0)
             return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: a short-input / aggregate-first layer must be layer 0");
         if (!L.gamma || !L.beta || !L.bias) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: hidden layers need bias and LayerNorm");

@@ -450,7 +450,7 @@ class ResidentPages:
         feats = [g.ndata[feat_key] for g in cpu_graphs]
         self.feat = (upload_rows(feats, self.device) if with_feat
                      else torch.empty((0, int(feats[0].shape[1])), dtype=torch.float32, device=self.device))
-        self.feat_p3, self.p3_mode = None, False
+        self.feat_p3, self.agg_p3, self.p3_mode = None, None, False
         lab = whole.ndata.get(label_key)
         self.label = None if lab is None else lab.to(torch.float32).reshape(-1, 1).contiguous()
         w = whole.edata.get(weight_key)
@@ -478,7 +478,7 @@ class ResidentPages:
 
     @classmethod
     def from_arrays(cls, device, node_off_host: torch.Tensor, feat: torch.Tensor, label: Optional[torch.Tensor], sets: dict,
-                    weighted: bool, max_deg: dict, feat_p3=None, p3_mode=False, node_off_dev=None) -> "ResidentPages":
+                    weighted: bool, max_deg: dict, feat_p3=None, p3_mode=False, node_off_dev=None, agg_p3=None) -> "ResidentPages":
         """A resident set over arrays that already live on the device in this class's layout (models/residency.py: a WINDOW of a
         host-resident dataset, uploaded slice by slice).  ``sets[name]`` = {edge_off (int32, device), edge_off_host (int64, cpu),
         indptr_loc, indices_loc, weight | None}; ``feat`` may be an empty [0, F] placeholder when ``feat_p3`` carries the rows."""
@@ -486,7 +486,7 @@ class ResidentPages:
         self.device = torch.device(device)
         self.node_off_host = node_off_host
         self.n_pages, self.n_nodes = int(node_off_host.numel() - 1), int(node_off_host[-1])
-        self.feat, self.feat_p3, self.p3_mode = feat, feat_p3, p3_mode
+        self.feat, self.feat_p3, self.agg_p3, self.p3_mode = feat, feat_p3, agg_p3, p3_mode
         self.label = label
         self.weighted = weighted
         # (node_off_dev: already uploaded by the caller -- a pageable host->device copy here would block the host until the
@@ -496,10 +496,47 @@ class ResidentPages:
         self._sets = sets
         return self
 
-    def enable_p3(self) -> None:
+    def whole_in_csr(self):
+        """(indptr [N + 1], indices [E], weights | None) of the in-edge CSR over ALL resident pages in global row ids, put together
+        from the per-page local arrays (temporaries of E entries; used once, by the cached input aggregate)."""
+        dev, s = self.device, self._sets["in"]
+        P, N = self.n_pages, self.n_nodes
+        sizes = (self.node_off[1:] - self.node_off[:-1]).long()
+        page_of_node = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
+        eoff = s["edge_off"].long()
+        rows = torch.arange(N, device=dev)
+        indptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        indptr[:N] = (s["indptr_loc"].long()[rows + page_of_node] + eoff[page_of_node]).to(torch.int32)
+        indptr[N] = eoff[P].to(torch.int32)
+        E = int(s["edge_off_host"][P])
+        page_of_entry = torch.repeat_interleave(torch.arange(P, device=dev), (eoff[1:] - eoff[:-1]))
+        indices = (s["indices_loc"][:E].long() + self.node_off.long()[page_of_entry]).to(torch.int32)
+        return indptr, indices, (None if s["weight"] is None else s["weight"][:E])
+
+    def build_agg_image(self, x_f32: Optional[torch.Tensor] = None, out=None):
+        """The P3 image of norm . A_w x -- the mean aggregate of the input features over the in-edges (models.py:53-57 for layer 0:
+        `g.update_all(u_mul_e, sum)`, `ah * norm`) -- for every resident node.  It is page-local and does not change over a run,
+        so it is made ONCE here instead of once per step: the input layer then multiplies [x | ahn] straight from the two resident
+        images (gte_gemm_p3_nt_rows2) and its weight gradient needs no transpose aggregation (gte_gemm_p3_tn_rows2)."""
+        from . import ops
+        x = self.feat if x_f32 is None else x_f32
+        if x.shape[0] != self.n_nodes:
+            raise ValueError("build_agg_image needs the fp32 feature rows of every resident node")
+        indptr, indices, w = self.whole_in_csr()
+        if out is None:
+            out = ops.P3.empty(self.n_nodes, int(x.shape[1]), self.device, rows_cap=self.n_nodes + 1)
+            out.data[self.n_nodes:].zero_()                       # (the zero row the row maps' padding entries name)
+        ops.spmm_csr_p3(indptr, indices, w, x, self.n_nodes, mean=True, out=out)
+        self.agg_p3 = out
+        return out
+
+    def enable_p3(self, agg: bool = False) -> None:
         """Keep the features as a P3 image (three bf16 planes per value, csrc/p3.h: the operand format of the planes GEMMs)
         and assemble batches of image rows from now on: a batch then carries ``feat_p3`` instead of ``ndata['feat']``.
-        Called by the train loop when layer 0 of the step engine takes its input as an image."""
+        Called by the train loop when layer 0 of the step engine takes its input as an image.  ``agg``: also keep the image of the
+        input's mean aggregate (build_agg_image); batches then carry ``agg_p3`` behind the same row map."""
+        if agg and self.agg_p3 is None and self.feat.shape[0] == self.n_nodes:
+            self.build_agg_image()
         if self.feat_p3 is None:
             from . import ops
             # one row more than the set has nodes, zero: the row maps' padding entries name it (an image of 4 GB or more is
@@ -610,6 +647,8 @@ class ResidentPages:
         if rows is not None:
             from . import ops
             g.feat_p3 = ops.P3(self.feat_p3.data, n_out, f, row_map=rows, res_rows=self.n_nodes)
+            if self.agg_p3 is not None:
+                g.agg_p3 = ops.P3(self.agg_p3.data, n_out, f, row_map=rows, res_rows=self.n_nodes)
         elif p3:
             from . import ops
             g.feat_p3 = ops.P3(feat, n_out, f)           # no ndata['feat']: a consumer that needs fp32 rows fails loudly

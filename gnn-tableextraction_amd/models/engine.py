@@ -184,6 +184,10 @@ class FusedGcnSageStep(TrainStep):
         # ... for EVERY hidden width up to 1024 and any input width through the one-call plan (padded rows, masked LayerNorm
         # kernels, aggregate-first input layer, output layer on the planes GEMMs); GTE_PLANES_GENERAL=0: the tuned range only
         self.general_planes = os.environ.get("GTE_PLANES_GENERAL", "1") == "1"
+        # input layer on the CACHED mean aggregate of the input (graph.ResidentPages.build_agg_image: page-local, constant over a
+        # run): z = [x | ahn] W^T from two resident images behind the batch's row map, no aggregation / q / feature copy in the
+        # step for layer 0 (GTE_LAYER_CACHED).  Costs a second resident image; GTE_CACHE_AGG=0 turns it off
+        self.cache_input_agg = os.environ.get("GTE_CACHE_AGG", "1") == "1"
         self._wimg = {}                               # layer index -> (forward image, backward image or None)
         # one-call step: the fold + Adam launch also writes the weight images of the updated parameters
         # (gte_fold_defer_flush_adam_images) and the next step's forward skips their conversion launch.  _wimg_sig = the version
@@ -294,7 +298,7 @@ class FusedGcnSageStep(TrainStep):
         b["stats"] = [z32(2 * cap) for _ in range(nh)]
         b["ahn"] = [z32(cap, dims[0]) if kinds[i] == 1 else None for i in range(nh)]
         b["ahnp"] = [img(cap, dims[0]) if kinds[i] == 2 else None for i in range(nh)]
-        b["hp"] = [img(cap, dims[i]) if kinds[i] != 1 else None for i in range(nh)]
+        b["hp"] = [img(cap, dims[i]) if kinds[i] not in (1, 3) else None for i in range(nh)]      # (3: both operands are resident)
         b["dzp"] = [img(cap, dims[i + 1]) if kinds[i] != 1 else None for i in range(nh)]
         b["qp"] = [img(cap, dims[i + 1]) if kinds[i] == 0 else None for i in range(nh)]
         b["ws_dw"] = [u8(lib.gte_gemm_p3_tn_workspace_bytes(dims[i + 1], 2 * dims[i], dims[i], cap) if kinds[i] != 1
@@ -483,17 +487,33 @@ class FusedGcnSageStep(TrainStep):
                 and bool(self.lib.gte_sage_linear_fwd_fuses_ln(2 * fin, layer.out_feats))
                 and bool(self.lib.gte_sage_smallk_bwd_supported(2 * fin, layer.out_feats)))
 
-    def _layer_kind(self, i: int, L, fin: int, n: int = 0):
+    def _cached_layer0(self, L, fin: int) -> bool:
+        """Layer 0 can run on the cached mean aggregate of the input (GTE_LAYER_CACHED) when the batch brings it: any LayerNorm
+        layer with fin >= 16 on the planes path (the tuned one-pass kernels of the 13-feature input keep their path)."""
+        return (self.cache_input_agg and self.general_planes and self._planes_on() and isinstance(L.lynorm, nn.LayerNorm)
+                and L.linear.bias is not None and (L.activation is None or _is_relu(L.activation)) and fin >= 16
+                and L.out_feats <= 1024)
+
+    def wants_agg_image(self, f0: int) -> bool:
+        """True when the train loop should keep the image of the input's mean aggregate next to the feature image
+        (graph.ResidentPages.enable_p3(agg=True))."""
+        L = self.model.layers[0]
+        return len(self.model.layers) >= 2 and self._cached_layer0(L, f0) and self._layer_kind(0, L, f0) == 0
+
+    def _layer_kind(self, i: int, L, fin: int, n: int = 0, cached: bool = False):
         """How hidden layer i runs on the one-call plan (gte_step_layer.kind): 0 planes layer in transform-first order, 1 the
-        one-pass short-input layer (BBOX features), 2 aggregate-first planes input layer (fin < fout); None: not on the plan.
+        one-pass short-input layer (BBOX features), 2 aggregate-first planes input layer (fin < fout), 3 (``cached``: the batch
+        brings the resident image of the input's mean aggregate) the input layer on [x | ahn] from two resident images; None: not on the plan.
         Every shape the reference's runs produce is covered (run_multiple_train.sh:8-113: hidden 1000, or
         int(calculate_hidden) = 96 ... 218, with F0 = 13 ... 831): hidden widths up to 1024, any input width."""
         fout = L.out_feats
         if not (self._planes_on() and isinstance(L.lynorm, nn.LayerNorm) and L.linear.bias is not None
                 and (L.activation is None or _is_relu(L.activation))):
             return None
+        # (a layer 0 that takes its input as an image -- kind 0 -- moves to the cached form when the batch brings the second image)
+        up = 3 if (i == 0 and cached and self._cached_layer0(L, fin)) else 0
         if self._planes_layer(i, L, fin, n):
-            return 0                                             # the tuned range: 128 <= fout <= 256, fout % 16 == 0
+            return up                                            # the tuned range: 128 <= fout <= 256, fout % 16 == 0
         if (i == 0 and not self._transform_first(L, fin) and fout % 16 == 0
                 and bool(self.lib.gte_sage_linear_fwd_fuses_ln(2 * fin, fout)) and not ops.use_tiled(n, fin, None)):
             return 1
@@ -502,10 +522,11 @@ class FusedGcnSageStep(TrainStep):
         # transform-first while the layer does not widen by more than a quarter (the aggregation then moves fout columns: 1000
         # against 831 costs less than a per-batch fp32 copy of the input rows, and layer 0 reads the RESIDENT image through the row
         # map); aggregate-first for a widening input layer (13 / 63 / 313 / 363 -> 1000: aggregate fin columns)
-        return 0 if (i > 0 or 4 * fout <= 5 * fin) else 2
+        return up if (i > 0 or 4 * fout <= 5 * fin) else 2
 
-    def _plan_kinds(self, f0: int, n: int):
-        """Layer kinds of the one-call step (gte_gcnsage_step) or None when the configuration needs the call-by-call path."""
+    def _plan_kinds(self, f0: int, n: int, cached: bool = False):
+        """Layer kinds of the one-call step (gte_gcnsage_step) or None when the configuration needs the call-by-call path.
+        ``cached``: the batch carries ``agg_p3`` (the resident image of the input's mean aggregate behind its row map)."""
         layers = list(self.model.layers)
         if (not self.use_c_step or not self._planes_on() or len(layers) < 2 or len(layers) > 8 or ops._timers is not None):
             return None
@@ -519,7 +540,7 @@ class FusedGcnSageStep(TrainStep):
             return None
         kinds = []
         for i, L in enumerate(layers[:-1]):
-            k = self._layer_kind(i, L, dims[i], n)
+            k = self._layer_kind(i, L, dims[i], n, cached)
             if k is None:
                 return None
             # (the planes GEMMs address their output through 32-bit buffer offsets: [n][2 ld] fp32 must stay below 2 GB)
@@ -540,6 +561,11 @@ class FusedGcnSageStep(TrainStep):
         g.feat_p3 = ops.p3_from_f32(ops._row_major(x.to(torch.float32)))
         return True
 
+    @staticmethod
+    def _batch_cached(g) -> bool:
+        xp, ap = getattr(g, "feat_p3", None), getattr(g, "agg_p3", None)
+        return xp is not None and ap is not None and xp.row_map is not None and xp.data.numel() < (1 << 32) - (1 << 20)
+
     def _plan_mode(self, kinds, f0: int):
         """(general, out_gemm) of a plan: ``general`` = it runs on the padded buffer set (_alloc_gen) -- some hidden layer lies
         outside the tuned range or the output layer runs on the planes GEMMs; ``out_gemm`` = the latter (hidden width beyond the
@@ -548,7 +574,7 @@ class FusedGcnSageStep(TrainStep):
         dims = [f0] + [l.out_feats for l in layers]
         last = len(layers) - 1
         out_gemm = not (self._narrow(layers[last], dims[last]) and self._fused_head(last, layers[last], dims[last]))
-        gen = out_gemm or any(k == 2 or (k == 0 and not self._planes_layer(i, layers[i], dims[i])) for i, k in enumerate(kinds))
+        gen = out_gemm or any(k in (2, 3) or (k == 0 and not self._planes_layer(i, layers[i], dims[i])) for i, k in enumerate(kinds))
         return gen, out_gemm
 
     def _weight_images_gen(self, dims, kinds, out_gemm: bool):
@@ -585,7 +611,7 @@ class FusedGcnSageStep(TrainStep):
                     descs.append(_lib.P3Desc(wp, ldw, fin, fout, 1, bwd.data.data_ptr(), bwd.ldp))
                     descs.append(_lib.P3Desc(wp + 4 * fin, ldw, fin, fout, 1, bwd.data.data_ptr() + (ld // 16) * 96, bwd.ldp))
                 imgs[i] = (fwd, bwd)
-            elif k == 2:
+            elif k in (2, 3):
                 kp = _c16(fin)
                 fwd = img(fout, 2 * kp)
                 descs.append(_lib.P3Desc(wp, ldw, fout, fin, 0, fwd.data.data_ptr(), fwd.ldp))
@@ -657,8 +683,10 @@ class FusedGcnSageStep(TrainStep):
                 sl.wimg_fwd, sl.ldp_wfwd = P(wf.data), wf.ldp
                 if wb is not None:
                     sl.wimg_bwd, sl.ldp_wbwd = P(wb.data), wb.ldp
-                sl.hp, sl.ldp_h = P(b["hp"][i].data), b["hp"][i].ldp
                 sl.dzp, sl.ldp_o = P(b["dzp"][i].data), b["dzp"][i].ldp
+                if kinds[i] == 3:
+                    continue                                      # (both operand images are the batch's: bound per call)
+                sl.hp, sl.ldp_h = P(b["hp"][i].data), b["hp"][i].ldp
                 if kinds[i] == 0:
                     sl.qp = P(b["qp"][i].data)
                 else:
@@ -705,7 +733,14 @@ class FusedGcnSageStep(TrainStep):
         plan.fuse_ln_dx = (int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (8 if self.fuse_smallk_dx else 0)
                            | (4 if self.fuse_head_gemm else 0))
         L0 = plan.layer[0]
-        if kinds[0] == 0:
+        if kinds[0] == 3:
+            ap = getattr(g, "agg_p3", None)
+            if xp is None or ap is None or xp.row_map is None:
+                raise _lib.GteError("a cached-aggregate input layer needs a resident batch with feat_p3 and agg_p3 behind a row map")
+            L0.hp, L0.ldp_h, L0.make_hp, L0.x = P(xp.data), xp.ldp, 0, None
+            L0.ahnp, L0.ldp_ahn = P(ap.data), ap.ldp
+            L0.h_rows, L0.n_res_rows = P(xp.row_map), xp.res_rows
+        elif kinds[0] == 0:
             if xp is not None:
                 L0.hp, L0.ldp_h, L0.make_hp, L0.x = P(xp.data), xp.ldp, 0, None
                 L0.h_rows, L0.n_res_rows = (P(xp.row_map), xp.res_rows) if xp.row_map is not None else (None, 0)
@@ -887,7 +922,7 @@ class FusedGcnSageStep(TrainStep):
         features to a planes input layer (a validation graph: the plan would write their image first) -- run the module path."""
         xp = getattr(g, "feat_p3", None)
         n, f0 = (xp.rows, xp.cols) if xp is not None else g.ndata['feat'].shape
-        kinds = self._plan_kinds(f0, n) if n > 0 else None
+        kinds = self._plan_kinds(f0, n, self._batch_cached(g)) if n > 0 else None
         if kinds is not None and xp is None and kinds[0] == 0 and n * f0 > self.FORWARD_IMAGE_MAX_ELEMS:
             # fp32 features under a planes input layer: the one-call plan would first write their P3 image (65 us at 21.5 k x 831)
             # -- more than the call saves on a graph of this size; the module path multiplies the fp32 rows directly
@@ -917,7 +952,7 @@ class FusedGcnSageStep(TrainStep):
         if upto_layer == 0:
             xp = getattr(g, "feat_p3", None)
             n, f0 = (xp.rows, xp.cols) if xp is not None else g.ndata['feat'].shape
-            kinds = self._plan_kinds(f0, n)
+            kinds = self._plan_kinds(f0, n, self._batch_cached(g))
             if kinds is not None:
                 return self._c_step(g, labels, grad_scale, kinds, with_adam=bool(self._fuse_adam_req))
         return self._run(g, labels, grad_scale, len(self.model.layers) - 1, upto_layer, forward=True)

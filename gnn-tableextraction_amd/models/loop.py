@@ -188,7 +188,8 @@ def run_steps(step, pipe: BatchPipeline, page_steps: Sequence[np.ndarray], n_glo
         # layer 0 multiplies a P3 image (planes GEMMs): resident features and batches become images -- or back to fp32 rows when
         # the GEMM mode was switched; the buffer sets of the other kind are dropped
         torch.cuda.synchronize(pipe.device)
-        pipe.res.enable_p3() if want_p3 else pipe.res.disable_p3()
+        # (agg: layer 0 on the cached mean aggregate of the input -- a second resident image, engine.wants_agg_image)
+        pipe.res.enable_p3(agg=bool(getattr(step, "wants_agg_image", lambda f: False)(pipe.res.feat.shape[1]))) if want_p3 else pipe.res.disable_p3()
         pipe._sets = []
         pipe._free_ev = [None] * pipe.depth
     pipe.load(page_steps)

@@ -133,7 +133,7 @@ def predict_resident(engine, pipe, batch_pages: int, page_ids=None) -> torch.Ten
     want_p3 = bool(engine.wants_p3_features(f0))
     if want_p3 != bool(res.p3_mode):                       # as loop.run_steps: layer 0 reads the resident feature image
         torch.cuda.synchronize(pipe.device)
-        res.enable_p3() if want_p3 else res.disable_p3()
+        res.enable_p3(agg=bool(engine.wants_agg_image(f0))) if want_p3 else res.disable_p3()
         pipe._sets, pipe._free_ev = [], [None] * pipe.depth
     pipe.load(steps)
     total = sum(pipe.nodes(s) for s in range(len(steps)))

@@ -250,6 +250,19 @@ def spmm_csr(indptr, indices, weight, x: torch.Tensor, n_rows: int, mean: bool =
     return out
 
 
+def spmm_csr_p3(indptr, indices, weight, x: torch.Tensor, n_rows: int, mean: bool = False, out: Optional["P3"] = None) -> "P3":
+    """The aggregation written straight as a P3 image (gte_spmm_csr_p3): out[v] = (1 / in_deg(v) if mean) sum_e w_e x[src(e)]."""
+    require_device(x, "spmm_csr_p3")
+    lib = _lib.load()
+    x = _row_major(x)
+    f = x.shape[1]
+    if out is None:
+        out = P3.empty(n_rows, f, x.device)
+    check(lib.gte_spmm_csr_p3(ptr(indptr), ptr(indices), ptr(weight), ptr(x), _ld(x), ptr(out.data), out.ldp, n_rows, f,
+                              _lib.REDUCE_MEAN if mean else _lib.REDUCE_SUM, current_stream()), "gte_spmm_csr_p3")
+    return out
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
          out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """C = op(A) op(B) in fp32 on the MFMA path.  ``a``/``b`` are the STORED matrices."""

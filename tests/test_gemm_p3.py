@@ -197,6 +197,49 @@ def test_tn_through_a_row_map_is_bitwise_the_gathered_gemm(rows64, rows, k, m):
     assert torch.equal(ops.gemm_p3_tn(dz, mapped2), ops.gemm_p3_tn(dz, mapped2.gathered()))
 
 
+@pytest.mark.parametrize("rows,k,n", [(24437, 831, 256), (3000, 831, 96), (3000, 363, 160), (100, 313, 1000), (1, 48, 256), (6001, 781, 112)])
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 5, 6])
+def test_nt_with_two_resident_images_behind_one_row_map(monkeypatch, rows, k, n, cfg):
+    """z = [x | ahn][rows] W^T + b (gte_gemm_p3_nt_rows2: the input layer on its features and their cached mean aggregate) is bit for
+    bit the two-segment product on the gathered rows; every tile configuration."""
+    if cfg is not None:
+        if rows != 3000 or k != 831:
+            pytest.skip("forced tile shapes: one problem size")
+        monkeypatch.setenv("GTE_P3_NT_CFG", str(cfg))
+    n_res = 30000
+    g = torch.Generator(device=DEV).manual_seed(rows + 7)
+    res1 = _resident_image(torch.randn(n_res, k, device=DEV, generator=g))
+    res2 = _resident_image(torch.randn(n_res, k, device=DEV, generator=g))
+    kp = -(-k // 16) * 16
+    wb = torch.zeros(n, 2 * kp, device=DEV)
+    wb[:, :k], wb[:, kp:kp + k] = torch.randn(n, k, device=DEV, generator=g), torch.randn(n, k, device=DEV, generator=g)
+    w = ops.P3(ops.p3_from_f32(wb).data, n, 2 * kp)
+    bias = torch.randn(n, device=DEV, generator=g)
+    rm = _row_map(n_res, rows, rows)
+    m1 = ops.P3(res1.data, rows, k, row_map=rm, res_rows=n_res)
+    m2 = ops.P3(res2.data, rows, k, row_map=rm, res_rows=n_res)
+    want = ops.gemm_p3_nt(m1.gathered(), w, a2=m2.gathered(), bias=bias)
+    got = ops.gemm_p3_nt(m1, w, a2=m2, bias=bias)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("rows,k,m", [(24437, 831, 256), (3000, 831, 96), (100, 363, 160), (17, 48, 256), (6001, 781, 100)])
+def test_tn_with_two_resident_images_behind_one_row_map(rows64, rows, k, m):
+    """dW0 = [dz^T x | dz^T ahn] with x / ahn = mapped rows of two resident images (gte_gemm_p3_tn_rows2), 32-bit offsets and 64-bit
+    addresses: bit for bit the product on the gathered rows."""
+    n_res = 30000
+    g = torch.Generator(device=DEV).manual_seed(rows + 3)
+    res1 = _resident_image(torch.randn(n_res, k, device=DEV, generator=g))
+    res2 = _resident_image(torch.randn(n_res, k, device=DEV, generator=g))
+    dz = ops.p3_from_f32(torch.randn(rows, m, device=DEV, generator=g))
+    rm = _row_map(n_res, rows, rows + 1)
+    m1 = ops.P3(res1.data, rows, k, row_map=rm, res_rows=n_res)
+    m2 = ops.P3(res2.data, rows, k, row_map=rm, res_rows=n_res)
+    want = ops.gemm_p3_tn(dz, m1.gathered(), b2=m2.gathered(), two_segments=True)
+    got = ops.gemm_p3_tn(dz, m1, b2=m2, two_segments=True)
+    assert torch.equal(got, want)
+
+
 def test_row_map_entry_points_validate():
     lib = _lib.load()
     z = torch.zeros(64, 96, dtype=torch.uint8, device=DEV)

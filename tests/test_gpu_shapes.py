@@ -250,8 +250,10 @@ def _resident(pages, tr, f0):
     return G.ResidentPages(graphs, DEV)
 
 
-@pytest.mark.parametrize("f0,hid,n_pages", [(831, 256, 100), (831, 96, 40), (63, 1000, 16), (13, 218, 40), (831, 1000, 12)])
-def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages):
+@pytest.mark.parametrize("cached", [True, False], ids=["cached_agg", "no_cache"])
+@pytest.mark.parametrize("f0,hid,n_pages", [(831, 256, 100), (831, 96, 40), (63, 1000, 16), (13, 218, 40), (831, 1000, 12), (781, 100, 40),
+                                            (313, 157, 40)])
+def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages, cached):
     """The path ``bench.py`` and ``train()`` run -- ResidentPages (features as a P3 image + row map where layer 0 takes one),
     BatchPipeline, run_steps, the one-call step with Adam in the fold launch -- for ONE step on n_pages pages against the CPU
     oracle's step on the same pages: logits 1e-5 (forward_logits on the assembled batch), loss 1e-5, every gradient 1e-4,
@@ -283,9 +285,16 @@ def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages):
     def on_step(s, g, out3):
         seen["n"] = g.num_nodes()
     # forward only, on the batch the pipeline assembles (row-map batch in image mode)
+    # ``cached``: layer 0 on the resident image of the input's mean aggregate (GTE_LAYER_CACHED: what run_steps sets up by
+    # default); False: the image is not built, layer 0 aggregates in the step
+    fused.cache_input_agg = cached
+    if cached and not fused.wants_agg_image(f0):
+        pytest.skip("layer 0 of this shape does not take resident images")
     if fused.wants_p3_features(f0):
-        res.enable_p3()
-        assert res.p3_mode == "rows"
+        res.enable_p3(agg=cached)
+        assert res.p3_mode == "rows" and (res.agg_p3 is not None) == cached
+        b0 = res.batch(ids)
+        assert fused._plan_kinds(f0, n, fused._batch_cached(b0))[0] == (3 if cached else 0)
     logits = fused.forward_logits(res.batch(ids)).cpu().numpy()
     np.testing.assert_allclose(logits, want_logits, rtol=1e-5, atol=1e-5)
     out3 = run_steps(fused, pipe, [ids], on_step=on_step)
@@ -303,6 +312,7 @@ def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages):
             # most three such rows, each within 1e-3 of the tensor's largest entry; everything else at 1e-4.
             # (the feature's entry of the bias / LayerNorm gradients moves with it)
             rows = np.unique(np.nonzero(bad)[0])
+            print(f"ReLU-mask branch: ({f0}, {hid}) {k}: {int(bad.sum())} entries in rows {rows.tolist()} beyond 1e-4")
             assert rows.size <= 3 and np.abs(got - ref)[rows].max() <= 1e-3 * np.abs(ref).max(), \
                 f"{k}: {int(bad.sum())} entries in {rows.size} rows differ (max {np.abs(got - ref).max():.3e})"
     params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
@@ -533,3 +543,29 @@ def _windowed_vs_resident(f0, hid, delay):
     assert len(losses_w) == len(losses_r) == n_steps
     assert torch.equal(torch.cat(losses_w), torch.cat(losses_r))
     assert torch.equal(tr.flat_param, tr2.flat_param) and torch.equal(tr.exp_avg_sq, tr2.exp_avg_sq)
+
+
+@pytest.mark.parametrize("f0", [831, 63, 16])
+def test_resident_agg_image_is_the_mean_aggregate_of_every_page(f0):
+    """ResidentPages.build_agg_image: the P3 image of norm . A_w x over all resident pages (made once; the cached operand of
+    GTE_LAYER_CACHED) holds exactly the fp32 values gte_spmm_csr (mean) computes on the batched graph of all pages -- which is
+    pinned on the oracle -- and row n_nodes of the allocation is zero."""
+    pages = S.make_pages(23, in_feats=f0)
+    graphs = []
+    for p in pages:
+        g = gte.PageGraph(p.src, p.dst, p.num_nodes)
+        g.ndata["feat"], g.ndata["label"] = torch.from_numpy(p.feat), torch.from_numpy(p.label.astype(np.float32))
+        g.edata["feat"] = torch.from_numpy(p.weight)
+        graphs.append(g)
+    res = G.ResidentPages(graphs, DEV)
+    img = res.build_agg_image()
+    whole = res.batch(np.arange(len(pages)))
+    csr = whole.in_csr()
+    want = ops.spmm_csr(csr.indptr, csr.indices, whole.in_weights(None), res.feat, res.n_nodes, mean=True)
+    got = ops.p3_to_f32(ops.P3(img.data, res.n_nodes, f0))
+    assert torch.equal(got, want)
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    ref = oc.OracleGraph(src, dst, int(off[-1]), w)
+    ah = oc._SpMM.apply(torch.from_numpy(feat), ref) * torch.from_numpy(ref.norm)            # models.py:53-57, 74-78
+    np.testing.assert_allclose(got.cpu().numpy(), ah.numpy(), rtol=1e-5, atol=1e-5 * float(np.abs(feat).max()))
+    assert img.data.shape[0] == res.n_nodes + 1 and not img.data[res.n_nodes].any()

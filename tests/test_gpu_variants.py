@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 ENGINE_SWITCHES = ["GTE_C_STEP=0", "GTE_P3_ROWS=0", "GTE_FUSE_ADAM=0", "GTE_TAIL_SPLIT=0", "GTE_FUSED_HEAD=0", "GTE_TRANSFORM_FIRST=0",
                    "GTE_PIPE_LATE=0", "GTE_FUSE_LN_FWD=0", "GTE_FUSE_LN_DX=0", "GTE_FUSE_LN_NARROW=0", "GTE_FUSE_SMALLK_DX=0",
-                   "GTE_WIMG_IN_FOLD=0", "GTE_PLANES=0", "GTE_PLANES_GENERAL=0", "GTE_FUSE_HEAD_GEMM=0", "GTE_C_STEP=0 GTE_FUSE_LN_DX=0",
+                   "GTE_WIMG_IN_FOLD=0", "GTE_CACHE_AGG=0", "GTE_PLANES=0", "GTE_PLANES_GENERAL=0", "GTE_FUSE_HEAD_GEMM=0", "GTE_C_STEP=0 GTE_FUSE_LN_DX=0",
                    "GTE_C_STEP=0 GTE_FUSE_LN_NARROW=0"]
 LIBRARY_SWITCHES = ["GTE_SMALLK=0", "GTE_SMALLK_BWD=0", "GTE_NARROW_FWD16=0", "GTE_GEMM_MODE=f32", "GTE_P3_ROWS64=1"]
 CONFIGS = [(831, 256, True), (13, 256, False), (63, 200, False)]      # (F0, hidden, class weights)
@@ -48,9 +48,8 @@ def train_three_steps():
         cw = torch.linspace(0.5, 2.0, 9, device=dev) if weighted else None
         tr = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4, class_weights=cw)
         res = G.ResidentPages(graphs, dev)
-        if tr.wants_p3_features(f0):
-            res.enable_p3()                                        # (as train() and bench.py do: batches are row maps into the image)
-        pipe = BatchPipeline(res)
+        pipe = BatchPipeline(res)          # (run_steps turns the resident features into images -- and, by default, caches the
+                                           # input's mean aggregate next to them -- as train() and bench.py get it)
         losses = []
         steps = [np.array([(4 * s + j) % 14 for j in range(7)]) for s in range(3)]
         run_steps(tr, pipe, steps, on_step=lambda s, g, o: losses.append(o[:1].clone()))
