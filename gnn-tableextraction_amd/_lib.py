@@ -112,6 +112,13 @@ SIGNATURES = {
                                      c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "gte_gemm_p3_tn_rows2": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                      c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gte_gemm_p3_nt_ln_fwd_supported": (c_int, [c_int64]),
+    "gte_gemm_p3_nt_ln_fwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                      c_int64, c_int64, c_void_p]),
+    "gte_gemm_p3_nt_rows2_ln_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                            c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                            c_void_p, c_int64, c_int64, c_void_p]),
     "gte_gemm_p3_set_rows64": (c_int, [c_int]),
     "gte_head_dlq_finish_workspace_bytes": (c_int64, [c_int64]),
     "gte_head_dlq_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_float, c_void_p,

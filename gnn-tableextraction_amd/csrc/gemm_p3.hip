@@ -72,6 +72,10 @@ struct P3Gemm {
     // and leaves the column partials {sum g xhat, sum g, sum dz} in ln_part[tile][3][N]  (gte_gemm_p3_nt_ln_bwd)
     const float* ln_z; long long ln_ldz; const float* ln_stats; const float* ln_gamma; const float* ln_beta; int ln_relu;
     float* ln_dz; long long ln_lddz; char* ln_dzp3; long long ln_ldp3; float* ln_part;
+    // LayerNorm(+ReLU) FORWARD as the epilogue of an NT product whose tile holds whole rows (N <= 256; gte_gemm_p3_nt_ln_fwd): the
+    // workgroup writes z = product + bias (fp32, to C: the backward's operand), the row statistics, y = relu?(LN(z)) as fp32
+    // (nullable) and as a P3 image (nullable); gamma / beta / relu in the ln_* fields above
+    float* lnf_y; long long lnf_ldy; char* lnf_yp3; long long lnf_ldp; float* lnf_stats; float lnf_eps;
     // ... or the WHOLE backward of a short-input layer below (gte_gemm_p3_nt_smallk_bwd): z recomputed from its k1 + k2 <= 28 inputs,
     // LayerNorm backward, dW = dz^T [x | ahn] accumulated per lane; outputs: sk_part_dw[tile][N][K], ln_part[tile][3][N]
     const float* sk_x; long long sk_ldx; int sk_k1; const float* sk_ahn; long long sk_ldahn; int sk_k2;
@@ -665,6 +669,80 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
     if constexpr (LNB == 0) {
         store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
                            p.accumulate, lane);
+    } else if constexpr (LNB == 4) {
+        // ---- LayerNorm(+ReLU) FORWARD of the tile's rows: z = product + bias goes to LDS row-major per slice of TM * 32 rows, then
+        // every wave takes rows of the slice in the layout and with the arithmetic of ln_relu_fwd_gen_kernel<1, .> (lane l = columns
+        // 4 l .. 4 l + 3, two-pass statistics over the n true columns): z, stats, y and the image are bit for bit what
+        // gte_gemm_p3_nt + gte_ln_relu_fwd_p3 write ----
+        asm volatile("s_barrier" ::: "memory");
+        static_assert(BN == 256 && TN == 2, "whole rows per workgroup");
+        constexpr int SR = TM * 32, LDT = 256;
+        float* tile = reinterpret_cast<float*>(lds);
+        const int n = p.N, M = p.M;
+        const int j4 = 4 * lane;
+        const int n16 = (n + 15) & ~15;
+        const bool okc = j4 < n, imc = j4 < n16;
+        float gam[4], bet[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gam[e] = j4 + e < n ? p.ln_gamma[j4 + e] : 0.f; bet[e] = j4 + e < n ? p.ln_beta[j4 + e] : 0.f; }
+        const float inv_n = 1.0f / (float)n;
+        const int col_l = lane & 31, hrow = (lane >> 5) * 4;
+        float bv[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = wn * 64 + b * 32 + col_l;
+            bv[b] = (p.bias && col < n) ? p.bias[col] : 0.f;
+        }
+        for (int sl = 0; sl < WM; ++sl) {
+            asm volatile("s_barrier" ::: "memory");                    // the previous slice's readers are done
+            if (wm == sl) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            tile[(a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * LDT + wn * 64 + b * 32 + col_l] = acc[a][b][r] + bv[b];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int row_base = m0 + sl * SR;
+            for (int rl = wave; rl < SR; rl += NW) {
+                const long long rg = row_base + rl;
+                if (rg >= M) break;                                     // wave-uniform
+                float c[4] = {0.f, 0.f, 0.f, 0.f};
+                if (okc) {
+                    const float4 t = *reinterpret_cast<const float4*>(tile + rl * LDT + j4);
+                    c[0] = t.x; c[1] = j4 + 1 < n ? t.y : 0.f; c[2] = j4 + 2 < n ? t.z : 0.f; c[3] = j4 + 3 < n ? t.w : 0.f;
+                }
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += c[e];
+                const float mean = gte_group_sum<64>(s) * inv_n;
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = j4 + e < n ? c[e] - mean : 0.f; q = fmaf(d, d, q); }
+                const float rstd = rsqrtf(gte_group_sum<64>(q) * inv_n + p.lnf_eps);
+                if (p.lnf_stats && lane == 0) { p.lnf_stats[rg] = mean; p.lnf_stats[M + rg] = rstd; }
+                if (okc) {                                              // z: the operand of the layer's LayerNorm backward
+                    f4u o; o.x = c[0]; o.y = c[1]; o.z = c[2]; o.w = c[3];
+                    *reinterpret_cast<f4u*>(p.C + rg * p.ldc + j4) = o;
+                }
+                if (imc) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = fmaf((c[e] - mean) * rstd, gam[e], bet[e]);
+                        if (p.ln_relu) o[e] = fmaxf(o[e], 0.f);
+                        if (j4 + e >= n) o[e] = 0.f;
+                    }
+                    if (p.lnf_y && okc) {
+                        f4u t; t.x = o[0]; t.y = o[1]; t.z = o[2]; t.w = o[3];
+                        *reinterpret_cast<f4u*>(p.lnf_y + rg * p.lnf_ldy + j4) = t;
+                    }
+                    if (p.lnf_yp3) p3::store4(p.lnf_yp3 + rg * p.lnf_ldp, j4, o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
     } else {
         // ---- LayerNorm(+ReLU) backward of the tile's rows (the stage images are dead once the loader waves' last requests have
         // landed: they wait for them and join this barrier before they leave) ----
@@ -1399,6 +1477,65 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
             hipLaunchKernelGGL(p3_colsum_fold_kernel, dim3((unsigned)gte::ceil_div(n, 256)), dim3(256), 0, s, p.ln_part + i * n,
                                (long long)3 * n, nb, (int)n, outs[i]);
     return gte::check_launch("gemm_p3_nt_ln_bwd fold");
+}
+
+// ---- the NT product with LayerNorm(+ReLU) FORWARD as its epilogue ------------------------------------------------------------
+// z = [a1 | a2] b^T + bias (m x n, n <= 256: a workgroup's tile holds whole rows) is written as fp32 (the operand of the layer's
+// LayerNorm backward), and the workgroup that computed a row block normalises it: stats (mean, rstd), y = relu?(LN(z)) as fp32
+// (nullable) and as a P3 image (nullable).  Bit-identical to gte_gemm_p3_nt + gte_ln_relu_fwd_p3 (one launch, the z read-back and
+// the LayerNorm launch gone).  Rows of z / y padded to a multiple of 4 floats.
+static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, const void* a2, int64_t lda2, int64_t k2, const int32_t* a_rows,
+                                  int64_t n_res_rows, const void* b, int64_t ldb, const float* bias, const float* gamma,
+                                  const float* beta, float eps, int relu, float* z, int64_t ldz, float* y, int64_t ldy, void* yp3,
+                                  int64_t ldyp3, float* stats, int64_t m, int64_t n, void* stream) {
+    if (m < 0 || n <= 0 || n > 256 || k1 <= 0 || k2 < 0 || m > INT32_MAX || k1 > INT32_MAX || k2 > INT32_MAX)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_fwd: bad sizes (n <= 256)");
+    if (m == 0) return GTE_OK;
+    if (!a1 || !b || !z || !gamma || !beta || (!y && !yp3) || (k2 > 0 && !a2))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_fwd: null pointer");
+    const int64_t kb1 = p3::blocks(k1), kb2 = k2 > 0 ? p3::blocks(k2) : 0, n4 = gte::round_up(n, 4);
+    if (lda1 < kb1 * 96 || (k2 > 0 && lda2 < kb2 * 96) || ldb < (kb1 + kb2) * 96 || ldz < n4 || (y && ldy < n4) ||
+        (yp3 && (ldyp3 < p3::row_bytes(n) || ldyp3 % 16 != 0)))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_fwd: leading dimension too small (rows of z / y padded to 4 floats)");
+    if (lda1 >= (1 << 22) || lda2 >= (1 << 22) || ldb >= (1 << 22))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_fwd: row strides must be < 4 MB");
+    P3Gemm p = {};
+    p.A1 = (const char*)a1; p.lda1 = lda1; p.KB1 = (int)kb1;
+    p.A2 = k2 > 0 ? (const char*)a2 : nullptr; p.lda2 = lda2; p.KB2 = (int)kb2;
+    p.B = (const char*)b; p.ldb = ldb; p.C = z; p.ldc = ldz; p.bias = bias;
+    p.bsa1 = p.bsa2 = p.bsb = 96;
+    p.M = (int)m; p.N = (int)n; p.splits = 1;
+    p.ln_gamma = gamma; p.ln_beta = beta; p.ln_relu = relu;
+    p.lnf_y = y; p.lnf_ldy = ldy; p.lnf_yp3 = reinterpret_cast<char*>(yp3); p.lnf_ldp = ldyp3; p.lnf_stats = stats; p.lnf_eps = eps;
+    if (a_rows) {
+        if (n_res_rows <= 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_fwd: empty resident image");
+        p.rowsA = a_rows; p.res_bytes = n_res_rows * lda1;
+        if (k2 > 0) { p.rows_both = 1; p.res_bytes2 = n_res_rows * lda2; }
+        if (rows64_needed(p.res_bytes) || (k2 > 0 && rows64_needed(p.res_bytes2)))
+            return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_fwd: resident images must stay below 4 GB (32-bit row offsets)");
+    } else if ((m + 256) * lda1 >= ((int64_t)1 << 31) || (k2 > 0 && (m + 256) * lda2 >= ((int64_t)1 << 31))) {
+        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_fwd: operand images must be < 2 GB");
+    }
+    launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
+    return gte::check_launch("gemm_p3_nt_ln_fwd");
+}
+extern "C" int gte_gemm_p3_nt_ln_fwd_supported(int64_t n) { return (n >= 1 && n <= 256) ? 1 : 0; }
+extern "C" int gte_gemm_p3_nt_ln_fwd(const void* a1, int64_t lda1, int64_t k1, const void* a2, int64_t lda2, int64_t k2, const void* b,
+                                     int64_t ldb, const float* bias, const float* gamma, const float* beta, float eps, int relu, float* z,
+                                     int64_t ldz, float* y, int64_t ldy, void* yp3, int64_t ldyp3, float* stats, int64_t m, int64_t n,
+                                     void* stream) {
+    return gemm_p3_nt_ln_fwd_impl(a1, lda1, k1, a2, lda2, k2, nullptr, 0, b, ldb, bias, gamma, beta, eps, relu, z, ldz, y, ldy, yp3, ldyp3,
+                                  stats, m, n, stream);
+}
+// ... with [A | A2] = the rows a_rows[0 .. m) of two resident images of k columns each (gte_gemm_p3_nt_rows2): the whole forward of
+// an input layer on its features and their cached mean aggregate in ONE launch
+extern "C" int gte_gemm_p3_nt_rows2_ln_fwd(const void* a_res, int64_t ldpa, const void* a2_res, int64_t ldpa2, int64_t k,
+                                           const int32_t* a_rows, int64_t n_res_rows, const void* b, int64_t ldb, const float* bias,
+                                           const float* gamma, const float* beta, float eps, int relu, float* z, int64_t ldz, float* y,
+                                           int64_t ldy, void* yp3, int64_t ldyp3, float* stats, int64_t m, int64_t n, void* stream) {
+    if (!a_rows || !a2_res) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_rows2_ln_fwd: null row map / second image");
+    return gemm_p3_nt_ln_fwd_impl(a_res, ldpa, k, a2_res, ldpa2, k, a_rows, n_res_rows, b, ldb, bias, gamma, beta, eps, relu, z, ldz, y, ldy,
+                                  yp3, ldyp3, stats, m, n, stream);
 }
 
 // ---- ... with the WHOLE backward of a short-input layer below (gte_sage_smallk_bwd) as its epilogue --------------------------

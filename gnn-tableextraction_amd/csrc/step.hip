@@ -61,6 +61,12 @@ int forward_hidden(const gte_step_plan& p, void* st, bool fwd_only = false) {
             GTE_TRY(gte_p3_from_f32(L.x, L.ldx, n, L.fin, 0, L.hp, L.ldp_h, st));
             GTE_TRY(gte_spmm_csr_p3(p.indptr, p.indices, p.w_in, L.x, L.ldx, L.ahnp, L.ldp_ahn, n, L.fin, GTE_REDUCE_MEAN, st));
             mark(2 * i);
+            if ((p.fuse_ln_dx & 16) && gte_gemm_p3_nt_ln_fwd_supported(L.fout)) {      // LayerNorm + ReLU as the GEMM's epilogue
+                GTE_TRY(gte_gemm_p3_nt_ln_fwd(L.hp, L.ldp_h, L.fin, L.ahnp, L.ldp_ahn, L.fin, L.wimg_fwd, L.ldp_wfwd, L.bias, L.gamma, L.beta,
+                                              L.eps, L.relu, L.t, ld, L.y, ld, L.yp, L.ldp_y, L.stats, n, L.fout, st));
+                mark(2 * i + 1);
+                continue;
+            }
             GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, L.ahnp, L.ldp_ahn, L.fin, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, ld, n, L.fout,
                                    0, 0, st));
             mark(2 * i + 1);
@@ -71,10 +77,17 @@ int forward_hidden(const gte_step_plan& p, void* st, bool fwd_only = false) {
             // z = [x | ahn] W^T + b with x AND its mean aggregate read from their RESIDENT images through the batch's row map (the
             // aggregate of the input is page-local and constant: cached when the pages were loaded), then LayerNorm + ReLU
             mark(2 * i);
+            float* const y3 = (fwd_only && L.yp) ? nullptr : L.y;
+            if ((p.fuse_ln_dx & 16) && gte_gemm_p3_nt_ln_fwd_supported(L.fout)) {      // the layer's whole forward in ONE launch
+                GTE_TRY(gte_gemm_p3_nt_rows2_ln_fwd(L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd, L.ldp_wfwd,
+                                                    L.bias, L.gamma, L.beta, L.eps, L.relu, L.t, ld, y3, ld, L.yp, L.ldp_y, L.stats, n,
+                                                    L.fout, st));
+                mark(2 * i + 1);
+                continue;
+            }
             GTE_TRY(gte_gemm_p3_nt_rows2(L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd, L.ldp_wfwd, L.bias,
                                          L.fout, L.t, ld, n, L.fout, 0, 0, st));
             mark(2 * i + 1);
-            float* const y3 = (fwd_only && L.yp) ? nullptr : L.y;
             GTE_TRY(gte_ln_relu_fwd_p3(L.t, ld, L.gamma, L.beta, L.eps, L.relu, y3, ld, L.yp, L.ldp_y, L.stats, n, L.fout, st));
             continue;
         }

@@ -734,7 +734,7 @@ class FusedGcnSageStep(TrainStep):
         # per call: switches and class weights (public attributes), the graph, the features
         plan.class_weights = P(self.class_weights)
         plan.fuse_ln_dx = (int(self.fuse_ln_dx) | (2 if self.fuse_ln_narrow else 0) | (8 if self.fuse_smallk_dx else 0)
-                           | (4 if self.fuse_head_gemm else 0))
+                           | (4 if self.fuse_head_gemm else 0) | (16 if self.fuse_ln_fwd else 0))
         L0 = plan.layer[0]
         if kinds[0] == 3:
             ap = getattr(g, "agg_p3", None)

@@ -678,6 +678,26 @@ def gemm_p3_nt(a1: P3, b: P3, a2: Optional[P3] = None, bias: Optional[torch.Tens
     return out
 
 
+def gemm_p3_nt_ln_fwd(a1: P3, b: P3, a2: Optional[P3], bias, gamma, beta, eps: float, relu: bool, z: torch.Tensor,
+                      y: Optional[torch.Tensor] = None, yp3: Optional[P3] = None, stats: Optional[torch.Tensor] = None):
+    """z = [a1 | a2] b^T + bias and its LayerNorm(+ReLU) in one launch (gte_gemm_p3_nt_ln_fwd / ..._rows2_ln_fwd for two row-mapped
+    resident images): z fp32, stats [2 m], y fp32 and / or P3 image."""
+    lib = _lib.load()
+    m, n = a1.rows, b.rows
+    common = (ptr(bias), ptr(gamma), ptr(beta), float(eps), int(relu), ptr(z), _ld(z), ptr(y), 0 if y is None else _ld(y),
+              ptr(yp3.data) if yp3 is not None else None, yp3.ldp if yp3 is not None else 0, ptr(stats), m, n, current_stream())
+    if a1.row_map is not None:
+        if a2 is None or a2.row_map is None:
+            raise ValueError("gemm_p3_nt_ln_fwd: row-mapped operands come as two resident images")
+        check(lib.gte_gemm_p3_nt_rows2_ln_fwd(ptr(a1.data), a1.ldp, ptr(a2.data), a2.ldp, a1.cols, ptr(a1.row_map), a1.res_rows, ptr(b.data),
+                                              b.ldp, *common), "gte_gemm_p3_nt_rows2_ln_fwd")
+    else:
+        check(lib.gte_gemm_p3_nt_ln_fwd(ptr(a1.data), a1.ldp, a1.cols, ptr(a2.data) if a2 is not None else None,
+                                        a2.ldp if a2 is not None else 0, a2.cols if a2 is not None else 0, ptr(b.data), b.ldp, *common),
+              "gte_gemm_p3_nt_ln_fwd")
+    return z
+
+
 def gemm_p3_nt_ln_bwd(a1: P3, b: P3, a2: Optional[P3], z: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                       relu: bool, dz: torch.Tensor, dzp3: Optional[P3] = None, dgamma=None, dbeta=None, dbias=None) -> torch.Tensor:
     """dz = LN'(z)(mask . ([a1 | a2] b^T)) without storing the product (gte_gemm_p3_nt_ln_bwd): the backward GEMM that produces

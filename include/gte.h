@@ -353,6 +353,20 @@ int gte_gemm_p3_nt_rows(const void* a_res, int64_t ldpa, int64_t k, const int32_
 int gte_gemm_p3_nt_rows2(const void* a_res, int64_t ldpa, const void* a2_res, int64_t ldpa2, int64_t k, const int32_t* a_rows,
                          int64_t n_res_rows, const void* b, int64_t ldpb, const float* bias, int64_t bias_cols, float* c, int64_t ldc,
                          int64_t m, int64_t n, int relu, int accumulate, void* stream);
+/* gte_gemm_p3_nt + gte_ln_relu_fwd_p3 in ONE launch (n <= 256: a workgroup's tile holds whole rows): z = [a1 | a2] b^T + bias is
+ * written as fp32 (ldz >= n rounded up to 4: the operand of the layer's LayerNorm backward) and normalised by the workgroup that
+ * computed it -- models.py:63-66 `linear`, `lynorm`, `activation` of an aggregate-first layer: stats = {mean [m], rstd [m]}, y =
+ * relu?(LN(z)) as fp32 (nullable) and as a P3 image (nullable; columns up to the next multiple of 16 zero).  Bit-identical to the two
+ * launches.  ..._rows2_...: [a1 | a2] = mapped rows of two resident images (gte_gemm_p3_nt_rows2). */
+int gte_gemm_p3_nt_ln_fwd_supported(int64_t n);
+int gte_gemm_p3_nt_ln_fwd(const void* a1, int64_t ldpa1, int64_t k1, const void* a2, int64_t ldpa2, int64_t k2, const void* b,
+                          int64_t ldpb, const float* bias, const float* gamma, const float* beta, float eps, int relu, float* z,
+                          int64_t ldz, float* y, int64_t ldy, void* yp3, int64_t ldyp3, float* stats, int64_t m, int64_t n,
+                          void* stream);
+int gte_gemm_p3_nt_rows2_ln_fwd(const void* a_res, int64_t ldpa, const void* a2_res, int64_t ldpa2, int64_t k, const int32_t* a_rows,
+                                int64_t n_res_rows, const void* b, int64_t ldpb, const float* bias, const float* gamma,
+                                const float* beta, float eps, int relu, float* z, int64_t ldz, float* y, int64_t ldy, void* yp3,
+                                int64_t ldyp3, float* stats, int64_t m, int64_t n, void* stream);
 /* gte_gemm_p3_nt (no bias / relu / accumulate) whose product dy [m][n], n <= 256, is NOT stored: the workgroup that computed a
  * block of rows runs the LayerNorm(+ReLU) backward of those rows on it (models.py:64-66 autograd of the layer below): dz as fp32
  * and as a P3 image (dzp3 nullable), column sums dgamma / dbeta / dbias (nullable) into the fold deferral.  z / stats / gamma /
@@ -481,7 +495,9 @@ typedef struct gte_step_plan {
     int fuse_ln_dx;                        /* bit 0: dX of a PLANES layer above a PLANES layer runs gte_gemm_p3_nt_ln_bwd;
                                               bit 1: the output layer's backward runs gte_sage_narrow_bwd_ln_p3;
                                               bit 2: the GEMM output layer (out_gemm) runs gte_head_agg_ce + gte_head_dlq_finish;
-                                              bit 3: dX of layer 1 above a SMALLK layer 0 runs gte_gemm_p3_nt_smallk_bwd      */
+                                              bit 3: dX of layer 1 above a SMALLK layer 0 runs gte_gemm_p3_nt_smallk_bwd;
+                                              bit 4: an AGGFIRST / CACHED input layer with fout <= 256 runs its LayerNorm forward as
+                                                     the epilogue of its GEMM (gte_gemm_p3_nt[_rows2]_ln_fwd)                  */
     int wimg_fresh;                        /* the weight images already hold the current parameters: the forward skips their
                                               conversion launch (set by the caller after a step that returned *adam_fused & 2) */
     int wimg_in_fold;                      /* the fold + Adam launch also writes the weight images of the UPDATED parameters

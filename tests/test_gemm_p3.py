@@ -240,6 +240,49 @@ def test_tn_with_two_resident_images_behind_one_row_map(rows64, rows, k, m):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("m,n,k", [(24437, 256, 831), (3000, 218, 13), (3000, 96, 363), (700, 100, 781), (100, 139, 63), (1, 5, 48),
+                                   (260, 256, 16)])
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("mapped", [False, True], ids=["dense", "rows2"])
+def test_nt_with_layernorm_forward_epilogue_is_bitwise_the_two_launches(m, n, k, relu, mapped):
+    """gte_gemm_p3_nt_ln_fwd / gte_gemm_p3_nt_rows2_ln_fwd: z = [a1 | a2] b^T + bias, the row statistics, y as fp32 and as a P3 image
+    are bit for bit what gte_gemm_p3_nt (+ _rows2) followed by gte_ln_relu_fwd_p3 write; padding columns zero."""
+    lib, P = _lib.load(), _lib.ptr
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)
+    n_res = max(2 * m, 64)
+    x1, x2 = torch.randn(n_res, k, device=DEV, generator=g), torch.randn(n_res, k, device=DEV, generator=g)
+    kp, ld = -(-k // 16) * 16, -(-n // 16) * 16
+    wb = torch.zeros(n, 2 * kp, device=DEV)
+    wb[:, :k], wb[:, kp:kp + k] = torch.randn(n, k, device=DEV, generator=g) * 0.1, torch.randn(n, k, device=DEV, generator=g) * 0.1
+    w = ops.P3(ops.p3_from_f32(wb).data, n, 2 * kp)
+    bias, gamma, beta = (torch.randn(n, device=DEV, generator=g) for _ in range(3))
+    if mapped:
+        rm = _row_map(n_res, m, m + 5)
+        a1 = ops.P3(_resident_image(x1).data, m, k, row_map=rm, res_rows=n_res)
+        a2 = ops.P3(_resident_image(x2).data, m, k, row_map=rm, res_rows=n_res)
+    else:
+        a1, a2 = ops.p3_from_f32(x1[:m].contiguous()), ops.p3_from_f32(x2[:m].contiguous())
+
+    def bufs():
+        z = torch.zeros((m, ld), dtype=torch.float32, device=DEV)
+        y = torch.full((m, ld), 7.0, dtype=torch.float32, device=DEV)
+        y[:, n:] = 0
+        yp = ops.P3.empty(m, n, DEV)
+        yp.data.fill_(0x55)
+        return z, y, yp, torch.zeros(2 * m, dtype=torch.float32, device=DEV)
+    z0, y0, yp0, st0 = bufs()
+    ops.gemm_p3_nt(a1, w, a2=a2, bias=bias, out=z0[:, :n])
+    _lib.check(lib.gte_ln_relu_fwd_p3(P(z0), ld, P(gamma), P(beta), 1e-5, int(relu), P(y0), ld, P(yp0.data), yp0.ldp, P(st0), m, n,
+                                      _lib.current_stream()), "ln_relu_fwd_p3")
+    z1, y1, yp1, st1 = bufs()
+    ops.gemm_p3_nt_ln_fwd(a1, w, a2, bias, gamma, beta, 1e-5, relu, z1, y=y1, yp3=yp1, stats=st1)
+    assert torch.equal(z1, z0) and torch.equal(st1, st0) and torch.equal(y1, y0) and torch.equal(yp1.data, yp0.data)
+    # image only (what the step asks for when the next layer takes an image)
+    z2, _, yp2, st2 = bufs()
+    ops.gemm_p3_nt_ln_fwd(a1, w, a2, bias, gamma, beta, 1e-5, relu, z2, y=None, yp3=yp2, stats=st2)
+    assert torch.equal(z2, z0) and torch.equal(yp2.data, yp0.data)
+
+
 def test_row_map_entry_points_validate():
     lib = _lib.load()
     z = torch.zeros(64, 96, dtype=torch.uint8, device=DEV)
