@@ -717,10 +717,11 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s += c[e];
-                const float mean = gte_group_sum<64>(s) * inv_n;
-                float q = 0.f;
+                const float wsum = gte_group_sum<64>(s);               // (z - mean as one fused multiply-add of the row sum, as
+                const float mean = wsum * inv_n;                       // ln_relu_fwd_gen_kernel writes it)
+                float q = 0.f, dv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = j4 + e < n ? c[e] - mean : 0.f; q = fmaf(d, d, q); }
+                for (int e = 0; e < 4; ++e) { dv[e] = j4 + e < n ? fmaf(-inv_n, wsum, c[e]) : 0.f; q = fmaf(dv[e], dv[e], q); }
                 const float rstd = rsqrtf(gte_group_sum<64>(q) * inv_n + p.lnf_eps);
                 if (p.lnf_stats && lane == 0) { p.lnf_stats[rg] = mean; p.lnf_stats[M + rg] = rstd; }
                 if (okc) {                                              // z: the operand of the layer's LayerNorm backward
@@ -731,7 +732,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
                     float o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o[e] = fmaf((c[e] - mean) * rstd, gam[e], bet[e]);
+                        o[e] = fmaf(fmaf(-inv_n, wsum, c[e]) * rstd, gam[e], bet[e]);
                         if (p.ln_relu) o[e] = fmaxf(o[e], 0.f);
                         if (j4 + e >= n) o[e] = 0.f;
                     }

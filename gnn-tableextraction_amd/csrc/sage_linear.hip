@@ -1268,12 +1268,15 @@ ln_relu_fwd_gen_kernel(const float* __restrict__ z, int64_t ldz, const float* __
         for (int v = 0; v < NV; ++v)
 #pragma unroll
             for (int e = 0; e < 4; ++e) s += c[u][v][e];
-        const float mean = wave_sum(s) * inv_n;
+        // (z - mean as ONE fused multiply-add of the row sum, written out: hipcc contracts `c - wave_sum(s) * inv_n` this way, and
+        // the LayerNorm-forward epilogue of the planes GEMM -- gemm_p3.hip, LNB == 4 -- is held bit for bit to this kernel)
+        const float wsum = wave_sum(s);
+        const float mean = wsum * inv_n;
         float q = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = 4 * (lane + 64 * v) + e < n ? c[u][v][e] - mean : 0.f; q = fmaf(d, d, q); }
+            for (int e = 0; e < 4; ++e) { const float d = 4 * (lane + 64 * v) + e < n ? fmaf(-inv_n, wsum, c[u][v][e]) : 0.f; q = fmaf(d, d, q); }
         const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
         if (stats && lane == 0) { stats[r] = mean; stats[M + r] = rstd; }
 #pragma unroll
@@ -1283,7 +1286,7 @@ ln_relu_fwd_gen_kernel(const float* __restrict__ z, int64_t ldz, const float* __
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o[e] = ln_affine((c[u][v][e] - mean) * rstd, g[v][e], b[v][e]);
+                o[e] = ln_affine(fmaf(-inv_n, wsum, c[u][v][e]) * rstd, g[v][e], b[v][e]);
                 if (relu) o[e] = fmaxf(o[e], 0.f);
                 if (j + e >= n) o[e] = 0.f;
             }
