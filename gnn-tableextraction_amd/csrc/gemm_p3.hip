@@ -1359,16 +1359,28 @@ void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
 // (~1.3 PF bf16 whatever the tile), so what matters is ONE balanced round of tiles: the row tile is the smallest of
 // 128 / 160 / 192 / 224 / 256 that covers M with at most one tile per CU; N is cut in 256-column tiles.
 struct NtCfg { int id, bm, bn, wgs; };
+// (ids 8 ... 19, round 5: column tiles of 160 / 192 / 224 for the hidden widths of the reference's scaled runs -- 2 x 96 ... 2 x 224
+// output columns on 256-wide tiles ran 14 ... 78 % padding through the matrix pipe; 1 x WN waves of (32 TM) x 32)
 constexpr NtCfg kNtCfg[] = {{0, 64, 128, 3}, {1, 128, 128, 2}, {2, 128, 256, 1}, {3, 160, 256, 1}, {4, 192, 256, 1}, {5, 224, 256, 1},
-                            {6, 256, 256, 1}};
+                            {6, 256, 256, 1},
+                            {8, 128, 160, 1}, {9, 160, 160, 1}, {10, 192, 160, 1}, {11, 224, 160, 1},
+                            {12, 128, 192, 1}, {13, 160, 192, 1}, {14, 192, 192, 1}, {15, 224, 192, 1},
+                            {16, 128, 224, 1}, {17, 160, 224, 1}, {18, 192, 224, 1}, {19, 224, 224, 1}};
+// forced tile configuration: -1 = the chooser; gte_gemm_p3_set_nt_cfg (tests force every configuration in ONE process; until round 5
+// this was a static getenv read once -- the per-configuration tests that set the variable after the first GEMM of the process ran
+// the chooser's pick every time) or GTE_P3_NT_CFG at the first call
+int g_nt_cfg = -2;
 int nt_choose(const P3Gemm& p) {
-    static const int forced = getenv("GTE_P3_NT_CFG") ? atoi(getenv("GTE_P3_NT_CFG")) : -1;
-    if (forced >= 0 && forced <= 7) return forced;
+    if (g_nt_cfg == -2) g_nt_cfg = getenv("GTE_P3_NT_CFG") ? atoi(getenv("GTE_P3_NT_CFG")) : -1;
+    const int forced = g_nt_cfg;
+    if (forced >= 0 && forced <= 19) return forced;
+    static const int wide_only = getenv("GTE_P3_NT_WIDE") ? atoi(getenv("GTE_P3_NT_WIDE")) : 0;      // (measurement: 1 = the round-4 tile set)
     const int cus = gte::device_props().cus;
     double best = 1e30;
     int bi = 0;
     for (const NtCfg& c : kNtCfg) {
         if (p.N <= 128 && c.bn > 128) continue;
+        if (wide_only && c.id >= 8) continue;
         const int64_t tiles = gte::ceil_div(p.M, c.bm) * gte::ceil_div(p.N, c.bn);
         const int64_t rounds = gte::ceil_div(tiles, (int64_t)cus * c.wgs);
         // makespan in units of tile area; small tiles pay for their operand traffic (load-bound below ~128 x 256)
@@ -1396,11 +1408,29 @@ int launch_nt(const P3Gemm& p, hipStream_t s) {
         case 3: launch_ring<1, 8, 5, 1, 3, 1>(p, s); break;    // 160 x 256: 1 x 8 waves of 160 x 32
         case 4: launch_lw<2, 4, 3, 2, 4>(p, s); break;         // 192 x 256: 8 compute + 4 loader waves
         case 5: launch_ring<1, 8, 7, 1, 3, 1>(p, s); break;    // 224 x 256
+        case 8: launch_ring<1, 5, 4, 1, 3, 1>(p, s); break;    // 128 ... 224 x 160
+        case 9: launch_ring<1, 5, 5, 1, 3, 1>(p, s); break;
+        case 10: launch_ring<1, 5, 6, 1, 3, 1>(p, s); break;
+        case 11: launch_ring<1, 5, 7, 1, 3, 1>(p, s); break;
+        case 12: launch_ring<1, 6, 4, 1, 3, 1>(p, s); break;   // 128 ... 224 x 192
+        case 13: launch_ring<1, 6, 5, 1, 3, 1>(p, s); break;
+        case 14: launch_ring<1, 6, 6, 1, 3, 1>(p, s); break;
+        case 15: launch_ring<1, 6, 7, 1, 3, 1>(p, s); break;
+        case 16: launch_ring<1, 7, 4, 1, 3, 1>(p, s); break;   // 128 ... 224 x 224
+        case 17: launch_ring<1, 7, 5, 1, 3, 1>(p, s); break;
+        case 18: launch_ring<1, 7, 6, 1, 3, 1>(p, s); break;
+        case 19: launch_ring<1, 7, 7, 1, 3, 1>(p, s); break;
         default: launch_ring<2, 4, 4, 2, 3, 1>(p, s); break;   // 256 x 256
     }
     return gte::check_launch("gemm_p3_nt");
 }
 }  // namespace
+
+extern "C" int gte_gemm_p3_set_nt_cfg(int cfg) {
+    if (cfg < -1 || cfg > 19) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_set_nt_cfg: -1 (chooser) or a configuration id 0 ... 19");
+    g_nt_cfg = cfg;
+    return GTE_OK;
+}
 
 // ---- the NT product with the LayerNorm(+ReLU) backward of the layer below as its epilogue ------------------------------
 namespace {

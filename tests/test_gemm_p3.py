@@ -75,13 +75,29 @@ def test_nt_is_bitwise_the_split_kernel(split_mode, m, n, k):
     assert torch.equal(acc, want + 0.5)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
-def test_every_nt_tile_configuration_gives_the_same_bits(split_mode, monkeypatch, cfg):
-    """The chooser picks one tile shape per problem; each shape, forced, gives the bits of the split kernel (ragged M and N)."""
+ALL_NT_CFGS = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+
+
+@pytest.fixture
+def force_nt_cfg():
+    """force a tile configuration of the NT planes GEMM for the test (gte_gemm_p3_set_nt_cfg), the chooser again afterwards"""
+    lib = _lib.load()
+
+    def force(cfg):
+        assert lib.gte_gemm_p3_set_nt_cfg(-1 if cfg is None else int(cfg)) == 0
+    yield force
+    assert lib.gte_gemm_p3_set_nt_cfg(-1) == 0
+
+
+@pytest.mark.parametrize("cfg", ALL_NT_CFGS)
+@pytest.mark.parametrize("n", [500, 192, 200, 448])
+def test_every_nt_tile_configuration_gives_the_same_bits(split_mode, force_nt_cfg, cfg, n):
+    """The chooser picks one tile shape per problem; each shape, forced, gives the bits of the split kernel (ragged M and N; output
+    widths of the reference's scaled runs: 2 x 96, 2 x 100, 2 x 224)."""
     g = torch.Generator(device=DEV).manual_seed(cfg)
-    a, b = torch.randn(3001, 363, device=DEV, generator=g), torch.randn(500, 363, device=DEV, generator=g)
+    a, b = torch.randn(3001, 363, device=DEV, generator=g), torch.randn(n, 363, device=DEV, generator=g)
     want = ops.gemm(a, b, trans_b=True)
-    monkeypatch.setenv("GTE_P3_NT_CFG", str(cfg))
+    force_nt_cfg(cfg)
     assert torch.equal(ops.gemm_p3_nt(ops.p3_from_f32(a), ops.p3_from_f32(b)), want)
 
 
@@ -160,12 +176,12 @@ def rows64(request):
 
 
 @pytest.mark.parametrize("rows,k,n", [(24437, 831, 512), (3000, 831, 512), (100, 363, 256), (1, 48, 256), (6001, 831, 256)])
-@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 5, 6])
-def test_nt_through_a_row_map_is_bitwise_the_gathered_gemm(monkeypatch, rows64, rows, k, n, cfg):
+@pytest.mark.parametrize("cfg", [None] + ALL_NT_CFGS)
+def test_nt_through_a_row_map_is_bitwise_the_gathered_gemm(force_nt_cfg, rows64, rows, k, n, cfg):
     if cfg is not None:
         if rows != 3000 or rows64:
             pytest.skip("forced tile shapes: one problem size, 32-bit offsets (the 64-bit path has its own two tiles)")
-        monkeypatch.setenv("GTE_P3_NT_CFG", str(cfg))
+    force_nt_cfg(cfg)
     n_res = 40000
     g = torch.Generator(device=DEV).manual_seed(rows)
     res = _resident_image(torch.randn(n_res, k, device=DEV, generator=g))
@@ -198,14 +214,14 @@ def test_tn_through_a_row_map_is_bitwise_the_gathered_gemm(rows64, rows, k, m):
 
 
 @pytest.mark.parametrize("rows,k,n", [(24437, 831, 256), (3000, 831, 96), (3000, 363, 160), (100, 313, 1000), (1, 48, 256), (6001, 781, 112)])
-@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 5, 6])
-def test_nt_with_two_resident_images_behind_one_row_map(monkeypatch, rows, k, n, cfg):
+@pytest.mark.parametrize("cfg", [None] + ALL_NT_CFGS)
+def test_nt_with_two_resident_images_behind_one_row_map(force_nt_cfg, rows, k, n, cfg):
     """z = [x | ahn][rows] W^T + b (gte_gemm_p3_nt_rows2: the input layer on its features and their cached mean aggregate) is bit for
     bit the two-segment product on the gathered rows; every tile configuration."""
     if cfg is not None:
         if rows != 3000 or k != 831:
             pytest.skip("forced tile shapes: one problem size")
-        monkeypatch.setenv("GTE_P3_NT_CFG", str(cfg))
+    force_nt_cfg(cfg)
     n_res = 30000
     g = torch.Generator(device=DEV).manual_seed(rows + 7)
     res1 = _resident_image(torch.randn(n_res, k, device=DEV, generator=g))
