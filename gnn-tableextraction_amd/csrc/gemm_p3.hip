@@ -675,7 +675,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         // 4 l .. 4 l + 3, two-pass statistics over the n true columns): z, stats, y and the image are bit for bit what
         // gte_gemm_p3_nt + gte_ln_relu_fwd_p3 write ----
         asm volatile("s_barrier" ::: "memory");
-        static_assert(BN == 256 && TN == 2, "whole rows per workgroup");
+        static_assert(BN <= 256 && TN == 2, "whole rows per workgroup");
         constexpr int SR = TM * 32, LDT = 256;
         float* tile = reinterpret_cast<float*>(lds);
         const int n = p.N, M = p.M;
@@ -751,7 +751,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         // Per slice of TM * 32 rows: the waves that own them put their accumulators into LDS row-major, then every wave takes
         // rows of the slice in the layout of ln_relu_bwd_vec_kernel (lane l = columns 4 l .. 4 l + 3, two rows in flight) with
         // ITS arithmetic: dz is bit for bit what the separate launch computes from the stored product.
-        static_assert(BN == 256 && TN == 2, "whole rows per workgroup");
+        static_assert(BN <= 256 && TN == 2, "whole rows per workgroup");     // (BN = 128 / 192: hidden widths up to 128 / 192)
         constexpr int SR = TM * 32, LDT = 256;                        // slice rows; floats per LDS row
         float* tile = reinterpret_cast<float*>(lds);
         constexpr bool MSK = LNB == 3;
@@ -1492,8 +1492,15 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
     p.ln_part = reinterpret_cast<float*>(workspace);
     hipStream_t s = gte::as_stream(stream);
     const int bm = lnb_row_tile(m);
-    if (n % 16 == 0) launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
-    else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);           // per-element validity, zero image columns up to the next multiple of 16
+    // column tile = the hidden width rounded up to 128 / 192 / 256 (round 5: the scaled runs' 96 ... 157 columns ran 256-wide tiles)
+    static const int wide_only = getenv("GTE_P3_NT_WIDE") ? atoi(getenv("GTE_P3_NT_WIDE")) : 0;      // (measurement: the round-4 tile)
+    const int wn = wide_only ? 4 : (n <= 128 ? 2 : (n <= 192 ? 3 : 4));
+    if (n % 16 == 0) {
+        if (wn == 2) launch_lw_lnb<2, 2, 2, 2, 4>(p, s); else if (wn == 3) launch_lw_lnb<2, 3, 2, 2, 4>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
+    } else {                                              // per-element validity, zero image columns up to the next multiple of 16
+        if (wn == 2) launch_lw_lnb<2, 2, 2, 2, 4, 3>(p, s); else if (wn == 3) launch_lw_lnb<2, 3, 2, 2, 4, 3>(p, s);
+        else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);
+    }
     int rc = gte::check_launch("gemm_p3_nt_ln_bwd");
     if (rc != GTE_OK) return rc;
     const int nb = (int)gte::ceil_div(m, bm);
@@ -1547,7 +1554,9 @@ static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, cons
     } else if ((m + 256) * lda1 >= ((int64_t)1 << 31) || (k2 > 0 && (m + 256) * lda2 >= ((int64_t)1 << 31))) {
         return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_fwd: operand images must be < 2 GB");
     }
-    launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
+    if (n <= 128) launch_lw_lnb<2, 2, 2, 2, 4, 4>(p, gte::as_stream(stream));
+    else if (n <= 192) launch_lw_lnb<2, 3, 2, 2, 4, 4>(p, gte::as_stream(stream));
+    else launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
     return gte::check_launch("gemm_p3_nt_ln_fwd");
 }
 extern "C" int gte_gemm_p3_nt_ln_fwd_supported(int64_t n) { return (n >= 1 && n <= 256) ? 1 : 0; }
