@@ -623,13 +623,14 @@ def residency_probe(args, gte, dev, pages, loop):
         return FusedGcnSageStep(m, lr=0.01, weight_decay=5e-4)
     tr = fresh()
     want_p3 = tr.wants_p3_features(args.in_feats)
+    want_agg = bool(want_p3 and tr.wants_agg_image(args.in_feats))       # (the cached aggregate of the input travels with every window)
     t0 = time.perf_counter()
     host = R.HostPages(graphs, dev)
     build_s = time.perf_counter() - t0
-    per_node = R.WindowedPages.bytes_per_node(host.page_nodes, host.page_edges, args.in_feats, want_p3)
+    per_node = R.WindowedPages.bytes_per_node(host.page_nodes, host.page_edges, args.in_feats, want_p3, want_agg)
     set_bytes = float(host.page_nodes.sum()) * per_node
     budget = set_bytes / 2.5                                     # two slots of ~1/6 of the set each (+ the staging rows)
-    wp = R.WindowedPages(host, budget, want_p3)
+    wp = R.WindowedPages(host, budget, want_p3, want_agg)
     # raw pinned-host -> device rate of this box (one window's feature rows)
     p0, p1 = wp.ranges[0]
     n0, n1 = int(host.node_off[p0]), int(host.node_off[p1])
@@ -675,7 +676,7 @@ def residency_probe(args, gte, dev, pages, loop):
     tr2 = fresh()
     res = G.ResidentPages(graphs, dev)
     if want_p3:
-        res.enable_p3()
+        res.enable_p3(agg=want_agg)
     pipe2 = loop.BatchPipeline(res)
     stream2 = R.WindowStream(wp.ranges, args.pages, 4, 42)
 

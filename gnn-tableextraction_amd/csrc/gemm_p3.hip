@@ -584,6 +584,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         // BIG: the lane's piece of its image row as a pointer.  Rows past the tile's valid rows read the tile's first row (their
         // products are never stored), stages past the end of K re-read the last block (never multiplied): no lane leaves the image.
         const char* ap[NI];
+        long long ap2d[NI];                                     // rows_both: byte distance from the lane's piece in image 1 to image 2
         if constexpr (BIG)
             static_for<NI>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -591,6 +592,8 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
                 const int s = ii * 64 + lane, row = s / 6, part = s - row * 6, sp = part ^ ((row >> 3) & 1);
                 const int rr = (ii < A_INST) ? p.rowsA[m0 + (row < rowsA ? row : 0)] : 0;
                 ap[i] = p.A1 + (long long)rr * p.lda1 + sp * 16;
+                ap2d[i] = p.rows_both ? (long long)(reinterpret_cast<uintptr_t>(p.A2) + (unsigned long long)((long long)rr * p.lda2 + sp * 16)) -
+                                            (long long)reinterpret_cast<uintptr_t>(ap[i]) : 0;
             });
         auto issue = [&](int t, char* buf) {
             const bool seg = t >= KB1;
@@ -598,10 +601,13 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
             if constexpr (BIG) {
                 const __amdgpu_buffer_rsrc_t sbb =
                     __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
-                const long long ta = (long long)(t < T ? t : T - 1) * bsa1;
+                // (stages past the end re-read the last block of the last segment: never multiplied)
+                const int tc = t < T ? t : T - 1;
+                const bool seg2 = p.rows_both && tc >= KB1;
+                const long long ta = seg2 ? (long long)(tc - KB1) * bsa2 : (long long)tc * bsa1;
                 static_for<NI>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    if (i * NL + lw < A_INST) gdma16(ap[i] + ta, buf + (i * NL + lw) * 1024);      // (wave-uniform choice)
+                    if (i * NL + lw < A_INST) gdma16(ap[i] + (seg2 ? ap2d[i] : 0) + ta, buf + (i * NL + lw) * 1024);      // (wave-uniform choice)
                     else dma16(sbb, buf + (i * NL + lw) * 1024, vo1[i]);
                 });
                 return;
@@ -1283,8 +1289,7 @@ static int gemm_p3_nt_impl(const void* a1, int64_t lda1, int64_t k1, const void*
         p.rows64 = rows64_needed(p.res_bytes);
         if (rows_both) {
             p.rows_both = 1; p.res_bytes2 = n_res_rows * lda2;
-            if (p.rows64 || rows64_needed(p.res_bytes2))
-                return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_rows2: resident images must stay below 4 GB (32-bit row offsets)");
+            if (rows64_needed(p.res_bytes2)) p.rows64 = 1;     // (64-bit per-lane addresses for both images)
         }
     }
     return launch_nt(p, gte::as_stream(stream));
@@ -1342,18 +1347,18 @@ void launch_lw(const P3Gemm& p, hipStream_t s) {
     const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
     hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, 0, BIG>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
-template <int WM, int WN, int TM, int TN, int NL, int LNB = 1>
+template <int WM, int WN, int TM, int TN, int NL, int LNB = 1, bool BIG = false>
 void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NI = ((BM + BN) * 96 / 1024 + NL - 1) / NL, shm = 3 * NI * NL * 1024;
     static_assert(shm >= TM * 32 * 256 * 4 && shm >= WM * WN * 3 * 256 * 4, "the epilogue's row slice lives in the stage images");
     static bool configured = false;
     if (!configured) {
-        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB>), shm);
+        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG>), shm);
         configured = true;
     }
     const dim3 grid((unsigned)gte::ceil_div(p.M, BM));
-    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
+    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
 // Configurations (measured on the step's shapes, profiles/r03/gemm_p3.md): the kernel runs at the chip's power limit
 // (~1.3 PF bf16 whatever the tile), so what matters is ONE balanced round of tiles: the row tile is the smallest of
@@ -1549,12 +1554,15 @@ static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, cons
         if (n_res_rows <= 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_fwd: empty resident image");
         p.rowsA = a_rows; p.res_bytes = n_res_rows * lda1;
         if (k2 > 0) { p.rows_both = 1; p.res_bytes2 = n_res_rows * lda2; }
-        if (rows64_needed(p.res_bytes) || (k2 > 0 && rows64_needed(p.res_bytes2)))
-            return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_fwd: resident images must stay below 4 GB (32-bit row offsets)");
+        p.rows64 = (rows64_needed(p.res_bytes) || (k2 > 0 && rows64_needed(p.res_bytes2))) ? 1 : 0;
     } else if ((m + 256) * lda1 >= ((int64_t)1 << 31) || (k2 > 0 && (m + 256) * lda2 >= ((int64_t)1 << 31))) {
         return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_fwd: operand images must be < 2 GB");
     }
-    if (n <= 128) launch_lw_lnb<2, 2, 2, 2, 4, 4>(p, gte::as_stream(stream));
+    if (p.rows64) {                                        // images of 4 GB or more: 64-bit per-lane addresses (no range check: the
+        if (n <= 128) launch_lw_lnb<2, 2, 2, 2, 4, 4, true>(p, gte::as_stream(stream));      // rows past the tile re-read its first row)
+        else if (n <= 192) launch_lw_lnb<2, 3, 2, 2, 4, 4, true>(p, gte::as_stream(stream));
+        else launch_lw_lnb<2, 4, 2, 2, 4, 4, true>(p, gte::as_stream(stream));
+    } else if (n <= 128) launch_lw_lnb<2, 2, 2, 2, 4, 4>(p, gte::as_stream(stream));
     else if (n <= 192) launch_lw_lnb<2, 3, 2, 2, 4, 4>(p, gte::as_stream(stream));
     else launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
     return gte::check_launch("gemm_p3_nt_ln_fwd");

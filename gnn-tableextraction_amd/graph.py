@@ -502,14 +502,16 @@ class ResidentPages:
         dev, s = self.device, self._sets["in"]
         P, N = self.n_pages, self.n_nodes
         sizes = (self.node_off[1:] - self.node_off[:-1]).long()
-        page_of_node = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
+        E = int(s["edge_off_host"][P])
+        # (output_size: without it repeat_interleave reads the total back from the device -- a host synchronisation on the copy
+        # stream of a window upload, models/residency.py)
+        page_of_node = torch.repeat_interleave(torch.arange(P, device=dev), sizes, output_size=N)
         eoff = s["edge_off"].long()
         rows = torch.arange(N, device=dev)
         indptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         indptr[:N] = (s["indptr_loc"].long()[rows + page_of_node] + eoff[page_of_node]).to(torch.int32)
         indptr[N] = eoff[P].to(torch.int32)
-        E = int(s["edge_off_host"][P])
-        page_of_entry = torch.repeat_interleave(torch.arange(P, device=dev), (eoff[1:] - eoff[:-1]))
+        page_of_entry = torch.repeat_interleave(torch.arange(P, device=dev), (eoff[1:] - eoff[:-1]), output_size=E)
         indices = (s["indices_loc"][:E].long() + self.node_off.long()[page_of_entry]).to(torch.int32)
         return indptr, indices, (None if s["weight"] is None else s["weight"][:E])
 

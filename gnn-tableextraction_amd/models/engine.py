@@ -567,7 +567,7 @@ class FusedGcnSageStep(TrainStep):
     @staticmethod
     def _batch_cached(g) -> bool:
         xp, ap = getattr(g, "feat_p3", None), getattr(g, "agg_p3", None)
-        return xp is not None and ap is not None and xp.row_map is not None and xp.data.numel() < (1 << 32) - (1 << 20)
+        return xp is not None and ap is not None and xp.row_map is not None
 
     def _plan_mode(self, kinds, f0: int):
         """(general, out_gemm) of a plan: ``general`` = it runs on the padded buffer set (_alloc_gen) -- some hidden layer lies

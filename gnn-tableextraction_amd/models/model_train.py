@@ -198,7 +198,8 @@ def train(data, config, name_time=None):
     all_nodes = np.array([g.num_nodes() for g in train_graphs], dtype=np.int64)
     all_edges = np.array([g.num_edges() for g in train_graphs], dtype=np.int64)
     want_p3 = bool(getattr(step, "wants_p3_features", lambda f: False)(in_feats))
-    set_bytes = float(all_nodes.sum()) * R.WindowedPages.bytes_per_node(all_nodes, all_edges, in_feats, want_p3)
+    want_agg = want_p3 and bool(getattr(step, "wants_agg_image", lambda f: False)(in_feats))      # (the cached aggregate of the input)
+    set_bytes = float(all_nodes.sum()) * R.WindowedPages.bytes_per_node(all_nodes, all_edges, in_feats, want_p3, want_agg)
     budget_gb = float(os.environ.get("GTE_RESIDENT_BUDGET_GB", "0") or 0)
     if budget_gb <= 0 and torch.device(device).type == 'cuda':
         free_b, total_b = torch.cuda.mem_get_info(device)
@@ -232,7 +233,7 @@ def train(data, config, name_time=None):
         if tier == "windowed":
             passes = int(os.environ.get("GTE_WINDOW_PASSES", "8"))
             host = R.HostPages([train_graphs[i] for i in mine], device)
-            wp = R.WindowedPages(host, budget_gb * 1e9, want_p3)
+            wp = R.WindowedPages(host, budget_gb * 1e9, want_p3, want_agg)
         else:
             passes = 1                 # one window = every page the rank owns: a pass is a shuffled epoch over them
             wp = R.OwnedResident([train_graphs[i] for i in mine], device)
@@ -240,7 +241,7 @@ def train(data, config, name_time=None):
         streams = []
         for r in range(world):
             ids = rank_pages[r]
-            rng_ = (R.WindowedPages.layout(all_nodes[ids], all_edges[ids], in_feats, budget_gb * 1e9, want_p3) if tier == "windowed"
+            rng_ = (R.WindowedPages.layout(all_nodes[ids], all_edges[ids], in_feats, budget_gb * 1e9, want_p3, want_agg) if tier == "windowed"
                     else [(0, len(ids))])
             streams.append(R.WindowStream(rng_, batch_size, passes, seed0, rank=r))
         assert streams[rank].ranges == wp.ranges

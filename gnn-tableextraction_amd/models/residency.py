@@ -234,28 +234,34 @@ class WindowedPages:
     ROW_MAP_LIMIT = (1 << 32) - (1 << 20)
 
     @staticmethod
-    def bytes_per_node(page_nodes: np.ndarray, page_edges: np.ndarray, n_feat: int, want_p3: bool) -> float:
-        """HBM bytes of a resident node: its feature row (P3 image, or fp32) + label + both CSRs (indptr, indices, weights)."""
+    def bytes_per_node(page_nodes: np.ndarray, page_edges: np.ndarray, n_feat: int, want_p3: bool, want_agg: bool = False) -> float:
+        """HBM bytes of a resident node: its feature row (P3 image, or fp32; ``want_agg``: and the image of its input's mean
+        aggregate) + label + both CSRs (indptr, indices, weights)."""
         ldp = 96 * (-(-n_feat // 16)) if want_p3 else 0
         deg = max(float(page_edges.sum()) / max(float(page_nodes.sum()), 1.0), 1.0)
-        return (ldp if want_p3 else 4 * n_feat) + 4 + 2 * (4 + deg * 8) + 8
+        return (ldp * (2 if want_agg else 1) if want_p3 else 4 * n_feat) + 4 + 2 * (4 + deg * 8) + 8
 
     @staticmethod
-    def layout(page_nodes: np.ndarray, page_edges: np.ndarray, n_feat: int, budget_bytes: float, want_p3: bool) -> List[Tuple[int, int]]:
+    def layout(page_nodes: np.ndarray, page_edges: np.ndarray, n_feat: int, budget_bytes: float, want_p3: bool,
+               want_agg: bool = False) -> List[Tuple[int, int]]:
         """The window page ranges of a rank: pure host arithmetic on the page table (every rank can compute every rank's)."""
         ldp = 96 * (-(-n_feat // 16)) if want_p3 else 0
-        per_node = WindowedPages.bytes_per_node(page_nodes, page_edges, n_feat, want_p3)
+        per_node = WindowedPages.bytes_per_node(page_nodes, page_edges, n_feat, want_p3, want_agg)
         # (the fp32 staging rows of the image conversion are shared by the two slots: one upload at a time)
         stage = 4 * n_feat if want_p3 else 0
         slot_bytes = budget_bytes / (2.0 + stage / per_node)
         max_nodes = (WindowedPages.ROW_MAP_LIMIT // ldp) if want_p3 else None
         return window_ranges(page_nodes, per_node, slot_bytes, max_nodes)
 
-    def __init__(self, host: HostPages, budget_bytes: float, want_p3: bool):
+    def __init__(self, host: HostPages, budget_bytes: float, want_p3: bool, want_agg: bool = False):
+        """``want_agg`` (with ``want_p3``): every window also carries the image of the input's mean aggregate, computed on the copy
+        stream from the uploaded rows and the window's own CSR (graph.ResidentPages.build_agg_image): the input layer then runs
+        on the cached aggregate (engine GTE_LAYER_CACHED) exactly as on an all-resident set."""
         self.host, self.device, self.want_p3 = host, host.device, bool(want_p3)
+        self.want_agg = bool(want_agg and want_p3)
         F = host.n_feat
         self.ldp = 96 * (-(-F // 16)) if want_p3 else 0
-        self.ranges = self.layout(host.page_nodes, host.page_edges, F, budget_bytes, want_p3)
+        self.ranges = self.layout(host.page_nodes, host.page_edges, F, budget_bytes, want_p3, self.want_agg)
         dev = self.device
         nmax = max(int(host.node_off[p1] - host.node_off[p0]) for p0, p1 in self.ranges)
         pmax = max(p1 - p0 for p0, p1 in self.ranges)
@@ -266,6 +272,7 @@ class WindowedPages:
         for _ in range(2):
             sl = {"feat": torch.empty((nmax, self.ldp), dtype=torch.uint8, device=dev) if want_p3
                   else torch.empty((nmax, F), dtype=torch.float32, device=dev),
+                  "agg": torch.empty((nmax, self.ldp), dtype=torch.uint8, device=dev) if self.want_agg else None,
                   "label": torch.empty((nmax, 1), dtype=torch.float32, device=dev) if host.has_label else None,
                   "window": None, "ready": None, "free": None, "res": None,
                   # page tables of the window (node / in-edge / out-edge offsets): pinned staging + device copy, so that their
@@ -287,7 +294,7 @@ class WindowedPages:
         self.delay_cycles = 0                                 # test hook: spin this many GPU cycles in front of every upload
         self._no_feat = torch.empty((0, F), dtype=torch.float32, device=dev)
         self.device_bytes = sum(t.numel() * t.element_size() for sl in self.slots for t in
-                                [sl["feat"], sl["label"]] + [v for n in ("in", "out") for v in sl[n].values()] if t is not None)
+                                [sl["feat"], sl["agg"], sl["label"]] + [v for n in ("in", "out") for v in sl[n].values()] if t is not None)
         self.device_bytes += self.stage.numel() * 4 if self.stage is not None else 0
         self.uploaded_bytes = 0
 
@@ -349,6 +356,8 @@ class WindowedPages:
                 res = G.ResidentPages.from_arrays(self.device, node_off, feat, label, sets, h.weighted, h.max_deg,
                                                   feat_p3=ops.P3(sl["feat"][:n], n, h.n_feat), p3_mode="rows",
                                                   node_off_dev=sl["meta_dev"][:np_ + 1])
+                if self.want_agg:                             # norm . A_w x of the window's rows, from the staged fp32 rows
+                    res.build_agg_image(x_f32=self.stage[:n], out=ops.P3(sl["agg"][:n], n, h.n_feat))
             else:
                 sl["feat"][:n].copy_(h.feat[n0:n1], non_blocking=True)
                 res = G.ResidentPages.from_arrays(self.device, node_off, sl["feat"][:n], label, sets, h.weighted, h.max_deg,

@@ -33,9 +33,10 @@ want_p3 = tr.wants_p3_features(F0)
 t0 = time.perf_counter()
 host = R.HostPages(graphs, dev)
 build_s = time.perf_counter() - t0
-per_node = R.WindowedPages.bytes_per_node(host.page_nodes, host.page_edges, F0, want_p3)
+want_agg = bool(want_p3 and tr.wants_agg_image(F0))
+per_node = R.WindowedPages.bytes_per_node(host.page_nodes, host.page_edges, F0, want_p3, want_agg)
 set_bytes = float(host.page_nodes.sum()) * per_node
-wp = R.WindowedPages(host, budget, want_p3)
+wp = R.WindowedPages(host, budget, want_p3, want_agg)
 stream = R.WindowStream(wp.ranges, B, passes, 42)
 wp.prefetch(stream.peek_window())
 pipe = loop.BatchPipeline(wp.acquire(stream.peek_window()))
@@ -58,7 +59,7 @@ p0, p1 = wp.ranges[0]
 tr2 = fresh()
 rp = G.ResidentPages(graphs[p0:p1], dev)
 if want_p3:
-    rp.enable_p3()
+    rp.enable_p3(agg=want_agg)
 pipe2 = loop.BatchPipeline(rp)
 rng = np.random.default_rng(0)
 plan = lambda k: [np.sort(rng.choice(p1 - p0, B, replace=False)) for _ in range(k)]

@@ -474,10 +474,12 @@ def test_edge_parallel_aggregation_beats_the_row_kernel_on_hub_rows():
 
 
 # ---------------------------------------------------------------- host-resident training sets (models/residency.py)
-@pytest.mark.parametrize("f0,hid,gemm_mode,delay,late", [(831, 256, None, 0, "1"), (13, 256, None, 0, "1"), (63, 200, None, 0, "1"),
-                                                         (831, 256, None, 60_000_000, "1"), (63, 200, None, 60_000_000, "0"),
-                                                         (63, 64, "f32", 60_000_000, "1"), (63, 64, "f32", 60_000_000, "0")])
-def test_windowed_run_is_bitwise_the_all_resident_run_on_the_same_step_stream(f0, hid, gemm_mode, delay, late, monkeypatch):
+@pytest.mark.parametrize("f0,hid,gemm_mode,delay,late,agg", [(831, 256, None, 0, "1", True), (831, 256, None, 0, "1", False),
+                                                             (13, 256, None, 0, "1", False), (63, 200, None, 0, "1", False),
+                                                             (831, 256, None, 60_000_000, "1", True), (363, 149, None, 60_000_000, "0", True),
+                                                             (63, 200, None, 60_000_000, "0", False),
+                                                             (63, 64, "f32", 60_000_000, "1", False), (63, 64, "f32", 60_000_000, "0", False)])
+def test_windowed_run_is_bitwise_the_all_resident_run_on_the_same_step_stream(f0, hid, gemm_mode, delay, late, agg, monkeypatch):
     """A training set kept in pinned host memory with a two-slot window in HBM (uploads on a copy stream while the previous
     window trains, image conversion on the device, row-map batches) against the SAME step stream run on the all-resident set:
     losses and parameters bit for bit after three sweeps' worth of steps.
@@ -485,18 +487,20 @@ def test_windowed_run_is_bitwise_the_all_resident_run_on_the_same_step_stream(f0
     ``delay``: every upload is held back by a ~30 ms spin on the copy stream (longer than all the steps of a window take), so a
     reader that is not ordered behind the window's `ready` event reads a slot that has not arrived -- round 4's assembly stream
     was such a reader (it waited for its own buffer events only; advisor finding): page tables, CSRs, labels and, in fp32 'copy'
-    mode (``gemm_mode='f32'``), the feature rows.  ``late='0'``: GTE_PIPE_LATE=0, every assembly starts ahead of its step."""
+    mode (``gemm_mode='f32'``), the feature rows.  ``late='0'``: GTE_PIPE_LATE=0, every assembly starts ahead of its step.
+    ``agg``: the windows carry the image of the input's mean aggregate (computed per upload on the copy stream) and layer 0 runs
+    on it (GTE_LAYER_CACHED), as on the all-resident set with its one image."""
     monkeypatch.setenv("GTE_PIPE_LATE", late)
     if gemm_mode is not None:
         prev_mode = ops.set_gemm_mode(gemm_mode)
         try:
-            return _windowed_vs_resident(f0, hid, delay)
+            return _windowed_vs_resident(f0, hid, delay, agg)
         finally:
             ops.set_gemm_mode(prev_mode)
-    _windowed_vs_resident(f0, hid, delay)
+    _windowed_vs_resident(f0, hid, delay, agg)
 
 
-def _windowed_vs_resident(f0, hid, delay):
+def _windowed_vs_resident(f0, hid, delay, agg=False):
     from gnn_tableextraction_amd.models import residency as R
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
     from gnn_tableextraction_amd.models.loop import BatchPipeline, run_steps
@@ -517,8 +521,9 @@ def _windowed_vs_resident(f0, hid, delay):
     tr = fresh()
     want_p3 = tr.wants_p3_features(f0)
     host = R.HostPages(graphs, DEV, chunk_bytes=1 << 20)                # (several construction chunks)
-    total = host.feature_bytes() * (1.5 if want_p3 else 1.0)
-    wp = R.WindowedPages(host, budget_bytes=total * 0.9, want_p3=want_p3)     # two slots of < half the set: >= 3 windows
+    agg = bool(agg and want_p3 and tr.wants_agg_image(f0))
+    total = host.feature_bytes() * ((3.0 if agg else 1.5) if want_p3 else 1.0)
+    wp = R.WindowedPages(host, budget_bytes=total * 0.9, want_p3=want_p3, want_agg=agg)     # two slots of < half the set: >= 3 windows
     assert len(wp.ranges) >= 3
     wp.delay_cycles = delay
     stream = R.WindowStream(wp.ranges, B, passes=2, seed=5)
@@ -532,7 +537,7 @@ def _windowed_vs_resident(f0, hid, delay):
     tr2 = fresh()
     res = G.ResidentPages(graphs, DEV)
     if want_p3:
-        res.enable_p3()
+        res.enable_p3(agg=agg)
     pipe2 = BatchPipeline(res)
     stream2 = R.WindowStream(wp.ranges, B, passes=2, seed=5)
     losses_r = []
