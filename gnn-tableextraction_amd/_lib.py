@@ -196,6 +196,8 @@ SIGNATURES = {
     "gte_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                               c_float, c_float, c_int64, c_float, c_void_p]),
     "gte_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gte_adam_step_dev_images": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_void_p, c_void_p]),
 }
 
 class P3Desc(ctypes.Structure):

@@ -1,5 +1,6 @@
 // libgte_hip.so: error reporting, version and device facts.
 #include "gte_common.h"
+#include "fold_images.h"
 #include "p3.h"
 
 #include <stdlib.h>
@@ -57,67 +58,7 @@ struct FoldDesc {
 // Optional optimiser tail of the batch (gte_fold_defer_flush_adam): when `param` is set every folded element is a gradient
 // element of the flat buffer starting at `grad`, and the thread that writes it applies the Adam update of that element.
 struct FoldAdam { float* param; float* grad; float* exp_avg; float* exp_avg_sq; float* state; long long* step; unsigned* ticket; int vec_ok; };
-// ... and, behind the update, the P3 images (csrc/p3.h) of parameter sub-matrices -- the operand images the planes GEMMs of the
-// NEXT step multiply (gte_fold_defer_flush_adam_images): the thread that updates a parameter element writes its three bf16
-// pieces into every image that holds it.  off = element offset of the sub-matrix in the flat parameter buffer; its rows x cols
-// elements sit at row stride ld; image(r, c) = transpose ? sub(c, r) : sub(r, c).
-constexpr int kMaxFoldImages = 12;
-struct FoldImage { long long off; unsigned span, ld, magic; int cols, transpose, pad; char* dst; long long ldp; };
-struct FoldImages { FoldImage im[kMaxFoldImages]; int n; };
 struct FoldBatch { FoldDesc d[kMaxFolds]; int n; FoldAdam adam; FoldImages img; };
-
-// (row, column) of element o of a sub-matrix with row stride ld: magic = floor(2^32 / ld) + 1 is exact for o < 2^32 / ld
-// (checked on the host); a 64-bit division per element cost the launch more than the conversion launch it replaces
-__device__ __forceinline__ void fold_rc(const FoldImage& im, unsigned o, int& r, int& c) {
-    unsigned q = __umulhi(o, im.magic);
-    unsigned rem = o - q * im.ld;
-    if (rem >= im.ld) { rem -= im.ld; ++q; }
-    r = (int)q; c = (int)rem;
-}
-__device__ __forceinline__ void fold_write_image1(const FoldImage& im, long long i, float v) {
-    const long long o = i - im.off;
-    if (o < 0 || o >= (long long)im.span) return;
-    int r, c;
-    fold_rc(im, (unsigned)o, r, c);
-    if (c >= im.cols) return;
-    const int ir = im.transpose ? c : r, ic = im.transpose ? r : c;
-    unsigned h, m, l;
-    p3::split2(v, 0.f, h, m, l);
-    unsigned short* q = reinterpret_cast<unsigned short*>(im.dst + (long long)ir * im.ldp + (ic >> 4) * p3::BLOCK_BYTES + (ic & 15) * 2);
-    q[0] = (unsigned short)h;
-    q[p3::PLANE_BYTES / 2] = (unsigned short)m;
-    q[p3::PLANE_BYTES] = (unsigned short)l;
-}
-// the images in `mask` only (FoldDesc::img_mask: the images whose source overlaps the fold's destination)
-__device__ __forceinline__ void fold_write_images(const FoldImages& fi, unsigned mask, long long i, float v) {
-    for (int k = 0; k < fi.n; ++k)
-        if (mask >> k & 1) fold_write_image1(fi.im[k], i, v);
-}
-// two consecutive parameter elements: where both fall into the same row of an untransposed image at an even column they
-// leave as ONE 4-byte store per plane; everything else goes element by element
-__device__ __forceinline__ void fold_write_images2(const FoldImages& fi, unsigned mask, long long i, float v0, float v1) {
-    for (int k = 0; k < fi.n; ++k) {
-        if (!(mask >> k & 1)) continue;
-        const FoldImage& im = fi.im[k];
-        const long long o = i - im.off;
-        if (o + 1 < 0 || o >= (long long)im.span) continue;
-        if (o >= 0 && !im.transpose) {
-            int r, c;
-            fold_rc(im, (unsigned)o, r, c);
-            if ((c & 1) == 0 && c + 1 < im.cols) {
-                unsigned h, m, l;
-                p3::split2(v0, v1, h, m, l);
-                unsigned* q = reinterpret_cast<unsigned*>(im.dst + (long long)r * im.ldp + (c >> 4) * p3::BLOCK_BYTES + (c & 15) * 2);
-                q[0] = h;
-                q[p3::PLANE_BYTES / 4] = m;
-                q[p3::PLANE_BYTES / 2] = l;
-                continue;
-            }
-        }
-        fold_write_image1(im, i, v0);
-        fold_write_image1(im, i + 1, v1);
-    }
-}
 struct FoldQueue {
     FoldBatch batch; bool open = false; hipStream_t stream = nullptr; int blocks = 0;
     bool spilled = false;                 // a full batch was flushed early: the queued folds no longer cover the whole deferral
@@ -389,28 +330,10 @@ extern "C" int gte_fold_defer_flush_adam_images(float* param, float* grad, float
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam: null pointer or n <= 0");
     }
     gte::FoldImages fi;
-    fi.n = 0;
-    if (n_images < 0 || (n_images > 0 && !images)) {
-        (void)gte::flush_folds(q);
-        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam_images: bad image list");
+    {
+        const int rc_img = gte::make_fold_images(param, n, images, n_images, fi, "fold_defer_flush_adam_images");
+        if (rc_img != GTE_OK) { (void)gte::flush_folds(q); return rc_img; }
     }
-    bool images_ok = n_images > 0 && n_images <= gte::kMaxFoldImages;
-    for (int k = 0; images_ok && k < n_images; ++k) {
-        const gte_p3_desc& d = images[k];
-        const int64_t srows = d.transpose ? d.cols : d.rows, scols = d.transpose ? d.rows : d.cols;
-        if (!d.src || !d.dst || d.rows <= 0 || d.cols <= 0 || d.ld < scols || d.ld > INT32_MAX || d.ldp < p3::row_bytes(d.cols) ||
-            d.src < param || (d.src - param) + (srows - 1) * d.ld + scols > n) {
-            (void)gte::flush_folds(q);
-            return gte::fail(GTE_ERR_INVALID_ARGUMENT, "fold_defer_flush_adam_images: image %d does not describe a sub-matrix of the parameters", k);
-        }
-        gte::FoldImage& im = fi.im[k];
-        const int64_t span = (srows - 1) * d.ld + scols;
-        // (the multiply-high row split would not be exact; ld == 1: the magic constant 2^32 + 1 does not fit 32 bits)
-        if (d.ld < 2 || span >= ((int64_t)1 << 32) / d.ld) { images_ok = false; break; }
-        im.off = d.src - param; im.span = (unsigned)span; im.ld = (unsigned)d.ld; im.magic = (unsigned)((((uint64_t)1 << 32) / d.ld) + 1);
-        im.cols = (int)scols; im.transpose = d.transpose ? 1 : 0; im.pad = 0; im.dst = reinterpret_cast<char*>(d.dst); im.ldp = d.ldp;
-    }
-    if (images_ok) fi.n = n_images;
     if (spilled || q.batch.n == 0 || !gte::folds_cover(q, grad, n)) return gte::flush_folds(q);   // caller runs gte_adam_step_dev
     const int vec_ok = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                          reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;

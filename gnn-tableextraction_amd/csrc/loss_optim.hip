@@ -8,6 +8,7 @@
 // Both are HBM-bound and tiny next to the transforms (N x 9 logits; <= 4 M parameters).  The CE
 // is deterministic: per-block partial sums in a fixed order, one reducing block, no atomics.
 #include "gte_common.h"
+#include "fold_images.h"
 #include "ce_fold.h"
 #include "p3.h"
 
@@ -128,10 +129,16 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
 //   state = {lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, sqrt(bc2)} for step t = *step_counter + 1.
 // The block that finishes LAST (ticket counter) advances the state to step t + 1: every block has read the state before it
 // takes its ticket, so the update cannot race with a reader.  bc in double like gte_adam_step's host side.
+// IMG: behind its update every thread writes the three bf16 pieces of the new parameter values into the operand images that hold
+// them (fold_images.h) -- the data-parallel step's Adam launch then leaves the next forward's weight images behind, as the
+// fold + Adam launch of the one-GPU step does (no conversion launch in front of the forward)
+template <bool IMG>
 __global__ void __launch_bounds__(1024)
 adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                int64_t n, float* __restrict__ state, int64_t* __restrict__ step_counter, unsigned* __restrict__ ticket) {
+                int64_t n, float* __restrict__ state, int64_t* __restrict__ step_counter, unsigned* __restrict__ ticket,
+                const gte::FoldImages img) {
     const gte::AdamCoef co = gte::adam_coef(state);
+    const unsigned all = img.n >= 32 ? 0xffffffffu : ((1u << img.n) - 1u);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     auto update = [&](float& pi, float gi_raw, float& mi_io, float& vi_io) { gte::adam_update(co, pi, gi_raw, mi_io, vi_io); };
     // 16-byte accesses over the aligned body (the flat buffers come from one allocation each: 16-byte aligned bases),
@@ -147,11 +154,16 @@ adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __res
         reinterpret_cast<float4*>(m)[i] = mv;
         reinterpret_cast<float4*>(v)[i] = vv;
         reinterpret_cast<float4*>(p)[i] = pv;
+        if constexpr (IMG) {
+            gte::fold_write_images2(img, all, 4 * i, pv.x, pv.y);
+            gte::fold_write_images2(img, all, 4 * i + 2, pv.z, pv.w);
+        }
     }
     for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float pi = p[i], mi = m[i], vi = v[i];
         update(pi, g[i], mi, vi);
         m[i] = mi; v[i] = vi; p[i] = pi;
+        if constexpr (IMG) gte::fold_write_images(img, all, i, pi);
     }
     gte::adam_advance(state, reinterpret_cast<long long*>(step_counter), ticket);
 }
@@ -367,7 +379,34 @@ extern "C" int gte_adam_step_dev(float* param, const float* grad, float* exp_avg
     // 1024 threads per block: at 590 k parameters every thread updates ONE 16-byte group (a 256-thread block looped 2-3
     // times through dependent load -> store chains: 10 us)
     const int64_t blocks = gte::ceil_div(n, 4096) < 256 ? gte::ceil_div(n, 4096) : 256;
-    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(1024), 0, gte::as_stream(stream), param, grad, exp_avg,
-                       exp_avg_sq, n, state, step_counter, ticket);
+    gte::FoldImages none;
+    none.n = 0;
+    hipLaunchKernelGGL(adam_dev_kernel<false>, dim3((unsigned)blocks), dim3(1024), 0, gte::as_stream(stream), param, grad, exp_avg,
+                       exp_avg_sq, n, state, step_counter, ticket, none);
     return gte::check_launch("adam_step_dev");
+}
+
+// gte_adam_step_dev that also writes the P3 images of the UPDATED parameters (gte_p3_desc[]: sub-matrices of `param`, as
+// gte_fold_defer_flush_adam_images takes them): the optimiser launch of the data-parallel step -- behind the gradient all-reduce,
+// where the fold launch cannot apply the update -- leaves the next forward's weight images behind.  *wrote = 1 when it did (a list
+// the launch cannot carry -- more than 12 images -- is skipped: the caller converts as before).
+extern "C" int gte_adam_step_dev_images(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                        int64_t* step_counter, unsigned* ticket, const gte_p3_desc* images, int n_images, int* wrote,
+                                        void* stream) {
+    if (wrote) *wrote = 0;
+    if (n <= 0) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev_images: n <= 0");
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state || !step_counter || !ticket || !wrote)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "adam_step_dev_images: null pointer");
+    gte::FoldImages fi;
+    const int rc = gte::make_fold_images(param, n, images, n_images, fi, "adam_step_dev_images");
+    if (rc != GTE_OK) return rc;
+    const int64_t blocks = gte::ceil_div(n, 4096) < 256 ? gte::ceil_div(n, 4096) : 256;
+    if (fi.n > 0)
+        hipLaunchKernelGGL(adam_dev_kernel<true>, dim3((unsigned)blocks), dim3(1024), 0, gte::as_stream(stream), param, grad, exp_avg,
+                           exp_avg_sq, n, state, step_counter, ticket, fi);
+    else
+        hipLaunchKernelGGL(adam_dev_kernel<false>, dim3((unsigned)blocks), dim3(1024), 0, gte::as_stream(stream), param, grad, exp_avg,
+                           exp_avg_sq, n, state, step_counter, ticket, fi);
+    *wrote = fi.n > 0 ? 1 : 0;
+    return gte::check_launch("adam_step_dev_images");
 }

@@ -875,6 +875,7 @@ class FusedGcnSageStep(TrainStep):
         lib, P = self.lib, _lib.ptr
         st = _lib.current_stream()
         plan, fused, b, n, keep = self._bind_plan(g, kinds, with_adam)
+        _arr = plan.wimg_descs                                       # (the descriptor array lives in the plan cache)
         lab = labels if labels.dtype in (torch.float32, torch.int64) else labels.to(torch.int64)
         plan.labels, plan.labels_f32 = P(lab), int(lab.dtype == torch.float32)
         plan.grad_scale = float(grad_scale)
@@ -914,6 +915,8 @@ class FusedGcnSageStep(TrainStep):
         if not capturing and ((fused.value & 2) or not with_adam):
             self._wimg_sig = sig
         self._keep = (lab,) + tuple(keep)                              # alive until the next step
+        # (the data-parallel step's own Adam launch writes the same images: gte_adam_step_dev_images)
+        self._last_wimg = (plan.wimg_descs, int(plan.n_wimg_descs), b["_wkey"], _arr) if not capturing else None
         return b["out3"]
 
     FORWARD_IMAGE_MAX_ELEMS = 1 << 21     # forward_logits: largest fp32 feature matrix that is converted to an image per call
@@ -1419,6 +1422,20 @@ class FusedGcnSageStep(TrainStep):
     def _adam_dev_launch(self) -> None:
         P = _lib.ptr
         self._wimg_sig = None
+        last = getattr(self, "_last_wimg", None)
+        self._last_wimg = None
+        if (last is not None and self.wimg_in_fold and 0 < last[1] <= 12 and not torch.cuda.is_current_stream_capturing()):
+            # the optimiser launch behind the all-reduce also writes the weight images of the step that just ran (one launch instead
+            # of Adam + a conversion launch in front of the next forward: the one-GPU step has both inside its fold launch)
+            wrote = ctypes.c_int(0)
+            _lib.check(self.lib.gte_adam_step_dev_images(P(self.flat_param), P(self.flat_grad), P(self.exp_avg), P(self.exp_avg_sq),
+                                                         self.flat_param.numel(), P(self._hyper), P(self._step_dev), P(self._ticket),
+                                                         last[0], last[1], ctypes.byref(wrote), _lib.current_stream()),
+                       "gte_adam_step_dev_images")
+            if wrote.value:
+                self._wimg_sig = (self._param_sig(), last[2])
+            self._step_dev_host += 1
+            return
         _lib.check(self.lib.gte_adam_step_dev(P(self.flat_param), P(self.flat_grad), P(self.exp_avg), P(self.exp_avg_sq),
                                               self.flat_param.numel(), P(self._hyper), P(self._step_dev), P(self._ticket),
                                               _lib.current_stream()), "gte_adam_step_dev")

@@ -712,6 +712,13 @@ int gte_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int64_t gte_adam_ticket_bytes(void);
 int gte_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                       int64_t* step_counter, unsigned* ticket, void* stream);
+/* gte_adam_step_dev + the P3 images of the UPDATED parameters in the same launch (images: sub-matrices of `param`, as
+ * gte_fold_defer_flush_adam_images takes them): the optimiser launch of the data-parallel step (behind the all-reduce of
+ * model_train.py:327-332's gradients, where the fold launch cannot apply the update) leaves the weight images of the next forward
+ * behind.  *wrote = 1 when the images were written (a list of more than 12 images is skipped). */
+int gte_adam_step_dev_images(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                             int64_t* step_counter, uint32_t* ticket, const gte_p3_desc* images, int n_images, int* wrote,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A13  multi-head graph attention (BASELINE.json configs[2]).  The reference has NO GAT: the

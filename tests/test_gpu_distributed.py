@@ -211,3 +211,56 @@ def test_a_budget_the_ranks_share_fits_makes_every_rank_hold_only_its_own_pages(
     m0, m1 = (np.load(os.path.join(tmp_path, f"train_metrics_{r}.npy")) for r in range(world))
     np.testing.assert_array_equal(m0[:2], m1[:2])
     assert np.isfinite(m0).all() and m0[0] < np.log(9.0)
+
+
+def _one_rank_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch.distributed as dist
+    import gnn_tableextraction_amd as gte
+    from gnn_tableextraction_amd import graph as G
+    from gnn_tableextraction_amd.data import synthetic as S
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    from gnn_tableextraction_amd.models.loop import BatchPipeline, run_steps
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    dev = "cuda:0"
+    out = {}
+    for f0, hid in ((831, 256), (363, 149), (13, 256)):
+        pages = S.make_pages(12, in_feats=f0)
+        graphs = []
+        for p in pages:
+            g = gte.PageGraph(p.src, p.dst, p.num_nodes)
+            g.ndata["feat"], g.ndata["label"] = torch.from_numpy(p.feat), torch.from_numpy(p.label.astype(np.float32))
+            g.edata["feat"] = torch.from_numpy(p.weight)
+            graphs.append(g)
+        steps = [np.array([(3 * s + j) % 12 for j in range(5)]) for s in range(4)]
+        res = {}
+        for dp in (False, True):
+            torch.manual_seed(5)
+            model = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0).to(dev)
+            tr = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4, distributed=dp)
+            pipe = BatchPipeline(G.ResidentPages(graphs, dev))
+            losses = []
+            counts = [int(sum(pages[i].num_nodes for i in ids)) for ids in steps]
+            run_steps(tr, pipe, steps, n_global=counts if dp else None, on_step=lambda s, g, o: losses.append(float(o[0])))
+            torch.cuda.synchronize()
+            res[dp] = (np.array(losses), tr.flat_param.detach().cpu().numpy(), tr.exp_avg_sq.detach().cpu().numpy(), tr._wimg_sig is not None)
+        out[f"{f0}_{hid}"] = res
+    import pickle
+    pickle.dump(out, open(os.path.join(out_dir, "one_rank.pkl"), "wb"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_with_one_rank_is_bitwise_the_single_gpu_step(tmp_path):
+    """The data-parallel step (fold launch -> all-reduce -> ONE launch for Adam + the weight images of the next forward,
+    gte_adam_step_dev_images) with a world of one rank against the one-GPU step (Adam and the images inside the fold launch): the
+    same arithmetic in a different launch -- losses, parameters and optimiser state bit for bit over four steps of the train loop,
+    and the images really were left by the optimiser launch (the next forward skipped their conversion)."""
+    import pickle
+    mp.start_processes(_one_rank_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    out = pickle.load(open(tmp_path / "one_rank.pkl", "rb"))
+    for k, res in out.items():
+        (l0, p0, v0, _), (l1, p1, v1, fresh) = res[False], res[True]
+        np.testing.assert_array_equal(l0, l1, err_msg=k)
+        np.testing.assert_array_equal(p0, p1, err_msg=k)
+        np.testing.assert_array_equal(v0, v1, err_msg=k)
+        assert fresh, f"{k}: the data-parallel optimiser launch did not leave the weight images behind"
