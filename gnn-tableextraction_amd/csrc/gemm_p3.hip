@@ -681,7 +681,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         // 4 l .. 4 l + 3, two-pass statistics over the n true columns): z, stats, y and the image are bit for bit what
         // gte_gemm_p3_nt + gte_ln_relu_fwd_p3 write ----
         asm volatile("s_barrier" ::: "memory");
-        static_assert(BN <= 256 && TN == 2, "whole rows per workgroup");
+        static_assert(BN <= 256, "whole rows per workgroup");
         constexpr int SR = TM * 32, LDT = 256;
         float* tile = reinterpret_cast<float*>(lds);
         const int n = p.N, M = p.M;
@@ -696,7 +696,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         float bv[TN];
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            const int col = wn * 64 + b * 32 + col_l;
+            const int col = wn * (TN * 32) + b * 32 + col_l;
             bv[b] = (p.bias && col < n) ? p.bias[col] : 0.f;
         }
         for (int sl = 0; sl < WM; ++sl) {
@@ -708,7 +708,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
                     for (int a = 0; a < TM; ++a)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            tile[(a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * LDT + wn * 64 + b * 32 + col_l] = acc[a][b][r] + bv[b];
+                            tile[(a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * LDT + wn * (TN * 32) + b * 32 + col_l] = acc[a][b][r] + bv[b];
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int row_base = m0 + sl * SR;
@@ -757,7 +757,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         // Per slice of TM * 32 rows: the waves that own them put their accumulators into LDS row-major, then every wave takes
         // rows of the slice in the layout of ln_relu_bwd_vec_kernel (lane l = columns 4 l .. 4 l + 3, two rows in flight) with
         // ITS arithmetic: dz is bit for bit what the separate launch computes from the stored product.
-        static_assert(BN <= 256 && TN == 2, "whole rows per workgroup");     // (BN = 128 / 192: hidden widths up to 128 / 192)
+        static_assert(BN <= 256, "whole rows per workgroup");     // (BN = 128 / 192: hidden widths up to 128 / 192)
         constexpr int SR = TM * 32, LDT = 256;                        // slice rows; floats per LDS row
         float* tile = reinterpret_cast<float*>(lds);
         constexpr bool MSK = LNB == 3;
@@ -787,7 +787,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
                     for (int a = 0; a < TM; ++a)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            tile[(a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * LDT + wn * 64 + b * 32 + col_l] = acc[a][b][r];
+                            tile[(a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * LDT + wn * (TN * 32) + b * 32 + col_l] = acc[a][b][r];
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int row_base = m0 + sl * SR;
@@ -1442,7 +1442,14 @@ namespace {
 // Row tile of the fused dX + LayerNorm-backward launch: 128.  (A 192-row instantiation served m > 128 x #CUs until round 3: its
 // epilogue's row slice + 96 accumulator registers did not fit the 170-register budget of three waves per SIMD -- 140 bytes of
 // scratch per lane.  Batches beyond one round of 128-row tiles run several rounds of the same kernel.)
-int lnb_row_tile(int64_t) { return 128; }
+// Round 5: 96 rows (1 x 8 waves of 96 x 32) while that covers m in ONE round of tiles -- 24 317 rows of the headline batch are 190
+// tiles of 128 rows on 256 CUs, a quarter of the chip idle for the whole launch; 254 tiles of 96 rows fill it.
+int lnb_row_tile(int64_t m) {
+    static const int forced = getenv("GTE_P3_LN_ROWS") ? atoi(getenv("GTE_P3_LN_ROWS")) : 0;         // (measurement: 96 / 128)
+    if (forced == 96 || forced == 128) return forced;
+    const int64_t cus = gte::device_props().cus;
+    return (m > 128 * cus / 2 && gte::ceil_div(m, 96) <= cus) ? 96 : 128;
+}
 // out[j] = sum_k part[k * stride + j]   (only when no fold deferral is open)
 __global__ void __launch_bounds__(256)
 p3_colsum_fold_kernel(const float* __restrict__ part, long long stride, int count, int n, float* __restrict__ out) {
@@ -1457,7 +1464,7 @@ p3_colsum_fold_kernel(const float* __restrict__ part, long long stride, int coun
 extern "C" int gte_gemm_p3_nt_ln_bwd_supported(int64_t n) { return (n >= 1 && n <= 256) ? 1 : 0; }
 extern "C" int64_t gte_gemm_p3_nt_ln_bwd_workspace_bytes(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 256;
-    return gte::round_up(gte::ceil_div(m, lnb_row_tile(m)) * 3 * n * 4, 256);
+    return gte::round_up(gte::ceil_div(m, 96) * 3 * n * 4, 256);       // (the smaller of the two row tiles: covers either choice)
 }
 // dy = [a1 | a2] b^T (m x n, n <= 256: a workgroup's tile holds whole rows) is NOT stored: the workgroup that computed a row
 // block runs the LayerNorm(+ReLU) backward of those rows on it -- dz = LN'(z)(mask . dy) as fp32 (feeds the transpose
@@ -1496,15 +1503,17 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
     p.ln_dz = dz; p.ln_lddz = lddz; p.ln_dzp3 = reinterpret_cast<char*>(dzp3); p.ln_ldp3 = ldp3;
     p.ln_part = reinterpret_cast<float*>(workspace);
     hipStream_t s = gte::as_stream(stream);
-    const int bm = lnb_row_tile(m);
+    const int wn_ = (n <= 128 ? 2 : (n <= 192 ? 3 : 4));
+    const int bm = (wn_ == 4 || getenv("GTE_P3_NT_WIDE")) ? lnb_row_tile(m) : 128;       // (the 96-row tile exists 256 columns wide)
     // column tile = the hidden width rounded up to 128 / 192 / 256 (round 5: the scaled runs' 96 ... 157 columns ran 256-wide tiles)
     static const int wide_only = getenv("GTE_P3_NT_WIDE") ? atoi(getenv("GTE_P3_NT_WIDE")) : 0;      // (measurement: the round-4 tile)
     const int wn = wide_only ? 4 : (n <= 128 ? 2 : (n <= 192 ? 3 : 4));
     if (n % 16 == 0) {
-        if (wn == 2) launch_lw_lnb<2, 2, 2, 2, 4>(p, s); else if (wn == 3) launch_lw_lnb<2, 3, 2, 2, 4>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
+        if (wn == 2) launch_lw_lnb<2, 2, 2, 2, 4>(p, s); else if (wn == 3) launch_lw_lnb<2, 3, 2, 2, 4>(p, s);
+        else if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
     } else {                                              // per-element validity, zero image columns up to the next multiple of 16
         if (wn == 2) launch_lw_lnb<2, 2, 2, 2, 4, 3>(p, s); else if (wn == 3) launch_lw_lnb<2, 3, 2, 2, 4, 3>(p, s);
-        else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);
+        else if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4, 3>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);
     }
     int rc = gte::check_launch("gemm_p3_nt_ln_bwd");
     if (rc != GTE_OK) return rc;
@@ -1564,6 +1573,7 @@ static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, cons
         else launch_lw_lnb<2, 4, 2, 2, 4, 4, true>(p, gte::as_stream(stream));
     } else if (n <= 128) launch_lw_lnb<2, 2, 2, 2, 4, 4>(p, gte::as_stream(stream));
     else if (n <= 192) launch_lw_lnb<2, 3, 2, 2, 4, 4>(p, gte::as_stream(stream));
+    else if (lnb_row_tile(m) == 96) launch_lw_lnb<1, 8, 3, 1, 4, 4>(p, gte::as_stream(stream));
     else launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
     return gte::check_launch("gemm_p3_nt_ln_fwd");
 }
