@@ -471,6 +471,30 @@ def forward_gemm_rate(ops, n, fin, fout, dev, aggregate_first=False, reps=10):
     return e0.elapsed_time(e1) / reps, flops
 
 
+def loop_forward_gemms(trainer, pipe, epochs, loop, f0, hid, kinds, n_global=None):
+    """The forward transform GEMMs of the two hidden layers INSIDE the train loop: HIP events recorded by the one-call step on its
+    launch stream around those launches (gte_step_plan.fwd_events), the steps of ``epochs`` one at a time.  A layer whose LayerNorm
+    runs as the GEMM's epilogue (the cached-aggregate input layer) is timed with it.  -> (ms [2], flops [2], steps)"""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    trainer.fwd_events = evs
+    ms, fl, steps = [0.0, 0.0], [0.0, 0.0], 0
+    try:
+        for e, plan_ in enumerate(epochs):
+            for k, ids in enumerate(plan_):
+                loop.run_steps(trainer, pipe, [ids], n_global=None if n_global is None else [n_global[e][k]])
+                torch.cuda.synchronize()
+                nn = pipe.nodes(0)
+                steps += 1
+                for li in range(2):
+                    if kinds[li] == 1:
+                        continue
+                    ms[li] += evs[2 * li].elapsed_time(evs[2 * li + 1])
+                    fl[li] += 2.0 * nn * (f0 if li == 0 else hid) * 2 * hid
+    finally:
+        trainer.fwd_events = None
+    return ms, fl, steps
+
+
 def shapes_probe(args, gte, dev, page_sets, loop):
     """The train loop (the same run_steps as the headline) on the shapes the reference's shipped runs use.  Per shape: nodes/s,
     ms/step, the layer plan the engine chose, and the forward transform GEMMs of the two hidden layers in isolation on the
@@ -510,7 +534,7 @@ def shapes_probe(args, gte, dev, page_sets, loop):
             if el is None or nodes_ / el_ > nodes / el:
                 el, nodes = el_, nodes_
         n_step = int(nodes / steps)
-        kinds = trainer._plan_kinds(f0, n_step)
+        kinds = trainer._plan_kinds(f0, n_step, res.agg_p3 is not None)
         gen, out_gemm = trainer._plan_mode(kinds, f0) if kinds is not None else (None, None)
         dims = [f0] + [hid] * (args.layers - 1) + [9]
         deg = float(sum(len(p.src) for p in pages)) / max(float(sum(p.num_nodes for p in pages)), 1.0)
@@ -518,7 +542,7 @@ def shapes_probe(args, gte, dev, page_sets, loop):
         entry = {"value": nodes / el, "unit": "nodes/s", "ms_per_step": el / steps * 1e3, "nodes_per_step": n_step,
                  "final_loss": float(out3[0]),
                  "plan": None if kinds is None else {"layer_kinds": kinds, "kinds": "0 planes transform-first, 1 one-pass short input, "
-                                                     "2 planes aggregate-first", "padded_rows": bool(gen),
+                                                     "2 planes aggregate-first, 3 cached aggregate (two resident images)", "padded_rows": bool(gen),
                                                      "output_layer": "planes GEMMs" if out_gemm else "narrow kernels"},
                  "step_tflops_fp32_eq": nodes / el * flops_node / 1e12,
                  "mfma_bound_nodes_per_s": mfma_b, "hbm_bound_nodes_per_s": hbm_b, "bytes_per_node": bytes_node,
@@ -528,21 +552,8 @@ def shapes_probe(args, gte, dev, page_sets, loop):
         if kinds is not None and trainer._planes_on():
             # the forward transform GEMMs of the two hidden layers INSIDE the loop: HIP events recorded by the one-call step on its
             # launch stream around those launches (gte_step_plan.fwd_events), eight more steps of the same loop, one at a time
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            trainer.fwd_events = evs
             more, e = epoch_steps(sizes, args.pages, 42, e, 8)
-            ms, fl = [0.0, 0.0], [0.0, 0.0]
-            for plan_ in more:
-                for ids in plan_:
-                    loop.run_steps(trainer, pipe, [ids])
-                    torch.cuda.synchronize()
-                    nn = pipe.nodes(0)
-                    for li in range(2):
-                        if kinds[li] == 1:
-                            continue
-                        ms[li] += evs[2 * li].elapsed_time(evs[2 * li + 1])
-                        fl[li] += 2.0 * nn * (f0 if li == 0 else hid) * 2 * hid
-            trainer.fwd_events = None
+            ms, fl, _ = loop_forward_gemms(trainer, pipe, more, loop, f0, hid, kinds)
             tot_ms, tot_fl = ms[0] + ms[1], fl[0] + fl[1]
             entry["forward_gemms"] = {"how": "HIP events on the launch stream around the two hidden layers' forward GEMM launches, 8 steps "
                                              "of the same loop (an event pair costs ~5 us of the interval it brackets)",
@@ -1196,8 +1207,19 @@ def main():
     else:
         nodes_total = float(nodes_local)
 
+    # the forward transform GEMMs of the loop the timed region ran (one-call step: events on its launch stream around them)
+    kinds_hl = trainer._plan_kinds(args.in_feats, int(np.mean(sizes)) * args.pages, resident.agg_p3 is not None) if args.layers == 3 else None
+    fwd_ev = None
+    if kinds_hl is not None and trainer._planes_on():
+        more, ep = epoch_steps(sizes, args.pages, seed, ep, 8)
+        ms2, fl2, n2 = loop_forward_gemms(trainer, pipe, more, loop, args.in_feats, args.hidden, kinds_hl,
+                                          n_global=global_counts(more) if distributed else None)
+        launches = n2 * sum(1 for k in kinds_hl[:2] if k != 1)
+        fwd_ev = (launches, ms2[0] + ms2[1], fl2[0] + fl2[1], ms2, fl2)
     if rank == 0:
         n_launch, ms, flops = kt.get("gemm_nt", (0, 0.0, 0.0))
+        if fwd_ev is not None and fwd_ev[1] > 0:
+            n_launch, ms, flops = fwd_ev[0], fwd_ev[1], fwd_ev[2]
         tf = (flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0
         # split mode: fp32-equivalent flops (2 M N K) against the bf16 matrix peak / 6 (six bf16 MFMA products per fp32 product)
         gemm_peak = MFMA_BF16_PEAK_TF / 6.0 if split_mode else MFMA_F32_PEAK_TF
@@ -1208,11 +1230,17 @@ def main():
                                ("gemm_split_kernel<NT> (layer transforms, forward; fp32 operands as 3 exact bf16 pieces, 6 bf16 "
                                 "MFMA products, fp32 accumulate; peak = bf16 dense / 6)")) if split_mode
                               else "gemm_f32_mfma_kernel<NT> (layer transforms, forward)",
-                    "kernel_short": (("gemm_p3_nt_lw/ring fwd (bf16x3 planes, peak=bf16/6)" if trainer._planes_on() else "gemm_split<NT> fwd (peak=bf16/6)")
+                    "kernel_short": (("gemm_p3_nt_lw/ring fwd, L0 with LN epilogue (bf16x3 planes, peak=bf16/6)" if trainer._planes_on() else "gemm_split<NT> fwd (peak=bf16/6)")
                                      if split_mode else "gemm_f32_mfma<NT> fwd"),
                     "achieved": tf, "peak": gemm_peak, "unit": "TFLOP/s", "frac": tf / gemm_peak,
                     "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
                     "algorithmic_flops_per_launch": flops / max(n_launch, 1),
+                    "how": ("HIP events recorded by the one-call step on its launch stream around the forward transform GEMM of each "
+                            "hidden layer, 8 steps of the same loop right after the timed region (layer kinds "
+                            f"{kinds_hl}: 3 = input layer on [x | cached mean aggregate], K = 2 F0, LayerNorm + ReLU in the GEMM's epilogue)")
+                           if fwd_ev is not None else "HIP-event timers around the tagged launches of the call-by-call schedule",
+                    "layer_ms": None if fwd_ev is None else [fwd_ev[3][0] / 8, fwd_ev[3][1] / 8],
+                    "layer_tflops": None if fwd_ev is None else [fwd_ev[4][i] / max(fwd_ev[3][i], 1e-9) / 1e9 for i in range(2)],
                     "traffic": pmc_traffic()[0].get(("gemm_nt_p3_bytes_per_launch" if trainer._planes_on() else "gemm_nt_split_bytes_per_launch")
                                                     if split_mode else "gemm_nt_bytes_per_launch")
                                if args.in_feats == 831 else None,
