@@ -14,7 +14,7 @@ out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pa
                  "profiles/pmc_probe.py spmm (cfg4); bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of "
                  "the kernel family (FETCH_SIZE x2: gfx950 counts the 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md HBM "
                  "section); the counters sit on the L2's memory side, so Infinity-Cache hits are included.  Scripts: profiles/refresh.sh, "
-                 "pmc_traffic_summary.py, make_pmc_traffic.py", "round": 4}
+                 "pmc_traffic_summary.py, make_pmc_traffic.py", "round": 5}
 for tag, pred in (("gemm_nt", lambda k: "gemm_f32_mfma_kernel<true, true" in k), ("gemm_tn", lambda k: "gemm_f32_mfma_kernel<false, false" in k),
                   ("gemm_nn", lambda k: "gemm_f32_mfma_kernel<true, false" in k), ("batch_assemble", lambda k: "batch_assemble" in k),
                   ("spmm_csr", lambda k: k.startswith("spmm_csr_kernel"))):

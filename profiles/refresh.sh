@@ -27,6 +27,7 @@ timeout 300 python3 profiles/debug/gemm_split_check.py > $O/gemm_split_check.txt
 python3 profiles/rocpd_summary.py $(ls $O/trace/*.db | head -1) $O/final_kernel_stats.csv > /dev/null
 python3 profiles/rocpd_summary.py $(ls $O/trace_step/*.db | head -1) $O/step_kernel_stats.csv > /dev/null
 bash profiles/pmc_refresh.sh $TAG > /dev/null       # FETCH_SIZE / WRITE_SIZE passes over profiles/pmc_step.py and the cfg4 probe
+bash profiles/pmc_mfma.sh $TAG > /dev/null          # round 5: matrix-pipe busy cycles / effective clock of the step's GEMM kernels
 # round 4: the reference's run shapes, the validation-graph forward, planes GEMMs beyond one round of tiles, the host-resident set
 bash profiles/shapes_refresh.sh $TAG > /dev/null
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_val -o t -- python3 $R/profiles/val_forward.py > $O/val_forward.log 2>&1)
