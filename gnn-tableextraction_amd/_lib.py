@@ -93,6 +93,13 @@ SIGNATURES = {
                                           c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                           c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gte_sage_narrow_pad_supported": (c_int, [c_int64, c_int64, c_int64]),
+    "gte_sage_narrow_fwd_pad": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                        c_void_p, c_int64, c_int64, c_void_p]),
+    "gte_sage_narrow_bwd_ln_p3_pad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+                                              c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                              c_int64, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gte_gemm_p3_nt_ln_bwd_supported": (c_int, [c_int64]),
     "gte_gemm_p3_nt_ln_bwd_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "gte_gemm_p3_nt_ln_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,

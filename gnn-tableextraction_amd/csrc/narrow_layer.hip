@@ -195,18 +195,24 @@ struct __attribute__((packed, aligned(4))) f4n { float x, y, z, w; };
 
 // stage rows of W into an LDS image: image row m <- W[src_row(m)][seg(m) * F + 0 .. F), zero when src_row >= C
 // HALF: image rows [0, HALF) come from W_s (seg 0), rows [HALF, 2 HALF) from W_n (seg 1)
+// Ft: the TRUE feature width of W ([C][2 Ft]: W_s = columns [0, Ft), W_n = [Ft, 2 Ft)); F >= Ft is the width the kernel computes
+// over (rows of h padded with zeros up to it -- hidden widths that are not a multiple of 8: round 5); image columns Ft .. F-1 zero
 template <int ROWS, int HALF>
 __device__ __forceinline__ void stage_w_image(float* __restrict__ img, int FP, const float* __restrict__ W, int64_t ldw, int F,
-                                              int C) {
+                                              int C, int Ft) {
     const int f4 = F / 4;
     for (int idx = threadIdx.x; idx < ROWS * f4; idx += blockDim.x) {
         const int m = idx / f4, k = (idx - m * f4) * 4;
         const int seg = m >= HALF ? 1 : 0, c = m - seg * HALF;
         float* dst = img + m * FP + k;
-        if (c < C) {
-            const float* src = W + (int64_t)c * ldw + seg * F + k;
+        if (c < C && k + 3 < Ft) {
+            const float* src = W + (int64_t)c * ldw + seg * Ft + k;
             const float x = src[0], y = src[1], z = src[2], w = src[3];
             dst[0] = x; dst[1] = y; dst[2] = z; dst[3] = w;
+        } else if (c < C && k < Ft) {
+            const float* src = W + (int64_t)c * ldw + seg * Ft + k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] = k + e < Ft ? src[e] : 0.f;
         } else {
             dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f;
         }
@@ -223,10 +229,10 @@ template <bool LNF>
 __global__ void __launch_bounds__(256)
 narrow_fwd_mfma_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ W, int64_t ldw,
                        const float* __restrict__ bias, float* __restrict__ t_self, int64_t lds_,
-                       float* __restrict__ t_neigh, int64_t ldn, int n, int F, int C, const LnForward lnf) {
+                       float* __restrict__ t_neigh, int64_t ldn, int n, int F, int C, const LnForward lnf, int Ft) {
     extern __shared__ __attribute__((aligned(16))) float Wl[];     // [32][F + 4]: col c < 16 -> W_s row c, 16 + c -> W_n row c
     const int FP = F + 4;                                          // LNF: + gamma[F], beta[F] behind the image
-    stage_w_image<32, 16>(Wl, FP, W, ldw, F, C);
+    stage_w_image<32, 16>(Wl, FP, W, ldw, F, C, Ft);
     float* GB = Wl + 32 * FP;
     if constexpr (LNF) {
         for (int k = threadIdx.x; k < F; k += blockDim.x) { GB[k] = lnf.gamma[k]; GB[F + k] = lnf.beta[k]; }
@@ -324,10 +330,10 @@ template <bool LNF>
 __global__ void __launch_bounds__(512)
 narrow_fwd_mfma16_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ W, int64_t ldw,
                          const float* __restrict__ bias, float* __restrict__ t_self, int64_t lds_,
-                         float* __restrict__ t_neigh, int64_t ldn, int n, int F, int C, const LnForward lnf) {
+                         float* __restrict__ t_neigh, int64_t ldn, int n, int F, int C, const LnForward lnf, int Ft) {
     extern __shared__ __attribute__((aligned(16))) float Wl[];
     const int FP = F + 4;
-    stage_w_image<32, 16>(Wl, FP, W, ldw, F, C);
+    stage_w_image<32, 16>(Wl, FP, W, ldw, F, C, Ft);
     float* GB = Wl + 32 * FP;
     if constexpr (LNF) {
         for (int k = threadIdx.x; k < F; k += blockDim.x) { GB[k] = lnf.gamma[k]; GB[F + k] = lnf.beta[k]; }
@@ -424,13 +430,17 @@ struct LnBackward {
 // (Round 2's form 1 -- the LayerNorm backward in the accumulator layout, row sums across the four waves -- measured slower than
 // two launches, 41.6 against 39 us at 24 k x 256, and is gone; so is form 2's option of gathering q = A_w^T (norm dl) from the
 // out-edge CSR inside the kernel: 18 us of dependent loads for the 6 us launch it saved.  profiles/r03/gemm_p3.md keeps the numbers.)
-template <int NCT, int LNB = 0>
+// MSK (with Ft < F): the rows are PADDED -- Ft true columns, zeros up to F (a multiple of 16): W is [C][2 Ft], the dW / LayerNorm
+// partials are written compact ([.][Ft]), the LayerNorm backward runs over the Ft true columns with per-element validity (the
+// arithmetic of ln_relu_bwd_gen_kernel) and writes zeros into the padding of dz and of its image
+template <int NCT, int LNB = 0, bool MSK = false>
 __global__ void __launch_bounds__(256)
 narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* __restrict__ q, int64_t ldq,
                        const float* __restrict__ h, int64_t ldh, const float* __restrict__ W, int64_t ldw,
                        float* __restrict__ dh, int64_t lddh, float* __restrict__ partial, int n, int F, int C,
                        const float* __restrict__ ce_partial, int64_t ce_blocks, float grad_scale, float* __restrict__ out3,
-                       const LnBackward lnb = LnBackward{}) {
+                       const LnBackward lnb = LnBackward{}, int Ft_ = 0) {
+    const int Ft = MSK ? Ft_ : F;
     constexpr int KD = 2 * NCT;                 // compact K of the dh product / M of the dW product
     constexpr int DP = KD + 1;                  // row stride of the DLQ image (odd: conflict-free read both ways)
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -451,14 +461,17 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
     struct __attribute__((packed, aligned(4))) f2n { float x, y; };
     // LNB == 2: lane l owns columns 4 l .. 4 l + 3 of the rows its wave takes
     const int j4 = 4 * lane;
-    const bool okc = j4 < F;
+    const bool okc = MSK ? j4 < ((Ft + 3) & ~3) : j4 < F;      // the lane holds a valid column
+    const bool imc = MSK ? j4 < F : okc;                        // ... or an image column of the padding (written as zero)
+    bool oke[4];
     float gam4[4] = {1.f, 1.f, 1.f, 1.f}, bet4[4] = {0.f, 0.f, 0.f, 0.f};
     float c_dg[4] = {0.f, 0.f, 0.f, 0.f}, c_db[4] = {0.f, 0.f, 0.f, 0.f}, c_dz[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (LNB == 2) {
-        if (okc) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { gam4[e] = lnb.gamma[j4 + e]; bet4[e] = lnb.beta[j4 + e]; }
-        }
+    for (int e = 0; e < 4; ++e) oke[e] = MSK ? j4 + e < Ft : okc;
+    if constexpr (LNB == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (oke[e]) { gam4[e] = lnb.gamma[j4 + e]; bet4[e] = lnb.beta[j4 + e]; }
     }
 
     // Row-block pipeline: the h rows (for the dW product) and the dl / q values of the NEXT row block are requested before
@@ -495,7 +508,7 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
         alpha = wsum > 0.f ? grad_scale / wsum : 0.f;
         if (blockIdx.x == 0 && threadIdx.x == 0 && out3) gte_ce::ce_write_out3(ce_red, out3);
     }
-    stage_w_image<KD, NCT>(Wst, FP, W, ldw, F, C);
+    stage_w_image<KD, NCT>(Wst, FP, W, ldw, F, C, Ft);
 
     for (int rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
         const int row0 = rb * 32;
@@ -556,7 +569,7 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                     }
                 }
                 __syncthreads();
-                const float inv_f = 1.0f / (float)F;
+                const float inv_f = 1.0f / (float)Ft;
 #pragma unroll
                 for (int trip = 0; trip < 2; ++trip) {
                     float gy[4][4];
@@ -574,16 +587,18 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                         if (rr >= n) continue;                               // wave-uniform
                         float xh[4], g[4];
                         float a = 0.f, b = 0.f;
-                        gte_ln_bwd_pre4(gy[u4], zr[u], mu2[u], rs2[u], gam4, bet4, okc, lnb.relu, xh, g, a, b);
+                        if constexpr (MSK) gte_ln_bwd_pre4m(gy[u4], zr[u], mu2[u], rs2[u], gam4, bet4, oke, lnb.relu, xh, g, a, b);
+                        else gte_ln_bwd_pre4(gy[u4], zr[u], mu2[u], rs2[u], gam4, bet4, okc, lnb.relu, xh, g, a, b);
                         const float c1 = gte_group_sum<64>(a) * inv_f, c2 = gte_group_sum<64>(b) * inv_f;
                         float d[4];
-                        gte_ln_bwd_post4(g, xh, gam4, rs2[u], c1, c2, okc, d, c_dg, c_db, c_dz);
+                        if constexpr (MSK) gte_ln_bwd_post4m(g, xh, gam4, rs2[u], c1, c2, oke, d, c_dg, c_db, c_dz);
+                        else gte_ln_bwd_post4(g, xh, gam4, rs2[u], c1, c2, okc, d, c_dg, c_db, c_dz);
                         if (okc) {
                             struct __attribute__((packed, aligned(4))) f4n { float x, y, z, w; };
                             f4n ov; ov.x = d[0]; ov.y = d[1]; ov.z = d[2]; ov.w = d[3];
                             *reinterpret_cast<f4n*>(dh + rr * lddh + j4) = ov;
-                            if (lnb.dzp3) p3::store4(lnb.dzp3 + rr * lnb.ldp3, j4, d[0], d[1], d[2], d[3]);
                         }
+                        if (imc && lnb.dzp3) p3::store4(lnb.dzp3 + rr * lnb.ldp3, j4, d[0], d[1], d[2], d[3]);
                     }
                 }
             } else
@@ -607,20 +622,20 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
     }
 
     // the workgroup's partial: every wave writes its own column slice
-    float* pp = partial + (int64_t)blockIdx.x * (2 * C * F + C);
+    float* pp = partial + (int64_t)blockIdx.x * (2 * C * Ft + C);       // (compact: [2 C][Ft] + [C])
     if (colok) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
             const int c = m < NCT ? m : m - NCT;
             if (m < KD && c < C) {
-                float* dst = pp + (int64_t)((m < NCT ? 0 : C) + c) * F + col;
-                dst[0] = gw[0][r];
-                dst[1] = gw[1][r];
+                float* dst = pp + (int64_t)((m < NCT ? 0 : C) + c) * Ft + col;
+                if (!MSK || col < Ft) dst[0] = gw[0][r];
+                if (!MSK || col + 1 < Ft) dst[1] = gw[1][r];
             }
         }
     }
-    if (wave == 0 && i < C && hh == 0) pp[2 * C * F + i] = gb;
+    if (wave == 0 && i < C && hh == 0) pp[2 * C * Ft + i] = gb;
     if constexpr (LNB == 2) {                   // column partials: the four waves through LDS, added in wave order
         __syncthreads();
         float* red = D + 32 * DP;                // [4][3][F]
@@ -633,9 +648,11 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
             }
         }
         __syncthreads();
-        float* lp = lnb.lnpart + (int64_t)blockIdx.x * 3 * F;
-        for (int t = threadIdx.x; t < 3 * F; t += 256)
-            lp[t] = ((red[t] + red[3 * F + t]) + red[6 * F + t]) + red[9 * F + t];
+        float* lp = lnb.lnpart + (int64_t)blockIdx.x * 3 * Ft;           // (compact: [3][Ft])
+        for (int t = threadIdx.x; t < 3 * F; t += 256) {
+            const int qq = t / F, j = t - qq * F;
+            if (!MSK || j < Ft) lp[qq * Ft + j] = ((red[t] + red[3 * F + t]) + red[6 * F + t]) + red[9 * F + t];
+        }
     }
 }
 
@@ -808,15 +825,18 @@ extern "C" int gte_sage_narrow_supported(int64_t n_feat, int64_t n_out) {
     return (n_out >= 1 && n_out <= NC_MAX && n_feat >= 1 && n_feat <= 256) ? 1 : 0;
 }
 
-extern "C" int gte_sage_narrow_fwd(const float* h, int64_t ldh, int64_t n_feat, const float* W, int64_t ldw,
-                                   const float* bias, int64_t n_out, float* t_self, int64_t ld_self, float* t_neigh,
-                                   int64_t ld_neigh, int64_t n_nodes, void* stream) {
-    if (!gte_sage_narrow_supported(n_feat, n_out) || n_nodes < 0 || n_nodes > INT32_MAX)
+// n_true: the width of W's halves ([C][2 n_true]); n_feat >= n_true: the width computed over (h rows zero-padded up to it)
+static int narrow_fwd_impl(const float* h, int64_t ldh, int64_t n_feat, int64_t n_true, const float* W, int64_t ldw,
+                           const float* bias, int64_t n_out, float* t_self, int64_t ld_self, float* t_neigh,
+                           int64_t ld_neigh, int64_t n_nodes, void* stream) {
+    if (!gte_sage_narrow_supported(n_feat, n_out) || n_nodes < 0 || n_nodes > INT32_MAX || n_true < 1 || n_true > n_feat)
         return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_fwd: needs n_out <= 16 and n_feat <= 256");
     if (n_nodes == 0) return GTE_OK;
     if (!h || !W || !t_self || !t_neigh) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_fwd: null pointer");
-    if (ldh < n_feat || ldw < 2 * n_feat || ld_self < n_out || ld_neigh < n_out)
+    if (ldh < n_feat || ldw < 2 * n_true || ld_self < n_out || ld_neigh < n_out)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_fwd: leading dimension too small");
+    if (n_true != n_feat && n_feat % 16 != 0)
+        return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_fwd_pad: the padded width must be a multiple of 16");
     hipStream_t s = gte::as_stream(stream);
     if (n_feat % 8 == 0) {                                 // matrix-pipe version
         const int64_t nblk = gte::ceil_div(n_nodes, 32);
@@ -828,12 +848,12 @@ extern "C" int gte_sage_narrow_fwd(const float* h, int64_t ldh, int64_t n_feat, 
             const int64_t nb16 = gte::ceil_div(gte::ceil_div(n_nodes, 16), 8);
             hipLaunchKernelGGL(narrow_fwd_mfma16_kernel<false>, dim3((unsigned)(nb16 < 2048 ? nb16 : 2048)), dim3(512),
                                (size_t)32 * (n_feat + 4) * 4, s, h, ldh, W, ldw, bias, t_self, ld_self, t_neigh, ld_neigh,
-                               (int)n_nodes, (int)n_feat, (int)n_out, LnForward{});
+                               (int)n_nodes, (int)n_feat, (int)n_out, LnForward{}, (int)n_true);
             return gte::check_launch("sage_narrow_fwd");
         }
         hipLaunchKernelGGL(narrow_fwd_mfma_kernel<false>, dim3((unsigned)mb), dim3(64 * wpb), (size_t)32 * (n_feat + 4) * 4, s, h,
                            ldh, W, ldw, bias, t_self, ld_self, t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out,
-                           LnForward{});
+                           LnForward{}, (int)n_true);
         return gte::check_launch("sage_narrow_fwd");
     }
     const int blocks = (int)(gte::ceil_div(n_nodes, 4) < 2048 ? gte::ceil_div(n_nodes, 4) : 2048);
@@ -847,6 +867,25 @@ extern "C" int gte_sage_narrow_fwd(const float* h, int64_t ldh, int64_t n_feat, 
 #undef GTE_NF
 #undef GTE_NF2
     return gte::check_launch("sage_narrow_fwd");
+}
+
+extern "C" int gte_sage_narrow_fwd(const float* h, int64_t ldh, int64_t n_feat, const float* W, int64_t ldw,
+                                   const float* bias, int64_t n_out, float* t_self, int64_t ld_self, float* t_neigh,
+                                   int64_t ld_neigh, int64_t n_nodes, void* stream) {
+    return narrow_fwd_impl(h, ldh, n_feat, n_feat, W, ldw, bias, n_out, t_self, ld_self, t_neigh, ld_neigh, n_nodes, stream);
+}
+// ... on PADDED rows: h [n][n_pad] holds n_feat true columns followed by zeros (n_pad a multiple of 16, <= 256: how the one-call
+// plan keeps hidden widths that are not a multiple of 16); W is the reference's [C][2 n_feat].  The products run over n_pad
+// columns against a weight image whose columns n_feat .. n_pad-1 are zero: the same sums, on the matrix-pipe kernels.
+extern "C" int gte_sage_narrow_pad_supported(int64_t n_feat, int64_t n_pad, int64_t n_out) {
+    return (n_out >= 1 && n_out <= NC_MAX && n_feat >= 1 && n_feat <= n_pad && n_pad <= 256 && n_pad % 16 == 0) ? 1 : 0;
+}
+extern "C" int gte_sage_narrow_fwd_pad(const float* h, int64_t ldh, int64_t n_feat, int64_t n_pad, const float* W, int64_t ldw,
+                                       const float* bias, int64_t n_out, float* t_self, int64_t ld_self, float* t_neigh,
+                                       int64_t ld_neigh, int64_t n_nodes, void* stream) {
+    if (!gte_sage_narrow_pad_supported(n_feat, n_pad, n_out))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_fwd_pad: needs n_out <= 16, n_feat <= n_pad <= 256, n_pad %% 16 == 0");
+    return narrow_fwd_impl(h, ldh, n_pad, n_feat, W, ldw, bias, n_out, t_self, ld_self, t_neigh, ld_neigh, n_nodes, stream);
 }
 
 extern "C" int gte_sage_narrow_fwd_ln_supported(int64_t n_feat, int64_t n_out) {
@@ -872,12 +911,12 @@ extern "C" int gte_sage_narrow_fwd_ln(const float* z, int64_t ldz, int64_t n_fea
         const int64_t nb16 = gte::ceil_div(gte::ceil_div(n_nodes, 16), 8);
         hipLaunchKernelGGL(narrow_fwd_mfma16_kernel<true>, dim3((unsigned)(nb16 < 2048 ? nb16 : 2048)), dim3(512),
                            (size_t)(32 * (n_feat + 4) + 2 * n_feat) * 4, gte::as_stream(stream), z, ldz, W, ldw, bias, t_self,
-                           ld_self, t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out, lnf);
+                           ld_self, t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out, lnf, (int)n_feat);
         return gte::check_launch("sage_narrow_fwd_ln");
     }
     hipLaunchKernelGGL(narrow_fwd_mfma_kernel<true>, dim3((unsigned)mb), dim3(64 * wpb),
                        (size_t)(32 * (n_feat + 4) + 2 * n_feat) * 4, gte::as_stream(stream), z, ldz, W, ldw, bias, t_self, ld_self,
-                       t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out, lnf);
+                       t_neigh, ld_neigh, (int)n_nodes, (int)n_feat, (int)n_out, lnf, (int)n_feat);
     return gte::check_launch("sage_narrow_fwd_ln");
 }
 
@@ -886,63 +925,73 @@ extern "C" int64_t gte_sage_narrow_bwd_workspace_bytes(int64_t n_nodes, int64_t 
 }
 
 namespace {
+// n_true (0: = n_feat): the true width of W's halves / of the hidden rows; n_feat then is the padded width computed over
 int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh, int64_t n_feat,
                     const float* W, int64_t ldw, int64_t n_out, float* dh, int64_t lddh, float* dW, int64_t lddw, float* dbias,
                     int64_t n_nodes, void* workspace, int64_t workspace_bytes, const float* ce_partial, int64_t ce_blocks,
                     float grad_scale, float* out3, void* stream, const LnBackward* lnb = nullptr, float* dgamma = nullptr,
-                    float* dbeta = nullptr, float* dbias_below = nullptr) {
-    if (!gte_sage_narrow_supported(n_feat, n_out) || n_nodes < 0 || n_nodes > INT32_MAX)
+                    float* dbeta = nullptr, float* dbias_below = nullptr, int64_t n_true = 0) {
+    if (n_true <= 0) n_true = n_feat;
+    if (!gte_sage_narrow_supported(n_feat, n_out) || n_nodes < 0 || n_nodes > INT32_MAX || n_true > n_feat)
         return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd: needs n_out <= 16 and n_feat <= 256");
     if (n_nodes == 0) return GTE_OK;
     if (!dl || !q || !h || !W || !dW || !workspace)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd: null pointer");
-    if (lddl < n_out || ldq < n_out || ldh < n_feat || ldw < 2 * n_feat || lddw < 2 * n_feat || (dh && lddh < n_feat))
+    if (lddl < n_out || ldq < n_out || ldh < n_feat || ldw < 2 * n_true || lddw < 2 * n_true || (dh && lddh < n_feat))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd: leading dimension too small");
     if (workspace_bytes < gte_sage_narrow_bwd_workspace_bytes(n_nodes, n_feat, n_out))
         return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd: workspace too small");
+    const bool msk = n_true != n_feat;
+    if (msk && (n_feat % 16 != 0 || !lnb))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd (padded rows): the padded width must be a multiple of 16, with the fused LayerNorm backward");
     hipStream_t s = gte::as_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
-    const int C = (int)n_out, F = (int)n_feat;
+    const int C = (int)n_out, F = (int)n_feat, Ft = (int)n_true;
     if (n_feat % 8 == 0) {                                 // matrix-pipe version
         const int nbm = narrow_mfma_blocks(n_nodes);
 #define GTE_NBM(NCT)                                                                                                  \
     do {                                                                                                              \
-        if (lnb)                                                                                                      \
+        if (lnb && msk)                                                                                               \
+            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 2, true>), dim3((unsigned)nbm), dim3(256),                \
+                               (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1) + 32 * F) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, \
+                               lddh, part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, *lnb, Ft);    \
+        else if (lnb)                                                                                                 \
             hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 2>), dim3((unsigned)nbm), dim3(256),                      \
                                (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1) + 32 * F) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, \
-                               lddh, part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, *lnb);        \
+                               lddh, part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, *lnb, 0);     \
         else                                                                                                          \
             hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 0>), dim3((unsigned)nbm), dim3(256),                      \
                                (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1)) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, lddh, \
-                               part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, LnBackward{});      \
+                               part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, LnBackward{}, 0);   \
     } while (0)
         if (n_out <= 4) GTE_NBM(4); else if (n_out <= 8) GTE_NBM(8); else if (n_out <= 12) GTE_NBM(12); else GTE_NBM(16);
 #undef GTE_NBM
+        // (the partials are compact: rows of Ft = the true width)
         if (lnb) {                                          // column sums of the fused LayerNorm backward
-            const bool own = !gte::defer_fold(lnb->lnpart, 3 * (int64_t)F, nbm, 1, F, dgamma, F);
+            const bool own = !gte::defer_fold(lnb->lnpart, 3 * (int64_t)Ft, nbm, 1, Ft, dgamma, Ft);
             if (own) {                                      // no deferral open: run the three folds now, as one launch
                 int rc = gte_fold_defer_begin(stream);
                 if (rc != GTE_OK) return rc;
-                gte::defer_fold(lnb->lnpart, 3 * (int64_t)F, nbm, 1, F, dgamma, F);
+                gte::defer_fold(lnb->lnpart, 3 * (int64_t)Ft, nbm, 1, Ft, dgamma, Ft);
             }
-            gte::defer_fold(lnb->lnpart + F, 3 * (int64_t)F, nbm, 1, F, dbeta, F);
-            gte::defer_fold(lnb->lnpart + 2 * F, 3 * (int64_t)F, nbm, 1, F, dbias_below, F);
+            gte::defer_fold(lnb->lnpart + Ft, 3 * (int64_t)Ft, nbm, 1, Ft, dbeta, Ft);
+            gte::defer_fold(lnb->lnpart + 2 * Ft, 3 * (int64_t)Ft, nbm, 1, Ft, dbias_below, Ft);
             if (own) {
                 // the narrow layer's own folds join the same launch
-                const int64_t ps = 2 * (int64_t)C * F + C;
-                gte::defer_fold(part, ps, nbm, C, F, dW, lddw);
-                gte::defer_fold(part + (int64_t)C * F, ps, nbm, C, F, dW + F, lddw);
-                gte::defer_fold(part + 2 * (int64_t)C * F, ps, nbm, 1, C, dbias, C);
+                const int64_t ps = 2 * (int64_t)C * Ft + C;
+                gte::defer_fold(part, ps, nbm, C, Ft, dW, lddw);
+                gte::defer_fold(part + (int64_t)C * Ft, ps, nbm, C, Ft, dW + Ft, lddw);
+                gte::defer_fold(part + 2 * (int64_t)C * Ft, ps, nbm, 1, C, dbias, C);
                 return gte_fold_defer_flush();
             }
         }
-        const int64_t pstride = 2 * (int64_t)C * F + C;
-        if (gte::defer_fold(part, pstride, nbm, C, F, dW, lddw)) {                    // [dl^T h]
-            gte::defer_fold(part + (int64_t)C * F, pstride, nbm, C, F, dW + F, lddw);   // [q^T h]
-            gte::defer_fold(part + 2 * (int64_t)C * F, pstride, nbm, 1, C, dbias, C);
+        const int64_t pstride = 2 * (int64_t)C * Ft + C;
+        if (gte::defer_fold(part, pstride, nbm, C, Ft, dW, lddw)) {                    // [dl^T h]
+            gte::defer_fold(part + (int64_t)C * Ft, pstride, nbm, C, Ft, dW + Ft, lddw);   // [q^T h]
+            gte::defer_fold(part + 2 * (int64_t)C * Ft, pstride, nbm, 1, C, dbias, C);
         } else {
-            hipLaunchKernelGGL(narrow_fold16_kernel, dim3((unsigned)gte::ceil_div(2 * C * F + C, 64)), dim3(1024), 0, s, part, nbm,
-                               F, C, dW, lddw, dbias);
+            hipLaunchKernelGGL(narrow_fold16_kernel, dim3((unsigned)gte::ceil_div(2 * C * Ft + C, 64)), dim3(1024), 0, s, part, nbm,
+                               Ft, C, dW, lddw, dbias);
         }
         return gte::check_launch("sage_narrow_bwd");
     }
@@ -1044,6 +1093,34 @@ extern "C" int gte_sage_narrow_bwd_ln_p3(const float* dl, int64_t lddl, const fl
                            workspace_bytes, reinterpret_cast<const float*>(ce_partial),
                            gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream, &lnb, dgamma_below,
                            dbeta_below, dbias_below);
+}
+
+// gte_sage_narrow_bwd_ln_p3 on PADDED rows (gte_sage_narrow_fwd_pad): h / z_below / dz_below rows hold n_feat true columns and
+// zeros up to n_pad (a multiple of 16; the image dzp3 is ceil(n_feat / 16) = n_pad / 16 blocks wide); W, dW are the reference's
+// [C][2 n_feat]; the LayerNorm backward runs over the n_feat true columns (the arithmetic of gte_ln_relu_bwd_p3 at that width) and
+// writes zeros into the padding.  Workspaces as for n_pad.
+extern "C" int gte_sage_narrow_bwd_ln_p3_pad(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
+                                             int64_t n_feat, int64_t n_pad, const float* W, int64_t ldw, int64_t n_out, float* dz_below,
+                                             int64_t lddz, void* dzp3, int64_t ldp3, float* dW, int64_t lddw, float* dbias,
+                                             int64_t n_nodes, void* workspace, int64_t workspace_bytes, const void* ce_partial,
+                                             float grad_scale, float* out3, const float* z_below, int64_t ldz, const float* stats_below,
+                                             const float* gamma_below, const float* beta_below, int relu_below, float* dgamma_below,
+                                             float* dbeta_below, float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes,
+                                             void* stream) {
+    if (!gte_sage_narrow_pad_supported(n_feat, n_pad, n_out))
+        return gte::fail(GTE_ERR_UNSUPPORTED, "sage_narrow_bwd_ln_p3_pad: needs n_out <= 16, n_feat <= n_pad <= 256, n_pad %% 16 == 0");
+    if (!dz_below || !z_below || !stats_below || !gamma_below || !beta_below || !ln_workspace || (ce_partial && !out3))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln_p3_pad: null pointer");
+    if (ldz < n_pad || lddz < n_pad || (dzp3 && (ldp3 < (int64_t)p3::row_bytes(n_pad) || ldp3 % 16 != 0)))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "sage_narrow_bwd_ln_p3_pad: leading dimension too small");
+    if (ln_workspace_bytes < gte_sage_narrow_bwd_ln_workspace_bytes(n_nodes, n_pad))
+        return gte::fail(GTE_ERR_WORKSPACE_TOO_SMALL, "sage_narrow_bwd_ln_p3_pad: LayerNorm workspace too small");
+    const LnBackward lnb = {z_below, ldz, stats_below, gamma_below, beta_below, relu_below, reinterpret_cast<float*>(ln_workspace),
+                            reinterpret_cast<char*>(dzp3), ldp3};
+    return narrow_bwd_impl(dl, lddl, q, ldq, h, ldh, n_pad, W, ldw, n_out, dz_below, lddz, dW, lddw, dbias, n_nodes, workspace,
+                           workspace_bytes, reinterpret_cast<const float*>(ce_partial),
+                           gte::ceil_div(n_nodes > 0 ? n_nodes : 1, 64), grad_scale, out3, stream, &lnb, dgamma_below,
+                           dbeta_below, dbias_below, n_feat);
 }
 
 extern "C" int64_t gte_sage_narrow_bwd_ln_workspace_bytes(int64_t n_nodes, int64_t n_feat) {

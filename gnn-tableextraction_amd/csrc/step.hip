@@ -27,6 +27,11 @@ bool head_gemm_fused(const gte_step_plan& p) {
 }
 
 
+// the narrow output kernels on a hidden width that is not a multiple of 8 (padded rows of ld_h_out floats: the general plan)
+bool narrow_padded(const gte_step_plan& p) {
+    return !p.out_gemm && p.out_fin % 8 != 0 && p.ld_h_out > p.out_fin && gte_sage_narrow_pad_supported(p.out_fin, p.ld_h_out, p.n_classes);
+}
+
 // weight images + the hidden layers (the output layer's input is p.h_out / p.hp_out afterwards).  fwd_only: nothing is kept for a
 // backward -- a planes layer whose output is consumed as an image (by the next planes layer, or by the output layer's GEMM) does
 // not write its fp32 rows (a sixth of the aggregation + LayerNorm kernel's bytes)
@@ -114,6 +119,9 @@ int forward_out_products(const gte_step_plan& p, void* st) {
     if (p.out_gemm)            // hidden widths the narrow kernels do not cover: one planes GEMM with N = 32 (rows 0.. = W_s, 16.. = W_n)
         return gte_gemm_p3_nt(p.hp_out, p.ldp_hout, p.out_fin, nullptr, 0, 0, p.wimg_out_fwd, p.ldp_wout_fwd, p.b_out, C, p.logits, lg, n,
                               32, 0, 0, st);
+    if (narrow_padded(p))      // hidden rows padded to 16 floats (zeros): the narrow kernels over the padded width
+        return gte_sage_narrow_fwd_pad(p.h_out, p.ld_h_out, p.out_fin, p.ld_h_out, p.W_out, 2 * p.out_fin, p.b_out, C, p.logits, lg, p.tn,
+                                       lg, n, st);
     return gte_sage_narrow_fwd(p.h_out, p.ld_h_out, p.out_fin, p.W_out, 2 * p.out_fin, p.b_out, C, p.logits, lg, p.tn, lg, n, st);
 }
 
@@ -179,6 +187,15 @@ int backward_a(const gte_step_plan& p, void* st) {
             GTE_TRY(gte_gemm_p3_nt(p.dlqp, p.ldp_dlq, 32, nullptr, 0, 0, p.wimg_out_bwd, p.ldp_wout_bwd, nullptr, 0, p.dh_out, p.ld_h_out, n,
                                    p.out_fin, 0, 0, st));
         }
+    } else if (narrow_padded(p)) {
+        // ... the same on padded rows (hidden widths that are not a multiple of 8): LayerNorm backward of the last hidden layer over
+        // its true width, partials written compact
+        GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));
+        GTE_TRY(gte_sage_narrow_bwd_ln_p3_pad(p.dl, C, p.q_out, C, p.h_out, p.ld_h_out, p.out_fin, p.ld_h_out, p.W_out, 2 * p.out_fin, C,
+                                              p.dh_out, p.ld_h_out, T.dzp, T.ldp_o, p.gW_out, 2 * p.out_fin, p.gb_out, n, p.ws_nar,
+                                              p.ws_nar_bytes, p.ce_part, p.grad_scale, p.out3, z_of(T), ldz_of(T), T.stats, T.gamma, T.beta,
+                                              T.relu, T.ggamma, T.gbeta, T.gbias, T.ws_ln, T.ws_ln_bytes, st));
+        ln_done = true;
     } else if ((p.fuse_ln_dx & 2) && T.kind == GTE_LAYER_PLANES && T.fout % 16 == 0 && gte_head_supported(p.out_fin, C)) {
         // the output layer's backward runs the LayerNorm(+ReLU) backward of the last hidden layer on the dh tile of every row block
         GTE_TRY(gte_spmm_csr(p.rindptr, p.rindices, p.w_out, p.dl, C, p.q_out, C, n, C, GTE_F32, GTE_REDUCE_SUM, st));

@@ -305,7 +305,7 @@ class FusedGcnSageStep(TrainStep):
                          else self._ws_dw_bytes(i, dims, cap)) for i in range(nh)]
         b["ws_ln"] = [u8(max(lib.gte_ln_relu_bwd_workspace_bytes(cap, dims[i + 1]),
                              lib.gte_gemm_p3_nt_ln_bwd_workspace_bytes(cap, dims[i + 1]) if dims[i + 1] <= 256 else 0,
-                             lib.gte_sage_narrow_bwd_ln_workspace_bytes(cap, min(dims[i + 1], 256)))) for i in range(nh)]
+                             lib.gte_sage_narrow_bwd_ln_workspace_bytes(cap, min(_c16(dims[i + 1]), 256)))) for i in range(nh)]
         C = dims[-1]
         b["out3"] = z32(3)
         if out_gemm:
@@ -318,7 +318,7 @@ class FusedGcnSageStep(TrainStep):
         else:
             b["logits"], b["tn"], b["q"], b["dl"] = z32(cap, C), z32(cap, C), z32(cap, C), z32(cap, C)
             b["ce_part"] = u8(lib.gte_head_agg_ce_workspace_bytes(cap))
-            b["ws_nar"] = u8(lib.gte_sage_narrow_bwd_workspace_bytes(cap, min(dims[-2], 256), min(C, 16)))
+            b["ws_nar"] = u8(lib.gte_sage_narrow_bwd_workspace_bytes(cap, min(_c16(dims[-2]), 256), min(C, 16)))
         return b
 
     def _buffers_gen(self, n: int, f0: int, kinds, out_gemm: bool):
@@ -396,6 +396,13 @@ class FusedGcnSageStep(TrainStep):
         (gte_sage_narrow_bwd_ln_p3: dz as fp32 + image)."""
         return (self.fuse_ln_narrow and i > 0 and i == len(layers) - 1 and bool(b["pl"][i - 1])
                 and self._narrow(layers[i], fin) and fin % 16 == 0 and bool(self.lib.gte_head_supported(fin, layers[i].out_feats)))
+
+    def _narrow_padded(self, layer, fin: int) -> bool:
+        """The narrow output kernels on PADDED hidden rows (gte_sage_narrow_fwd_pad / gte_sage_narrow_bwd_ln_p3_pad): a hidden width
+        that is not a multiple of 8 -- 100 / 139 / 149 / 157 / 206 / 218 of the reference's scaled runs -- up to 256 after padding
+        to 16; needs the fused head and the LayerNorm backward inside the output layer's backward (the padded form has no other)."""
+        return (self.general_planes and self.fused_head and self.fuse_ln_narrow and fin % 8 != 0
+                and bool(self.lib.gte_sage_narrow_pad_supported(fin, _c16(fin), layer.out_feats)))
 
     def _fused_head(self, i: int, layer, fin: int) -> bool:
         """Output layer + weighted CE as gte_head_agg_ce / gte_sage_narrow_bwd_ce (the last, narrow layer only)."""
@@ -576,7 +583,8 @@ class FusedGcnSageStep(TrainStep):
         layers = list(self.model.layers)
         dims = [f0] + [l.out_feats for l in layers]
         last = len(layers) - 1
-        out_gemm = not (self._narrow(layers[last], dims[last]) and self._fused_head(last, layers[last], dims[last]))
+        out_gemm = not (self._narrow(layers[last], dims[last]) and
+                        (self._fused_head(last, layers[last], dims[last]) or self._narrow_padded(layers[last], dims[last])))
         gen = out_gemm or any(k in (2, 3) or (k == 0 and not self._planes_layer(i, layers[i], dims[i])) for i, k in enumerate(kinds))
         return gen, out_gemm
 

@@ -636,6 +636,23 @@ int gte_sage_narrow_bwd_ln_p3(const float* dl, int64_t lddl, const float* q, int
                               const float* z_below, int64_t ldz, const float* stats_below, const float* gamma_below,
                               const float* beta_below, int relu_below, float* dgamma_below, float* dbeta_below,
                               float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes, void* stream);
+/* The output layer on PADDED hidden rows (round 5: hidden widths that are not a multiple of 8 -- int(calculate_hidden) = 100 / 139 /
+ * 149 / 157 / 206 / 218 of the reference's scaled runs -- keep the narrow kernels instead of three planes GEMMs): h, z_below and
+ * dz_below rows hold n_feat true columns and zeros up to n_pad (a multiple of 16, <= 256); W / dW are the reference's [C][2 n_feat].
+ * The products run over n_pad columns against a weight image whose padding is zero (the same sums); the fused LayerNorm backward
+ * runs over the n_feat true columns with the arithmetic of gte_ln_relu_bwd_p3 at that width and writes zeros into the padding of
+ * dz_below and of its image (n_pad / 16 blocks).  Workspace sizes: the functions above with n_feat = n_pad. */
+int gte_sage_narrow_pad_supported(int64_t n_feat, int64_t n_pad, int64_t n_out);
+int gte_sage_narrow_fwd_pad(const float* h, int64_t ldh, int64_t n_feat, int64_t n_pad, const float* W, int64_t ldw, const float* bias,
+                            int64_t n_out, float* t_self, int64_t ld_self, float* t_neigh, int64_t ld_neigh, int64_t n_nodes,
+                            void* stream);
+int gte_sage_narrow_bwd_ln_p3_pad(const float* dl, int64_t lddl, const float* q, int64_t ldq, const float* h, int64_t ldh,
+                                  int64_t n_feat, int64_t n_pad, const float* W, int64_t ldw, int64_t n_out, float* dz_below,
+                                  int64_t lddz, void* dzp3, int64_t ldp3, float* dW, int64_t lddw, float* dbias, int64_t n_nodes,
+                                  void* workspace, int64_t workspace_bytes, const void* ce_partial, float grad_scale, float* out3,
+                                  const float* z_below, int64_t ldz, const float* stats_below, const float* gamma_below,
+                                  const float* beta_below, int relu_below, float* dgamma_below, float* dbeta_below,
+                                  float* dbias_below, void* ln_workspace, int64_t ln_workspace_bytes, void* stream);
 
 /* LayerNorm + ReLU alone (row-wise over n_out):  y = relu?(gamma * (z - mean) * rstd + beta).
  * replaces models.py:64-66 when the caller ran the linear part separately.  In place (y == z) is

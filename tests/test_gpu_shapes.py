@@ -574,3 +574,60 @@ def test_resident_agg_image_is_the_mean_aggregate_of_every_page(f0):
     ah = oc._SpMM.apply(torch.from_numpy(feat), ref) * torch.from_numpy(ref.norm)            # models.py:53-57, 74-78
     np.testing.assert_allclose(got.cpu().numpy(), ah.numpy(), rtol=1e-5, atol=1e-5 * float(np.abs(feat).max()))
     assert img.data.shape[0] == res.n_nodes + 1 and not img.data[res.n_nodes].any()
+
+
+@pytest.mark.parametrize("f", [100, 139, 149, 157, 206, 218, 5, 250])
+@pytest.mark.parametrize("n,relu", [(3000, True), (77, False)])
+def test_narrow_output_kernels_on_padded_rows(f, n, relu):
+    """gte_sage_narrow_fwd_pad / gte_sage_narrow_bwd_ln_p3_pad (hidden widths that are not a multiple of 8, rows padded with zeros
+    to 16 floats: the one-call plan's layout) against the plain-FMA narrow kernels + gte_ln_relu_bwd_p3 at the true width: the
+    same sums in another order; W / dW in the reference's [C][2 f] layout; the padding of dz and of its image written as zeros."""
+    lib, P, cs, check = _lib.load(), _lib.ptr, _lib.current_stream, _lib.check
+    c, ld = 9, c16(f)
+    assert lib.gte_sage_narrow_pad_supported(f, ld, c) == 1
+    rng = np.random.default_rng(n + f)
+    t = torch.zeros((n, 2 * ld), device=DEV)                          # z = the left half of t (padding zero), as the planes layer keeps it
+    t[:, :f] = dev(rng.standard_normal((n, f)).astype(np.float32))
+    t[:, ld:ld + f] = dev(rng.standard_normal((n, f)).astype(np.float32))
+    gam, bet = dev(1 + 0.1 * rng.standard_normal(f).astype(np.float32)), dev(0.1 * rng.standard_normal(f).astype(np.float32))
+    h, stats = torch.zeros((n, ld), device=DEV), torch.zeros(2 * n, device=DEV)
+    check(lib.gte_ln_relu_fwd_p3(P(t), 2 * ld, P(gam), P(bet), 1e-5, int(relu), P(h), ld, None, 0, P(stats), n, f, cs()), "ln fwd")
+    assert not h[:, f:].any()
+    W = dev((rng.standard_normal((c, 2 * f)) / np.sqrt(2 * f)).astype(np.float32))
+    bias = dev(rng.standard_normal(c).astype(np.float32))
+    # forward
+    ts_a, tn_a, ts_b, tn_b = (torch.zeros((n, c), device=DEV) for _ in range(4))
+    check(lib.gte_sage_narrow_fwd(P(h), ld, f, P(W), 2 * f, P(bias), c, P(ts_a), c, P(tn_a), c, n, cs()), "fwd")
+    check(lib.gte_sage_narrow_fwd_pad(P(h), ld, f, ld, P(W), 2 * f, P(bias), c, P(ts_b), c, P(tn_b), c, n, cs()), "fwd_pad")
+    for got, want in ((ts_b, ts_a), (tn_b, tn_a)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(want.abs().max()) + 1e-7)
+    # backward: two launches at the true width
+    dl, q = dev(rng.standard_normal((n, c)).astype(np.float32) / n), dev(rng.standard_normal((n, c)).astype(np.float32) / n)
+    wsn = torch.empty(int(lib.gte_sage_narrow_bwd_workspace_bytes(n, ld, c)), dtype=torch.uint8, device=DEV)
+    dh, dWa, dba = torch.zeros((n, ld), device=DEV), torch.zeros((c, 2 * f), device=DEV), torch.zeros(c, device=DEV)
+    check(lib.gte_sage_narrow_bwd(P(dl), c, P(q), c, P(h), ld, f, P(W), 2 * f, c, P(dh), ld, P(dWa), 2 * f, P(dba), n, P(wsn), wsn.numel(),
+                                  cs()), "bwd")
+    dga, dbea, dbia = (torch.zeros(f, device=DEV) for _ in range(3))
+    dza, dzp_a = torch.zeros((n, ld), device=DEV), ops.P3.empty(n, f, DEV)
+    wl = torch.empty(int(lib.gte_ln_relu_bwd_workspace_bytes(n, f)), dtype=torch.uint8, device=DEV)
+    check(lib.gte_ln_relu_bwd_p3(P(dh), ld, P(t), 2 * ld, P(stats), P(gam), P(bet), int(relu), P(dza), ld, P(dzp_a.data), dzp_a.ldp, P(dga),
+                                 P(dbea), P(dbia), n, f, P(wl), wl.numel(), cs()), "ln bwd p3")
+    # one launch on the padded rows
+    dzb = torch.full((n, ld), 7.0, device=DEV)
+    dzb[:, (f + 3) // 4 * 4:] = 0                                       # (the padding beyond the row's last 16-byte chunk is the buffer's)
+    dWb, dbb = torch.zeros((c, 2 * f), device=DEV), torch.zeros(c, device=DEV)
+    dgb, dbeb, dbib = (torch.zeros(f, device=DEV) for _ in range(3))
+    dzp_b = ops.P3.empty(n, f, DEV)
+    dzp_b.data.fill_(0x55)
+    wln = torch.empty(int(lib.gte_sage_narrow_bwd_ln_workspace_bytes(n, ld)), dtype=torch.uint8, device=DEV)
+    check(lib.gte_sage_narrow_bwd_ln_p3_pad(P(dl), c, P(q), c, P(h), ld, f, ld, P(W), 2 * f, c, P(dzb), ld, P(dzp_b.data), dzp_b.ldp,
+                                            P(dWb), 2 * f, P(dbb), n, P(wsn), wsn.numel(), None, 1.0, None, P(t), 2 * ld, P(stats), P(gam),
+                                            P(bet), int(relu), P(dgb), P(dbeb), P(dbib), P(wln), wln.numel(), cs()), "bwd_ln_p3_pad")
+    ref = dza.cpu().numpy()
+    np.testing.assert_allclose(dzb.cpu().numpy()[:, :f], ref[:, :f], rtol=2e-5, atol=3e-6 * float(np.abs(ref).max()))
+    assert not dzb[:, f:].any()
+    img = ops.p3_to_f32(ops.P3(dzp_b.data, n, ld))                      # the whole padded image row
+    assert torch.equal(img[:, :f], dzb[:, :f]) and not img[:, f:].any()
+    for got, want in ((dWb, dWa), (dbb, dba), (dgb, dga), (dbeb, dbea), (dbib, dbia)):
+        r = want.cpu().numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), r, rtol=2e-5, atol=3e-6 * np.abs(r).max() + 1e-12)
