@@ -208,7 +208,7 @@ def test_run_shape_step_matches_reference_golden(name, both_gemm_modes):
         assert kinds is not None, "every run shape of the reference is on the one-call plan"
         gen, out_gemm = fused._plan_mode(kinds, f0)
         assert kinds[1:] == [0] * (len(kinds) - 1) and kinds[0] == (0 if 4 * hid <= 5 * f0 else 2)
-        assert out_gemm == (hid > 256 or hid % 8 != 0)
+        assert out_gemm == (hid > 256)       # (widths that are not a multiple of 8: the narrow kernels on padded rows, round 5)
     logits = fused.forward_logits(g).cpu().numpy()                  # gte_gcnsage_forward on the plan (module path in fp32 mode)
     np.testing.assert_allclose(logits, z["logits"], rtol=1e-5, atol=1e-5)
     out3 = fused.step(g, dev(y).float())
