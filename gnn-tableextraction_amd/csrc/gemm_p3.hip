@@ -681,7 +681,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         // 4 l .. 4 l + 3, two-pass statistics over the n true columns): z, stats, y and the image are bit for bit what
         // gte_gemm_p3_nt + gte_ln_relu_fwd_p3 write ----
         asm volatile("s_barrier" ::: "memory");
-        static_assert(BN <= 256, "whole rows per workgroup");
+        static_assert(BN == 256, "whole rows per workgroup");
         constexpr int SR = TM * 32, LDT = 256;
         float* tile = reinterpret_cast<float*>(lds);
         const int n = p.N, M = p.M;
@@ -757,7 +757,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         // Per slice of TM * 32 rows: the waves that own them put their accumulators into LDS row-major, then every wave takes
         // rows of the slice in the layout of ln_relu_bwd_vec_kernel (lane l = columns 4 l .. 4 l + 3, two rows in flight) with
         // ITS arithmetic: dz is bit for bit what the separate launch computes from the stored product.
-        static_assert(BN <= 256, "whole rows per workgroup");     // (BN = 128 / 192: hidden widths up to 128 / 192)
+        static_assert(BN == 256, "whole rows per workgroup");
         constexpr int SR = TM * 32, LDT = 256;                        // slice rows; floats per LDS row
         float* tile = reinterpret_cast<float*>(lds);
         constexpr bool MSK = LNB == 3;
@@ -1364,13 +1364,12 @@ void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
 // (~1.3 PF bf16 whatever the tile), so what matters is ONE balanced round of tiles: the row tile is the smallest of
 // 128 / 160 / 192 / 224 / 256 that covers M with at most one tile per CU; N is cut in 256-column tiles.
 struct NtCfg { int id, bm, bn, wgs; };
-// (ids 8 ... 19, round 5: column tiles of 160 / 192 / 224 for the hidden widths of the reference's scaled runs -- 2 x 96 ... 2 x 224
-// output columns on 256-wide tiles ran 14 ... 78 % padding through the matrix pipe; 1 x WN waves of (32 TM) x 32)
+// (Round 5 measured column tiles of 160 / 192 / 224 -- 1 x WN waves of (32 TM) x 32 -- for the output widths of the reference's
+// scaled runs, 2 x 96 ... 2 x 224 columns, which run 14 ... 78 % padding through the matrix pipe on 256-wide tiles: no gain, 1 - 3 %
+// slower on five of six shapes (profiles/r05/nt_tile_widths.txt): these launches are bound by the operand stream into LDS, the
+// padded MFMAs are free, and the 2 x 4 wave layout with loader waves hides more latency.  Removed again.)
 constexpr NtCfg kNtCfg[] = {{0, 64, 128, 3}, {1, 128, 128, 2}, {2, 128, 256, 1}, {3, 160, 256, 1}, {4, 192, 256, 1}, {5, 224, 256, 1},
-                            {6, 256, 256, 1},
-                            {8, 128, 160, 1}, {9, 160, 160, 1}, {10, 192, 160, 1}, {11, 224, 160, 1},
-                            {12, 128, 192, 1}, {13, 160, 192, 1}, {14, 192, 192, 1}, {15, 224, 192, 1},
-                            {16, 128, 224, 1}, {17, 160, 224, 1}, {18, 192, 224, 1}, {19, 224, 224, 1}};
+                            {6, 256, 256, 1}};
 // forced tile configuration: -1 = the chooser; gte_gemm_p3_set_nt_cfg (tests force every configuration in ONE process; until round 5
 // this was a static getenv read once -- the per-configuration tests that set the variable after the first GEMM of the process ran
 // the chooser's pick every time) or GTE_P3_NT_CFG at the first call
@@ -1378,14 +1377,12 @@ int g_nt_cfg = -2;
 int nt_choose(const P3Gemm& p) {
     if (g_nt_cfg == -2) g_nt_cfg = getenv("GTE_P3_NT_CFG") ? atoi(getenv("GTE_P3_NT_CFG")) : -1;
     const int forced = g_nt_cfg;
-    if (forced >= 0 && forced <= 19) return forced;
-    static const int wide_only = getenv("GTE_P3_NT_WIDE") ? atoi(getenv("GTE_P3_NT_WIDE")) : 0;      // (measurement: 1 = the round-4 tile set)
+    if (forced >= 0 && forced <= 7) return forced;
     const int cus = gte::device_props().cus;
     double best = 1e30;
     int bi = 0;
     for (const NtCfg& c : kNtCfg) {
         if (p.N <= 128 && c.bn > 128) continue;
-        if (wide_only && c.id >= 8) continue;
         const int64_t tiles = gte::ceil_div(p.M, c.bm) * gte::ceil_div(p.N, c.bn);
         const int64_t rounds = gte::ceil_div(tiles, (int64_t)cus * c.wgs);
         // makespan in units of tile area; small tiles pay for their operand traffic (load-bound below ~128 x 256)
@@ -1413,18 +1410,6 @@ int launch_nt(const P3Gemm& p, hipStream_t s) {
         case 3: launch_ring<1, 8, 5, 1, 3, 1>(p, s); break;    // 160 x 256: 1 x 8 waves of 160 x 32
         case 4: launch_lw<2, 4, 3, 2, 4>(p, s); break;         // 192 x 256: 8 compute + 4 loader waves
         case 5: launch_ring<1, 8, 7, 1, 3, 1>(p, s); break;    // 224 x 256
-        case 8: launch_ring<1, 5, 4, 1, 3, 1>(p, s); break;    // 128 ... 224 x 160
-        case 9: launch_ring<1, 5, 5, 1, 3, 1>(p, s); break;
-        case 10: launch_ring<1, 5, 6, 1, 3, 1>(p, s); break;
-        case 11: launch_ring<1, 5, 7, 1, 3, 1>(p, s); break;
-        case 12: launch_ring<1, 6, 4, 1, 3, 1>(p, s); break;   // 128 ... 224 x 192
-        case 13: launch_ring<1, 6, 5, 1, 3, 1>(p, s); break;
-        case 14: launch_ring<1, 6, 6, 1, 3, 1>(p, s); break;
-        case 15: launch_ring<1, 6, 7, 1, 3, 1>(p, s); break;
-        case 16: launch_ring<1, 7, 4, 1, 3, 1>(p, s); break;   // 128 ... 224 x 224
-        case 17: launch_ring<1, 7, 5, 1, 3, 1>(p, s); break;
-        case 18: launch_ring<1, 7, 6, 1, 3, 1>(p, s); break;
-        case 19: launch_ring<1, 7, 7, 1, 3, 1>(p, s); break;
         default: launch_ring<2, 4, 4, 2, 3, 1>(p, s); break;   // 256 x 256
     }
     return gte::check_launch("gemm_p3_nt");
@@ -1432,7 +1417,7 @@ int launch_nt(const P3Gemm& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int gte_gemm_p3_set_nt_cfg(int cfg) {
-    if (cfg < -1 || cfg > 19) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_set_nt_cfg: -1 (chooser) or a configuration id 0 ... 19");
+    if (cfg < -1 || cfg > 7) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_set_nt_cfg: -1 (chooser) or a configuration id 0 ... 7");
     g_nt_cfg = cfg;
     return GTE_OK;
 }
@@ -1503,17 +1488,12 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
     p.ln_dz = dz; p.ln_lddz = lddz; p.ln_dzp3 = reinterpret_cast<char*>(dzp3); p.ln_ldp3 = ldp3;
     p.ln_part = reinterpret_cast<float*>(workspace);
     hipStream_t s = gte::as_stream(stream);
-    const int wn_ = (n <= 128 ? 2 : (n <= 192 ? 3 : 4));
-    const int bm = (wn_ == 4 || getenv("GTE_P3_NT_WIDE")) ? lnb_row_tile(m) : 128;       // (the 96-row tile exists 256 columns wide)
-    // column tile = the hidden width rounded up to 128 / 192 / 256 (round 5: the scaled runs' 96 ... 157 columns ran 256-wide tiles)
-    static const int wide_only = getenv("GTE_P3_NT_WIDE") ? atoi(getenv("GTE_P3_NT_WIDE")) : 0;      // (measurement: the round-4 tile)
-    const int wn = wide_only ? 4 : (n <= 128 ? 2 : (n <= 192 ? 3 : 4));
+    const int bm = lnb_row_tile(m);
+    // (column tiles of 128 / 192 for hidden widths up to 128 / 192 were measured in round 5 and removed: 27 -> 30 us at 96 columns)
     if (n % 16 == 0) {
-        if (wn == 2) launch_lw_lnb<2, 2, 2, 2, 4>(p, s); else if (wn == 3) launch_lw_lnb<2, 3, 2, 2, 4>(p, s);
-        else if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
+        if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
     } else {                                              // per-element validity, zero image columns up to the next multiple of 16
-        if (wn == 2) launch_lw_lnb<2, 2, 2, 2, 4, 3>(p, s); else if (wn == 3) launch_lw_lnb<2, 3, 2, 2, 4, 3>(p, s);
-        else if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4, 3>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);
+        if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4, 3>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);
     }
     int rc = gte::check_launch("gemm_p3_nt_ln_bwd");
     if (rc != GTE_OK) return rc;
@@ -1567,12 +1547,8 @@ static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, cons
     } else if ((m + 256) * lda1 >= ((int64_t)1 << 31) || (k2 > 0 && (m + 256) * lda2 >= ((int64_t)1 << 31))) {
         return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_fwd: operand images must be < 2 GB");
     }
-    if (p.rows64) {                                        // images of 4 GB or more: 64-bit per-lane addresses (no range check: the
-        if (n <= 128) launch_lw_lnb<2, 2, 2, 2, 4, 4, true>(p, gte::as_stream(stream));      // rows past the tile re-read its first row)
-        else if (n <= 192) launch_lw_lnb<2, 3, 2, 2, 4, 4, true>(p, gte::as_stream(stream));
-        else launch_lw_lnb<2, 4, 2, 2, 4, 4, true>(p, gte::as_stream(stream));
-    } else if (n <= 128) launch_lw_lnb<2, 2, 2, 2, 4, 4>(p, gte::as_stream(stream));
-    else if (n <= 192) launch_lw_lnb<2, 3, 2, 2, 4, 4>(p, gte::as_stream(stream));
+    if (p.rows64)                                          // images of 4 GB or more: 64-bit per-lane addresses (no range check: the
+        launch_lw_lnb<2, 4, 2, 2, 4, 4, true>(p, gte::as_stream(stream));                    // rows past the tile re-read its first row)
     else if (lnb_row_tile(m) == 96) launch_lw_lnb<1, 8, 3, 1, 4, 4>(p, gte::as_stream(stream));
     else launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
     return gte::check_launch("gemm_p3_nt_ln_fwd");

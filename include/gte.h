@@ -418,9 +418,8 @@ int64_t gte_head_dlq_finish_workspace_bytes(int64_t n_nodes);
 int gte_head_dlq_finish(const int32_t* rindptr, const int32_t* rindices, const float* w_out, const float* dlq, int64_t lddlq,
                         int64_t n_nodes, int64_t n_classes, const void* ce_partial, float grad_scale, float* out3, void* dlqp3,
                         int64_t ldp, float* gbias, void* workspace, int64_t workspace_bytes, void* stream);
-/* Tile configuration of gte_gemm_p3_nt / _rows / _rows2: -1 = chosen per problem (default), 0 ... 19 = forced (tests run every
- * configuration against the same bits; 0 - 6 the 128- and 256-column tiles, 7 a measurement tile, 8 - 19 row tiles of 128 ... 224
- * on column tiles of 160 / 192 / 224 for output widths that are not a multiple of 256). */
+/* Tile configuration of gte_gemm_p3_nt / _rows / _rows2: -1 = chosen per problem (default), 0 ... 7 = forced (tests run every
+ * configuration against the same bits; 0 - 6 the 128- and 256-column tiles, 7 a measurement tile). */
 int gte_gemm_p3_set_nt_cfg(int cfg);
 /* Row maps: 0 = 64-bit addresses for resident images of 4 GB or more only (default), 1 = always (tests, A/B timing; the
  * zero-row requirement of gte_gemm_p3_tn_rows then holds for every image). */

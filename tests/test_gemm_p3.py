@@ -75,7 +75,7 @@ def test_nt_is_bitwise_the_split_kernel(split_mode, m, n, k):
     assert torch.equal(acc, want + 0.5)
 
 
-ALL_NT_CFGS = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+ALL_NT_CFGS = [0, 1, 2, 3, 4, 5, 6, 7]
 
 
 @pytest.fixture
