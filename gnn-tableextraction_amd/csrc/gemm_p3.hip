@@ -1544,8 +1544,6 @@ static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, cons
         p.rowsA = a_rows; p.res_bytes = n_res_rows * lda1;
         if (k2 > 0) { p.rows_both = 1; p.res_bytes2 = n_res_rows * lda2; }
         p.rows64 = (rows64_needed(p.res_bytes) || (k2 > 0 && rows64_needed(p.res_bytes2))) ? 1 : 0;
-    } else if ((m + 256) * lda1 >= ((int64_t)1 << 31) || (k2 > 0 && (m + 256) * lda2 >= ((int64_t)1 << 31))) {
-        return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_fwd: operand images must be < 2 GB");
     }
     if (p.rows64)                                          // images of 4 GB or more: 64-bit per-lane addresses (no range check: the
         launch_lw_lnb<2, 4, 2, 2, 4, 4, true>(p, gte::as_stream(stream));                    // rows past the tile re-read its first row)

@@ -83,15 +83,25 @@ int forward_hidden(const gte_step_plan& p, void* st, bool fwd_only = false) {
             // aggregate of the input is page-local and constant: cached when the pages were loaded), then LayerNorm + ReLU
             mark(2 * i);
             float* const y3 = (fwd_only && L.yp) ? nullptr : L.y;
+            // (h_rows == NULL: the two images hold the graph's own rows -- a graph that is evaluated again and again, e.g. the
+            // validation graph of train(), with its images made once)
             if ((p.fuse_ln_dx & 16) && gte_gemm_p3_nt_ln_fwd_supported(L.fout)) {      // the layer's whole forward in ONE launch
-                GTE_TRY(gte_gemm_p3_nt_rows2_ln_fwd(L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd, L.ldp_wfwd,
-                                                    L.bias, L.gamma, L.beta, L.eps, L.relu, L.t, ld, y3, ld, L.yp, L.ldp_y, L.stats, n,
-                                                    L.fout, st));
+                if (L.h_rows)
+                    GTE_TRY(gte_gemm_p3_nt_rows2_ln_fwd(L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd,
+                                                        L.ldp_wfwd, L.bias, L.gamma, L.beta, L.eps, L.relu, L.t, ld, y3, ld, L.yp, L.ldp_y,
+                                                        L.stats, n, L.fout, st));
+                else
+                    GTE_TRY(gte_gemm_p3_nt_ln_fwd(L.hp, L.ldp_h, L.fin, L.ahnp, L.ldp_ahn, L.fin, L.wimg_fwd, L.ldp_wfwd, L.bias, L.gamma,
+                                                  L.beta, L.eps, L.relu, L.t, ld, y3, ld, L.yp, L.ldp_y, L.stats, n, L.fout, st));
                 mark(2 * i + 1);
                 continue;
             }
-            GTE_TRY(gte_gemm_p3_nt_rows2(L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd, L.ldp_wfwd, L.bias,
-                                         L.fout, L.t, ld, n, L.fout, 0, 0, st));
+            if (L.h_rows)
+                GTE_TRY(gte_gemm_p3_nt_rows2(L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.fin, L.h_rows, L.n_res_rows, L.wimg_fwd, L.ldp_wfwd, L.bias,
+                                             L.fout, L.t, ld, n, L.fout, 0, 0, st));
+            else
+                GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, L.ahnp, L.ldp_ahn, L.fin, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, ld, n,
+                                       L.fout, 0, 0, st));
             mark(2 * i + 1);
             GTE_TRY(gte_ln_relu_fwd_p3(L.t, ld, L.gamma, L.beta, L.eps, L.relu, y3, ld, L.yp, L.ldp_y, L.stats, n, L.fout, st));
             continue;
@@ -262,6 +272,9 @@ int backward_b(const gte_step_plan& p, void* st) {
                                    L.relu, L.gW, 2 * L.fin, L.gbias, L.ggamma, L.gbeta, n, L.fout, L.ws_dw, L.ws_dw_bytes, st);
     if (L.kind == GTE_LAYER_SMALLK)
         return gte_sage_linear_dw(L.dy, L.fout, L.x, L.ldx, L.fin, L.ahn, L.fin, L.fin, L.gW, 2 * L.fin, L.fout, n, L.ws_dw, L.ws_dw_bytes, st);
+    if (L.kind == GTE_LAYER_CACHED && !L.h_rows)       // (the graph's own images: as the aggregate-first layer below)
+        return gte_gemm_p3_tn(L.dzp, L.ldp_o, nullptr, 0, L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.fin, L.gW, 2 * L.fin, L.fout, 2 * L.fin, n,
+                              L.ws_dw, L.ws_dw_bytes, st);
     if (L.kind == GTE_LAYER_CACHED)                    // dW = [dz^T x | dz^T ahn], both operands resident behind the row map
         return gte_gemm_p3_tn_rows2(L.dzp, L.ldp_o, L.hp, L.ldp_h, L.ahnp, L.ldp_ahn, L.h_rows, L.n_res_rows, L.fin, L.gW, 2 * L.fin,
                                     L.fout, 2 * L.fin, n, L.ws_dw, L.ws_dw_bytes, st);
@@ -295,8 +308,8 @@ int check_plan(const gte_step_plan& p) {
         const gte_step_layer& L = p.layer[i];
         if (L.kind != GTE_LAYER_PLANES && L.kind != GTE_LAYER_SMALLK && L.kind != GTE_LAYER_AGGFIRST && L.kind != GTE_LAYER_CACHED)
             return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: layer kind");
-        if (L.kind == GTE_LAYER_CACHED && (!L.hp || !L.ahnp || !L.h_rows || L.n_res_rows <= 0))
-            return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: a cached-aggregate layer needs both resident images and the row map");
+        if (L.kind == GTE_LAYER_CACHED && (!L.hp || !L.ahnp || (L.h_rows && L.n_res_rows <= 0)))
+            return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gcnsage_step: a cached-aggregate layer needs the images of the input and of its aggregate");
         if (L.kind != GTE_LAYER_PLANES && i != 0)
             return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: a short-input / aggregate-first layer must be layer 0");
         if (!L.gamma || !L.beta || !L.bias) return gte::fail(GTE_ERR_UNSUPPORTED, "gcnsage_step: hidden layers need bias and LayerNorm");

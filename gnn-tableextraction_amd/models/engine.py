@@ -568,13 +568,19 @@ class FusedGcnSageStep(TrainStep):
         x = g.ndata.get('feat')
         if x is None or not x.is_cuda or not self.wants_p3_features(x.shape[1]):
             return False
-        g.feat_p3 = ops.p3_from_f32(ops._row_major(x.to(torch.float32)))
+        x = ops._row_major(x.to(torch.float32))
+        g.feat_p3 = ops.p3_from_f32(x)
+        if self.wants_agg_image(x.shape[1]):
+            # ... and the image of the input's mean aggregate (constant too): layer 0 then is ONE launch, [x | ahn] W^T with LayerNorm
+            # + ReLU in its epilogue, instead of a GEMM and an aggregation + LayerNorm launch over [n, 2 hidden]
+            csr = g.in_csr()
+            g.agg_p3 = ops.spmm_csr_p3(csr.indptr, csr.indices, g.in_weights(g.edata.get("feat")), x, x.shape[0], mean=True)
         return True
 
     @staticmethod
     def _batch_cached(g) -> bool:
         xp, ap = getattr(g, "feat_p3", None), getattr(g, "agg_p3", None)
-        return xp is not None and ap is not None and xp.row_map is not None
+        return xp is not None and ap is not None and (xp.row_map is None) == (ap.row_map is None)
 
     def _plan_mode(self, kinds, f0: int):
         """(general, out_gemm) of a plan: ``general`` = it runs on the padded buffer set (_alloc_gen) -- some hidden layer lies
@@ -746,11 +752,11 @@ class FusedGcnSageStep(TrainStep):
         L0 = plan.layer[0]
         if kinds[0] == 3:
             ap = getattr(g, "agg_p3", None)
-            if xp is None or ap is None or xp.row_map is None:
-                raise _lib.GteError("a cached-aggregate input layer needs a resident batch with feat_p3 and agg_p3 behind a row map")
+            if xp is None or ap is None:
+                raise _lib.GteError("a cached-aggregate input layer needs feat_p3 and agg_p3 (resident images behind a row map, or the graph's own)")
             L0.hp, L0.ldp_h, L0.make_hp, L0.x = P(xp.data), xp.ldp, 0, None
             L0.ahnp, L0.ldp_ahn = P(ap.data), ap.ldp
-            L0.h_rows, L0.n_res_rows = P(xp.row_map), xp.res_rows
+            L0.h_rows, L0.n_res_rows = (P(xp.row_map), xp.res_rows) if xp.row_map is not None else (None, 0)
         elif kinds[0] == 0:
             if xp is not None:
                 L0.hp, L0.ldp_h, L0.make_hp, L0.x = P(xp.data), xp.ldp, 0, None

@@ -631,3 +631,40 @@ def test_narrow_output_kernels_on_padded_rows(f, n, relu):
     for got, want in ((dWb, dWa), (dbb, dba), (dgb, dga), (dbeb, dbea), (dbib, dbia)):
         r = want.cpu().numpy()
         np.testing.assert_allclose(got.cpu().numpy(), r, rtol=2e-5, atol=3e-6 * np.abs(r).max() + 1e-12)
+
+
+@pytest.mark.parametrize("f0,hid", [(831, 256), (363, 149), (831, 1000)])
+def test_a_graph_with_its_own_cached_images_runs_the_cached_input_layer(f0, hid):
+    """engine.attach_feature_image (what train() does to the validation graph): the graph keeps the P3 image of its features AND of
+    their mean aggregate, made once; forward_logits then runs layer 0 as ONE launch on [x | ahn] (GTE_LAYER_CACHED without a row map)
+    -- logits against the CPU oracle at 1e-5 -- and a training step on such a graph matches the step on the plain graph."""
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    pages = S.make_pages(9, in_feats=f0)
+    src, dst, w, feat, label, off = S.concat_pages(pages)
+    n = int(off[-1])
+    torch.manual_seed(7)
+    model = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0)
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    og = oc.OracleGraph(src, dst, n, w)
+    want = oc.gcnsage_forward(state0, og, torch.from_numpy(feat)).numpy()
+
+    def graph():
+        g = gte.PageGraph(src, dst, n, device=DEV)
+        g.ndata["feat"], g.edata["feat"] = dev(feat), dev(w)
+        return g
+    fused = FusedGcnSageStep(model.to(DEV), lr=0.01, weight_decay=5e-4)
+    g = graph()
+    assert fused.attach_feature_image(g) and g.agg_p3 is not None
+    assert fused._plan_kinds(f0, n, fused._batch_cached(g))[0] == 3
+    np.testing.assert_allclose(fused.forward_logits(g).cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    y = dev(label).float()
+    out_c = fused.step(g, y).clone()
+    p_c = fused.flat_param.detach().clone()
+    # the same step on the plain graph (layer 0 aggregates in the step)
+    torch.manual_seed(7)
+    m2 = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0).to(DEV)
+    f2 = FusedGcnSageStep(m2, lr=0.01, weight_decay=5e-4)
+    out_p = f2.step(graph(), y)
+    assert abs(float(out_c[0]) - float(out_p[0])) < 1e-5
+    d = (p_c - f2.flat_param).abs()
+    assert float(d.max()) <= 0.0201 and float((d > 1e-4).float().mean()) < 0.03        # (Adam's first step: lr where a gradient is noise)
