@@ -954,9 +954,11 @@ def compact_record(full):
     if "residency" in full:
         w = full["residency"]["windowed"]
         rec["residency"] = {"over_all_resident": {k: v["over_all_resident"] for k, v in w.items()}}
-    for k in ("replay", "secondary", "val_graph"):
+    for k in ("replay", "secondary"):
         if k in full and isinstance(full[k], dict) and "value" in full[k]:
             rec[k] = full[k]["value"]
+    if isinstance(full.get("val_graph"), dict) and "nodes_per_s" in full["val_graph"]:
+        rec["val_graph"] = full["val_graph"]["nodes_per_s"]
     if "gemm_modes" in full:
         rec["f32_mfma_mode"] = full["gemm_modes"]["other_mode"]["value"]
     if "dist_1rank" in full:

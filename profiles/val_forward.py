@@ -20,7 +20,7 @@ g.ndata["feat"], g.edata["feat"] = torch.from_numpy(feat).to(dev), torch.from_nu
 torch.manual_seed(0)
 model = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0).to(dev)
 eng = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
-print("image:", eng.attach_feature_image(g), "kinds:", eng._plan_kinds(f0, n))
+print("image:", eng.attach_feature_image(g), "kinds:", eng._plan_kinds(f0, n, eng._batch_cached(g)))
 for _ in range(3):
     eng.forward_logits(g)
 torch.cuda.synchronize()
