@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--no-shapes", action="store_true", help="skip the reference's own run shapes (hidden 1000 / scaled hidden)")
     ap.add_argument("--no-size-sweep", action="store_true", help="skip the pages-per-step sweep of the headline configuration")
     ap.add_argument("--no-residency", action="store_true", help="skip the host-resident (windowed) training-set probe")
+    ap.add_argument("--no-dist-probe", action="store_true", help="skip the one-rank data-parallel step (RCCL group of one) against the plain step")
     ap.add_argument("--gemm-mode", choices=["f32", "split_bf16"], default=None,
                     help="arithmetic of the transform GEMMs for the headline loop (default: GTE_GEMM_MODE or f32)")
     ap.add_argument("--no-split-probe", action="store_true",
@@ -202,6 +203,59 @@ def cpu_baseline(args, host_batch, state):
                       f"dense ops = torch CPU ({torch.get_num_threads()} threads)",
             "sample_short": f"{len(times)} train steps (median) on one {int(off[-1])}-node batch of the workload, {time.time() - t_all:.0f} s",
             "ms_per_step": med * 1e3}
+
+
+def dist_one_rank_probe(args, gte, dev, resident, pipe, sizes, loop, ep):
+    """The data-parallel step with ONE rank through the real RCCL process group against the one-GPU step, same loop, interleaved:
+    what the collective's launch and the split of the optimiser launch cost before any wire time (the fixed part of every weak-
+    scaling step).  The data-parallel step: fold launch -> all-reduce of the flat gradient -> ONE launch for Adam + the next
+    forward's weight images (gte_adam_step_dev_images)."""
+    import torch.distributed as dist
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    if dist.is_initialized():
+        return None
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env_keep = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE")}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    try:
+        import datetime
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=60))
+        trainers = {}
+        for dp in (False, True):
+            torch.manual_seed(42)
+            m = gte.GcnSAGE(args.in_feats, args.hidden, 9, args.layers, torch.nn.functional.relu, 0).to(dev)
+            trainers[dp] = FusedGcnSageStep(m, lr=0.01, weight_decay=5e-4, distributed=dp)
+        best = {False: None, True: None}
+        for rnd in range(3):
+            for dp in (False, True):
+                epochs, ep = epoch_steps(sizes, args.pages, 4242, ep, 12 if rnd == 0 else 48)
+                counts = [[int(sum(sizes[i] for i in ids)) for ids in plan] for plan in epochs]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                k = 0
+                for plan, cnt in zip(epochs, counts):
+                    loop.run_steps(trainers[dp], pipe, plan, n_global=cnt if dp else None)
+                    k += len(plan)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / k * 1e3
+                if rnd > 0 and (best[dp] is None or ms < best[dp]):
+                    best[dp] = ms
+        return {"plain_ms_per_step": best[False], "dist_1rank_ms_per_step": best[True], "extra_us": (best[True] - best[False]) * 1e3,
+                "how": "48 steps of the train loop per arm, two interleaved rounds after a warm-up round, the better of each arm; "
+                       "RCCL process group of one rank"}
+    except Exception as e:                                   # (no RCCL on this box / rendezvous refused: the probe is optional)
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in env_keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def val_graph_probe(args, gte, S, model, dev, pages, eng=None):
@@ -961,8 +1015,8 @@ def compact_record(full):
         rec["val_graph"] = full["val_graph"]["nodes_per_s"]
     if "gemm_modes" in full:
         rec["f32_mfma_mode"] = full["gemm_modes"]["other_mode"]["value"]
-    if "dist_1rank" in full:
-        rec["dist_1rank"] = full["dist_1rank"]
+    if isinstance(full.get("dist_1rank"), dict) and "extra_us" in full["dist_1rank"]:
+        rec["dist_1rank_extra_us"] = full["dist_1rank"]["extra_us"]
     rec["extras"] = "bench_extras.json"
     rec = {k: (_r(v, 7) if k in keep else _r(v)) for k, v in rec.items()}
     s = json.dumps(rec, separators=(",", ":"))
@@ -1320,6 +1374,10 @@ def main():
             pages_res = None
         if extras and not args.no_cfg3:
             line["cfg3"] = cfg3_probe(args, gte, dev)
+        if extras and not args.no_dist_probe and split_mode:
+            dp = dist_one_rank_probe(args, gte, dev, resident, pipe, sizes, loop, ep)
+            if dp is not None:
+                line["dist_1rank"] = dp
         if world == 1 and not args.no_cpu_baseline:
             ids = timed[0][0]
             cb = cpu_baseline(args, S.concat_pages([pages[int(i)] for i in ids]), state0)

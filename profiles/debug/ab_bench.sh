@@ -3,7 +3,7 @@
 #   bash profiles/debug/ab_bench.sh "GTE_CACHE_AGG=1" "GTE_CACHE_AGG=0"
 # prints value / ms_per_step / shapes per variant and round (bench_extras.json of each run is kept under gpurun_out/ab/)
 mkdir -p gpurun_out/ab
-FLAGS="--no-gather-probe --no-cfg3 --no-residency --no-size-sweep --no-inference --no-replay --val-graph 0 --no-cpu-baseline --no-split-probe --no-secondary ${AB_FLAGS}"
+FLAGS="--no-gather-probe --no-cfg3 --no-residency --no-size-sweep --no-inference --no-replay --val-graph 0 --no-cpu-baseline --no-split-probe --no-secondary --no-dist-probe ${AB_FLAGS}"
 for round in 1 2; do
   i=0
   for v in "$@"; do
