@@ -1042,12 +1042,27 @@ def emit(full):
                 print(f"bench.py: could not write bench_extras.json in {d}: {e}", file=sys.stderr)
     print(json.dumps(full), file=sys.stderr, flush=True)
     sys.stdout.flush()
-    print(compact_record(full), flush=True)
+    rec = compact_record(full) + "\n"
+    if _RECORD_FD is not None:
+        os.write(_RECORD_FD, rec.encode())
+    else:
+        sys.stdout.write(rec)
+        sys.stdout.flush()
+
+
+_RECORD_FD = None
 
 
 def main():
     args = parse()
     maybe_spawn(args)                       # --gpus N outside torchrun: N fresh ranks, before any GPU call (does not return)
+    # The record must be the LAST line on stdout.  Libraries write there too -- RCCL prints "Librccl path : ..." from C code when the
+    # process exits, after everything Python printed -- so file descriptor 1 of every rank is pointed at stderr for the rest of the
+    # process and the record alone goes to a private duplicate of the real stdout (emit).
+    global _RECORD_FD
+    sys.stdout.flush()
+    _RECORD_FD = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
