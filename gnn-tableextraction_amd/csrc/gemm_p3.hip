@@ -533,13 +533,10 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
 // not a multiple of 16 -- per-element validity, zeros up to the next multiple of 16 in the image); 2 the whole backward of a short-input
 // layer below as the epilogue
 // BIG: the row-mapped A operand (p.rowsA) is read through 64-bit per-lane addresses -- a resident image of 4 GB or more
-// NBUF: stage images in the ring (NBUF - 1 stages requested ahead).  Round 5: 4 for the one-column-of-tiles GEMMs with an epilogue
-// (96 / 128-row tiles): their stages are short (18 - 24 MFMAs per wave) against the same memory latency as the big tiles'
-template <int WM, int WN, int TM, int TN, int NL, int LNB = 0, bool BIG = false, int NBUF = 3>
+template <int WM, int WN, int TM, int TN, int NL, int LNB = 0, bool BIG = false>
 __global__ void __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL + 3) / 4)
 gemm_p3_nt_lw_kernel(const P3Gemm p) {
-    constexpr int NW = WM * WN;
-    static_assert(NBUF >= 3 && NBUF <= 5, "ring depth");
+    constexpr int NW = WM * WN, NBUF = 3;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_INST = BM * 96 / 1024, B_INST = BN * 96 / 1024, N_INST = A_INST + B_INST;
     constexpr int A_BYTES = BM * 96;
@@ -625,15 +622,14 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
                 dma16(isb[i] ? sb : sa, buf + (i * NL + lw) * 1024, seg ? vo2[i] : vo1[i]);
             });
         };
-        static_assert((NBUF - 2) * NI <= 24, "counted wait");
-#pragma unroll
-        for (int d = 0; d < NBUF - 1; ++d) issue(d, lds + d * STAGE);
-        wait_dma_barrier<(NBUF - 2) * NI>();                    // stage 0 has landed
-        int wr = NBUF - 1;
+        issue(0, lds);
+        issue(1, lds + STAGE);
+        wait_dma_barrier<NI>();
+        int wr = 2;
         for (int t = 0; t < T; ++t) {
-            issue(t + NBUF - 1, lds + wr * STAGE);              // (into the image stage t - 1 was read from: its readers passed the barrier)
+            issue(t + 2, lds + wr * STAGE);
             wr = wr + 1 == NBUF ? 0 : wr + 1;
-            wait_dma_barrier<(NBUF - 2) * NI>();                // stage t + 1 has landed
+            wait_dma_barrier<NI>();
         }
         // an epilogue that re-uses the stage images must not start before the LAST requests have landed: the two stages
         // requested past the end are empty windows, and an out-of-range LDS-DMA lane WRITES a zero
@@ -1351,24 +1347,18 @@ void launch_lw(const P3Gemm& p, hipStream_t s) {
     const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
     hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, 0, BIG>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
-template <int WM, int WN, int TM, int TN, int NL, int LNB = 1, bool BIG = false, int NBUF = 3>
+template <int WM, int WN, int TM, int TN, int NL, int LNB = 1, bool BIG = false>
 void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int NI = ((BM + BN) * 96 / 1024 + NL - 1) / NL, shm = NBUF * NI * NL * 1024;
-    static_assert(shm <= 160 * 1024, "LDS");
+    constexpr int NI = ((BM + BN) * 96 / 1024 + NL - 1) / NL, shm = 3 * NI * NL * 1024;
     static_assert(shm >= TM * 32 * 256 * 4 && shm >= WM * WN * 3 * 256 * 4, "the epilogue's row slice lives in the stage images");
     static bool configured = false;
     if (!configured) {
-        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG, NBUF>), shm);
+        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG>), shm);
         configured = true;
     }
     const dim3 grid((unsigned)gte::ceil_div(p.M, BM));
-    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG, NBUF>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
-}
-// ring depth of the LayerNorm-epilogue GEMMs (measurement: GTE_P3_LW_NBUF=3 keeps round 4's three stage images)
-int lw_nbuf() {
-    static const int v = getenv("GTE_P3_LW_NBUF") ? atoi(getenv("GTE_P3_LW_NBUF")) : 4;
-    return v == 3 ? 3 : 4;
+    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
 // Configurations (measured on the step's shapes, profiles/r03/gemm_p3.md): the kernel runs at the chip's power limit
 // (~1.3 PF bf16 whatever the tile), so what matters is ONE balanced round of tiles: the row tile is the smallest of
@@ -1500,13 +1490,10 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
     hipStream_t s = gte::as_stream(stream);
     const int bm = lnb_row_tile(m);
     // (column tiles of 128 / 192 for hidden widths up to 128 / 192 were measured in round 5 and removed: 27 -> 30 us at 96 columns)
-    const bool deep = lw_nbuf() == 4;
     if (n % 16 == 0) {
-        if (bm == 96) { if (deep) launch_lw_lnb<1, 8, 3, 1, 4, 1, false, 4>(p, s); else launch_lw_lnb<1, 8, 3, 1, 4>(p, s); }
-        else { if (deep) launch_lw_lnb<2, 4, 2, 2, 4, 1, false, 4>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4>(p, s); }
+        if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
     } else {                                              // per-element validity, zero image columns up to the next multiple of 16
-        if (bm == 96) { if (deep) launch_lw_lnb<1, 8, 3, 1, 4, 3, false, 4>(p, s); else launch_lw_lnb<1, 8, 3, 1, 4, 3>(p, s); }
-        else { if (deep) launch_lw_lnb<2, 4, 2, 2, 4, 3, false, 4>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s); }
+        if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4, 3>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);
     }
     int rc = gte::check_launch("gemm_p3_nt_ln_bwd");
     if (rc != GTE_OK) return rc;
@@ -1560,13 +1547,8 @@ static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, cons
     }
     if (p.rows64)                                          // images of 4 GB or more: 64-bit per-lane addresses (no range check: the
         launch_lw_lnb<2, 4, 2, 2, 4, 4, true>(p, gte::as_stream(stream));                    // rows past the tile re-read its first row)
-    else if (lnb_row_tile(m) == 96) {
-        if (lw_nbuf() == 4) launch_lw_lnb<1, 8, 3, 1, 4, 4, false, 4>(p, gte::as_stream(stream));
-        else launch_lw_lnb<1, 8, 3, 1, 4, 4>(p, gte::as_stream(stream));
-    } else {
-        if (lw_nbuf() == 4) launch_lw_lnb<2, 4, 2, 2, 4, 4, false, 4>(p, gte::as_stream(stream));
-        else launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
-    }
+    else if (lnb_row_tile(m) == 96) launch_lw_lnb<1, 8, 3, 1, 4, 4>(p, gte::as_stream(stream));
+    else launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
     return gte::check_launch("gemm_p3_nt_ln_fwd");
 }
 extern "C" int gte_gemm_p3_nt_ln_fwd_supported(int64_t n) { return (n >= 1 && n <= 256) ? 1 : 0; }
