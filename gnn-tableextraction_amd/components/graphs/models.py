@@ -62,10 +62,11 @@ class GcnSAGELayer(nn.Module):
         ln = isinstance(self.lynorm, nn.LayerNorm)
         fused_relu = _is_relu(self.activation)
         if self.dropout and self.training:
-            # dropout acts on cat(h, ah*norm): aggregate first, drop both halves, then the linear
+            # dropout acts on cat(h, ah*norm) (models.py:60-61 of the reference: concat, then ONE dropout call over [N, 2 in]):
+            # aggregate first, one mask over the concatenation, then the linear
             if not self.use_pp:
                 ahn = ops.aggregate(g, h, edge_weight, mean=True)
-                h = torch.cat((self.dropout(h), self.dropout(ahn)), dim=1)
+                h = self.dropout(torch.cat((h, ahn), dim=1))
             else:
                 h = self.dropout(h)
             out = ops.sage_layer(g, h, self.linear.weight, self.linear.bias,

@@ -1182,3 +1182,46 @@ def test_cfg2_primary_full_size_step_matches_the_oracle():
         after = model(g).cpu().numpy()
     ref_after = oc.gcnsage_forward(hyb, og, xt).numpy()
     assert np.abs(after - ref_after).max() < 1e-4
+
+
+@pytest.mark.parametrize("p_drop", [0.3, 0.5])
+def test_dropout_layer_draws_one_mask_over_the_concatenation_and_matches_torch(p_drop):
+    """GcnSAGELayer with dropout > 0 in training mode (models.py:58-66 of the reference: `h = concat(h, ah * norm)`, then ONE
+    `self.dropout(h)` over [N, 2 in], linear, LayerNorm, ReLU): with the device generator re-seeded, the layer's output and its
+    gradients equal the same formula in torch with the mask that one call draws (the reference's RNG consumption: one draw per
+    layer over the concatenation; round 4 drew two)."""
+    rng = np.random.default_rng(11)
+    n, f, out = 300, 24, 40
+    src, dst = rng.integers(0, n, 5 * n), rng.integers(0, n, 5 * n)
+    w = rng.uniform(0.1, 1.0, 5 * n).astype(np.float32)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    g = gte.PageGraph(src, dst, n, device=DEV)
+    g.edata["feat"] = dev(w)
+    torch.manual_seed(3)
+    layer = gte.GcnSAGELayer(f, out, torch.nn.functional.relu, p_drop).to(DEV)
+    layer.train()
+    xh = dev(x).requires_grad_(True)
+    torch.manual_seed(77)
+    y = layer(g, xh)
+    y.square().sum().backward()
+    gW, gx = layer.linear.weight.grad.clone(), xh.grad.clone()
+    # the same in torch: the mask of ONE dropout call over [n, 2 f] from the same generator state
+    og = oc.OracleGraph(src, dst, n, w)
+    torch.manual_seed(77)
+    mask = torch.nn.functional.dropout(torch.ones((n, 2 * f), device=DEV), p_drop, training=True)
+    xr = dev(x).double().requires_grad_(True)
+    A = torch.zeros((n, n), dtype=torch.float64, device=DEV)
+    A.index_put_((dev(dst).long(), dev(src).long()), dev(w).double(), accumulate=True)
+    norm = dev(og.norm).double()
+    cat = torch.cat((xr, (A @ xr) * norm), dim=1) * mask.double()
+    W, b = layer.linear.weight.detach().double().requires_grad_(True), layer.linear.bias.detach().double()
+    z = cat @ W.t() + b
+    ref = torch.relu(torch.nn.functional.layer_norm(z, (out,), layer.lynorm.weight.detach().double(), layer.lynorm.bias.detach().double(), 1e-5))
+    ref.square().sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gW.cpu().numpy(), W.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(W.grad.abs().max()))
+    np.testing.assert_allclose(gx.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(xr.grad.abs().max()))
+    layer.eval()                                                  # evaluation mode: no mask
+    with torch.no_grad():
+        y_eval = layer(g, dev(x))
+    assert not torch.equal(y_eval, y.detach())
