@@ -533,11 +533,7 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
 // not a multiple of 16 -- per-element validity, zeros up to the next multiple of 16 in the image); 2 the whole backward of a short-input
 // layer below as the epilogue
 // BIG: the row-mapped A operand (p.rowsA) is read through 64-bit per-lane addresses -- a resident image of 4 GB or more
-// DBF: the compute waves keep TWO fragment sets: the fragments of stage t + 1 are requested right behind the barrier that says
-// "stage t + 1 has landed, everybody has read stage t" and arrive under the MFMAs of stage t -- without it a wave's LDS reads of a
-// stage sit between the barrier and its first MFMA, and the two compute waves of a SIMD, released by the same barrier, read at
-// the same time.  Needs (TM + TN) * 24 more registers: the 96-row tile (TM = 3, TN = 1) has them.
-template <int WM, int WN, int TM, int TN, int NL, int LNB = 0, bool BIG = false, bool DBF = false>
+template <int WM, int WN, int TM, int TN, int NL, int LNB = 0, bool BIG = false>
 __global__ void __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL + 3) / 4)
 gemm_p3_nt_lw_kernel(const P3Gemm p) {
     constexpr int NW = WM * WN, NBUF = 3;
@@ -669,36 +665,12 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     asm volatile("s_barrier" ::: "memory");
     int rd = 0;
-    if constexpr (DBF) {
-        F fa, fb;
-        read_frags(fa, lds);
-        int t = 0;
-        // one stage: this wave's fragments of stage t are in registers (lgkmcnt) and so are everybody's (barrier): the loader may
-        // overwrite the image two stages on; stage t + 1 has landed (the loader waited for it in front of the same barrier)
-#define GTE_DBF_STAGE(CUR, NXT)                                                        \
-        {                                                                              \
-            /* builtins, not inline assembly: the compiler's wait-count pass must KNOW that the current set has arrived, */ \
-            /* or it waits for it again in front of the first MFMA -- behind the reads just issued (counters are in order) */  \
-            __builtin_amdgcn_s_waitcnt(0xc07f);              /* lgkmcnt(0) */          \
-            __builtin_amdgcn_s_barrier();                                              \
-            rd = rd + 1 == NBUF ? 0 : rd + 1;                                          \
-            if (t + 1 < T) read_frags(NXT, lds + rd * STAGE);                          \
-            products<TM, TN>(acc, CUR);                                                \
-            ++t;                                                                       \
-        }
-        while (t < T) {
-            GTE_DBF_STAGE(fa, fb)
-            if (t < T) GTE_DBF_STAGE(fb, fa)
-        }
-#undef GTE_DBF_STAGE
-    } else {
-        for (int t = 0; t < T; ++t) {
-            F f;
-            read_frags(f, lds + rd * STAGE);
-            products<TM, TN>(acc, f);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            rd = rd + 1 == NBUF ? 0 : rd + 1;
-        }
+    for (int t = 0; t < T; ++t) {
+        F f;
+        read_frags(f, lds + rd * STAGE);
+        products<TM, TN>(acc, f);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        rd = rd + 1 == NBUF ? 0 : rd + 1;
     }
     if constexpr (LNB == 0) {
         store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
@@ -1375,22 +1347,18 @@ void launch_lw(const P3Gemm& p, hipStream_t s) {
     const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, BN)));
     hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, 0, BIG>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
-template <int WM, int WN, int TM, int TN, int NL, int LNB = 1, bool BIG = false, bool DBF = false>
+template <int WM, int WN, int TM, int TN, int NL, int LNB = 1, bool BIG = false>
 void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NI = ((BM + BN) * 96 / 1024 + NL - 1) / NL, shm = 3 * NI * NL * 1024;
     static_assert(shm >= TM * 32 * 256 * 4 && shm >= WM * WN * 3 * 256 * 4, "the epilogue's row slice lives in the stage images");
     static bool configured = false;
     if (!configured) {
-        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG, DBF>), shm);
+        GTE_SET_LDS((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG>), shm);
         configured = true;
     }
     const dim3 grid((unsigned)gte::ceil_div(p.M, BM));
-    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG, DBF>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
-}
-bool lw_dbf() {                                          // (measurement: GTE_P3_DBF=0 keeps the single fragment set)
-    static const int v = getenv("GTE_P3_DBF") ? atoi(getenv("GTE_P3_DBF")) : 1;
-    return v != 0;
+    hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
 // Configurations (measured on the step's shapes, profiles/r03/gemm_p3.md): the kernel runs at the chip's power limit
 // (~1.3 PF bf16 whatever the tile), so what matters is ONE balanced round of tiles: the row tile is the smallest of
@@ -1523,11 +1491,9 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
     const int bm = lnb_row_tile(m);
     // (column tiles of 128 / 192 for hidden widths up to 128 / 192 were measured in round 5 and removed: 27 -> 30 us at 96 columns)
     if (n % 16 == 0) {
-        if (bm == 96) { if (lw_dbf()) launch_lw_lnb<1, 8, 3, 1, 4, 1, false, true>(p, s); else launch_lw_lnb<1, 8, 3, 1, 4>(p, s); }
-        else launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
+        if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
     } else {                                              // per-element validity, zero image columns up to the next multiple of 16
-        if (bm == 96) { if (lw_dbf()) launch_lw_lnb<1, 8, 3, 1, 4, 3, false, true>(p, s); else launch_lw_lnb<1, 8, 3, 1, 4, 3>(p, s); }
-        else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);
+        if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4, 3>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);
     }
     int rc = gte::check_launch("gemm_p3_nt_ln_bwd");
     if (rc != GTE_OK) return rc;
@@ -1581,10 +1547,8 @@ static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, cons
     }
     if (p.rows64)                                          // images of 4 GB or more: 64-bit per-lane addresses (no range check: the
         launch_lw_lnb<2, 4, 2, 2, 4, 4, true>(p, gte::as_stream(stream));                    // rows past the tile re-read its first row)
-    else if (lnb_row_tile(m) == 96) {
-        if (lw_dbf()) launch_lw_lnb<1, 8, 3, 1, 4, 4, false, true>(p, gte::as_stream(stream));
-        else launch_lw_lnb<1, 8, 3, 1, 4, 4>(p, gte::as_stream(stream));
-    } else launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
+    else if (lnb_row_tile(m) == 96) launch_lw_lnb<1, 8, 3, 1, 4, 4>(p, gte::as_stream(stream));
+    else launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
     return gte::check_launch("gemm_p3_nt_ln_fwd");
 }
 extern "C" int gte_gemm_p3_nt_ln_fwd_supported(int64_t n) { return (n >= 1 && n <= 256) ? 1 : 0; }
