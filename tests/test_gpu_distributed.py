@@ -126,7 +126,7 @@ def test_bench_self_spawned_two_ranks_share_the_gpu():
 # ---------------------------------------------------------------------------------------------------------------------
 # train() end to end with two ranks (the box has one GPU: both ranks on cuda:0, gloo): the eval confusion-matrix all-reduce
 # and the early-stop broadcast of model_train.py:230-249 run every epoch
-def _train_worker(rank, world, port, out_dir, budget_gb=None):
+def _train_worker(rank, world, port, out_dir, budget_gb=None, wide=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       GTE_KEEP_LAST_RUN="1")
     os.environ.pop("GTE_RESIDENT_BUDGET_GB", None)
@@ -137,12 +137,16 @@ def _train_worker(rank, world, port, out_dir, budget_gb=None):
     from gnn_tableextraction_amd.models import model_train
     from gnn_tableextraction_amd.parsers.graphs import parse_args_ModelTrain
     dist.init_process_group("gloo", rank=rank, world_size=world)       # train() finds the group initialised and keeps it
-    data = PrebuiltPages.synthetic(40, in_feats=13)
+    # wide: BBOX + REPR + SPACY = 363 input features, hidden 128 -- the input layer runs on the cached mean aggregate of the input
+    # (a second resident image; the windows of a host-resident set compute theirs per upload)
+    data = PrebuiltPages.synthetic(80 if wide else 40, in_feats=363 if wide else 13)
     for p, g in zip(data.page_arrays, data.graphs):                   # learnable labels (as test_gpu_train_entry.py)
         y = (p.feat[:, 1] // 260).astype(np.int64).clip(0, 8)
         p.label[:] = y
         g.ndata['label'] = torch.from_numpy(y.astype(np.float32))
-    cfg = parse_args_ModelTrain(argv=["--mode=knn", "--features", "BBOX", "--n_layers=3", "--mode_params=fixed", "--h_layer_dim=64",
+    feats = ["BBOX", "REPR", "SPACY"] if wide else ["BBOX"]
+    cfg = parse_args_ModelTrain(argv=["--mode=knn", "--features"] + feats + ["--n_layers=3", "--mode_params=fixed",
+                                      f"--h_layer_dim={128 if wide else 64}",
                                       "--batch_size=4", "--n_epochs=3", "--lr=0.01", "--output_dir", os.path.join(out_dir, f"rank{rank}")])
     metrics = model_train.train(data, cfg)
     run = model_train.LAST_RUN
@@ -264,3 +268,20 @@ def test_data_parallel_step_with_one_rank_is_bitwise_the_single_gpu_step(tmp_pat
         np.testing.assert_array_equal(p0, p1, err_msg=k)
         np.testing.assert_array_equal(v0, v1, err_msg=k)
         assert fresh, f"{k}: the data-parallel optimiser launch did not leave the weight images behind"
+
+
+def test_windowed_residency_with_the_cached_aggregate_and_two_ranks(tmp_path):
+    """train() at 363 input features / hidden 128 under a budget below a rank's share: the windows carry the image of the input's
+    mean aggregate (computed per upload on the copy stream) and the input layer runs on it; two ranks keep bit-identical replicas,
+    the run learns."""
+    world = 2
+    # 76 training pages ~ 17 500 nodes x (2 x 2 208 B of images + ~120 B of CSRs) ~ 80 MB: 30 MB per rank (a slot of ~13 MB holds the
+    # largest page) forces three or four windows per rank
+    mp.start_processes(_train_worker, args=(world, _free_port(), str(tmp_path), 0.03, True), nprocs=world, join=True, start_method="spawn")
+    assert [open(os.path.join(tmp_path, f"train_tier_{r}.txt")).read() for r in range(world)] == ["windowed", "windowed"]
+    p0, p1 = (np.load(os.path.join(tmp_path, f"train_param_{r}.npy")) for r in range(world))
+    np.testing.assert_array_equal(p0, p1)
+    w0 = np.load(os.path.join(tmp_path, "train_windows_0.npy"))
+    assert w0[0] >= 2 and w0[1] > 0
+    m0 = np.load(os.path.join(tmp_path, "train_metrics_0.npy"))
+    assert np.isfinite(m0).all() and m0[0] < np.log(9.0)
