@@ -555,8 +555,18 @@ class ResidentPages:
         want = os.environ.get("GTE_P3_ROWS", "1").lower() not in ("0", "off", "false")
         self.p3_mode = "rows" if (rows_ok and want) else "copy"
 
+    def drop_f32(self) -> None:
+        """Free the fp32 feature rows once the batches are row maps into the image(s): nothing in the step reads them any more
+        (4 of the 16 bytes a resident feature value costs with both images).  ``disable_p3`` brings them back from the image,
+        which holds exactly the fp32 values."""
+        if self.feat_p3 is not None and self.p3_mode == "rows" and self.feat.shape[0] == self.n_nodes:
+            self.feat = torch.empty((0, int(self.feat.shape[1])), dtype=torch.float32, device=self.device)
+
     def disable_p3(self) -> None:
         """batches carry fp32 ``ndata['feat']`` again (the image stays cached for the next switch)"""
+        if self.feat.shape[0] != self.n_nodes and self.feat_p3 is not None:
+            from . import ops
+            self.feat = ops.p3_to_f32(ops.P3(self.feat_p3.data[:self.n_nodes], self.n_nodes, int(self.feat.shape[1])))
         self.p3_mode = False
 
     def __len__(self):

@@ -237,6 +237,8 @@ def train(data, config, name_time=None):
         else:
             passes = 1                 # one window = every page the rank owns: a pass is a shuffled epoch over them
             wp = R.OwnedResident([train_graphs[i] for i in mine], device)
+            if want_p3:
+                wp.to_images(want_agg)
         # every rank's stream (pure host logic): the node counts / weight sums of a step follow without communication
         streams = []
         for r in range(world):
@@ -272,6 +274,10 @@ def train(data, config, name_time=None):
         resident = G.ResidentPages(train_graphs, device)
         pipe = BatchPipeline(resident)          # a step's batch is assembled on a side stream while the step before it runs
         sizes = resident.page_sizes()
+        if want_p3:
+            # the images now (run_steps would make them at the first epoch) so that the fp32 rows can go: batches are row maps
+            resident.enable_p3(agg=want_agg)
+            resident.drop_f32()
     val_shard = val_graphs[rank::world] if distributed else val_graphs
     val_graph = G.batch([g.to(device) for g in val_shard]) if val_shard else None
     val_labels = None if val_graph is None else val_graph.ndata['label']

@@ -456,14 +456,20 @@ class OwnedResident:
     def acquire(self, w: int, also: Sequence[torch.cuda.Stream] = ()) -> G.ResidentPages:
         return self.res
 
+    def to_images(self, agg: bool) -> None:
+        """layer 0 takes images: make them now and let the fp32 rows go (graph.ResidentPages.drop_f32)"""
+        self.res.enable_p3(agg=agg)
+        self.res.drop_f32()
+
     def release(self, w: int) -> None:
         pass
 
 
 def default_budget_bytes(set_bytes: float, free_bytes: float, total_bytes: float) -> Optional[float]:
     """The HBM budget of the training pages when GTE_RESIDENT_BUDGET_GB is not set: None (keep the whole set resident) while the
-    set fits in 70 % of what is free now -- the rest is for the validation graph, the step's per-batch buffers (a few GB at
-    hidden 1000) and the allocator's slack --, otherwise half of the free memory (two window slots + staging rows)."""
-    if set_bytes <= 0.7 * free_bytes:
+    set fits in 60 % of what is free now -- while the images are made the fp32 rows are still there (a third more than the resident
+    form), and the rest is for the validation graph, the step's per-batch buffers (a few GB at hidden 1000) and the allocator's
+    slack --, otherwise half of the free memory (two window slots + staging rows)."""
+    if set_bytes <= 0.6 * free_bytes:
         return None
     return 0.5 * free_bytes

@@ -133,8 +133,9 @@ def test_window_stream_skip_lands_where_take_would():
 
 def test_default_budget_keeps_a_fitting_set_resident_and_windows_a_larger_one():
     GB = 1e9
-    assert R.default_budget_bytes(100 * GB, 280 * GB, 288 * GB) is None          # fits in 70 % of the free HBM: all resident
-    assert R.default_budget_bytes(195 * GB, 280 * GB, 288 * GB) is None
+    assert R.default_budget_bytes(100 * GB, 280 * GB, 288 * GB) is None          # fits in 60 % of the free HBM: all resident
+    assert R.default_budget_bytes(165 * GB, 280 * GB, 288 * GB) is None
+    assert R.default_budget_bytes(175 * GB, 280 * GB, 288 * GB) == 140 * GB
     b = R.default_budget_bytes(500 * GB, 280 * GB, 288 * GB)                     # PubLayNet's full train split at F0 = 831
     assert b == 140 * GB
     assert R.default_budget_bytes(10 * GB, 12 * GB, 288 * GB) == 6 * GB          # a device that is mostly taken already
