@@ -508,7 +508,14 @@ class FusedGcnSageStep(TrainStep):
         """True when the train loop should keep the image of the input's mean aggregate next to the feature image
         (graph.ResidentPages.enable_p3(agg=True))."""
         L = self.model.layers[0]
-        return len(self.model.layers) >= 2 and self._cached_layer0(L, f0) and self._layer_kind(0, L, f0) == 0
+        return len(self.model.layers) >= 2 and self._cached_layer0(L, f0) and self._layer_kind(0, L, f0) in (0, 2)
+
+    def wants_resident_images(self, f0: int) -> bool:
+        """True when the train loop should keep the resident features as images (and hand out row-map batches): layer 0 takes its
+        input as an image (wants_p3_features), or it is a widening aggregate-first layer that can run on the cached aggregate --
+        63 / 313 / 363 -> 1000, 63 -> 206 of the reference's runs: without the cache such a layer copies its fp32 rows per batch and
+        makes both images per step."""
+        return self.wants_p3_features(f0) or self.wants_agg_image(f0)
 
     def _layer_kind(self, i: int, L, fin: int, n: int = 0, cached: bool = False):
         """How hidden layer i runs on the one-call plan (gte_step_layer.kind): 0 planes layer in transform-first order, 1 the
@@ -520,7 +527,7 @@ class FusedGcnSageStep(TrainStep):
         if not (self._planes_on() and isinstance(L.lynorm, nn.LayerNorm) and L.linear.bias is not None
                 and (L.activation is None or _is_relu(L.activation))):
             return None
-        # (a layer 0 that takes its input as an image -- kind 0 -- moves to the cached form when the batch brings the second image)
+        # (an input layer on images -- kind 0 or 2 -- moves to the cached form when the batch brings the second image)
         up = 3 if (i == 0 and cached and self._cached_layer0(L, fin)) else 0
         if self._planes_layer(i, L, fin, n):
             return up                                            # the tuned range: 128 <= fout <= 256, fout % 16 == 0
@@ -532,7 +539,7 @@ class FusedGcnSageStep(TrainStep):
         # transform-first while the layer does not widen by more than a quarter (the aggregation then moves fout columns: 1000
         # against 831 costs less than a per-batch fp32 copy of the input rows, and layer 0 reads the RESIDENT image through the row
         # map); aggregate-first for a widening input layer (13 / 63 / 313 / 363 -> 1000: aggregate fin columns)
-        return up if (i > 0 or 4 * fout <= 5 * fin) else 2
+        return up if (i > 0 or 4 * fout <= 5 * fin) else (3 if up == 3 else 2)
 
     def _plan_kinds(self, f0: int, n: int, cached: bool = False):
         """Layer kinds of the one-call step (gte_gcnsage_step) or None when the configuration needs the call-by-call path.
@@ -566,7 +573,7 @@ class FusedGcnSageStep(TrainStep):
         if getattr(g, "feat_p3", None) is not None:
             return True
         x = g.ndata.get('feat')
-        if x is None or not x.is_cuda or not self.wants_p3_features(x.shape[1]):
+        if x is None or not x.is_cuda or not self.wants_resident_images(x.shape[1]):
             return False
         x = ops._row_major(x.to(torch.float32))
         g.feat_p3 = ops.p3_from_f32(x)
@@ -990,8 +997,11 @@ class FusedGcnSageStep(TrainStep):
         if xp is not None:
             x, n, f0 = None, xp.rows, xp.cols
             if not self.wants_p3_features(f0):
-                raise _lib.GteError("the batch holds its features as a P3 image, but layer 0 of this step does not take one "
-                                    "(GEMM mode / GTE_PLANES changed after the resident pages were converted?)")
+                # an image batch on a layer that reads fp32 rows (this schedule does not know the cached-aggregate form; or the GEMM
+                # mode changed after the resident pages were converted): the rows back from the image -- exactly the fp32 values
+                if 'feat' not in g.ndata:
+                    g.ndata['feat'] = ops.p3_to_f32(xp)
+                x, xp = ops._row_major(g.ndata['feat']), None
         else:
             x = ops._row_major(g.ndata['feat'])
             _lib.require_device(x, "FusedGcnSageStep")

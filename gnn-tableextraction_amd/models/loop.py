@@ -183,7 +183,8 @@ def run_steps(step, pipe: BatchPipeline, page_steps: Sequence[np.ndarray], n_glo
     ahead on the pipeline's side stream.  ``n_global[s]`` = node count of step s over all ranks, ``loss_scale[s]`` an
     explicit local loss factor (class-weighted data parallelism).  Returns the last step's device vector
     [loss, sum of class weights, #correct] (not synchronised)."""
-    want_p3 = bool(hasattr(step, "wants_p3_features") and step.wants_p3_features(pipe.res.feat.shape[1]))
+    want_p3 = bool(step.wants_resident_images(pipe.res.feat.shape[1]) if hasattr(step, "wants_resident_images") else
+                   (hasattr(step, "wants_p3_features") and step.wants_p3_features(pipe.res.feat.shape[1])))
     if want_p3 != bool(pipe.res.p3_mode):
         # layer 0 multiplies a P3 image (planes GEMMs): resident features and batches become images -- or back to fp32 rows when
         # the GEMM mode was switched; the buffer sets of the other kind are dropped

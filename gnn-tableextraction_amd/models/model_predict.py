@@ -130,7 +130,7 @@ def predict_resident(engine, pipe, batch_pages: int, page_ids=None) -> torch.Ten
     ids = np.arange(len(res.page_sizes()), dtype=np.int64) if page_ids is None else np.asarray(page_ids, dtype=np.int64)
     steps = [ids[i:i + batch_pages] for i in range(0, ids.size, batch_pages)]
     f0 = res.feat.shape[1]
-    want_p3 = bool(engine.wants_p3_features(f0))
+    want_p3 = bool(engine.wants_resident_images(f0))
     if want_p3 != bool(res.p3_mode):                       # as loop.run_steps: layer 0 reads the resident feature image
         torch.cuda.synchronize(pipe.device)
         res.enable_p3(agg=bool(engine.wants_agg_image(f0))) if want_p3 else res.disable_p3()

@@ -197,7 +197,7 @@ def train(data, config, name_time=None):
     from . import residency as R
     all_nodes = np.array([g.num_nodes() for g in train_graphs], dtype=np.int64)
     all_edges = np.array([g.num_edges() for g in train_graphs], dtype=np.int64)
-    want_p3 = bool(getattr(step, "wants_p3_features", lambda f: False)(in_feats))
+    want_p3 = bool(getattr(step, "wants_resident_images", getattr(step, "wants_p3_features", lambda f: False))(in_feats))
     want_agg = want_p3 and bool(getattr(step, "wants_agg_image", lambda f: False)(in_feats))      # (the cached aggregate of the input)
     set_bytes = float(all_nodes.sum()) * R.WindowedPages.bytes_per_node(all_nodes, all_edges, in_feats, want_p3, want_agg)
     budget_gb = float(os.environ.get("GTE_RESIDENT_BUDGET_GB", "0") or 0)

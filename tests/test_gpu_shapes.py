@@ -252,7 +252,7 @@ def _resident(pages, tr, f0):
 
 @pytest.mark.parametrize("cached", [True, False], ids=["cached_agg", "no_cache"])
 @pytest.mark.parametrize("f0,hid,n_pages", [(831, 256, 100), (831, 96, 40), (63, 1000, 16), (13, 218, 40), (831, 1000, 12), (781, 100, 40),
-                                            (313, 157, 40)])
+                                            (313, 157, 40), (63, 206, 40), (363, 1000, 12)])
 def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages, cached):
     """The path ``bench.py`` and ``train()`` run -- ResidentPages (features as a P3 image + row map where layer 0 takes one),
     BatchPipeline, run_steps, the one-call step with Adam in the fold launch -- for ONE step on n_pages pages against the CPU
@@ -290,7 +290,7 @@ def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages, cached):
     fused.cache_input_agg = cached
     if cached and not fused.wants_agg_image(f0):
         pytest.skip("layer 0 of this shape does not run on the cached aggregate (short input, or a hidden width below 128)")
-    if fused.wants_p3_features(f0):
+    if fused.wants_resident_images(f0) if cached else fused.wants_p3_features(f0):
         res.enable_p3(agg=cached)
         assert res.p3_mode == "rows" and (res.agg_p3 is not None) == cached
         b0 = res.batch(ids)
