@@ -774,7 +774,11 @@ class FusedGcnSageStep(TrainStep):
                 L0.x, L0.ldx = P(x), ops._ld(x)
         else:
             if x is None:
-                raise _lib.GteError("the batch holds its features as a P3 image, but layer 0 reads fp32 rows")
+                # an image-only batch on a layer that reads fp32 rows (copied image rows without the aggregate image, GTE_P3_ROWS=0):
+                # the rows back from the image -- exactly the fp32 values; slow, a measurement configuration
+                if 'feat' not in g.ndata:
+                    g.ndata['feat'] = ops.p3_to_f32(xp)
+                x = ops._row_major(g.ndata['feat'])
             L0.x, L0.ldx = P(x), ops._ld(x)
         plan.indptr, plan.indices, plan.w_in = P(csr.indptr), P(csr.indices), P(w_in)
         plan.rindptr, plan.rindices, plan.w_out = P(rcsr.indptr), P(rcsr.indices), P(w_out)
