@@ -496,12 +496,12 @@ class FusedGcnSageStep(TrainStep):
 
     def _cached_layer0(self, L, fin: int) -> bool:
         """Layer 0 can run on the cached mean aggregate of the input (GTE_LAYER_CACHED) when the batch brings it: any LayerNorm
-        layer with fin >= 16 on the planes path (the tuned one-pass kernels of the 13-feature input keep their path)."""
+        layer on the planes path (the tuned one-pass kernels of the 13-feature input at aligned hidden widths keep their path)."""
         # (hidden widths below 128 keep the transform-first order: their input GEMM is bound by the operand stream, and the cached
         # form reads two input images where transform-first reads one -- measured (831, 96) 62 against 71 M nodes/s, (781, 100) 58
         # against 66; from 139 columns up the cached form wins 4 - 6 %: profiles/r05/cache_agg_ab.txt)
         return (self.cache_input_agg and self.general_planes and self._planes_on() and isinstance(L.lynorm, nn.LayerNorm)
-                and L.linear.bias is not None and (L.activation is None or _is_relu(L.activation)) and fin >= 16
+                and L.linear.bias is not None and (L.activation is None or _is_relu(L.activation))
                 and 128 <= L.out_feats <= 1024)
 
     def wants_agg_image(self, f0: int) -> bool:
