@@ -370,7 +370,7 @@ class FusedGcnSageStep(TrainStep):
                 "dzp": [None if t is None else t.view_rows(n) for t in full["dzp"]],
                 "qp": [None if t is None else t.view_rows(n) for t in full["qp"]]}
 
-    def reserve(self, n_nodes: int, f0: int) -> None:
+    def reserve(self, n_nodes: int, f0: int, cached: bool = False) -> None:
         """Size the shared per-batch buffers for batches of up to ``n_nodes`` nodes now (the train loop knows the largest batch
         its page table can produce): no reallocation -- a device synchronisation plus ~12 KB per node of new buffers -- later,
         in the middle of an epoch."""
@@ -378,7 +378,7 @@ class FusedGcnSageStep(TrainStep):
         if not hasattr(self, "_reserved"):
             self._reserved = {}
         self._reserved[f0] = max(self._reserved.get(f0, 0), cap)
-        kinds = self._plan_kinds(f0, 0)
+        kinds = self._plan_kinds(f0, 0, cached)     # (cached: the batches bring the aggregate image -> the general plan's buffer set)
         if kinds is not None and self._plan_mode(kinds, f0)[0]:
             return                      # a general plan allocates its own (padded) set at this capacity on first use
         key = (f0, self._planes_on())
@@ -1000,9 +1000,10 @@ class FusedGcnSageStep(TrainStep):
         xp = getattr(g, "feat_p3", None)              # resident batches in image mode bring the features as a P3 image only
         if xp is not None:
             x, n, f0 = None, xp.rows, xp.cols
-            if not self.wants_p3_features(f0):
-                # an image batch on a layer that reads fp32 rows (this schedule does not know the cached-aggregate form; or the GEMM
-                # mode changed after the resident pages were converted): the rows back from the image -- exactly the fp32 values
+            if not self._planes_layer(0, self.model.layers[0], f0, n):
+                # an image batch on a layer that reads fp32 rows (this schedule runs layer 0 on planes for fewer shapes than the
+                # one-call plans, and does not know the cached-aggregate form; or the GEMM mode changed after the resident pages
+                # were converted): the rows back from the image -- exactly the fp32 values
                 if 'feat' not in g.ndata:
                     g.ndata['feat'] = ops.p3_to_f32(xp)
                 x, xp = ops._row_major(g.ndata['feat']), None

@@ -199,7 +199,8 @@ def run_steps(step, pipe: BatchPipeline, page_steps: Sequence[np.ndarray], n_glo
     if n_steps == 0:
         return out3
     if hasattr(step, "reserve"):                 # the engine's per-batch buffers: sized once for the largest possible batch
-        step.reserve(pipe.max_batch_nodes(), pipe.res.feat.shape[1])
+        step.reserve(pipe.max_batch_nodes(), pipe.res.feat.shape[1],
+                     cached=bool(pipe.res.p3_mode == "rows" and pipe.res.agg_p3 is not None))
     pipe.start(0)
     # where the next batch is assembled: an engine with a `before_last_gemm` hook (FusedGcnSageStep) gets it under the last,
     # MFMA-bound GEMM of the current step -- late enough that the batch is still cache-resident when the next step starts

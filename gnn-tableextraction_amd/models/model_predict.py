@@ -140,7 +140,7 @@ def predict_resident(engine, pipe, batch_pages: int, page_ids=None) -> torch.Ten
     pred = torch.empty(total, dtype=torch.int64, device=pipe.device)
     if not steps:
         return pred
-    engine.reserve(pipe.max_batch_nodes(), f0)
+    engine.reserve(pipe.max_batch_nodes(), f0, cached=bool(res.p3_mode == "rows" and res.agg_p3 is not None))
     pipe.start(0)
     off = 0
     for s in range(len(steps)):

@@ -250,6 +250,35 @@ def _resident(pages, tr, f0):
     return G.ResidentPages(graphs, DEV)
 
 
+@pytest.mark.parametrize("f0,hid", [(831, 256), (831, 96), (63, 206), (13, 218), (363, 149)])
+def test_the_kernel_timer_schedule_runs_on_the_loops_image_batches(f0, hid):
+    """bench.py's per-kernel HIP-event pass (ops.enable_kernel_timers) switches the engine to its launch-by-launch schedule on
+    the SAME resident pages -- which, in image mode, hand over batches without fp32 rows, and with the aggregate image the
+    one-call plan wanted.  That schedule takes layer 0 as planes for fewer shapes than the plan: it must convert such a batch
+    back (exactly) instead of reading a feature tensor that is not there, and reach the one-call step's loss."""
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    from gnn_tableextraction_amd.models.loop import BatchPipeline, run_steps
+    pages = S.make_pages(30, in_feats=f0)
+    ids = [np.arange(0, 14), np.arange(14, 30)]
+    losses = []
+    for timers in (False, True):
+        torch.manual_seed(7)
+        model = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0).to(DEV)
+        fused = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+        pipe = BatchPipeline(_resident(pages, fused, f0))
+        run_steps(fused, pipe, ids[:1])                  # the one-call plan sets the resident pages up (image mode where it wants it)
+        ops.enable_kernel_timers(timers)
+        try:
+            out3 = run_steps(fused, pipe, ids[1:])
+            torch.cuda.synchronize()
+            if timers:
+                assert ops.kernel_timer_report()
+        finally:
+            ops.enable_kernel_timers(False)
+        losses.append(float(out3[0]))
+    assert np.isfinite(losses).all() and abs(losses[0] - losses[1]) < 2e-5, losses
+
+
 @pytest.mark.parametrize("cached", [True, False], ids=["cached_agg", "no_cache"])
 @pytest.mark.parametrize("f0,hid,n_pages", [(831, 256, 100), (831, 96, 40), (63, 1000, 16), (13, 218, 40), (831, 1000, 12), (781, 100, 40),
                                             (313, 157, 40), (63, 206, 40), (363, 1000, 12)])
