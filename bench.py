@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--no-dist-probe", action="store_true", help="skip the one-rank data-parallel step (RCCL group of one) against the plain step")
     ap.add_argument("--gemm-mode", choices=["f32", "split_bf16"], default=None,
                     help="arithmetic of the transform GEMMs for the headline loop (default: GTE_GEMM_MODE or f32)")
+    ap.add_argument("--no-kernel-timers", action="store_true",
+                    help="skip the per-kernel HIP-event pass (the launch-by-launch schedule; profiles/sequence_refresh.sh traces the loop alone)")
     ap.add_argument("--no-split-probe", action="store_true",
                     help="skip the secondary run of the same loop in the split-bf16 GEMM mode")
     ap.add_argument("--gather-nodes", type=int, default=1_000_000)
@@ -1263,11 +1265,13 @@ def main():
         step_events = None
 
     # ---- per-kernel HIP-event timing: the SAME loop with event pairs around the tagged launches, right after -------------
-    run(prof[:1], prof_cnt[:1])                  # untimed: settle
-    ops.enable_kernel_timers(True)
-    run(prof, prof_cnt)
-    kt = ops.kernel_timer_report()
-    ops.enable_kernel_timers(False)
+    kt = {}
+    if not args.no_kernel_timers:
+        run(prof[:1], prof_cnt[:1])              # untimed: settle
+        ops.enable_kernel_timers(True)
+        run(prof, prof_cnt)
+        kt = ops.kernel_timer_report()
+        ops.enable_kernel_timers(False)
 
     stat = torch.tensor([elapsed, float(nodes_local)], dtype=torch.float64, device=dev)
     if distributed:

@@ -27,13 +27,20 @@ from .. import graph as G
 
 
 class BatchPipeline:
-    def __init__(self, resident: G.ResidentPages, depth: int = 2, side_stream: bool = True):
+    def __init__(self, resident: G.ResidentPages, depth: int = 2, side_stream: Optional[bool] = None):
         if depth < 2:
             raise ValueError("BatchPipeline needs at least two buffer sets (one being read, one being written)")
         self.res, self.depth = resident, depth
         self.device = resident.device
-        # side_stream=False (measurements only): assemble on the caller's stream, i.e. in front of the step
-        self.side = torch.cuda.Stream(device=self.device) if side_stream else torch.cuda.current_stream(self.device)
+        # Where a batch is assembled.  "side": on the pipeline's own stream, under the kernels of the step before (events order
+        # the buffer sets) -- what a batch that COPIES its feature rows needs (~45 us for 100 pages x 831 fp32 columns).  "same":
+        # in the caller's stream order, no events at all -- a row-map batch (image mode: page table, CSRs and labels only) is
+        # 7 us there against 14-20 us beside a GEMM plus three event packets on the caller's stream per step (profiles/r05/
+        # side_stream_ab.txt: -7 ... -12 us per step on every shape).  Decided per load(): GTE_PIPE_SIDE=1 / 0 force either.
+        self.side = torch.cuda.Stream(device=self.device)
+        self._force_side = {"1": True, "0": False}.get(os.environ.get("GTE_PIPE_SIDE", ""), side_stream)     # None: per load()
+        self._same = False
+        self._meta_pending = False                      # the caller's stream has not yet waited for the last metadata upload
         self._sets: List[dict] = []
         self._free_ev: List[Optional[torch.cuda.Event]] = [None] * depth
         self._pinned = None
@@ -98,6 +105,7 @@ class BatchPipeline:
             if self._meta_ev is not None:
                 self._meta_ev.synchronize()                      # (a larger device table: the old one may still be read)
             self._meta_dev = torch.empty(max(self._pinned.numel(), total), dtype=torch.int32, device=self.device)
+            self._meta_dev.record_stream(self.side)              # (read on the side stream too: no reuse under it once dropped)
         stage = self._pinned.numpy()
         off = 0
         cap = [0, 0, 0]
@@ -110,7 +118,18 @@ class BatchPipeline:
             self._info.append((off, nb, int(b_node[-1]), int(b_in[-1]), int(b_out[-1]), self._page_nodes[ids]))
             cap = [max(cap[0], int(b_node[-1])), max(cap[1], int(b_in[-1])), max(cap[2], int(b_out[-1]))]
             off += 4 * nb + 3
-        # the side stream runs in order: assemblies queued earlier read the old metadata before this copy overwrites it
+        same = (self.res.p3_mode == "rows") if self._force_side is None else (not self._force_side)
+        if same != self._same and self._meta_ev is not None:
+            torch.cuda.synchronize(self.device)         # (the resident pages changed mode: rare; no ordering left to think about)
+            self._free_ev = [None] * self.depth
+        self._same = same
+        # the side stream runs in order: assemblies queued earlier read the old metadata before this copy overwrites it -- those
+        # queued on the caller's stream through one event
+        if self._same and self._meta_ev is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(ev)
+        self._meta_pending = True
         with torch.cuda.stream(self.side):
             self._meta_dev[:total].copy_(self._pinned[:total], non_blocking=True)
             self._meta_ev = torch.cuda.Event()
@@ -152,26 +171,34 @@ class BatchPipeline:
         additionally waits for everything queued on the CURRENT stream so far (used to place it under a chosen kernel)."""
         off, nb, n, e_in, e_out, n_sizes = self._info[s]
         k = s % self.depth
-        if self._free_ev[k] is not None:
+        if self._same and self._meta_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._meta_ev)
+            self._meta_pending = False
+        if self._free_ev[k] is not None and not self._same:
             self.side.wait_event(self._free_ev[k])               # the step that last read this buffer set has finished
-        if after_current and self.side is not torch.cuda.current_stream(self.device):
+        if after_current and not self._same and self.side is not torch.cuda.current_stream(self.device):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.side.wait_event(ev)
         g = self.res.assemble(self._meta_dev[off:off + 4 * nb + 3], nb, n, e_in, e_out, self._sets[k], n_sizes,
-                              stream=self.side.cuda_stream)
-        ev = torch.cuda.Event()
-        ev.record(self.side)
+                              stream=(torch.cuda.current_stream(self.device) if self._same else self.side).cuda_stream)
+        ev = None
+        if not self._same:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
         self._ready[s] = (g, ev)
 
     def get(self, s: int) -> G.ResidentBatch:
         """The batch of step s; the CURRENT stream waits (on the device) for its assembly."""
         g, ev = self._ready.pop(s)
-        torch.cuda.current_stream(self.device).wait_event(ev)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
         return g
 
     def release(self, s: int) -> None:
         """Step s has been queued on the current stream: its buffer set may be rewritten once it is through."""
+        if self._same:
+            return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._free_ev[s % self.depth] = ev

@@ -65,7 +65,7 @@ def run_long(pipe):
         loop.run_steps(step, pipe, plan[:n])
         return sum(pipe.nodes(i) for i in range(n))
     return f
-pm, ps = loop.BatchPipeline(res, side_stream=False), loop.BatchPipeline(res)
+pm, ps = loop.BatchPipeline(res, side_stream=False), loop.BatchPipeline(res, side_stream=True)
 for rep in range(int(os.environ.get("REPS", "3"))):
     if not os.environ.get("ONLY_LOOP"):
         report("replay", run_replay, steps)
