@@ -1429,11 +1429,19 @@ namespace {
 // scratch per lane.  Batches beyond one round of 128-row tiles run several rounds of the same kernel.)
 // Round 5: 96 rows (1 x 8 waves of 96 x 32) while that covers m in ONE round of tiles -- 24 317 rows of the headline batch are 190
 // tiles of 128 rows on 256 CUs, a quarter of the chip idle for the whole launch; 254 tiles of 96 rows fill it.
+// ... and 64 / 32 rows (1 x 8 waves of 64 x 32 / 32 x 32) for batches that leave CUs idle even then: the launch lasts as long
+// as ONE tile's K loop whatever the number of tiles in the round (L0 forward, K = 1 662: 106 us on 50 tiles of 128 rows, 109 us
+// on 95, 124 us on 202 -- profiles/r05/sequence_pages*.txt), so a small batch wants the smallest tile that still is one round.
+int g_ln_rows = -1;                     // forced row tile of the LayerNorm-epilogue launches: 0 = the chooser (gte_gemm_p3_set_ln_rows)
 int lnb_row_tile(int64_t m) {
-    static const int forced = getenv("GTE_P3_LN_ROWS") ? atoi(getenv("GTE_P3_LN_ROWS")) : 0;         // (measurement: 96 / 128)
-    if (forced == 96 || forced == 128) return forced;
+    if (g_ln_rows < 0) g_ln_rows = getenv("GTE_P3_LN_ROWS") ? atoi(getenv("GTE_P3_LN_ROWS")) : 0;        // (measurement: 32 / 64 / 96 / 128)
+    const int forced = g_ln_rows;
+    if (forced == 32 || forced == 64 || forced == 96 || forced == 128) return forced;
+    static const int min_tile = getenv("GTE_P3_LN_MIN_ROWS") ? atoi(getenv("GTE_P3_LN_MIN_ROWS")) : 32;  // (measurement)
     const int64_t cus = gte::device_props().cus;
-    return (m > 128 * cus / 2 && gte::ceil_div(m, 96) <= cus) ? 96 : 128;
+    for (int t = 32; t <= 96; t += 32)
+        if (t >= min_tile && gte::ceil_div(m, t) <= cus) return t;
+    return 128;
 }
 // out[j] = sum_k part[k * stride + j]   (only when no fold deferral is open)
 __global__ void __launch_bounds__(256)
@@ -1445,11 +1453,17 @@ p3_colsum_fold_kernel(const float* __restrict__ part, long long stride, int coun
     out[j] = s;
 }
 }
+extern "C" int gte_gemm_p3_set_ln_rows(int rows) {
+    if (rows != 0 && rows != 32 && rows != 64 && rows != 96 && rows != 128)
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_set_ln_rows: 0 (chooser), 32, 64, 96 or 128");
+    g_ln_rows = rows;
+    return GTE_OK;
+}
 // any width up to 256 (a workgroup's tile holds whole rows); n % 4 != 0 needs rows of z / dz padded to a multiple of 4 floats
 extern "C" int gte_gemm_p3_nt_ln_bwd_supported(int64_t n) { return (n >= 1 && n <= 256) ? 1 : 0; }
 extern "C" int64_t gte_gemm_p3_nt_ln_bwd_workspace_bytes(int64_t m, int64_t n) {
     if (m <= 0 || n <= 0) return 256;
-    return gte::round_up(gte::ceil_div(m, 96) * 3 * n * 4, 256);       // (the smaller of the two row tiles: covers either choice)
+    return gte::round_up(gte::ceil_div(m, 32) * 3 * n * 4, 256);       // (the smallest row tile: covers every choice, for every m' <= m)
 }
 // dy = [a1 | a2] b^T (m x n, n <= 256: a workgroup's tile holds whole rows) is NOT stored: the workgroup that computed a row
 // block runs the LayerNorm(+ReLU) backward of those rows on it -- dz = LN'(z)(mask . dy) as fp32 (feeds the transpose
@@ -1491,9 +1505,15 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
     const int bm = lnb_row_tile(m);
     // (column tiles of 128 / 192 for hidden widths up to 128 / 192 were measured in round 5 and removed: 27 -> 30 us at 96 columns)
     if (n % 16 == 0) {
-        if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
+        if (bm == 32) launch_lw_lnb<1, 8, 1, 1, 4>(p, s);
+        else if (bm == 64) launch_lw_lnb<1, 8, 2, 1, 4>(p, s);
+        else if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4>(p, s);
+        else launch_lw_lnb<2, 4, 2, 2, 4>(p, s);
     } else {                                              // per-element validity, zero image columns up to the next multiple of 16
-        if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4, 3>(p, s); else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);
+        if (bm == 32) launch_lw_lnb<1, 8, 1, 1, 4, 3>(p, s);
+        else if (bm == 64) launch_lw_lnb<1, 8, 2, 1, 4, 3>(p, s);
+        else if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4, 3>(p, s);
+        else launch_lw_lnb<2, 4, 2, 2, 4, 3>(p, s);
     }
     int rc = gte::check_launch("gemm_p3_nt_ln_bwd");
     if (rc != GTE_OK) return rc;
@@ -1547,6 +1567,8 @@ static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, cons
     }
     if (p.rows64)                                          // images of 4 GB or more: 64-bit per-lane addresses (no range check: the
         launch_lw_lnb<2, 4, 2, 2, 4, 4, true>(p, gte::as_stream(stream));                    // rows past the tile re-read its first row)
+    else if (lnb_row_tile(m) == 32) launch_lw_lnb<1, 8, 1, 1, 4, 4>(p, gte::as_stream(stream));
+    else if (lnb_row_tile(m) == 64) launch_lw_lnb<1, 8, 2, 1, 4, 4>(p, gte::as_stream(stream));
     else if (lnb_row_tile(m) == 96) launch_lw_lnb<1, 8, 3, 1, 4, 4>(p, gte::as_stream(stream));
     else launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
     return gte::check_launch("gemm_p3_nt_ln_fwd");

@@ -421,6 +421,10 @@ int gte_head_dlq_finish(const int32_t* rindptr, const int32_t* rindices, const f
 /* Tile configuration of gte_gemm_p3_nt / _rows / _rows2: -1 = chosen per problem (default), 0 ... 7 = forced (tests run every
  * configuration against the same bits; 0 - 6 the 128- and 256-column tiles, 7 a measurement tile). */
 int gte_gemm_p3_set_nt_cfg(int cfg);
+/* Row tile of the launches with a LayerNorm epilogue (gte_gemm_p3_nt_ln_fwd / _rows2_ln_fwd / _ln_bwd; images below 4 GB): 0 = the
+ * smallest of 32 / 64 / 96 rows that covers m in one round of workgroups, else 128 (default); 32 / 64 / 96 / 128 = forced (tests run
+ * every tile against the same bits). */
+int gte_gemm_p3_set_ln_rows(int rows);
 /* Row maps: 0 = 64-bit addresses for resident images of 4 GB or more only (default), 1 = always (tests, A/B timing; the
  * zero-row requirement of gte_gemm_p3_tn_rows then holds for every image). */
 int gte_gemm_p3_set_rows64(int mode);

@@ -1,16 +1,7 @@
 #!/bin/bash
-# A/B of environment switches on ONE box, interleaved: bash profiles/debug/ab_env.sh "GTE_C_STEP=0" "GTE_C_STEP=1" ...
-# prints value (M nodes/s), long_run (M nodes/s) and ms/step of the train loop alone per variant and round.
-STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --no-inference --val-graph 0 --no-shapes --no-size-sweep --no-residency"
-ROUNDS=${ROUNDS:-2}
-for r in $(seq 1 $ROUNDS); do
-  for v in "$@"; do
-    out=$(env $v timeout 150 python bench.py $STEP_ONLY $EXTRA 2>/dev/null | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{\"metric\"'):
-        d = json.loads(l); print(round(d['value']/1e6,2), round(d['long_run']['value']/1e6,2), round(d['ms_per_step'],4))
-")
-    echo "round $r [$v]: $out"
-  done
-done
+# A/B of one environment switch on the train loop alone (un-profiled), interleaved:  bash profiles/debug/ab_env.sh VAR "v1 v2 ..." "F:H F:H ..." [reps]
+VAR=$1; VALS=$2; SHAPES=${3:-"831:256"}; REPS=${4:-2}
+STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --no-inference --no-shapes --no-size-sweep --no-residency --no-dist-probe --no-kernel-timers --val-graph 0 --long-run-seconds 0.5"
+for rep in $(seq 1 $REPS); do for sh in $SHAPES; do F=${sh%%:*}; H=${sh##*:}; for v in $VALS; do
+echo -n "rep $rep F=$F H=$H $VAR=$v: "; env $VAR=$v timeout 300 python bench.py --in-feats $F --hidden $H $STEP_ONLY 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']/1e6,2), d['ms_per_step'], 'long', round(d['long_run']['value']/1e6,2))"
+done; done; done

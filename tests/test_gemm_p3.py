@@ -78,6 +78,15 @@ def test_nt_is_bitwise_the_split_kernel(split_mode, m, n, k):
 ALL_NT_CFGS = [0, 1, 2, 3, 4, 5, 6, 7]
 
 
+@pytest.fixture(params=[0, 32, 64, 96, 128], ids=lambda r: f"ln_rows{r}" if r else "ln_rows_auto")
+def ln_rows(request):
+    """every row tile of the launches with a LayerNorm epilogue (gte_gemm_p3_set_ln_rows; 0 = the chooser), the chooser again afterwards"""
+    lib = _lib.load()
+    assert lib.gte_gemm_p3_set_ln_rows(int(request.param)) == 0
+    yield request.param
+    assert lib.gte_gemm_p3_set_ln_rows(0) == 0
+
+
 @pytest.fixture
 def force_nt_cfg():
     """force a tile configuration of the NT planes GEMM for the test (gte_gemm_p3_set_nt_cfg), the chooser again afterwards"""
@@ -260,7 +269,7 @@ def test_tn_with_two_resident_images_behind_one_row_map(rows64, rows, k, m):
                                    (260, 256, 16)])
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("mapped", [False, True], ids=["dense", "rows2"])
-def test_nt_with_layernorm_forward_epilogue_is_bitwise_the_two_launches(rows64, m, n, k, relu, mapped):
+def test_nt_with_layernorm_forward_epilogue_is_bitwise_the_two_launches(rows64, ln_rows, m, n, k, relu, mapped):
     """gte_gemm_p3_nt_ln_fwd / gte_gemm_p3_nt_rows2_ln_fwd: z = [a1 | a2] b^T + bias, the row statistics, y as fp32 and as a P3 image
     are bit for bit what gte_gemm_p3_nt (+ _rows2) followed by gte_ln_relu_fwd_p3 write; padding columns zero."""
     if rows64 and not mapped:
@@ -345,7 +354,7 @@ def test_row_maps_into_a_resident_image_above_4_gb():
 @pytest.mark.parametrize("m,n,k,relu", [(24437, 256, 256, True), (3000, 256, 256, False), (129, 128, 64, True), (1, 256, 256, True),
                                         (40000, 256, 128, True), (500, 144, 256, True), (40000, 256, 256, True), (80000, 256, 256, True),
                                         (80149, 96, 96, False)])
-def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(m, n, k, relu):
+def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(ln_rows, m, n, k, relu):
     """gte_gemm_p3_nt_ln_bwd: dy = [dz1 | q1] [W_s^T | W_n^T]^T is never stored; dz0 (fp32 and image) must be bit for bit what
     gte_gemm_p3_nt + gte_ln_relu_bwd_p3 produce, the column sums agree to summation order."""
     g = torch.Generator(device=DEV).manual_seed(m + n)
@@ -377,7 +386,7 @@ def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(m, n, k
 
 @pytest.mark.parametrize("m,n,relu", [(24437, 218, True), (3000, 149, True), (5001, 206, False), (24437, 100, True), (777, 157, True),
                                       (260, 5, True), (2, 250, True)])
-def test_nt_with_layernorm_backward_epilogue_at_widths_that_are_not_multiples_of_16(m, n, relu):
+def test_nt_with_layernorm_backward_epilogue_at_widths_that_are_not_multiples_of_16(ln_rows, m, n, relu):
     """The hidden widths the reference's runs use (218, 206, 157, 149, 100): rows of z / dz padded to 16 floats, the LayerNorm over
     the true width.  dz -- fp32 with its padding, and the image up to the next multiple of 16 columns -- bit for bit what
     gte_gemm_p3_nt + gte_ln_relu_bwd_p3 (the general-width kernel) produce; k = n as in the step (dX of the layer above)."""
