@@ -823,7 +823,7 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
                     float d[4];
                     if constexpr (MSK) gte_ln_bwd_post4m(g, xh, gam, rstd[u], c1, c2, oke, d, s_dg, s_db, s_dbias);
                     else gte_ln_bwd_post4(g, xh, gam, rstd[u], c1, c2, okc, d, s_dg, s_db, s_dbias);
-                    if (okc) {
+                    if (okc && p.ln_dz) {                               // (nullable: a consumer that reads the image only)
                         f4u o; o.x = d[0]; o.y = d[1]; o.z = d[2]; o.w = d[3];
                         *reinterpret_cast<f4u*>(p.ln_dz + rg * p.ln_lddz + j4) = o;
                     }
@@ -1468,7 +1468,9 @@ extern "C" int64_t gte_gemm_p3_nt_ln_bwd_workspace_bytes(int64_t m, int64_t n) {
 // dy = [a1 | a2] b^T (m x n, n <= 256: a workgroup's tile holds whole rows) is NOT stored: the workgroup that computed a row
 // block runs the LayerNorm(+ReLU) backward of those rows on it -- dz = LN'(z)(mask . dy) as fp32 (feeds the transpose
 // aggregation) and as a P3 image (dzp3 nullable; feeds the layer's dW / dX GEMMs) -- and the column sums dgamma / dbeta / dbias
-// (each nullable) join the fold deferral.  Same arithmetic as gte_gemm_p3_nt + gte_ln_relu_bwd_p3: dz is bit-identical.
+// (each nullable) join the fold deferral.  Same arithmetic as gte_gemm_p3_nt + gte_ln_relu_bwd_p3: dz is bit-identical.  dz itself is
+// nullable when dzp3 is given (the layer below reads the image only: an input layer on the cached aggregate has no transpose
+// aggregation, its dW = dz^T [x | ahn] takes the image -- 25 MB per step less at 24 k x 256).
 extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, const void* a2, int64_t lda2, int64_t k2, const void* b,
                                      int64_t ldb, const float* z, int64_t ldz, const float* stats, const float* gamma,
                                      const float* beta, int relu, float* dz, int64_t lddz, void* dzp3, int64_t ldp3, float* dgamma,
@@ -1478,11 +1480,11 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: bad sizes");
     if (!gte_gemm_p3_nt_ln_bwd_supported(n)) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_bwd: needs n <= 256");
     if (m == 0) return GTE_OK;
-    if (!a1 || !b || !z || !stats || !gamma || !beta || !dz || !workspace || (k2 > 0 && !a2))
+    if (!a1 || !b || !z || !stats || !gamma || !beta || (!dz && !dzp3) || !workspace || (k2 > 0 && !a2))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: null pointer");
     const int64_t kb1 = p3::blocks(k1), kb2 = k2 > 0 ? p3::blocks(k2) : 0;
     const int64_t n4 = gte::round_up(n, 4);
-    if (lda1 < p3::row_bytes(k1) || (k2 > 0 && lda2 < p3::row_bytes(k2)) || ldb < (kb1 + kb2) * 96 || ldz < n4 || lddz < n4 ||
+    if (lda1 < p3::row_bytes(k1) || (k2 > 0 && lda2 < p3::row_bytes(k2)) || ldb < (kb1 + kb2) * 96 || ldz < n4 || (dz && lddz < n4) ||
         (dzp3 && (ldp3 < p3::row_bytes(n) || ldp3 % 16 != 0)))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: leading dimension too small");
     if (lda1 >= (1 << 23) || lda2 >= (1 << 23) || ldb >= (1 << 23) || (m + 256) * lda1 >= ((int64_t)1 << 31) ||

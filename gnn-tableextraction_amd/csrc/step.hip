@@ -7,6 +7,8 @@
 // ~0.25 ms of host time per 0.37 ms step).
 #include "gte_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 #define GTE_TRY(call)            \
@@ -45,6 +47,13 @@ int forward_hidden(const gte_step_plan& p, void* st, bool fwd_only = false) {
     auto mark = [&](int k) {        // (measurement: an event in front of / behind a layer's forward GEMM)
         if (p.fwd_events && p.fwd_events[k]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(p.fwd_events[k]), gte::as_stream(st));
     };
+    // y of hidden layer i as fp32 rows is read by nobody when the layer above is a PLANES layer on this layer's image (its forward
+    // and its dW take the image; every LayerNorm backward recomputes the ReLU mask from z); the last hidden layer's rows feed the
+    // narrow output kernels (a forward-only pass with the GEMM output layer reads the image there too)
+    auto y_unread = [&](int i) {
+        if (i + 1 < p.n_hidden) return p.layer[i + 1].kind == GTE_LAYER_PLANES && !p.layer[i + 1].make_hp;
+        return fwd_only && p.out_gemm != 0;
+    };
     for (int i = 0; i < p.n_hidden; ++i) {
         const gte_step_layer& L = p.layer[i];
         const int64_t ld = ldf(L);
@@ -82,7 +91,7 @@ int forward_hidden(const gte_step_plan& p, void* st, bool fwd_only = false) {
             // z = [x | ahn] W^T + b with x AND its mean aggregate read from their RESIDENT images through the batch's row map (the
             // aggregate of the input is page-local and constant: cached when the pages were loaded), then LayerNorm + ReLU
             mark(2 * i);
-            float* const y3 = (fwd_only && L.yp) ? nullptr : L.y;
+            float* const y3 = (L.yp && (fwd_only || y_unread(i))) ? nullptr : L.y;
             // (h_rows == NULL: the two images hold the graph's own rows -- a graph that is evaluated again and again, e.g. the
             // validation graph of train(), with its images made once)
             if ((p.fuse_ln_dx & 16) && gte_gemm_p3_nt_ln_fwd_supported(L.fout)) {      // the layer's whole forward in ONE launch
@@ -116,7 +125,7 @@ int forward_hidden(const gte_step_plan& p, void* st, bool fwd_only = false) {
             GTE_TRY(gte_gemm_p3_nt(L.hp, L.ldp_h, L.fin, nullptr, 0, 0, L.wimg_fwd, L.ldp_wfwd, L.bias, L.fout, L.t, 2 * ld, n,
                                    2 * ld, 0, 0, st));
         mark(2 * i + 1);
-        float* const y = (fwd_only && L.yp && (i + 1 < p.n_hidden ? (p.layer[i + 1].kind == GTE_LAYER_PLANES && !p.layer[i + 1].make_hp) : p.out_gemm != 0)) ? nullptr : L.y;
+        float* const y = (L.yp && y_unread(i)) ? nullptr : L.y;
         GTE_TRY(gte_spmm_csr_accumulate_ln_p3(p.indptr, p.indices, p.w_in, L.t + ld, 2 * ld, L.t, 2 * ld, n, L.fout,
                                               GTE_REDUCE_MEAN, L.gamma, L.beta, L.eps, L.relu, y, ld, L.yp, L.ldp_y, L.stats, st));
     }
@@ -168,6 +177,7 @@ inline int64_t ldz_of(const gte_step_layer& L) { return L.kind == GTE_LAYER_PLAN
 
 // backward of the output layer and of hidden layers n_hidden - 1 .. 1, and of layer 0 up to its weight-gradient GEMM
 int backward_a(const gte_step_plan& p, void* st) {
+    static const bool keep_dz0 = getenv("GTE_STEP_KEEP_DZ0") && atoi(getenv("GTE_STEP_KEEP_DZ0")) != 0;      // (measurement: round 5 before the skip)
     const int64_t n = p.n_nodes, C = p.n_classes, lg = ld_lg(p);
     bool ln_done = false, smallk_done = false;
     const gte_step_layer& T = p.layer[p.n_hidden - 1];
@@ -247,9 +257,9 @@ int backward_a(const gte_step_plan& p, void* st) {
         } else if ((p.fuse_ln_dx & 1) && B.kind != GTE_LAYER_SMALLK && gte_gemm_p3_nt_ln_bwd_supported(L.fin) &&
                    (L.fin % 16 == 0 || ldf(B) >= ((L.fin + 3) & ~(int64_t)3))) {      // (unaligned widths: padded rows)
             GTE_TRY(gte_gemm_p3_nt_ln_bwd(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, z_of(B), ldz_of(B), B.stats,
-                                          B.gamma, B.beta, B.relu, B.dy, ldf(B), B.dzp, B.ldp_o, B.ggamma, B.gbeta, B.gbias, n, L.fin, B.ws_ln,
-                                          B.ws_ln_bytes, st));
-            ln_done = true;
+                                          B.gamma, B.beta, B.relu, (B.kind == GTE_LAYER_CACHED && B.dzp && !keep_dz0) ? nullptr : B.dy, ldf(B), B.dzp, B.ldp_o,
+                                          B.ggamma, B.gbeta, B.gbias, n, L.fin, B.ws_ln, B.ws_ln_bytes, st));      // (cached input layer: dW reads
+            ln_done = true;                                                                                      //  the image only)
         } else {
             GTE_TRY(gte_gemm_p3_nt(L.dzp, L.ldp_o, L.fout, L.qp, L.ldp_o, L.fout, L.wimg_bwd, L.ldp_wbwd, nullptr, 0, B.dy, ldf(B), n, L.fin, 0,
                                    0, st));

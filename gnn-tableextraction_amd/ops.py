@@ -699,7 +699,7 @@ def gemm_p3_nt_ln_fwd(a1: P3, b: P3, a2: Optional[P3], bias, gamma, beta, eps: f
 
 
 def gemm_p3_nt_ln_bwd(a1: P3, b: P3, a2: Optional[P3], z: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
-                      relu: bool, dz: torch.Tensor, dzp3: Optional[P3] = None, dgamma=None, dbeta=None, dbias=None) -> torch.Tensor:
+                      relu: bool, dz: Optional[torch.Tensor], dzp3: Optional[P3] = None, dgamma=None, dbeta=None, dbias=None) -> torch.Tensor:
     """dz = LN'(z)(mask . ([a1 | a2] b^T)) without storing the product (gte_gemm_p3_nt_ln_bwd): the backward GEMM that produces
     d(loss)/d(y of the layer below) with that layer's LayerNorm(+ReLU) backward as its epilogue."""
     lib = _lib.load()
@@ -707,7 +707,7 @@ def gemm_p3_nt_ln_bwd(a1: P3, b: P3, a2: Optional[P3], z: torch.Tensor, stats: t
     ws = _workspace(lib.gte_gemm_p3_nt_ln_bwd_workspace_bytes(m, n), a1.data.device, "gemm_p3_lnb")
     check(lib.gte_gemm_p3_nt_ln_bwd(ptr(a1.data), a1.ldp, a1.cols, ptr(a2.data) if a2 is not None else None,
                                     a2.ldp if a2 is not None else 0, a2.cols if a2 is not None else 0, ptr(b.data), b.ldp, ptr(z),
-                                    _ld(z), ptr(stats), ptr(gamma), ptr(beta), int(relu), ptr(dz), _ld(dz),
+                                    _ld(z), ptr(stats), ptr(gamma), ptr(beta), int(relu), ptr(dz), _ld(dz) if dz is not None else 0,
                                     ptr(dzp3.data) if dzp3 is not None else None, dzp3.ldp if dzp3 is not None else 0, ptr(dgamma),
                                     ptr(dbeta), ptr(dbias), m, n, ptr(ws), ws.numel(), current_stream()), "gte_gemm_p3_nt_ln_bwd")
     return dz

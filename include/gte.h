@@ -373,7 +373,7 @@ int gte_gemm_p3_nt_rows2_ln_fwd(const void* a_res, int64_t ldpa, const void* a2_
  * beta as gte_ln_relu_bwd.  Replaces gte_gemm_p3_nt + gte_ln_relu_bwd_p3 (one launch, 2 m n 4 bytes of traffic less); dz is
  * bit-identical to theirs.  Any n in 1 .. 256; n % 4 != 0 needs the rows of z and dz padded to a multiple of 4 floats (ldz,
  * lddz >= that, padding of dz written as zeros), and whenever n % 16 != 0 the image's columns up to the next multiple of 16 are
- * written as zeros. */
+ * written as zeros.  dz is nullable when dzp3 is given (a layer below whose weight gradient reads the image only). */
 int gte_gemm_p3_nt_ln_bwd_supported(int64_t n);
 int64_t gte_gemm_p3_nt_ln_bwd_workspace_bytes(int64_t m, int64_t n);
 int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t ldpa1, int64_t k1, const void* a2, int64_t ldpa2, int64_t k2, const void* b,

@@ -379,6 +379,11 @@ def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(ln_rows
     dg, db, dbias = (torch.full((n,), 7.0, device=DEV) for _ in range(3))
     ops.gemm_p3_nt_ln_bwd(a1p, wp, a2p, z, stats, gam, bet, relu, dz, dzp, dg, db, dbias)
     assert torch.equal(dz, dz_ref)
+    # image only (an input layer on the cached aggregate: its dW reads the image, nothing reads the fp32 rows)
+    dzp_only = ops.P3.empty(m, n, DEV)
+    dzp_only.data.fill_(0x55)
+    ops.gemm_p3_nt_ln_bwd(a1p, wp, a2p, z, stats, gam, bet, relu, None, dzp_only, *(torch.zeros(n, device=DEV) for _ in range(3)))
+    assert torch.equal(dzp_only.data, dzp_ref.data)
     assert torch.equal(ops.p3_to_f32(dzp), dz_ref)
     for got, want in ((dg, dg_ref), (db, db_ref), (dbias, dbias_ref)):
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-6)
