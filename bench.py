@@ -988,7 +988,7 @@ def compact_record(full):
                        "launches": ro["launches"], "algorithmic_flops_per_launch": ro["algorithmic_flops_per_launch"]}
     sr = full["step_roofline"]
     rec["step_roofline"] = {k: sr[k] for k in ("bound", "frac", "flops_per_node", "bytes_per_node", "mfma_bound_nodes_per_s",
-                                                "hbm_bound_nodes_per_s")}
+                                                "hbm_bound_nodes_per_s", "traffic_bytes_per_node", "traffic_GBs") if k in sr}
     if "cpu_baseline" in full:
         cb = full["cpu_baseline"]
         rec["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
@@ -1355,6 +1355,12 @@ def main():
                                  "mfma_bound_nodes_per_s": mfma_bound, "hbm_bound_nodes_per_s": hbm_bound,
                                  "bound": "mfma" if mfma_bound < hbm_bound else "hbm",
                                  "frac": line["value"] / min(mfma_bound, hbm_bound)}
+        # ... and what the step REALLY moves (FETCH_SIZE / WRITE_SIZE over every launch of a step, profiles/pmc_step.py): the headline
+        # configuration in the default GEMM mode only -- the committed passes were run on that
+        tpn = pmc_traffic()[0].get("step_p3_bytes_per_node")
+        if tpn and (args.in_feats, args.hidden, args.layers) == (831, 256, 3) and trainer._planes_on():
+            line["step_roofline"].update({"traffic_bytes_per_node": tpn, "traffic_over_algorithmic": tpn / bytes_node,
+                                          "traffic_GBs": tpn * line["value"] / world / 1e9, "traffic_source": pmc_traffic()[1]})
         if extras and not args.no_replay:
             # round 1's headline mode, kept as a secondary: HIP-graph replay of 4 pre-captured resident batches
             fixed = [resident.batch(ids) for ids in timed[0][:4]]

@@ -1,5 +1,6 @@
 """pmc_traffic.json (what bench.py reads for roofline.traffic) from the per-kernel PMC tables of profiles/pmc_traffic_summary.py.
-usage: python profiles/make_pmc_traffic.py <step per-kernel json> <full per-kernel json> <out json> [<step per-kernel json, split GEMM mode>]"""
+usage: python profiles/make_pmc_traffic.py <step per-kernel json> <full per-kernel json> <out json> [<step per-kernel json, split GEMM mode>
+       [<steps the driver ran> <mean nodes per step>]]"""
 import json, sys
 step, full = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
 
@@ -37,6 +38,18 @@ if len(sys.argv) > 4:
     for tag, pat in (("batch_assemble_p3", "batch_assemble"), ("ln_relu_bwd_p3", "ln_relu_bwd_vec_kernel"), ("fold_adam", "gte_fold_batch_kernel")):
         b, n = fam(split, lambda k, pat=pat: pat in k)
         out[f"{tag}_bytes_per_launch"], out[f"{tag}_launches_sampled"] = b, n
+    # the WHOLE step (default mode): every launch of the step's kernel families over the steps the driver ran -- the one-time
+    # launches of the set-up (feature / aggregate images: p3_from_f32, the 4-rows-per-wave aggregation into an image) are not the step's
+    if len(sys.argv) > 5:
+        n_steps = int(sys.argv[5])
+        step_kernel = lambda k: (k.startswith(("gemm_p3_", "narrow_", "head_", "gte_fold_batch", "batch_assemble", "ln_relu_")) or
+                                 (k.startswith("spmm_csr_kernel") and split[k]["launches"] >= n_steps))
+        tot = sum(v["bytes_per_launch"] * v["launches"] for k, v in split.items() if step_kernel(k))
+        out["step_p3_bytes_per_step"] = tot / n_steps
+        out["step_p3_launches_per_step"] = sum(v["launches"] for k, v in split.items() if step_kernel(k)) / n_steps
+        nps = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
+        out["step_p3_nodes_per_step"] = nps or None
+        out["step_p3_bytes_per_node"] = (tot / n_steps / nps) if nps else None
 b, n = fam(full, lambda k: "spmm_tiled_full_kernel" in k)
 out["gather_cfg4_tiled_bytes_per_launch"], out["gather_cfg4_tiled_launches_sampled"] = b, n
 b, n = fam(full, lambda k: k.startswith("spmm_csr_kernel<F32, 64") or k.startswith("spmm_csr_kernel<F32; 64"))
