@@ -25,4 +25,5 @@ pipe = loop.BatchPipeline(res)
 plan = [r[0] for r in D.plan_epoch(res.page_sizes(), 100, 1, seed=42, epoch=0)] + [r[0] for r in D.plan_epoch(res.page_sizes(), 100, 1, seed=42, epoch=1)]
 loop.run_steps(tr, pipe, plan[:steps])
 torch.cuda.synchronize()
-print("PMC_STEP steps", steps, "nodes_per_step", sum(pipe.nodes(i) for i in range(steps)) / steps)
+ran = len(pipe)                                  # (the plan may hold fewer steps than asked for)
+print("PMC_STEP steps", ran, "nodes_per_step", sum(pipe.nodes(i) for i in range(ran)) / max(ran, 1))
