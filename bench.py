@@ -557,7 +557,7 @@ def shapes_probe(args, gte, dev, page_sets, loop):
     step's operand shapes (fp32-equivalent TFLOP/s against the bf16 matrix peak / 6)."""
     from gnn_tableextraction_amd import graph as G, ops
     from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
-    out = {"how": f"{args.pages} pages per step, 6 warm-up + 20 timed steps of models/loop.py: run_steps per shape (the better of two such loops); forward GEMMs: "
+    out = {"how": f"{args.pages} pages per step, 12 warm-up + 40 timed steps of models/loop.py: run_steps per shape (the best of three such loops); forward GEMMs: "
                   "10 isolated launches per HIP-event pair on operands of the step's shapes",
            "source": "run_multiple_train.sh:8-113 (--h_layer_dim=1000 | --mode_params=scaled --params_no=100000)"}
     peak = MFMA_BF16_PEAK_TF / 6.0
@@ -580,12 +580,12 @@ def shapes_probe(args, gte, dev, page_sets, loop):
         model = gte.GcnSAGE(f0, hid, 9, args.layers, torch.nn.functional.relu, 0).to(dev)
         trainer = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
         sizes = res.page_sizes()
-        warm, e = epoch_steps(sizes, args.pages, 42, 0, 6)
+        warm, e = epoch_steps(sizes, args.pages, 42, 0, 12)
         timed_loop(trainer, pipe, warm, loop)
-        steps = 20
+        steps = 40                                              # (round 5: 20 steps x 2 loops read +-8 % from run to run on the 0.3 ms shapes)
         el, nodes, out3 = None, 0, None
-        for _ in range(2):                                      # (the better of two loops: a one-off stall -- a buffer set that grows,
-            epochs, e = epoch_steps(sizes, args.pages, 42, e, steps)      # a busy host -- is tens of ms against a 10 - 60 ms loop)
+        for _ in range(3):                                      # (the best of three loops: a one-off stall -- a buffer set that grows,
+            epochs, e = epoch_steps(sizes, args.pages, 42, e, steps)      # a busy host -- is tens of ms against a 15 - 120 ms loop)
             el_, nodes_, out3 = timed_loop(trainer, pipe, epochs, loop)
             if el is None or nodes_ / el_ > nodes / el:
                 el, nodes = el_, nodes_
@@ -649,17 +649,17 @@ def shapes_probe(args, gte, dev, page_sets, loop):
 def size_sweep_probe(args, trainer, pipe, sizes, loop, first_epoch):
     """nodes/s of the headline configuration at other batch sizes (pages per step): real PubLayNet pages give 2 x 10^4 ... 8 x 10^4
     nodes per 100-page step; the time of a step should follow its node count, not the number of tile rounds."""
-    out = {"how": "4 warm-up + 16 timed steps of the same loop per point (the better of two such loops), same resident pages", "points": []}
+    out = {"how": "8 warm-up + 32 timed steps of the same loop per point (the best of three such loops), same resident pages", "points": []}
     e = first_epoch
     for pages_per_step in (50, 100, 135, 150, 200, 330):
         if pages_per_step > len(sizes):
             continue
-        warm, e = epoch_steps(sizes, pages_per_step, 42, e, 4)
+        warm, e = epoch_steps(sizes, pages_per_step, 42, e, 8)
         timed_loop(trainer, pipe, warm, loop)
-        steps = 16
+        steps = 32
         el, nodes = None, 0
-        for _ in range(2):                  # (a buffer set that grows inside a timed loop -- a batch larger than every warm-up
-            ep, e = epoch_steps(sizes, pages_per_step, 42, e, steps)       # batch -- costs tens of ms once: the better of two loops)
+        for _ in range(3):                  # (a buffer set that grows inside a timed loop -- a batch larger than every warm-up
+            ep, e = epoch_steps(sizes, pages_per_step, 42, e, steps)       # batch -- costs tens of ms once: the best of three loops)
             el_, nodes_, _ = timed_loop(trainer, pipe, ep, loop)
             if el is None or nodes_ / el_ > nodes / el:
                 el, nodes = el_, nodes_
