@@ -250,6 +250,35 @@ def _resident(pages, tr, f0):
     return G.ResidentPages(graphs, DEV)
 
 
+@pytest.mark.parametrize("f0,hid,image_mode", [(831, 256, True), (13, 218, True), (831, 256, False)])
+def test_batches_assembled_in_stream_order_train_bitwise_as_on_the_side_stream(f0, hid, image_mode, monkeypatch):
+    """BatchPipeline assembles a row-map batch in the caller's stream order (no events) and a batch that copies fp32 rows on its side
+    stream under the step before; either placement forced (side_stream=False / True) over several load()s of different lengths --
+    metadata uploads in between, both buffer sets reused -- must train bit for bit the same parameters."""
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    from gnn_tableextraction_amd.models.loop import BatchPipeline, run_steps
+    if not image_mode:
+        monkeypatch.setenv("GTE_PLANES", "0")            # fp32 feature rows: the batches copy them
+    pages = S.make_pages(60, in_feats=f0)
+    rng = np.random.default_rng(3)
+    chunks = [[rng.permutation(60)[:k] for k in ks] for ks in ([9, 14, 5], [20], [7, 7, 7, 11], [3, 25])]
+    results = []
+    for side in (True, False, None):
+        torch.manual_seed(11)
+        model = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0).to(DEV)
+        fused = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+        pipe = BatchPipeline(_resident(pages, fused, f0), side_stream=side)
+        losses = []
+        for chunk in chunks:
+            out3 = run_steps(fused, pipe, chunk)
+            losses.append(out3.clone())
+        torch.cuda.synchronize()
+        assert pipe._same == ((not side) if side is not None else (pipe.res.p3_mode == "rows"))
+        results.append((torch.stack(losses).cpu(), torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()))
+    for got in results[1:]:
+        assert torch.equal(got[0], results[0][0]) and torch.equal(got[1], results[0][1])
+
+
 @pytest.mark.parametrize("f0,hid", [(831, 256), (831, 96), (63, 206), (13, 218), (363, 149)])
 def test_the_kernel_timer_schedule_runs_on_the_loops_image_batches(f0, hid):
     """bench.py's per-kernel HIP-event pass (ops.enable_kernel_timers) switches the engine to its launch-by-launch schedule on
