@@ -129,6 +129,7 @@ SIGNATURES = {
     "gte_gemm_p3_set_rows64": (c_int, [c_int]),
     "gte_gemm_p3_set_nt_cfg": (c_int, [c_int]),
     "gte_gemm_p3_set_ln_rows": (c_int, [c_int]),
+    "gte_batch_assemble_defer": (c_int, [c_int]),
     "gte_head_dlq_finish_workspace_bytes": (c_int64, [c_int64]),
     "gte_head_dlq_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_float, c_void_p,
                                     c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -1,5 +1,6 @@
 // libgte_hip.so: error reporting, version and device facts.
 #include "gte_common.h"
+#include "batch_assemble.h"
 #include "fold_images.h"
 #include "p3.h"
 
@@ -58,9 +59,11 @@ struct FoldDesc {
 // Optional optimiser tail of the batch (gte_fold_defer_flush_adam): when `param` is set every folded element is a gradient
 // element of the flat buffer starting at `grad`, and the thread that writes it applies the Adam update of that element.
 struct FoldAdam { float* param; float* grad; float* exp_avg; float* exp_avg_sq; float* state; long long* step; unsigned* ticket; int vec_ok; };
-struct FoldBatch { FoldDesc d[kMaxFolds]; int n; FoldAdam adam; FoldImages img; };
+struct FoldBatch { FoldDesc d[kMaxFolds]; int n; FoldAdam adam; FoldImages img; int fold_blocks; };
 struct FoldQueue {
     FoldBatch batch; bool open = false; hipStream_t stream = nullptr; int blocks = 0;
+    // the next batch's assembly, carried by the flush launch as workgroups behind the folds' (batch_assemble.h: defer_assemble)
+    gte_asm::AssembleJob asm_job = {}; bool has_asm = false;
     bool spilled = false;                 // a full batch was flushed early: the queued folds no longer cover the whole deferral
     // coverage cache of gte_fold_defer_flush_adam: the descriptor signature it was computed for and its verdict
     unsigned long long cover_key = 0; bool cover_ok = false;
@@ -77,8 +80,14 @@ static FoldQueue& fold_queue() {
 // elements) runs with one slice -- a thread streams its element through all partials; a block-partial set (hundreds
 // of partials, a few thousand elements) with 16.
 __global__ void __launch_bounds__(256)
-gte_fold_batch_kernel(const gte::FoldBatch fb) {
+gte_fold_batch_kernel(const gte::FoldBatch fb, const gte_asm::AssembleJob aj) {
     __shared__ __attribute__((aligned(16))) float part[4 * 256];
+    if ((int)blockIdx.x >= fb.fold_blocks) {
+        // a workgroup of the co-launched batch assembly (independent of the folds: another buffer set, read by the NEXT step)
+        gte_asm::assemble_block(aj.a, aj.feat_wgs, aj.rows_per_wg, aj.n_out, (int)blockIdx.x - fb.fold_blocks);
+        if (fb.adam.param) gte::adam_advance(fb.adam.state, fb.adam.step, fb.adam.ticket);      // (every workgroup of the grid checks in)
+        return;
+    }
     int di = 0;
 #pragma unroll 1
     for (int i = 1; i < fb.n; ++i) if ((int)blockIdx.x >= fb.d[i].first_block) di = i;
@@ -204,7 +213,8 @@ gte_fold_batch_kernel(const gte::FoldBatch fb) {
 namespace gte {
 
 static int flush_folds(FoldQueue& q, const FoldAdam* adam = nullptr, const FoldImages* images = nullptr) {
-    if (q.batch.n == 0) return GTE_OK;
+    if (q.batch.n == 0 && !q.has_asm) return GTE_OK;
+    if (q.batch.n == 0) adam = nullptr;                 // (a deferred assembly alone: no folds, no optimiser tail)
     q.batch.adam = adam ? *adam : FoldAdam{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (images) q.batch.img = *images; else q.batch.img.n = 0;
     for (int i = 0; i < q.batch.n; ++i) {
@@ -215,10 +225,23 @@ static int flush_folds(FoldQueue& q, const FoldAdam* adam = nullptr, const FoldI
         for (int k = 0; k < images->n; ++k)
             if (images->im[k].off < hi && images->im[k].off + (long long)images->im[k].span > lo) d.img_mask |= 1u << k;
     }
-    hipLaunchKernelGGL(gte_fold_batch_kernel, dim3((unsigned)q.blocks), dim3(256), 0, q.stream, q.batch);
+    q.batch.fold_blocks = q.blocks;
+    const gte_asm::AssembleJob none = {};
+    const int asm_blocks = q.has_asm ? q.asm_job.blocks : 0;
+    hipLaunchKernelGGL(gte_fold_batch_kernel, dim3((unsigned)(q.blocks + asm_blocks)), dim3(256), 0, q.stream, q.batch,
+                       q.has_asm ? q.asm_job : none);
     q.batch.n = 0;
     q.blocks = 0;
+    q.has_asm = false;
     return check_launch("fold_batch");
+}
+
+bool defer_assemble(const gte_asm::AssembleJob& job, hipStream_t stream) {
+    FoldQueue& q = fold_queue();
+    if (!q.open || q.stream != stream || q.has_asm || job.blocks <= 0) return false;
+    q.asm_job = job;
+    q.has_asm = true;
+    return true;
 }
 
 bool defer_fold(const float* src, int64_t stride, int count, int rows, int rowlen, float* dst, int64_t ld) {

@@ -41,6 +41,9 @@ class BatchPipeline:
         self._force_side = {"1": True, "0": False}.get(os.environ.get("GTE_PIPE_SIDE", ""), side_stream)     # None: per load()
         self._same = False
         self._meta_pending = False                      # the caller's stream has not yet waited for the last metadata upload
+        self._ride = os.environ.get("GTE_PIPE_RIDE", "1") == "1"       # (0: measurement -- the in-stream assembly as its own launch)
+        from .. import _lib as _gte_lib
+        self._lib = _gte_lib.load()
         self._sets: List[dict] = []
         self._free_ev: List[Optional[torch.cuda.Event]] = [None] * depth
         self._pinned = None
@@ -180,8 +183,18 @@ class BatchPipeline:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.side.wait_event(ev)
-        g = self.res.assemble(self._meta_dev[off:off + 4 * nb + 3], nb, n, e_in, e_out, self._sets[k], n_sizes,
-                              stream=(torch.cuda.current_stream(self.device) if self._same else self.side).cuda_stream)
+        # in stream order and from inside a step (the engine's before-last-GEMM hook): the assembly rides the step's fold +
+        # optimiser launch as extra workgroups (gte_batch_assemble_defer) -- it writes the OTHER buffer set, which nothing of
+        # this step reads; outside a step (no fold deferral open) the same call launches at once
+        ride = self._same and after_current and self._ride
+        if ride:
+            self._lib.gte_batch_assemble_defer(1)
+        try:
+            g = self.res.assemble(self._meta_dev[off:off + 4 * nb + 3], nb, n, e_in, e_out, self._sets[k], n_sizes,
+                                  stream=(torch.cuda.current_stream(self.device) if self._same else self.side).cuda_stream)
+        finally:
+            if ride:
+                self._lib.gte_batch_assemble_defer(0)
         ev = None
         if not self._same:
             ev = torch.cuda.Event()

@@ -186,6 +186,12 @@ int gte_batch_assemble(const int32_t* pages, int64_t n_batch, const int32_t* nod
                        const gte_batch_arrays* in_edges, const gte_batch_arrays* out_edges,
                        const float* feat, int64_t ld_feat, int64_t n_cols, float* feat_out,
                        const float* label, float* label_out, int64_t n_out, void* stream);
+/* 1: a gte_batch_assemble / gte_batch_assemble_rows call made while a fold deferral is open on its stream (i.e. from inside a
+ * training step: gte_gcnsage_step's before-last-GEMM callback) is not launched; the deferral's flush -- the fold + optimiser launch
+ * that ends the step -- carries it as extra workgroups (the NEXT batch's buffers are independent of everything that launch
+ * touches).  One job per deferral; without an open deferral on that stream the call launches as always.  0 (default): off.
+ * Per host thread; returns the previous setting. */
+int gte_batch_assemble_defer(int on);
 /* out[b_node_off[i] + r, 0:n_cols] = in[node_off[pages[i]] + r, 0:n_cols]  (features, labels stored as f32) */
 int gte_batch_rows(const int32_t* pages, int64_t n_batch, const int32_t* node_off, const int32_t* b_node_off,
                    const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t n_out, int64_t n_cols,
