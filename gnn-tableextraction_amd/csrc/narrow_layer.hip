@@ -433,8 +433,11 @@ struct LnBackward {
 // MSK (with Ft < F): the rows are PADDED -- Ft true columns, zeros up to F (a multiple of 16): W is [C][2 Ft], the dW / LayerNorm
 // partials are written compact ([.][Ft]), the LayerNorm backward runs over the Ft true columns with per-element validity (the
 // arithmetic of ln_relu_bwd_gen_kernel) and writes zeros into the padding of dz and of its image
+#ifndef NB_ABL
+#define NB_ABL 0          // measurement builds (profiles/debug/build_variant.sh): 1 no dW products, 2 no LayerNorm phase, 4 no dh products,
+#endif                    // 8 no dz stores, 16 no z loads, 32 no CE fold / alpha
 template <int NCT, int LNB = 0, bool MSK = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, LNB == 2 ? 2 : 1)
 narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* __restrict__ q, int64_t ldq,
                        const float* __restrict__ h, int64_t ldh, const float* __restrict__ W, int64_t ldw,
                        float* __restrict__ dh, int64_t lddh, float* __restrict__ partial, int n, int F, int C,
@@ -477,14 +480,21 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
     // Row-block pipeline: the h rows (for the dW product) and the dl / q values of the NEXT row block are requested before
     // the current block is computed; the first block's requests go out before the CE fold and the W image are done.
     constexpr int ND = (32 * KD + 255) / 256;
-    f2n hvn[16];
+    // LNB == 2 runs two workgroups per CU (256 registers per lane): the h rows of a block are requested at its top -- their only use
+    // is the dW product at its end, a whole block later -- instead of a block ahead (32 registers), and the other workgroup of the CU
+    // covers what latency is left.  Measured before (one workgroup per CU, 316 registers): the phases of a block simply add up --
+    // skeleton 11 + dh 4 + LayerNorm 18 + dW 8 us of 38 (profiles/r05/narrow_bwd_abl.txt).
+    constexpr bool AHEAD = LNB != 2;
+    f2n hvn[AHEAD ? 16 : 1];
     float dvn[ND];
     auto request = [&](int rbn) {
         const int r0 = rbn * 32;
+        if constexpr (AHEAD) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            hvn[s] = f2n{0.f, 0.f};
-            if (colok) hvn[s] = *reinterpret_cast<const f2n*>(h + (int64_t)min(r0 + 2 * s + hh, n - 1) * ldh + col);
+            for (int s = 0; s < 16; ++s) {
+                hvn[s] = f2n{0.f, 0.f};
+                if (colok) hvn[s] = *reinterpret_cast<const f2n*>(h + (int64_t)min(r0 + 2 * s + hh, n - 1) * ldh + col);
+            }
         }
 #pragma unroll
         for (int t = 0; t < ND; ++t) {
@@ -501,7 +511,7 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
     // fused head (gte_head_agg_ce): dl / q arrive WITHOUT the 1 / sum(w) of the weighted cross-entropy; every block folds
     // the CE partials itself (fixed order, same value everywhere) and scales its DLQ image; block 0 publishes out3
     float alpha = 1.f;
-    if (ce_partial) {
+    if (ce_partial && !(NB_ABL & 32)) {
         __shared__ double ce_red[3][gte_ce::kCeBlock];
         gte_ce::ce_fold(ce_partial, ce_blocks, ce_red);
         const float wsum = (float)ce_red[1][0];
@@ -515,7 +525,13 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
         f2n hv[16];
         float dv[ND];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) hv[s] = hvn[s];
+        for (int s = 0; s < 16; ++s) {
+            if constexpr (AHEAD) hv[s] = hvn[s];
+            else {
+                hv[s] = f2n{0.f, 0.f};
+                if (colok) hv[s] = *reinterpret_cast<const f2n*>(h + (int64_t)min(row0 + 2 * s + hh, n - 1) * ldh + col);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < ND; ++t) dv[t] = dvn[t];
         if (rb + (int)gridDim.x < nblk) request(rb + gridDim.x);
@@ -527,7 +543,7 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                 const int rr = min(row0 + wave + 4 * u, n - 1);
                 struct __attribute__((packed, aligned(4))) f4n { float x, y, z, w; };
                 f4n t{0.f, 0.f, 0.f, 0.f};
-                if (okc) t = *reinterpret_cast<const f4n*>(lnb.z + (int64_t)rr * lnb.ldz + j4);
+                if (okc && !(NB_ABL & 16)) t = *reinterpret_cast<const f4n*>(lnb.z + (int64_t)rr * lnb.ldz + j4);
                 zr[u][0] = t.x; zr[u][1] = t.y; zr[u][2] = t.z; zr[u][3] = t.w;
                 mu2[u] = lnb.stats[rr]; rs2[u] = lnb.stats[n + rr];
             }
@@ -551,7 +567,7 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < NCT; ++s) {
+            for (int s = 0; s < ((NB_ABL & 4) ? 1 : NCT); ++s) {
                 const float a = D[i * DP + 2 * s + hh];
                 float b0 = 0.f, b1 = 0.f;
                 if (colok) { const float2 b = *reinterpret_cast<const float2*>(Wst + (2 * s + hh) * FP + col); b0 = b.x; b1 = b.y; }
@@ -571,7 +587,7 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                 __syncthreads();
                 const float inv_f = 1.0f / (float)Ft;
 #pragma unroll
-                for (int trip = 0; trip < 2; ++trip) {
+                for (int trip = 0; trip < ((NB_ABL & 2) ? 0 : 2); ++trip) {
                     float gy[4][4];
 #pragma unroll
                     for (int u4 = 0; u4 < 4; ++u4) {
@@ -587,18 +603,23 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
                         if (rr >= n) continue;                               // wave-uniform
                         float xh[4], g[4];
                         float a = 0.f, b = 0.f;
-                        if constexpr (MSK) gte_ln_bwd_pre4m(gy[u4], zr[u], mu2[u], rs2[u], gam4, bet4, oke, lnb.relu, xh, g, a, b);
+                        // (MSK: the per-element validity is recomputed here -- four registers less across the block loop, which is
+                        // what keeps the <12, 2, true> instantiation inside the 256 registers of two workgroups per CU)
+                        bool okl[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) okl[e] = MSK ? j4 + e < Ft : okc;
+                        if constexpr (MSK) gte_ln_bwd_pre4m(gy[u4], zr[u], mu2[u], rs2[u], gam4, bet4, okl, lnb.relu, xh, g, a, b);
                         else gte_ln_bwd_pre4(gy[u4], zr[u], mu2[u], rs2[u], gam4, bet4, okc, lnb.relu, xh, g, a, b);
                         const float c1 = gte_group_sum<64>(a) * inv_f, c2 = gte_group_sum<64>(b) * inv_f;
                         float d[4];
-                        if constexpr (MSK) gte_ln_bwd_post4m(g, xh, gam4, rs2[u], c1, c2, oke, d, c_dg, c_db, c_dz);
+                        if constexpr (MSK) gte_ln_bwd_post4m(g, xh, gam4, rs2[u], c1, c2, okl, d, c_dg, c_db, c_dz);
                         else gte_ln_bwd_post4(g, xh, gam4, rs2[u], c1, c2, okc, d, c_dg, c_db, c_dz);
-                        if (okc) {
+                        if (okc && (!(NB_ABL & 8) || d[0] == 12345.f)) {
                             struct __attribute__((packed, aligned(4))) f4n { float x, y, z, w; };
                             f4n ov; ov.x = d[0]; ov.y = d[1]; ov.z = d[2]; ov.w = d[3];
                             *reinterpret_cast<f4n*>(dh + rr * lddh + j4) = ov;
                         }
-                        if (imc && lnb.dzp3) p3::store4(lnb.dzp3 + rr * lnb.ldp3, j4, d[0], d[1], d[2], d[3]);
+                        if (imc && lnb.dzp3 && (!(NB_ABL & 8) || d[0] == 12345.f)) p3::store4(lnb.dzp3 + rr * lnb.ldp3, j4, d[0], d[1], d[2], d[3]);
                     }
                 }
             } else
@@ -614,7 +635,7 @@ narrow_bwd_mfma_kernel(const float* __restrict__ dl, int64_t lddl, const float* 
             }
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < ((NB_ABL & 1) ? 1 : 16); ++s) {
             const float a = i < KD ? D[(2 * s + hh) * DP + i] : 0.f;
             gw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hv[s].x, gw[0], 0, 0, 0);
             gw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hv[s].y, gw[1], 0, 0, 0);
@@ -806,9 +827,12 @@ int narrow_blocks(int64_t n) {
 // workgroups of the matrix-pipe backward (each walks 32-row blocks): one per CU.  Every workgroup leaves an 18 KB dW
 // partial behind (written here, read again by the fold): at 512 workgroups that was 14 MB of extra traffic on a 50 MB
 // kernel; measured per step 0.773 (512) / 0.766 (384) / 0.761 (256) / 0.769 ms (192).
-int narrow_mfma_blocks(int64_t n) {
+// per_cu = 2: the form with the LayerNorm backward behind the dh product (round 5: 256 registers, two workgroups per CU -- 38.6 -> 34.3 us at
+// 24 k x 256 for +2.3 us of fold, profiles/r05/narrow_bwd_abl.txt)
+int narrow_mfma_blocks(int64_t n, int per_cu = 1) {
     static const int forced = getenv("GTE_NARROW_BLOCKS") ? atoi(getenv("GTE_NARROW_BLOCKS")) : 0;      // (measurement)
-    const int cap = forced > 0 && forced <= NB_MAX ? forced : (gte::device_props().cus < NB_MAX ? gte::device_props().cus : NB_MAX);
+    const int want = gte::device_props().cus * per_cu;
+    const int cap = forced > 0 && forced <= NB_MAX ? forced : (want < NB_MAX ? want : NB_MAX);
     const int64_t b = gte::ceil_div(n, 32);
     return (int)(b < cap ? b : cap);
 }
@@ -948,12 +972,12 @@ int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, 
     float* part = reinterpret_cast<float*>(workspace);
     const int C = (int)n_out, F = (int)n_feat, Ft = (int)n_true;
     if (n_feat % 8 == 0) {                                 // matrix-pipe version
-        const int nbm = narrow_mfma_blocks(n_nodes);
-#define GTE_NBM(NCT)                                                                                                  \
+        const int nbm = narrow_mfma_blocks(n_nodes, lnb ? 2 : 1);
+#define GTE_NBM(NCT, NCTM)                                                                                            \
     do {                                                                                                              \
         if (lnb && msk)                                                                                               \
-            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 2, true>), dim3((unsigned)nbm), dim3(256),                \
-                               (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1) + 32 * F) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, \
+            hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCTM, 2, true>), dim3((unsigned)nbm), dim3(256),               \
+                               (size_t)(2 * NCTM * (F + 4) + 32 * (2 * NCTM + 1) + 32 * F) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, \
                                lddh, part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, *lnb, Ft);    \
         else if (lnb)                                                                                                 \
             hipLaunchKernelGGL((narrow_bwd_mfma_kernel<NCT, 2>), dim3((unsigned)nbm), dim3(256),                      \
@@ -964,7 +988,9 @@ int narrow_bwd_impl(const float* dl, int64_t lddl, const float* q, int64_t ldq, 
                                (size_t)(2 * NCT * (F + 4) + 32 * (2 * NCT + 1)) * 4, s, dl, lddl, q, ldq, h, ldh, W, ldw, dh, lddh, \
                                part, (int)n_nodes, F, C, ce_partial, ce_blocks, grad_scale, out3, LnBackward{}, 0);   \
     } while (0)
-        if (n_out <= 4) GTE_NBM(4); else if (n_out <= 8) GTE_NBM(8); else if (n_out <= 12) GTE_NBM(12); else GTE_NBM(16);
+        // (padded rows with 9 ... 12 classes take the 16-class instantiation: <12, 2, true> needs 259 registers -- 12 bytes of scratch per
+        // lane inside the 256 of two workgroups per CU --, <16, 2, true> fits; eight more MFMAs per 32-row block)
+        if (n_out <= 4) GTE_NBM(4, 4); else if (n_out <= 8) GTE_NBM(8, 8); else if (n_out <= 12) GTE_NBM(12, 16); else GTE_NBM(16, 16);
 #undef GTE_NBM
         // (the partials are compact: rows of Ft = the true width)
         if (lnb) {                                          // column sums of the fused LayerNorm backward
@@ -1124,5 +1150,5 @@ extern "C" int gte_sage_narrow_bwd_ln_p3_pad(const float* dl, int64_t lddl, cons
 }
 
 extern "C" int64_t gte_sage_narrow_bwd_ln_workspace_bytes(int64_t n_nodes, int64_t n_feat) {
-    return gte::round_up((int64_t)narrow_mfma_blocks(n_nodes > 0 ? n_nodes : 1) * 3 * n_feat * 4, 256);
+    return gte::round_up((int64_t)narrow_mfma_blocks(n_nodes > 0 ? n_nodes : 1, 2) * 3 * n_feat * 4, 256);
 }
