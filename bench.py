@@ -231,9 +231,9 @@ def dist_one_rank_probe(args, gte, dev, resident, pipe, sizes, loop, ep):
             m = gte.GcnSAGE(args.in_feats, args.hidden, 9, args.layers, torch.nn.functional.relu, 0).to(dev)
             trainers[dp] = FusedGcnSageStep(m, lr=0.01, weight_decay=5e-4, distributed=dp)
         best = {False: None, True: None}
-        for rnd in range(3):
+        for rnd in range(4):
             for dp in (False, True):
-                epochs, ep = epoch_steps(sizes, args.pages, 4242, ep, 12 if rnd == 0 else 48)
+                epochs, ep = epoch_steps(sizes, args.pages, 4242, ep, 12 if rnd == 0 else 96)
                 counts = [[int(sum(sizes[i] for i in ids)) for ids in plan] for plan in epochs]
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -246,7 +246,8 @@ def dist_one_rank_probe(args, gte, dev, resident, pipe, sizes, loop, ep):
                 if rnd > 0 and (best[dp] is None or ms < best[dp]):
                     best[dp] = ms
         return {"plain_ms_per_step": best[False], "dist_1rank_ms_per_step": best[True], "extra_us": (best[True] - best[False]) * 1e3,
-                "how": "48 steps of the train loop per arm, two interleaved rounds after a warm-up round, the better of each arm; "
+                "how": "96 steps of the train loop per arm, three interleaved rounds after a warm-up round, the best of each arm "
+                       "(round 5: 48 x 2 read +7 ... +20 us from run to run); "
                        "RCCL process group of one rank"}
     except Exception as e:                                   # (no RCCL on this box / rendezvous refused: the probe is optional)
         return {"error": f"{type(e).__name__}: {e}"[:200]}

@@ -8,6 +8,8 @@
 // Both are HBM-bound and tiny next to the transforms (N x 9 logits; <= 4 M parameters).  The CE
 // is deterministic: per-block partial sums in a fixed order, one reducing block, no atomics.
 #include "gte_common.h"
+
+#include <stdlib.h>
 #include "fold_images.h"
 #include "ce_fold.h"
 #include "p3.h"
@@ -400,12 +402,17 @@ extern "C" int gte_adam_step_dev_images(float* param, const float* grad, float* 
     gte::FoldImages fi;
     const int rc = gte::make_fold_images(param, n, images, n_images, fi, "adam_step_dev_images");
     if (rc != GTE_OK) return rc;
-    const int64_t blocks = gte::ceil_div(n, 4096) < 256 ? gte::ceil_div(n, 4096) : 256;
+    // (round 5: workgroups of 256 -- one 16-byte group per thread up to 2 048 workgroups -- instead of <= 256 of 1 024: the launch is a
+    // chain of dependent memory round trips plus scattered 2-byte image stores, more workgroups in flight shorten it)
+    static const int bt = getenv("GTE_ADAM_DEV_BLOCK") ? atoi(getenv("GTE_ADAM_DEV_BLOCK")) : 256;      // (measurement: 1024 = round 4)
+    const int threads = bt == 1024 ? 1024 : 256;
+    const int64_t want = gte::ceil_div(n, 4 * (int64_t)threads), cap = threads == 1024 ? 256 : 2048;
+    const int64_t blocks = want < cap ? want : cap;
     if (fi.n > 0)
-        hipLaunchKernelGGL(adam_dev_kernel<true>, dim3((unsigned)blocks), dim3(1024), 0, gte::as_stream(stream), param, grad, exp_avg,
+        hipLaunchKernelGGL(adam_dev_kernel<true>, dim3((unsigned)blocks), dim3(threads), 0, gte::as_stream(stream), param, grad, exp_avg,
                            exp_avg_sq, n, state, step_counter, ticket, fi);
     else
-        hipLaunchKernelGGL(adam_dev_kernel<false>, dim3((unsigned)blocks), dim3(1024), 0, gte::as_stream(stream), param, grad, exp_avg,
+        hipLaunchKernelGGL(adam_dev_kernel<false>, dim3((unsigned)blocks), dim3(threads), 0, gte::as_stream(stream), param, grad, exp_avg,
                            exp_avg_sq, n, state, step_counter, ticket, fi);
     *wrote = fi.n > 0 ? 1 : 0;
     return gte::check_launch("adam_step_dev_images");
