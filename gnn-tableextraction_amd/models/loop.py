@@ -170,8 +170,10 @@ class BatchPipeline:
 
     # ---- per step --------------------------------------------------------------------------------
     def start(self, s: int, after_current: bool = False) -> None:
-        """Queue the assembly of step s's batch on the side stream (returns immediately).  ``after_current``: the assembly
-        additionally waits for everything queued on the CURRENT stream so far (used to place it under a chosen kernel)."""
+        """Queue the assembly of step s's batch (returns immediately): in the caller's stream order or on the side stream (see
+        __init__; decided by the last load()).  ``after_current``: the caller is inside a step, in front of its last GEMM -- a
+        side-stream assembly additionally waits for everything queued on the CURRENT stream so far (which places it under that
+        GEMM), an in-stream assembly rides the step's fold + optimiser launch."""
         off, nb, n, e_in, e_out, n_sizes = self._info[s]
         k = s % self.depth
         if self._same and self._meta_pending:
