@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--no-shapes", action="store_true", help="skip the reference's own run shapes (hidden 1000 / scaled hidden)")
     ap.add_argument("--no-size-sweep", action="store_true", help="skip the pages-per-step sweep of the headline configuration")
     ap.add_argument("--no-residency", action="store_true", help="skip the host-resident (windowed) training-set probe")
+    ap.add_argument("--no-uncached", action="store_true", help="skip the loop without the cached input aggregate (`uncached`)")
     ap.add_argument("--no-dist-probe", action="store_true", help="skip the one-rank data-parallel step (RCCL group of one) against the plain step")
     ap.add_argument("--gemm-mode", choices=["f32", "split_bf16"], default=None,
                     help="arithmetic of the transform GEMMs for the headline loop (default: GTE_GEMM_MODE or f32)")
@@ -651,6 +652,36 @@ def shapes_probe(args, gte, dev, page_sets, loop):
     return out
 
 
+def uncached_probe(args, gte, dev, pages, loop):
+    """The headline loop WITHOUT the cached input aggregate (GTE_CACHE_AGG=0's path): layer 0 aggregates its input in every step
+    (reference models.py:53-54 as written) instead of reading the per-page aggregate made once at load.  Same model, same pages."""
+    from gnn_tableextraction_amd import graph as G
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    torch.cuda.empty_cache()
+    res = G.ResidentPages(to_page_graphs(gte, pages[:600]), dev)
+    pipe = loop.BatchPipeline(res)
+    torch.manual_seed(42)
+    model = gte.GcnSAGE(args.in_feats, args.hidden, 9, args.layers, torch.nn.functional.relu, 0).to(dev)
+    trainer = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+    trainer.cache_input_agg = False
+    sizes = res.page_sizes()
+    warm, e = epoch_steps(sizes, args.pages, 42, 0, 12)
+    timed_loop(trainer, pipe, warm, loop)
+    steps, el, nodes = 40, None, 0
+    for _ in range(3):
+        epochs, e = epoch_steps(sizes, args.pages, 42, e, steps)
+        el_, nodes_, _ = timed_loop(trainer, pipe, epochs, loop)
+        if el is None or nodes_ / el_ > nodes / el:
+            el, nodes = el_, nodes_
+    kinds = trainer._plan_kinds(args.in_feats, int(nodes / steps), res.agg_p3 is not None)
+    out = {"workload": "the headline loop with the input's mean aggregate computed in every step (no cached aggregate image)",
+           "how": "12 warm-up + 40 timed steps of run_steps, the best of three such loops, 600 resident pages",
+           "value": nodes / el, "unit": "nodes/s", "ms_per_step": el / steps * 1e3, "layer_kinds": kinds}
+    del trainer, model, pipe, res
+    torch.cuda.empty_cache()
+    return out
+
+
 def size_sweep_probe(args, trainer, pipe, sizes, loop, first_epoch):
     """nodes/s of the headline configuration at other batch sizes (pages per step): real PubLayNet pages give 2 x 10^4 ... 8 x 10^4
     nodes per 100-page step; the time of a step should follow its node count, not the number of tile rounds."""
@@ -984,13 +1015,17 @@ def compact_record(full):
     rec["config"] = {"workload": (f"cfg2: {cfg['pages_per_gpu_per_step']} synthetic PubLayNet-style page graphs per GPU per step "
                                   f"(~{cfg['nodes_per_step_per_gpu']} nodes), GcnSAGE {cfg['layers']} layers F0={cfg['in_feats']} "
                                   f"hidden={cfg['hidden']} classes=9 fp32, CE + Adam; train loop, a different device-built batch "
-                                  f"every step"),
+                                  f"every step" + ("; layer-0 input aggregate cached per resident page (made once at load, not in the "
+                                                   "timed step; `uncached` = the same loop aggregating the input every step)"
+                                                   if cfg.get("input_aggregate_cached") else "")),
                      "pages_per_gpu_per_step": cfg["pages_per_gpu_per_step"], "nodes_per_step_per_gpu": cfg["nodes_per_step_per_gpu"],
                      "resident_pages_per_gpu": cfg["resident_pages_per_gpu"], "parallelism": cfg["parallelism"]}
     ro = full["roofline"]
     rec["roofline"] = {"bound": ro["bound"], "achieved": ro["achieved"], "peak": ro["peak"], "unit": ro["unit"], "frac": ro["frac"],
                        "traffic": ro["traffic"], "kernel": ro["kernel_short"], "avg_launch_ms": ro["avg_launch_ms"],
                        "launches": ro["launches"], "algorithmic_flops_per_launch": ro["algorithmic_flops_per_launch"]}
+    if ro.get("layer1"):
+        rec["roofline"]["layer1"] = ro["layer1"]
     sr = full["step_roofline"]
     rec["step_roofline"] = {k: sr[k] for k in ("bound", "frac", "flops_per_node", "bytes_per_node", "mfma_bound_nodes_per_s",
                                                 "hbm_bound_nodes_per_s", "traffic_bytes_per_node", "traffic_GBs") if k in sr}
@@ -1000,6 +1035,8 @@ def compact_record(full):
                                "sample": cb["sample_short"], "ms_per_step": cb["ms_per_step"]}
         rec["gpu_over_cpu"] = full["gpu_over_cpu"]
     rec["final_loss"] = full["final_loss"]
+    if isinstance(full.get("uncached"), dict) and "value" in full["uncached"]:
+        rec["uncached"] = full["uncached"]["value"]
     if "long_run" in full:
         rec["long_run"] = {k: full["long_run"][k] for k in ("steps", "seconds", "value")}
     if "gather" in full:
@@ -1294,8 +1331,10 @@ def main():
         more, ep = epoch_steps(sizes, args.pages, seed, ep, 8)
         ms2, fl2, n2 = loop_forward_gemms(trainer, pipe, more, loop, args.in_feats, args.hidden, kinds_hl,
                                           n_global=global_counts(more) if distributed else None)
-        launches = n2 * sum(1 for k in kinds_hl[:2] if k != 1)
-        fwd_ev = (launches, ms2[0] + ms2[1], fl2[0] + fl2[1], ms2, fl2)
+        # the DOMINANT kernel is ONE kernel: the layer-0 forward GEMM (layer 1's goes beside it as `layer1`, never averaged in);
+        # a short-input layer 0 (kind 1) is no GEMM: layer 1's forward is the dominant GEMM then
+        dom = 0 if kinds_hl[0] != 1 else 1
+        fwd_ev = (n2, ms2[dom], fl2[dom], ms2, fl2, dom)
     if rank == 0:
         n_launch, ms, flops = kt.get("gemm_nt", (0, 0.0, 0.0))
         if fwd_ev is not None and fwd_ev[1] > 0:
@@ -1310,7 +1349,9 @@ def main():
                                ("gemm_split_kernel<NT> (layer transforms, forward; fp32 operands as 3 exact bf16 pieces, 6 bf16 "
                                 "MFMA products, fp32 accumulate; peak = bf16 dense / 6)")) if split_mode
                               else "gemm_f32_mfma_kernel<NT> (layer transforms, forward)",
-                    "kernel_short": (("gemm_p3_nt_lw/ring fwd, L0 with LN epilogue (bf16x3 planes, peak=bf16/6)" if trainer._planes_on() else "gemm_split<NT> fwd (peak=bf16/6)")
+                    "kernel_short": ((((f"layer-{fwd_ev[5]} forward GEMM alone" + (" ([x|cached ahn]W^T, K=2*F0, LN+ReLU epilogue)" if kinds_hl[0] == 3 else "")
+                                        + ", gemm_p3_nt (bf16x3 planes, peak=bf16/6)") if fwd_ev is not None else "gemm_p3_nt fwd (bf16x3 planes, peak=bf16/6)")
+                                      if trainer._planes_on() else "gemm_split<NT> fwd (peak=bf16/6)")
                                      if split_mode else "gemm_f32_mfma<NT> fwd"),
                     "achieved": tf, "peak": gemm_peak, "unit": "TFLOP/s", "frac": tf / gemm_peak,
                     "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
@@ -1319,7 +1360,10 @@ def main():
                             "hidden layer, 8 steps of the same loop right after the timed region (layer kinds "
                             f"{kinds_hl}: 3 = input layer on [x | cached mean aggregate], K = 2 F0, LayerNorm + ReLU in the GEMM's epilogue)")
                            if fwd_ev is not None else "HIP-event timers around the tagged launches of the call-by-call schedule",
-                    "layer_ms": None if fwd_ev is None else [fwd_ev[3][0] / 8, fwd_ev[3][1] / 8],
+                    "layer_ms": None if fwd_ev is None else [fwd_ev[3][0] / max(fwd_ev[0], 1), fwd_ev[3][1] / max(fwd_ev[0], 1)],
+                    "layer1": None if fwd_ev is None else {"avg_launch_ms": fwd_ev[3][1] / max(fwd_ev[0], 1),
+                                                           "algorithmic_flops_per_launch": fwd_ev[4][1] / max(fwd_ev[0], 1),
+                                                           "frac": fwd_ev[4][1] / max(fwd_ev[3][1], 1e-9) / 1e9 / gemm_peak},
                     "layer_tflops": None if fwd_ev is None else [fwd_ev[4][i] / max(fwd_ev[3][i], 1e-9) / 1e9 for i in range(2)],
                     "traffic": pmc_traffic()[0].get(("gemm_nt_p3_bytes_per_launch" if trainer._planes_on() else "gemm_nt_split_bytes_per_launch")
                                                     if split_mode else "gemm_nt_bytes_per_launch")
@@ -1347,7 +1391,8 @@ def main():
                        "layers": args.layers, "in_feats": args.in_feats, "hidden": args.hidden,
                        "pages_per_gpu_per_step": args.pages, "global_pages_per_step": args.pages * world,
                        "resident_pages_per_gpu": args.resident_pages, "nodes_per_step_per_gpu": mean_nodes,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       "input_aggregate_cached": bool(kinds_hl is not None and kinds_hl[0] == 3)},
             "final_loss": final_loss, "roofline": roofline, "kernels": per_kernel, "host_page_generation_s": gen_s,
         }
         if long_run is not None:
@@ -1399,6 +1444,8 @@ def main():
             if pages13 is not None:
                 sets[13] = pages13[:300]
             line["shapes"] = shapes_probe(args, gte, dev, sets, loop)
+        if extras and not args.no_uncached and split_mode and line["config"]["input_aggregate_cached"]:
+            line["uncached"] = uncached_probe(args, gte, dev, pages, loop)
         if extras and not args.no_residency and split_mode:
             line["residency"] = residency_probe(args, gte, dev, pages + (pages_res or []), loop)
             pages_res = None

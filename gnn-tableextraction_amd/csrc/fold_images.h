@@ -8,9 +8,9 @@
 namespace gte {
 // The thread that updates a parameter element writes its three bf16
 // pieces into every image that holds it.  off = element offset of the sub-matrix in the flat parameter buffer; its rows x cols
-// elements sit at row stride ld; image(r, c) = transpose ? sub(c, r) : sub(r, c).
+// elements sit at row stride ld; image(r, c) = transpose ? sub(c, r) : sub(r, c); block fb of image row r at r * ldp + fb * bsp.
 constexpr int kMaxFoldImages = 12;
-struct FoldImage { long long off; unsigned span, ld, magic; int cols, transpose, pad; char* dst; long long ldp; };
+struct FoldImage { long long off; unsigned span, ld, magic; int cols, transpose, pad; char* dst; long long ldp, bsp; };
 struct FoldImages { FoldImage im[kMaxFoldImages]; int n; };
 
 // (row, column) of element o of a sub-matrix with row stride ld: magic = floor(2^32 / ld) + 1 is exact for o < 2^32 / ld
@@ -30,7 +30,7 @@ __device__ __forceinline__ void fold_write_image1(const FoldImage& im, long long
     const int ir = im.transpose ? c : r, ic = im.transpose ? r : c;
     unsigned h, m, l;
     p3::split2(v, 0.f, h, m, l);
-    unsigned short* q = reinterpret_cast<unsigned short*>(im.dst + (long long)ir * im.ldp + (ic >> 4) * p3::BLOCK_BYTES + (ic & 15) * 2);
+    unsigned short* q = reinterpret_cast<unsigned short*>(im.dst + (long long)ir * im.ldp + (long long)(ic >> 4) * im.bsp + (ic & 15) * 2);
     q[0] = (unsigned short)h;
     q[p3::PLANE_BYTES / 2] = (unsigned short)m;
     q[p3::PLANE_BYTES] = (unsigned short)l;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void fold_write_images2(const FoldImages& fi, unsigne
             if ((c & 1) == 0 && c + 1 < im.cols) {
                 unsigned h, m, l;
                 p3::split2(v0, v1, h, m, l);
-                unsigned* q = reinterpret_cast<unsigned*>(im.dst + (long long)r * im.ldp + (c >> 4) * p3::BLOCK_BYTES + (c & 15) * 2);
+                unsigned* q = reinterpret_cast<unsigned*>(im.dst + (long long)r * im.ldp + (long long)(c >> 4) * im.bsp + (c & 15) * 2);
                 q[0] = h;
                 q[p3::PLANE_BYTES / 4] = m;
                 q[p3::PLANE_BYTES / 2] = l;
@@ -75,7 +75,9 @@ inline int make_fold_images(const float* param, int64_t n, const gte_p3_desc* im
     for (int k = 0; images_ok && k < n_images; ++k) {
         const gte_p3_desc& d = images[k];
         const int64_t srows = d.transpose ? d.cols : d.rows, scols = d.transpose ? d.rows : d.cols;
-        if (!d.src || !d.dst || d.rows <= 0 || d.cols <= 0 || d.ld < scols || d.ld > INT32_MAX || d.ldp < p3::row_bytes(d.cols) ||
+        // (a negative ldp: a block-major image, block stride -ldp, rows at 96 bytes -- include/gte.h)
+        const bool ldp_ok = d.ldp < 0 ? (-d.ldp >= d.rows * 96 && (-d.ldp) % 16 == 0) : d.ldp >= p3::row_bytes(d.cols);
+        if (!d.src || !d.dst || d.rows <= 0 || d.cols <= 0 || d.ld < scols || d.ld > INT32_MAX || !ldp_ok ||
             d.src < param || (d.src - param) + (srows - 1) * d.ld + scols > n)
             return gte::fail(GTE_ERR_INVALID_ARGUMENT, "%s: image %d does not describe a sub-matrix of the parameters", who, k);
         FoldImage& im = fi.im[k];
@@ -83,7 +85,8 @@ inline int make_fold_images(const float* param, int64_t n, const gte_p3_desc* im
         // (the multiply-high row split would not be exact; ld == 1: the magic constant 2^32 + 1 does not fit 32 bits)
         if (d.ld < 2 || span >= ((int64_t)1 << 32) / d.ld) { images_ok = false; break; }
         im.off = d.src - param; im.span = (unsigned)span; im.ld = (unsigned)d.ld; im.magic = (unsigned)((((uint64_t)1 << 32) / d.ld) + 1);
-        im.cols = (int)scols; im.transpose = d.transpose ? 1 : 0; im.pad = 0; im.dst = reinterpret_cast<char*>(d.dst); im.ldp = d.ldp;
+        im.cols = (int)scols; im.transpose = d.transpose ? 1 : 0; im.pad = 0; im.dst = reinterpret_cast<char*>(d.dst);
+        im.ldp = d.ldp < 0 ? 96 : d.ldp; im.bsp = d.ldp < 0 ? -d.ldp : p3::BLOCK_BYTES;
     }
     if (images_ok) fi.n = n_images;
     return GTE_OK;

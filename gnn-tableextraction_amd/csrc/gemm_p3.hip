@@ -141,6 +141,18 @@ __device__ __forceinline__ void products(f32x16 (&acc)[TM][TN], const Frags<TM, 
 #endif
 }
 
+// (measurement builds: the fragments count as used)
+template <int TM, int TN>
+__device__ __forceinline__ void keep_frags(const Frags<TM, TN>& f) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) asm volatile("" ::"v"(f.a[pl][a]));
+#pragma unroll
+        for (int b = 0; b < TN; ++b) asm volatile("" ::"v"(f.b[pl][b]));
+    }
+}
+
 // Store epilogue of a wave's TM x TN accumulator tiles through a buffer descriptor over the output: rows past M and columns
 // past `cols_valid` get an offset outside the window and are dropped by the range check (branch-free; sage_linear.hip).
 // The stored value goes through a VGPR on purpose: with an accumulator element as the store's data operand hipcc 7.2 emitted
@@ -198,8 +210,9 @@ __device__ __forceinline__ void wait_dma_barrier() {
 #define GTE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 constexpr int SG_MFMA = 0x008, SG_VMEM_R = 0x020, SG_DS_R = 0x100;      // (sched_group_barrier masks: 0x002 VALU, 0x004 SALU, 0x200 DS write)
 #ifndef P3_ABL
-#define P3_ABL 0          // measurement builds only (profiles/micro/gemm_p3_abl.hip): 1 no DMA, 2 no barrier, 4 fragments read once,
-#endif                    // 8 no MFMA, 16 clock stamps into p.slab; results are wrong by construction when a bit is set
+#define P3_ABL 0          // measurement builds only (profiles/micro/gemm_p3_abl.hip, l0_fwd_abl.hip): 1 no DMA, 2 no barrier, 4 fragments
+#endif                    // read once, 8 no MFMA, 16 clock stamps into p.slab, 32 no epilogue, 64 / 128 the A / B requests move nothing
+                          // (loader-wave kernel); results are wrong by construction when a bit is set
 
 // WM x WN waves (4 or 8), every wave TM x TN accumulator tiles of 32 x 32; block tile BM x BN = (32 TM WM) x (32 TN WN).
 // The stage images live in a ring of NBUF LDS buffers and the LDS-DMA of stage t + NBUF - 1 is requested at the start of
@@ -476,10 +489,7 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
         read_frags(f, lds + rd * STAGE);
 #endif
 #if P3_ABL & 8
-        static_for<3>([&](auto P) {
-            static_for<TM>([&](auto A) { asm volatile("" ::"v"(f.a[decltype(P)::value][decltype(A)::value])); });
-            static_for<TN>([&](auto B) { asm volatile("" ::"v"(f.b[decltype(P)::value][decltype(B)::value])); });
-        });
+        keep_frags<TM, TN>(f);
 #else
         products<TM, TN>(acc, f);
 #endif
@@ -523,6 +533,241 @@ gemm_p3_nt_ring_kernel(const P3Gemm p) {
 
 // (A variant of the ring kernel on v_mfma_f32_16x16x32_bf16 -- two plane products per instruction -- was measured in round 3 and
 // removed in round 4: same matrix-pipe time, no clock advantage at these tile shapes; profiles/r03/gemm_p3.md section 5.)
+
+// ---- epilogues of a loader-wave tile (compute waves only; the loader waves have left, or wait at the epilogue's first barrier) ----
+// LNB: 0 plain store; 1 / 3 LayerNorm(+ReLU) backward of the tile's rows (3: a width that is not a multiple of 16); 4 LayerNorm(+ReLU)
+// forward.  The LayerNorm forms need whole rows per workgroup (BN = 256) and re-use the stage images as the tile's row slice.
+template <int WM, int WN, int TM, int TN, int LNB>
+__device__ __forceinline__ void lw_epilogue(const f32x16 (&acc)[TM][TN], char* lds, const P3Gemm& p, int m0, int n0, unsigned lb, int wave,
+                                            int lane, int tid) {
+    constexpr int NW = WM * WN, BN = WN * TN * 32;
+    const int wm = wave / WN, wn = wave % WN;
+    if constexpr (LNB == 0) {
+        store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
+                           p.accumulate, lane);
+    } else if constexpr (LNB == 4) {
+        // ---- LayerNorm(+ReLU) FORWARD of the tile's rows: z = product + bias goes to LDS row-major per slice of TM * 32 rows, then
+        // every wave takes rows of the slice in the layout and with the arithmetic of ln_relu_fwd_gen_kernel<1, .> (lane l = columns
+        // 4 l .. 4 l + 3, two-pass statistics over the n true columns): z, stats, y and the image are bit for bit what
+        // gte_gemm_p3_nt + gte_ln_relu_fwd_p3 write ----
+        asm volatile("s_barrier" ::: "memory");
+        static_assert(BN == 256, "whole rows per workgroup");
+        constexpr int SR = TM * 32, LDT = 256;
+        float* tile = reinterpret_cast<float*>(lds);
+        const int n = p.N, M = p.M;
+        const int j4 = 4 * lane;
+        const int n16 = (n + 15) & ~15;
+        const bool okc = j4 < n;
+        float gam[4], bet[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gam[e] = j4 + e < n ? p.ln_gamma[j4 + e] : 0.f; bet[e] = j4 + e < n ? p.ln_beta[j4 + e] : 0.f; }
+        const float inv_n = 1.0f / (float)n;
+        const int col_l = lane & 31, hrow = (lane >> 5) * 4;
+        float bv[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = wn * (TN * 32) + b * 32 + col_l;
+            bv[b] = (p.bias && col < n) ? p.bias[col] : 0.f;
+        }
+        for (int sl = 0; sl < WM; ++sl) {
+            asm volatile("s_barrier" ::: "memory");                    // the previous slice's readers are done
+            if (wm == sl) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            tile[(a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * LDT + wn * (TN * 32) + b * 32 + col_l] = acc[a][b][r] + bv[b];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int row_base = m0 + sl * SR;
+            // Two rows per round.  The stores are what this phase waits for (every workgroup of the launch is here at once: ~7 bytes
+            // per cycle and CU, issue-bound), so they are made wide: lanes 2 i / 2 i + 1 swap halves and store EIGHT consecutive image
+            // columns of ONE row each (16 bytes per plane instead of 8), and the row statistics collect in lanes (lane k = the
+            // wave's k-th row) and leave in two stores per wave instead of two per row.  Values and bytes unchanged.
+            float st_mean = 0.f, st_rstd = 0.f;
+            int kk = 0;
+            for (int rl = wave; rl < SR; rl += 2 * NW, kk += 2) {
+                if (row_base + rl >= M) break;                          // wave-uniform
+                float o[2][4];
+                bool rv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int rlu = rl + u * NW;
+                    const long long rg = row_base + rlu;
+                    rv[u] = rlu < SR && rg < M;                         // wave-uniform
+                    float c[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (okc && rv[u]) {
+                        const float4 t = *reinterpret_cast<const float4*>(tile + rlu * LDT + j4);
+                        c[0] = t.x; c[1] = j4 + 1 < n ? t.y : 0.f; c[2] = j4 + 2 < n ? t.z : 0.f; c[3] = j4 + 3 < n ? t.w : 0.f;
+                    }
+                    float s = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s += c[e];
+                    const float wsum = gte_group_sum<64>(s);           // (z - mean as one fused multiply-add of the row sum, as
+                    const float mean = wsum * inv_n;                   // ln_relu_fwd_gen_kernel writes it)
+                    float q = 0.f, dv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { dv[e] = j4 + e < n ? fmaf(-inv_n, wsum, c[e]) : 0.f; q = fmaf(dv[e], dv[e], q); }
+                    const float rstd = rsqrtf(gte_group_sum<64>(q) * inv_n + p.lnf_eps);
+                    if (lane == kk + u) { st_mean = mean; st_rstd = rstd; }
+                    if (okc && rv[u]) {                                 // z: the operand of the layer's LayerNorm backward
+                        f4u t; t.x = c[0]; t.y = c[1]; t.z = c[2]; t.w = c[3];
+                        *reinterpret_cast<f4u*>(p.C + rg * p.ldc + j4) = t;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[u][e] = fmaf(fmaf(-inv_n, wsum, c[e]) * rstd, gam[e], bet[e]);
+                        if (p.ln_relu) o[u][e] = fmaxf(o[u][e], 0.f);
+                        if (j4 + e >= n) o[u][e] = 0.f;
+                    }
+                    if (p.lnf_y && okc && rv[u]) {
+                        f4u t; t.x = o[u][0]; t.y = o[u][1]; t.z = o[u][2]; t.w = o[u][3];
+                        *reinterpret_cast<f4u*>(p.lnf_y + rg * p.lnf_ldy + j4) = t;
+                    }
+                }
+                if (p.lnf_yp3) {
+                    // even lane: row 0, columns 8 i .. 8 i + 7 = its own four and its neighbour's; odd lane: row 1 likewise
+                    const bool odd = lane & 1;
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float got = gte_quad_swap1(odd ? o[0][e] : o[1][e]);
+                        x[e] = odd ? got : o[0][e];
+                        x[4 + e] = odd ? o[1][e] : got;
+                    }
+                    const int col0 = 4 * (lane & ~1);
+                    if (col0 < n16 && rv[odd ? 1 : 0])
+                        p3::store8(p.lnf_yp3 + (long long)(row_base + rl + (odd ? NW : 0)) * p.lnf_ldp, col0, x);
+                }
+            }
+            if (p.lnf_stats) {
+                const int rlk = wave + lane * NW;
+                const long long rg = row_base + rlk;
+                if (lane < kk && rlk < SR && rg < M) { p.lnf_stats[rg] = st_mean; p.lnf_stats[M + rg] = st_rstd; }
+            }
+        }
+    } else {
+        // ---- LayerNorm(+ReLU) backward of the tile's rows (the stage images are dead once the loader waves' last requests have
+        // landed: they wait for them and join this barrier before they leave) ----
+        asm volatile("s_barrier" ::: "memory");
+        // Per slice of TM * 32 rows: the waves that own them put their accumulators into LDS row-major, then every wave takes
+        // rows of the slice in the layout of ln_relu_bwd_vec_kernel (lane l = columns 4 l .. 4 l + 3, two rows in flight) with
+        // ITS arithmetic: dz is bit for bit what the separate launch computes from the stored product.
+        static_assert(BN == 256, "whole rows per workgroup");
+        constexpr int SR = TM * 32, LDT = 256;                        // slice rows; floats per LDS row
+        float* tile = reinterpret_cast<float*>(lds);
+        constexpr bool MSK = LNB == 3;
+        const int n = p.N, M = p.M;
+        const int j4 = 4 * lane;
+        // MSK: n is any width; the lane takes part while it has a valid column (the rows of z / dz are padded to a multiple of 4
+        // floats), and writes image columns up to the next multiple of 16
+        const bool okc = MSK ? j4 < ((n + 3) & ~3) : j4 < n;
+        bool oke[4];
+        float gam[4], bet[4], s_dg[4], s_db[4], s_dbias[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            oke[e] = MSK ? j4 + e < n : okc;
+            gam[e] = oke[e] ? p.ln_gamma[j4 + e] : 1.f;
+            bet[e] = oke[e] ? p.ln_beta[j4 + e] : 0.f;
+            s_dg[e] = s_db[e] = s_dbias[e] = 0.f;
+        }
+        const float inv_n = 1.0f / (float)n;
+        const int col_l = lane & 31, hrow = (lane >> 5) * 4;
+        for (int sl = 0; sl < WM; ++sl) {
+            asm volatile("s_barrier" ::: "memory");                    // the previous slice's readers are done
+            if (wm == sl) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            tile[(a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * LDT + wn * (TN * 32) + b * 32 + col_l] = acc[a][b][r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int row_base = m0 + sl * SR;
+            constexpr int RF = 4;                                       // rows in flight per wave (one workgroup per CU: the
+                                                                        // memory-level parallelism of this phase is all there is)
+            for (int rl = wave; rl < SR; rl += RF * NW) {
+                float gy[RF][4], zz[RF][4], mean[RF], rstd[RF];
+                bool rok[RF];
+#pragma unroll
+                for (int u = 0; u < RF; ++u) {
+                    const int rloc = rl + u * NW, rg = row_base + rloc;
+                    rok[u] = rloc < SR && rg < M;
+                    const int rc = rok[u] ? rg : min(row_base, M - 1);
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bz = a;
+                    if (okc) {
+                        if (rok[u]) a = *reinterpret_cast<const float4*>(tile + rloc * LDT + j4);
+                        const f4u zt = *reinterpret_cast<const f4u*>(p.ln_z + (long long)rc * p.ln_ldz + j4);
+                        bz = make_float4(zt.x, zt.y, zt.z, zt.w);
+                    }
+                    gy[u][0] = a.x; gy[u][1] = a.y; gy[u][2] = a.z; gy[u][3] = a.w;
+                    zz[u][0] = bz.x; zz[u][1] = bz.y; zz[u][2] = bz.z; zz[u][3] = bz.w;
+                    mean[u] = p.ln_stats[rc]; rstd[u] = p.ln_stats[M + rc];
+                }
+                float dd[RF][4];
+#pragma unroll
+                for (int u = 0; u < RF; ++u) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dd[u][e] = 0.f;
+                    if (!rok[u]) continue;                              // wave-uniform
+                    const long long rg = row_base + rl + u * NW;
+                    float xh[4], g[4];
+                    float a = 0.f, b = 0.f;
+                    if constexpr (MSK) gte_ln_bwd_pre4m(gy[u], zz[u], mean[u], rstd[u], gam, bet, oke, p.ln_relu, xh, g, a, b);
+                    else gte_ln_bwd_pre4(gy[u], zz[u], mean[u], rstd[u], gam, bet, okc, p.ln_relu, xh, g, a, b);
+                    const float c1 = gte_group_sum<64>(a) * inv_n, c2 = gte_group_sum<64>(b) * inv_n;
+                    if constexpr (MSK) gte_ln_bwd_post4m(g, xh, gam, rstd[u], c1, c2, oke, dd[u], s_dg, s_db, s_dbias);
+                    else gte_ln_bwd_post4(g, xh, gam, rstd[u], c1, c2, okc, dd[u], s_dg, s_db, s_dbias);
+                    if (okc && p.ln_dz) {                               // (nullable: a consumer that reads the image only)
+                        f4u o; o.x = dd[u][0]; o.y = dd[u][1]; o.z = dd[u][2]; o.w = dd[u][3];
+                        *reinterpret_cast<f4u*>(p.ln_dz + rg * p.ln_lddz + j4) = o;
+                    }
+                }
+                // the image rows leave two at a time: lanes 2 i / 2 i + 1 swap halves and store EIGHT consecutive columns of one row
+                // each (16 bytes per plane; the forward epilogue above has the why)
+                if (p.ln_dzp3) {
+                    const bool odd = lane & 1;
+                    const int col0 = 4 * (lane & ~1);
+                    const bool im8 = MSK ? col0 < ((n + 15) & ~15) : col0 < n;
+#pragma unroll
+                    for (int u = 0; u < RF; u += 2) {
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float got = gte_quad_swap1(odd ? dd[u][e] : dd[u + 1][e]);
+                            x[e] = odd ? got : dd[u][e];
+                            x[4 + e] = odd ? dd[u + 1][e] : got;
+                        }
+                        if (im8 && rok[odd ? u + 1 : u])
+                            p3::store8(p.ln_dzp3 + (long long)(row_base + rl + (odd ? u + 1 : u) * NW) * p.ln_ldp3, col0, x);
+                    }
+                }
+            }
+        }
+        // column partials of the workgroup: the eight waves through LDS, added in wave order
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float* red = reinterpret_cast<float*>(lds);                    // [NW][3][256]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(wave * 3 + 0) * 256 + j4 + e] = s_dg[e];
+            red[(wave * 3 + 1) * 256 + j4 + e] = s_db[e];
+            red[(wave * 3 + 2) * 256 + j4 + e] = s_dbias[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float* pp = p.ln_part + (long long)lb * 3 * n;
+        for (int i = tid; i < 3 * 256; i += NW * 64) {
+            const int q = i >> 8, j = i & 255;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[(w * 3 + q) * 256 + j];
+            if (j < n) pp[q * n + j] = v;
+        }
+    }
+}
 
 // NT with LOADER WAVES: WM x WN compute waves (fragment reads + MFMAs only) and NL loader waves that issue every LDS-DMA
 // instruction of the workgroup.  In the ring kernel above each wave spends ~NI x 60-100 issue cycles per stage on its DMA
@@ -619,7 +864,12 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)t * bsb), 0, rowsB * ldb * live, SRD_FLAGS);
             static_for<NI>([&](auto I) {
                 constexpr int i = decltype(I)::value;
+#if P3_ABL & (64 | 128)                                      // (measurement: one operand's requests move nothing -- still counted)
+                const int vo = ((P3_ABL & 64) && !isb[i]) || ((P3_ABL & 128) && isb[i]) ? OOB : (seg ? vo2[i] : vo1[i]);
+                dma16(isb[i] ? sb : sa, buf + (i * NL + lw) * 1024, vo);
+#else
                 dma16(isb[i] ? sb : sa, buf + (i * NL + lw) * 1024, seg ? vo2[i] : vo1[i]);
+#endif
             });
         };
         issue(0, lds);
@@ -627,7 +877,9 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
         wait_dma_barrier<NI>();
         int wr = 2;
         for (int t = 0; t < T; ++t) {
+#if !(P3_ABL & 1)
             issue(t + 2, lds + wr * STAGE);
+#endif
             wr = wr + 1 == NBUF ? 0 : wr + 1;
             wait_dma_barrier<NI>();
         }
@@ -665,191 +917,222 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     asm volatile("s_barrier" ::: "memory");
     int rd = 0;
+#if P3_ABL & 16
+    const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if P3_ABL & 4
+    F f;
+    read_frags(f, lds);
+#endif
     for (int t = 0; t < T; ++t) {
+#if !(P3_ABL & 4)
         F f;
         read_frags(f, lds + rd * STAGE);
+#endif
+#if P3_ABL & 8
+        keep_frags<TM, TN>(f);
+#else
         products<TM, TN>(acc, f);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         rd = rd + 1 == NBUF ? 0 : rd + 1;
     }
-    if constexpr (LNB == 0) {
-        store_tile<TM, TN>(acc, p.C, p.ldc, p.M, p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, p.N, p.bias, p.bias_cols, p.relu,
-                           p.accumulate, lane);
-    } else if constexpr (LNB == 4) {
-        // ---- LayerNorm(+ReLU) FORWARD of the tile's rows: z = product + bias goes to LDS row-major per slice of TM * 32 rows, then
-        // every wave takes rows of the slice in the layout and with the arithmetic of ln_relu_fwd_gen_kernel<1, .> (lane l = columns
-        // 4 l .. 4 l + 3, two-pass statistics over the n true columns): z, stats, y and the image are bit for bit what
-        // gte_gemm_p3_nt + gte_ln_relu_fwd_p3 write ----
-        asm volatile("s_barrier" ::: "memory");
-        static_assert(BN == 256, "whole rows per workgroup");
-        constexpr int SR = TM * 32, LDT = 256;
-        float* tile = reinterpret_cast<float*>(lds);
-        const int n = p.N, M = p.M;
-        const int j4 = 4 * lane;
-        const int n16 = (n + 15) & ~15;
-        const bool okc = j4 < n, imc = j4 < n16;
-        float gam[4], bet[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { gam[e] = j4 + e < n ? p.ln_gamma[j4 + e] : 0.f; bet[e] = j4 + e < n ? p.ln_beta[j4 + e] : 0.f; }
-        const float inv_n = 1.0f / (float)n;
-        const int col_l = lane & 31, hrow = (lane >> 5) * 4;
-        float bv[TN];
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int col = wn * (TN * 32) + b * 32 + col_l;
-            bv[b] = (p.bias && col < n) ? p.bias[col] : 0.f;
-        }
-        for (int sl = 0; sl < WM; ++sl) {
-            asm volatile("s_barrier" ::: "memory");                    // the previous slice's readers are done
-            if (wm == sl) {
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            tile[(a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * LDT + wn * (TN * 32) + b * 32 + col_l] = acc[a][b][r] + bv[b];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int row_base = m0 + sl * SR;
-            for (int rl = wave; rl < SR; rl += NW) {
-                const long long rg = row_base + rl;
-                if (rg >= M) break;                                     // wave-uniform
-                float c[4] = {0.f, 0.f, 0.f, 0.f};
-                if (okc) {
-                    const float4 t = *reinterpret_cast<const float4*>(tile + rl * LDT + j4);
-                    c[0] = t.x; c[1] = j4 + 1 < n ? t.y : 0.f; c[2] = j4 + 2 < n ? t.z : 0.f; c[3] = j4 + 3 < n ? t.w : 0.f;
-                }
-                float s = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s += c[e];
-                const float wsum = gte_group_sum<64>(s);               // (z - mean as one fused multiply-add of the row sum, as
-                const float mean = wsum * inv_n;                       // ln_relu_fwd_gen_kernel writes it)
-                float q = 0.f, dv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { dv[e] = j4 + e < n ? fmaf(-inv_n, wsum, c[e]) : 0.f; q = fmaf(dv[e], dv[e], q); }
-                const float rstd = rsqrtf(gte_group_sum<64>(q) * inv_n + p.lnf_eps);
-                if (p.lnf_stats && lane == 0) { p.lnf_stats[rg] = mean; p.lnf_stats[M + rg] = rstd; }
-                if (okc) {                                              // z: the operand of the layer's LayerNorm backward
-                    f4u o; o.x = c[0]; o.y = c[1]; o.z = c[2]; o.w = c[3];
-                    *reinterpret_cast<f4u*>(p.C + rg * p.ldc + j4) = o;
-                }
-                if (imc) {
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o[e] = fmaf(fmaf(-inv_n, wsum, c[e]) * rstd, gam[e], bet[e]);
-                        if (p.ln_relu) o[e] = fmaxf(o[e], 0.f);
-                        if (j4 + e >= n) o[e] = 0.f;
-                    }
-                    if (p.lnf_y && okc) {
-                        f4u t; t.x = o[0]; t.y = o[1]; t.z = o[2]; t.w = o[3];
-                        *reinterpret_cast<f4u*>(p.lnf_y + rg * p.lnf_ldy + j4) = t;
-                    }
-                    if (p.lnf_yp3) p3::store4(p.lnf_yp3 + rg * p.lnf_ldp, j4, o[0], o[1], o[2], o[3]);
-                }
-            }
-        }
-    } else {
-        // ---- LayerNorm(+ReLU) backward of the tile's rows (the stage images are dead once the loader waves' last requests have
-        // landed: they wait for them and join this barrier before they leave) ----
-        asm volatile("s_barrier" ::: "memory");
-        // Per slice of TM * 32 rows: the waves that own them put their accumulators into LDS row-major, then every wave takes
-        // rows of the slice in the layout of ln_relu_bwd_vec_kernel (lane l = columns 4 l .. 4 l + 3, two rows in flight) with
-        // ITS arithmetic: dz is bit for bit what the separate launch computes from the stored product.
-        static_assert(BN == 256, "whole rows per workgroup");
-        constexpr int SR = TM * 32, LDT = 256;                        // slice rows; floats per LDS row
-        float* tile = reinterpret_cast<float*>(lds);
-        constexpr bool MSK = LNB == 3;
-        const int n = p.N, M = p.M;
-        const int j4 = 4 * lane;
-        // MSK: n is any width; the lane takes part while it has a valid column (the rows of z / dz are padded to a multiple of 4
-        // floats), and writes image columns up to the next multiple of 16
-        const bool okc = MSK ? j4 < ((n + 3) & ~3) : j4 < n;
-        const bool imc = MSK ? j4 < ((n + 15) & ~15) : okc;
-        bool oke[4];
-        float gam[4], bet[4], s_dg[4], s_db[4], s_dbias[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            oke[e] = MSK ? j4 + e < n : okc;
-            gam[e] = oke[e] ? p.ln_gamma[j4 + e] : 1.f;
-            bet[e] = oke[e] ? p.ln_beta[j4 + e] : 0.f;
-            s_dg[e] = s_db[e] = s_dbias[e] = 0.f;
-        }
-        const float inv_n = 1.0f / (float)n;
-        const int col_l = lane & 31, hrow = (lane >> 5) * 4;
-        for (int sl = 0; sl < WM; ++sl) {
-            asm volatile("s_barrier" ::: "memory");                    // the previous slice's readers are done
-            if (wm == sl) {
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            tile[(a * 32 + hrow + (r & 3) + 8 * (r >> 2)) * LDT + wn * (TN * 32) + b * 32 + col_l] = acc[a][b][r];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int row_base = m0 + sl * SR;
-            constexpr int RF = 4;                                       // rows in flight per wave (one workgroup per CU: the
-                                                                        // memory-level parallelism of this phase is all there is)
-            for (int rl = wave; rl < SR; rl += RF * NW) {
-                float gy[RF][4], zz[RF][4], mean[RF], rstd[RF];
-                bool rok[RF];
-#pragma unroll
-                for (int u = 0; u < RF; ++u) {
-                    const int rloc = rl + u * NW, rg = row_base + rloc;
-                    rok[u] = rloc < SR && rg < M;
-                    const int rc = rok[u] ? rg : min(row_base, M - 1);
-                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bz = a;
-                    if (okc) {
-                        if (rok[u]) a = *reinterpret_cast<const float4*>(tile + rloc * LDT + j4);
-                        const f4u zt = *reinterpret_cast<const f4u*>(p.ln_z + (long long)rc * p.ln_ldz + j4);
-                        bz = make_float4(zt.x, zt.y, zt.z, zt.w);
-                    }
-                    gy[u][0] = a.x; gy[u][1] = a.y; gy[u][2] = a.z; gy[u][3] = a.w;
-                    zz[u][0] = bz.x; zz[u][1] = bz.y; zz[u][2] = bz.z; zz[u][3] = bz.w;
-                    mean[u] = p.ln_stats[rc]; rstd[u] = p.ln_stats[M + rc];
-                }
-#pragma unroll
-                for (int u = 0; u < RF; ++u) {
-                    if (!rok[u]) continue;                              // wave-uniform
-                    const long long rg = row_base + rl + u * NW;
-                    float xh[4], g[4];
-                    float a = 0.f, b = 0.f;
-                    if constexpr (MSK) gte_ln_bwd_pre4m(gy[u], zz[u], mean[u], rstd[u], gam, bet, oke, p.ln_relu, xh, g, a, b);
-                    else gte_ln_bwd_pre4(gy[u], zz[u], mean[u], rstd[u], gam, bet, okc, p.ln_relu, xh, g, a, b);
-                    const float c1 = gte_group_sum<64>(a) * inv_n, c2 = gte_group_sum<64>(b) * inv_n;
-                    float d[4];
-                    if constexpr (MSK) gte_ln_bwd_post4m(g, xh, gam, rstd[u], c1, c2, oke, d, s_dg, s_db, s_dbias);
-                    else gte_ln_bwd_post4(g, xh, gam, rstd[u], c1, c2, okc, d, s_dg, s_db, s_dbias);
-                    if (okc && p.ln_dz) {                               // (nullable: a consumer that reads the image only)
-                        f4u o; o.x = d[0]; o.y = d[1]; o.z = d[2]; o.w = d[3];
-                        *reinterpret_cast<f4u*>(p.ln_dz + rg * p.ln_lddz + j4) = o;
-                    }
-                    if (imc && p.ln_dzp3) p3::store4(p.ln_dzp3 + rg * p.ln_ldp3, j4, d[0], d[1], d[2], d[3]);
-                }
-            }
-        }
-        // column partials of the workgroup: the eight waves through LDS, added in wave order
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        float* red = reinterpret_cast<float*>(lds);                    // [NW][3][256]
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            red[(wave * 3 + 0) * 256 + j4 + e] = s_dg[e];
-            red[(wave * 3 + 1) * 256 + j4 + e] = s_db[e];
-            red[(wave * 3 + 2) * 256 + j4 + e] = s_dbias[e];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        float* pp = p.ln_part + (long long)lb * 3 * n;
-        for (int i = tid; i < 3 * 256; i += NW * 64) {
-            const int q = i >> 8, j = i & 255;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) v += red[(w * 3 + q) * 256 + j];
-            if (j < n) pp[q * n + j] = v;
-        }
+#if P3_ABL & 16
+    if (tid == 0 && p.slab) {
+        long long* st = reinterpret_cast<long long*>(p.slab) + 2 * blockIdx.x;
+        st[0] = __builtin_amdgcn_s_memtime() - c0;
+        st[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
+#endif
+#if P3_ABL & 32
+    if (p.K != 12345) return;                                  // (measurement: no epilogue)
+#endif
+    lw_epilogue<WM, WN, TM, TN, LNB>(acc, lds, p, m0, n0, lb, wave, lane, tid);
+}
+
+// NT, one column of 256-wide tiles, weights BLOCK-MAJOR (p.ldb == 96: block t of the image is one contiguous [rows][96 bytes]
+// run at t * p.bsb): 1 x 8 compute waves of (32 TM) x 32 + NL loader waves.
+//   * B never touches LDS: a wave's 32 weight rows of a K block are 3 KB contiguous; lane (r, h) loads its MFMA operand (row r,
+//     k = 8 h .. 8 h + 7 of each plane) with three 16-byte buffer loads straight into registers, three K blocks ahead (a ring of four
+//     fragment sets).  In the loader-wave kernel above the weights are 2/3 of what a stage moves into LDS and every byte of them
+//     is read from LDS exactly once.
+//   * A moves through LDS in SLOTS of SQ = 4 K blocks (64 k): [block][row][96 bytes], the stage image of the kernel above four
+//     times.  The four 96-byte requests of a row group (1 KB of a block's image) are issued back to back by one loader wave: they
+//     touch the same three 128-byte lines of every row, and the vector L1 merges them (profiles/r06/l0_fwd_ablation.txt: 96-byte
+//     runs requested a K block at a time fetch every line twice -- 50 GB/s per CU against 82 for whole lines).
+//   * ONE barrier per slot (64 k) instead of one per 16 k: inside a slot the two compute waves of a SIMD drift apart and one's
+//     fragment reads hide under the other's MFMAs.
+// K segments are cut into slots separately (a slot never straddles [a1 | a2]); the last slot of a segment may hold fewer than SQ
+// blocks: the missing ones are multiplied as zeros (the launcher takes this kernel when that wastes little).
+// Bit-identical to the kernels above: the same six products per fragment pair in the same order, K blocks in the same order.
+template <int TM, int NL, int LNB = 0, int SQ = 4>
+__global__ void __launch_bounds__((8 + NL) * 64, (8 + NL + 3) / 4)
+gemm_p3_nt_sq_kernel(const P3Gemm p) {
+    constexpr int WM = 1, WN = 8, TN = 1, NW = 8, NSLOT = 3;
+    constexpr int BM = TM * 32, BN = 256;
+    constexpr int G = BM * 96 / 1024;                                      // row groups: 1 KB of a block's image each
+    constexpr int NG = (G + NL - 1) / NL;                                  // ... per loader wave
+    constexpr int NIQ = NG * SQ;                                           // requests per loader wave and slot
+    constexpr int BLK = BM * 96, SLOT = SQ * BLK;
+    static_assert(SQ == 4 && BLK % 1024 == 0 && NIQ <= 24, "slot");
+    extern __shared__ __attribute__((aligned(16))) char lds[];             // NSLOT slots + 1 KB (where padding requests write their zeros)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const unsigned lb = gte_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = (int)(lb / (unsigned)tiles_n), tn = (int)(lb % (unsigned)tiles_n);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int KB1 = p.KB1, KB2 = p.KB2, T = KB1 + KB2;
+    const int S1 = (KB1 + SQ - 1) / SQ, S = S1 + (KB2 + SQ - 1) / SQ;
+
+    if (wave >= NW) {
+        // ---------------- loader ----------------
+        const int lw = wave - NW;
+        const int rowsA = min(BM, p.M - m0);
+        const int lda1 = (int)p.lda1, lda2 = (int)(p.A2 ? p.lda2 : p.lda1);
+        const char* baseA1 = p.rowsA ? p.A1 : p.A1 + (long long)m0 * p.lda1;
+        const char* baseA2 = p.A2 ? (p.rows_both ? p.A2 : p.A2 + (long long)m0 * p.lda2) : baseA1;
+        const int recA1 = p.rowsA ? (int)(unsigned)p.res_bytes : rowsA * lda1;
+        const int recA2 = p.rows_both ? (int)(unsigned)p.res_bytes2 : rowsA * lda2;
+        constexpr int OOB = (int)0xfffffc00u;                              // past every window, also with a block offset on top
+        char* const scratch = lds + NSLOT * SLOT;
+        int vo1[NG], vo2[NG];
+        static_for<NG>([&](auto GI) {
+            constexpr int g = decltype(GI)::value;
+            const int gi = g * NL + lw;
+            const int sl = gi * 64 + lane, row = sl / 6, part = sl - row * 6, sp = part ^ ((row >> 3) & 1);
+            vo1[g] = gi >= G ? OOB : row * lda1 + sp * 16;
+            vo2[g] = gi >= G ? OOB : row * lda2 + sp * 16;
+            if (p.rowsA && gi < G) {
+                const int rr = row < rowsA ? p.rowsA[m0 + row] : -1;
+                vo1[g] = rr < 0 ? OOB : (int)((unsigned)rr * (unsigned)lda1 + (unsigned)(sp * 16));
+                if (p.rows_both) vo2[g] = rr < 0 ? OOB : (int)((unsigned)rr * (unsigned)lda2 + (unsigned)(sp * 16));
+            }
+        });
+        auto issue = [&](int s, char* slot) {
+            const bool seg = s >= S1;
+            const int kb0 = (seg ? s - S1 : s) * SQ, kbs = seg ? KB2 : KB1;
+            const int live = s < S ? 1 : 0;
+            const char* pa = seg ? baseA2 + (long long)kb0 * 96 : baseA1 + (long long)kb0 * 96;
+            const __amdgpu_buffer_rsrc_t sa =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? recA2 : recA1) * live, SRD_FLAGS);
+            static_for<NG>([&](auto GI) {
+                constexpr int g = decltype(GI)::value;
+                const int gi = g * NL + lw;
+                const int vo = seg ? vo2[g] : vo1[g];
+                static_for<SQ>([&](auto QI) {
+                    constexpr int q = decltype(QI)::value;
+#if P3_ABL & 1
+                    if (s >= 2) return;
+#endif
+                    dma16(sa, gi < G ? slot + q * BLK + gi * 1024 : scratch, (kb0 + q < kbs && vo != OOB) ? vo + q * 96 : OOB);
+                });
+            });
+        };
+        issue(0, lds);
+        issue(1, lds + SLOT);
+        wait_dma_barrier<NIQ>();
+        int wr = 2;
+        for (int s = 0; s < S; ++s) {
+            issue(s + 2, lds + wr * SLOT);
+            wr = wr + 1 == NSLOT ? 0 : wr + 1;
+            wait_dma_barrier<NIQ>();
+        }
+        if constexpr (LNB != 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+    }
+    // ---------------- compute ----------------
+    const int wn = wave;
+    const int r = lane & 31, hsel = lane >> 5;
+    const int a_rd = r * 96 + (hsel ^ ((r >> 3) & 1)) * 16;
+    const int rowsB = min(BN, p.N - n0);
+    const char* const baseB = p.B + (long long)n0 * 96;
+    const int b_vo = (wn * 32 + r) * 96 + hsel * 16;
+    const long long bsb = p.bsb;
+    bf16x8 bq[4][3];                                                       // fragment sets of four K blocks in flight
+    // (a window per K block: the range check covers scalar offset + lane offset, so the block cannot ride in the scalar offset;
+    // invalid = a K block the segment does not have: an empty window, the fragments are zeros)
+    auto load_b = [&](bf16x8 (&dst)[3], int t, bool valid) {
+        const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (long long)min(t, T - 1) * bsb), 0,
+                                                                            valid ? rowsB * 96 : 0, SRD_FLAGS);
+        static_for<3>([&](auto PL) {
+            constexpr int pl = decltype(PL)::value;
+            dst[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(sb, b_vo + pl * 32, 0, 0));
+        });
+    };
+    f32x16 acc[TM][1];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][0][e] = 0.f;
+    auto block = [&](const char* blk, const bf16x8 (&b)[3]) {
+        bf16x8 fa[3][TM];
+        static_for<3>([&](auto GQ) {                                        // planes in the order the products need them: h, l, m
+            constexpr int g = decltype(GQ)::value;
+            constexpr int oa = g == 0 ? 0 : (g == 1 ? 2 : 1);
+            static_for<TM>([&](auto A) {
+                constexpr int a = decltype(A)::value;
+                fa[oa][a] = *reinterpret_cast<const bf16x8*>(blk + a_rd + a * 32 * 96 + oa * 32);
+            });
+        });
+#if P3_ABL & 8
+        static_for<3>([&](auto PL) {
+            static_for<TM>([&](auto A) { asm volatile("" ::"v"(fa[decltype(PL)::value][decltype(A)::value])); });
+            asm volatile("" ::"v"(b[decltype(PL)::value]));
+        });
+#else
+        // the six piece products, smallest terms first (products<>()): hl, lh, mm, hm, mh, hh
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+        static_for<6>([&](auto QQ) {
+            constexpr int q = decltype(QQ)::value;
+            static_for<TM>([&](auto A) {
+                constexpr int a = decltype(A)::value;
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][a], b[PB[q]], acc[a][0], 0, 0, 0);
+            });
+        });
+#endif
+        __builtin_amdgcn_sched_barrier(0);                                  // (no fragment reads hoisted over a whole block: registers)
+    };
+    // slot s holds K blocks kfirst(s) .. kfirst(s) + nvalid(s) - 1 of the weight image; the blocks a segment's last slot lacks are
+    // multiplied as zeros (the loader's requests for them leave the window: zeros in LDS; the weight fragments: load_b): ONE slot
+    // body without branches -- with a second, branching copy for short slots the compiler moved all 48 accumulators through
+    // copies at the join and spilled the fragment ring
+    auto kfirst = [&](int s) { return s >= S1 ? KB1 + (s - S1) * SQ : s * SQ; };
+    auto nvalid = [&](int s) { return s >= S ? 0 : min(SQ, (s >= S1 ? T : KB1) - kfirst(s)); };
+    int k0 = 0, nv = nvalid(0);
+    load_b(bq[0], 0, 0 < nv);
+    load_b(bq[1], 1, 1 < nv);
+    load_b(bq[2], 2, 2 < nv);
+    asm volatile("s_barrier" ::: "memory");
+#if P3_ABL & 16
+    const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    int rd = 0;
+    for (int s = 0; s < S; ++s) {
+        const char* slot = lds + rd * SLOT;
+        const int k1 = kfirst(s + 1), nv1 = nvalid(s + 1);
+        static_for<SQ>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j + 3 < SQ) load_b(bq[(j + 3) & 3], k0 + j + 3, j + 3 < nv);
+            else load_b(bq[(j + 3) & 3], k1 + j + 3 - SQ, j + 3 - SQ < nv1);
+            block(slot + j * BLK, bq[j]);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        rd = rd + 1 == NSLOT ? 0 : rd + 1;
+        k0 = k1; nv = nv1;
+    }
+#if P3_ABL & 16
+    if (tid == 0 && p.slab) {
+        long long* st = reinterpret_cast<long long*>(p.slab) + 2 * blockIdx.x;
+        st[0] = __builtin_amdgcn_s_memtime() - c0;
+        st[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+#endif
+#if P3_ABL & 32
+    if (p.K != 12345) return;                                  // (measurement: no epilogue)
+#endif
+    lw_epilogue<WM, WN, TM, TN, LNB>(acc, lds, p, m0, n0, lb, wave, lane, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1129,9 +1412,10 @@ gemm_p3_tn_kernel(const P3Gemm p) {
 // fp32 <-> P3
 // ---------------------------------------------------------------------------------------------------------------
 // dst (P3, [rows][cols]) element (r, c) = transpose ? src[c * ld + r] : src[r * ld + c].  One thread per half block (8 features).
+// Image addressing everywhere below: block fb of row r at r * ldp + fb * bsp (row-major: bsp = 96; block-major: ldp = 96).
 __global__ void __launch_bounds__(256)
 p3_from_f32_kernel(const float* __restrict__ src, long long ld, int rows, int cols, int transpose, char* __restrict__ dst,
-                   long long ldp) {
+                   long long ldp, long long bsp) {
     const int hb = (int)((cols + 7) / 8);                 // half blocks per row that hold data
     const int hbt = (int)p3::blocks(cols) * 2;            // half blocks per row (the last may be all padding)
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1144,7 +1428,7 @@ p3_from_f32_kernel(const float* __restrict__ src, long long ld, int rows, int co
         x[e] = 0.f;
         if (j < hb && c < cols) x[e] = transpose ? src[(long long)c * ld + r] : src[(long long)r * ld + c];
     }
-    p3::store8(dst + (long long)r * ldp, j * 8, x);
+    p3::store8(dst + (long long)r * ldp + (long long)(j >> 1) * bsp, (j & 1) * 8, x);
 }
 
 // several small matrices in one launch (the weight images of every layer after an optimiser step): blockIdx.y = matrix
@@ -1153,6 +1437,7 @@ struct P3BatchArgs { gte_p3_desc d[kMaxP3Batch]; };
 __global__ void __launch_bounds__(256)
 p3_from_f32_batch_kernel(const P3BatchArgs a) {
     const gte_p3_desc d = a.d[blockIdx.y];
+    const long long ldp = d.ldp < 0 ? 96 : d.ldp, bsp = d.ldp < 0 ? -d.ldp : 96;
     const int hb = (int)((d.cols + 7) / 8), hbt = (int)p3::blocks(d.cols) * 2;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (long long)d.rows * hbt; idx += (long long)gridDim.x * 256) {
         const int r = (int)(idx / hbt), j = (int)(idx - (long long)r * hbt);
@@ -1163,16 +1448,16 @@ p3_from_f32_batch_kernel(const P3BatchArgs a) {
             x[e] = 0.f;
             if (j < hb && c < d.cols) x[e] = d.transpose ? d.src[c * d.ld + r] : d.src[(long long)r * d.ld + c];
         }
-        p3::store8(reinterpret_cast<char*>(d.dst) + (long long)r * d.ldp, j * 8, x);
+        p3::store8(reinterpret_cast<char*>(d.dst) + (long long)r * ldp + (long long)(j >> 1) * bsp, (j & 1) * 8, x);
     }
 }
 
 __global__ void __launch_bounds__(256)
-p3_to_f32_kernel(const char* __restrict__ src, long long ldp, int rows, int cols, float* __restrict__ dst, long long ld) {
+p3_to_f32_kernel(const char* __restrict__ src, long long ldp, long long bsp, int rows, int cols, float* __restrict__ dst, long long ld) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)rows * cols) return;
     const int r = (int)(idx / cols), c = (int)(idx - (long long)r * cols);
-    dst[(long long)r * ld + c] = p3::load1(src + (long long)r * ldp, c);
+    dst[(long long)r * ld + c] = p3::load1(src + (long long)r * ldp + (long long)(c >> 4) * bsp, c & 15);
 }
 
 // TN tile: 128 x 128 (4 waves, two workgroups per CU).  (The 256 x 128 tile -- 8 waves, one workgroup per CU, a quarter less
@@ -1206,16 +1491,29 @@ namespace { int launch_nt(const P3Gemm& p, hipStream_t s); }
 
 extern "C" int64_t gte_p3_row_bytes(int64_t cols) { return cols > 0 ? p3::row_bytes(cols) : 0; }
 
+// (row stride, block stride) of an image from the signed "ldp" of the ABI: a NEGATIVE value names a BLOCK-MAJOR image whose 16-feature
+// block fb starts at byte fb * (-ldp) and whose rows follow each other at 96 bytes inside a block (include/gte.h)
+namespace {
+struct P3Strides { long long ld, bs; bool block_major; };
+inline P3Strides p3_strides(int64_t ldp) { return ldp < 0 ? P3Strides{96, -ldp, true} : P3Strides{ldp, 96, false}; }
+// is [rows][cols] addressable with these strides?
+inline bool p3_strides_ok(int64_t ldp, int64_t rows, int64_t cols) {
+    if (ldp < 0) return (-ldp) % 16 == 0 && -ldp >= rows * 96;
+    return ldp % 16 == 0 && ldp >= p3::row_bytes(cols);
+}
+}
+
 extern "C" int gte_p3_from_f32(const float* src, int64_t ld, int64_t rows, int64_t cols, int transpose, void* dst, int64_t ldp,
                                void* stream) {
     if (rows < 0 || cols < 0 || rows > INT32_MAX || cols > INT32_MAX) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_from_f32: bad sizes");
     if (rows == 0 || cols == 0) return GTE_OK;
     if (!src || !dst) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_from_f32: null pointer");
-    if (ld < (transpose ? rows : cols) || ldp < p3::row_bytes(cols) || ldp % 16 != 0 || (reinterpret_cast<uintptr_t>(dst) & 15))
+    if (ld < (transpose ? rows : cols) || !p3_strides_ok(ldp, rows, cols) || (reinterpret_cast<uintptr_t>(dst) & 15))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_from_f32: leading dimension too small or image not 16-byte aligned");
     const int64_t work = rows * p3::blocks(cols) * 2;
+    const P3Strides st = p3_strides(ldp);
     hipLaunchKernelGGL(p3_from_f32_kernel, dim3((unsigned)gte::ceil_div(work, 256)), dim3(256), 0, gte::as_stream(stream), src,
-                       (long long)ld, (int)rows, (int)cols, transpose ? 1 : 0, reinterpret_cast<char*>(dst), (long long)ldp);
+                       (long long)ld, (int)rows, (int)cols, transpose ? 1 : 0, reinterpret_cast<char*>(dst), st.ld, st.bs);
     return gte::check_launch("p3_from_f32");
 }
 
@@ -1226,8 +1524,8 @@ extern "C" int gte_p3_from_f32_batch(const gte_p3_desc* descs, int n, void* stre
     int64_t work = 1;
     for (int i = 0; i < n; ++i) {
         const gte_p3_desc& d = descs[i];
-        if (!d.src || !d.dst || d.rows <= 0 || d.cols <= 0 || d.ld < (d.transpose ? d.rows : d.cols) || d.ldp < p3::row_bytes(d.cols) ||
-            d.ldp % 16 != 0 || (reinterpret_cast<uintptr_t>(d.dst) & 15))
+        if (!d.src || !d.dst || d.rows <= 0 || d.cols <= 0 || d.ld < (d.transpose ? d.rows : d.cols) || !p3_strides_ok(d.ldp, d.rows, d.cols) ||
+            (reinterpret_cast<uintptr_t>(d.dst) & 15))
             return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_from_f32_batch: bad descriptor %d", i);
         a.d[i] = d;
         const int64_t w = d.rows * p3::blocks(d.cols) * 2;
@@ -1243,9 +1541,10 @@ extern "C" int gte_p3_to_f32(const void* src, int64_t ldp, int64_t rows, int64_t
     if (rows < 0 || cols < 0 || rows > INT32_MAX || cols > INT32_MAX) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_to_f32: bad sizes");
     if (rows == 0 || cols == 0) return GTE_OK;
     if (!src || !dst) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_to_f32: null pointer");
-    if (ld < cols || ldp < p3::row_bytes(cols)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_to_f32: leading dimension too small");
+    if (ld < cols || !p3_strides_ok(ldp, rows, cols)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "p3_to_f32: leading dimension too small");
+    const P3Strides st = p3_strides(ldp);
     hipLaunchKernelGGL(p3_to_f32_kernel, dim3((unsigned)gte::ceil_div(rows * cols, 256)), dim3(256), 0, gte::as_stream(stream),
-                       reinterpret_cast<const char*>(src), (long long)ldp, (int)rows, (int)cols, dst, (long long)ld);
+                       reinterpret_cast<const char*>(src), st.ld, st.bs, (int)rows, (int)cols, dst, (long long)ld);
     return gte::check_launch("p3_to_f32");
 }
 
@@ -1272,15 +1571,16 @@ static int gemm_p3_nt_impl(const void* a1, int64_t lda1, int64_t k1, const void*
     if (m == 0 || n == 0) return GTE_OK;
     if (!a1 || !b || !c || (k2 > 0 && !a2)) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt: null pointer");
     const int64_t kb1 = p3::blocks(k1), kb2 = p3::blocks(k2);
-    if (lda1 < kb1 * 96 || (k2 > 0 && lda2 < kb2 * 96) || ldb < (kb1 + kb2) * 96 || ldc < n)
+    const P3Strides sb = p3_strides(ldb);
+    if (lda1 < kb1 * 96 || (k2 > 0 && lda2 < kb2 * 96) || !p3_strides_ok(ldb, n, 16 * (kb1 + kb2)) || ldc < n)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt: leading dimension too small");
-    if (lda1 >= (1 << 22) || lda2 >= (1 << 22) || ldb >= (1 << 22) || (m + 256) * ldc * 4 >= ((int64_t)1 << 31))
+    if (lda1 >= (1 << 22) || lda2 >= (1 << 22) || sb.ld >= (1 << 22) || (m + 256) * ldc * 4 >= ((int64_t)1 << 31))
         return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt: row strides must be < 4 MB and the output < 2 GB");
     P3Gemm p = {};
     p.A1 = (const char*)a1; p.lda1 = lda1; p.KB1 = (int)kb1;
     p.A2 = k2 > 0 ? (const char*)a2 : nullptr; p.lda2 = lda2; p.KB2 = (int)kb2;
-    p.B = (const char*)b; p.ldb = ldb; p.C = c; p.ldc = ldc; p.bias = bias; p.bias_cols = (int)bias_cols;
-    p.bsa1 = p.bsa2 = p.bsb = 96;
+    p.B = (const char*)b; p.ldb = sb.ld; p.C = c; p.ldc = ldc; p.bias = bias; p.bias_cols = (int)bias_cols;
+    p.bsa1 = p.bsa2 = 96; p.bsb = sb.bs;
     p.M = (int)m; p.N = (int)n; p.relu = relu; p.accumulate = accumulate; p.splits = 1;
     if (a_rows) {
         if (k2 > 0 && !rows_both) return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_rows: one K segment only (two: gte_gemm_p3_nt_rows2)");
@@ -1359,6 +1659,26 @@ void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
     }
     const dim3 grid((unsigned)gte::ceil_div(p.M, BM));
     hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
+}
+// The block-major-weights kernel takes a product when the weights ARE block-major, the rows are reached through 32-bit offsets, one
+// column of tiles covers the output, and cutting each K segment into slots of four blocks pads the K loop by at most 1 / 12
+inline bool sq_applies(const P3Gemm& p) {
+    if (p.ldb != 96 || p.bsb < 96 || p.rows64 || p.N > 256 || p.bsa1 != 96 || p.bsa2 != 96) return false;
+    const int T = p.KB1 + p.KB2, S4 = 4 * ((p.KB1 + 3) / 4 + (p.KB2 + 3) / 4);
+    return (S4 - T) * 12 <= T;
+}
+// the block-major-weights kernel (gemm_p3_nt_sq_kernel): (32 TM) x 256 tiles
+template <int TM, int NL, int LNB>
+void launch_sq(const P3Gemm& p, hipStream_t s) {
+    constexpr int BM = TM * 32, shm = 3 * 4 * BM * 96 + 1024;
+    static_assert(LNB == 0 || (shm >= BM * 256 * 4 && shm >= 8 * 3 * 256 * 4), "the epilogue's row slice lives in the slots");
+    static bool configured = false;
+    if (!configured) {
+        GTE_SET_LDS((gemm_p3_nt_sq_kernel<TM, NL, LNB>), shm);
+        configured = true;
+    }
+    const dim3 grid((unsigned)(gte::ceil_div(p.M, BM) * gte::ceil_div(p.N, 256)));
+    hipLaunchKernelGGL((gemm_p3_nt_sq_kernel<TM, NL, LNB>), grid, dim3((8 + NL) * 64), shm, s, p);
 }
 // Configurations (measured on the step's shapes, profiles/r03/gemm_p3.md): the kernel runs at the chip's power limit
 // (~1.3 PF bf16 whatever the tile), so what matters is ONE balanced round of tiles: the row tile is the smallest of
@@ -1484,10 +1804,11 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: null pointer");
     const int64_t kb1 = p3::blocks(k1), kb2 = k2 > 0 ? p3::blocks(k2) : 0;
     const int64_t n4 = gte::round_up(n, 4);
-    if (lda1 < p3::row_bytes(k1) || (k2 > 0 && lda2 < p3::row_bytes(k2)) || ldb < (kb1 + kb2) * 96 || ldz < n4 || (dz && lddz < n4) ||
-        (dzp3 && (ldp3 < p3::row_bytes(n) || ldp3 % 16 != 0)))
+    const P3Strides sb = p3_strides(ldb);
+    if (lda1 < p3::row_bytes(k1) || (k2 > 0 && lda2 < p3::row_bytes(k2)) || !p3_strides_ok(ldb, n, 16 * (kb1 + kb2)) || ldz < n4 ||
+        (dz && lddz < n4) || (dzp3 && (ldp3 < p3::row_bytes(n) || ldp3 % 16 != 0)))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_bwd: leading dimension too small");
-    if (lda1 >= (1 << 23) || lda2 >= (1 << 23) || ldb >= (1 << 23) || (m + 256) * lda1 >= ((int64_t)1 << 31) ||
+    if (lda1 >= (1 << 23) || lda2 >= (1 << 23) || sb.ld >= (1 << 23) || (m + 256) * lda1 >= ((int64_t)1 << 31) ||
         (k2 > 0 && (m + 256) * lda2 >= ((int64_t)1 << 31)))
         return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_bwd: operand images must be < 2 GB with row strides < 8 MB");
     const int64_t need = gte_gemm_p3_nt_ln_bwd_workspace_bytes(m, n);
@@ -1497,8 +1818,8 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
     P3Gemm p = {};
     p.A1 = reinterpret_cast<const char*>(a1); p.lda1 = lda1; p.KB1 = (int)kb1;
     p.A2 = k2 > 0 ? reinterpret_cast<const char*>(a2) : nullptr; p.lda2 = lda2; p.KB2 = (int)kb2;
-    p.B = reinterpret_cast<const char*>(b); p.ldb = ldb;
-    p.bsa1 = p.bsa2 = p.bsb = 96;
+    p.B = reinterpret_cast<const char*>(b); p.ldb = sb.ld;
+    p.bsa1 = p.bsa2 = 96; p.bsb = sb.bs;
     p.M = (int)m; p.N = (int)n; p.splits = 1;
     p.ln_z = z; p.ln_ldz = ldz; p.ln_stats = stats; p.ln_gamma = gamma; p.ln_beta = beta; p.ln_relu = relu;
     p.ln_dz = dz; p.ln_lddz = lddz; p.ln_dzp3 = reinterpret_cast<char*>(dzp3); p.ln_ldp3 = ldp3;
@@ -1506,7 +1827,19 @@ extern "C" int gte_gemm_p3_nt_ln_bwd(const void* a1, int64_t lda1, int64_t k1, c
     hipStream_t s = gte::as_stream(stream);
     const int bm = lnb_row_tile(m);
     // (column tiles of 128 / 192 for hidden widths up to 128 / 192 were measured in round 5 and removed: 27 -> 30 us at 96 columns)
-    if (n % 16 == 0) {
+    if (sq_applies(p)) {                                  // block-major weights: fragments straight to registers, 64-deep A slots
+        if (n % 16 == 0) {
+            if (bm == 32) launch_sq<1, 4, 1>(p, s);
+            else if (bm == 64) launch_sq<2, 4, 1>(p, s);
+            else if (bm == 96) launch_sq<3, 4, 1>(p, s);
+            else launch_sq<4, 4, 1>(p, s);
+        } else {
+            if (bm == 32) launch_sq<1, 4, 3>(p, s);
+            else if (bm == 64) launch_sq<2, 4, 3>(p, s);
+            else if (bm == 96) launch_sq<3, 4, 3>(p, s);
+            else launch_sq<4, 4, 3>(p, s);
+        }
+    } else if (n % 16 == 0) {
         if (bm == 32) launch_lw_lnb<1, 8, 1, 1, 4>(p, s);
         else if (bm == 64) launch_lw_lnb<1, 8, 2, 1, 4>(p, s);
         else if (bm == 96) launch_lw_lnb<1, 8, 3, 1, 4>(p, s);
@@ -1548,16 +1881,17 @@ static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, cons
     if (!a1 || !b || !z || !gamma || !beta || (!y && !yp3) || (k2 > 0 && !a2))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_fwd: null pointer");
     const int64_t kb1 = p3::blocks(k1), kb2 = k2 > 0 ? p3::blocks(k2) : 0, n4 = gte::round_up(n, 4);
-    if (lda1 < kb1 * 96 || (k2 > 0 && lda2 < kb2 * 96) || ldb < (kb1 + kb2) * 96 || ldz < n4 || (y && ldy < n4) ||
+    const P3Strides sb = p3_strides(ldb);
+    if (lda1 < kb1 * 96 || (k2 > 0 && lda2 < kb2 * 96) || !p3_strides_ok(ldb, n, 16 * (kb1 + kb2)) || ldz < n4 || (y && ldy < n4) ||
         (yp3 && (ldyp3 < p3::row_bytes(n) || ldyp3 % 16 != 0)))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_ln_fwd: leading dimension too small (rows of z / y padded to 4 floats)");
-    if (lda1 >= (1 << 22) || lda2 >= (1 << 22) || ldb >= (1 << 22))
+    if (lda1 >= (1 << 22) || lda2 >= (1 << 22) || sb.ld >= (1 << 22))
         return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_ln_fwd: row strides must be < 4 MB");
     P3Gemm p = {};
     p.A1 = (const char*)a1; p.lda1 = lda1; p.KB1 = (int)kb1;
     p.A2 = k2 > 0 ? (const char*)a2 : nullptr; p.lda2 = lda2; p.KB2 = (int)kb2;
-    p.B = (const char*)b; p.ldb = ldb; p.C = z; p.ldc = ldz; p.bias = bias;
-    p.bsa1 = p.bsa2 = p.bsb = 96;
+    p.B = (const char*)b; p.ldb = sb.ld; p.C = z; p.ldc = ldz; p.bias = bias;
+    p.bsa1 = p.bsa2 = 96; p.bsb = sb.bs;
     p.M = (int)m; p.N = (int)n; p.splits = 1;
     p.ln_gamma = gamma; p.ln_beta = beta; p.ln_relu = relu;
     p.lnf_y = y; p.lnf_ldy = ldy; p.lnf_yp3 = reinterpret_cast<char*>(yp3); p.lnf_ldp = ldyp3; p.lnf_stats = stats; p.lnf_eps = eps;
@@ -1569,7 +1903,13 @@ static int gemm_p3_nt_ln_fwd_impl(const void* a1, int64_t lda1, int64_t k1, cons
     }
     if (p.rows64)                                          // images of 4 GB or more: 64-bit per-lane addresses (no range check: the
         launch_lw_lnb<2, 4, 2, 2, 4, 4, true>(p, gte::as_stream(stream));                    // rows past the tile re-read its first row)
-    else if (lnb_row_tile(m) == 32) launch_lw_lnb<1, 8, 1, 1, 4, 4>(p, gte::as_stream(stream));
+    else if (sq_applies(p)) {                              // block-major weights: fragments straight to registers, 64-deep A slots
+        const int bm = lnb_row_tile(m);
+        if (bm == 32) launch_sq<1, 4, 4>(p, gte::as_stream(stream));
+        else if (bm == 64) launch_sq<2, 4, 4>(p, gte::as_stream(stream));
+        else if (bm == 96) launch_sq<3, 4, 4>(p, gte::as_stream(stream));
+        else launch_sq<4, 4, 4>(p, gte::as_stream(stream));
+    } else if (lnb_row_tile(m) == 32) launch_lw_lnb<1, 8, 1, 1, 4, 4>(p, gte::as_stream(stream));
     else if (lnb_row_tile(m) == 64) launch_lw_lnb<1, 8, 2, 1, 4, 4>(p, gte::as_stream(stream));
     else if (lnb_row_tile(m) == 96) launch_lw_lnb<1, 8, 3, 1, 4, 4>(p, gte::as_stream(stream));
     else launch_lw_lnb<2, 4, 2, 2, 4, 4>(p, gte::as_stream(stream));
@@ -1621,10 +1961,11 @@ extern "C" int gte_gemm_p3_nt_smallk_bwd(const void* a1, int64_t lda1, int64_t k
     if (!a1 || !b || !x || (k2 > 0 && !ahn) || !W || !bias || !gamma || !beta || !stats || !dW || !workspace || (kg2 > 0 && !a2))
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_smallk_bwd: null pointer");
     const int64_t kb1 = p3::blocks(kg1), kb2 = kg2 > 0 ? p3::blocks(kg2) : 0;
-    if (lda1 < p3::row_bytes(kg1) || (kg2 > 0 && lda2 < p3::row_bytes(kg2)) || ldb < (kb1 + kb2) * 96 || ldx < k1 || (k2 > 0 && ldahn < k2) ||
+    const P3Strides sb = p3_strides(ldb);
+    if (lda1 < p3::row_bytes(kg1) || (kg2 > 0 && lda2 < p3::row_bytes(kg2)) || !p3_strides_ok(ldb, n, 16 * (kb1 + kb2)) || ldx < k1 || (k2 > 0 && ldahn < k2) ||
         ldw < K || lddw < K)
         return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_smallk_bwd: leading dimension too small");
-    if (lda1 >= (1 << 23) || lda2 >= (1 << 23) || ldb >= (1 << 23) || (m + 256) * lda1 >= ((int64_t)1 << 31) ||
+    if (lda1 >= (1 << 23) || lda2 >= (1 << 23) || sb.ld >= (1 << 23) || (m + 256) * lda1 >= ((int64_t)1 << 31) ||
         (kg2 > 0 && (m + 256) * lda2 >= ((int64_t)1 << 31)))
         return gte::fail(GTE_ERR_UNSUPPORTED, "gemm_p3_nt_smallk_bwd: operand images must be < 2 GB with row strides < 8 MB");
     const int64_t need = gte_gemm_p3_nt_smallk_bwd_workspace_bytes(m, K, n);
@@ -1636,8 +1977,8 @@ extern "C" int gte_gemm_p3_nt_smallk_bwd(const void* a1, int64_t lda1, int64_t k
     P3Gemm p = {};
     p.A1 = reinterpret_cast<const char*>(a1); p.lda1 = lda1; p.KB1 = (int)kb1;
     p.A2 = kg2 > 0 ? reinterpret_cast<const char*>(a2) : nullptr; p.lda2 = lda2; p.KB2 = (int)kb2;
-    p.B = reinterpret_cast<const char*>(b); p.ldb = ldb;
-    p.bsa1 = p.bsa2 = p.bsb = 96;
+    p.B = reinterpret_cast<const char*>(b); p.ldb = sb.ld;
+    p.bsa1 = p.bsa2 = 96; p.bsb = sb.bs;
     p.M = (int)m; p.N = (int)n; p.splits = 1;
     p.ln_stats = stats; p.ln_gamma = gamma; p.ln_beta = beta; p.ln_relu = relu;
     p.sk_x = x; p.sk_ldx = ldx; p.sk_k1 = (int)k1; p.sk_ahn = k2 > 0 ? ahn : nullptr; p.sk_ldahn = ldahn; p.sk_k2 = (int)k2;

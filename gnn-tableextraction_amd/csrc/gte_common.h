@@ -127,6 +127,11 @@ __device__ __forceinline__ float gte_group_sum(float v) {
     return v;
 }
 
+// value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float gte_quad_swap1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+
 // value of lane T of every quad, in all four lanes of the quad (DPP quad_perm broadcast; T is a compile-time constant)
 template <int T>
 __device__ __forceinline__ int gte_quad_bcast(int v) {

@@ -189,6 +189,10 @@ class FusedGcnSageStep(TrainStep):
         # step for layer 0 (GTE_LAYER_CACHED).  Costs a second resident image; GTE_CACHE_AGG=0 turns it off
         self.cache_input_agg = os.environ.get("GTE_CACHE_AGG", "1") == "1"
         self._wimg = {}                               # layer index -> (forward image, backward image or None)
+        # weight images in the block-major layout (ops.P3): a K block of the weights is ONE contiguous run, whole cache lines for
+        # every NT planes GEMM, and the block-major-weights kernel (gemm_p3_nt_sq_kernel) loads its fragments straight into
+        # registers.  GTE_WIMG_BLOCK_MAJOR=0: row-major images (the layout up to round 5; A/B measurements, tests)
+        self.block_major_weights = os.environ.get("GTE_WIMG_BLOCK_MAJOR", "1") == "1"
         # one-call step: the fold + Adam launch also writes the weight images of the updated parameters
         # (gte_fold_defer_flush_adam_images) and the next step's forward skips their conversion launch.  _wimg_sig = the version
         # counters of the parameters the images were made from (None: stale).  In-place writes through torch (load_state_dict,
@@ -462,21 +466,22 @@ class FusedGcnSageStep(TrainStep):
                 continue
             img = self._wimg.get(i)
             if img is None:
-                fwd = ops.P3.empty(2 * fout, fin, self.flat_param.device)
+                # (weight images are BLOCK-MAJOR: the B operand of every NT planes GEMM -- ops.P3)
+                fwd = ops.P3.empty(2 * fout, fin, self.flat_param.device, block_major=self.block_major_weights)
                 fwd.data.zero_()
                 bwd = None
                 if i > 0:
-                    bwd = ops.P3.empty(fin, 2 * fout, self.flat_param.device)
+                    bwd = ops.P3.empty(fin, 2 * fout, self.flat_param.device, block_major=self.block_major_weights)
                     bwd.data.zero_()
                 img = self._wimg[i] = (fwd, bwd)
             fwd, bwd = img
             W = L.linear.weight
             wp, ld = W.data_ptr(), W.stride(0)
-            descs.append(_lib.P3Desc(wp, ld, fout, fin, 0, fwd.data.data_ptr(), fwd.ldp))
-            descs.append(_lib.P3Desc(wp + 4 * fin, ld, fout, fin, 0, fwd.data.data_ptr() + fout * fwd.ldp, fwd.ldp))
+            descs.append(_lib.P3Desc(wp, ld, fout, fin, 0, fwd.at(0, 0), fwd.ldp))
+            descs.append(_lib.P3Desc(wp + 4 * fin, ld, fout, fin, 0, fwd.at(fout, 0), fwd.ldp))
             if bwd is not None:
-                descs.append(_lib.P3Desc(wp, ld, fin, fout, 1, bwd.data.data_ptr(), bwd.ldp))
-                descs.append(_lib.P3Desc(wp + 4 * fin, ld, fin, fout, 1, bwd.data.data_ptr() + (fout // 16) * 96, bwd.ldp))
+                descs.append(_lib.P3Desc(wp, ld, fin, fout, 1, bwd.at(0, 0), bwd.ldp))
+                descs.append(_lib.P3Desc(wp + 4 * fin, ld, fin, fout, 1, bwd.at(0, fout // 16), bwd.ldp))
         self._wimg_descs = descs
         if launch:
             st = _lib.current_stream()
@@ -614,8 +619,8 @@ class FusedGcnSageStep(TrainStep):
         dev = self.flat_param.device
         layers = list(self.model.layers)
 
-        def img(rows, cols):
-            t = ops.P3.empty(rows, cols, dev)
+        def img(rows, cols):                          # (weight images are BLOCK-MAJOR: the B operand of every NT planes GEMM -- ops.P3)
+            t = ops.P3.empty(rows, cols, dev, block_major=self.block_major_weights)
             t.data.zero_()
             return t
         imgs, descs = {}, []
@@ -627,19 +632,19 @@ class FusedGcnSageStep(TrainStep):
             if k == 0:
                 ld = _c16(fout)
                 fwd = img(2 * ld, fin)
-                descs.append(_lib.P3Desc(wp, ldw, fout, fin, 0, fwd.data.data_ptr(), fwd.ldp))
-                descs.append(_lib.P3Desc(wp + 4 * fin, ldw, fout, fin, 0, fwd.data.data_ptr() + ld * fwd.ldp, fwd.ldp))
+                descs.append(_lib.P3Desc(wp, ldw, fout, fin, 0, fwd.at(0, 0), fwd.ldp))
+                descs.append(_lib.P3Desc(wp + 4 * fin, ldw, fout, fin, 0, fwd.at(ld, 0), fwd.ldp))
                 bwd = None
                 if i > 0:
                     bwd = img(fin, 2 * ld)
-                    descs.append(_lib.P3Desc(wp, ldw, fin, fout, 1, bwd.data.data_ptr(), bwd.ldp))
-                    descs.append(_lib.P3Desc(wp + 4 * fin, ldw, fin, fout, 1, bwd.data.data_ptr() + (ld // 16) * 96, bwd.ldp))
+                    descs.append(_lib.P3Desc(wp, ldw, fin, fout, 1, bwd.at(0, 0), bwd.ldp))
+                    descs.append(_lib.P3Desc(wp + 4 * fin, ldw, fin, fout, 1, bwd.at(0, ld // 16), bwd.ldp))
                 imgs[i] = (fwd, bwd)
             elif k in (2, 3):
                 kp = _c16(fin)
                 fwd = img(fout, 2 * kp)
-                descs.append(_lib.P3Desc(wp, ldw, fout, fin, 0, fwd.data.data_ptr(), fwd.ldp))
-                descs.append(_lib.P3Desc(wp + 4 * fin, ldw, fout, fin, 0, fwd.data.data_ptr() + (kp // 16) * 96, fwd.ldp))
+                descs.append(_lib.P3Desc(wp, ldw, fout, fin, 0, fwd.at(0, 0), fwd.ldp))
+                descs.append(_lib.P3Desc(wp + 4 * fin, ldw, fout, fin, 0, fwd.at(0, kp // 16), fwd.ldp))
                 imgs[i] = (fwd, None)
         if out_gemm:
             Lo = layers[-1]
@@ -647,10 +652,10 @@ class FusedGcnSageStep(TrainStep):
             W = Lo.linear.weight
             wp, ldw = W.data_ptr(), W.stride(0)
             fwd, bwd = img(32, H), img(H, 32)
-            descs.append(_lib.P3Desc(wp, ldw, C, H, 0, fwd.data.data_ptr(), fwd.ldp))
-            descs.append(_lib.P3Desc(wp + 4 * H, ldw, C, H, 0, fwd.data.data_ptr() + 16 * fwd.ldp, fwd.ldp))
-            descs.append(_lib.P3Desc(wp, ldw, H, C, 1, bwd.data.data_ptr(), bwd.ldp))
-            descs.append(_lib.P3Desc(wp + 4 * H, ldw, H, C, 1, bwd.data.data_ptr() + 96, bwd.ldp))
+            descs.append(_lib.P3Desc(wp, ldw, C, H, 0, fwd.at(0, 0), fwd.ldp))
+            descs.append(_lib.P3Desc(wp + 4 * H, ldw, C, H, 0, fwd.at(16, 0), fwd.ldp))
+            descs.append(_lib.P3Desc(wp, ldw, H, C, 1, bwd.at(0, 0), bwd.ldp))
+            descs.append(_lib.P3Desc(wp + 4 * H, ldw, H, C, 1, bwd.at(0, 1), bwd.ldp))
             imgs["out"] = (fwd, bwd)
         if len(descs) > 32:
             raise _lib.GteError("gte_gcnsage_step: more than 32 weight images")

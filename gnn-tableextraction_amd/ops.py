@@ -600,26 +600,40 @@ def get_gemm_mode() -> int:
 # P3 operands (three bf16 planes of an fp32 matrix, csrc/p3.h) and the planes GEMMs
 # --------------------------------------------------------------------------------------------------
 class P3:
-    """Device image of a logical fp32 matrix [rows][cols] in the P3 format: ``data`` is a uint8 tensor [rows_cap, ldp]."""
-    __slots__ = ("data", "rows", "cols", "row_map", "res_rows")
+    """Device image of a logical fp32 matrix [rows][cols] in the P3 format.  Row-major (the default): ``data`` is a uint8 tensor
+    [rows_cap, ldp], 16-feature block fb of row r at r * ldp + 96 fb.  BLOCK-MAJOR (``block_major``; weight images, the B operand
+    of the NT planes GEMMs): ``data`` is [blocks, rows_cap, 96], block fb is one contiguous [rows_cap][96 bytes] run -- what the
+    block-major-weights kernel streams straight into registers (csrc/gemm_p3.hip: gemm_p3_nt_sq_kernel).  The C ABI takes one
+    signed stride per image: ``ldp`` > 0 = row stride of a row-major image, < 0 = minus the block stride of a block-major one."""
+    __slots__ = ("data", "rows", "cols", "row_map", "res_rows", "block_major")
 
-    def __init__(self, data: torch.Tensor, rows: int, cols: int, row_map: Optional[torch.Tensor] = None, res_rows: int = 0):
+    def __init__(self, data: torch.Tensor, rows: int, cols: int, row_map: Optional[torch.Tensor] = None, res_rows: int = 0,
+                 block_major: bool = False):
         """``row_map`` (int32, rows rounded up to 16, plus 1, entries; the entries past ``rows`` = res_rows): the matrix is the
         rows row_map[0 .. rows) of the RESIDENT image ``data`` [res_rows] -- what ResidentPages hands the input layer instead of
         a per-batch copy (gte_gemm_p3_nt_rows / gte_gemm_p3_tn_rows)."""
-        self.data, self.rows, self.cols, self.row_map, self.res_rows = data, rows, cols, row_map, res_rows
+        self.data, self.rows, self.cols, self.row_map, self.res_rows, self.block_major = data, rows, cols, row_map, res_rows, block_major
 
     @property
     def ldp(self) -> int:
-        return self.data.stride(0)
+        return -self.data.stride(0) if self.block_major else self.data.stride(0)
+
+    def at(self, row: int = 0, block: int = 0) -> int:
+        """device address of 16-feature block ``block`` of row ``row`` (sub-images: the halves of a weight arrangement)"""
+        if self.block_major:
+            return self.data.data_ptr() + block * self.data.stride(0) + row * 96
+        return self.data.data_ptr() + row * self.data.stride(0) + block * 96
 
     @staticmethod
-    def empty(rows: int, cols: int, device, rows_cap: Optional[int] = None) -> "P3":
+    def empty(rows: int, cols: int, device, rows_cap: Optional[int] = None, block_major: bool = False) -> "P3":
         ldp = _lib.load().gte_p3_row_bytes(cols)
+        if block_major:
+            return P3(torch.empty((max(ldp // 96, 1), max(rows_cap or rows, 1), 96), dtype=torch.uint8, device=device), rows, cols,
+                      block_major=True)
         return P3(torch.empty((max(rows_cap or rows, 1), ldp), dtype=torch.uint8, device=device), rows, cols)
 
     def view_rows(self, rows: int) -> "P3":
-        return P3(self.data, rows, self.cols, self.row_map, self.res_rows)
+        return P3(self.data, rows, self.cols, self.row_map, self.res_rows, self.block_major)
 
     def gathered(self) -> "P3":
         """a contiguous copy of a row-mapped image (tests)"""
@@ -628,16 +642,18 @@ class P3:
         return P3(self.data[self.row_map[:self.rows].long()].contiguous(), self.rows, self.cols)
 
 
-def p3_from_f32(src: torch.Tensor, transpose: bool = False, out: Optional[P3] = None, row0: int = 0) -> P3:
-    """P3 image of ``src`` ([rows][cols], or its transpose).  ``out``/``row0``: write rows [row0, row0 + rows) of an existing image
-    (how the weight arrangement [W_s ; W_n] of a transform-first layer is put together)."""
+def p3_from_f32(src: torch.Tensor, transpose: bool = False, out: Optional[P3] = None, row0: int = 0, block_major: bool = False,
+                block0: int = 0) -> P3:
+    """P3 image of ``src`` ([rows][cols], or its transpose).  ``out``/``row0``/``block0``: write rows [row0, row0 + rows) from column
+    block ``block0`` on of an existing image (how the weight arrangements [W_s ; W_n] and [W_s | W_n] are put together).
+    ``block_major``: a new image in the block-major layout (weights; see :class:`P3`)."""
     require_device(src, "p3_from_f32")
     lib = _lib.load()
     src = _row_major(src)
     rows, cols = (src.shape[1], src.shape[0]) if transpose else src.shape
     if out is None:
-        out = P3.empty(rows, cols, src.device)
-    check(lib.gte_p3_from_f32(ptr(src), _ld(src), rows, cols, int(transpose), out.data.data_ptr() + row0 * out.ldp, out.ldp,
+        out = P3.empty(rows, cols, src.device, block_major=block_major)
+    check(lib.gte_p3_from_f32(ptr(src), _ld(src), rows, cols, int(transpose), out.at(row0, block0), out.ldp,
                               current_stream()), "gte_p3_from_f32")
     return out
 

@@ -290,7 +290,13 @@ int gte_gemm_set_thread_mode(int mode);
  * mode on the fp32 operand (same pieces, same products, same order).
  * P3 image of a logical fp32 matrix [rows][cols]: row r at byte r * ldp (ldp >= gte_p3_row_bytes(cols), a multiple of 16; the
  * image 16-byte aligned); 16-feature block fb at + 96 fb; in a block plane h (16 bf16), plane m, plane l; x = h + m + l
- * exactly; features >= cols are zero.  "ldp*" arguments of this section are row strides in BYTES. */
+ * exactly; features >= cols are zero.  "ldp*" arguments of this section are row strides in BYTES.
+ * BLOCK-MAJOR images (round 6; the weights -- the B operand "b, ldb" of the gte_gemm_p3_nt* entry points -- and every gte_p3_desc /
+ * gte_p3_from_f32 / gte_p3_to_f32 image): a NEGATIVE ldp names an image whose 16-feature block fb is ONE contiguous run at byte
+ * fb * (-ldp), row r at + 96 r inside it (-ldp >= 96 rows, a multiple of 16).  A K block of the weights is then whole cache lines
+ * (row-major: 96-byte runs at the row stride, every line fetched twice), and where a product has one column of 256-wide tiles the
+ * block-major-weights kernel (csrc/gemm_p3.hip gemm_p3_nt_sq_kernel) loads its weight fragments straight into registers.  Same
+ * products, same bits as the row-major image.  A operands, row-mapped resident images and the TN operands stay row-major. */
 int64_t gte_p3_row_bytes(int64_t cols);
 /* dst(r, c) = transpose ? src[c * ld + r] : src[r * ld + c]  for r < rows, c < cols (ld in elements) */
 int gte_p3_from_f32(const float* src, int64_t ld, int64_t rows, int64_t cols, int transpose, void* dst, int64_t ldp,
@@ -301,7 +307,7 @@ typedef struct gte_p3_desc {
     const float* src; int64_t ld;      /* fp32 source, leading dimension in elements */
     int64_t rows, cols;                /* of the IMAGE: dst(r, c) = transpose ? src[c * ld + r] : src[r * ld + c] */
     int transpose;
-    void* dst; int64_t ldp;            /* image (first byte of its row 0 / column block 0), row stride in bytes */
+    void* dst; int64_t ldp;            /* image (first byte of its row 0 / column block 0), row stride in bytes (< 0: block-major) */
 } gte_p3_desc;
 int gte_p3_from_f32_batch(const gte_p3_desc* descs, int n, void* stream);
 /* Producers that write their result as a P3 image: the aggregation (q = A_w^T (norm dz), aggregated inputs; any n_feat, the

@@ -36,6 +36,19 @@ def _wide(r, c, seed=0):
     return torch.randn(r, c, device=DEV, generator=g) * torch.exp(3 * torch.randn(r, c, device=DEV, generator=g))
 
 
+def _weights(img, block_major):
+    """a row-major weight image in the layout under test (block-major: ops.P3 -- block fb is one contiguous [rows][96 bytes] run)"""
+    if not block_major:
+        return img
+    r, ldp = img.data.shape
+    return ops.P3(img.data.view(r, ldp // 96, 96).permute(1, 0, 2).contiguous(), img.rows, img.cols, block_major=True)
+
+
+@pytest.fixture(params=[False, True], ids=["w_row_major", "w_block_major"])
+def wlayout(request):
+    return request.param
+
+
 def _units(c, ref64, unit):
     return float(((c.double() - ref64).abs() / unit.clamp_min(1e-300)).max())
 
@@ -47,6 +60,36 @@ def test_p3_round_trip_is_exact(r, c):
     assert img.ldp == _lib.load().gte_p3_row_bytes(c) == 96 * ((c + 15) // 16)
     assert torch.equal(ops.p3_to_f32(img), x)
     assert torch.equal(ops.p3_to_f32(ops.p3_from_f32(x, transpose=True)), x.t())
+    # the block-major layout (weight images): the same 96-byte blocks, block fb of every row in one run
+    blk = ops.p3_from_f32(x, block_major=True)
+    assert blk.ldp == -96 * r and torch.equal(blk.data, _weights(img, True).data)
+    assert torch.equal(ops.p3_to_f32(blk), x)
+    assert torch.equal(ops.p3_to_f32(ops.p3_from_f32(x, transpose=True, block_major=True)), x.t())
+
+
+@pytest.mark.parametrize("m,n,k1,k2", [(500, 256, 256, 256), (24437, 256, 831, 831), (24437, 512, 256, 0), (333, 100, 40, 24), (3000, 200, 363, 363),
+                                       (4100, 48, 1030, 0), (2000, 1000, 256, 256)])
+def test_block_major_weights_give_the_same_bits(split_mode, m, n, k1, k2):
+    """every NT planes GEMM takes its B operand row-major or block-major (a negative ldp at the ABI): same products, same bits"""
+    g = torch.Generator(device=DEV).manual_seed(m + n + k1)
+    kp = -(-k1 // 16) * 16
+    a1 = ops.p3_from_f32(torch.randn(m, k1, device=DEV, generator=g))
+    a2 = ops.p3_from_f32(torch.randn(m, k2, device=DEV, generator=g)) if k2 else None
+    wb = torch.zeros(n, kp + k2, device=DEV)
+    wb[:, :k1] = torch.randn(n, k1, device=DEV, generator=g)
+    if k2:
+        wb[:, kp:] = torch.randn(n, k2, device=DEV, generator=g)
+    w = ops.p3_from_f32(wb)
+    bias = torch.randn(n, device=DEV, generator=g)
+    want = ops.gemm_p3_nt(a1, w, a2=a2, bias=bias)
+    assert torch.equal(ops.gemm_p3_nt(a1, _weights(w, True), a2=a2, bias=bias), want)
+    # ... written in place, half by half, as the engine's weight arrangements are (ops.P3.at)
+    img = ops.P3.empty(n, kp + k2, DEV, block_major=True)
+    img.data.zero_()
+    ops.p3_from_f32(wb[:, :kp].contiguous(), out=img)
+    if k2:
+        ops.p3_from_f32(wb[:, kp:].contiguous(), out=img, block0=kp // 16)
+    assert torch.equal(img.data, _weights(w, True).data)
 
 
 @pytest.mark.parametrize("m,n,k", [(100, 128, 16), (128, 128, 32), (300, 512, 831), (2000, 256, 256), (24437, 512, 831),
@@ -269,7 +312,7 @@ def test_tn_with_two_resident_images_behind_one_row_map(rows64, rows, k, m):
                                    (260, 256, 16)])
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("mapped", [False, True], ids=["dense", "rows2"])
-def test_nt_with_layernorm_forward_epilogue_is_bitwise_the_two_launches(rows64, ln_rows, m, n, k, relu, mapped):
+def test_nt_with_layernorm_forward_epilogue_is_bitwise_the_two_launches(rows64, ln_rows, wlayout, m, n, k, relu, mapped):
     """gte_gemm_p3_nt_ln_fwd / gte_gemm_p3_nt_rows2_ln_fwd: z = [a1 | a2] b^T + bias, the row statistics, y as fp32 and as a P3 image
     are bit for bit what gte_gemm_p3_nt (+ _rows2) followed by gte_ln_relu_fwd_p3 write; padding columns zero."""
     if rows64 and not mapped:
@@ -302,11 +345,12 @@ def test_nt_with_layernorm_forward_epilogue_is_bitwise_the_two_launches(rows64, 
     _lib.check(lib.gte_ln_relu_fwd_p3(P(z0), ld, P(gamma), P(beta), 1e-5, int(relu), P(y0), ld, P(yp0.data), yp0.ldp, P(st0), m, n,
                                       _lib.current_stream()), "ln_relu_fwd_p3")
     z1, y1, yp1, st1 = bufs()
-    ops.gemm_p3_nt_ln_fwd(a1, w, a2, bias, gamma, beta, 1e-5, relu, z1, y=y1, yp3=yp1, stats=st1)
+    wl = _weights(w, wlayout)              # (block-major: the block-major-weights kernel where it applies, gemm_p3_nt_sq_kernel)
+    ops.gemm_p3_nt_ln_fwd(a1, wl, a2, bias, gamma, beta, 1e-5, relu, z1, y=y1, yp3=yp1, stats=st1)
     assert torch.equal(z1, z0) and torch.equal(st1, st0) and torch.equal(y1, y0) and torch.equal(yp1.data, yp0.data)
     # image only (what the step asks for when the next layer takes an image)
     z2, _, yp2, st2 = bufs()
-    ops.gemm_p3_nt_ln_fwd(a1, w, a2, bias, gamma, beta, 1e-5, relu, z2, y=None, yp3=yp2, stats=st2)
+    ops.gemm_p3_nt_ln_fwd(a1, wl, a2, bias, gamma, beta, 1e-5, relu, z2, y=None, yp3=yp2, stats=st2)
     assert torch.equal(z2, z0) and torch.equal(yp2.data, yp0.data)
 
 
@@ -354,7 +398,7 @@ def test_row_maps_into_a_resident_image_above_4_gb():
 @pytest.mark.parametrize("m,n,k,relu", [(24437, 256, 256, True), (3000, 256, 256, False), (129, 128, 64, True), (1, 256, 256, True),
                                         (40000, 256, 128, True), (500, 144, 256, True), (40000, 256, 256, True), (80000, 256, 256, True),
                                         (80149, 96, 96, False)])
-def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(ln_rows, m, n, k, relu):
+def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(ln_rows, wlayout, m, n, k, relu):
     """gte_gemm_p3_nt_ln_bwd: dy = [dz1 | q1] [W_s^T | W_n^T]^T is never stored; dz0 (fp32 and image) must be bit for bit what
     gte_gemm_p3_nt + gte_ln_relu_bwd_p3 produce, the column sums agree to summation order."""
     g = torch.Generator(device=DEV).manual_seed(m + n)
@@ -377,6 +421,7 @@ def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(ln_rows
     # one launch
     dz, dzp = torch.full((m, n), 7.0, device=DEV), ops.P3.empty(m, n, DEV)
     dg, db, dbias = (torch.full((n,), 7.0, device=DEV) for _ in range(3))
+    wp = _weights(wp, wlayout)
     ops.gemm_p3_nt_ln_bwd(a1p, wp, a2p, z, stats, gam, bet, relu, dz, dzp, dg, db, dbias)
     assert torch.equal(dz, dz_ref)
     # image only (an input layer on the cached aggregate: its dW reads the image, nothing reads the fp32 rows)
@@ -391,7 +436,7 @@ def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(ln_rows
 
 @pytest.mark.parametrize("m,n,relu", [(24437, 218, True), (3000, 149, True), (5001, 206, False), (24437, 100, True), (777, 157, True),
                                       (260, 5, True), (2, 250, True)])
-def test_nt_with_layernorm_backward_epilogue_at_widths_that_are_not_multiples_of_16(ln_rows, m, n, relu):
+def test_nt_with_layernorm_backward_epilogue_at_widths_that_are_not_multiples_of_16(ln_rows, wlayout, m, n, relu):
     """The hidden widths the reference's runs use (218, 206, 157, 149, 100): rows of z / dz padded to 16 floats, the LayerNorm over
     the true width.  dz -- fp32 with its padding, and the image up to the next multiple of 16 columns -- bit for bit what
     gte_gemm_p3_nt + gte_ln_relu_bwd_p3 (the general-width kernel) produce; k = n as in the step (dX of the layer above)."""
@@ -422,7 +467,7 @@ def test_nt_with_layernorm_backward_epilogue_at_widths_that_are_not_multiples_of
     dzb, dzp = torch.zeros(m, ld, device=DEV), ops.P3.empty(m, n, DEV)
     dzp.data.fill_(0x55)                                       # the fused launch must write every column block of the image itself
     dg, db, dbias = (torch.full((n,), 7.0, device=DEV) for _ in range(3))
-    ops.gemm_p3_nt_ln_bwd(a1p, wp, a2p, z, stats, gam, bet, relu, dzb[:, :n], dzp, dg, db, dbias)
+    ops.gemm_p3_nt_ln_bwd(a1p, _weights(wp, wlayout), a2p, z, stats, gam, bet, relu, dzb[:, :n], dzp, dg, db, dbias)
     assert torch.equal(dzb, dz_ref)
     assert torch.equal(dzp.data, dzp_ref.data)
     assert float(dzb[:, n:].abs().sum()) == 0.0

@@ -235,6 +235,12 @@ def test_bench_line_keeps_the_driver_contract():
     assert ro["bound"] in ("hbm", "mfma") and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and "traffic" in ro
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert abs(rec["value"] - rec["config"]["nodes_per_step_per_gpu"] / (rec["ms_per_step"] * 1e-3)) < 0.05 * rec["value"]
+    # the roofline block describes ONE kernel -- the layer-0 forward GEMM [x | cached ahn] W^T, K = 2 x 831, N = 256 --, the other
+    # hidden layer's forward GEMM beside it; the work hoisted out of the timed step is named, and its cost measured (`uncached`)
+    n_step = rec["config"]["nodes_per_step_per_gpu"]
+    assert abs(ro["algorithmic_flops_per_launch"] - 2.0 * n_step * 1662 * 256) < 0.08 * 2.0 * n_step * 1662 * 256, ro
+    assert "layer-0" in ro["kernel"] and ro["layer1"]["algorithmic_flops_per_launch"] < ro["algorithmic_flops_per_launch"]
+    assert "input aggregate cached" in rec["config"]["workload"] and 0 < rec["uncached"] < 1.1 * rec["value"]
     # everything else: bench_extras.json next to bench.py (the full measurements, the same keys as before)
     d = json.load(open(os.path.join(root, rec["extras"])))
     assert abs(d["value"] - rec["value"]) <= 1e-6 * d["value"] and d["steps"] == 4
