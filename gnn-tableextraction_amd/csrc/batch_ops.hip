@@ -135,7 +135,7 @@ static int batch_assemble_impl(const int32_t* pages, int64_t n_batch, const int3
     // ~32 KB of feature rows per workgroup (at least one row): ~2 500 workgroups for a 100-page batch of 831-wide rows
     int64_t rows_per_wg = feat ? 32768 / (n_cols * 4) : 1;
     if (rows_per_wg < 1) rows_per_wg = 1;
-    static const int forced = getenv("GTE_ASSEMBLE_ROWS") ? atoi(getenv("GTE_ASSEMBLE_ROWS")) : 0;      // measurements only
+    static const int forced = GTE_MEASURE_INT("GTE_ASSEMBLE_ROWS", 0);
     if (forced > 0) rows_per_wg = forced;
     const int64_t feat_wgs = feat ? gte::ceil_div(n_out, rows_per_wg) : 0;
     // gte_batch_assemble_defer(1) and an open fold deferral on this stream (the caller is inside a training step, in front of its

@@ -331,8 +331,7 @@ gat_fold_kernel(const float* __restrict__ partial, int nblk, int HD, float* __re
 
 // GTE_GAT_ROWS=0 keeps the lane-per-feature kernels (A/B measurements)
 bool gat_rows_enabled() {                   // read per call: tests switch it inside one process
-    const char* e = getenv("GTE_GAT_ROWS");
-    return !(e && atoi(e) == 0);
+    return !GTE_MEASURE_OFF("GTE_GAT_ROWS");
 }
 
 int check_dims(int64_t n, int H, int D, const char* who) {

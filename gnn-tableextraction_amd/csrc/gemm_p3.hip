@@ -1470,9 +1470,9 @@ TnPlan tn_plan(int64_t M, int64_t N, int64_t Nseg, int64_t K) {
     const int64_t stages = gte::ceil_div(K > 0 ? K : 1, 16);
     // fill the resident slots exactly or stay below (a straggler round costs a whole unit time); >= 8 stages per split
     int64_t splits = slots / tiles;
-    static const int forced = getenv("GTE_P3_TN_SPLITS") ? atoi(getenv("GTE_P3_TN_SPLITS")) : 0;       // (measurement)
+    static const int forced = GTE_MEASURE_INT("GTE_P3_TN_SPLITS", 0);
     if (forced > 0) splits = forced;
-    static const int min_stages = getenv("GTE_P3_TN_MIN_STAGES") ? atoi(getenv("GTE_P3_TN_MIN_STAGES")) : 8;
+    static const int min_stages = GTE_MEASURE_INT("GTE_P3_TN_MIN_STAGES", 8);
     if (splits > stages / min_stages) splits = stages / min_stages;
     if (splits < 1) splits = 1;
     TnPlan pl;
@@ -1550,9 +1550,11 @@ extern "C" int gte_p3_to_f32(const void* src, int64_t ldp, int64_t rows, int64_t
 
 // Row maps: 32-bit buffer offsets reach images below 4 GB; larger ones are read through 64-bit per-lane addresses
 // (gte_gemm_p3_set_rows64(1) forces that path for any size: tests, A/B timing)
-static int g_rows64_mode = 0;
+// (the three forced configurations of this file -- rows64, the NT tile, the LayerNorm-epilogue row tile -- are THREAD-LOCAL test hooks:
+// they affect the calling host thread's launches only; the library keeps no mutable process-wide state besides the GEMM mode)
+static thread_local int g_rows64_mode = 0;
 static inline int rows64_needed(long long res_bytes) {
-    static const int env = getenv("GTE_P3_ROWS64") ? atoi(getenv("GTE_P3_ROWS64")) : 0;          // (A/B timing of the train loop)
+    static const int env = GTE_MEASURE_INT("GTE_P3_ROWS64", 0);          // (A/B timing of the train loop)
     return (g_rows64_mode == 1 || env == 1 || res_bytes >= ((long long)1 << 32) - 4096) ? 1 : 0;
 }
 extern "C" int gte_gemm_p3_set_rows64(int mode) {
@@ -1693,9 +1695,9 @@ constexpr NtCfg kNtCfg[] = {{0, 64, 128, 3}, {1, 128, 128, 2}, {2, 128, 256, 1},
 // forced tile configuration: -1 = the chooser; gte_gemm_p3_set_nt_cfg (tests force every configuration in ONE process; until round 5
 // this was a static getenv read once -- the per-configuration tests that set the variable after the first GEMM of the process ran
 // the chooser's pick every time) or GTE_P3_NT_CFG at the first call
-int g_nt_cfg = -2;
+thread_local int g_nt_cfg = -2;
 int nt_choose(const P3Gemm& p) {
-    if (g_nt_cfg == -2) g_nt_cfg = getenv("GTE_P3_NT_CFG") ? atoi(getenv("GTE_P3_NT_CFG")) : -1;
+    if (g_nt_cfg == -2) g_nt_cfg = GTE_MEASURE_INT("GTE_P3_NT_CFG", -1);
     const int forced = g_nt_cfg;
     if (forced >= 0 && forced <= 7) return forced;
     const int cus = gte::device_props().cus;
@@ -1712,6 +1714,7 @@ int nt_choose(const P3Gemm& p) {
     }
     return bi;
 }
+int lnb_row_tile(int64_t m);
 int launch_nt(const P3Gemm& p, hipStream_t s) {
     if (p.rowsA && p.rows64) {
         // a row map into an image of 4 GB or more: the two loader-wave tiles, whichever makes the shorter schedule
@@ -1720,6 +1723,17 @@ int launch_nt(const P3Gemm& p, hipStream_t s) {
         const int64_t r192 = gte::ceil_div(gte::ceil_div(p.M, 192) * gte::ceil_div(p.N, 256), cus) * 192;
         if (r192 < r128) launch_lw<2, 4, 3, 2, 4, true>(p, s); else launch_lw<2, 4, 2, 2, 4, true>(p, s);
         return gte::check_launch("gemm_p3_nt_rows");
+    }
+    if (g_nt_cfg == -2) g_nt_cfg = GTE_MEASURE_INT("GTE_P3_NT_CFG", -1);
+    if (g_nt_cfg < 0 && sq_applies(p) && p.N > 128) {
+        // block-major weights and one column of tiles more than half full: the block-major-weights kernel, on the smallest row tile
+        // that covers M in one round (the narrow-width input GEMMs of the scaled runs: 2 x 96 ... 2 x 128 columns over K = 781 / 831)
+        const int bm = lnb_row_tile(p.M);
+        if (bm == 32) launch_sq<1, 4, 0>(p, s);
+        else if (bm == 64) launch_sq<2, 4, 0>(p, s);
+        else if (bm == 96) launch_sq<3, 4, 0>(p, s);
+        else launch_sq<4, 4, 0>(p, s);
+        return gte::check_launch("gemm_p3_nt");
     }
     int cfg = nt_choose(p);
     switch (cfg) {
@@ -1752,12 +1766,12 @@ namespace {
 // ... and 64 / 32 rows (1 x 8 waves of 64 x 32 / 32 x 32) for batches that leave CUs idle even then: the launch lasts as long
 // as ONE tile's K loop whatever the number of tiles in the round (L0 forward, K = 1 662: 106 us on 50 tiles of 128 rows, 109 us
 // on 95, 124 us on 202 -- profiles/r05/sequence_pages*.txt), so a small batch wants the smallest tile that still is one round.
-int g_ln_rows = -1;                     // forced row tile of the LayerNorm-epilogue launches: 0 = the chooser (gte_gemm_p3_set_ln_rows)
+thread_local int g_ln_rows = -1;        // forced row tile of the LayerNorm-epilogue launches: 0 = the chooser (gte_gemm_p3_set_ln_rows)
 int lnb_row_tile(int64_t m) {
-    if (g_ln_rows < 0) g_ln_rows = getenv("GTE_P3_LN_ROWS") ? atoi(getenv("GTE_P3_LN_ROWS")) : 0;        // (measurement: 32 / 64 / 96 / 128)
+    if (g_ln_rows < 0) g_ln_rows = GTE_MEASURE_INT("GTE_P3_LN_ROWS", 0);        // (32 / 64 / 96 / 128)
     const int forced = g_ln_rows;
     if (forced == 32 || forced == 64 || forced == 96 || forced == 128) return forced;
-    static const int min_tile = getenv("GTE_P3_LN_MIN_ROWS") ? atoi(getenv("GTE_P3_LN_MIN_ROWS")) : 32;  // (measurement)
+    static const int min_tile = GTE_MEASURE_INT("GTE_P3_LN_MIN_ROWS", 32);
     const int64_t cus = gte::device_props().cus;
     for (int t = 32; t <= 96; t += 32)
         if (t >= min_tile && gte::ceil_div(m, t) <= cus) return t;

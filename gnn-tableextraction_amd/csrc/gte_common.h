@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/gte.h"
 
@@ -42,6 +43,18 @@ struct TailWorkspace { float* ptr; int64_t bytes; };
 TailWorkspace tail_workspace();
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Measurement switches.  The shipped library reads ONE environment variable (GTE_GEMM_MODE, documented in include/gte.h); every
+// other switch -- forced tile / block counts, kernel paths turned off for A/B runs -- exists only in the measurement build
+// (-DGTE_MEASURE: libgte_hip_measure.so of the Makefile, which tests/test_gpu_variants.py and the scripts under profiles/ load
+// through GTE_LIB_PATH).  In the shipped build the macros below are their default: no getenv, no name string in the binary.
+#ifdef GTE_MEASURE
+#define GTE_MEASURE_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define GTE_MEASURE_OFF(name) (getenv(name) && getenv(name)[0] == '0')       /* true: the switch turns its path OFF */
+#else
+#define GTE_MEASURE_INT(name, dflt) (dflt)
+#define GTE_MEASURE_OFF(name) (false)
+#endif
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
 }  // namespace gte

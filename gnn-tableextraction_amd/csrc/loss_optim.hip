@@ -404,7 +404,7 @@ extern "C" int gte_adam_step_dev_images(float* param, const float* grad, float* 
     if (rc != GTE_OK) return rc;
     // (round 5: workgroups of 256 -- one 16-byte group per thread up to 2 048 workgroups -- instead of <= 256 of 1 024: the launch is a
     // chain of dependent memory round trips plus scattered 2-byte image stores, more workgroups in flight shorten it)
-    static const int bt = getenv("GTE_ADAM_DEV_BLOCK") ? atoi(getenv("GTE_ADAM_DEV_BLOCK")) : 256;      // (measurement: 1024 = round 4)
+    static const int bt = GTE_MEASURE_INT("GTE_ADAM_DEV_BLOCK", 256);      // (1024 = round 4)
     const int threads = bt == 1024 ? 1024 : 256;
     const int64_t want = gte::ceil_div(n, 4 * (int64_t)threads), cap = threads == 1024 ? 256 : 2048;
     const int64_t blocks = want < cap ? want : cap;

@@ -830,7 +830,7 @@ int narrow_blocks(int64_t n) {
 // per_cu = 2: the form with the LayerNorm backward behind the dh product (round 5: 256 registers, two workgroups per CU -- 38.6 -> 34.3 us at
 // 24 k x 256 for +2.3 us of fold, profiles/r05/narrow_bwd_abl.txt)
 int narrow_mfma_blocks(int64_t n, int per_cu = 1) {
-    static const int forced = getenv("GTE_NARROW_BLOCKS") ? atoi(getenv("GTE_NARROW_BLOCKS")) : 0;      // (measurement)
+    static const int forced = GTE_MEASURE_INT("GTE_NARROW_BLOCKS", 0);
     const int want = gte::device_props().cus * per_cu;
     const int cap = forced > 0 && forced <= NB_MAX ? forced : (want < NB_MAX ? want : NB_MAX);
     const int64_t b = gte::ceil_div(n, 32);
@@ -841,7 +841,7 @@ int narrow_mfma_blocks(int64_t n, int per_cu = 1) {
 
 // 16-row-block forward (narrow_fwd_mfma16_kernel): F a multiple of 16; GTE_NARROW_FWD16=0 keeps the 32-row kernel (A/B)
 static bool narrow_fwd16(int64_t n_feat) {
-    static const bool on = !(getenv("GTE_NARROW_FWD16") && atoi(getenv("GTE_NARROW_FWD16")) == 0);
+    static const bool on = !GTE_MEASURE_OFF("GTE_NARROW_FWD16");
     return on && n_feat % 16 == 0;
 }
 

@@ -755,7 +755,7 @@ Plan make_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t Nseg = 0) {
         // split-K with very few output tiles (dW of a 256 x 256 layer: 4 tiles over 24 k nodes): smaller tiles ->
         // half the K splits -> half the slab bytes (measured 58 -> 44 us; at 14 tiles, 256 x 831, it loses: 147 -> 161)
         if (t128 <= 8 && M >= 64) pl.bm = 64;
-        static const int force_bm = getenv("GTE_GEMM_BM") ? atoi(getenv("GTE_GEMM_BM")) : 0;   // measurement only
+        static const int force_bm = GTE_MEASURE_INT("GTE_GEMM_BM", 0);
         if (force_bm == 64 || force_bm == 128) pl.bm = force_bm;
     }
     pl.tiles = (int)(gte::ceil_div(M, pl.bm) * (Nseg > 0 ? 2 * gte::ceil_div(Nseg, pl.bn) : gte::ceil_div(N, pl.bn)));
@@ -1501,7 +1501,7 @@ colsum_fold_kernel(const float* __restrict__ partial, int nblocks, int n, float*
 }
 
 int ln_bwd_blocks(int64_t M) {
-    static const int forced = getenv("GTE_LNB_BLOCKS") ? atoi(getenv("GTE_LNB_BLOCKS")) : 0;        // (measurement)
+    static const int forced = GTE_MEASURE_INT("GTE_LNB_BLOCKS", 0);
     const int cap = forced > 0 ? forced : LNB_MAX_BLOCKS;
     const int64_t b = gte::ceil_div(M, 4);
     return (int)(b < cap ? b : cap);
@@ -1649,7 +1649,7 @@ sage_smallk_fwd_kernel(const float* __restrict__ a1, int64_t lda1, int k1, const
 }
 
 bool smallk_supported(int64_t K, int64_t n_out) {
-    static const bool off = getenv("GTE_SMALLK") && getenv("GTE_SMALLK")[0] == '0';
+    static const bool off = GTE_MEASURE_OFF("GTE_SMALLK");
     return !off && K >= 1 && K <= SMALLK_MAX && n_out % 4 == 0 && n_out >= 4 && n_out <= 256;
 }
 

@@ -204,7 +204,7 @@ int skb_blocks(int64_t M) {
 }
 
 bool skb_supported(int64_t K, int64_t n_out) {
-    static const bool off = getenv("GTE_SMALLK_BWD") && getenv("GTE_SMALLK_BWD")[0] == '0';
+    static const bool off = GTE_MEASURE_OFF("GTE_SMALLK_BWD");
     return !off && K >= 1 && K <= SKB_KLIMIT && n_out % 4 == 0 && n_out >= 4 && n_out <= 256;
 }
 

@@ -177,7 +177,7 @@ inline int64_t ldz_of(const gte_step_layer& L) { return L.kind == GTE_LAYER_PLAN
 
 // backward of the output layer and of hidden layers n_hidden - 1 .. 1, and of layer 0 up to its weight-gradient GEMM
 int backward_a(const gte_step_plan& p, void* st) {
-    static const bool keep_dz0 = getenv("GTE_STEP_KEEP_DZ0") && atoi(getenv("GTE_STEP_KEEP_DZ0")) != 0;      // (measurement: round 5 before the skip)
+    static const bool keep_dz0 = GTE_MEASURE_INT("GTE_STEP_KEEP_DZ0", 0) != 0;      // (round 5 before the skip)
     const int64_t n = p.n_nodes, C = p.n_classes, lg = ld_lg(p);
     bool ln_done = false, smallk_done = false;
     const gte_step_layer& T = p.layer[p.n_hidden - 1];

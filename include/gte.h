@@ -430,7 +430,11 @@ int64_t gte_head_dlq_finish_workspace_bytes(int64_t n_nodes);
 int gte_head_dlq_finish(const int32_t* rindptr, const int32_t* rindices, const float* w_out, const float* dlq, int64_t lddlq,
                         int64_t n_nodes, int64_t n_classes, const void* ce_partial, float grad_scale, float* out3, void* dlqp3,
                         int64_t ldp, float* gbias, void* workspace, int64_t workspace_bytes, void* stream);
-/* Tile configuration of gte_gemm_p3_nt / _rows / _rows2: -1 = chosen per problem (default), 0 ... 7 = forced (tests run every
+/* The three setters below are TEST HOOKS with THREAD-LOCAL effect: they change what the calling host thread's later launches pick,
+ * nothing any other thread sees (the library keeps no mutable process-wide state besides the GEMM mode above).  Environment
+ * variables: the shipped library reads GTE_GEMM_MODE only; every other switch of earlier rounds lives in the measurement build
+ * (libgte_hip_measure.so, -DGTE_MEASURE: csrc/gte_common.h).
+ * Tile configuration of gte_gemm_p3_nt / _rows / _rows2: -1 = chosen per problem (default), 0 ... 7 = forced (tests run every
  * configuration against the same bits; 0 - 6 the 128- and 256-column tiles, 7 a measurement tile). */
 int gte_gemm_p3_set_nt_cfg(int cfg);
 /* Row tile of the launches with a LayerNorm epilogue (gte_gemm_p3_nt_ln_fwd / _rows2_ln_fwd / _ln_bwd; images below 4 GB): 0 = the

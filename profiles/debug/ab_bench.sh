@@ -1,9 +1,11 @@
 #!/bin/bash
+# (library switches live in the measurement build: both arms load it)
+export GTE_LIB_PATH=${GTE_LIB_PATH:-$(cd $(dirname $0)/../.. && pwd)/gnn-tableextraction_amd/libgte_hip_measure.so}
 # A/B of environment variants on the bench's train loop (headline + run shapes), interleaved on one box:
 #   bash profiles/debug/ab_bench.sh "GTE_CACHE_AGG=1" "GTE_CACHE_AGG=0"
 # prints value / ms_per_step / shapes per variant and round (bench_extras.json of each run is kept under gpurun_out/ab/)
 mkdir -p gpurun_out/ab
-FLAGS="--no-gather-probe --no-cfg3 --no-residency --no-size-sweep --no-inference --no-replay --val-graph 0 --no-cpu-baseline --no-split-probe --no-secondary --no-dist-probe ${AB_FLAGS}"
+FLAGS="--no-gather-probe --no-cfg3 --no-residency --no-uncached --no-size-sweep --no-inference --no-replay --val-graph 0 --no-cpu-baseline --no-split-probe --no-secondary --no-dist-probe ${AB_FLAGS}"
 for round in 1 2; do
   i=0
   for v in "$@"; do

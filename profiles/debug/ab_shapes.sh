@@ -1,7 +1,9 @@
 #!/bin/bash
+# (library switches live in the measurement build: both arms load it)
+export GTE_LIB_PATH=${GTE_LIB_PATH:-$(cd $(dirname $0)/../.. && pwd)/gnn-tableextraction_amd/libgte_hip_measure.so}
 # the run shapes of the reference under environment variants, interleaved on one box:
 #   bash profiles/debug/ab_shapes.sh "GTE_FUSE_LN_DX=1" "GTE_FUSE_LN_DX=0"      -> M nodes/s and ms/step per shape
-F="--no-cpu-baseline --no-gather-probe --no-cfg3 --no-replay --no-split-probe --no-inference --val-graph 0 --no-size-sweep --no-residency --long-run-seconds 0"
+F="--no-cpu-baseline --no-gather-probe --no-cfg3 --no-replay --no-split-probe --no-inference --val-graph 0 --no-size-sweep --no-residency --no-uncached --long-run-seconds 0"
 ROUNDS=${ROUNDS:-2}
 for r in $(seq 1 $ROUNDS); do
   for v in "$@"; do

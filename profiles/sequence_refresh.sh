@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --no-inference --no-shapes --no-size-sweep --no-residency --no-dist-probe --no-kernel-timers --val-graph 0 --long-run-seconds 0.1 --resident-pages 400"
+STEP_ONLY="--no-cpu-baseline --no-gather-probe --no-secondary --no-cfg3 --no-replay --no-split-probe --no-inference --no-shapes --no-size-sweep --no-residency --no-uncached --no-dist-probe --no-kernel-timers --val-graph 0 --long-run-seconds 0.1 --resident-pages 400"
 for sh in $SHAPES; do
   F=${sh%%:*}; H=${sh##*:}
   timeout 300 rocprofv3 --kernel-trace -d $O/seq_${F}_${H} -o t -- python3 $R/bench.py --in-feats $F --hidden $H $STEP_ONLY > $O/seq_f${F}_h${H}.log 2>&1

@@ -226,6 +226,23 @@ def test_bench_epoch_steps_follow_the_train_loop_plan():
     assert len(set(flat)) == len(flat) == 500                # an epoch never revisits a page
 
 
+def test_the_shipped_library_reads_one_environment_variable():
+    """no globals besides a read-only device-props cache.  The measurement switches of earlier rounds (17 getenv reads)
+    are compiled into libgte_hip_measure.so only; the shipped library holds the name of ONE variable, GTE_GEMM_MODE (include/gte.h),
+    and both builds export the same symbols."""
+    import re
+    import subprocess
+    lib = os.path.join(ROOT, "gnn-tableextraction_amd", "libgte_hip.so")
+    names = set(re.findall(rb"(?<![A-Z0-9_])GTE_[A-Z0-9_]{3,}(?=\x00)", open(lib, "rb").read()))
+    assert names == {b"GTE_GEMM_MODE"}, names
+    measure = os.path.join(ROOT, "gnn-tableextraction_amd", "libgte_hip_measure.so")
+    if os.path.exists(measure):
+        syms = lambda p: {l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True).stdout.splitlines()
+                          if " T " in l and l.split()[-1].startswith("gte_")}
+        assert syms(lib) == syms(measure) and len(syms(lib)) > 100
+        assert len(set(re.findall(rb"(?<![A-Z0-9_])GTE_[A-Z0-9_]{3,}(?=\x00)", open(measure, "rb").read()))) >= 15
+
+
 def test_no_kernel_of_the_library_spills():
     """Every kernel of libgte_hip.so keeps its working set in registers: ScratchSize == 0 in hipcc's kernel-resource-usage remarks
     (csrc/_build/*.ru, written by the Makefile next to every object; compiled here when the logs are missing).  Round 3 shipped

@@ -308,6 +308,32 @@ def test_the_kernel_timer_schedule_runs_on_the_loops_image_batches(f0, hid):
     assert np.isfinite(losses).all() and abs(losses[0] - losses[1]) < 2e-5, losses
 
 
+def _relu_branch_record(f0, hid, n_pages, cached, hit):
+    """How often the ReLU-mask branch of the test below is taken: gpurun_out/relu_branch.json (kept as profiles/r06/relu_branch.json) --
+    the test log keeps no stdout.  One entry per case; ``hits``: the tensors whose rows moved beyond 1e-4."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out")
+    if not os.path.isdir(d):
+        return
+    path = os.path.join(d, "relu_branch.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        rec = {}
+    key = f"f{f0}_h{hid}_p{n_pages}_{'cached' if cached else 'nocache'}"
+    e = rec.setdefault(key, {"runs": 0, "branch_taken": 0, "hits": []})
+    if hit is None:
+        e["runs"] += 1
+        e["_counted"] = False
+    else:
+        if not e.get("_counted"):
+            e["branch_taken"] += 1
+            e["_counted"] = True
+        e["hits"].append({"tensor": hit[0], "entries": hit[1], "rows": hit[2]})
+    json.dump(rec, open(path, "w"), indent=1)
+
+
 @pytest.mark.parametrize("cached", [True, False], ids=["cached_agg", "no_cache"])
 @pytest.mark.parametrize("f0,hid,n_pages", [(831, 256, 100), (831, 96, 40), (63, 1000, 16), (13, 218, 40), (831, 1000, 12), (781, 100, 40),
                                             (313, 157, 40), (63, 206, 40), (363, 1000, 12)])
@@ -360,6 +386,7 @@ def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages, cached):
     assert seen["n"] == n and fused.adam_fused_steps == 1
     assert abs(float(out3[0]) - want_loss) < 1e-5
     flipped = {}
+    _relu_branch_record(f0, hid, n_pages, cached, None)          # (the case ran; the branch count is filled in below)
     for k, p in model.named_parameters():
         got, ref = fused._gslice[id(p)].cpu().numpy(), want_grads[k]
         bad = ~np.isclose(got, ref, rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(ref).max())
@@ -371,6 +398,7 @@ def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages, cached):
             # (the feature's entry of the bias / LayerNorm gradients moves with it)
             rows = np.unique(np.nonzero(bad)[0])
             print(f"ReLU-mask branch: ({f0}, {hid}) {k}: {int(bad.sum())} entries in rows {rows.tolist()} beyond 1e-4")
+            _relu_branch_record(f0, hid, n_pages, cached, (k, int(bad.sum()), rows.tolist()))
             assert rows.size <= 3 and np.abs(got - ref)[rows].max() <= 1e-3 * np.abs(ref).max(), \
                 f"{k}: {int(bad.sum())} entries in {rows.size} rows differ (max {np.abs(got - ref).max():.3e})"
     params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
@@ -388,6 +416,57 @@ def test_the_loop_bench_times_matches_the_oracle_step(f0, hid, n_pages, cached):
     hyb = poststep.hybrid_state(want_state, params, g_eff)
     ref_after = oc.gcnsage_forward(hyb, og, xt).numpy()
     assert np.abs(after - ref_after).max() < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["split_bf16", "f32"])
+@pytest.mark.parametrize("f0,hid", [(831, 256), (13, 218)])
+def test_the_loop_follows_the_oracle_over_eight_steps(f0, hid, mode):
+    """A TRAJECTORY of the loop ``train()`` and ``bench.py`` run (reference model_train.py:283-340: forward, CE, backward, Adam, next
+    batch) against the CPU oracle: eight consecutive DIFFERENT 40-page batches through ONE ``run_steps`` call with the default
+    switches -- resident images + row maps, cached input aggregate where the plan takes it, the next batch assembled inside the fold
+    launch, Adam (t = 1 ... 8) and the next step's weight images written by the fold launch -- against eight ``OracleTrainer.step``
+    calls on the same batches.  The loss of every step within 1e-4 of the oracle's, the logits of a held-out batch after the eight
+    steps within 1e-3 (every single-step test starts from equal parameters; here steps 2 ... 8 start from the loop's OWN state)."""
+    from gnn_tableextraction_amd.models.engine import FusedGcnSageStep
+    from gnn_tableextraction_amd.models.loop import BatchPipeline, run_steps
+    prev = ops.set_gemm_mode(mode)
+    try:
+        n_steps, per = 8, 40
+        pages = S.make_pages(n_steps * per + per, in_feats=f0)
+        rng = np.random.default_rng(5)
+        order = rng.permutation(n_steps * per)
+        steps = [np.sort(order[i * per:(i + 1) * per]) for i in range(n_steps)]
+        held = np.arange(n_steps * per, n_steps * per + per)
+        torch.manual_seed(42)
+        model = gte.GcnSAGE(f0, hid, 9, 3, torch.nn.functional.relu, 0)
+        state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        tr_o = oc.OracleTrainer(state0, lr=0.01, weight_decay=5e-4)
+        want = []
+        for ids in steps:
+            src, dst, w, feat, label, off = S.concat_pages([pages[i] for i in ids])
+            loss, _ = tr_o.step(oc.OracleGraph(src, dst, int(off[-1]), w), torch.from_numpy(feat), torch.from_numpy(label))
+            want.append(loss)
+        src, dst, w, feat, label, off = S.concat_pages([pages[i] for i in held])
+        want_held = oc.gcnsage_forward({k: v.detach() for k, v in tr_o.state.items()}, oc.OracleGraph(src, dst, int(off[-1]), w),
+                                       torch.from_numpy(feat)).numpy()
+
+        model = model.to(DEV)
+        fused = FusedGcnSageStep(model, lr=0.01, weight_decay=5e-4)
+        res = _resident(pages, fused, f0)
+        pipe = BatchPipeline(res)
+        got = []
+        out3 = run_steps(fused, pipe, steps, on_step=lambda s, g, o: got.append(o.clone()))
+        torch.cuda.synchronize()
+        got = [float(o[0]) for o in got]
+        assert len(got) == n_steps
+        if mode == "split_bf16" and f0 == 831:
+            assert res.p3_mode == "rows" and res.agg_p3 is not None and fused.adam_fused_steps == n_steps     # the default switches
+        assert np.isfinite(got).all() and want[0] > want[-1]   # (it trains)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+        after = fused.forward_logits(res.batch(held)).cpu().numpy()
+        np.testing.assert_allclose(after, want_held, rtol=0, atol=1e-3)
+    finally:
+        ops.set_gemm_mode(prev)
 
 
 @pytest.mark.parametrize("n,C", [(24437, 9), (300, 16), (1, 3), (257, 9)])

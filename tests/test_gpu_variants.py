@@ -4,8 +4,9 @@ three configurations -- the headline layout on resident image batches with class
 run shape (aggregate-first input layer, padded hidden width, output layer on the planes GEMMs) -- must give the default run's
 losses to 1e-5 and its parameters to the conditioning of Adam's first steps.
 
-Switches read by the Python engine are set in-process; switches the library reads once per process (static getenv in csrc/)
-run the same function in a child process."""
+Switches read by the Python engine are set in-process; switches the LIBRARY reads exist in the measurement build only
+(libgte_hip_measure.so, -DGTE_MEASURE: the shipped library reads GTE_GEMM_MODE and nothing else) and are read once per process: the
+same function runs in a child process that loads that build through GTE_LIB_PATH."""
 import json
 import os
 import subprocess
@@ -98,6 +99,9 @@ def test_library_switch_gives_the_default_runs_results(tmp_path, switch):
     for kv in switch.split():
         k, v = kv.split("=")
         env[k] = v
+    measure = os.path.join(ROOT, "gnn-tableextraction_amd", "libgte_hip_measure.so")
+    assert os.path.exists(measure), "the measurement build is missing: make -C gnn-tableextraction_amd/csrc all"
+    env["GTE_LIB_PATH"] = measure
     path = str(tmp_path / "out.npz")
     code = ("import sys, numpy as np; sys.path.insert(0, %r); from tests.test_gpu_variants import train_three_steps as t; r = t(); "
             "np.savez(%r, **{k + '.loss': v[0] for k, v in r.items()}, **{k + '.param': v[1] for k, v in r.items()})" % (ROOT, path))
