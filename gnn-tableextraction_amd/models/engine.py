@@ -946,7 +946,11 @@ class FusedGcnSageStep(TrainStep):
             self._wimg_sig = sig
         self._keep = (lab,) + tuple(keep)                              # alive until the next step
         # (the data-parallel step's own Adam launch writes the same images: gte_adam_step_dev_images)
-        self._last_wimg = (plan.wimg_descs, int(plan.n_wimg_descs), b["_wkey"], _arr) if not capturing else None
+        # (kept only while an UNFUSED optimiser launch may still follow this very step -- a step whose fold launch already ran Adam
+        # must not leave descriptors behind for a later launch of another plan; the tuple keeps the descriptor array AND the image
+        # tensors it points into alive)
+        self._last_wimg = ((plan.wimg_descs, int(plan.n_wimg_descs), b["_wkey"], _arr, dict(self._wimg))
+                           if not capturing and not (fused.value & 1) else None)
         return b["out3"]
 
     FORWARD_IMAGE_MAX_ELEMS = 1 << 21     # forward_logits: largest fp32 feature matrix that is converted to an image per call
@@ -956,6 +960,7 @@ class FusedGcnSageStep(TrainStep):
         [n, n_classes] through ONE host call (gte_gcnsage_forward) on the step's own buffers -- a view that the next step or
         forward on this engine overwrites.  Configurations the one-call plan does not cover -- and large graphs that bring fp32
         features to a planes input layer (a validation graph: the plan would write their image first) -- run the module path."""
+        self._last_wimg = None
         xp = getattr(g, "feat_p3", None)
         n, f0 = (xp.rows, xp.cols) if xp is not None else g.ndata['feat'].shape
         kinds = self._plan_kinds(f0, n, self._batch_cached(g)) if n > 0 else None
@@ -1000,6 +1005,7 @@ class FusedGcnSageStep(TrainStep):
     def _run(self, g, labels, grad_scale, hi, lo, forward):
         lib, P, check = self.lib, _lib.ptr, _lib.check
         self._wimg_sig = None                         # (this schedule converts the weight images in front of every forward)
+        self._last_wimg = None                        # (... and no later optimiser launch may rewrite another plan's images)
         st = _lib.current_stream()
         timed = ops._timed
         xp = getattr(g, "feat_p3", None)              # resident batches in image mode bring the features as a P3 image only

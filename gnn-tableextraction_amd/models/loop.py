@@ -104,11 +104,26 @@ class BatchPipeline:
         if self._pin2[k] is None or self._pin2[k].numel() < total:
             self._pin2[k] = torch.empty(max(total, 4096), dtype=torch.int32).pin_memory()
         self._pinned = self._pin2[k]
-        if self._meta_dev is None or self._meta_dev.numel() < total:
+        # ... and two DEVICE tables, used alternately as well: the upload of this load() goes into the table the load() before the
+        # previous one used, whose assemblies were queued a whole load() ago -- it waits (on the side stream) for an event that has
+        # long passed instead of for everything queued on the caller's stream up to now (round 5: one full host-to-device latency
+        # per window chunk of a host-resident set, in front of the next step)
+        if getattr(self, "_meta2", None) is None:
+            self._meta2, self._meta_done = [None, None], [None, None]
+        cur = torch.cuda.current_stream(self.device)
+        if self._meta_dev is not None and self._meta2[k ^ 1] is self._meta_dev:
+            # every assembly that reads the previous load()'s table has been queued by now: the mark its next overwrite waits for
+            self._meta_done[k ^ 1] = torch.cuda.Event()
+            self._meta_done[k ^ 1].record(cur)
+        if self._meta2[k] is None or self._meta2[k].numel() < total:
+            if self._meta_done[k] is not None:
+                self._meta_done[k].synchronize()                 # (a larger device table: the old one may still be read)
             if self._meta_ev is not None:
-                self._meta_ev.synchronize()                      # (a larger device table: the old one may still be read)
-            self._meta_dev = torch.empty(max(self._pinned.numel(), total), dtype=torch.int32, device=self.device)
-            self._meta_dev.record_stream(self.side)              # (read on the side stream too: no reuse under it once dropped)
+                self._meta_ev.synchronize()
+            self._meta2[k] = torch.empty(max(self._pinned.numel(), total), dtype=torch.int32, device=self.device)
+            self._meta2[k].record_stream(self.side)              # (read on the side stream too: no reuse under it once dropped)
+            self._meta_done[k] = None
+        self._meta_dev = self._meta2[k]
         stage = self._pinned.numpy()
         off = 0
         cap = [0, 0, 0]
@@ -126,13 +141,11 @@ class BatchPipeline:
             torch.cuda.synchronize(self.device)         # (the resident pages changed mode: rare; no ordering left to think about)
             self._free_ev = [None] * self.depth
         self._same = same
-        # the side stream runs in order: assemblies queued earlier read the old metadata before this copy overwrites it -- those
-        # queued on the caller's stream through one event
-        if self._same and self._meta_ev is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self.side.wait_event(ev)
-        self._meta_pending = True
+        # the side stream runs in order: assemblies queued there earlier read their table before a later copy overwrites it; those
+        # queued on the caller's stream are covered by the mark recorded one load() ago (above)
+        if self._meta_done[k] is not None:
+            self.side.wait_event(self._meta_done[k])
+        self._meta_pending = self._same                  # (side mode: the assemblies run behind the upload on the side stream itself)
         with torch.cuda.stream(self.side):
             self._meta_dev[:total].copy_(self._pinned[:total], non_blocking=True)
             self._meta_ev = torch.cuda.Event()

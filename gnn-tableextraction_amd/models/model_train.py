@@ -118,6 +118,23 @@ def evaluate(model, graph, labels, class_weights=None, engine=None):
 LAST_RUN = None          # {"model", "step", "rank", "world"} of the last train() call in this process
 
 
+def _check_layout(saved, now, path):
+    """A resumed run must stand on the residency layout of the run it continues: tier, ranks, windows, passes (they fix the order the
+    pages are visited in).  A checkpoint written before round 6 has no layout: it resumes only onto the all-resident tier."""
+    if saved is None:
+        if now['tier'] != "all":
+            raise RuntimeError(f"checkpoint '{path}' records no residency layout (written before round 6) and this run takes the "
+                               f"'{now['tier']}' tier: the position of its page stream cannot be restored.  Set GTE_RESIDENT_BUDGET_GB so "
+                               f"that the set is resident, or restart the run.")
+        return
+    keys = ('tier', 'world', 'passes', 'batch_size', 'ranges')
+    diff = [k for k in keys if saved.get(k) != now.get(k)]
+    if diff:
+        raise RuntimeError(f"checkpoint '{path}' was written under another residency layout ({', '.join(f'{k}: {saved.get(k)!r}'[:80] for k in diff)}; now "
+                           f"{', '.join(f'{k}: {now.get(k)!r}'[:80] for k in diff)}): the resumed page stream would not continue the interrupted one.  "
+                           f"Run with the interrupted run's GTE_RESIDENT_BUDGET_GB ({saved.get('budget_gb')}), GTE_WINDOW_PASSES and world size.")
+
+
 def train(data, config, name_time=None):
     rank, local_rank, world = D.env_world()
     distributed = world > 1
@@ -175,6 +192,7 @@ def train(data, config, name_time=None):
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(_lr_holder, 'min', factor=0.5)
 
     start_epoch = 0
+    ck_layout = None                  # the interrupted run's residency layout (budget, tier, windows): a resumed run must reproduce it
     ckpt_path = os.path.join(ckpt_dir, logs)
     if config.GENERAL.from_checkpoint and os.path.isfile(ckpt_path):
         # our own checkpoint (written below): a dict of tensors + python scalars + the metrics dict, hence weights_only=False
@@ -183,6 +201,7 @@ def train(data, config, name_time=None):
         model.load_state_dict(ck['state_dict'])             # parameters are views of the flat buffer: copies in place
         load_adam_state_dict(step, model, ck['optimizer'])
         metrics = AttrDict(ck['metrics'])
+        ck_layout = ck.get('residency')
         _lr_holder.param_groups[0]['lr'] = step.lr
         say(f"=> loaded checkpoint '{ckpt_path}' (epoch {start_epoch})")
 
@@ -193,7 +212,8 @@ def train(data, config, name_time=None):
         page_wsum = [float(np.asarray(cw, dtype=np.float64)[g.ndata['label'].long().numpy()].sum()) for g in train_graphs]
     # GTE_RESIDENT_BUDGET_GB: HBM the training pages may take per rank.  A set that fits is kept whole in HBM (below); a larger one
     # stays in pinned host memory and a window of it is resident (models/residency.py).
-    # Unset: derived from the free HBM of this rank's device when the set does not fit (residency.default_budget_bytes).
+    # Unset: derived from the TOTAL HBM of this rank's device when the set does not fit (residency.default_budget_bytes); a resumed
+    # run takes the interrupted run's budget from the checkpoint.
     from . import residency as R
     all_nodes = np.array([g.num_nodes() for g in train_graphs], dtype=np.int64)
     all_edges = np.array([g.num_edges() for g in train_graphs], dtype=np.int64)
@@ -201,19 +221,20 @@ def train(data, config, name_time=None):
     want_agg = want_p3 and bool(getattr(step, "wants_agg_image", lambda f: False)(in_feats))      # (the cached aggregate of the input)
     set_bytes = float(all_nodes.sum()) * R.WindowedPages.bytes_per_node(all_nodes, all_edges, in_feats, want_p3, want_agg)
     budget_gb = float(os.environ.get("GTE_RESIDENT_BUDGET_GB", "0") or 0)
-    if budget_gb <= 0 and torch.device(device).type == 'cuda':
+    if budget_gb <= 0 and ck_layout is not None:
+        # a resumed run takes the budget the interrupted run ran under: the budget fixes the tier and the windows, those fix the
+        # order the pages are visited in (and which pages a rank owns) -- st.skip() below is only meaningful on the same layout
+        budget_gb = float(ck_layout.get('budget_gb') or 0)
+    elif budget_gb <= 0 and torch.device(device).type == 'cuda':
+        # derived from the device's TOTAL memory, never from what happens to be free at launch (round 5 did: the data order of a
+        # default run then depended on what other processes held at that moment); a device that is short of the derived budget
+        # fails at allocation, loudly
         free_b, total_b = torch.cuda.mem_get_info(device)
-        derived = R.default_budget_bytes(set_bytes, float(free_b), float(total_b))
-        if distributed:
-            # one decision for all ranks (their free memory differs by a few MB): the smallest budget, "none" only if none needs one
-            import torch.distributed as dist
-            t_ = torch.tensor([derived if derived is not None else float('inf')], dtype=torch.float64, device=device)
-            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
-            derived = None if not np.isfinite(float(t_.item())) else float(t_.item())
+        derived = R.default_budget_bytes(set_bytes, float(total_b))
         if derived is not None:
             budget_gb = derived / 1e9
-            say(f"DATA: {set_bytes / 1e9:.1f} GB of training pages against {free_b / 1e9:.1f} GB of free HBM: budget {budget_gb:.1f} GB "
-                f"(set GTE_RESIDENT_BUDGET_GB to choose)")
+            say(f"DATA: {set_bytes / 1e9:.1f} GB of training pages against {total_b / 1e9:.1f} GB of HBM: budget {budget_gb:.1f} GB "
+                f"(set GTE_RESIDENT_BUDGET_GB to choose; {free_b / 1e9:.1f} GB are free now)")
     # Three tiers under a budget: (i) the set fits it -> all resident on every rank (the plan deals every step's pages to the
     # ranks by node count: distributed.plan_epoch); (ii) a rank's share -- the pages it OWNS, set / world -- fits -> the rank holds
     # its own pages for good and plans over them; (iii) otherwise the own pages stay in pinned host memory, a window is resident.
@@ -253,9 +274,21 @@ def train(data, config, name_time=None):
         lost = sum(len(st.never_visited()) for st in streams)
         if lost:
             say(f"DATA: {lost} training pages lie in windows smaller than one batch of {batch_size} pages and are never visited")
+        if tier == "windowed":
+            # what this tier changes against the reference's loop, said once (model_train.py:279-283 shuffles ALL training pages
+            # every epoch and visits each once per epoch): here a rank draws its batches from ONE window of its pages at a time
+            # and stays on it for `passes` shuffled passes before the next window is uploaded -- the same arithmetic per step, a
+            # different sampling order (GTE_WINDOW_PASSES=1 restores one visit per page and epoch at the host link's rate)
+            say(f"DATA: windowed residency -- {len(wp.ranges)} windows per rank, {passes} shuffled passes over a window per visit; "
+                f"the sample order DIFFERS from the reference's epoch (model_train.py:279-283: every page once per epoch, one shuffle over "
+                f"the whole set): a page is seen {passes} times while its window is resident, then not until the windows come round again; "
+                f"pages never visited: {lost}.  GTE_WINDOW_PASSES=1 keeps the reference's one visit per epoch (host-link bound).")
+        layout = {'budget_gb': float(budget_gb), 'tier': tier, 'world': int(world), 'passes': int(passes), 'batch_size': int(batch_size),
+                  'ranges': [[[int(a), int(b)] for a, b in st.ranges] for st in streams]}
         if start_epoch:
             # a resumed run continues every rank's stream where the interrupted run stood (its position is a function of the steps
-            # taken, as plan_epoch's plan is a function of the epoch)
+            # taken, as plan_epoch's plan is a function of the epoch) -- on the SAME layout only
+            _check_layout(ck_layout, layout, ckpt_path)
             for st in streams:
                 st.skip(start_epoch * steps_per_epoch)
         wp.prefetch(streams[rank].peek_window())
@@ -271,6 +304,9 @@ def train(data, config, name_time=None):
     else:
         # all training pages concatenated ONCE in HBM (features, labels, both CSRs, CSR-ordered weights); a batch is
         # four kernel launches of index arithmetic instead of dgl.batch(...).to(device) per step (:297)
+        layout = {'budget_gb': float(budget_gb), 'tier': tier, 'world': int(world), 'passes': None, 'batch_size': int(batch_size), 'ranges': None}
+        if start_epoch:
+            _check_layout(ck_layout, layout, ckpt_path)
         resident = G.ResidentPages(train_graphs, device)
         pipe = BatchPipeline(resident)          # a step's batch is assembled on a side stream while the step before it runs
         sizes = resident.page_sizes()
@@ -385,7 +421,7 @@ def train(data, config, name_time=None):
                 os.makedirs(ckpt_dir, exist_ok=True)
                 torch.save({'epoch': epoch + 1,
                             'state_dict': {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
-                            'optimizer': adam_state_dict(step, model), 'metrics': dict(metrics)}, ckpt_path)
+                            'optimizer': adam_state_dict(step, model), 'metrics': dict(metrics), 'residency': layout}, ckpt_path)
     finally:
         gc.unfreeze()          # a library entry point must not leave the caller's objects in the permanent generation
 

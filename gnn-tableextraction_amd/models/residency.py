@@ -465,11 +465,12 @@ class OwnedResident:
         pass
 
 
-def default_budget_bytes(set_bytes: float, free_bytes: float, total_bytes: float) -> Optional[float]:
+def default_budget_bytes(set_bytes: float, total_bytes: float) -> Optional[float]:
     """The HBM budget of the training pages when GTE_RESIDENT_BUDGET_GB is not set: None (keep the whole set resident) while the
-    set fits in 60 % of what is free now -- while the images are made the fp32 rows are still there (a third more than the resident
-    form), and the rest is for the validation graph, the step's per-batch buffers (a few GB at hidden 1000) and the allocator's
-    slack --, otherwise half of the free memory (two window slots + staging rows)."""
-    if set_bytes <= 0.6 * free_bytes:
+    set fits in half of the device's memory -- while the images are made the fp32 rows are still there (a third more than the
+    resident form), and the rest is for the validation graph, the step's per-batch buffers (a few GB at hidden 1000) and the
+    allocator's slack --, otherwise 45 % of it (two window slots + staging rows).  A function of the device's TOTAL memory: what
+    other processes hold at launch must not change the tier, the windows and with them the order the pages are visited in."""
+    if set_bytes <= 0.5 * total_bytes:
         return None
-    return 0.5 * free_bytes
+    return 0.45 * total_bytes

@@ -21,6 +21,7 @@ python3 profiles/pmc_traffic_summary.py $O/full $O/pmc_per_kernel.json > $O/pmc_
 python3 profiles/pmc_traffic_summary.py $O/step $O/pmc_per_kernel_step.json > $O/pmc_per_kernel_step.txt
 python3 profiles/pmc_traffic_summary.py $O/step_split $O/pmc_per_kernel_step_split.json > $O/pmc_per_kernel_step_split.txt
 NPS=$(grep -h "^PMC_STEP" $O/pmc_step_split_FETCH_SIZE.log | tail -1 | awk '{print $5}')
-python3 profiles/make_pmc_traffic.py $O/pmc_per_kernel_step.json $O/pmc_per_kernel.json $O/pmc_traffic.json $O/pmc_per_kernel_step_split.json 4 ${NPS:-0} > /dev/null
+NST=$(grep -h "^PMC_STEP" $O/pmc_step_split_FETCH_SIZE.log | tail -1 | awk '{print $3}')       # the steps the driver really ran
+python3 profiles/make_pmc_traffic.py $O/pmc_per_kernel_step.json $O/pmc_per_kernel.json $O/pmc_traffic.json $O/pmc_per_kernel_step_split.json ${NST:-4} ${NPS:-0} > /dev/null
 rm -rf $O/full $O/step $O/step_split
 cat $O/pmc_per_kernel_step.txt | head -20; cat $O/pmc_per_kernel.txt | head -5

@@ -29,7 +29,7 @@ def fresh():
     m = gte.GcnSAGE(F0, 256, 9, 3, torch.nn.functional.relu, 0).to(dev)
     return FusedGcnSageStep(m, lr=0.01, weight_decay=5e-4)
 tr = fresh()
-want_p3 = tr.wants_p3_features(F0)
+want_p3 = bool(tr.wants_resident_images(F0))        # (what train(), run_steps and predict_resident decide with)
 t0 = time.perf_counter()
 host = R.HostPages(graphs, dev)
 build_s = time.perf_counter() - t0

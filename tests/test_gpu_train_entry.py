@@ -43,7 +43,9 @@ def test_train_writes_reference_layout_and_learns(tmp_path):
     assert set(res) == {"train_loss", "train_acc", "val_loss", "val_acc", "cell_f1", "header_f1"}
     assert metrics.val.loss < np.log(9.0)                              # better than uniform
     ck = torch.load(tmp_path / "checkpoints" / logs, weights_only=False)
-    assert ck["epoch"] == 4 and set(ck) == {"epoch", "state_dict", "optimizer", "metrics"}
+    # (the reference's four keys + `residency`: the layout a resumed run must reproduce -- budget, tier, ranks, windows)
+    assert ck["epoch"] == 4 and set(ck) == {"epoch", "state_dict", "optimizer", "metrics", "residency"}
+    assert ck["residency"]["tier"] == "all" and ck["residency"]["world"] == 1 and ck["residency"]["ranges"] is None
     assert sorted(ck["state_dict"]) == ["layers.0.linear.bias", "layers.0.linear.weight", "layers.0.lynorm.bias",
                                         "layers.0.lynorm.weight", "layers.1.linear.bias", "layers.1.linear.weight",
                                         "layers.1.lynorm.bias", "layers.1.lynorm.weight", "layers.2.linear.bias",

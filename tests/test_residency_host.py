@@ -132,10 +132,26 @@ def test_window_stream_skip_lands_where_take_would():
 
 
 def test_default_budget_keeps_a_fitting_set_resident_and_windows_a_larger_one():
+    """A function of the device's TOTAL memory (round 5 derived it from the free memory at launch: the tier, the windows and with them
+    the data order of a default run then depended on what other processes held at that moment)."""
     GB = 1e9
-    assert R.default_budget_bytes(100 * GB, 280 * GB, 288 * GB) is None          # fits in 60 % of the free HBM: all resident
-    assert R.default_budget_bytes(165 * GB, 280 * GB, 288 * GB) is None
-    assert R.default_budget_bytes(175 * GB, 280 * GB, 288 * GB) == 140 * GB
-    b = R.default_budget_bytes(500 * GB, 280 * GB, 288 * GB)                     # PubLayNet's full train split at F0 = 831
-    assert b == 140 * GB
-    assert R.default_budget_bytes(10 * GB, 12 * GB, 288 * GB) == 6 * GB          # a device that is mostly taken already
+    assert R.default_budget_bytes(100 * GB, 288 * GB) is None                    # fits in half of the HBM: all resident
+    assert R.default_budget_bytes(144 * GB, 288 * GB) is None
+    assert R.default_budget_bytes(150 * GB, 288 * GB) == 0.45 * 288 * GB
+    assert R.default_budget_bytes(500 * GB, 288 * GB) == 0.45 * 288 * GB         # PubLayNet's full train split at F0 = 831
+
+
+def test_a_resumed_run_must_stand_on_the_interrupted_runs_layout():
+    """The checkpoint records the residency layout (budget, tier, ranks, passes, window ranges of every rank); resuming under another one
+    -- where the page stream's position means something else -- fails loudly instead of training on a different stream."""
+    from gnn_tableextraction_amd.models.model_train import _check_layout
+    lay = {'budget_gb': 12.0, 'tier': 'windowed', 'world': 2, 'passes': 8, 'batch_size': 100, 'ranges': [[[0, 500], [500, 900]], [[0, 450], [450, 900]]]}
+    _check_layout(dict(lay), dict(lay), "ck")                                    # the same layout: fine
+    _check_layout(dict(lay, budget_gb=11.9), dict(lay), "ck")                    # (the budget itself may differ while it yields the same windows)
+    for change in ({'tier': 'owned'}, {'world': 4}, {'passes': 1}, {'ranges': [[[0, 900]], [[0, 900]]]}, {'batch_size': 50}):
+        with pytest.raises(RuntimeError, match="another residency layout"):
+            _check_layout(dict(lay), dict(lay, **change), "ck")
+    # a checkpoint from before round 6 (no layout) resumes onto the all-resident tier only
+    _check_layout(None, {'tier': 'all', 'world': 1, 'passes': None, 'batch_size': 100, 'ranges': None, 'budget_gb': 0.0}, "ck")
+    with pytest.raises(RuntimeError, match="records no residency layout"):
+        _check_layout(None, dict(lay), "ck")
