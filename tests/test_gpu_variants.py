@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENGINE_SWITCHES = ["GTE_C_STEP=0", "GTE_P3_ROWS=0", "GTE_FUSE_ADAM=0", "GTE_TAIL_SPLIT=0", "GTE_FUSED_HEAD=0", "GTE_TRANSFORM_FIRST=0",
                    "GTE_PIPE_LATE=0", "GTE_FUSE_LN_FWD=0", "GTE_FUSE_LN_DX=0", "GTE_FUSE_LN_NARROW=0", "GTE_FUSE_SMALLK_DX=0",
                    "GTE_WIMG_IN_FOLD=0", "GTE_CACHE_AGG=0", "GTE_PLANES=0", "GTE_PLANES_GENERAL=0", "GTE_FUSE_HEAD_GEMM=0", "GTE_C_STEP=0 GTE_FUSE_LN_DX=0",
-                   "GTE_C_STEP=0 GTE_FUSE_LN_NARROW=0", "GTE_PIPE_SIDE=1", "GTE_PIPE_SIDE=0", "GTE_PIPE_SIDE=1 GTE_PIPE_LATE=0", "GTE_PIPE_RIDE=0"]
+                   "GTE_C_STEP=0 GTE_FUSE_LN_NARROW=0", "GTE_PIPE_SIDE=1", "GTE_PIPE_SIDE=0", "GTE_PIPE_SIDE=1 GTE_PIPE_LATE=0", "GTE_PIPE_RIDE=0", "GTE_WIMG_BLOCK_MAJOR=0"]
 LIBRARY_SWITCHES = ["GTE_SMALLK=0", "GTE_SMALLK_BWD=0", "GTE_NARROW_FWD16=0", "GTE_GEMM_MODE=f32", "GTE_P3_ROWS64=1", "GTE_P3_LN_ROWS=128",
                     "GTE_P3_LN_ROWS=64"]
 CONFIGS = [(831, 256, True), (13, 256, False), (63, 200, False)]      # (F0, hidden, class weights)
