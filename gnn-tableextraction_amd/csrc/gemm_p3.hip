@@ -962,8 +962,9 @@ gemm_p3_nt_lw_kernel(const P3Gemm p) {
 //     runs requested a K block at a time fetch every line twice -- 50 GB/s per CU against 82 for whole lines).
 //   * ONE barrier per slot (64 k) instead of one per 16 k: inside a slot the two compute waves of a SIMD drift apart and one's
 //     fragment reads hide under the other's MFMAs.
-// K segments are cut into slots separately (a slot never straddles [a1 | a2]); the last slot of a segment may hold fewer than SQ
-// blocks: the missing ones are multiplied as zeros (the launcher takes this kernel when that wastes little).
+// The K blocks of [a1 | a2] form one list cut into slots (a slot may straddle the segments: every request picks its segment's
+// window); the LAST slot may hold fewer than SQ blocks: the missing ones are multiplied as zeros (the launcher takes this kernel
+// when that pads K by at most 1 / 12).
 // Bit-identical to the kernels above: the same six products per fragment pair in the same order, K blocks in the same order.
 template <int TM, int NL, int LNB = 0, int SQ = 4>
 __global__ void __launch_bounds__((8 + NL) * 64, (8 + NL + 3) / 4)
@@ -983,8 +984,8 @@ gemm_p3_nt_sq_kernel(const P3Gemm p) {
     const unsigned lb = gte_xcd_remap(blockIdx.x, gridDim.x);
     const int tm = (int)(lb / (unsigned)tiles_n), tn = (int)(lb % (unsigned)tiles_n);
     const int m0 = tm * BM, n0 = tn * BN;
-    const int KB1 = p.KB1, KB2 = p.KB2, T = KB1 + KB2;
-    const int S1 = (KB1 + SQ - 1) / SQ, S = S1 + (KB2 + SQ - 1) / SQ;
+    const int KB1 = p.KB1, T = p.KB1 + p.KB2;
+    const int S = (T + SQ - 1) / SQ;                                       // slots over the K blocks of [a1 | a2] as ONE list
 
     if (wave >= NW) {
         // ---------------- loader ----------------
@@ -1010,23 +1011,24 @@ gemm_p3_nt_sq_kernel(const P3Gemm p) {
                 if (p.rows_both) vo2[g] = rr < 0 ? OOB : (int)((unsigned)rr * (unsigned)lda2 + (unsigned)(sp * 16));
             }
         });
+        // a slot's K blocks t = SQ s .. SQ s + SQ - 1 of the list; block t lives in segment (t >= KB1) at block t - KB1 (or t): a
+        // slot may straddle the two segments -- each request picks its segment's window -- and only the LAST slot can be short
+        const __amdgpu_buffer_rsrc_t sa1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseA1), 0, recA1, SRD_FLAGS);
+        const __amdgpu_buffer_rsrc_t sa2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseA2), 0, recA2, SRD_FLAGS);
         auto issue = [&](int s, char* slot) {
-            const bool seg = s >= S1;
-            const int kb0 = (seg ? s - S1 : s) * SQ, kbs = seg ? KB2 : KB1;
-            const int live = s < S ? 1 : 0;
-            const char* pa = seg ? baseA2 + (long long)kb0 * 96 : baseA1 + (long long)kb0 * 96;
-            const __amdgpu_buffer_rsrc_t sa =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (seg ? recA2 : recA1) * live, SRD_FLAGS);
             static_for<NG>([&](auto GI) {
                 constexpr int g = decltype(GI)::value;
                 const int gi = g * NL + lw;
-                const int vo = seg ? vo2[g] : vo1[g];
                 static_for<SQ>([&](auto QI) {
                     constexpr int q = decltype(QI)::value;
 #if P3_ABL & 1
                     if (s >= 2) return;
 #endif
-                    dma16(sa, gi < G ? slot + q * BLK + gi * 1024 : scratch, (kb0 + q < kbs && vo != OOB) ? vo + q * 96 : OOB);
+                    const int t = s * SQ + q;
+                    const bool seg = t >= KB1;
+                    const int vo = seg ? vo2[g] : vo1[g];
+                    dma16(seg ? sa2 : sa1, gi < G ? slot + q * BLK + gi * 1024 : scratch,
+                          (t < T && vo != OOB) ? vo + (seg ? t - KB1 : t) * 96 : OOB);
                 });
             });
         };
@@ -1094,12 +1096,11 @@ gemm_p3_nt_sq_kernel(const P3Gemm p) {
 #endif
         __builtin_amdgcn_sched_barrier(0);                                  // (no fragment reads hoisted over a whole block: registers)
     };
-    // slot s holds K blocks kfirst(s) .. kfirst(s) + nvalid(s) - 1 of the weight image; the blocks a segment's last slot lacks are
-    // multiplied as zeros (the loader's requests for them leave the window: zeros in LDS; the weight fragments: load_b): ONE slot
-    // body without branches -- with a second, branching copy for short slots the compiler moved all 48 accumulators through
-    // copies at the join and spilled the fragment ring
-    auto kfirst = [&](int s) { return s >= S1 ? KB1 + (s - S1) * SQ : s * SQ; };
-    auto nvalid = [&](int s) { return s >= S ? 0 : min(SQ, (s >= S1 ? T : KB1) - kfirst(s)); };
+    // slot s holds K blocks SQ s .. of the list (= of the weight image); the blocks the LAST slot lacks are multiplied as zeros (the
+    // loader's requests for them leave the window: zeros in LDS; the weight fragments: load_b): ONE slot body without branches -- with
+    // a second, branching copy for a short slot the compiler moved all 48 accumulators through copies at the join and spilled the ring
+    auto kfirst = [&](int s) { return s * SQ; };
+    auto nvalid = [&](int s) { return s >= S ? 0 : min(SQ, T - s * SQ); };
     int k0 = 0, nv = nvalid(0);
     load_b(bq[0], 0, 0 < nv);
     load_b(bq[1], 1, 1 < nv);
@@ -1663,11 +1664,14 @@ void launch_lw_lnb(const P3Gemm& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_p3_nt_lw_kernel<WM, WN, TM, TN, NL, LNB, BIG>), grid, dim3((WM * WN + NL) * 64), shm, s, p);
 }
 // The block-major-weights kernel takes a product when the weights ARE block-major, the rows are reached through 32-bit offsets, one
-// column of tiles covers the output, and cutting each K segment into slots of four blocks pads the K loop by at most 1 / 12
+// column of tiles covers the output, and cutting the K blocks into slots of four pads the K loop by at most 1 / 12 ...
 inline bool sq_applies(const P3Gemm& p) {
     if (p.ldb != 96 || p.bsb < 96 || p.rows64 || p.N > 256 || p.bsa1 != 96 || p.bsa2 != 96) return false;
-    const int T = p.KB1 + p.KB2, S4 = 4 * ((p.KB1 + 3) / 4 + (p.KB2 + 3) / 4);
-    return (S4 - T) * 12 <= T;
+    // ... and K is at least 32 blocks deep: below that the slots' longer pipeline fill (four K blocks before the first MFMA) costs what
+    // the loop gains -- dX + LayerNorm backward at K = 2 x 13 / 2 x 14 blocks: 42.9 -> 44.5 / 44.2 -> 45.2 us; at 32 blocks 57.3 -> 50.4,
+    // at 52 blocks 56.6 -> 52.0, at 104 blocks 122 -> 108 (profiles/r06/sequence_*.txt)
+    const int T = p.KB1 + p.KB2, S4 = 4 * ((T + 3) / 4);
+    return T >= 32 && (S4 - T) * 12 <= T;
 }
 // the block-major-weights kernel (gemm_p3_nt_sq_kernel): (32 TM) x 256 tiles
 template <int TM, int NL, int LNB>
