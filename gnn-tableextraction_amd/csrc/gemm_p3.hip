@@ -675,6 +675,26 @@ __device__ __forceinline__ void lw_epilogue(const f32x16 (&acc)[TM][TN], char* l
         }
         const float inv_n = 1.0f / (float)n;
         const int col_l = lane & 31, hrow = (lane >> 5) * 4;
+        constexpr int RF = 4;                                           // rows a wave works on at a time
+        // One row slice per tile (WM == 1: the 1 x 8 wave layouts): the z rows and statistics of ALL the wave's rows are requested
+        // here, before the accumulators go to LDS -- 4 TM rows in flight per wave under the tile write and its two barriers, instead
+        // of TM rounds of four rows with a memory latency each (one workgroup per CU: the memory-level parallelism of this phase is
+        // all there is)
+        // (up to 96-row tiles: at 128 rows the 16 x 6 registers beside the 64 accumulators spill)
+        constexpr bool PRE = WM == 1 && SR / NW <= 12;
+        constexpr int RPW = PRE ? SR / NW : 1;                          // rows of the tile per wave
+        float zpre[RPW][4], mpre[RPW], rpre[RPW];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                const int rg = m0 + wave + k * NW;
+                const int rc = rg < M ? rg : min(m0, M - 1);
+                f4u zt; zt.x = zt.y = zt.z = zt.w = 0.f;
+                if (okc) zt = *reinterpret_cast<const f4u*>(p.ln_z + (long long)rc * p.ln_ldz + j4);
+                zpre[k][0] = zt.x; zpre[k][1] = zt.y; zpre[k][2] = zt.z; zpre[k][3] = zt.w;
+                mpre[k] = p.ln_stats[rc]; rpre[k] = p.ln_stats[M + rc];
+            }
+        }
         for (int sl = 0; sl < WM; ++sl) {
             asm volatile("s_barrier" ::: "memory");                    // the previous slice's readers are done
             if (wm == sl) {
@@ -688,9 +708,11 @@ __device__ __forceinline__ void lw_epilogue(const f32x16 (&acc)[TM][TN], char* l
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int row_base = m0 + sl * SR;
-            constexpr int RF = 4;                                       // rows in flight per wave (one workgroup per CU: the
-                                                                        // memory-level parallelism of this phase is all there is)
-            for (int rl = wave; rl < SR; rl += RF * NW) {
+            constexpr int ROUNDS = (SR + RF * NW - 1) / (RF * NW);
+#pragma unroll
+            for (int rd = 0; rd < ROUNDS; ++rd) {
+                const int rl = wave + rd * RF * NW;
+                if (rl >= SR) break;
                 float gy[RF][4], zz[RF][4], mean[RF], rstd[RF];
                 bool rok[RF];
 #pragma unroll
@@ -701,12 +723,21 @@ __device__ __forceinline__ void lw_epilogue(const f32x16 (&acc)[TM][TN], char* l
                     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bz = a;
                     if (okc) {
                         if (rok[u]) a = *reinterpret_cast<const float4*>(tile + rloc * LDT + j4);
-                        const f4u zt = *reinterpret_cast<const f4u*>(p.ln_z + (long long)rc * p.ln_ldz + j4);
-                        bz = make_float4(zt.x, zt.y, zt.z, zt.w);
+                        if constexpr (!PRE) {
+                            const f4u zt = *reinterpret_cast<const f4u*>(p.ln_z + (long long)rc * p.ln_ldz + j4);
+                            bz = make_float4(zt.x, zt.y, zt.z, zt.w);
+                        }
                     }
                     gy[u][0] = a.x; gy[u][1] = a.y; gy[u][2] = a.z; gy[u][3] = a.w;
-                    zz[u][0] = bz.x; zz[u][1] = bz.y; zz[u][2] = bz.z; zz[u][3] = bz.w;
-                    mean[u] = p.ln_stats[rc]; rstd[u] = p.ln_stats[M + rc];
+                    if constexpr (PRE) {
+                        const int k = rd * RF + u;                      // (constant after unrolling: k < RPW because RF divides RPW)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) zz[u][e] = zpre[k < RPW ? k : 0][e];
+                        mean[u] = mpre[k < RPW ? k : 0]; rstd[u] = rpre[k < RPW ? k : 0];
+                    } else {
+                        zz[u][0] = bz.x; zz[u][1] = bz.y; zz[u][2] = bz.z; zz[u][3] = bz.w;
+                        mean[u] = p.ln_stats[rc]; rstd[u] = p.ln_stats[M + rc];
+                    }
                 }
                 float dd[RF][4];
 #pragma unroll
