@@ -1110,10 +1110,12 @@ gemm_p3_nt_sq_kernel(const P3Gemm p) {
             });
         });
 #if P3_ABL & 8
-        static_for<3>([&](auto PL) {
-            static_for<TM>([&](auto A) { asm volatile("" ::"v"(fa[decltype(PL)::value][decltype(A)::value])); });
-            asm volatile("" ::"v"(b[decltype(PL)::value]));
-        });
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) asm volatile("" ::"v"(fa[pl][a]));
+            asm volatile("" ::"v"(b[pl]));
+        }
 #else
         // the six piece products, smallest terms first (products<>()): hl, lh, mm, hm, mh, hh
         constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};

@@ -11,6 +11,12 @@ done
 [ -x $O/l0_16 ] && ABL_ROWS=128 timeout 120 $O/l0_16 gemm
 [ -x $O/l0_16 ] && ABL_ROWS=128 timeout 120 $O/l0_16 gemm 104
 [ -x $O/l0_17 ] && ABL_ROWS=128 timeout 120 $O/l0_17 gemm 104
+echo "# the block-major-weights kernel (gemm_p3_nt_sq_kernel) on the same problem; first: element by element against the kernel above"
+[ -x $O/l0_16 ] && ABL_REF=1 ABL_SQ=1 timeout 120 $O/l0_16 gemm
+for a in 17 24 48; do [ -x $O/l0_$a ] && ABL_SQ=1 timeout 120 $O/l0_$a gemm; done
+[ -x $O/l0_16 ] && ABL_SQ=1 ABL_ZERO=1 timeout 120 $O/l0_16 gemm
+[ -x $O/l0_16 ] && ABL_SQ=1 ABL_ROWS=128 timeout 120 $O/l0_16 gemm 104
+[ -x $O/l0_16 ] && ABL_BBLK=1 timeout 120 $O/l0_16 gemm
 echo
 timeout 300 $O/l0_0 dma
 } 2>&1 | tee gpurun_out/l0_fwd_ablation.txt

@@ -22,7 +22,8 @@ cd $R
 python3 profiles/rocpd_summary.py $(ls $O/trace_f32/*.db | head -1) $O/f32_step_kernel_stats.csv > /dev/null
 python3 profiles/rocpd_summary.py $(ls $O/trace_13/*.db | head -1) $O/f13_step_kernel_stats.csv > /dev/null
 timeout 200 python3 profiles/debug/gemm_p3_check.py > $O/gemm_p3_check.txt 2>&1
-for c in 1 2 3 4 5 6; do GTE_P3_NT_CFG=$c timeout 200 python3 profiles/debug/gemm_p3_nt_cfg.py 2>&1 | grep -v "amdgpu.ids\|bitwise" >> $O/gemm_p3_nt_cfg.txt; done
+MLIB=$R/gnn-tableextraction_amd/libgte_hip_measure.so      # (forced tile configurations: a switch of the measurement build)
+for c in 1 2 3 4 5 6; do GTE_LIB_PATH=$MLIB GTE_P3_NT_CFG=$c timeout 200 python3 profiles/debug/gemm_p3_nt_cfg.py 2>&1 | grep -v "amdgpu.ids\|bitwise" >> $O/gemm_p3_nt_cfg.txt; done
 timeout 200 python3 profiles/debug/gemm_step_shapes.py > $O/gemm_step_shapes.txt 2>&1
 timeout 300 python3 profiles/debug/gemm_split_check.py > $O/gemm_split_check.txt 2>&1
 python3 profiles/rocpd_summary.py $(ls $O/trace/*.db | head -1) $O/final_kernel_stats.csv > /dev/null
@@ -34,10 +35,13 @@ bash profiles/shapes_refresh.sh $TAG > /dev/null
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_val -o t -- python3 $R/profiles/val_forward.py > $O/val_forward.log 2>&1)
 python3 profiles/rocpd_summary.py $(ls $O/trace_val/*.db | head -1) $O/val_forward_kernel_stats.csv > /dev/null; rm -rf $O/trace_val
 timeout 300 python3 profiles/gemm_p3_big_m.py 2> /dev/null > $O/gemm_p3_big_m.txt
-for c in 2 4 5; do GTE_P3_NT_CFG=$c timeout 300 python3 profiles/gemm_p3_big_m.py 2> /dev/null >> $O/gemm_p3_big_m.txt; done
+for c in 2 4 5; do GTE_LIB_PATH=$MLIB GTE_P3_NT_CFG=$c timeout 300 python3 profiles/gemm_p3_big_m.py 2> /dev/null >> $O/gemm_p3_big_m.txt; done
 timeout 300 python3 profiles/debug/residency_probe_alone.py 2> /dev/null > $O/residency_alone.txt
 timeout 300 python3 profiles/residency_trace.py 3000 4 2.5 2> /dev/null | grep -v "^chunk" | head -12 > $O/residency_trace.txt
 [ -x profiles/micro/stream_bw ] && timeout 60 ./profiles/micro/stream_bw 2048 > $O/stream_bw.txt
 [ -x profiles/micro/copy_variants ] && timeout 60 ./profiles/micro/copy_variants 2048 > $O/copy_variants.txt
+# round 6: the ablation table of the layer-0 forward kernels (binaries built by profiles/debug/l0_abl_build.sh travel with the tree)
+[ -x profiles/micro/l0abl/l0_16 ] && bash profiles/debug/l0_abl_run.sh > /dev/null 2>&1 && cp gpurun_out/l0_fwd_ablation.txt $O/l0_fwd_ablation.txt
+bash profiles/sequence_refresh.sh $TAG "831:256 831:96 13:218 831:1000 363:149" > /dev/null 2>&1
 rm -rf $O/trace $O/trace_step $O/trace_f32 $O/trace_13
 du -sh $O; tail -c 300 $O/bench.json
