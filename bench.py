@@ -204,7 +204,8 @@ def cpu_baseline(args, host_batch, state):
                       f"{len(src)} edges, F0={args.in_feats}); aggregation = "
                       f"{'OpenMP CSR SpMM' if oc.omp_available() else 'torch.sparse_csr'}, "
                       f"dense ops = torch CPU ({torch.get_num_threads()} threads)",
-            "sample_short": f"{len(times)} train steps (median) on one {int(off[-1])}-node batch of the workload, {time.time() - t_all:.0f} s",
+            "sample_short": (f"{len(times)} train steps (median) on ONE {int(off[-1])}-node batch of the workload repeated (warm caches; the GPU "
+                             f"loop assembles a different batch every step), {time.time() - t_all:.0f} s"),
             "ms_per_step": med * 1e3}
 
 
@@ -1365,9 +1366,11 @@ def main():
                                                            "algorithmic_flops_per_launch": fwd_ev[4][1] / max(fwd_ev[0], 1),
                                                            "frac": fwd_ev[4][1] / max(fwd_ev[3][1], 1e-9) / 1e9 / gemm_peak},
                     "layer_tflops": None if fwd_ev is None else [fwd_ev[4][i] / max(fwd_ev[3][i], 1e-9) / 1e9 for i in range(2)],
-                    "traffic": pmc_traffic()[0].get(("gemm_nt_p3_bytes_per_launch" if trainer._planes_on() else "gemm_nt_split_bytes_per_launch")
-                                                    if split_mode else "gemm_nt_bytes_per_launch")
-                               if args.in_feats == 831 else None,
+                    # (HBM-side bytes of THE kernel `achieved` describes: the layer-0 forward family of the committed PMC passes)
+                    "traffic": (pmc_traffic()[0].get(("gemm_nt_ln_fwd_p3_bytes_per_launch" if (kinds_hl is not None and kinds_hl[0] == 3) else
+                                                      "gemm_nt_p3_bytes_per_launch") if trainer._planes_on() else "gemm_nt_split_bytes_per_launch")
+                                if split_mode else pmc_traffic()[0].get("gemm_nt_bytes_per_launch"))
+                               if (args.in_feats, args.hidden) == (831, 256) else None,
                     "traffic_source": pmc_traffic()[1]}
         per_kernel = {}
         for tag, (n, tms, work) in kt.items():

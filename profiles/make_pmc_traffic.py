@@ -15,7 +15,7 @@ out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pa
                  "profiles/pmc_probe.py spmm (cfg4); bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of "
                  "the kernel family (FETCH_SIZE x2: gfx950 counts the 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md HBM "
                  "section); the counters sit on the L2's memory side, so Infinity-Cache hits are included.  Scripts: profiles/refresh.sh, "
-                 "pmc_traffic_summary.py, make_pmc_traffic.py", "round": 5}
+                 "pmc_traffic_summary.py, make_pmc_traffic.py", "round": 6}
 for tag, pred in (("gemm_nt", lambda k: "gemm_f32_mfma_kernel<true, true" in k), ("gemm_tn", lambda k: "gemm_f32_mfma_kernel<false, false" in k),
                   ("gemm_nn", lambda k: "gemm_f32_mfma_kernel<true, false" in k), ("batch_assemble", lambda k: "batch_assemble" in k),
                   ("spmm_csr", lambda k: k.startswith("spmm_csr_kernel"))):
@@ -30,9 +30,14 @@ if len(sys.argv) > 4:
     # (dX with the LayerNorm-backward epilogue is its own family)
     import re
     # (the loader-wave NT kernel whose sixth template argument -- the epilogue -- is 1 or 3: LayerNorm backward)
-    lnb = lambda k: re.search(r"gemm_p3_nt_lw_kernel<\d+[,;] \d+[,;] \d+[,;] \d+[,;] \d+[,;] [13][,;>]", k) is not None
-    for tag, pred in (("gemm_nt", lambda k: "gemm_p3_nt" in k and not lnb(k)), ("gemm_tn", lambda k: "gemm_p3_tn" in k),
-                      ("gemm_nt_ln_bwd", lnb)):
+    # (round 6: the block-major-weights kernel gemm_p3_nt_sq_kernel<TM, NL, LNB, SQ> carries the epilogue as its THIRD argument)
+    def epi(k):
+        m = re.search(r"gemm_p3_nt_lw_kernel<\d+[,;] \d+[,;] \d+[,;] \d+[,;] \d+[,;] (\d+)[,;>]", k) or re.search(r"gemm_p3_nt_sq_kernel<\d+[,;] \d+[,;] (\d+)[,;>]", k)
+        return int(m.group(1)) if m else (0 if "gemm_p3_nt" in k else None)
+    lnb = lambda k: epi(k) in (1, 3)
+    lnf = lambda k: epi(k) == 4                      # the layer-0 forward on [x | cached ahn] with LayerNorm + ReLU: the DOMINANT kernel
+    for tag, pred in (("gemm_nt", lambda k: "gemm_p3_nt" in k and not lnb(k) and not lnf(k)), ("gemm_tn", lambda k: "gemm_p3_tn" in k),
+                      ("gemm_nt_ln_bwd", lnb), ("gemm_nt_ln_fwd", lnf)):
         b, n = fam(split, pred)
         out[f"{tag}_p3_bytes_per_launch"], out[f"{tag}_p3_launches_sampled"] = b, n
     for tag, pat in (("batch_assemble_p3", "batch_assemble"), ("ln_relu_bwd_p3", "ln_relu_bwd_vec_kernel"), ("fold_adam", "gte_fold_batch_kernel")):
