@@ -397,12 +397,12 @@ def test_row_maps_into_a_resident_image_above_4_gb():
 # ---- the backward GEMM with the LayerNorm backward of the layer below as its epilogue ---------------------------------------
 @pytest.mark.parametrize("m,n,k,relu", [(24437, 256, 256, True), (3000, 256, 256, False), (129, 128, 64, True), (1, 256, 256, True),
                                         (40000, 256, 128, True), (500, 144, 256, True), (40000, 256, 256, True), (80000, 256, 256, True),
-                                        (80149, 96, 96, False), (3000, 256, 296, True), (24437, 160, 1000, False)])
+                                        (80149, 96, 96, False), (3000, 256, 304, True), (24437, 160, 1008, False)])
 def test_nt_with_layernorm_backward_epilogue_is_bitwise_the_two_launches(ln_rows, wlayout, m, n, k, relu):
     """gte_gemm_p3_nt_ln_bwd: dy = [dz1 | q1] [W_s^T | W_n^T]^T is never stored; dz0 (fp32 and image) must be bit for bit what
-    gte_gemm_p3_nt + gte_ln_relu_bwd_p3 produce, the column sums agree to summation order.  (k = 296: 19 + 19 K blocks -- with
+    gte_gemm_p3_nt + gte_ln_relu_bwd_p3 produce, the column sums agree to summation order.  (k = 304: 19 + 19 K blocks -- with
     block-major weights a 64-deep slot of the block-major-weights kernel straddles the two K segments and the last slot is short;
-    k = 1000: 126 blocks, the H = 1000 shapes' depth.)"""
+    k = 1008: 126 blocks, the H = 1000 shapes' depth.)"""
     g = torch.Generator(device=DEV).manual_seed(m + n)
     rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
     a1, a2, w = rnd(m, k), rnd(m, k), rnd(n, 2 * k) / 16
