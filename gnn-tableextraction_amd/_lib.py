@@ -127,6 +127,7 @@ SIGNATURES = {
                                             c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                             c_void_p, c_int64, c_int64, c_void_p]),
     "gte_gemm_p3_set_rows64": (c_int, [c_int]),
+    "gte_gemm_p3_nt_plan": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     "gte_gemm_p3_set_nt_cfg": (c_int, [c_int]),
     "gte_gemm_p3_set_ln_rows": (c_int, [c_int]),
     "gte_batch_assemble_defer": (c_int, [c_int]),

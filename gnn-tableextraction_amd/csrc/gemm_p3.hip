@@ -1706,6 +1706,8 @@ inline bool sq_applies(const P3Gemm& p) {
     const int T = p.KB1 + p.KB2, S4 = 4 * ((T + 3) / 4);
     return T >= 32 && (S4 - T) * 12 <= T;
 }
+// ... a PLAIN product (no LayerNorm epilogue) additionally wants its one column of tiles more than half full
+inline bool sq_plain_wanted(const P3Gemm& p) { return p.N > 128; }
 // the block-major-weights kernel (gemm_p3_nt_sq_kernel): (32 TM) x 256 tiles
 template <int TM, int NL, int LNB>
 void launch_sq(const P3Gemm& p, hipStream_t s) {
@@ -1751,6 +1753,12 @@ int nt_choose(const P3Gemm& p) {
     }
     return bi;
 }
+// the smallest of 32 / 64 / 96 rows that covers m in ONE round of workgroups, else 128
+inline int one_round_row_tile(int64_t m, int64_t cus, int min_tile = 32) {
+    for (int t = 32; t <= 96; t += 32)
+        if (t >= min_tile && gte::ceil_div(m, t) <= cus) return t;
+    return 128;
+}
 int lnb_row_tile(int64_t m);
 int launch_nt(const P3Gemm& p, hipStream_t s) {
     if (p.rowsA && p.rows64) {
@@ -1762,7 +1770,7 @@ int launch_nt(const P3Gemm& p, hipStream_t s) {
         return gte::check_launch("gemm_p3_nt_rows");
     }
     if (g_nt_cfg == -2) g_nt_cfg = GTE_MEASURE_INT("GTE_P3_NT_CFG", -1);
-    if (g_nt_cfg < 0 && sq_applies(p) && p.N > 128) {
+    if (g_nt_cfg < 0 && sq_applies(p) && sq_plain_wanted(p)) {
         // block-major weights and one column of tiles more than half full: the block-major-weights kernel, on the smallest row tile
         // that covers M in one round (the narrow-width input GEMMs of the scaled runs: 2 x 96 ... 2 x 128 columns over K = 781 / 831)
         const int bm = lnb_row_tile(p.M);
@@ -1787,6 +1795,24 @@ int launch_nt(const P3Gemm& p, hipStream_t s) {
 }
 }  // namespace
 
+// Which kernel family an NT product with ONE column of tiles takes (pure host logic: no device call when `cus` > 0).  Returns 1 for
+// the block-major-weights kernel (gemm_p3_nt_sq_kernel), 0 for the loader-wave / ring kernels; *row_tile = rows of its tile where
+// the launch picks one by the one-round rule (the LayerNorm-epilogue launches and the narrow plain products), else 0.
+extern "C" int gte_gemm_p3_nt_plan(int64_t m, int64_t n, int64_t k1, int64_t k2, int weights_block_major, int epilogue, int cus,
+                                   int* row_tile) {
+    if (row_tile) *row_tile = 0;
+    if (m <= 0 || n <= 0 || k1 <= 0 || k2 < 0 || (epilogue != 0 && epilogue != 1 && epilogue != 3 && epilogue != 4))
+        return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_nt_plan: bad arguments (epilogue: 0 plain, 1 / 3 LayerNorm backward, 4 LayerNorm forward)");
+    P3Gemm p = {};
+    p.M = (int)m; p.N = (int)n; p.KB1 = (int)p3::blocks(k1); p.KB2 = (int)p3::blocks(k2);
+    p.bsa1 = p.bsa2 = 96;
+    p.ldb = weights_block_major ? 96 : (p.KB1 + p.KB2) * 96; p.bsb = weights_block_major ? gte::round_up(n, 16) * 96 : 96;
+    const int bm = one_round_row_tile(m, cus > 0 ? cus : gte::device_props().cus);
+    const bool sq = sq_applies(p) && (epilogue != 0 || sq_plain_wanted(p));
+    if (row_tile && n <= 256 && (epilogue != 0 || sq)) *row_tile = bm;
+    return sq ? 1 : 0;
+}
+
 extern "C" int gte_gemm_p3_set_nt_cfg(int cfg) {
     if (cfg < -1 || cfg > 7) return gte::fail(GTE_ERR_INVALID_ARGUMENT, "gemm_p3_set_nt_cfg: -1 (chooser) or a configuration id 0 ... 7");
     g_nt_cfg = cfg;
@@ -1809,10 +1835,7 @@ int lnb_row_tile(int64_t m) {
     const int forced = g_ln_rows;
     if (forced == 32 || forced == 64 || forced == 96 || forced == 128) return forced;
     static const int min_tile = GTE_MEASURE_INT("GTE_P3_LN_MIN_ROWS", 32);
-    const int64_t cus = gte::device_props().cus;
-    for (int t = 32; t <= 96; t += 32)
-        if (t >= min_tile && gte::ceil_div(m, t) <= cus) return t;
-    return 128;
+    return one_round_row_tile(m, gte::device_props().cus, min_tile);
 }
 // out[j] = sum_k part[k * stride + j]   (only when no fold deferral is open)
 __global__ void __launch_bounds__(256)

@@ -430,6 +430,13 @@ int64_t gte_head_dlq_finish_workspace_bytes(int64_t n_nodes);
 int gte_head_dlq_finish(const int32_t* rindptr, const int32_t* rindices, const float* w_out, const float* dlq, int64_t lddlq,
                         int64_t n_nodes, int64_t n_classes, const void* ce_partial, float grad_scale, float* out3, void* dlqp3,
                         int64_t ldp, float* gbias, void* workspace, int64_t workspace_bytes, void* stream);
+/* Which kernel family gte_gemm_p3_nt / _rows / _rows2 (epilogue 0), gte_gemm_p3_nt_ln_bwd (1; 3 = a width that is not a multiple
+ * of 16) or gte_gemm_p3_nt[_rows2]_ln_fwd (4) would launch for [m x n] = [a1 | a2] b^T with k1 + k2 columns: 1 = the
+ * block-major-weights kernel (weight fragments straight into registers, A through 64-deep LDS slots; needs block-major weights, one
+ * column of 256-wide tiles, at least 32 K blocks, K padded by at most 1 / 12), 0 = the loader-wave / ring kernels.  *row_tile = the row
+ * tile of the launch where it is chosen by the one-round rule (32 / 64 / 96, else 128), 0 where the tile chooser picks.  Host logic
+ * only: with cus > 0 no device is touched (tests run it on the CPU); cus <= 0 reads the device's CU count. */
+int gte_gemm_p3_nt_plan(int64_t m, int64_t n, int64_t k1, int64_t k2, int weights_block_major, int epilogue, int cus, int* row_tile);
 /* The three setters below are TEST HOOKS with THREAD-LOCAL effect: they change what the calling host thread's later launches pick,
  * nothing any other thread sees (the library keeps no mutable process-wide state besides the GEMM mode above).  Environment
  * variables: the shipped library reads GTE_GEMM_MODE only; every other switch of earlier rounds lives in the measurement build

@@ -35,6 +35,34 @@ def test_library_exports_every_declared_symbol():
     assert lib.gte_weighted_ce_workspace_bytes(1000) >= 4 * 3 * 4
 
 
+def test_which_products_take_the_block_major_weights_kernel():
+    """gte_gemm_p3_nt_plan (host logic only, run here without a GPU): the dispatch rule of the NT planes GEMMs.  The headline step's
+    layer-0 forward ([x | cached ahn] W^T, K = 2 x 831, LayerNorm epilogue) and dX + LayerNorm backward (K = 2 x 256) take the
+    block-major-weights kernel on the smallest row tile that covers the batch in one round of 256 CUs; products with several
+    columns of tiles, short K loops, row-major weights and badly padded K do not."""
+    import ctypes
+    lib = _lib.load()
+
+    def plan(m, n, k1, k2, bm=1, epi=0):
+        rt = ctypes.c_int(-1)
+        r = lib.gte_gemm_p3_nt_plan(m, n, k1, k2, bm, epi, 256, ctypes.byref(rt))
+        return r, rt.value
+    assert plan(24400, 256, 831, 831, epi=4) == (1, 96)            # layer-0 forward of the headline, <= 24 576 rows
+    assert plan(25300, 256, 831, 831, epi=4) == (1, 128)           # ... above: 128-row tiles on 198 CUs
+    assert plan(24400, 256, 256, 256, epi=1) == (1, 96)            # dX + LayerNorm backward of layer 0
+    assert plan(12000, 256, 831, 831, epi=4) == (1, 64) and plan(6000, 256, 831, 831, epi=4) == (1, 32)
+    assert plan(24400, 256, 831, 831, bm=0, epi=4) == (0, 96)      # row-major weights: the loader-wave kernel
+    assert plan(24400, 512, 256, 0) == (0, 0)                      # layer-1 forward: two columns of tiles
+    assert plan(22500, 192, 831, 0) == (1, 96)                     # (831, 96): the narrow input GEMM, 2 x 96 columns
+    assert plan(22500, 96, 831, 0)[0] == 0                         # half-empty tile column: the tile chooser
+    assert plan(24400, 218, 218, 218, epi=3) == (0, 96)            # 2 x 14 K blocks: below 32 (the row tile rule is the epilogue launches')
+    assert plan(24400, 256, 144, 0, epi=1)[0] == 0                 # 9 K blocks
+    assert plan(24400, 160, 363, 363, epi=4) == (1, 96)            # 46 blocks in slots of four: padded to 48 (4 %)
+    assert plan(24400, 256, 272, 272, epi=1) == (1, 96)            # 34 blocks padded to 36: 5.9 % <= 1 / 12
+    assert plan(24400, 256, 528, 0, epi=1)[0] == 0                 # 33 blocks padded to 36: 9.1 % > 1 / 12
+    assert lib.gte_gemm_p3_nt_plan(10, 10, 0, 0, 1, 0, 256, None) == -1 and lib.gte_gemm_p3_nt_plan(10, 10, 16, 0, 1, 2, 256, None) == -1
+
+
 def test_bad_arguments_return_error_codes_not_crashes():
     lib = _lib.load()
     rc = lib.gte_spmm_csr(None, None, None, None, 4, None, 4, 10, 4, 0, 0, None)
