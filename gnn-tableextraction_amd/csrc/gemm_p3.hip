@@ -680,20 +680,23 @@ __device__ __forceinline__ void lw_epilogue(const f32x16 (&acc)[TM][TN], char* l
         // here, before the accumulators go to LDS -- 4 TM rows in flight per wave under the tile write and its two barriers, instead
         // of TM rounds of four rows with a memory latency each (one workgroup per CU: the memory-level parallelism of this phase is
         // all there is)
-        // (up to 96-row tiles: at 128 rows the 16 x 6 registers beside the 64 accumulators spill)
-        constexpr bool PRE = WM == 1 && SR / NW <= 12;
+        // (at 128 rows all 16 x 6 registers beside the 64 accumulators spill: a ring of 8 rows -- the first two rounds' rows are
+        // requested here, a round's entries are re-requested for the round after next as soon as it has consumed them)
+        constexpr bool PRE = WM == 1;
         constexpr int RPW = PRE ? SR / NW : 1;                          // rows of the tile per wave
-        float zpre[RPW][4], mpre[RPW], rpre[RPW];
+        constexpr int PD = RPW <= 12 ? RPW : 8;                         // rows requested ahead
+        float zpre[PD][4], mpre[PD], rpre[PD];
+        auto request_row = [&](int slot, int k) {                       // row k of this wave -> ring entry `slot`
+            const int rg = m0 + wave + k * NW;
+            const int rc = rg < M ? rg : min(m0, M - 1);
+            f4u zt; zt.x = zt.y = zt.z = zt.w = 0.f;
+            if (okc) zt = *reinterpret_cast<const f4u*>(p.ln_z + (long long)rc * p.ln_ldz + j4);
+            zpre[slot][0] = zt.x; zpre[slot][1] = zt.y; zpre[slot][2] = zt.z; zpre[slot][3] = zt.w;
+            mpre[slot] = p.ln_stats[rc]; rpre[slot] = p.ln_stats[M + rc];
+        };
         if constexpr (PRE) {
 #pragma unroll
-            for (int k = 0; k < RPW; ++k) {
-                const int rg = m0 + wave + k * NW;
-                const int rc = rg < M ? rg : min(m0, M - 1);
-                f4u zt; zt.x = zt.y = zt.z = zt.w = 0.f;
-                if (okc) zt = *reinterpret_cast<const f4u*>(p.ln_z + (long long)rc * p.ln_ldz + j4);
-                zpre[k][0] = zt.x; zpre[k][1] = zt.y; zpre[k][2] = zt.z; zpre[k][3] = zt.w;
-                mpre[k] = p.ln_stats[rc]; rpre[k] = p.ln_stats[M + rc];
-            }
+            for (int k = 0; k < PD; ++k) request_row(k, k);
         }
         for (int sl = 0; sl < WM; ++sl) {
             asm volatile("s_barrier" ::: "memory");                    // the previous slice's readers are done
@@ -731,9 +734,11 @@ __device__ __forceinline__ void lw_epilogue(const f32x16 (&acc)[TM][TN], char* l
                     gy[u][0] = a.x; gy[u][1] = a.y; gy[u][2] = a.z; gy[u][3] = a.w;
                     if constexpr (PRE) {
                         const int k = rd * RF + u;                      // (constant after unrolling: k < RPW because RF divides RPW)
+                        const int e_ = (k < RPW ? k : 0) % PD;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) zz[u][e] = zpre[k < RPW ? k : 0][e];
-                        mean[u] = mpre[k < RPW ? k : 0]; rstd[u] = rpre[k < RPW ? k : 0];
+                        for (int e = 0; e < 4; ++e) zz[u][e] = zpre[e_][e];
+                        mean[u] = mpre[e_]; rstd[u] = rpre[e_];
+                        if (k + PD < RPW) request_row(e_, k + PD);      // (the entry is free: its row for the round after next)
                     } else {
                         zz[u][0] = bz.x; zz[u][1] = bz.y; zz[u][2] = bz.z; zz[u][3] = bz.w;
                         mean[u] = p.ln_stats[rc]; rstd[u] = p.ln_stats[M + rc];
